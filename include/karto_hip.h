@@ -1,0 +1,219 @@
+/*
+ * karto_hip.h -- C ABI of libkartohip.so, the MI355X (gfx950) implementation of slam_toolbox's
+ * data-parallel hot path:
+ *   (A) karto correlative scan matcher   (reference: lib/karto_sdk/src/Mapper.cpp:477-1208,
+ *                                          lib/karto_sdk/include/karto_sdk/Mapper.h:1074-1544,
+ *                                          Karto.h:6603-6963)
+ *   (B) pose-graph SPA solver plugin     (reference: solvers/ceres_solver.cpp, solvers/ceres_utils.h,
+ *                                          karto::ScanSolver Mapper.h:954-1066)
+ *
+ * Everything is POD: plain pointers and sizes, caller-owned buffers, int status returns.  No C++
+ * or torch types cross this boundary.  A handle is NOT re-entrant (like karto::ScanMatcher,
+ * which keeps per-call state in members, Mapper.cpp:767-772); different handles may be used
+ * from different threads.  The thin C++ adaptors that restore the reference's class surface
+ * (karto::ScanMatcher / karto::ScanSolver look-alikes) live in include/karto_hip/ and are
+ * header-only over this ABI; INTEGRATION.md shows the binding a slam_toolbox maintainer adds.
+ *
+ * All paths compute on the GPU.  There is no CPU fallback: every entry point that needs the
+ * device returns KH_ERR_NO_DEVICE when no gfx950 device / HIP runtime is usable.
+ */
+#ifndef KARTO_HIP_H_
+#define KARTO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KH_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- status codes */
+enum {
+  KH_OK = 0,
+  KH_ERR_INVALID_ARG = 1,   /* ScanMatcher::Create returns NULL (Mapper.cpp:481-493) / smear out of range throws (Mapper.h:1226-1235) */
+  KH_ERR_NO_DEVICE = 2,     /* no HIP device: the product has no CPU fallback */
+  KH_ERR_HIP = 3,           /* a HIP runtime call failed (kh_last_error() has the text) */
+  KH_ERR_SEARCH = 4,        /* the reference throws std::runtime_error (Mapper.cpp:786-796, 828) */
+  KH_ERR_NOT_FOUND = 5,     /* unknown node / constraint id (reference logs and returns) */
+  KH_ERR_SOLVER = 6         /* solution not usable (ceres_solver.cpp:249-254): state left unchanged */
+};
+
+KH_API const char * kh_last_error(void);
+KH_API int kh_device_count(void);           /* 0 when no GPU is visible */
+KH_API const char * kh_version(void);
+
+/* ---------------------------------------------------------------- scans */
+/* What the matcher reads from a karto::LocalizedRangeScan (Karto.h:5380-5760):
+ *   ranges       GetRangeReadings()                      n doubles (NaN / inf allowed)
+ *   points_xy    GetPointReadings(false): the UNFILTERED world points of all n beams as left by
+ *                the scan's last Update() (Karto.h:5644-5704), x0,y0,x1,y1,...
+ *   sensor_pose  GetSensorPose()                         x, y, heading
+ * Buffers are host memory owned by the caller and only read during the call. */
+typedef struct kh_scan {
+  int32_t n;
+  const double * ranges;
+  const double * points_xy;
+  double sensor_pose[3];
+} kh_scan;
+
+/* helper restating LocalizedRangeScan::Update for callers without karto objects
+ * (Karto.h:5644-5704): pt_i = pose + r_i * (cos, sin)(heading + min_angle + i * ang_res) */
+KH_API int kh_scan_points(const double * ranges, int32_t n, const double sensor_pose[3],
+                          double min_angle, double angular_resolution, double * out_points_xy);
+
+/* ---------------------------------------------------------------- scan matcher (A) */
+typedef struct kh_matcher kh_matcher;
+
+/* The eight Mapper parameters ScanMatcher reads through friend access
+ * (Mapper.cpp:590-591, 600, 626-627, 674-682), AS STORED by karto::Mapper -- i.e. the two
+ * variance penalties are the already-squared values (setters square them, Mapper.cpp:2562-2570). */
+typedef struct kh_match_params {
+  double coarse_search_angle_offset;   /* m_pCoarseSearchAngleOffset */
+  double coarse_angle_resolution;      /* m_pCoarseAngleResolution   */
+  double fine_search_angle_offset;     /* m_pFineSearchAngleOffset   */
+  int32_t use_response_expansion;      /* m_pUseResponseExpansion    */
+  double distance_variance_penalty;    /* m_pDistanceVariancePenalty (squared) */
+  double minimum_distance_penalty;     /* m_pMinimumDistancePenalty  */
+  double angle_variance_penalty;       /* m_pAngleVariancePenalty (squared) */
+  double minimum_angle_penalty;        /* m_pMinimumAnglePenalty     */
+} kh_match_params;
+
+/* karto defaults of Mapper::InitializeParameters (Mapper.cpp:2250-2293) */
+KH_API void kh_match_params_default(kh_match_params * p);
+
+/* ScanMatcher::Create (Mapper.cpp:477-522).  device = HIP device ordinal; max_batch = number of
+ * independent matches one kh_matcher_match_batch call may carry (each owns a correlation grid in
+ * HBM: (side + 2*ceil(range/res) + 2*border)^2 bytes). */
+KH_API int kh_matcher_create(double search_size, double resolution, double smear_deviation,
+                             double range_threshold, int32_t device, int32_t max_batch,
+                             kh_matcher ** out);
+KH_API void kh_matcher_destroy(kh_matcher * m);
+KH_API int kh_matcher_set_params(kh_matcher * m, const kh_match_params * p);
+
+/* ScanMatcher::MatchScan<LocalizedRangeScanVector> (Mapper.cpp:534-639); base scans in container
+ * order.  mean = x, y, heading; cov = row-major 3x3; *response in [0, 1]. */
+KH_API int kh_matcher_match(kh_matcher * m, const kh_scan * query, const kh_scan * base,
+                            int32_t n_base, int32_t do_penalize, int32_t do_refine,
+                            double mean[3], double cov[9], double * response);
+
+/* n independent MatchScan calls in one pass (loop-closure candidate batches, BASELINE config 3).
+ * base scans of all matches are concatenated; base_begin[i]..base_begin[i+1] delimits match i
+ * (n+1 entries).  status[i] is the per-match status. */
+KH_API int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries,
+                                  const kh_scan * base, const int32_t * base_begin,
+                                  int32_t do_penalize, int32_t do_refine,
+                                  double * means /* 3n */, double * covs /* 9n */,
+                                  double * responses /* n */, int32_t * status /* n */);
+
+/* MatchScan steps 1-4 + AddScans only (Mapper.cpp:543-574): centre the grid of batch slot
+ * `slot` on the query's sensor pose and rasterise the base scans into it. */
+KH_API int kh_matcher_add_scans(kh_matcher * m, int32_t slot, const kh_scan * query,
+                                const kh_scan * base, int32_t n_base);
+
+/* ScanMatcher::CorrelateScan (Mapper.cpp:712-862) against the grid currently rasterised in
+ * `slot`.  cov is in/out: the fine pass (doing_fine_match) only rewrites cov[8]. */
+KH_API int kh_matcher_correlate(kh_matcher * m, int32_t slot, const kh_scan * query,
+                                const double center[3], const double search_offset[2],
+                                const double search_resolution[2], double angle_offset,
+                                double angle_resolution, int32_t do_penalize,
+                                int32_t doing_fine_match, double mean[3], double cov[9],
+                                double * response);
+
+/* The same CorrelateScan on n slots at once (one launch per kernel for the whole batch);
+ * arrays are per-slot (slot i uses queries[i], centers[3i..], ...). */
+KH_API int kh_matcher_correlate_batch(kh_matcher * m, int32_t n, const kh_scan * queries,
+                                      const double * centers, const double search_offset[2],
+                                      const double search_resolution[2], double angle_offset,
+                                      double angle_resolution, int32_t do_penalize,
+                                      int32_t doing_fine_match, double * means, double * covs,
+                                      double * responses, int32_t * status);
+
+/* ---- introspection used by the parity tests and the bench (not needed by the adaptor) ---- */
+typedef struct kh_grid_info {
+  int32_t width, height, width_step, data_size;      /* Grid<kt_int8u> incl. border (Karto.h:4636-4664) */
+  int32_t roi_x, roi_y, roi_w, roi_h;                /* CorrelationGrid ROI (Mapper.h:1204) */
+  int32_t kernel_size;                               /* Mapper.h:1240 */
+  int32_t search_side;                               /* side of the search-space-probs grid (Mapper.cpp:498) */
+  double offset_x, offset_y, scale;                  /* CoordinateConverter of `slot` */
+} kh_grid_info;
+KH_API int kh_matcher_grid_info(kh_matcher * m, int32_t slot, kh_grid_info * out);
+KH_API int kh_matcher_read_grid(kh_matcher * m, int32_t slot, uint8_t * out /* data_size */);
+KH_API int kh_matcher_read_kernel(kh_matcher * m, uint8_t * out /* kernel_size^2 */);
+/* last lookup table of `slot`: n_angles x n_points int32 (Karto.h:6797-6894); pass out=NULL to query sizes */
+KH_API int kh_matcher_read_lookup(kh_matcher * m, int32_t slot, int32_t * n_angles,
+                                  int32_t * n_points, int32_t * out);
+/* last response volume of `slot` in the reference's order ((y*nX + x)*nAngles + a), Mapper.cpp:688:
+ * raw integer sums (GetResponse numerator, Mapper.cpp:1200) and the penalised responses */
+KH_API int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, int32_t * ny,
+                                  int32_t * na, int32_t * out_sums, double * out_responses);
+/* keep the penalised response volume of every CorrelateScan on the device so that
+ * kh_matcher_read_volume can return it (parity tests); off by default */
+KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume);
+/* HIP stream all kernels of this handle are launched on (hipStream_t as void*), so the caller can
+ * bracket launches with HIP events on the right stream */
+KH_API void * kh_matcher_stream(kh_matcher * m);
+/* accumulated GPU time of the scoring kernel (K3) since the last reset, measured with HIP events
+ * on the handle's stream when profiling is enabled: total ms and launch count */
+KH_API int kh_matcher_profile(kh_matcher * m, int32_t enable, double * score_ms, int64_t * score_launches,
+                              double * raster_ms, int64_t * raster_launches);
+
+/* ---------------------------------------------------------------- SPA solver (B) */
+typedef struct kh_spa kh_spa;
+
+/* options hard-wired by CeresSolver::Configure (ceres_solver.cpp:157-186) + Ceres defaults */
+typedef struct kh_spa_options {
+  int32_t max_num_iterations;          /* Ceres default 50 */
+  double function_tolerance;           /* 1e-3 */
+  double gradient_tolerance;           /* 1e-6 */
+  double parameter_tolerance;          /* 1e-3 */
+  double min_relative_decrease;        /* 1e-3 */
+  double initial_trust_region_radius;  /* 1e4 */
+  double max_trust_region_radius;      /* 1e8 */
+  double min_trust_region_radius;      /* 1e-16 */
+  double min_lm_diagonal;              /* 1e-6 */
+  double max_lm_diagonal;              /* 1e32 */
+  int32_t max_num_consecutive_invalid_steps;   /* 3 */
+  int32_t use_nonmonotonic_steps;              /* true */
+  int32_t max_consecutive_nonmonotonic_steps;  /* 3 */
+  int32_t jacobi_scaling;                      /* true */
+} kh_spa_options;
+KH_API void kh_spa_options_default(kh_spa_options * o);
+
+typedef struct kh_spa_summary {
+  int32_t iterations;           /* LM iterations executed (successful + unsuccessful) */
+  int32_t successful_steps;
+  int32_t termination;          /* 0 convergence, 1 no convergence (max iters), 2 failure */
+  int32_t usable;               /* Summary::IsSolutionUsable() */
+  double initial_cost, final_cost;
+  double linearize_ms, solve_ms, total_ms;   /* GPU/host wall split of Compute() */
+  int64_t nnz_factor;           /* scalar non-zeros of the Cholesky factor */
+} kh_spa_summary;
+
+KH_API int kh_spa_create(int32_t device, kh_spa ** out);
+KH_API void kh_spa_destroy(kh_spa * s);
+KH_API int kh_spa_set_options(kh_spa * s, const kh_spa_options * o);
+KH_API int kh_spa_reset(kh_spa * s);                                   /* ScanSolver::Reset  (ceres_solver.cpp:279-314) */
+KH_API int kh_spa_clear(kh_spa * s);                                   /* ScanSolver::Clear  (ceres_solver.cpp:272-276) */
+KH_API int kh_spa_add_node(kh_spa * s, int32_t id, const double pose[3]);   /* AddNode (ceres_solver.cpp:317-336) */
+/* AddConstraint (ceres_solver.cpp:339-392): z = LinkInfo::GetPoseDifference, cov = LinkInfo::GetCovariance
+ * (row-major 3x3); the inverse (Karto.h:2533-2577), symmetrisation and upper Cholesky happen inside */
+KH_API int kh_spa_add_constraint(kh_spa * s, int32_t id_a, int32_t id_b, const double z[3],
+                                 const double cov[9]);
+KH_API int kh_spa_remove_node(kh_spa * s, int32_t id);                 /* ceres_solver.cpp:395-427 */
+KH_API int kh_spa_remove_constraint(kh_spa * s, int32_t id_a, int32_t id_b);  /* :430-448 */
+KH_API int kh_spa_modify_node(kh_spa * s, int32_t id, const double pose[3]);  /* :451-461 (adds old yaw) */
+KH_API int kh_spa_get_node(kh_spa * s, int32_t id, double pose[3]);    /* getGraph()/GetNodeOrientation */
+KH_API int32_t kh_spa_num_nodes(kh_spa * s);
+KH_API int32_t kh_spa_num_constraints(kh_spa * s);
+KH_API int kh_spa_compute(kh_spa * s, kh_spa_summary * summary);       /* Compute (ceres_solver.cpp:214-269) */
+/* GetCorrections (ceres_solver.cpp:272): pass ids=NULL to query the count */
+KH_API int kh_spa_get_corrections(kh_spa * s, int32_t * n, int32_t * ids, double * poses /* 3n */);
+/* LinkInfo::Update (Mapper.h:174-188) for callers without karto objects */
+KH_API int kh_link_info(const double pose1[3], const double pose2[3], const double cov[9],
+                        double pose_difference[3], double cov_out[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* KARTO_HIP_H_ */

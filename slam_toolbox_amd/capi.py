@@ -1,0 +1,142 @@
+"""ctypes binding of the C ABI in include/karto_hip.h (libkartohip.so).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is
+no Python / CPU fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkartohip.so")
+
+KH_OK, KH_ERR_INVALID_ARG, KH_ERR_NO_DEVICE, KH_ERR_HIP, KH_ERR_SEARCH, KH_ERR_NOT_FOUND, KH_ERR_SOLVER = range(7)
+
+dptr = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+iptr = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+bptr = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+class KhScan(C.Structure):
+    _fields_ = [("n", C.c_int32), ("ranges", C.POINTER(C.c_double)), ("points_xy", C.POINTER(C.c_double)),
+                ("sensor_pose", C.c_double * 3)]
+
+
+class KhMatchParams(C.Structure):
+    _fields_ = [("coarse_search_angle_offset", C.c_double), ("coarse_angle_resolution", C.c_double),
+                ("fine_search_angle_offset", C.c_double), ("use_response_expansion", C.c_int32),
+                ("distance_variance_penalty", C.c_double), ("minimum_distance_penalty", C.c_double),
+                ("angle_variance_penalty", C.c_double), ("minimum_angle_penalty", C.c_double)]
+
+
+class KhGridInfo(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("width", "height", "width_step", "data_size", "roi_x", "roi_y", "roi_w",
+                                          "roi_h", "kernel_size", "search_side")] + \
+               [(k, C.c_double) for k in ("offset_x", "offset_y", "scale")]
+
+
+class KhSpaOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int32), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("min_relative_decrease", C.c_double), ("initial_trust_region_radius", C.c_double),
+                ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("max_num_consecutive_invalid_steps", C.c_int32), ("use_nonmonotonic_steps", C.c_int32),
+                ("max_consecutive_nonmonotonic_steps", C.c_int32), ("jacobi_scaling", C.c_int32)]
+
+
+class KhSpaSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32),
+                ("usable", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("linearize_ms", C.c_double), ("solve_ms", C.c_double), ("total_ms", C.c_double),
+                ("nnz_factor", C.c_int64)]
+
+
+# every symbol include/karto_hip.h declares (tests check that the built library exports all of them)
+SYMBOLS = [
+    "kh_last_error", "kh_device_count", "kh_version", "kh_scan_points", "kh_match_params_default",
+    "kh_matcher_create", "kh_matcher_destroy", "kh_matcher_set_params", "kh_matcher_match",
+    "kh_matcher_match_batch", "kh_matcher_add_scans", "kh_matcher_correlate", "kh_matcher_correlate_batch",
+    "kh_matcher_grid_info", "kh_matcher_read_grid", "kh_matcher_read_kernel", "kh_matcher_read_lookup",
+    "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile",
+    "kh_spa_options_default", "kh_spa_create", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
+    "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
+    "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
+    "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info",
+]
+
+_lib = None
+
+
+class KartoHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = ""
+        try:
+            msg = lib().kh_last_error().decode()
+        except Exception:
+            pass
+        super().__init__(f"{where}: status {code} {msg}")
+
+
+def lib():
+    """Loads libkartohip.so; raises if it has not been built (run `python -m slam_toolbox_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m slam_toolbox_amd.build` "
+                          "(the HIP extension is the product; there is no fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, dbl = C.c_void_p, C.c_int32, C.c_double
+    L.kh_last_error.restype = C.c_char_p
+    L.kh_version.restype = C.c_char_p
+    L.kh_device_count.restype = C.c_int
+    L.kh_scan_points.argtypes = [dptr, i32, dptr, dbl, dbl, dptr]
+    L.kh_match_params_default.argtypes = [C.POINTER(KhMatchParams)]
+    L.kh_matcher_create.argtypes = [dbl, dbl, dbl, dbl, i32, i32, C.POINTER(vp)]
+    L.kh_matcher_destroy.argtypes = [vp]
+    L.kh_matcher_destroy.restype = None
+    L.kh_matcher_set_params.argtypes = [vp, C.POINTER(KhMatchParams)]
+    L.kh_matcher_match.argtypes = [vp, C.POINTER(KhScan), C.POINTER(KhScan), i32, i32, i32, dptr, dptr, C.POINTER(dbl)]
+    L.kh_matcher_match_batch.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), iptr, i32, i32, dptr, dptr, dptr, iptr]
+    L.kh_matcher_add_scans.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), i32]
+    L.kh_matcher_correlate.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, C.POINTER(dbl)]
+    L.kh_matcher_correlate_batch.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, dptr, iptr]
+    L.kh_matcher_grid_info.argtypes = [vp, i32, C.POINTER(KhGridInfo)]
+    L.kh_matcher_read_grid.argtypes = [vp, i32, bptr]
+    L.kh_matcher_read_kernel.argtypes = [vp, bptr]
+    L.kh_matcher_read_lookup.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), vp]
+    L.kh_matcher_read_volume.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), vp, vp]
+    L.kh_matcher_set_debug.argtypes = [vp, i32]
+    L.kh_matcher_stream.argtypes = [vp]
+    L.kh_matcher_stream.restype = vp
+    L.kh_matcher_profile.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(C.c_int64), C.POINTER(dbl), C.POINTER(C.c_int64)]
+    if hasattr(L, "kh_spa_create"):
+        L.kh_spa_options_default.argtypes = [C.POINTER(KhSpaOptions)]
+        L.kh_spa_create.argtypes = [i32, C.POINTER(vp)]
+        L.kh_spa_destroy.argtypes = [vp]
+        L.kh_spa_destroy.restype = None
+        L.kh_spa_set_options.argtypes = [vp, C.POINTER(KhSpaOptions)]
+        L.kh_spa_reset.argtypes = [vp]
+        L.kh_spa_clear.argtypes = [vp]
+        L.kh_spa_add_node.argtypes = [vp, i32, dptr]
+        L.kh_spa_add_constraint.argtypes = [vp, i32, i32, dptr, dptr]
+        L.kh_spa_remove_node.argtypes = [vp, i32]
+        L.kh_spa_remove_constraint.argtypes = [vp, i32, i32]
+        L.kh_spa_modify_node.argtypes = [vp, i32, dptr]
+        L.kh_spa_get_node.argtypes = [vp, i32, dptr]
+        L.kh_spa_num_nodes.argtypes = [vp]
+        L.kh_spa_num_constraints.argtypes = [vp]
+        L.kh_spa_compute.argtypes = [vp, C.POINTER(KhSpaSummary)]
+        L.kh_spa_get_corrections.argtypes = [vp, C.POINTER(i32), vp, vp]
+        L.kh_link_info.argtypes = [dptr, dptr, dptr, dptr, dptr]
+    _lib = L
+    return L
+
+
+def check(code, where):
+    if code != KH_OK:
+        raise KartoHipError(code, where)

@@ -1,0 +1,77 @@
+// Internal definitions shared by the host side (matcher_host.cpp) and the gfx950 kernels
+// (matcher_kernels.hip) of libkartohip.  Not part of the public ABI (include/karto_hip.h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace kh
+{
+
+constexpr int32_t kInvalidScan = INT32_MAX;   // Math.h:47 INVALID_SCAN
+constexpr int32_t kOccupied = 100;            // GridStates_Occupied
+constexpr int32_t kTieCap = 2048;             // tie indices returned per CorrelateScan before the host falls back
+constexpr int32_t kGridPad = 256;             // zeroed slack after the grid so tile over-reads stay in bounds
+constexpr int32_t kTileBytes = 64;            // bytes of one grid row a scoring tile covers (16 lanes x dword)
+
+// One rasterisation job (ScanMatcher::AddScans, Mapper.cpp:1032-1105) -- device visible.
+struct RasterJob
+{
+  uint8_t * grid;            // data_size + kGridPad bytes
+  const double * points;     // 2 * n_points world coordinates (FindValidPoints output, container order)
+  const uint8_t * active;    // n_points flags (0 = skipped by the "already occupied" filter, Mapper.cpp:1093-1096)
+  int32_t n_points;
+  int32_t ws, roi_x, roi_y, roi_w, roi_h;
+  int32_t kernel_size;
+  double off_x, off_y, scale;   // CoordinateConverter (Karto.h:4421-4436)
+};
+
+// One CorrelateScan job (Mapper.cpp:712-862) -- device visible.  All pointers are device pointers.
+struct CorrJob
+{
+  const uint8_t * grid;
+  int32_t data_size, ws;
+  int32_t n_points;          // P: beams of the query scan (table row length, response denominator)
+  int32_t nx, ny, na;
+  int32_t linear;            // lattice base index is base0 + xi*sx + yi*sy_ws for all (xi, yi)
+  int32_t sx;                // 1 or 2 when linear (cells per x step)
+  int32_t sy_ws;             // bytes per y step when linear
+  int32_t base0;             // ROI-shifted grid index of lattice point (0,0) (Mapper.h:1122-1128)
+  int32_t tiles_x, tiles_y;  // scoring tiles over the lattice
+  int32_t ry;                // rows per lane of the scoring kernel
+  int32_t do_penalize;
+  int32_t coarse;            // !doingFineMatch: maintain probs (max over angle per (x, y))
+  int32_t write_resp;        // also store the penalised response volume (parity tests)
+  double denom;              // P * 100 (Mapper.cpp:1204)
+  double grid_off_x, grid_off_y, scale;
+  // inputs staged by the host (exact libm / reference arithmetic)
+  const int32_t * bx;        // nx: gx + roi_x            (Mapper.cpp:660-662)
+  const int32_t * by;        // ny: (gy + roi_y) * ws
+  const double * dist_pen;   // ny*nx distance penalty     (Mapper.cpp:673-677)
+  const double * ang_pen;    // na angle penalty           (Mapper.cpp:679-682)
+  const double * cos_sin;    // 2*na: cos, sin of each search angle (Karto.h:6857-6858)
+  const double * local;      // 2*P scan points in the sensor frame (Karto.h:6813-6824)
+  const uint8_t * invalid;   // P: range reading is NaN/inf (Karto.h:6869-6875)
+  // device scratch / outputs
+  int32_t * table;           // na*P full lookup table (Karto.h:6844-6894)
+  int32_t * fast;            // na*P compacted offsets valid for every pose of the lattice
+  int32_t * slow;            // na*P compacted offsets needing the per-pose range check
+  int32_t * counts;          // na*2: {n_fast, n_slow}
+  int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
+  double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
+  unsigned long long * out;  // result block, see below
+};
+
+// Result block layout (unsigned long long words) per job, zeroed before every CorrelateScan:
+//   [0]              best response, IEEE bits (responses are >= 0 so the bit pattern orders like the value)
+//   [1]              number of poses within KT_TOLERANCE of the best (Mapper.cpp:808)
+//   [2 .. 2+cap/2)   tie indices, uint32, in the reference's order index (y*nX + x)*nA + a
+//   [2+cap/2 .. )    probs: nx*ny doubles as bits, max over angle (Mapper.cpp:781-799)
+constexpr size_t kOutHeaderWords = 2 + kTieCap / 2;
+
+void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, const uint8_t * d_kernel, void * stream);
+void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
+void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
+                  int32_t sx_variant, int32_t ry, void * stream);
+void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, void * stream);
+
+}  // namespace kh

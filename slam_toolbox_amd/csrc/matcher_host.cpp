@@ -1,0 +1,1183 @@
+// Host side of the karto correlative scan matcher on MI355X: everything the reference does with
+// libm or in inherently sequential order is done here, in the reference's exact IEEE operation
+// order (compiled -ffp-contract=off); everything data-parallel is launched on the GPU
+// (matcher_kernels.hip).  There is no CPU scoring path.
+//
+// Reference: lib/karto_sdk/src/Mapper.cpp:477-1208 (ScanMatcher), Mapper.h:1074-1314
+// (CorrelationGrid), Karto.h:4393-4563 (CoordinateConverter), :6603-6963 (GridIndexLookup),
+// :2946-3041 (Transform), Math.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/karto_hip.h"
+#include "kh_internal.hpp"
+
+namespace kh
+{
+
+thread_local std::string g_last_error;
+void set_error(const std::string & s) {g_last_error = s;}
+
+#define KH_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_error(std::string(#call) + ": " + hipGetErrorString(e_));                          \
+      return KH_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+// ---- exact scalar helpers (Math.h) ----------------------------------------------------------
+constexpr double kTolerance = 1e-06;                 // Math.h:41
+constexpr double kPi = 3.14159265358979323846;       // Math.h:31
+constexpr double k2Pi = 6.28318530717958647692;      // Math.h:32
+constexpr double kPi180 = 0.01745329251994329577;    // Math.h:34
+constexpr double kMaxVariance = 500.0;               // Mapper.cpp:52
+constexpr double kDistanceGain = 0.2;                // Mapper.cpp:53
+constexpr double kAngleGain = 0.2;                   // Mapper.cpp:54
+
+static inline double round_half_away(double v) {return v >= 0.0 ? std::floor(v + 0.5) : std::ceil(v - 0.5);}
+static inline int32_t to_int32(double v)
+{
+  if (!(v > -2147483649.0 && v < 2147483648.0)) {return INT32_MIN;}
+  return static_cast<int32_t>(v);
+}
+static inline bool double_equal(double a, double b)
+{
+  const double delta = a - b;
+  return delta < 0.0 ? delta >= -kTolerance : delta <= kTolerance;
+}
+static double normalize_angle(double angle)   // Math.h:181-202
+{
+  while (angle < -kPi) {
+    if (angle < -k2Pi) {angle += static_cast<uint32_t>(angle / -k2Pi) * k2Pi;} else {angle += k2Pi;}
+  }
+  while (angle > kPi) {
+    if (angle > k2Pi) {angle -= static_cast<uint32_t>(angle / k2Pi) * k2Pi;} else {angle -= k2Pi;}
+  }
+  return angle;
+}
+static double normalize_angle_difference(double minuend, double subtrahend)   // Math.h:213-224
+{
+  while (minuend - subtrahend < -kPi) {minuend += k2Pi;}
+  while (minuend - subtrahend > kPi) {minuend -= k2Pi;}
+  return minuend;
+}
+struct Cell {int32_t x, y;};
+static inline Cell world_to_grid(double scale, double ox, double oy, double wx, double wy)   // Karto.h:4421-4436
+{
+  const double gx = (wx - ox) * scale;
+  const double gy = (wy - oy) * scale;
+  return Cell{to_int32(round_half_away(gx)), to_int32(round_half_away(gy))};
+}
+static inline size_t align_up(size_t v, size_t a) {return (v + a - 1) / a * a;}
+
+// ---- per-correlate host context (what finalisation needs) -----------------------------------
+struct CorrHost
+{
+  int32_t slot = 0;
+  int32_t P = 0, nx = 0, ny = 0, na = 0;
+  double center[3] = {0, 0, 0};
+  double off_x = 0, off_y = 0, res_x = 0, res_y = 0, ang_off = 0, ang_res = 0;
+  bool fine = false, penalize = false;
+  std::vector<double> x_poses, y_poses, angles, dist_pen, ang_pen;
+  std::vector<int32_t> bx, by;
+  double denom = 1.0;
+};
+
+struct Slot
+{
+  uint8_t * d_grid = nullptr;
+  double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
+  // correlate scratch
+  int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
+  size_t cap_table = 0, cap_counts = 0;
+  int32_t * d_sums = nullptr; double * d_resp = nullptr; size_t cap_volume = 0, cap_resp = 0;
+  unsigned long long * d_out = nullptr; size_t cap_out = 0;   // words
+  // raster staging
+  double * d_rpoints = nullptr; uint8_t * d_ractive = nullptr; size_t cap_rpoints = 0, cap_ractive = 0;
+  // last correlate (for the introspection calls)
+  CorrHost last;
+  bool has_last = false;
+};
+
+}  // namespace kh
+
+using namespace kh;
+
+struct kh_matcher
+{
+  double search_size = 0, resolution = 0, smear = 0, range_threshold = 0;
+  int32_t width = 0, height = 0, ws = 0, data_size = 0;
+  int32_t roi_x = 0, roi_y = 0, roi_w = 0, roi_h = 0, kernel_size = 0, side = 0;
+  double scale = 0;
+  std::vector<uint8_t> kernel;
+  std::vector<Cell> footprint100;       // kernel cells equal to 100 (relative offsets)
+  kh_match_params params;
+  int32_t device = 0, max_batch = 1;
+  hipStream_t stream = nullptr;
+  uint8_t * d_kernel = nullptr;
+  std::vector<Slot> slots;
+  // staging (pinned host + device mirror) for correlate jobs
+  uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_stage = 0, cap_dstage = 0;
+  // pinned result mirror
+  unsigned long long * h_out = nullptr; size_t cap_hout = 0;   // words
+  // raster staging (pinned) + jobs
+  double * h_rpoints = nullptr; uint8_t * h_ractive = nullptr; size_t cap_hrpoints = 0, cap_hractive = 0;
+  RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
+  int32_t * h_sums = nullptr; size_t cap_hsums = 0;
+  bool keep_responses = false;
+  // profiling
+  bool profiling = false;
+  double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  double grid_resolution() const {return 1.0 / scale;}   // Karto.h:4518-4521
+};
+
+namespace kh
+{
+
+static int32_t half_kernel_size(double smear, double resolution)   // Mapper.h:1275-1280
+{
+  return static_cast<int32_t>(round_half_away(2.0 * smear / resolution));
+}
+
+// FindValidPoints, Mapper.cpp:1113-1164: appends the kept points of `scan` to `out`
+static void find_valid_points(const kh_scan & scan, const double viewpoint[2], std::vector<double> & out)
+{
+  const double min_square_distance = 0.1 * 0.1;
+  int32_t trailing = 0;
+  double first_x = 0.0, first_y = 0.0;
+  bool first_time = true;
+  const double * pts = scan.points_xy;
+  for (int32_t it = 0; it < scan.n; ++it) {
+    const double cx = pts[2 * it], cy = pts[2 * it + 1];
+    if (first_time && !std::isnan(cx) && !std::isnan(cy)) {
+      first_x = cx; first_y = cy; first_time = false;
+    }
+    const double dx = first_x - cx, dy = first_y - cy;
+    if (dx * dx + dy * dy > min_square_distance) {
+      const double a = viewpoint[1] - first_y;
+      const double b = first_x - viewpoint[0];
+      const double c = first_y * viewpoint[0] - first_x * viewpoint[1];
+      const double ss = cx * a + cy * b + c;
+      first_x = cx; first_y = cy;
+      if (ss < 0.0) {
+        trailing = it;
+      } else {
+        for (; trailing != it; ++trailing) {
+          out.push_back(pts[2 * trailing]);
+          out.push_back(pts[2 * trailing + 1]);
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+static int ensure_device(T *& p, size_t & cap, size_t need, hipStream_t stream)
+{
+  if (need <= cap) {return KH_OK;}
+  if (p) {
+    KH_HIP(hipStreamSynchronize(stream));
+    KH_HIP(hipFree(p));
+    p = nullptr;
+  }
+  size_t n = std::max(need, cap + cap / 2);
+  KH_HIP(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+  cap = n;
+  return KH_OK;
+}
+template <class T>
+static int ensure_pinned(T *& p, size_t & cap, size_t need, hipStream_t stream)
+{
+  if (need <= cap) {return KH_OK;}
+  if (p) {
+    KH_HIP(hipStreamSynchronize(stream));
+    KH_HIP(hipHostFree(p));
+    p = nullptr;
+  }
+  size_t n = std::max(need, cap + cap / 2);
+  KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocDefault));
+  cap = n;
+  return KH_OK;
+}
+
+// ---- rasterisation of n jobs (slots[i] <- base scans of job i) ------------------------------
+struct RasterReq {int32_t slot; const kh_scan * query; const kh_scan * base; int32_t n_base;};
+
+static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
+{
+  if (reqs.empty()) {return KH_OK;}
+  const double res = m->grid_resolution();
+  // 1. centre grids, FindValidPoints (host, sequential per scan), optional order-dependent filter
+  std::vector<std::vector<double>> pts(reqs.size());
+  std::vector<std::vector<uint8_t>> act(reqs.size());
+  size_t max_points = 0;
+  for (size_t r = 0; r < reqs.size(); ++r) {
+    Slot & s = m->slots[reqs[r].slot];
+    const double * pose = reqs[r].query->sensor_pose;
+    // MatchScan steps 1-4, Mapper.cpp:543-569
+    s.off_x = pose[0] - (0.5 * (m->roi_w - 1) * res);
+    s.off_y = pose[1] - (0.5 * (m->roi_h - 1) * res);
+    std::vector<double> & v = pts[r];
+    for (int32_t b = 0; b < reqs[r].n_base; ++b) {
+      if (reqs[r].base[b].points_xy == nullptr) {continue;}    // NULL scan: skipped (Mapper.cpp:1039-1041)
+      find_valid_points(reqs[r].base[b], pose, v);
+    }
+    const size_t np = v.size() / 2;
+    act[r].assign(np, 1);
+    if (m->footprint100.size() > 1) {
+      // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon
+      // as the smear kernel writes 100 off-centre: resolve the active set in reference order.
+      std::unordered_set<uint64_t> occupied;
+      occupied.reserve(np * m->footprint100.size() * 2);
+      for (size_t p = 0; p < np; ++p) {
+        const Cell c = world_to_grid(m->scale, s.off_x, s.off_y, v[2 * p], v[2 * p + 1]);
+        if (!(c.x >= 0 && c.x < m->roi_w) || !(c.y >= 0 && c.y < m->roi_h)) {act[r][p] = 0; continue;}
+        const uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(c.y)) << 32) | static_cast<uint32_t>(c.x);
+        if (occupied.count(key)) {act[r][p] = 0; continue;}
+        for (const Cell & f : m->footprint100) {
+          occupied.insert((static_cast<uint64_t>(static_cast<uint32_t>(c.y + f.y)) << 32) |
+            static_cast<uint32_t>(c.x + f.x));
+        }
+      }
+    }
+    max_points = std::max(max_points, np);
+  }
+  // 2. stage + upload
+  size_t total = 0;
+  for (auto & v : pts) {total += v.size() / 2;}
+  int rc = ensure_pinned(m->h_rpoints, m->cap_hrpoints, std::max<size_t>(total, 1) * 2, m->stream);
+  if (rc) {return rc;}
+  rc = ensure_pinned(m->h_ractive, m->cap_hractive, std::max<size_t>(total, 1), m->stream);
+  if (rc) {return rc;}
+  size_t cursor = 0;
+  for (size_t r = 0; r < reqs.size(); ++r) {
+    Slot & s = m->slots[reqs[r].slot];
+    const size_t np = pts[r].size() / 2;
+    rc = ensure_device(s.d_rpoints, s.cap_rpoints, std::max<size_t>(np, 1) * 2, m->stream);
+    if (rc) {return rc;}
+    rc = ensure_device(s.d_ractive, s.cap_ractive, std::max<size_t>(np, 1), m->stream);
+    if (rc) {return rc;}
+    if (np) {
+      std::memcpy(m->h_rpoints + 2 * cursor, pts[r].data(), sizeof(double) * 2 * np);
+      std::memcpy(m->h_ractive + cursor, act[r].data(), np);
+      KH_HIP(hipMemcpyAsync(s.d_rpoints, m->h_rpoints + 2 * cursor, sizeof(double) * 2 * np, hipMemcpyHostToDevice, m->stream));
+      KH_HIP(hipMemcpyAsync(s.d_ractive, m->h_ractive + cursor, np, hipMemcpyHostToDevice, m->stream));
+    }
+    RasterJob & j = m->h_rjobs[r];
+    j.grid = s.d_grid; j.points = s.d_rpoints; j.active = s.d_ractive; j.n_points = static_cast<int32_t>(np);
+    j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
+    j.kernel_size = m->kernel_size; j.off_x = s.off_x; j.off_y = s.off_y; j.scale = m->scale;
+    cursor += np;
+  }
+  KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * reqs.size(), hipMemcpyHostToDevice, m->stream));
+  if (m->profiling) {KH_HIP(hipEventRecord(m->ev[2], m->stream));}
+  // 3. Grid::Clear (Karto.h:4612-4615) + stamps
+  for (size_t r = 0; r < reqs.size(); ++r) {
+    KH_HIP(hipMemsetAsync(m->slots[reqs[r].slot].d_grid, 0, static_cast<size_t>(m->data_size), m->stream));
+  }
+  launch_raster(m->d_rjobs, static_cast<int32_t>(reqs.size()), static_cast<int32_t>(max_points), m->d_kernel, m->stream);
+  KH_HIP(hipGetLastError());
+  if (m->profiling) {
+    KH_HIP(hipEventRecord(m->ev[3], m->stream));
+    KH_HIP(hipEventSynchronize(m->ev[3]));
+    float ms = 0;
+    KH_HIP(hipEventElapsedTime(&ms, m->ev[2], m->ev[3]));
+    m->raster_ms += ms; m->raster_launches += 1;
+  }
+  return KH_OK;
+}
+
+// ---- CorrelateScan on a set of slots ---------------------------------------------------------
+struct CorrReq
+{
+  int32_t slot;
+  const kh_scan * scan;
+  double center[3];
+  double off_x, off_y, res_x, res_y, ang_off, ang_res;
+  bool penalize, fine;
+  // results
+  double mean[3]; double cov[9]; double response; int status;
+};
+
+struct StageLayout {size_t bx, by, dist_pen, ang_pen, cos_sin, local, invalid, total;};
+static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na)
+{
+  StageLayout L;
+  size_t o = align_up(sizeof(CorrJob), 256);
+  L.bx = o; o = align_up(o + sizeof(int32_t) * nx, 16);
+  L.by = o; o = align_up(o + sizeof(int32_t) * ny, 16);
+  L.dist_pen = o; o = align_up(o + sizeof(double) * nx * ny, 16);
+  L.ang_pen = o; o = align_up(o + sizeof(double) * na, 16);
+  L.cos_sin = o; o = align_up(o + sizeof(double) * 2 * na, 16);
+  L.local = o; o = align_up(o + sizeof(double) * 2 * P, 16);
+  L.invalid = o; o = align_up(o + P, 16);
+  L.total = align_up(o, 256);
+  return L;
+}
+
+static int pick_ry(int32_t ny)
+{
+  if (ny > 16) {return 8;}
+  if (ny > 4) {return 4;}
+  return 1;
+}
+
+// Host half of ComputePositionalCovariance (Mapper.cpp:874-966) on the lattice maxima
+static int positional_covariance(
+  const kh_matcher * m, const CorrHost & c, const std::vector<double> & lattice_max,
+  const double best_pose[3], double best_response, double * cov)
+{
+  std::fill(cov, cov + 9, 0.0);
+  cov[0] = 1.0; cov[4] = 1.0; cov[8] = 1.0;       // SetToIdentity
+  if (best_response < kTolerance) {
+    cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * (c.ang_res * c.ang_res);
+    return KH_OK;
+  }
+  // search-space-probs grid (Grid<kt_double>, side x side, Mapper.cpp:513-514, 726-732, 781-799)
+  const int32_t side = m->side;
+  const double pscale = 1.0 / m->resolution;            // Grid::CreateGrid -> SetScale(1.0 / resolution)
+  const double pox = c.center[0] - c.off_x, poy = c.center[1] - c.off_y;
+  std::vector<double> probs(static_cast<size_t>(side) * side, 0.0);
+  for (int32_t yi = 0; yi < c.ny; ++yi) {
+    for (int32_t xi = 0; xi < c.nx; ++xi) {
+      const double px = c.center[0] + c.x_poses[xi], py = c.center[1] + c.y_poses[yi];
+      const Cell g = world_to_grid(pscale, pox, poy, px, py);
+      if (!(g.x >= 0 && g.x < side) || !(g.y >= 0 && g.y < side)) {return KH_ERR_SEARCH;}   // Mapper.cpp:786-796
+      double & cell = probs[static_cast<size_t>(g.y) * side + g.x];
+      const double v = lattice_max[static_cast<size_t>(yi) * c.nx + xi];
+      cell = v > cell ? v : cell;
+    }
+  }
+  double aXX = 0, aXY = 0, aYY = 0, norm = 0;
+  const double dx = best_pose[0] - c.center[0], dy = best_pose[1] - c.center[1];
+  const uint32_t nX = static_cast<uint32_t>(round_half_away(c.off_x * 2.0 / c.res_x) + 1);
+  const double startX = -c.off_x;
+  const uint32_t nY = static_cast<uint32_t>(round_half_away(c.off_y * 2.0 / c.res_y) + 1);
+  const double startY = -c.off_y;
+  for (uint32_t yi = 0; yi < nY; ++yi) {
+    const double y = startY + yi * c.res_y;
+    for (uint32_t xi = 0; xi < nX; ++xi) {
+      const double x = startX + xi * c.res_x;
+      const Cell g = world_to_grid(pscale, pox, poy, c.center[0] + x, c.center[1] + y);
+      if (!(g.x >= 0 && g.x < side) || !(g.y >= 0 && g.y < side)) {return KH_ERR_SEARCH;}
+      const double response = probs[static_cast<size_t>(g.y) * side + g.x];
+      if (response >= (best_response - 0.1)) {
+        norm += response;
+        aXX += ((x - dx) * (x - dx) * response);
+        aXY += ((x - dx) * (y - dy) * response);
+        aYY += ((y - dy) * (y - dy) * response);
+      }
+    }
+  }
+  if (norm > kTolerance) {
+    double vXX = aXX / norm, vXY = aXY / norm, vYY = aYY / norm;
+    const double vTHTH = 4 * (c.ang_res * c.ang_res);
+    const double minXX = 0.1 * (c.res_x * c.res_x), minYY = 0.1 * (c.res_y * c.res_y);
+    vXX = vXX > minXX ? vXX : minXX;
+    vYY = vYY > minYY ? vYY : minYY;
+    const double mult = 1.0 / best_response;
+    cov[0] = vXX * mult; cov[1] = vXY * mult; cov[3] = vXY * mult; cov[4] = vYY * mult; cov[8] = vTHTH;
+  }
+  if (double_equal(cov[0], 0.0)) {cov[0] = kMaxVariance;}
+  if (double_equal(cov[4], 0.0)) {cov[4] = kMaxVariance;}
+  return KH_OK;
+}
+
+static inline double host_response(const CorrHost & c, int32_t sum, int a, int yi, int xi)
+{
+  double response = static_cast<double>(sum) / c.denom;
+  if (c.penalize && !double_equal(response, 0.0)) {
+    response *= (c.dist_pen[static_cast<size_t>(yi) * c.nx + xi] * c.ang_pen[a]);
+  }
+  return response;
+}
+
+static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
+{
+  const size_t n = reqs.size();
+  if (n == 0) {return KH_OK;}
+  const kh_match_params & mp = m->params;
+  std::vector<CorrHost> ctx(n);
+  std::vector<StageLayout> lay(n);
+  size_t stride = 0, out_words = 0;
+  int32_t max_na = 0, max_tiles = 0, max_poses = 0;
+  int32_t sx_variant = -1, ry = -1;
+  bool uniform_kernel = true;
+
+  // ---- 1. host preparation (exact reference arithmetic) ----
+  for (size_t i = 0; i < n; ++i) {
+    CorrReq & q = reqs[i];
+    CorrHost & c = ctx[i];
+    q.status = KH_OK;
+    c.slot = q.slot;
+    c.P = q.scan->n;
+    std::copy(q.center, q.center + 3, c.center);
+    c.off_x = q.off_x; c.off_y = q.off_y; c.res_x = q.res_x; c.res_y = q.res_y;
+    c.ang_off = q.ang_off; c.ang_res = q.ang_res; c.fine = q.fine; c.penalize = q.penalize;
+    // Mapper.cpp:736-756
+    c.nx = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.off_x * 2.0 / q.res_x) + 1));
+    c.ny = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.off_y * 2.0 / q.res_y) + 1));
+    c.na = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.ang_off * 2.0 / q.ang_res) + 1));
+    if (c.nx <= 0 || c.ny <= 0 || c.na <= 0 || static_cast<int64_t>(c.nx) * c.ny * c.na > (1ll << 28)) {
+      set_error("search volume out of range");
+      return KH_ERR_INVALID_ARG;
+    }
+    const double startX = -q.off_x, startY = -q.off_y;
+    c.x_poses.resize(c.nx); c.y_poses.resize(c.ny);
+    for (int32_t k = 0; k < c.nx; ++k) {c.x_poses[k] = startX + static_cast<uint32_t>(k) * q.res_x;}
+    for (int32_t k = 0; k < c.ny; ++k) {c.y_poses[k] = startY + static_cast<uint32_t>(k) * q.res_y;}
+    c.denom = static_cast<double>(static_cast<uint32_t>(c.P) * 100u);     // Mapper.cpp:1204
+    lay[i] = stage_layout(c.P, c.nx, c.ny, c.na);
+    stride = std::max(stride, lay[i].total);
+    out_words = std::max(out_words, kOutHeaderWords + static_cast<size_t>(c.nx) * c.ny);
+    max_na = std::max(max_na, c.na);
+    max_poses = std::max(max_poses, c.nx * c.ny * c.na);
+  }
+  out_words = align_up(out_words, 32);
+  int rc = ensure_pinned(m->h_stage, m->cap_stage, stride * n, m->stream);
+  if (rc) {return rc;}
+  rc = ensure_device(m->d_stage, m->cap_dstage, m->cap_stage, m->stream);
+  if (rc) {return rc;}
+  rc = ensure_pinned(m->h_out, m->cap_hout, out_words * n, m->stream);
+  if (rc) {return rc;}
+
+  for (size_t i = 0; i < n; ++i) {
+    CorrReq & q = reqs[i];
+    CorrHost & c = ctx[i];
+    Slot & s = m->slots[c.slot];
+    const StageLayout & L = lay[i];
+    uint8_t * hb = m->h_stage + stride * i;
+    uint8_t * db = m->d_stage + stride * i;
+    CorrJob * job = reinterpret_cast<CorrJob *>(hb);
+    int32_t * bx = reinterpret_cast<int32_t *>(hb + L.bx);
+    int32_t * by = reinterpret_cast<int32_t *>(hb + L.by);
+    double * dist_pen = reinterpret_cast<double *>(hb + L.dist_pen);
+    double * ang_pen = reinterpret_cast<double *>(hb + L.ang_pen);
+    double * cos_sin = reinterpret_cast<double *>(hb + L.cos_sin);
+    double * local = reinterpret_cast<double *>(hb + L.local);
+    uint8_t * invalid = hb + L.invalid;
+
+    // lattice base indices: operator()(y), Mapper.cpp:649-662
+    c.bx.resize(c.nx); c.by.resize(c.ny);
+    for (int32_t k = 0; k < c.nx; ++k) {
+      const double newPositionX = c.center[0] + c.x_poses[k];
+      const double gx = (newPositionX - s.off_x) * m->scale;
+      c.bx[k] = to_int32(round_half_away(gx)) + m->roi_x;
+      bx[k] = c.bx[k];
+    }
+    for (int32_t k = 0; k < c.ny; ++k) {
+      const double newPositionY = c.center[1] + c.y_poses[k];
+      const double gy = (newPositionY - s.off_y) * m->scale;
+      c.by[k] = (to_int32(round_half_away(gy)) + m->roi_y) * m->ws;
+      by[k] = c.by[k];
+    }
+    int32_t sx = c.nx > 1 ? c.bx[1] - c.bx[0] : 1;
+    int32_t sy_ws = c.ny > 1 ? c.by[1] - c.by[0] : m->ws;
+    bool linear = (sx == 1 || sx == 2) && sy_ws > 0;
+    for (int32_t k = 1; k < c.nx && linear; ++k) {linear = (c.bx[k] - c.bx[k - 1]) == sx;}
+    for (int32_t k = 1; k < c.ny && linear; ++k) {linear = (c.by[k] - c.by[k - 1]) == sy_ws;}
+    // every window row read by a tile must stay inside the (padded) allocation
+    if (linear) {
+      const int64_t bmax = static_cast<int64_t>(c.bx[0]) + c.by[0] + static_cast<int64_t>(c.ny - 1) * sy_ws;
+      if (c.bx[0] + c.by[0] < 0 || bmax >= m->data_size) {linear = false;}
+    }
+    if (!linear) {sx = 1; sy_ws = m->ws;}
+
+    // penalties, Mapper.cpp:671-685
+    c.dist_pen.assign(static_cast<size_t>(c.nx) * c.ny, 1.0);
+    c.ang_pen.assign(c.na, 1.0);
+    c.angles.resize(c.na);
+    const double startAngle = c.center[2] - c.ang_off;
+    for (int32_t a = 0; a < c.na; ++a) {
+      const double angle = startAngle + static_cast<uint32_t>(a) * c.ang_res;
+      c.angles[a] = angle;
+      cos_sin[2 * a] = std::cos(angle);          // Karto.h:6857-6858
+      cos_sin[2 * a + 1] = std::sin(angle);
+      const double squaredAngleDistance = (angle - c.center[2]) * (angle - c.center[2]);
+      double anglePenalty = 1.0 - (kAngleGain * squaredAngleDistance / mp.angle_variance_penalty);
+      anglePenalty = anglePenalty > mp.minimum_angle_penalty ? anglePenalty : mp.minimum_angle_penalty;
+      c.ang_pen[a] = anglePenalty;
+      ang_pen[a] = anglePenalty;
+    }
+    for (int32_t yi = 0; yi < c.ny; ++yi) {
+      const double squareY = c.y_poses[yi] * c.y_poses[yi];
+      for (int32_t xi = 0; xi < c.nx; ++xi) {
+        const double squareX = c.x_poses[xi] * c.x_poses[xi];
+        const double squaredDistance = squareX + squareY;
+        double distancePenalty = 1.0 - (kDistanceGain * squaredDistance / mp.distance_variance_penalty);
+        distancePenalty = distancePenalty > mp.minimum_distance_penalty ? distancePenalty : mp.minimum_distance_penalty;
+        c.dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
+        dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
+      }
+    }
+
+    // scan points in the sensor frame: Transform(sensorPose).InverseTransformPose, Karto.h:6813-6824,
+    // 2987-2994, 3003-3024, 2482-2511, 2654-2666
+    {
+      const double tx = q.scan->sensor_pose[0], ty = q.scan->sensor_pose[1], th = q.scan->sensor_pose[2];
+      double r00, r01, r02, r10, r11, r12;
+      if (tx == 0.0 && ty == 0.0 && th == 0.0) {
+        r00 = 1; r01 = 0; r02 = 0; r10 = 0; r11 = 1; r12 = 0;
+      } else {
+        const double radians = 0.0 - th;
+        const double cosR = std::cos(radians), sinR = std::sin(radians), omc = 1.0 - cosR;
+        r00 = 0.0 * omc + cosR;
+        r01 = 0.0 * 0.0 * omc - 1.0 * sinR;
+        r02 = 0.0 * 1.0 * omc + 0.0 * sinR;
+        r10 = 0.0 * 0.0 * omc + 1.0 * sinR;
+        r11 = 0.0 * omc + cosR;
+        r12 = 0.0 * 1.0 * omc - 0.0 * sinR;
+      }
+      for (int32_t k = 0; k < c.P; ++k) {
+        const double sxp = q.scan->points_xy[2 * k] - tx, syp = q.scan->points_xy[2 * k + 1] - ty, sh = 0.0 - th;
+        local[2 * k] = r00 * sxp + r01 * syp + r02 * sh;
+        local[2 * k + 1] = r10 * sxp + r11 * syp + r12 * sh;
+        const double rr = q.scan->ranges[k];
+        invalid[k] = (std::isnan(rr) || std::isinf(rr)) ? 1 : 0;     // Karto.h:6869-6875
+      }
+    }
+
+    // device scratch for this slot
+    const size_t tp = static_cast<size_t>(c.na) * c.P;
+    if (tp > s.cap_table) {
+      if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_fast)); KH_HIP(hipFree(s.d_slow));}
+      const size_t cap = std::max(tp, s.cap_table + s.cap_table / 2);
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_table), cap * 4));
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_fast), cap * 4));
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_slow), cap * 4));
+      s.cap_table = cap;
+    }
+    rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * 2, m->stream); if (rc) {return rc;}
+    const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
+    rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
+    if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
+    rc = ensure_device(s.d_out, s.cap_out, out_words, m->stream); if (rc) {return rc;}
+
+    std::memset(job, 0, sizeof(CorrJob));
+    job->grid = s.d_grid; job->data_size = m->data_size; job->ws = m->ws;
+    job->n_points = c.P; job->nx = c.nx; job->ny = c.ny; job->na = c.na;
+    job->linear = linear ? 1 : 0; job->sx = sx; job->sy_ws = sy_ws; job->base0 = c.bx[0] + c.by[0];
+    const int this_sx = (linear && sx == 2) ? 2 : 1;
+    const int this_ry = pick_ry(c.ny);
+    if (sx_variant < 0) {sx_variant = this_sx; ry = this_ry;}
+    if (sx_variant != this_sx || ry != this_ry) {uniform_kernel = false;}
+    const int px = kTileBytes / this_sx;
+    job->tiles_x = (c.nx + px - 1) / px;
+    job->tiles_y = (c.ny + 4 * this_ry - 1) / (4 * this_ry);
+    job->ry = this_ry;
+    max_tiles = std::max(max_tiles, job->tiles_x * job->tiles_y);
+    job->do_penalize = q.penalize ? 1 : 0; job->coarse = q.fine ? 0 : 1;
+    job->write_resp = m->keep_responses ? 1 : 0;
+    job->denom = c.denom;
+    job->grid_off_x = s.off_x; job->grid_off_y = s.off_y; job->scale = m->scale;
+    job->bx = reinterpret_cast<const int32_t *>(db + L.bx);
+    job->by = reinterpret_cast<const int32_t *>(db + L.by);
+    job->dist_pen = reinterpret_cast<const double *>(db + L.dist_pen);
+    job->ang_pen = reinterpret_cast<const double *>(db + L.ang_pen);
+    job->cos_sin = reinterpret_cast<const double *>(db + L.cos_sin);
+    job->local = reinterpret_cast<const double *>(db + L.local);
+    job->invalid = db + L.invalid;
+    job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
+    job->sums = s.d_sums; job->resp = s.d_resp; job->out = s.d_out;
+  }
+
+  // ---- 2. upload, launch, download ----
+  KH_HIP(hipMemcpyAsync(m->d_stage, m->h_stage, stride * n, hipMemcpyHostToDevice, m->stream));
+  for (size_t i = 0; i < n; ++i) {
+    KH_HIP(hipMemsetAsync(m->slots[ctx[i].slot].d_out, 0, out_words * 8, m->stream));
+  }
+  launch_offsets(m->d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
+  if (m->profiling) {KH_HIP(hipEventRecord(m->ev[0], m->stream));}
+  if (uniform_kernel) {
+    launch_score(m->d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, m->stream);
+  } else {
+    for (size_t i = 0; i < n; ++i) {
+      const CorrJob * job = reinterpret_cast<const CorrJob *>(m->h_stage + stride * i);
+      launch_score(m->d_stage + stride * i, stride, 1, job->tiles_x * job->tiles_y, job->na,
+        (job->linear && job->sx == 2) ? 2 : 1, job->ry, m->stream);
+    }
+  }
+  if (m->profiling) {KH_HIP(hipEventRecord(m->ev[1], m->stream));}
+  launch_ties(m->d_stage, stride, static_cast<int32_t>(n), max_poses, m->stream);
+  KH_HIP(hipGetLastError());
+  for (size_t i = 0; i < n; ++i) {
+    const CorrHost & c = ctx[i];
+    const size_t words = kOutHeaderWords + (c.fine ? 0 : static_cast<size_t>(c.nx) * c.ny);
+    KH_HIP(hipMemcpyAsync(m->h_out + out_words * i, m->slots[c.slot].d_out, words * 8, hipMemcpyDeviceToHost, m->stream));
+  }
+  KH_HIP(hipStreamSynchronize(m->stream));
+  if (m->profiling) {
+    float ms = 0;
+    KH_HIP(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
+    m->score_ms += ms; m->score_launches += 1;
+  }
+
+  // ---- 3. finalisation (Mapper.cpp:775-862) ----
+  for (size_t i = 0; i < n; ++i) {
+    CorrReq & q = reqs[i];
+    CorrHost & c = ctx[i];
+    Slot & s = m->slots[c.slot];
+    const unsigned long long * out = m->h_out + out_words * i;
+    double best;
+    std::memcpy(&best, &out[0], 8);
+    const uint64_t tie_count = out[1];
+    const size_t plane = static_cast<size_t>(c.nx) * c.ny;
+    std::vector<uint32_t> ties;
+    std::vector<int32_t> host_sums;     // full volume, only when needed
+    auto fetch_volume = [&]() -> int {
+      if (!host_sums.empty()) {return KH_OK;}
+      host_sums.resize(plane * c.na);
+      KH_HIP(hipMemcpy(host_sums.data(), s.d_sums, host_sums.size() * 4, hipMemcpyDeviceToHost));
+      return KH_OK;
+    };
+    if (tie_count <= static_cast<uint64_t>(kTieCap)) {
+      const uint32_t * idx = reinterpret_cast<const uint32_t *>(out + 2);
+      ties.assign(idx, idx + tie_count);
+      std::sort(ties.begin(), ties.end());
+    } else {
+      // degenerate search (e.g. nothing rasterised: every pose ties at 0): walk the whole volume
+      // on the host in the reference's order
+      rc = fetch_volume(); if (rc) {return rc;}
+      for (int32_t yi = 0; yi < c.ny; ++yi) {
+        for (int32_t xi = 0; xi < c.nx; ++xi) {
+          for (int32_t a = 0; a < c.na; ++a) {
+            const double r = host_response(c, host_sums[static_cast<size_t>(a) * plane + static_cast<size_t>(yi) * c.nx + xi], a, yi, xi);
+            if (double_equal(r, best)) {ties.push_back(static_cast<uint32_t>((static_cast<size_t>(yi) * c.nx + xi) * c.na + a));}
+          }
+        }
+      }
+    }
+    if (ties.empty()) {q.status = KH_ERR_SEARCH; continue;}     // Mapper.cpp:828
+    // average all poses with the same highest response, Mapper.cpp:802-829
+    double ax = 0.0, ay = 0.0, thetaX = 0.0, thetaY = 0.0;
+    for (uint32_t t : ties) {
+      const int32_t a = static_cast<int32_t>(t % static_cast<uint32_t>(c.na));
+      const uint32_t xy = t / static_cast<uint32_t>(c.na);
+      const int32_t xi = static_cast<int32_t>(xy % static_cast<uint32_t>(c.nx)), yi = static_cast<int32_t>(xy / static_cast<uint32_t>(c.nx));
+      ax += c.center[0] + c.x_poses[xi];
+      ay += c.center[1] + c.y_poses[yi];
+      const double heading = normalize_angle(c.angles[a]);
+      thetaX += std::cos(heading);
+      thetaY += std::sin(heading);
+    }
+    const int32_t count = static_cast<int32_t>(ties.size());
+    ax /= count; ay /= count; thetaX /= count; thetaY /= count;
+    const double avg[3] = {ax, ay, std::atan2(thetaY, thetaX)};
+
+    if (!c.fine) {
+      std::vector<double> lattice(plane);
+      std::memcpy(lattice.data(), out + kOutHeaderWords, plane * 8);
+      const int prc = positional_covariance(m, c, lattice, avg, best, q.cov);
+      if (prc != KH_OK) {q.status = prc; continue;}
+    } else {
+      // ComputeAngularCovariance, Mapper.cpp:977-1025
+      const double bestAngle = normalize_angle_difference(avg[2], c.center[2]);
+      const Cell g = world_to_grid(m->scale, s.off_x, s.off_y, avg[0], avg[1]);
+      const int32_t gridIndex = (g.x + m->roi_x) + (g.y + m->roi_y) * m->ws;
+      // the raw responses of all angles at that cell: it is a lattice point unless the tie average
+      // left the lattice, in which case the sums are recomputed by a 1x1 search at that cell
+      int32_t fx = -1, fy = -1;
+      for (int32_t yi = 0; yi < c.ny && fx < 0; ++yi) {
+        for (int32_t xi = 0; xi < c.nx; ++xi) {
+          if (c.bx[xi] + c.by[yi] == gridIndex) {fx = xi; fy = yi; break;}
+        }
+      }
+      std::vector<int32_t> col(c.na, 0);
+      if (fx >= 0) {
+        KH_HIP(hipMemcpy2D(col.data(), 4, s.d_sums + static_cast<size_t>(fy) * c.nx + fx, plane * 4, 4, c.na, hipMemcpyDeviceToHost));
+      } else {
+        // off-lattice best pose: score the single cell through the generic (per-pose checked) path
+        CorrJob * job = reinterpret_cast<CorrJob *>(m->h_stage + stride * i);
+        CorrJob one = *job;
+        one.nx = 1; one.ny = 1; one.linear = 0; one.sx = 1; one.sy_ws = m->ws; one.base0 = gridIndex;
+        one.tiles_x = 1; one.tiles_y = 1; one.ry = 1; one.do_penalize = 0; one.coarse = 0; one.write_resp = 0;
+        // bx/by of the single pose: reuse the first entries of the staged arrays
+        int32_t one_bx = gridIndex, one_by = 0;
+        KH_HIP(hipMemcpy(const_cast<int32_t *>(job->bx), &one_bx, 4, hipMemcpyHostToDevice));
+        KH_HIP(hipMemcpy(const_cast<int32_t *>(job->by), &one_by, 4, hipMemcpyHostToDevice));
+        KH_HIP(hipMemcpy(m->d_stage + stride * i, &one, sizeof(CorrJob), hipMemcpyHostToDevice));
+        launch_offsets(m->d_stage + stride * i, stride, 1, one.na, m->stream);
+        launch_score(m->d_stage + stride * i, stride, 1, 1, one.na, 1, 1, m->stream);
+        KH_HIP(hipStreamSynchronize(m->stream));
+        KH_HIP(hipMemcpy(col.data(), s.d_sums, sizeof(int32_t) * c.na, hipMemcpyDeviceToHost));
+        // NOTE: the slot's stored volume now holds this 1x1 search (introspection only)
+      }
+      const double startAngle = c.center[2] - c.ang_off;
+      double norm = 0.0, acc = 0.0;
+      for (int32_t a = 0; a < c.na; ++a) {
+        const double angle = startAngle + static_cast<uint32_t>(a) * c.ang_res;
+        const double response = static_cast<double>(col[a]) / c.denom;     // GetResponse: no penalty
+        if (response >= (best - 0.1)) {
+          norm += response;
+          acc += ((angle - bestAngle) * (angle - bestAngle) * response);
+        }
+      }
+      if (norm > kTolerance) {
+        if (acc < kTolerance) {acc = c.ang_res * c.ang_res;}
+        acc /= norm;
+      } else {
+        acc = 1000 * (c.ang_res * c.ang_res);
+      }
+      q.cov[8] = acc;
+    }
+    q.mean[0] = avg[0]; q.mean[1] = avg[1]; q.mean[2] = avg[2];
+    q.response = best > 1.0 ? 1.0 : best;
+    s.last = c; s.has_last = true;
+  }
+  return KH_OK;
+}
+
+}  // namespace kh
+
+// =============================================================================================
+//                                         C ABI
+// =============================================================================================
+extern "C" {
+
+const char * kh_last_error(void) {return kh::g_last_error.c_str();}
+
+int kh_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {return 0;}
+  return n;
+}
+
+const char * kh_version(void) {return "karto-hip 0.1 (gfx950)";}
+
+int kh_scan_points(const double * ranges, int32_t n, const double sensor_pose[3], double min_angle,
+  double angular_resolution, double * out)
+{
+  if (!ranges || !out || n < 0) {return KH_ERR_INVALID_ARG;}
+  for (int32_t i = 0; i < n; ++i) {          // Karto.h:5663-5682
+    const double angle = sensor_pose[2] + min_angle + static_cast<uint32_t>(i) * angular_resolution;
+    out[2 * i] = sensor_pose[0] + (ranges[i] * std::cos(angle));
+    out[2 * i + 1] = sensor_pose[1] + (ranges[i] * std::sin(angle));
+  }
+  return KH_OK;
+}
+
+void kh_match_params_default(kh_match_params * p)
+{
+  // Mapper.cpp:2250-2293
+  p->coarse_search_angle_offset = 20 * kPi180;
+  p->coarse_angle_resolution = 2 * kPi180;
+  p->fine_search_angle_offset = 0.2 * kPi180;
+  p->use_response_expansion = 0;
+  p->distance_variance_penalty = 0.3 * 0.3;
+  p->minimum_distance_penalty = 0.5;
+  p->angle_variance_penalty = (20 * kPi180) * (20 * kPi180);
+  p->minimum_angle_penalty = 0.9;
+}
+
+int kh_matcher_create(double search_size, double resolution, double smear, double range_threshold,
+  int32_t device, int32_t max_batch, kh_matcher ** out)
+{
+  if (!out) {return KH_ERR_INVALID_ARG;}
+  *out = nullptr;
+  // Mapper.cpp:481-493
+  if (resolution <= 0 || search_size <= 0 || smear < 0 || range_threshold <= 0 || max_batch < 1) {
+    set_error("ScanMatcher::Create: invalid parameters");
+    return KH_ERR_INVALID_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    set_error("no usable HIP device (libkartohip has no CPU fallback)");
+    return KH_ERR_NO_DEVICE;
+  }
+  kh_matcher * m = new kh_matcher();
+  m->search_size = search_size; m->resolution = resolution; m->smear = smear; m->range_threshold = range_threshold;
+  m->device = device; m->max_batch = max_batch;
+  kh_match_params_default(&m->params);
+  // Mapper.cpp:498-505
+  const uint32_t side = static_cast<uint32_t>(round_half_away(search_size / resolution) + 1);
+  const uint32_t margin = static_cast<uint32_t>(std::ceil(range_threshold / resolution));
+  const int32_t grid_size = static_cast<int32_t>(side + 2 * margin);
+  // CorrelationGrid::CreateGrid / ctor, Mapper.h:1099-1114, 1194-1208; Grid::Resize Karto.h:4636-4664
+  const uint32_t border = static_cast<uint32_t>(half_kernel_size(smear, resolution)) + 1;
+  m->width = grid_size + 2 * static_cast<int32_t>(border);
+  m->height = m->width;
+  m->ws = static_cast<int32_t>((static_cast<size_t>(m->width) + 7) & ~static_cast<size_t>(7));
+  const int64_t ds = static_cast<int64_t>(m->ws) * m->height;
+  if (ds <= 0 || ds > (1ll << 31) - 4096) {delete m; set_error("grid too large"); return KH_ERR_INVALID_ARG;}
+  m->data_size = static_cast<int32_t>(ds);
+  m->scale = 1.0 / resolution;
+  m->roi_x = m->roi_y = static_cast<int32_t>(border);
+  m->roi_w = m->roi_h = grid_size;
+  m->side = static_cast<int32_t>(side);
+  // CalculateKernel, Mapper.h:1213-1266
+  const double res = m->grid_resolution();
+  const double min_dev = 0.5 * res, max_dev = 10 * res;
+  if (!(smear >= min_dev && smear <= max_dev)) {
+    delete m;
+    set_error("Mapper Error:  Smear deviation too small / too large");
+    return KH_ERR_INVALID_ARG;
+  }
+  m->kernel_size = 2 * half_kernel_size(smear, res) + 1;
+  const int32_t k = m->kernel_size, hk = k / 2;
+  m->kernel.resize(static_cast<size_t>(k) * k);
+  for (int32_t i = -hk; i <= hk; ++i) {
+    for (int32_t j = -hk; j <= hk; ++j) {
+      const double distance_from_mean = hypot(i * res, j * res);
+      const double z = exp(-0.5 * pow(distance_from_mean / smear, 2));
+      const uint32_t v = static_cast<uint32_t>(round_half_away(z * 100));
+      m->kernel[(i + hk) + k * (j + hk)] = static_cast<uint8_t>(v);
+      if (v == 100) {m->footprint100.push_back(Cell{i, j});}
+    }
+  }
+
+  auto fail = [&](hipError_t e, const char * what) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    kh_matcher_destroy(m);
+    return KH_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) {return fail(e, "hipSetDevice");}
+  if ((e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
+  for (auto & ev : m->ev) {
+    if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
+  }
+  if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
+  if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
+  m->slots.resize(max_batch);
+  for (auto & s : m->slots) {
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid), static_cast<size_t>(m->data_size) + kGridPad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
+    if ((e = hipMemset(s.d_grid, 0, static_cast<size_t>(m->data_size) + kGridPad)) != hipSuccess) {return fail(e, "hipMemset grid");}
+  }
+  if ((e = hipHostMalloc(reinterpret_cast<void **>(&m->h_rjobs), sizeof(RasterJob) * max_batch, hipHostMallocDefault)) != hipSuccess) {return fail(e, "hipHostMalloc");}
+  if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_rjobs), sizeof(RasterJob) * max_batch)) != hipSuccess) {return fail(e, "hipMalloc");}
+  *out = m;
+  return KH_OK;
+}
+
+void kh_matcher_destroy(kh_matcher * m)
+{
+  if (!m) {return;}
+  hipSetDevice(m->device);
+  if (m->stream) {hipStreamSynchronize(m->stream);}
+  for (auto & s : m->slots) {
+    hipFree(s.d_grid); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
+    hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_out); hipFree(s.d_rpoints); hipFree(s.d_ractive);
+  }
+  hipFree(m->d_kernel); hipFree(m->d_stage); hipFree(m->d_rjobs);
+  if (m->h_stage) {hipHostFree(m->h_stage);}
+  if (m->h_out) {hipHostFree(m->h_out);}
+  if (m->h_rpoints) {hipHostFree(m->h_rpoints);}
+  if (m->h_ractive) {hipHostFree(m->h_ractive);}
+  if (m->h_rjobs) {hipHostFree(m->h_rjobs);}
+  for (auto & ev : m->ev) {if (ev) {hipEventDestroy(ev);}}
+  if (m->stream) {hipStreamDestroy(m->stream);}
+  delete m;
+}
+
+int kh_matcher_set_params(kh_matcher * m, const kh_match_params * p)
+{
+  if (!m || !p) {return KH_ERR_INVALID_ARG;}
+  if (!(p->coarse_angle_resolution != 0.0) || !(p->fine_search_angle_offset != 0.0) ||
+    p->minimum_distance_penalty < 0.0 || p->minimum_angle_penalty < 0.0)
+  {
+    set_error("invalid match parameters");
+    return KH_ERR_INVALID_ARG;
+  }
+  m->params = *p;
+  return KH_OK;
+}
+
+int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
+{
+  if (!m) {return KH_ERR_INVALID_ARG;}
+  m->keep_responses = keep_response_volume != 0;
+  return KH_OK;
+}
+
+static int check_scan(const kh_scan * s)
+{
+  if (!s || s->n < 0 || (s->n > 0 && (!s->ranges || !s->points_xy))) {return KH_ERR_INVALID_ARG;}
+  return KH_OK;
+}
+
+int kh_matcher_add_scans(kh_matcher * m, int32_t slot, const kh_scan * query, const kh_scan * base, int32_t n_base)
+{
+  if (!m || slot < 0 || slot >= m->max_batch || !query || n_base < 0 || (n_base > 0 && !base)) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  std::vector<RasterReq> reqs{RasterReq{slot, query, base, n_base}};
+  int rc = raster_batch(m, reqs);
+  if (rc) {return rc;}
+  KH_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+
+int kh_matcher_correlate_batch(kh_matcher * m, int32_t n, const kh_scan * queries, const double * centers,
+  const double search_offset[2], const double search_resolution[2], double angle_offset,
+  double angle_resolution, int32_t do_penalize, int32_t fine, double * means, double * covs,
+  double * responses, int32_t * status)
+{
+  if (!m || n < 0 || n > m->max_batch || !queries || !centers || !means || !covs || !responses) {return KH_ERR_INVALID_ARG;}
+  if (!(search_resolution[0] > 0.0) || !(search_resolution[1] > 0.0) || angle_resolution == 0.0) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  std::vector<CorrReq> reqs(n);
+  for (int32_t i = 0; i < n; ++i) {
+    if (check_scan(&queries[i]) != KH_OK || queries[i].n == 0) {return KH_ERR_INVALID_ARG;}
+    CorrReq & q = reqs[i];
+    q.slot = i; q.scan = &queries[i];
+    std::copy(centers + 3 * i, centers + 3 * i + 3, q.center);
+    q.off_x = search_offset[0]; q.off_y = search_offset[1];
+    q.res_x = search_resolution[0]; q.res_y = search_resolution[1];
+    q.ang_off = angle_offset; q.ang_res = angle_resolution;
+    q.penalize = do_penalize != 0; q.fine = fine != 0;
+    std::copy(covs + 9 * i, covs + 9 * i + 9, q.cov);
+    q.response = 0; q.status = KH_OK;
+  }
+  int rc = correlate_batch(m, reqs);
+  if (rc) {return rc;}
+  int worst = KH_OK;
+  for (int32_t i = 0; i < n; ++i) {
+    std::copy(reqs[i].mean, reqs[i].mean + 3, means + 3 * i);
+    std::copy(reqs[i].cov, reqs[i].cov + 9, covs + 9 * i);
+    responses[i] = reqs[i].response;
+    if (status) {status[i] = reqs[i].status;}
+    if (reqs[i].status != KH_OK) {worst = reqs[i].status;}
+  }
+  return status ? KH_OK : worst;
+}
+
+int kh_matcher_correlate(kh_matcher * m, int32_t slot, const kh_scan * query, const double center[3],
+  const double search_offset[2], const double search_resolution[2], double angle_offset,
+  double angle_resolution, int32_t do_penalize, int32_t fine, double mean[3], double cov[9], double * response)
+{
+  if (!m || slot < 0 || slot >= m->max_batch || check_scan(query) != KH_OK || query->n == 0 || !mean || !cov || !response) {
+    return KH_ERR_INVALID_ARG;
+  }
+  if (!(search_resolution[0] > 0.0) || !(search_resolution[1] > 0.0) || angle_resolution == 0.0) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  std::vector<CorrReq> reqs(1);
+  CorrReq & q = reqs[0];
+  q.slot = slot; q.scan = query;
+  std::copy(center, center + 3, q.center);
+  q.off_x = search_offset[0]; q.off_y = search_offset[1]; q.res_x = search_resolution[0]; q.res_y = search_resolution[1];
+  q.ang_off = angle_offset; q.ang_res = angle_resolution; q.penalize = do_penalize != 0; q.fine = fine != 0;
+  std::copy(cov, cov + 9, q.cov);
+  q.response = 0; q.status = KH_OK;
+  int rc = correlate_batch(m, reqs);
+  if (rc) {return rc;}
+  if (q.status != KH_OK) {return q.status;}
+  std::copy(q.mean, q.mean + 3, mean);
+  std::copy(q.cov, q.cov + 9, cov);
+  *response = q.response;
+  return KH_OK;
+}
+
+// MatchScan for n independent (query, base chain) pairs, stage by stage over the whole batch
+int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, const kh_scan * base,
+  const int32_t * base_begin, int32_t do_penalize, int32_t do_refine, double * means, double * covs,
+  double * responses, int32_t * status)
+{
+  if (!m || n < 0 || n > m->max_batch || !queries || !base_begin || !means || !covs || !responses) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  const kh_match_params & mp = m->params;
+  std::vector<int> st(n, KH_OK);
+  std::vector<int32_t> active;
+  std::vector<RasterReq> rreqs;
+  for (int32_t i = 0; i < n; ++i) {
+    if (check_scan(&queries[i]) != KH_OK) {return KH_ERR_INVALID_ARG;}
+    const int32_t nb = base_begin[i + 1] - base_begin[i];
+    if (nb < 0 || (nb > 0 && !base)) {return KH_ERR_INVALID_ARG;}
+    for (int32_t b = 0; b < nb; ++b) {
+      if (check_scan(&base[base_begin[i] + b]) != KH_OK) {return KH_ERR_INVALID_ARG;}
+    }
+    double * mean = means + 3 * i; double * cov = covs + 9 * i;
+    std::fill(cov, cov + 9, 0.0);
+    if (queries[i].n == 0) {
+      // Mapper.cpp:547-557
+      std::copy(queries[i].sensor_pose, queries[i].sensor_pose + 3, mean);
+      cov[0] = kMaxVariance; cov[4] = kMaxVariance;
+      cov[8] = 4 * (mp.coarse_angle_resolution * mp.coarse_angle_resolution);
+      responses[i] = 0.0;
+      continue;
+    }
+    active.push_back(i);
+    rreqs.push_back(RasterReq{i, &queries[i], base ? base + base_begin[i] : nullptr, nb});
+  }
+  int rc = raster_batch(m, rreqs);
+  if (rc) {return rc;}
+
+  const double res = m->grid_resolution();
+  // Mapper.cpp:577-585
+  const double cso = 0.5 * (static_cast<double>(m->side) - 1) * res;
+  const double csr = 2 * res;
+
+  auto run = [&](const std::vector<int32_t> & which, double ang_off, double ang_res, bool fine) -> int {
+    std::vector<CorrReq> reqs(which.size());
+    for (size_t k = 0; k < which.size(); ++k) {
+      const int32_t i = which[k];
+      CorrReq & q = reqs[k];
+      q.slot = i; q.scan = &queries[i];
+      if (!fine) {
+        std::copy(queries[i].sensor_pose, queries[i].sensor_pose + 3, q.center);
+        q.off_x = cso; q.off_y = cso; q.res_x = csr; q.res_y = csr;
+      } else {
+        std::copy(means + 3 * i, means + 3 * i + 3, q.center);           // Mapper.cpp:625: centre = rMean
+        q.off_x = csr * 0.5; q.off_y = csr * 0.5; q.res_x = res; q.res_y = res;   // :622-624
+      }
+      q.ang_off = ang_off; q.ang_res = ang_res; q.penalize = do_penalize != 0; q.fine = fine;
+      std::copy(covs + 9 * i, covs + 9 * i + 9, q.cov);
+      q.response = 0; q.status = KH_OK;
+    }
+    int r = correlate_batch(m, reqs);
+    if (r) {return r;}
+    for (size_t k = 0; k < which.size(); ++k) {
+      const int32_t i = which[k];
+      st[i] = reqs[k].status;
+      if (reqs[k].status != KH_OK) {continue;}
+      std::copy(reqs[k].mean, reqs[k].mean + 3, means + 3 * i);
+      std::copy(reqs[k].cov, reqs[k].cov + 9, covs + 9 * i);
+      responses[i] = reqs[k].response;
+    }
+    return KH_OK;
+  };
+  auto alive = [&](const std::vector<int32_t> & v) {
+    std::vector<int32_t> o;
+    for (int32_t i : v) {if (st[i] == KH_OK) {o.push_back(i);}}
+    return o;
+  };
+
+  // coarse search, Mapper.cpp:588-592
+  rc = run(active, mp.coarse_search_angle_offset, mp.coarse_angle_resolution, false);
+  if (rc) {return rc;}
+  // response expansion, Mapper.cpp:594-619
+  if (mp.use_response_expansion) {
+    std::vector<int32_t> zero;
+    for (int32_t i : alive(active)) {if (double_equal(responses[i], 0.0)) {zero.push_back(i);}}
+    double newSearchAngleOffset = mp.coarse_search_angle_offset;
+    for (uint32_t k = 0; k < 3 && !zero.empty(); ++k) {
+      newSearchAngleOffset += 20 * kPi180;
+      rc = run(zero, newSearchAngleOffset, mp.coarse_angle_resolution, false);
+      if (rc) {return rc;}
+      std::vector<int32_t> still;
+      for (int32_t i : alive(zero)) {if (double_equal(responses[i], 0.0)) {still.push_back(i);}}
+      zero.swap(still);
+    }
+  }
+  // fine search, Mapper.cpp:621-629
+  if (do_refine) {
+    rc = run(alive(active), 0.5 * mp.coarse_angle_resolution, mp.fine_search_angle_offset, true);
+    if (rc) {return rc;}
+  }
+  int worst = KH_OK;
+  for (int32_t i = 0; i < n; ++i) {
+    if (status) {status[i] = st[i];}
+    if (st[i] != KH_OK) {worst = st[i];}
+  }
+  return status ? KH_OK : worst;
+}
+
+int kh_matcher_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32_t n_base,
+  int32_t do_penalize, int32_t do_refine, double mean[3], double cov[9], double * response)
+{
+  if (!m || !query || !mean || !cov || !response || n_base < 0) {return KH_ERR_INVALID_ARG;}
+  const int32_t begin[2] = {0, n_base};
+  int32_t status = KH_OK;
+  int rc = kh_matcher_match_batch(m, 1, query, base, begin, do_penalize, do_refine, mean, cov, response, &status);
+  if (rc) {return rc;}
+  return status;
+}
+
+int kh_matcher_grid_info(kh_matcher * m, int32_t slot, kh_grid_info * out)
+{
+  if (!m || !out || slot < 0 || slot >= m->max_batch) {return KH_ERR_INVALID_ARG;}
+  out->width = m->width; out->height = m->height; out->width_step = m->ws; out->data_size = m->data_size;
+  out->roi_x = m->roi_x; out->roi_y = m->roi_y; out->roi_w = m->roi_w; out->roi_h = m->roi_h;
+  out->kernel_size = m->kernel_size; out->search_side = m->side;
+  out->offset_x = m->slots[slot].off_x; out->offset_y = m->slots[slot].off_y; out->scale = m->scale;
+  return KH_OK;
+}
+
+int kh_matcher_read_grid(kh_matcher * m, int32_t slot, uint8_t * out)
+{
+  if (!m || !out || slot < 0 || slot >= m->max_batch) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  KH_HIP(hipStreamSynchronize(m->stream));
+  KH_HIP(hipMemcpy(out, m->slots[slot].d_grid, static_cast<size_t>(m->data_size), hipMemcpyDeviceToHost));
+  return KH_OK;
+}
+
+int kh_matcher_read_kernel(kh_matcher * m, uint8_t * out)
+{
+  if (!m || !out) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  KH_HIP(hipMemcpy(out, m->d_kernel, m->kernel.size(), hipMemcpyDeviceToHost));
+  return KH_OK;
+}
+
+int kh_matcher_read_lookup(kh_matcher * m, int32_t slot, int32_t * n_angles, int32_t * n_points, int32_t * out)
+{
+  if (!m || slot < 0 || slot >= m->max_batch || !n_angles || !n_points) {return KH_ERR_INVALID_ARG;}
+  Slot & s = m->slots[slot];
+  if (!s.has_last) {return KH_ERR_NOT_FOUND;}
+  *n_angles = s.last.na; *n_points = s.last.P;
+  if (out) {
+    KH_HIP(hipSetDevice(m->device));
+    KH_HIP(hipStreamSynchronize(m->stream));
+    KH_HIP(hipMemcpy(out, s.d_table, sizeof(int32_t) * s.last.na * s.last.P, hipMemcpyDeviceToHost));
+  }
+  return KH_OK;
+}
+
+int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, int32_t * ny, int32_t * na,
+  int32_t * out_sums, double * out_responses)
+{
+  if (!m || slot < 0 || slot >= m->max_batch || !nx || !ny || !na) {return KH_ERR_INVALID_ARG;}
+  Slot & s = m->slots[slot];
+  if (!s.has_last) {return KH_ERR_NOT_FOUND;}
+  const CorrHost & c = s.last;
+  *nx = c.nx; *ny = c.ny; *na = c.na;
+  if (!out_sums && !out_responses) {return KH_OK;}
+  KH_HIP(hipSetDevice(m->device));
+  KH_HIP(hipStreamSynchronize(m->stream));
+  const size_t plane = static_cast<size_t>(c.nx) * c.ny, vol = plane * c.na;
+  if (out_sums) {
+    std::vector<int32_t> tmp(vol);
+    KH_HIP(hipMemcpy(tmp.data(), s.d_sums, vol * 4, hipMemcpyDeviceToHost));
+    for (int32_t a = 0; a < c.na; ++a) {
+      for (size_t p = 0; p < plane; ++p) {out_sums[p * c.na + a] = tmp[static_cast<size_t>(a) * plane + p];}
+    }
+  }
+  if (out_responses) {
+    if (!m->keep_responses || !s.d_resp) {set_error("response volume not kept: call kh_matcher_set_debug(m, 1) first"); return KH_ERR_NOT_FOUND;}
+    std::vector<double> tmp(vol);
+    KH_HIP(hipMemcpy(tmp.data(), s.d_resp, vol * 8, hipMemcpyDeviceToHost));
+    for (int32_t a = 0; a < c.na; ++a) {
+      for (size_t p = 0; p < plane; ++p) {out_responses[p * c.na + a] = tmp[static_cast<size_t>(a) * plane + p];}
+    }
+  }
+  return KH_OK;
+}
+
+void * kh_matcher_stream(kh_matcher * m) {return m ? reinterpret_cast<void *>(m->stream) : nullptr;}
+
+int kh_matcher_profile(kh_matcher * m, int32_t enable, double * score_ms, int64_t * score_launches,
+  double * raster_ms, int64_t * raster_launches)
+{
+  if (!m) {return KH_ERR_INVALID_ARG;}
+  if (score_ms) {*score_ms = m->score_ms;}
+  if (score_launches) {*score_launches = m->score_launches;}
+  if (raster_ms) {*raster_ms = m->raster_ms;}
+  if (raster_launches) {*raster_launches = m->raster_launches;}
+  m->profiling = enable != 0;
+  m->score_ms = 0; m->raster_ms = 0; m->score_launches = 0; m->raster_launches = 0;
+  return KH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// gfx950 (MI355X / CDNA4) kernels of the karto correlative scan matcher.
+//
+//   k_raster   K1  AddScans/AddScan/SmearPoint      Mapper.cpp:1032-1105, Mapper.h:1152-1183
+//   k_offsets  K2  GridIndexLookup::ComputeOffsets  Karto.h:6844-6894 (+ per-lattice compaction)
+//   k_score    K3  operator()(y) + GetResponse      Mapper.cpp:641-694, 1172-1208
+//   k_ties     K4  best-response tie collection     Mapper.cpp:802-817
+//
+// Build with -ffp-contract=off: the grid-index roundings and the penalty product must see the
+// same IEEE operations, unfused, as the reference's generic x86-64 build.
+//
+// Scoring design (K3).  For a fixed search angle a and beam i every pose (x, y) of the search
+// lattice reads grid[base(x, y) + off[a][i]], and base is linear in (x, y): the nX x nY poses read
+// one contiguous window of the grid per beam.  So a wave owns a 64-byte x 4*RY-row window
+// (16 lanes x dword across, 4 lanes down, RY rows per lane), walks the beam list once with the
+// offset in an SGPR, issues ONE unaligned dword load per lane per row (4 lookups) and
+// accumulates the four bytes in two packed 2x16-bit registers -- no per-lookup address math, no
+// byte loads.  The 4 waves of a workgroup split the beam list and merge through LDS.  The
+// arithmetic is exact integer; the FP64 penalty is applied once per pose in the epilogue.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "kh_internal.hpp"
+
+namespace kh
+{
+
+// ---------------------------------------------------------------------------------------------
+// exact helpers (mirror Math.h:87-90 and the x86-64 double->int32 conversion)
+__device__ __forceinline__ double d_round(double v) {return v >= 0.0 ? floor(v + 0.5) : ceil(v - 0.5);}
+__device__ __forceinline__ int32_t d_to_int(double v)
+{
+  if (!(v > -2147483649.0 && v < 2147483648.0)) {return INT32_MIN;}   // cvttsd2si "integer indefinite"
+  return (int32_t)v;
+}
+__device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
+{
+  uint32_t r = 0;
+#pragma unroll
+  for (int s = 0; s < 32; s += 8) {
+    uint32_t x = (a >> s) & 0xffu, y = (b >> s) & 0xffu;
+    r |= (x > y ? x : y) << s;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: one wave per valid point; lanes = 4 kernel rows x 16 grid words; word-wise CAS "max".
+// The stamp is a commutative max, so the parallel result equals the sequential one; the only
+// order-dependent part of AddScan (skip if the cell is already 100) is resolved on the host
+// into `active` when the kernel holds 100 off-centre (see matcher_host.cpp).
+__global__ __launch_bounds__(256) void k_raster(const RasterJob * jobs, const uint8_t * __restrict__ kernel)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= job.n_points) {return;}
+  if (!job.active[p]) {return;}
+  // CoordinateConverter::WorldToGrid, Karto.h:4421-4436
+  const double wx = job.points[2 * p], wy = job.points[2 * p + 1];
+  const double gxd = (wx - job.off_x) * job.scale;
+  const double gyd = (wy - job.off_y) * job.scale;
+  const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
+  // Mapper.cpp:1083-1088
+  if (!(gx >= 0 && gx < job.roi_w) || !(gy >= 0 && gy < job.roi_h)) {return;}
+  const int k = job.kernel_size, hk = k / 2;
+  const int lrow = lane >> 4, lword = lane & 15;
+  uint32_t * words = reinterpret_cast<uint32_t *>(job.grid);
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int j = j0 + lrow;
+    if (j >= k) {continue;}
+    // first byte of kernel row j in the grid (CorrelationGrid::GridIndex, Mapper.h:1122-1128)
+    const int32_t s = (gx - hk + job.roi_x) + (gy + (j - hk) + job.roi_y) * job.ws;
+    const int32_t w0 = s >> 2, w1 = (s + k - 1) >> 2;
+    for (int32_t w = w0 + lword; w <= w1; w += 16) {
+      uint32_t stamp = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int kx = (w << 2) + b - s;
+        if (kx >= 0 && kx < k) {stamp |= (uint32_t)kernel[j * k + kx] << (8 * b);}
+      }
+      if (stamp == 0) {continue;}
+      uint32_t old = words[w];
+      while (true) {
+        const uint32_t neu = bytemax4(old, stamp);
+        if (neu == old) {break;}
+        const uint32_t prev = atomicCAS(&words[w], old, neu);
+        if (prev == old) {break;}
+        old = prev;
+      }
+    }
+  }
+}
+
+void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, const uint8_t * d_kernel, void * stream)
+{
+  if (n_jobs <= 0 || max_points <= 0) {return;}
+  dim3 grid((max_points + 3) / 4, n_jobs);
+  hipLaunchKernelGGL(k_raster, grid, dim3(256), 0, (hipStream_t)stream, d_jobs, d_kernel);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: one workgroup per (angle, job).  Bit-exact table + compaction into the lists K3 walks.
+__global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t stride)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.y * stride);
+  const int a = blockIdx.x;
+  if (a >= job.na) {return;}
+  __shared__ int32_t s_counts[2];
+  if (threadIdx.x < 2) {s_counts[threadIdx.x] = 0;}
+  __syncthreads();
+  const int P = job.n_points;
+  const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
+  // index range of the lattice (real poses only)
+  const int64_t bmin = job.base0;
+  const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
+  int32_t * table = job.table + (size_t)a * P;
+  int32_t * fast = job.fast + (size_t)a * P;
+  int32_t * slow = job.slow + (size_t)a * P;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    int32_t idx;
+    if (job.invalid[i]) {
+      idx = kInvalidScan;
+    } else {
+      const double lx = job.local[2 * i], ly = job.local[2 * i + 1];
+      // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
+      const double ox = cosine * lx - sine * ly;
+      const double oy = sine * lx + cosine * ly;
+      const double gxd = ((ox + job.grid_off_x) - job.grid_off_x) * job.scale;
+      const double gyd = ((oy + job.grid_off_y) - job.grid_off_y) * job.scale;
+      const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
+      idx = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)job.ws);   // base Grid::GridIndex, no ROI
+    }
+    table[i] = idx;
+    if (idx == kInvalidScan) {continue;}   // Mapper.cpp:1194
+    if (job.linear) {
+      if ((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size) {continue;}  // off the grid for every pose
+      if ((int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size) {
+        fast[atomicAdd(&s_counts[0], 1)] = idx;
+        continue;
+      }
+    }
+    slow[atomicAdd(&s_counts[1], 1)] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {job.counts[2 * a + threadIdx.x] = s_counts[threadIdx.x];}
+}
+
+void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream)
+{
+  if (n_jobs <= 0 || max_na <= 0) {return;}
+  hipLaunchKernelGGL(k_offsets, dim3(max_na, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs, stride);
+}
+
+// ---------------------------------------------------------------------------------------------
+// response of one pose from its integer sum: GetResponse's normalisation (Mapper.cpp:1204) and the
+// odometry penalty (Mapper.cpp:671-685).  Shared by K3 and K4 so both see identical bits.
+__device__ __forceinline__ double pose_response(const CorrJob & job, int32_t sum, int a, int yi, int xi)
+{
+  double response = (double)sum / job.denom;
+  if (job.do_penalize) {
+    const double delta = response - 0.0;
+    const bool is_zero = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;   // math::DoubleEqual, Math.h:135-139
+    if (!is_zero) {
+      response *= (job.dist_pen[yi * job.nx + xi] * job.ang_pen[a]);
+    }
+  }
+  return response;
+}
+
+// global-address-space views: keeps the hot loads on global_load (vmcnt only) instead of flat_load
+typedef __attribute__((address_space(1))) uint8_t gbyte;
+typedef __attribute__((address_space(1))) int32_t gint;
+typedef __attribute__((address_space(1))) uint32_t gu32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ const gbyte * as_global(const uint8_t * p) {return (const gbyte *)p;}
+__device__ __forceinline__ const gint * as_global(const int32_t * p) {return (const gint *)p;}
+
+// K3.  SX = grid cells per lattice step in x (1: fine / full-resolution search, 2: coarse search).
+// Tile = 64 grid bytes (64 poses at SX=1, 32 at SX=2) x 4*RY lattice rows.
+template <int SX, int RY>
+__global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stride)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.z * stride);
+  const int a = blockIdx.y;
+  if (a >= job.na) {return;}
+  const int tile = blockIdx.x;
+  if (tile >= job.tiles_x * job.tiles_y) {return;}
+  constexpr int PX = kTileBytes / SX;   // poses per tile row
+  constexpr int TY = 4 * RY;            // lattice rows per tile
+  constexpr int NB = (SX == 1) ? 4 : 2; // poses per lane per row
+  const int tx = tile % job.tiles_x, ty = tile / job.tiles_x;
+  const int x0 = tx * PX, y0 = ty * TY;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lx = lane & 15, ly = lane >> 4;
+
+  __shared__ int32_t s_tile[TY * PX];
+  for (int i = threadIdx.x; i < TY * PX; i += 256) {s_tile[i] = 0;}
+  __syncthreads();
+
+  const int P = job.n_points;
+  const int n_fast = job.counts[2 * a], n_slow = job.counts[2 * a + 1];
+  const int32_t * fast = job.fast + (size_t)a * P;
+  const int32_t * slow = job.slow + (size_t)a * P;
+
+  int32_t acc[RY][NB];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {acc[r][b] = 0;}
+  }
+
+  if (n_fast > 0) {
+    // per-lane byte offset of row r inside the window; rows beyond ny are clamped (sums discarded)
+    uint32_t voff[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      int yi = y0 + r * 4 + ly;
+      yi = yi < job.ny ? yi : job.ny - 1;
+      voff[r] = (uint32_t)(x0 * SX + 4 * lx) + (uint32_t)yi * (uint32_t)job.sy_ws;
+    }
+    const gbyte * gbase = as_global(job.grid) + job.base0;
+    const gint * gfast = as_global(fast);
+    // beams [j_begin, j_end) of this wave.  Offsets are fetched 64 at a time with one coalesced
+    // load and broadcast from the register with v_readlane, so the inner loop is: 1 SALU add for
+    // the window address, RY saddr-form dword loads, 4 VALU per dword.  Packed 16-bit partial
+    // sums are flushed every 512 beams (512 * 100 < 65536).
+    const int per = (n_fast + 3) / 4;
+    const int j_begin = wave * per;
+    const int j_end = min(n_fast, j_begin + per);
+    uint32_t lo[RY], hi[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {lo[r] = 0; hi[r] = 0;}
+    int since_flush = 0;
+    for (int jc = j_begin; jc < j_end; jc += 64) {
+      const int cnt = min(64, j_end - jc);
+      const int32_t mine = (lane < cnt) ? gfast[jc + lane] : 0;
+      for (int k = 0; k < cnt; ++k) {
+        const int32_t off = __builtin_amdgcn_readlane(mine, k);
+        const gbyte * wbase = gbase + off;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+          const uint32_t w = *reinterpret_cast<const gu32_unaligned *>(wbase + voff[r]);
+          lo[r] += w & 0x00ff00ffu;
+          if (SX == 1) {hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);}   // [0, b3, 0, b1]
+        }
+      }
+      since_flush += cnt;
+      if (since_flush + 64 > 512 || jc + 64 >= j_end) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+          if (SX == 1) {
+            acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
+            acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
+          } else {
+            acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
+          }
+          lo[r] = 0; hi[r] = 0;
+        }
+        since_flush = 0;
+      }
+    }
+  }
+
+  if (n_slow > 0) {
+    // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197); also the path of
+    // non-linear lattices (bx/by are exact per-pose indices)
+    for (int j = wave; j < n_slow; j += 4) {
+      const int32_t off = slow[j];
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        const int yi = y0 + r * 4 + ly;
+        if (yi >= job.ny) {continue;}
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int xi = x0 + NB * lx + b;
+          if (xi >= job.nx) {continue;}
+          const int64_t idx = (int64_t)job.bx[xi] + (int64_t)job.by[yi] + off;
+          if (idx >= 0 && idx < job.data_size) {acc[r][b] += job.grid[idx];}
+        }
+      }
+    }
+  }
+
+  // merge the four waves' partial sums
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (acc[r][b] != 0) {atomicAdd(&s_tile[(r * 4 + ly) * PX + NB * lx + b], acc[r][b]);}
+    }
+  }
+  __syncthreads();
+
+  // epilogue: sums, responses, best, probs
+  double best = 0.0;
+  const size_t plane = (size_t)job.nx * job.ny;
+  for (int p = threadIdx.x; p < TY * PX; p += 256) {
+    const int row = p / PX, col = p % PX;
+    const int xi = x0 + col, yi = y0 + row;
+    if (xi >= job.nx || yi >= job.ny) {continue;}
+    const int32_t sum = s_tile[p];
+    const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
+    job.sums[o] = sum;
+    const double response = pose_response(job, sum, a, yi, xi);
+    if (job.write_resp) {job.resp[o] = response;}
+    best = response > best ? response : best;
+    if (job.coarse && response > 0.0) {
+      atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
+    }
+  }
+  // wave max -> one atomic per wave
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const double o = __shfl_xor(best, s);
+    best = o > best ? o : best;
+  }
+  if (lane == 0 && best > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(best));}
+}
+
+void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
+                  int32_t sx_variant, int32_t ry, void * stream)
+{
+  if (n_jobs <= 0 || max_tiles <= 0 || max_na <= 0) {return;}
+  dim3 grid(max_tiles, max_na, n_jobs);
+  hipStream_t s = (hipStream_t)stream;
+  if (sx_variant == 2) {
+    if (ry == 8) {hipLaunchKernelGGL((k_score<2, 8>), grid, dim3(256), 0, s, d_jobs, stride);}
+    else if (ry == 4) {hipLaunchKernelGGL((k_score<2, 4>), grid, dim3(256), 0, s, d_jobs, stride);}
+    else {hipLaunchKernelGGL((k_score<2, 1>), grid, dim3(256), 0, s, d_jobs, stride);}
+  } else {
+    if (ry == 8) {hipLaunchKernelGGL((k_score<1, 8>), grid, dim3(256), 0, s, d_jobs, stride);}
+    else if (ry == 4) {hipLaunchKernelGGL((k_score<1, 4>), grid, dim3(256), 0, s, d_jobs, stride);}
+    else {hipLaunchKernelGGL((k_score<1, 1>), grid, dim3(256), 0, s, d_jobs, stride);}
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: collect the poses whose response is within KT_TOLERANCE of the best (Mapper.cpp:807-808).
+// The host sorts the (few) indices and does the libm averaging in the reference's order.
+__global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t stride)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.y * stride);
+  const size_t plane = (size_t)job.nx * job.ny;
+  const size_t total = plane * job.na;
+  const double best = __longlong_as_double((long long)job.out[0]);
+  uint32_t * tie_idx = reinterpret_cast<uint32_t *>(job.out + 2);
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    const int a = (int)(o / plane);
+    const int rem = (int)(o - (size_t)a * plane);
+    const int yi = rem / job.nx, xi = rem - yi * job.nx;
+    const double response = pose_response(job, job.sums[o], a, yi, xi);
+    const double delta = response - best;
+    const bool tie = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;
+    if (tie) {
+      const unsigned long long slot = atomicAdd(&job.out[1], 1ull);
+      if (slot < (unsigned long long)kTieCap) {
+        tie_idx[slot] = (uint32_t)(((size_t)yi * job.nx + xi) * job.na + a);
+      }
+    }
+  }
+}
+
+void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, void * stream)
+{
+  if (n_jobs <= 0 || max_poses <= 0) {return;}
+  int blocks = (max_poses + 255) / 256;
+  if (blocks > 1024) {blocks = 1024;}
+  hipLaunchKernelGGL(k_ties, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs, stride);
+}
+
+}  // namespace kh

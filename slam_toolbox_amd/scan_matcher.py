@@ -1,0 +1,238 @@
+"""Host-side mirror of the reference's scan-matcher interface (karto::ScanMatcher,
+lib/karto_sdk/include/karto_sdk/Mapper.h:1322-1544) over the C ABI of libkartohip.so.
+
+Same names, argument meaning and error behaviour as the reference so that the parity tests read
+like tests of the reference class:
+
+    matcher = ScanMatcher.Create(mapper_params, searchSize, resolution, smearDeviation, rangeThreshold)
+    response, mean, cov = matcher.MatchScan(scan, base_scans, doPenalize=True, doRefineMatch=True)
+    response, mean, cov = matcher.CorrelateScan(scan, searchCenter, searchSpaceOffset, searchSpaceResolution,
+                                                searchAngleOffset, searchAngleResolution, doPenalize,
+                                                covariance, doingFineMatch)
+
+All scoring runs on the GPU through the library; nothing here computes a response."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class MapperParams:
+    """The eight karto::Mapper parameters ScanMatcher reads (Mapper.cpp:590-627, 671-682).  As with the
+    reference setters (Mapper.cpp:2562-2570) distance/angle variance penalties are given UNSQUARED and
+    squared on the way in.  Defaults = Mapper::InitializeParameters (Mapper.cpp:2250-2293)."""
+    coarse_search_angle_offset: float = 20 * 0.01745329251994329577
+    coarse_angle_resolution: float = 2 * 0.01745329251994329577
+    fine_search_angle_offset: float = 0.2 * 0.01745329251994329577
+    use_response_expansion: bool = False
+    distance_variance_penalty: float = 0.3
+    minimum_distance_penalty: float = 0.5
+    angle_variance_penalty: float = 20 * 0.01745329251994329577
+    minimum_angle_penalty: float = 0.9
+
+    def c(self) -> capi.KhMatchParams:
+        p = capi.KhMatchParams()
+        p.coarse_search_angle_offset = self.coarse_search_angle_offset
+        p.coarse_angle_resolution = self.coarse_angle_resolution
+        p.fine_search_angle_offset = self.fine_search_angle_offset
+        p.use_response_expansion = int(self.use_response_expansion)
+        p.distance_variance_penalty = self.distance_variance_penalty * self.distance_variance_penalty
+        p.minimum_distance_penalty = self.minimum_distance_penalty
+        p.angle_variance_penalty = self.angle_variance_penalty * self.angle_variance_penalty
+        p.minimum_angle_penalty = self.minimum_angle_penalty
+        return p
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class LocalizedRangeScan:
+    """What the matcher reads from karto::LocalizedRangeScan (Karto.h:5380-5760): range readings, sensor
+    pose and the unfiltered point readings computed by Update() (Karto.h:5644-5704)."""
+
+    def __init__(self, ranges, sensor_pose, min_angle, angular_resolution):
+        self.ranges = _d(ranges)
+        self.min_angle = float(min_angle)
+        self.angular_resolution = float(angular_resolution)
+        self.SetSensorPose(sensor_pose)
+
+    def SetSensorPose(self, pose):
+        self.sensor_pose = _d(pose).copy()
+        self.points = np.zeros((self.ranges.shape[0], 2))
+        capi.check(capi.lib().kh_scan_points(self.ranges, self.ranges.shape[0], self.sensor_pose, self.min_angle,
+                                             self.angular_resolution, self.points), "kh_scan_points")
+
+    def GetSensorPose(self):
+        return self.sensor_pose.copy()
+
+    def GetNumberOfRangeReadings(self):
+        return self.ranges.shape[0]
+
+    def c(self) -> capi.KhScan:
+        s = capi.KhScan()
+        s.n = self.ranges.shape[0]
+        s.ranges = self.ranges.ctypes.data_as(C.POINTER(C.c_double))
+        s.points_xy = self.points.ctypes.data_as(C.POINTER(C.c_double))
+        for i in range(3):
+            s.sensor_pose[i] = self.sensor_pose[i]
+        return s
+
+
+def _scan_array(scans):
+    arr = (capi.KhScan * max(1, len(scans)))()
+    for i, s in enumerate(scans):
+        arr[i] = s.c()
+    return arr
+
+
+class ScanMatcher:
+    def __init__(self, handle, max_batch):
+        self._h = handle
+        self.max_batch = max_batch
+
+    @staticmethod
+    def Create(mapper_params: MapperParams, searchSize, resolution, smearDeviation, rangeThreshold,
+               device: int = 0, max_batch: int = 1):
+        """ScanMatcher::Create (Mapper.cpp:477-522): returns None for invalid parameters like the reference
+        returns NULL; raises when no GPU is available (no CPU fallback)."""
+        h = C.c_void_p()
+        rc = capi.lib().kh_matcher_create(searchSize, resolution, smearDeviation, rangeThreshold, device, max_batch,
+                                          C.byref(h))
+        if rc == capi.KH_ERR_INVALID_ARG:
+            return None
+        capi.check(rc, "kh_matcher_create")
+        m = ScanMatcher(h, max_batch)
+        m.SetParams(mapper_params)
+        return m
+
+    def SetParams(self, mapper_params: MapperParams):
+        p = mapper_params.c()
+        capi.check(capi.lib().kh_matcher_set_params(self._h, C.byref(p)), "kh_matcher_set_params")
+
+    def MatchScan(self, scan, base_scans, doPenalize=True, doRefineMatch=True):
+        mean = np.zeros(3)
+        cov = np.zeros(9)
+        resp = C.c_double(0.0)
+        cs = scan.c()
+        rc = capi.lib().kh_matcher_match(self._h, C.byref(cs), _scan_array(base_scans), len(base_scans),
+                                         int(doPenalize), int(doRefineMatch), mean, cov, C.byref(resp))
+        if rc == capi.KH_ERR_SEARCH:
+            raise RuntimeError("Mapper FATAL ERROR - Unable to find best position")   # Mapper.cpp:786-796, 828
+        capi.check(rc, "kh_matcher_match")
+        return resp.value, mean, cov.reshape(3, 3)
+
+    def MatchScanBatch(self, scans, base_lists, doPenalize=True, doRefineMatch=True):
+        n = len(scans)
+        flat = [b for lst in base_lists for b in lst]
+        begin = np.zeros(n + 1, dtype=np.int32)
+        begin[1:] = np.cumsum([len(lst) for lst in base_lists])
+        means = np.zeros(3 * n)
+        covs = np.zeros(9 * n)
+        resp = np.zeros(n)
+        status = np.zeros(n, dtype=np.int32)
+        capi.check(capi.lib().kh_matcher_match_batch(self._h, n, _scan_array(scans), _scan_array(flat), begin,
+                                                     int(doPenalize), int(doRefineMatch), means, covs, resp, status),
+                   "kh_matcher_match_batch")
+        return resp, means.reshape(n, 3), covs.reshape(n, 3, 3), status
+
+    def AddScans(self, scan, base_scans, slot=0):
+        cs = scan.c()
+        capi.check(capi.lib().kh_matcher_add_scans(self._h, slot, C.byref(cs), _scan_array(base_scans), len(base_scans)),
+                   "kh_matcher_add_scans")
+
+    def CorrelateScan(self, scan, searchCenter, searchSpaceOffset, searchSpaceResolution, searchAngleOffset,
+                      searchAngleResolution, doPenalize, covariance=None, doingFineMatch=False, slot=0):
+        mean = np.zeros(3)
+        cov = np.zeros(9) if covariance is None else _d(covariance).reshape(9).copy()
+        resp = C.c_double(0.0)
+        cs = scan.c()
+        rc = capi.lib().kh_matcher_correlate(self._h, slot, C.byref(cs), _d(searchCenter), _d(searchSpaceOffset),
+                                             _d(searchSpaceResolution), searchAngleOffset, searchAngleResolution,
+                                             int(doPenalize), int(doingFineMatch), mean, cov, C.byref(resp))
+        if rc == capi.KH_ERR_SEARCH:
+            raise RuntimeError("Mapper FATAL ERROR - Unable to find best position")
+        capi.check(rc, "kh_matcher_correlate")
+        return resp.value, mean, cov.reshape(3, 3)
+
+    def CorrelateScanBatch(self, scans, centers, searchSpaceOffset, searchSpaceResolution, searchAngleOffset,
+                           searchAngleResolution, doPenalize, doingFineMatch=False, scan_array=None):
+        n = len(scans) if scan_array is None else scan_array[1]
+        arr = _scan_array(scans) if scan_array is None else scan_array[0]
+        means = np.zeros(3 * n)
+        covs = np.zeros(9 * n)
+        resp = np.zeros(n)
+        status = np.zeros(n, dtype=np.int32)
+        capi.check(capi.lib().kh_matcher_correlate_batch(self._h, n, arr, _d(centers).reshape(-1),
+                                                         _d(searchSpaceOffset), _d(searchSpaceResolution),
+                                                         searchAngleOffset, searchAngleResolution, int(doPenalize),
+                                                         int(doingFineMatch), means, covs, resp, status),
+                   "kh_matcher_correlate_batch")
+        return resp, means.reshape(n, 3), covs.reshape(n, 3, 3), status
+
+    # ---- introspection (parity tests / bench) ----
+    def grid_info(self, slot=0):
+        g = capi.KhGridInfo()
+        capi.check(capi.lib().kh_matcher_grid_info(self._h, slot, C.byref(g)), "kh_matcher_grid_info")
+        return {k: getattr(g, k) for k, _ in capi.KhGridInfo._fields_}
+
+    def GetCorrelationGrid(self, slot=0):
+        n = self.grid_info(slot)["data_size"]
+        out = np.zeros(n, dtype=np.uint8)
+        capi.check(capi.lib().kh_matcher_read_grid(self._h, slot, out), "kh_matcher_read_grid")
+        return out
+
+    def kernel(self):
+        k = self.grid_info()["kernel_size"]
+        out = np.zeros(k * k, dtype=np.uint8)
+        capi.check(capi.lib().kh_matcher_read_kernel(self._h, out), "kh_matcher_read_kernel")
+        return out.reshape(k, k)
+
+    def lookup_table(self, slot=0):
+        na, npnt = C.c_int32(), C.c_int32()
+        capi.check(capi.lib().kh_matcher_read_lookup(self._h, slot, C.byref(na), C.byref(npnt), None), "read_lookup")
+        out = np.zeros((na.value, npnt.value), dtype=np.int32)
+        capi.check(capi.lib().kh_matcher_read_lookup(self._h, slot, C.byref(na), C.byref(npnt),
+                                                     out.ctypes.data_as(C.c_void_p)), "read_lookup")
+        return out
+
+    def set_debug(self, keep_response_volume: bool):
+        capi.check(capi.lib().kh_matcher_set_debug(self._h, int(keep_response_volume)), "kh_matcher_set_debug")
+
+    def volume(self, slot=0, responses=True):
+        nx, ny, na = C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(capi.lib().kh_matcher_read_volume(self._h, slot, C.byref(nx), C.byref(ny), C.byref(na), None, None),
+                   "read_volume")
+        sums = np.zeros((ny.value, nx.value, na.value), dtype=np.int32)
+        resp = np.zeros((ny.value, nx.value, na.value)) if responses else None
+        capi.check(capi.lib().kh_matcher_read_volume(self._h, slot, C.byref(nx), C.byref(ny), C.byref(na),
+                                                     sums.ctypes.data_as(C.c_void_p),
+                                                     resp.ctypes.data_as(C.c_void_p) if responses else None),
+                   "read_volume")
+        return sums, resp
+
+    def stream(self):
+        return capi.lib().kh_matcher_stream(self._h)
+
+    def profile(self, enable=True):
+        sm, rm = C.c_double(), C.c_double()
+        sl, rl = C.c_int64(), C.c_int64()
+        capi.check(capi.lib().kh_matcher_profile(self._h, int(enable), C.byref(sm), C.byref(sl), C.byref(rm), C.byref(rl)),
+                   "kh_matcher_profile")
+        return {"score_ms": sm.value, "score_launches": sl.value, "raster_ms": rm.value, "raster_launches": rl.value}
+
+    def close(self):
+        if self._h:
+            capi.lib().kh_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,78 @@
+"""Shared scenario builders for the tests: seeded synthetic scans + the three matcher presets of
+SURVEY.md section 8a (S sequential / L loop from config/mapper_params_offline.yaml, C2 = BASELINE config 2)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from slam_toolbox_amd import synth
+
+LASER = synth.Laser()
+
+# offline.yaml:58-66 (variance penalties are squared by the setters)
+OFFLINE_PARAMS = dict(coarse_search_angle_offset=0.349, coarse_angle_resolution=0.0349,
+                      fine_search_angle_offset=0.00349, use_response_expansion=True,
+                      distance_variance_penalty=0.5, minimum_distance_penalty=0.5,
+                      angle_variance_penalty=1.0, minimum_angle_penalty=0.9)
+# BASELINE config 2: +-20 deg @ 0.5 deg; fine_search_angle_offset 0.05 deg so the fine range divides evenly
+C2_PARAMS = dict(OFFLINE_PARAMS, coarse_search_angle_offset=math.radians(20.0),
+                 coarse_angle_resolution=math.radians(0.5), fine_search_angle_offset=math.radians(0.05))
+
+PRESETS = {
+    "S": dict(create=(0.5, 0.01, 0.1, 20.0), params=OFFLINE_PARAMS),      # offline.yaml:48-50
+    "L": dict(create=(8.0, 0.05, 0.03, 20.0), params=OFFLINE_PARAMS),     # offline.yaml:53-55
+    "C2": dict(create=(0.3, 0.005, 0.03, 20.0), params=C2_PARAMS),
+    "K": dict(create=(0.3, 0.01, 0.03, 12.0), params=dict(OFFLINE_PARAMS, use_response_expansion=False)),  # karto defaults, Mapper.cpp:2209-2225
+}
+
+
+class Scenario:
+    """n_base consecutive trajectory scans + one query scan whose pose is perturbed from the truth."""
+
+    def __init__(self, seed=7, n_base=10, start=0, perturb=(0.05, -0.03, 0.02), world_seed=12345, n_traj=400, step=1):
+        self.world = synth.make_world(world_seed)
+        rng = np.random.default_rng(seed)
+        truth, odom = synth.trajectory(n_traj)
+        idx = [start + step * i for i in range(n_base + 1)]
+        self.truth = truth[idx]
+        self.ranges = [synth.make_scan(self.world, truth[i], rng) for i in idx]
+        self.base_poses = [truth[i].copy() for i in idx[:-1]]
+        self.query_pose = truth[idx[-1]] + np.asarray(perturb)
+        self.query_ranges = self.ranges[-1]
+        self.n_base = n_base
+
+    def oracle_scans(self):
+        from oracle import karto
+        base = [karto.Scan(self.ranges[i], self.base_poses[i], LASER) for i in range(self.n_base)]
+        query = karto.Scan(self.query_ranges, self.query_pose, LASER)
+        return query, base
+
+    def hip_scans(self):
+        from slam_toolbox_amd.scan_matcher import LocalizedRangeScan
+        base = [LocalizedRangeScan(self.ranges[i], self.base_poses[i], LASER.min_angle, LASER.ang_res)
+                for i in range(self.n_base)]
+        query = LocalizedRangeScan(self.query_ranges, self.query_pose, LASER.min_angle, LASER.ang_res)
+        return query, base
+
+    def ref_scans(self):
+        from oracle import ref
+        base = [ref.RefScan(self.ranges[i], self.base_poses[i]) for i in range(self.n_base)]
+        query = ref.RefScan(self.query_ranges, self.query_pose)
+        return query, base
+
+
+def make_oracle_matcher(preset, threads=1):
+    from oracle import karto
+    p = PRESETS[preset]
+    return karto.Matcher(*p["create"], p["params"], threads=threads)
+
+
+def make_hip_matcher(preset, max_batch=1):
+    from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher
+    p = PRESETS[preset]
+    return ScanMatcher.Create(MapperParams(**p["params"]), *p["create"], max_batch=max_batch)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
