@@ -1,0 +1,190 @@
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+metric  : scan-matches/sec (BASELINE.json "scan-matches/sec + loop-closure solve ms, 10k-node graph")
+workload: BASELINE config[1] = single-scan CorrelateScan, 1081 beams, 0.3 m x 0.3 m x +-20 deg search @
+          5 mm / 0.5 deg (61 x 61 x 81 = 301 401 poses x 1081 beams, 8087^2 uint8 grid), one batch of
+          `--batch` independent (query scan, rasterised grid) pairs per step.  The grids (65.4 MB each)
+          and every device buffer are resident in HBM before the timed region; a step is one
+          kh_matcher_correlate_batch call through the C ABI: exact host tables -> K2 offsets -> K3
+          scoring -> K4 ties -> tiny D2H -> host finalisation (mean + covariance).
+multi-GPU: matches are independent units -> sharded across ranks, no data-path collective (weak scaling);
+          one process per GPU, torch.distributed(nccl = RCCL) only for the barrier / max-over-ranks.
+Also reported (extra keys): loop-closure solve ms of the 10k-node / 30k-edge SPA problem (config[3]).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+P_BEAMS = 1081
+C2 = dict(nx=61, ny=61, na=81)
+# B_corr = nPoses*P*(4+1) + nPoses*32 + A*P*4 bytes per CorrelateScan
+ALG_BYTES_C2 = C2["nx"] * C2["ny"] * C2["na"] * P_BEAMS * 5 + C2["nx"] * C2["ny"] * C2["na"] * 32 + C2["na"] * P_BEAMS * 4
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(reps_target_s=12.0):
+    """The reference's own CorrelateScan (oracle/_ref, row-parallel thread-pool stand-in for
+    tbb::parallel_for_each) -- or the C restatement when _ref is absent -- on all host cores."""
+    from common import C2_PARAMS, LASER, PRESETS, Scenario
+    cores = os.cpu_count() or 1
+    sc = Scenario(seed=7, n_base=10, start=0)
+    args = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+    from oracle import ref
+    kind = "reference" if ref.available() else "port"
+    if kind == "reference":
+        ref.init_laser(LASER)
+        ref.lib().ref_set_threads(cores)
+        q, base = sc.ref_scans()
+        m = ref.RefMatcher(*PRESETS["C2"]["create"], C2_PARAMS)
+        m.add_scans(q, base)
+        run = lambda: m.correlate_scan(q, sc.query_pose, *args, True, False)  # noqa: E731
+    else:
+        from oracle import karto
+        q, base = sc.oracle_scans()
+        m = karto.Matcher(*PRESETS["C2"]["create"], C2_PARAMS, threads=cores)
+        m.add_scans(q, base)
+        run = lambda: m.correlate_scan(q, sc.query_pose, *args, True, False)  # noqa: E731
+    # warm the cores up (idle vCPUs wake slowly), then median of the reps
+    t_end = time.time() + 1.5
+    while time.time() < t_end:
+        run()
+    times = []
+    t0 = time.time()
+    while len(times) < 20 or (time.time() - t0 < reps_target_s and len(times) < 200):
+        t = time.time()
+        run()
+        times.append(time.time() - t)
+        if time.time() - t0 > 2.5 * reps_target_s:
+            break
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "scan-matches/s", "cores": cores, "kind": kind,
+            "sample": f"{len(times)} x config-2 CorrelateScan (61x61x81 poses x 1081 beams), median {med * 1e3:.1f} ms, all {cores} cores"}
+
+
+def solver_leg():
+    """Loop-closure solve of BASELINE config[3]: 10k nodes / 30k edges (extra keys, rank 0 only)."""
+    try:
+        from slam_toolbox_amd import synth
+        from slam_toolbox_amd.scan_solver import HipSpaSolver
+    except ImportError:
+        return None
+    g = synth.make_pose_graph(10000, 30000, seed=12345)
+    sol = HipSpaSolver()
+    sol.load(g["init"], g["edges"], g["z"], g["cov"])
+    sol.Compute()                       # warm-up (symbolic analysis + allocation)
+    times = []
+    summ = None
+    for _ in range(5):
+        sol.load(g["init"], g["edges"], g["z"], g["cov"])
+        t = time.time()
+        summ = sol.Compute()
+        times.append(time.time() - t)
+    return {"solve_ms": float(np.median(times)) * 1e3, "solve_iterations": int(summ["iterations"]),
+            "solve_final_cost": float(summ["final_cost"]), "solve_graph": "10000 nodes / 30000 edges"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solver", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libkartohip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from common import C2_PARAMS, PRESETS, Scenario
+    from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher, _scan_array
+    B = args.batch
+    hm = ScanMatcher.Create(MapperParams(**C2_PARAMS), *PRESETS["C2"]["create"], device=local_rank, max_batch=B)
+    # B independent (query, chain of 10 base scans) pairs along the synthetic warehouse trajectory,
+    # different per rank; grids rasterised once -> resident in HBM
+    queries, centers = [], []
+    for b in range(B):
+        sc = Scenario(seed=1000 * rank + b, n_base=10, start=(37 * (rank * B + b)) % 380,
+                      perturb=(0.04 * math.sin(b), -0.03 * math.cos(b), 0.01 * (b % 5 - 2)))
+        q, base = sc.hip_scans()
+        hm.AddScans(q, base, slot=b)
+        queries.append(q)
+        centers.append(sc.query_pose)
+    arr = (_scan_array(queries), B)
+    centers = np.asarray(centers)
+    corr = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+
+    def step():
+        return hm.CorrelateScanBatch(None, centers, *corr, True, False, scan_array=arr)
+
+    for _ in range(args.warmup):
+        step()
+    hm.profile(True)          # HIP events on the library's stream around every K3 launch
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        resp, means, covs, status = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = hm.profile(False)
+    assert (status == 0).all() and (resp > 0.1).all(), "matches failed"
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        k3_ms = prof["score_ms"] / max(1, prof["score_launches"])
+        achieved = ALG_BYTES_C2 * B / (k3_ms * 1e-3) / 1e9
+        out = {
+            "metric": "scan-matches/sec", "value": world * B * args.steps / dt, "unit": "scan-matches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 gather / i32 sum / f64 penalty",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config[1]: single-scan CorrelateScan, 1081 beams, 0.3m x 0.3m x +-20deg @ 5mm/0.5deg "
+                                   "(61x61x81 poses), 8087^2 grid", "matches_per_step_per_gpu": B,
+                       "parallelism": f"{world} x independent match shards (no collective)"},
+            "roofline": {"bound": "hbm", "kernel": "k_score<1,8>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_C2 * B, "avg_launch_ms": k3_ms,
+                         "note": "algorithmic bytes = the reference's own access stream (SURVEY 8d); the windows are "
+                                 "L2/Infinity-Cache resident so frac may exceed 1 -- see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_solver:
+            s = solver_leg()
+            if s:
+                out.update(s)
+        print(json.dumps(out))
+    hm.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

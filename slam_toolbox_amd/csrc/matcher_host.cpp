@@ -101,7 +101,6 @@ struct Slot
   int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
   size_t cap_table = 0, cap_counts = 0;
   int32_t * d_sums = nullptr; double * d_resp = nullptr; size_t cap_volume = 0, cap_resp = 0;
-  unsigned long long * d_out = nullptr; size_t cap_out = 0;   // words
   // raster staging
   double * d_rpoints = nullptr; uint8_t * d_ractive = nullptr; size_t cap_rpoints = 0, cap_ractive = 0;
   // last correlate (for the introspection calls)
@@ -130,6 +129,7 @@ struct kh_matcher
   uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_stage = 0, cap_dstage = 0;
   // pinned result mirror
   unsigned long long * h_out = nullptr; size_t cap_hout = 0;   // words
+  unsigned long long * d_out = nullptr; size_t cap_dout = 0;   // words: one contiguous result block per job
   // raster staging (pinned) + jobs
   double * h_rpoints = nullptr; uint8_t * h_ractive = nullptr; size_t cap_hrpoints = 0, cap_hractive = 0;
   RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
@@ -452,6 +452,8 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   if (rc) {return rc;}
   rc = ensure_pinned(m->h_out, m->cap_hout, out_words * n, m->stream);
   if (rc) {return rc;}
+  rc = ensure_device(m->d_out, m->cap_dout, out_words * n, m->stream);
+  if (rc) {return rc;}
 
   for (size_t i = 0; i < n; ++i) {
     CorrReq & q = reqs[i];
@@ -563,7 +565,6 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
     rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
     if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
-    rc = ensure_device(s.d_out, s.cap_out, out_words, m->stream); if (rc) {return rc;}
 
     std::memset(job, 0, sizeof(CorrJob));
     job->grid = s.d_grid; job->data_size = m->data_size; job->ws = m->ws;
@@ -590,14 +591,12 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     job->local = reinterpret_cast<const double *>(db + L.local);
     job->invalid = db + L.invalid;
     job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
-    job->sums = s.d_sums; job->resp = s.d_resp; job->out = s.d_out;
+    job->sums = s.d_sums; job->resp = s.d_resp; job->out = m->d_out + out_words * i;
   }
 
   // ---- 2. upload, launch, download ----
   KH_HIP(hipMemcpyAsync(m->d_stage, m->h_stage, stride * n, hipMemcpyHostToDevice, m->stream));
-  for (size_t i = 0; i < n; ++i) {
-    KH_HIP(hipMemsetAsync(m->slots[ctx[i].slot].d_out, 0, out_words * 8, m->stream));
-  }
+  KH_HIP(hipMemsetAsync(m->d_out, 0, out_words * 8 * n, m->stream));
   launch_offsets(m->d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[0], m->stream));}
   if (uniform_kernel) {
@@ -612,11 +611,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[1], m->stream));}
   launch_ties(m->d_stage, stride, static_cast<int32_t>(n), max_poses, m->stream);
   KH_HIP(hipGetLastError());
-  for (size_t i = 0; i < n; ++i) {
-    const CorrHost & c = ctx[i];
-    const size_t words = kOutHeaderWords + (c.fine ? 0 : static_cast<size_t>(c.nx) * c.ny);
-    KH_HIP(hipMemcpyAsync(m->h_out + out_words * i, m->slots[c.slot].d_out, words * 8, hipMemcpyDeviceToHost, m->stream));
-  }
+  KH_HIP(hipMemcpyAsync(m->h_out, m->d_out, out_words * 8 * n, hipMemcpyDeviceToHost, m->stream));
   KH_HIP(hipStreamSynchronize(m->stream));
   if (m->profiling) {
     float ms = 0;
@@ -869,9 +864,9 @@ void kh_matcher_destroy(kh_matcher * m)
   if (m->stream) {hipStreamSynchronize(m->stream);}
   for (auto & s : m->slots) {
     hipFree(s.d_grid); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
-    hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_out); hipFree(s.d_rpoints); hipFree(s.d_ractive);
+    hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
   }
-  hipFree(m->d_kernel); hipFree(m->d_stage); hipFree(m->d_rjobs);
+  hipFree(m->d_kernel); hipFree(m->d_stage); hipFree(m->d_rjobs); hipFree(m->d_out);
   if (m->h_stage) {hipHostFree(m->h_stage);}
   if (m->h_out) {hipHostFree(m->h_out);}
   if (m->h_rpoints) {hipHostFree(m->h_rpoints);}

@@ -76,3 +76,43 @@ def make_hip_matcher(preset, max_batch=1):
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+# ---------------------------------------------------------------- golden fixtures (tests/golden/*.npz)
+import os  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_NAMES = ["match_K", "match_S", "match_L", "corr_C2"]
+
+
+class Golden:
+    """One fixture made by tests/golden/make_golden.py from the reference build."""
+
+    def __init__(self, name):
+        self.name = name
+        self.d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.preset = str(self.d["preset"])
+        self.n_base = int(self.d["n_base"])
+        self.ranges = self.d["ranges"]
+        self.base_poses = self.d["base_poses"]
+        self.query_pose = self.d["query_pose"]
+
+    def oracle_scans(self):
+        from oracle import karto
+        base = [karto.Scan(self.ranges[i], self.base_poses[i], LASER) for i in range(self.n_base)]
+        return karto.Scan(self.ranges[self.n_base], self.query_pose, LASER), base
+
+    def hip_scans(self):
+        from slam_toolbox_amd.scan_matcher import LocalizedRangeScan
+        base = [LocalizedRangeScan(self.ranges[i], self.base_poses[i], LASER.min_angle, LASER.ang_res)
+                for i in range(self.n_base)]
+        return LocalizedRangeScan(self.ranges[self.n_base], self.query_pose, LASER.min_angle, LASER.ang_res), base
+
+    def dense_grid(self):
+        g = np.zeros(int(self.d["grid_geom"][8]), dtype=np.uint8)
+        g[self.d["grid_idx"]] = self.d["grid_val"]
+        return g
+
+    def correlate_args(self):
+        a = self.d["correlate_args"]
+        return (a[0], a[1]), (a[2], a[3]), float(a[4]), float(a[5]), bool(a[6]), bool(a[7])

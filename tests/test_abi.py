@@ -1,0 +1,47 @@
+"""CPU: libkartohip.so builds, loads, exports every symbol include/karto_hip.h declares, and refuses to
+compute without a GPU (there is no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from slam_toolbox_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported(kartohip_lib):
+    header = open(os.path.join(ROOT, "include", "karto_hip.h")).read()
+    declared = sorted(set(re.findall(r"KH_API[^;(]*?\b(kh_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no KH_API declarations found"
+    assert sorted(capi.SYMBOLS) == declared, set(capi.SYMBOLS) ^ set(declared)
+    for name in declared:
+        assert hasattr(kartohip_lib, name), f"{name} is declared in karto_hip.h but not exported"
+
+
+def test_no_cpu_fallback(kartohip_lib):
+    if kartohip_lib.kh_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    rc = kartohip_lib.kh_matcher_create(0.3, 0.01, 0.03, 12.0, 0, 1, C.byref(h))
+    assert rc == capi.KH_ERR_NO_DEVICE
+    assert b"no CPU fallback" in kartohip_lib.kh_last_error()
+    s = C.c_void_p()
+    assert kartohip_lib.kh_spa_create(0, C.byref(s)) == capi.KH_ERR_NO_DEVICE
+
+
+def test_invalid_create_arguments(kartohip_lib):
+    h = C.c_void_p()
+    assert kartohip_lib.kh_matcher_create(0.3, 0.0, 0.03, 12.0, 0, 1, C.byref(h)) == capi.KH_ERR_INVALID_ARG
+    assert kartohip_lib.kh_matcher_create(-1.0, 0.01, 0.03, 12.0, 0, 1, C.byref(h)) == capi.KH_ERR_INVALID_ARG
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "slam_toolbox_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "karto_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
