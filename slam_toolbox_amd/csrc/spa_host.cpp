@@ -1,0 +1,922 @@
+// Host side of the pose-graph SPA solver (hot path B): plugin state, symbolic analysis, and the
+// Levenberg-Marquardt control loop; all numeric work runs on the GPU (spa_kernels.hip).
+//
+// Reference: solvers/ceres_solver.cpp (state + options + gauge), solvers/ceres_utils.h (residual),
+// lib/karto_sdk/include/karto_sdk/Mapper.h:954-1066 (karto::ScanSolver), :174-188 (LinkInfo::Update),
+// Karto.h:2533-2577 (Matrix3::Inverse).  The minimiser restates Ceres 2.0's trust-region LM
+// (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc, trust_region_step_evaluator.cc); Ceres
+// itself is a third-party dependency that is not in the reference tree ("parity unpinned").
+//
+// Linear algebra design (MI355X): the normal matrix is factorised by a multifrontal block Cholesky.
+// Ordering = geometric nested dissection on the node positions (a pose graph is a geometric graph:
+// edges only link poses a few metres apart), which directly yields the supernodes (leaf clusters and
+// separators); each supernode's frontal matrix is a small dense problem handled by one workgroup, and
+// the elimination tree is processed level by level.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/karto_hip.h"
+#include "spa_internal.hpp"
+
+namespace kh
+{
+void set_error(const std::string & s);
+
+#define KS_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_error(std::string(#call) + ": " + hipGetErrorString(e_));                          \
+      return KH_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+struct Node {int32_t id; double pose[3];};
+struct Constraint {int32_t a, b; double z[3]; double u[9];};
+
+struct Symbolic
+{
+  int32_t n_free = 0, n_fronts = 0;
+  std::vector<int32_t> elim_of_free, free_of_elim, sn_first, sn_of_elim;
+  std::vector<int32_t> rows_ptr, rows, parent, level;
+  std::vector<int64_t> front_off;
+  std::vector<int32_t> front_m, front_ns, front_first;
+  std::vector<int32_t> child_ptr, child_list, relpos_ptr, relpos;
+  std::vector<std::vector<int32_t>> levels;
+  int64_t fronts_size = 0;
+  int64_t nnz_factor = 0;
+};
+
+template <class T>
+struct DevBuf
+{
+  T * p = nullptr; size_t cap = 0;
+  int ensure(size_t n)
+  {
+    if (n <= cap) {return KH_OK;}
+    if (p) {KS_HIP(hipFree(p)); p = nullptr;}
+    cap = std::max(n, cap + cap / 2);
+    KS_HIP(hipMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T)));
+    return KH_OK;
+  }
+  int upload(const std::vector<T> & v, hipStream_t s)
+  {
+    int rc = ensure(std::max<size_t>(v.size(), 1));
+    if (rc) {return rc;}
+    if (!v.empty()) {KS_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));}
+    return KH_OK;
+  }
+  void release() {if (p) {(void)hipFree(p); p = nullptr; cap = 0;}}
+};
+
+}  // namespace kh
+
+using namespace kh;
+
+struct kh_spa
+{
+  int32_t device = 0;
+  hipStream_t stream = nullptr;
+  kh_spa_options opt;
+  std::vector<Node> nodes;                       // insertion order
+  std::unordered_map<int32_t, int32_t> index_of; // id -> position in nodes
+  std::vector<Constraint> cons;
+  std::multimap<std::pair<int32_t, int32_t>, int32_t> con_of;   // (a, b) -> position in cons
+  int32_t first_id = 0; bool has_first = false; bool was_constant_set = false;
+  std::vector<int32_t> corr_ids; std::vector<double> corr_poses;
+  bool topology_dirty = true;
+  // cached problem
+  Symbolic sym;
+  std::vector<int32_t> free_of_node, node_of_free;
+  int32_t fixed_index = -1;
+  // device buffers
+  DevBuf<int32_t> d_edge_a, d_edge_b, d_free_of_node, d_node_of_free, d_slot_contrib_ptr, d_slot_contrib,
+    d_bsr_row_ptr, d_bsr_col, d_bsr_diag, d_node_contrib_ptr, d_node_contrib, d_front_m, d_front_ns,
+    d_front_first, d_rows_ptr, d_rows, d_child_ptr, d_child_list, d_relpos_ptr, d_relpos, d_slot_ld,
+    d_elim_of_free, d_free_of_elim, d_level_fronts, d_fail;
+  DevBuf<int64_t> d_front_off, d_slot_dest;
+  DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_H, d_g, d_fronts, d_x, d_cand, d_scale,
+    d_diag, d_rhs, d_step, d_delta, d_scal;
+  double * h_scal = nullptr; int32_t * h_fail = nullptr;
+  int32_t n_slots = 0;
+  std::vector<int32_t> level_offsets;
+};
+
+namespace kh
+{
+
+// ---- exact host pieces ------------------------------------------------------------------------
+static void matrix3_inverse(const double * m, double * inv)    // Karto.h:2533-2577 (row-major 3x3)
+{
+  inv[0] = m[4] * m[8] - m[5] * m[7];
+  inv[1] = m[2] * m[7] - m[1] * m[8];
+  inv[2] = m[1] * m[5] - m[2] * m[4];
+  inv[3] = m[5] * m[6] - m[3] * m[8];
+  inv[4] = m[0] * m[8] - m[2] * m[6];
+  inv[5] = m[2] * m[3] - m[0] * m[5];
+  inv[6] = m[3] * m[7] - m[4] * m[6];
+  inv[7] = m[1] * m[6] - m[0] * m[7];
+  inv[8] = m[0] * m[4] - m[1] * m[3];
+  const double det = m[0] * inv[0] + m[1] * inv[3] + m[2] * inv[6];
+  if (std::fabs(det) <= 1e-14) {return;}      // assert(false) is compiled out in Release
+  const double inv_det = 1.0 / det;
+  for (int i = 0; i < 9; ++i) {inv[i] *= inv_det;}
+}
+
+// AddConstraint, ceres_solver.cpp:364-376: information = symmetrised inverse; U = llt().matrixU()
+static void sqrt_information(const double * cov, double * U)
+{
+  double p[9];
+  matrix3_inverse(cov, p);
+  const double a00 = p[0], a01 = p[1], a02 = p[2], a11 = p[4], a12 = p[5], a22 = p[8];
+  const double l00 = std::sqrt(a00);
+  const double l10 = a01 / l00, l20 = a02 / l00;
+  const double l11 = std::sqrt(a11 - l10 * l10);
+  const double l21 = (a12 - l20 * l10) / l11;
+  const double l22 = std::sqrt(a22 - l20 * l20 - l21 * l21);
+  U[0] = l00; U[1] = l10; U[2] = l20;
+  U[3] = 0.0; U[4] = l11; U[5] = l21;
+  U[6] = 0.0; U[7] = 0.0; U[8] = l22;
+}
+
+static double karto_normalize_angle(double angle)   // Math.h:181-202
+{
+  const double pi = 3.14159265358979323846, two_pi = 6.28318530717958647692;
+  while (angle < -pi) {
+    if (angle < -two_pi) {angle += static_cast<uint32_t>(angle / -two_pi) * two_pi;} else {angle += two_pi;}
+  }
+  while (angle > pi) {
+    if (angle > two_pi) {angle -= static_cast<uint32_t>(angle / two_pi) * two_pi;} else {angle -= two_pi;}
+  }
+  return angle;
+}
+
+// ---- symbolic analysis -------------------------------------------------------------------------
+struct NdContext
+{
+  const std::vector<std::vector<int32_t>> * adj;
+  const std::vector<double> * px; const std::vector<double> * py;
+  std::vector<int32_t> side;          // scratch: 0 none, 1 left, 2 right
+  std::vector<std::vector<int32_t>> supernodes;
+  int32_t leaf = 12;
+};
+
+static void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes)
+{
+  if (static_cast<int32_t>(nodes.size()) <= ctx.leaf) {
+    if (!nodes.empty()) {std::sort(nodes.begin(), nodes.end()); ctx.supernodes.push_back(nodes);}
+    return;
+  }
+  const auto & adj = *ctx.adj;
+  struct Cand {size_t sep; int axis; int which; std::vector<int32_t> order;};
+  Cand best; best.sep = std::numeric_limits<size_t>::max(); best.axis = -1; best.which = 0;
+  double ext[2];
+  for (int axis = 0; axis < 2; ++axis) {
+    const std::vector<double> & c = axis == 0 ? *ctx.px : *ctx.py;
+    double lo = 1e300, hi = -1e300;
+    for (int32_t v : nodes) {lo = std::min(lo, c[v]); hi = std::max(hi, c[v]);}
+    ext[axis] = hi - lo;
+  }
+  for (int axis = 0; axis < 2; ++axis) {
+    const std::vector<double> & c = axis == 0 ? *ctx.px : *ctx.py;
+    std::vector<int32_t> order = nodes;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {return c[a] < c[b] || (c[a] == c[b] && a < b);});
+    const size_t half = order.size() / 2;
+    for (size_t i = 0; i < order.size(); ++i) {ctx.side[order[i]] = i < half ? 1 : 2;}
+    size_t bl = 0, br = 0;
+    for (size_t i = 0; i < order.size(); ++i) {
+      const int32_t v = order[i];
+      const int other = ctx.side[v] == 1 ? 2 : 1;
+      bool boundary = false;
+      for (int32_t w : adj[v]) {if (ctx.side[w] == other) {boundary = true; break;}}
+      if (boundary) {(ctx.side[v] == 1 ? bl : br)++;}
+    }
+    for (int32_t v : order) {ctx.side[v] = 0;}
+    const size_t sep = std::min(bl, br);
+    const bool better = sep < best.sep || (sep == best.sep && ext[axis] > ext[best.axis < 0 ? 0 : best.axis]);
+    if (better) {best.sep = sep; best.axis = axis; best.which = bl <= br ? 1 : 2; best.order.swap(order);}
+  }
+  const size_t half = best.order.size() / 2;
+  for (size_t i = 0; i < best.order.size(); ++i) {ctx.side[best.order[i]] = i < half ? 1 : 2;}
+  std::vector<int32_t> A, B, S;
+  for (int32_t v : best.order) {
+    const int sd = ctx.side[v];
+    bool boundary = false;
+    if (sd == best.which) {
+      const int other = sd == 1 ? 2 : 1;
+      for (int32_t w : adj[v]) {if (ctx.side[w] == other) {boundary = true; break;}}
+    }
+    if (boundary) {S.push_back(v);} else if (sd == 1) {A.push_back(v);} else {B.push_back(v);}
+  }
+  for (int32_t v : best.order) {ctx.side[v] = 0;}
+  if (S.empty()) {              // the halves are not connected: two independent subtrees
+    nd_recurse(ctx, A);
+    nd_recurse(ctx, B);
+    return;
+  }
+  if (A.empty() || B.empty()) { // no useful split (clique-like set): one dense supernode
+    std::sort(nodes.begin(), nodes.end());
+    ctx.supernodes.push_back(nodes);
+    return;
+  }
+  nd_recurse(ctx, A);
+  nd_recurse(ctx, B);
+  std::sort(S.begin(), S.end());
+  ctx.supernodes.push_back(S);
+}
+
+static int build_symbolic(
+  Symbolic & sym, int32_t n_free, const std::vector<std::vector<int32_t>> & adj,
+  const std::vector<double> & px, const std::vector<double> & py)
+{
+  sym = Symbolic();
+  sym.n_free = n_free;
+  NdContext ctx;
+  ctx.adj = &adj; ctx.px = &px; ctx.py = &py;
+  ctx.side.assign(n_free, 0);
+  std::vector<int32_t> all(n_free);
+  for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
+  nd_recurse(ctx, all);
+  const int32_t K = static_cast<int32_t>(ctx.supernodes.size());
+  sym.n_fronts = K;
+  sym.elim_of_free.assign(n_free, -1);
+  sym.free_of_elim.assign(n_free, -1);
+  sym.sn_first.assign(K + 1, 0);
+  sym.sn_of_elim.assign(n_free, -1);
+  int32_t pos = 0;
+  for (int32_t k = 0; k < K; ++k) {
+    sym.sn_first[k] = pos;
+    for (int32_t v : ctx.supernodes[k]) {
+      sym.elim_of_free[v] = pos; sym.free_of_elim[pos] = v; sym.sn_of_elim[pos] = k; ++pos;
+    }
+  }
+  sym.sn_first[K] = pos;
+  if (pos != n_free) {set_error("nested dissection lost nodes"); return KH_ERR_SOLVER;}
+
+  // struct rows, parents, children
+  std::vector<std::vector<int32_t>> rows(K), children(K);
+  std::vector<int32_t> stamp(n_free, -1);
+  sym.parent.assign(K, -1);
+  for (int32_t k = 0; k < K; ++k) {
+    const int32_t end = sym.sn_first[k + 1];
+    std::vector<int32_t> & r = rows[k];
+    for (int32_t e = sym.sn_first[k]; e < end; ++e) {
+      for (int32_t w : adj[sym.free_of_elim[e]]) {
+        const int32_t ew = sym.elim_of_free[w];
+        if (ew >= end && stamp[ew] != k) {stamp[ew] = k; r.push_back(ew);}
+      }
+    }
+    for (int32_t c : children[k]) {
+      for (int32_t ew : rows[c]) {
+        if (ew >= end && stamp[ew] != k) {stamp[ew] = k; r.push_back(ew);}
+      }
+    }
+    std::sort(r.begin(), r.end());
+    if (!r.empty()) {
+      sym.parent[k] = sym.sn_of_elim[r[0]];
+      children[sym.parent[k]].push_back(k);
+    }
+  }
+  sym.rows_ptr.assign(K + 1, 0);
+  sym.child_ptr.assign(K + 1, 0);
+  sym.relpos_ptr.assign(K + 1, 0);
+  sym.level.assign(K, 0);
+  sym.front_off.assign(K, 0); sym.front_m.assign(K, 0); sym.front_ns.assign(K, 0); sym.front_first.assign(K, 0);
+  int64_t off = 0;
+  int32_t max_level = 0;
+  for (int32_t k = 0; k < K; ++k) {
+    sym.rows_ptr[k + 1] = sym.rows_ptr[k] + static_cast<int32_t>(rows[k].size());
+    sym.child_ptr[k + 1] = sym.child_ptr[k] + static_cast<int32_t>(children[k].size());
+    sym.relpos_ptr[k + 1] = sym.relpos_ptr[k] + static_cast<int32_t>(rows[k].size());
+    const int32_t ncols = sym.sn_first[k + 1] - sym.sn_first[k];
+    sym.front_ns[k] = 3 * ncols;
+    sym.front_m[k] = 3 * (ncols + static_cast<int32_t>(rows[k].size()));
+    sym.front_first[k] = sym.sn_first[k];
+    sym.front_off[k] = off;
+    off += static_cast<int64_t>(sym.front_m[k]) * sym.front_m[k];
+    sym.nnz_factor += static_cast<int64_t>(sym.front_ns[k]) * (sym.front_ns[k] + 1) / 2 +
+      static_cast<int64_t>(sym.front_ns[k]) * (sym.front_m[k] - sym.front_ns[k]);
+    for (int32_t c : children[k]) {sym.level[k] = std::max(sym.level[k], sym.level[c] + 1);}
+    max_level = std::max(max_level, sym.level[k]);
+    if (sym.front_ns[k] > 3072) {set_error("supernode too large for the triangular-solve kernel"); return KH_ERR_SOLVER;}
+  }
+  sym.fronts_size = off;
+  sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);
+  for (int32_t k = 0; k < K; ++k) {
+    sym.rows.insert(sym.rows.end(), rows[k].begin(), rows[k].end());
+    sym.child_list.insert(sym.child_list.end(), children[k].begin(), children[k].end());
+    const int32_t p = sym.parent[k];
+    if (p < 0) {continue;}
+    const int32_t pcols = sym.sn_first[p + 1] - sym.sn_first[p];
+    for (size_t q = 0; q < rows[k].size(); ++q) {
+      const int32_t r = rows[k][q];
+      int32_t at;
+      if (r < sym.sn_first[p + 1]) {
+        at = r - sym.sn_first[p];
+      } else {
+        auto it = std::lower_bound(rows[p].begin(), rows[p].end(), r);
+        if (it == rows[p].end() || *it != r) {set_error("symbolic: child row missing in parent front"); return KH_ERR_SOLVER;}
+        at = pcols + static_cast<int32_t>(it - rows[p].begin());
+      }
+      sym.relpos[sym.relpos_ptr[k] + q] = at;
+    }
+  }
+  sym.levels.assign(max_level + 1, {});
+  for (int32_t k = 0; k < K; ++k) {sym.levels[sym.level[k]].push_back(k);}
+  return KH_OK;
+}
+
+// ---- problem setup on the device -----------------------------------------------------------------
+static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
+{
+  const int32_t N = static_cast<int32_t>(s->nodes.size());
+  const int32_t E = static_cast<int32_t>(s->cons.size());
+  has_work = false;
+  // gauge: first inserted node is constant once it has parameter blocks (ceres_solver.cpp:228-241)
+  std::vector<uint8_t> used(N, 0);
+  std::vector<int32_t> ea(E), eb(E);
+  for (int32_t e = 0; e < E; ++e) {
+    ea[e] = s->index_of.at(s->cons[e].a); eb[e] = s->index_of.at(s->cons[e].b);
+    used[ea[e]] = 1; used[eb[e]] = 1;
+  }
+  if (!s->was_constant_set && s->has_first) {
+    auto it = s->index_of.find(s->first_id);
+    if (it != s->index_of.end() && used[it->second]) {s->was_constant_set = true;}
+  }
+  int32_t fixed = -1;
+  if (s->was_constant_set) {
+    auto it = s->index_of.find(s->first_id);
+    if (it != s->index_of.end()) {fixed = it->second;}
+  }
+  if (s->topology_dirty || fixed != s->fixed_index) {
+    s->fixed_index = fixed;
+    s->free_of_node.assign(N, -1);
+    s->node_of_free.clear();
+    for (int32_t i = 0; i < N; ++i) {
+      if (used[i] && i != fixed) {s->free_of_node[i] = static_cast<int32_t>(s->node_of_free.size()); s->node_of_free.push_back(i);}
+    }
+    const int32_t nf = static_cast<int32_t>(s->node_of_free.size());
+    if (nf == 0 || E == 0) {s->topology_dirty = true; return KH_OK;}
+    // adjacency + BSR pattern over the free nodes
+    std::vector<std::vector<int32_t>> adj(nf);
+    for (int32_t e = 0; e < E; ++e) {
+      const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
+      if (fa >= 0 && fb >= 0 && fa != fb) {adj[fa].push_back(fb); adj[fb].push_back(fa);}
+    }
+    std::vector<int32_t> row_ptr(nf + 1, 0), col, diag(nf), slot_row;
+    for (int32_t i = 0; i < nf; ++i) {
+      auto & a = adj[i];
+      std::sort(a.begin(), a.end());
+      a.erase(std::unique(a.begin(), a.end()), a.end());
+      std::vector<int32_t> r = a;
+      r.insert(std::lower_bound(r.begin(), r.end(), i), i);
+      for (int32_t j : r) {if (j == i) {diag[i] = static_cast<int32_t>(col.size());} col.push_back(j); slot_row.push_back(i);}
+      row_ptr[i + 1] = static_cast<int32_t>(col.size());
+    }
+    const int32_t n_slots = static_cast<int32_t>(col.size());
+    auto slot_of = [&](int32_t i, int32_t j) {
+      const auto b = col.begin() + row_ptr[i], e2 = col.begin() + row_ptr[i + 1];
+      return static_cast<int32_t>(std::lower_bound(b, e2, j) - col.begin());
+    };
+    std::vector<std::vector<int32_t>> sc(n_slots), nc(nf);
+    for (int32_t e = 0; e < E; ++e) {
+      const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
+      if (fa >= 0) {sc[slot_of(fa, fa)].push_back(e * 4 + 0); nc[fa].push_back(e * 2 + 0);}
+      if (fb >= 0) {sc[slot_of(fb, fb)].push_back(e * 4 + 1); nc[fb].push_back(e * 2 + 1);}
+      if (fa >= 0 && fb >= 0 && fa != fb) {
+        sc[slot_of(fa, fb)].push_back(e * 4 + 2);
+        sc[slot_of(fb, fa)].push_back(e * 4 + 3);
+      }
+    }
+    std::vector<int32_t> scp(n_slots + 1, 0), scl, ncp(nf + 1, 0), ncl;
+    for (int32_t k = 0; k < n_slots; ++k) {scl.insert(scl.end(), sc[k].begin(), sc[k].end()); scp[k + 1] = static_cast<int32_t>(scl.size());}
+    for (int32_t i = 0; i < nf; ++i) {ncl.insert(ncl.end(), nc[i].begin(), nc[i].end()); ncp[i + 1] = static_cast<int32_t>(ncl.size());}
+    // ordering + fronts
+    std::vector<double> px(nf), py(nf);
+    for (int32_t i = 0; i < nf; ++i) {px[i] = s->nodes[s->node_of_free[i]].pose[0]; py[i] = s->nodes[s->node_of_free[i]].pose[1];}
+    int rc = build_symbolic(s->sym, nf, adj, px, py);
+    if (rc) {return rc;}
+    const Symbolic & sym = s->sym;
+    std::vector<int64_t> slot_dest(n_slots, -1);
+    std::vector<int32_t> slot_ld(n_slots, 0);
+    for (int32_t k = 0; k < n_slots; ++k) {
+      const int32_t ei = sym.elim_of_free[slot_row[k]], ej = sym.elim_of_free[col[k]];
+      if (ei < ej) {continue;}
+      const int32_t f = sym.sn_of_elim[ej];
+      const int32_t ncols = sym.sn_first[f + 1] - sym.sn_first[f];
+      const int32_t colpos = ej - sym.sn_first[f];
+      int32_t rowpos;
+      if (ei < sym.sn_first[f + 1]) {
+        rowpos = ei - sym.sn_first[f];
+      } else {
+        const auto b = sym.rows.begin() + sym.rows_ptr[f], e2 = sym.rows.begin() + sym.rows_ptr[f + 1];
+        auto it = std::lower_bound(b, e2, ei);
+        if (it == e2 || *it != ei) {set_error("symbolic: matrix entry outside its front"); return KH_ERR_SOLVER;}
+        rowpos = ncols + static_cast<int32_t>(it - b);
+      }
+      slot_dest[k] = sym.front_off[f] + 3 * rowpos + static_cast<int64_t>(3 * colpos) * sym.front_m[f];
+      slot_ld[k] = sym.front_m[f];
+    }
+    // level lists, concatenated
+    std::vector<int32_t> level_fronts;
+    s->level_offsets.assign(1, 0);
+    for (auto & lv : sym.levels) {
+      level_fronts.insert(level_fronts.end(), lv.begin(), lv.end());
+      s->level_offsets.push_back(static_cast<int32_t>(level_fronts.size()));
+    }
+    // uploads
+    hipStream_t st = s->stream;
+    std::vector<int32_t> col_and_row = col;
+    col_and_row.insert(col_and_row.end(), slot_row.begin(), slot_row.end());
+    int r2 = 0;
+    r2 |= s->d_edge_a.upload(ea, st); r2 |= s->d_edge_b.upload(eb, st);
+    r2 |= s->d_free_of_node.upload(s->free_of_node, st); r2 |= s->d_node_of_free.upload(s->node_of_free, st);
+    r2 |= s->d_slot_contrib_ptr.upload(scp, st); r2 |= s->d_slot_contrib.upload(scl, st);
+    r2 |= s->d_bsr_row_ptr.upload(row_ptr, st); r2 |= s->d_bsr_col.upload(col_and_row, st); r2 |= s->d_bsr_diag.upload(diag, st);
+    r2 |= s->d_node_contrib_ptr.upload(ncp, st); r2 |= s->d_node_contrib.upload(ncl, st);
+    r2 |= s->d_front_off.upload(sym.front_off, st); r2 |= s->d_front_m.upload(sym.front_m, st);
+    r2 |= s->d_front_ns.upload(sym.front_ns, st); r2 |= s->d_front_first.upload(sym.front_first, st);
+    r2 |= s->d_rows_ptr.upload(sym.rows_ptr, st); r2 |= s->d_rows.upload(sym.rows, st);
+    r2 |= s->d_child_ptr.upload(sym.child_ptr, st); r2 |= s->d_child_list.upload(sym.child_list, st);
+    r2 |= s->d_relpos_ptr.upload(sym.relpos_ptr, st); r2 |= s->d_relpos.upload(sym.relpos, st);
+    r2 |= s->d_slot_dest.upload(slot_dest, st); r2 |= s->d_slot_ld.upload(slot_ld, st);
+    r2 |= s->d_elim_of_free.upload(sym.elim_of_free, st); r2 |= s->d_free_of_elim.upload(sym.free_of_elim, st);
+    r2 |= s->d_level_fronts.upload(level_fronts, st);
+    if (r2) {return KH_ERR_HIP;}
+    s->n_slots = n_slots;
+    const size_t scratch = std::max<size_t>(static_cast<size_t>(21) * E, static_cast<size_t>(9) * nf + 16);
+    r2 |= s->d_edge_lin.ensure(scratch); r2 |= s->d_edge_cost.ensure(std::max(E, 1));
+    r2 |= s->d_H.ensure(static_cast<size_t>(n_slots) * 9); r2 |= s->d_g.ensure(static_cast<size_t>(nf) * 3);
+    r2 |= s->d_fronts.ensure(static_cast<size_t>(sym.fronts_size) + 16);
+    r2 |= s->d_scale.ensure(3 * nf); r2 |= s->d_diag.ensure(3 * nf); r2 |= s->d_rhs.ensure(3 * nf);
+    r2 |= s->d_step.ensure(3 * nf); r2 |= s->d_delta.ensure(3 * nf);
+    r2 |= s->d_fail.ensure(4);
+    if (r2) {return KH_ERR_HIP;}
+    s->topology_dirty = false;
+  }
+  const int32_t nf = static_cast<int32_t>(s->node_of_free.size());
+  if (nf == 0 || E == 0) {return KH_OK;}
+  // values that change between calls without touching the topology
+  std::vector<double> z(static_cast<size_t>(E) * 3), u(static_cast<size_t>(E) * 9), x(static_cast<size_t>(N) * 3);
+  for (int32_t e = 0; e < E; ++e) {
+    std::copy(s->cons[e].z, s->cons[e].z + 3, z.begin() + 3 * e);
+    std::copy(s->cons[e].u, s->cons[e].u + 9, u.begin() + 9 * e);
+  }
+  for (int32_t i = 0; i < N; ++i) {std::copy(s->nodes[i].pose, s->nodes[i].pose + 3, x.begin() + 3 * i);}
+  int r3 = 0;
+  r3 |= s->d_edge_z.upload(z, s->stream); r3 |= s->d_edge_u.upload(u, s->stream);
+  r3 |= s->d_x.upload(x, s->stream); r3 |= s->d_cand.ensure(x.size()); r3 |= s->d_scal.ensure(32);
+  if (r3) {return KH_ERR_HIP;}
+  KS_HIP(hipStreamSynchronize(s->stream));   // the staging vectors above go out of scope
+
+  const Symbolic & sym = s->sym;
+  dev.n_nodes = N; dev.n_free = nf; dev.n_edges = E;
+  dev.edge_a = s->d_edge_a.p; dev.edge_b = s->d_edge_b.p; dev.edge_z = s->d_edge_z.p; dev.edge_u = s->d_edge_u.p;
+  dev.free_of_node = s->d_free_of_node.p; dev.node_of_free = s->d_node_of_free.p;
+  dev.edge_lin = s->d_edge_lin.p; dev.edge_cost = s->d_edge_cost.p;
+  dev.n_slots = s->n_slots; dev.slot_contrib_ptr = s->d_slot_contrib_ptr.p; dev.slot_contrib = s->d_slot_contrib.p;
+  dev.bsr_row_ptr = s->d_bsr_row_ptr.p; dev.bsr_col = s->d_bsr_col.p; dev.bsr_diag_slot = s->d_bsr_diag.p;
+  dev.H = s->d_H.p; dev.node_contrib_ptr = s->d_node_contrib_ptr.p; dev.node_contrib = s->d_node_contrib.p; dev.g = s->d_g.p;
+  dev.n_fronts = sym.n_fronts; dev.front_off = s->d_front_off.p; dev.front_m = s->d_front_m.p; dev.front_ns = s->d_front_ns.p;
+  dev.front_first = s->d_front_first.p; dev.front_rows_ptr = s->d_rows_ptr.p; dev.front_rows = s->d_rows.p;
+  dev.child_ptr = s->d_child_ptr.p; dev.child_list = s->d_child_list.p; dev.relpos_ptr = s->d_relpos_ptr.p; dev.relpos = s->d_relpos.p;
+  dev.slot_dest = s->d_slot_dest.p; dev.slot_ld = s->d_slot_ld.p;
+  dev.elim_of_free = s->d_elim_of_free.p; dev.free_of_elim = s->d_free_of_elim.p;
+  dev.fronts = s->d_fronts.p; dev.fronts_size = sym.fronts_size;
+  has_work = true;
+  return KH_OK;
+}
+
+}  // namespace kh
+
+// =============================================================================================
+extern "C" {
+
+void kh_spa_options_default(kh_spa_options * o)
+{
+  // ceres_solver.cpp:157-186; max_num_iterations is left at the Ceres default
+  o->max_num_iterations = 50;
+  o->function_tolerance = 1e-3; o->gradient_tolerance = 1e-6; o->parameter_tolerance = 1e-3;
+  o->min_relative_decrease = 1e-3;
+  o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e8; o->min_trust_region_radius = 1e-16;
+  o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 3; o->use_nonmonotonic_steps = 1;
+  o->max_consecutive_nonmonotonic_steps = 3; o->jacobi_scaling = 1;
+}
+
+int kh_spa_create(int32_t device, kh_spa ** out)
+{
+  if (!out) {return KH_ERR_INVALID_ARG;}
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    set_error("no usable HIP device (libkartohip has no CPU fallback)");
+    return KH_ERR_NO_DEVICE;
+  }
+  kh_spa * s = new kh_spa();
+  s->device = device;
+  kh_spa_options_default(&s->opt);
+  KS_HIP(hipSetDevice(device));
+  KS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_scal), sizeof(double) * 32, hipHostMallocDefault));
+  KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_fail), sizeof(int32_t) * 4, hipHostMallocDefault));
+  *out = s;
+  return KH_OK;
+}
+
+void kh_spa_destroy(kh_spa * s)
+{
+  if (!s) {return;}
+  (void)hipSetDevice(s->device);
+  if (s->stream) {(void)hipStreamSynchronize(s->stream);}
+  s->d_edge_a.release(); s->d_edge_b.release(); s->d_free_of_node.release(); s->d_node_of_free.release();
+  s->d_slot_contrib_ptr.release(); s->d_slot_contrib.release(); s->d_bsr_row_ptr.release(); s->d_bsr_col.release();
+  s->d_bsr_diag.release(); s->d_node_contrib_ptr.release(); s->d_node_contrib.release(); s->d_front_m.release();
+  s->d_front_ns.release(); s->d_front_first.release(); s->d_rows_ptr.release(); s->d_rows.release();
+  s->d_child_ptr.release(); s->d_child_list.release(); s->d_relpos_ptr.release(); s->d_relpos.release();
+  s->d_slot_ld.release(); s->d_elim_of_free.release(); s->d_free_of_elim.release(); s->d_level_fronts.release();
+  s->d_fail.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
+  s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_H.release(); s->d_g.release(); s->d_fronts.release();
+  s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
+  s->d_step.release(); s->d_delta.release(); s->d_scal.release();
+  if (s->h_scal) {(void)hipHostFree(s->h_scal);}
+  if (s->h_fail) {(void)hipHostFree(s->h_fail);}
+  if (s->stream) {(void)hipStreamDestroy(s->stream);}
+  delete s;
+}
+
+int kh_spa_set_options(kh_spa * s, const kh_spa_options * o)
+{
+  if (!s || !o) {return KH_ERR_INVALID_ARG;}
+  s->opt = *o;
+  return KH_OK;
+}
+
+int kh_spa_reset(kh_spa * s)     // ceres_solver.cpp:279-314
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  s->nodes.clear(); s->index_of.clear(); s->cons.clear(); s->con_of.clear();
+  s->corr_ids.clear(); s->corr_poses.clear();
+  s->has_first = false; s->was_constant_set = false; s->topology_dirty = true; s->fixed_index = -1;
+  return KH_OK;
+}
+
+int kh_spa_clear(kh_spa * s)     // ceres_solver.cpp:272-276
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  s->corr_ids.clear(); s->corr_poses.clear();
+  return KH_OK;
+}
+
+int kh_spa_add_node(kh_spa * s, int32_t id, const double pose[3])    // ceres_solver.cpp:317-336
+{
+  if (!s || !pose) {return KH_ERR_INVALID_ARG;}
+  if (s->index_of.count(id)) {return KH_OK;}       // unordered_map::insert keeps the existing entry
+  Node n; n.id = id; std::copy(pose, pose + 3, n.pose);
+  s->index_of[id] = static_cast<int32_t>(s->nodes.size());
+  s->nodes.push_back(n);
+  if (s->nodes.size() == 1) {s->first_id = id; s->has_first = true;}
+  s->topology_dirty = true;
+  return KH_OK;
+}
+
+int kh_spa_add_constraint(kh_spa * s, int32_t id_a, int32_t id_b, const double z[3], const double cov[9])   // :339-392
+{
+  if (!s || !z || !cov) {return KH_ERR_INVALID_ARG;}
+  if (!s->index_of.count(id_a) || !s->index_of.count(id_b) || id_a == id_b) {
+    set_error("CeresSolver: Failed to add constraint, could not find nodes.");
+    return KH_ERR_NOT_FOUND;
+  }
+  Constraint c; c.a = id_a; c.b = id_b;
+  std::copy(z, z + 3, c.z);
+  sqrt_information(cov, c.u);
+  s->con_of.insert({{id_a, id_b}, static_cast<int32_t>(s->cons.size())});
+  s->cons.push_back(c);
+  s->topology_dirty = true;
+  return KH_OK;
+}
+
+static void erase_constraints(kh_spa * s, const std::vector<int32_t> & doomed)
+{
+  if (doomed.empty()) {return;}
+  std::vector<uint8_t> kill(s->cons.size(), 0);
+  for (int32_t k : doomed) {kill[k] = 1;}
+  std::vector<Constraint> keep;
+  for (size_t k = 0; k < s->cons.size(); ++k) {if (!kill[k]) {keep.push_back(s->cons[k]);}}
+  s->cons.swap(keep);
+  s->con_of.clear();
+  for (size_t k = 0; k < s->cons.size(); ++k) {s->con_of.insert({{s->cons[k].a, s->cons[k].b}, static_cast<int32_t>(k)});}
+  s->topology_dirty = true;
+}
+
+int kh_spa_remove_node(kh_spa * s, int32_t id)     // ceres_solver.cpp:395-427 (RemoveParameterBlock drops its residuals)
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  auto it = s->index_of.find(id);
+  if (it == s->index_of.end()) {set_error("RemoveNode: Failed to find node matching id"); return KH_ERR_NOT_FOUND;}
+  std::vector<int32_t> doomed;
+  for (size_t k = 0; k < s->cons.size(); ++k) {if (s->cons[k].a == id || s->cons[k].b == id) {doomed.push_back(static_cast<int32_t>(k));}}
+  erase_constraints(s, doomed);
+  s->nodes.erase(s->nodes.begin() + it->second);
+  s->index_of.clear();
+  for (size_t k = 0; k < s->nodes.size(); ++k) {s->index_of[s->nodes[k].id] = static_cast<int32_t>(k);}
+  s->topology_dirty = true;
+  return KH_OK;
+}
+
+int kh_spa_remove_constraint(kh_spa * s, int32_t id_a, int32_t id_b)    // ceres_solver.cpp:430-448
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  auto it = s->con_of.find({id_a, id_b});
+  if (it == s->con_of.end()) {it = s->con_of.find({id_b, id_a});}
+  if (it == s->con_of.end()) {set_error("RemoveConstraint: Failed to find residual block"); return KH_ERR_NOT_FOUND;}
+  erase_constraints(s, {it->second});
+  return KH_OK;
+}
+
+int kh_spa_modify_node(kh_spa * s, int32_t id, const double pose[3])    // ceres_solver.cpp:451-461
+{
+  if (!s || !pose) {return KH_ERR_INVALID_ARG;}
+  auto it = s->index_of.find(id);
+  if (it == s->index_of.end()) {return KH_ERR_NOT_FOUND;}
+  Node & n = s->nodes[it->second];
+  const double yaw_init = n.pose[2];
+  n.pose[0] = pose[0]; n.pose[1] = pose[1]; n.pose[2] = pose[2];
+  n.pose[2] += yaw_init;
+  return KH_OK;
+}
+
+int kh_spa_get_node(kh_spa * s, int32_t id, double pose[3])
+{
+  if (!s || !pose) {return KH_ERR_INVALID_ARG;}
+  auto it = s->index_of.find(id);
+  if (it == s->index_of.end()) {return KH_ERR_NOT_FOUND;}
+  std::copy(s->nodes[it->second].pose, s->nodes[it->second].pose + 3, pose);
+  return KH_OK;
+}
+
+int32_t kh_spa_num_nodes(kh_spa * s) {return s ? static_cast<int32_t>(s->nodes.size()) : 0;}
+int32_t kh_spa_num_constraints(kh_spa * s) {return s ? static_cast<int32_t>(s->cons.size()) : 0;}
+
+int kh_spa_get_corrections(kh_spa * s, int32_t * n, int32_t * ids, double * poses)
+{
+  if (!s || !n) {return KH_ERR_INVALID_ARG;}
+  *n = static_cast<int32_t>(s->corr_ids.size());
+  if (ids) {std::copy(s->corr_ids.begin(), s->corr_ids.end(), ids);}
+  if (poses) {std::copy(s->corr_poses.begin(), s->corr_poses.end(), poses);}
+  return KH_OK;
+}
+
+int kh_link_info(const double pose1[3], const double pose2[3], const double cov[9], double diff[3], double cov_out[9])
+{
+  if (!pose1 || !pose2 || !cov || !diff || !cov_out) {return KH_ERR_INVALID_ARG;}
+  // LinkInfo::Update, Mapper.h:174-188; Transform(rPose1, Pose2()), Karto.h:3003-3024
+  const double x1 = pose1[0], y1 = pose1[1], t1 = pose1[2];
+  double c = 1.0, sn = 0.0, tx = 0.0, ty = 0.0, tth = 0.0;
+  if (!(x1 == 0.0 && y1 == 0.0 && t1 == 0.0)) {
+    c = std::cos(0.0 - t1); sn = std::sin(0.0 - t1);
+    if (x1 != 0.0 || y1 != 0.0) {
+      tx = 0.0 - (c * x1 + (0.0 - sn) * y1 + 0.0 * t1);
+      ty = 0.0 - (sn * x1 + c * y1 + 0.0 * t1);
+    }
+    tth = 0.0 - t1;
+  }
+  diff[0] = tx + (c * pose2[0] + (0.0 - sn) * pose2[1] + 0.0 * pose2[2]);
+  diff[1] = ty + (sn * pose2[0] + c * pose2[1] + 0.0 * pose2[2]);
+  diff[2] = karto_normalize_angle(pose2[2] + tth);
+  // covariance rotated into the frame of pose1: R(-t1) * cov * R(-t1)^T (Matrix3 triple-loop products)
+  const double cr = std::cos(-t1), sr = std::sin(-t1);
+  const double omc = 1.0 - cr;      // Matrix3::FromAxisAngle(0, 0, 1, -t1), Karto.h:2482-2511
+  const double R[9] = {0.0 * omc + cr, 0.0 - sr, 0.0, 0.0 + sr, 0.0 * omc + cr, 0.0, 0.0, 0.0, 1.0 * omc + cr};
+  double tmp[9], Rt[9];
+  for (int r = 0; r < 3; ++r) {for (int q = 0; q < 3; ++q) {Rt[3 * r + q] = R[3 * q + r];}}
+  for (int r = 0; r < 3; ++r) {
+    for (int q = 0; q < 3; ++q) {
+      tmp[3 * r + q] = R[3 * r] * cov[q] + R[3 * r + 1] * cov[3 + q] + R[3 * r + 2] * cov[6 + q];
+    }
+  }
+  for (int r = 0; r < 3; ++r) {
+    for (int q = 0; q < 3; ++q) {
+      cov_out[3 * r + q] = tmp[3 * r] * Rt[q] + tmp[3 * r + 1] * Rt[3 + q] + tmp[3 * r + 2] * Rt[6 + q];
+    }
+  }
+  return KH_OK;
+}
+
+// CeresSolver::Compute, ceres_solver.cpp:214-269
+int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  kh_spa_summary sum;
+  std::memset(&sum, 0, sizeof(sum));
+  sum.usable = 1;
+  auto finish = [&](int rc) {if (summary) {*summary = sum;} return rc;};
+  if (s->nodes.empty()) {
+    set_error("CeresSolver: Ceres was called when there are no nodes. This shouldn't happen.");
+    return finish(KH_ERR_NOT_FOUND);
+  }
+  KS_HIP(hipSetDevice(s->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  SpaDev dev;
+  std::memset(&dev, 0, sizeof(dev));
+  bool has_work = false;
+  int rc = prepare_problem(s, dev, has_work);
+  if (rc) {return finish(rc);}
+  auto store_corrections = [&]() {
+    s->corr_ids.clear(); s->corr_poses.clear();
+    for (const Node & n : s->nodes) {
+      s->corr_ids.push_back(n.id);
+      s->corr_poses.insert(s->corr_poses.end(), n.pose, n.pose + 3);
+    }
+  };
+  if (!has_work) {          // nothing to optimise: Ceres returns the input, which is "usable"
+    store_corrections();
+    return finish(KH_OK);
+  }
+  const kh_spa_options & opt = s->opt;
+  const Symbolic & sym = s->sym;
+  hipStream_t st = s->stream;
+  double * x = s->d_x.p; double * cand = s->d_cand.p;
+  double * scal = s->d_scal.p;
+  const int n_levels = static_cast<int>(sym.levels.size());
+  sum.nnz_factor = sym.nnz_factor;
+
+  auto fetch = [&]() -> int {
+    KS_HIP(hipMemcpyAsync(s->h_scal, scal, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+    KS_HIP(hipMemcpyAsync(s->h_fail, s->d_fail.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KS_HIP(hipStreamSynchronize(st));
+    return KH_OK;
+  };
+  double lin_ms = 0.0, solve_ms = 0.0;
+  auto now = []() {return std::chrono::steady_clock::now();};
+  auto ms_since = [](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
+
+  // ---- iteration zero ----
+  auto t0 = now();
+  spa_launch_linearize(dev, x, scal + 0, st);
+  if (opt.jacobi_scaling) {
+    spa_launch_jacobi_scale(dev, s->d_scale.p, st);
+  } else {
+    std::vector<double> ones(static_cast<size_t>(dev.n_free) * 3, 1.0);
+    KS_HIP(hipMemcpyAsync(s->d_scale.p, ones.data(), ones.size() * 8, hipMemcpyHostToDevice, st));
+    KS_HIP(hipStreamSynchronize(st));
+  }
+  spa_launch_grad_norms(dev, x, scal + 1, st);
+  KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
+  rc = fetch(); if (rc) {return finish(rc);}
+  lin_ms += ms_since(t0);
+  double x_cost = s->h_scal[0], gmax = s->h_scal[1], x_norm = std::sqrt(s->h_scal[2]);
+  sum.initial_cost = x_cost;
+  double minimum_cost = x_cost;
+  std::vector<double> best_x(static_cast<size_t>(dev.n_nodes) * 3);
+  for (int32_t i = 0; i < dev.n_nodes; ++i) {std::copy(s->nodes[i].pose, s->nodes[i].pose + 3, best_x.begin() + 3 * i);}
+  bool best_is_current = true;     // device x holds the minimum-cost iterate
+  // TrustRegionStepEvaluator
+  const int max_nonmono = opt.use_nonmonotonic_steps ? opt.max_consecutive_nonmonotonic_steps : 0;
+  double ev_min = x_cost, ev_cur = x_cost, ev_ref = x_cost, ev_cand = x_cost, ev_acc_ref = 0.0, ev_acc_cand = 0.0;
+  int ev_nonmono = 0;
+  // LevenbergMarquardtStrategy
+  double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false, have_diagonal = false;
+  int num_invalid = 0, iteration = 0;
+  bool step_successful = true;
+  sum.successful_steps = 1;
+  sum.termination = 1;
+  if (!(x_cost == x_cost) || std::isinf(x_cost)) {   // initial evaluation failed
+    sum.usable = 0; sum.termination = 2;
+    set_error("CeresSolver: Ceres could not find a usable solution to optimize.");
+    return finish(KH_ERR_SOLVER);
+  }
+
+  while (true) {
+    if (iteration >= opt.max_num_iterations) {sum.termination = 1; break;}
+    if (step_successful && gmax <= opt.gradient_tolerance) {sum.termination = 0; break;}
+    if (radius < opt.min_trust_region_radius) {sum.termination = 0; break;}
+    ++iteration;
+    step_successful = false;
+
+    // ---- ComputeTrustRegionStep ----
+    auto t1 = now();
+    if (!reuse_diagonal || !have_diagonal) {
+      spa_launch_diag(dev, s->d_scale.p, s->d_diag.p, opt.min_lm_diagonal, opt.max_lm_diagonal, st);
+      have_diagonal = true;
+    }
+    spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
+    KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
+    for (int l = 0; l < n_levels; ++l) {
+      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->d_fail.p, st);
+    }
+    spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, st);
+    for (int l = 0; l < n_levels; ++l) {
+      spa_launch_forward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->d_rhs.p, st);
+    }
+    for (int l = n_levels - 1; l >= 0; --l) {
+      spa_launch_backward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->d_rhs.p, st);
+    }
+    spa_launch_finish_step(dev, s->d_scale.p, s->d_rhs.p, s->d_step.p, s->d_delta.p, st);
+    spa_launch_model(dev, s->d_scale.p, s->d_step.p, scal + 3, st);
+    spa_launch_plus(dev, x, s->d_delta.p, cand, scal + 6, st);
+    spa_launch_cost(dev, cand, scal + 8, st);
+    KS_HIP(hipGetLastError());
+    rc = fetch(); if (rc) {return finish(rc);}
+    solve_ms += ms_since(t1);
+    reuse_diagonal = true;
+    const double step_dot_g = s->h_scal[3], step_H_step = s->h_scal[4], nonfinite = s->h_scal[5];
+    const double step_norm = std::sqrt(s->h_scal[6]);
+    const double cand_norm = std::sqrt(s->h_scal[7]);
+    double cand_cost = s->h_scal[8];
+    const double model_cost_change = -(step_dot_g + 0.5 * step_H_step);
+    bool step_valid = s->h_fail[0] == 0 && nonfinite == 0.0 && std::isfinite(model_cost_change) && model_cost_change > 0.0;
+    if (!step_valid) {
+      ++num_invalid;
+      if (num_invalid >= opt.max_num_consecutive_invalid_steps) {sum.termination = 2; sum.usable = 0; break;}
+      radius = radius / decrease_factor;      // StepIsInvalid -> StepRejected(0)
+      decrease_factor *= 2.0;
+      continue;
+    }
+    num_invalid = 0;
+    if (!std::isfinite(cand_cost)) {cand_cost = std::numeric_limits<double>::max();}
+
+    if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {sum.termination = 0; break;}
+    const double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= opt.function_tolerance * x_cost) {sum.termination = 0; break;}
+
+    double quality;
+    if (cand_cost >= std::numeric_limits<double>::max()) {
+      quality = std::numeric_limits<double>::lowest();
+    } else {
+      const double rel = (ev_cur - cand_cost) / model_cost_change;
+      const double hist = (ev_ref - cand_cost) / (ev_acc_ref + model_cost_change);
+      quality = std::max(rel, hist);
+    }
+    if (quality > opt.min_relative_decrease) {
+      // HandleSuccessfulStep
+      if (best_is_current) {   // keep a copy of the best iterate before x moves on
+        KS_HIP(hipMemcpyAsync(best_x.data(), x, best_x.size() * 8, hipMemcpyDeviceToHost, st));
+        KS_HIP(hipStreamSynchronize(st));
+        best_is_current = false;
+      }
+      std::swap(x, cand);
+      x_norm = cand_norm;
+      auto t2 = now();
+      spa_launch_linearize(dev, x, scal + 0, st);
+      spa_launch_grad_norms(dev, x, scal + 1, st);
+      rc = fetch(); if (rc) {return finish(rc);}
+      lin_ms += ms_since(t2);
+      x_cost = s->h_scal[0]; gmax = s->h_scal[1];
+      step_successful = true;
+      ++sum.successful_steps;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * quality - 1.0, 3));
+      radius = std::min(opt.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+      // TrustRegionStepEvaluator::StepAccepted
+      ev_cur = cand_cost;
+      ev_acc_cand += model_cost_change;
+      ev_acc_ref += model_cost_change;
+      if (ev_cur < ev_min) {
+        ev_min = ev_cur; ev_nonmono = 0; ev_cand = ev_cur; ev_acc_cand = 0.0;
+      } else {
+        ++ev_nonmono;
+        if (ev_cur > ev_cand) {ev_cand = ev_cur; ev_acc_cand = 0.0;}
+      }
+      if (ev_nonmono == max_nonmono) {ev_ref = ev_cand; ev_acc_ref = ev_acc_cand;}
+      if (x_cost < minimum_cost) {minimum_cost = x_cost; best_is_current = true;}
+    } else {
+      radius = radius / decrease_factor;      // StepRejected
+      decrease_factor *= 2.0;
+      reuse_diagonal = true;
+    }
+  }
+
+  sum.iterations = iteration;
+  sum.final_cost = minimum_cost;
+  sum.linearize_ms = lin_ms; sum.solve_ms = solve_ms;
+  if (!sum.usable) {
+    sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    set_error("CeresSolver: Ceres could not find a usable solution to optimize.");
+    return finish(KH_ERR_SOLVER);          // ceres_solver.cpp:249-254: state and corrections unchanged
+  }
+  if (best_is_current) {
+    KS_HIP(hipMemcpyAsync(best_x.data(), x, best_x.size() * 8, hipMemcpyDeviceToHost, st));
+    KS_HIP(hipStreamSynchronize(st));
+  }
+  for (int32_t i = 0; i < dev.n_nodes; ++i) {std::copy(best_x.begin() + 3 * i, best_x.begin() + 3 * i + 3, s->nodes[i].pose);}
+  store_corrections();
+  sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return finish(KH_OK);
+}
+
+}  // extern "C"

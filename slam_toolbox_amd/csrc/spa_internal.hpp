@@ -1,0 +1,73 @@
+// Internal structures shared by spa_host.cpp and spa_kernels.hip (pose-graph SPA solver, hot path B).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace kh
+{
+
+// Device view of one linear-algebra problem instance.  All pointers are device pointers.
+struct SpaDev
+{
+  // graph
+  int32_t n_nodes, n_free, n_edges;
+  const int32_t * edge_a;        // node index of the source pose
+  const int32_t * edge_b;
+  const double * edge_z;         // 3 per edge: measurement (LinkInfo::GetPoseDifference)
+  const double * edge_u;         // 9 per edge: upper sqrt-information U, row-major (ceres_solver.cpp:376)
+  const int32_t * free_of_node;  // node -> free index or -1 (gauge node / unused node)
+  const int32_t * node_of_free;  // free index -> node
+  // per-edge linearisation scratch: r(3) Ja(9) Jb(9), row-major
+  double * edge_lin;
+  double * edge_cost;
+  // BSR normal matrix over the free nodes (full symmetric pattern), 9 doubles per block, row-major blocks
+  int32_t n_slots;
+  const int32_t * slot_contrib_ptr;   // n_slots+1
+  const int32_t * slot_contrib;       // edge*4 + kind (0 = Ja^T Ja, 1 = Jb^T Jb, 2 = Ja^T Jb, 3 = Jb^T Ja)
+  const int32_t * bsr_row_ptr;        // n_free+1
+  const int32_t * bsr_col;            // n_slots
+  const int32_t * bsr_diag_slot;      // n_free
+  double * H;                         // n_slots*9
+  // gradient gather: per free node the incident edges (edge*2 + role)
+  const int32_t * node_contrib_ptr;   // n_free+1
+  const int32_t * node_contrib;
+  double * g;                         // 3*n_free
+  // multifrontal structure
+  int32_t n_fronts;
+  const int64_t * front_off;          // offset (doubles) of front k in `fronts`
+  const int32_t * front_m;            // scalar dimension of the front
+  const int32_t * front_ns;           // scalar number of pivot columns
+  const int32_t * front_first;        // first elimination position (node units) of the supernode
+  const int32_t * front_rows_ptr;     // n_fronts+1 : struct rows (node units, elimination positions)
+  const int32_t * front_rows;
+  const int32_t * child_ptr;          // n_fronts+1
+  const int32_t * child_list;
+  const int32_t * relpos_ptr;         // per front: positions (node units) of its struct rows inside the parent front
+  const int32_t * relpos;
+  const int64_t * slot_dest;          // per BSR slot: offset of block (0,0) inside `fronts`, or -1 (upper part)
+  const int32_t * slot_ld;            // leading dimension (front m) at that destination
+  const int32_t * elim_of_free;       // free index -> elimination position
+  const int32_t * free_of_elim;
+  double * fronts;
+  int64_t fronts_size;
+};
+
+void spa_launch_linearize(const SpaDev & d, const double * x, double * cost_out, void * stream);
+void spa_launch_cost(const SpaDev & d, const double * x, double * cost_out, void * stream);
+void spa_launch_diag(const SpaDev & d, const double * scale, double * diag_out, double min_diag, double max_diag, void * stream);
+void spa_launch_jacobi_scale(const SpaDev & d, double * scale_out, void * stream);
+void spa_launch_assemble(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, void * stream);
+void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t * fail_flag, void * stream);
+void spa_launch_forward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, double * rhs, void * stream);
+void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, double * rhs, void * stream);
+// rhs (elimination order) <- scale * g ; and back: step = -y (free order), delta = step * scale
+void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, void * stream);
+void spa_launch_finish_step(const SpaDev & d, const double * scale, const double * rhs, double * step, double * delta, void * stream);
+// out[0] = step.gs, out[1] = step^T Hs step, out[2] = any non-finite in step
+void spa_launch_model(const SpaDev & d, const double * scale, const double * step, double * out3, void * stream);
+// cand = Plus(x, delta); out[0] = |x - cand|^2 over free params, out[1] = |cand|^2 over free params
+void spa_launch_plus(const SpaDev & d, const double * x, const double * delta, double * cand, double * out2, void * stream);
+// projected-gradient norms: out[0] = max |x - Plus(x, -g)|, out[1] = |x_free|^2
+void spa_launch_grad_norms(const SpaDev & d, const double * x, double * out2, void * stream);
+
+}  // namespace kh

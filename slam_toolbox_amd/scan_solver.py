@@ -1,0 +1,158 @@
+"""Host-side mirror of the reference's solver plugin interface (karto::ScanSolver,
+lib/karto_sdk/include/karto_sdk/Mapper.h:954-1066, implemented by solver_plugins::CeresSolver in
+solvers/ceres_solver.cpp) over the C ABI of libkartohip.so.
+
+Method names, argument meaning and error behaviour follow the reference: failures are reported (a
+warning string is kept in `last_warning`) and the call returns leaving state unchanged, exactly like the
+RCLCPP_WARN-and-return paths of ceres_solver.cpp:219-225, 249-254, 354-361, 420-424, 442-447."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def link_info(pose1, pose2, covariance):
+    """LinkInfo::Update (Mapper.h:174-188) -> (pose difference, covariance in the frame of pose1)."""
+    diff = np.zeros(3)
+    cov = np.zeros(9)
+    capi.check(capi.lib().kh_link_info(_d(pose1), _d(pose2), _d(covariance).reshape(9), diff, cov), "kh_link_info")
+    return diff, cov.reshape(3, 3)
+
+
+class HipSpaSolver:
+    """solver_plugins::HipSpaSolver : karto::ScanSolver"""
+
+    def __init__(self, device: int = 0, options: dict = None):
+        h = C.c_void_p()
+        capi.check(capi.lib().kh_spa_create(device, C.byref(h)), "kh_spa_create")
+        self._h = h
+        self.last_warning = ""
+        self.summary = None
+        if options:
+            self.Configure(options)
+
+    # ---- karto::ScanSolver -----------------------------------------------------------------
+    def Configure(self, options: dict):
+        """CeresSolver::Configure: the option values hard-wired at ceres_solver.cpp:157-186 can be overridden
+        (e.g. the `tight` tolerances used by the parity tests)."""
+        o = capi.KhSpaOptions()
+        capi.lib().kh_spa_options_default(C.byref(o))
+        for k, v in options.items():
+            if not hasattr(o, k):
+                raise KeyError(k)
+            setattr(o, k, v)
+        capi.check(capi.lib().kh_spa_set_options(self._h, C.byref(o)), "kh_spa_set_options")
+
+    def AddNode(self, unique_id: int, corrected_pose):
+        capi.check(capi.lib().kh_spa_add_node(self._h, int(unique_id), _d(corrected_pose)), "kh_spa_add_node")
+
+    def AddConstraint(self, source_id: int, target_id: int, pose_difference, covariance):
+        rc = capi.lib().kh_spa_add_constraint(self._h, int(source_id), int(target_id), _d(pose_difference),
+                                              _d(covariance).reshape(9))
+        if rc == capi.KH_ERR_NOT_FOUND:
+            self.last_warning = "CeresSolver: Failed to add constraint, could not find nodes."
+            return
+        capi.check(rc, "kh_spa_add_constraint")
+
+    def RemoveNode(self, unique_id: int):
+        rc = capi.lib().kh_spa_remove_node(self._h, int(unique_id))
+        if rc == capi.KH_ERR_NOT_FOUND:
+            self.last_warning = f"RemoveNode: Failed to find node matching id {unique_id}"
+            return
+        capi.check(rc, "kh_spa_remove_node")
+
+    def RemoveConstraint(self, source_id: int, target_id: int):
+        rc = capi.lib().kh_spa_remove_constraint(self._h, int(source_id), int(target_id))
+        if rc == capi.KH_ERR_NOT_FOUND:
+            self.last_warning = f"RemoveConstraint: Failed to find residual block for {source_id} {target_id}"
+            return
+        capi.check(rc, "kh_spa_remove_constraint")
+
+    def Compute(self):
+        s = capi.KhSpaSummary()
+        rc = capi.lib().kh_spa_compute(self._h, C.byref(s))
+        self.summary = {k: getattr(s, k) for k, _ in capi.KhSpaSummary._fields_}
+        if rc == capi.KH_ERR_NOT_FOUND:
+            self.last_warning = "CeresSolver: Ceres was called when there are no nodes. This shouldn't happen."
+            return self.summary
+        if rc == capi.KH_ERR_SOLVER:
+            self.last_warning = "CeresSolver: Ceres could not find a usable solution to optimize."
+            return self.summary
+        capi.check(rc, "kh_spa_compute")
+        return self.summary
+
+    def GetCorrections(self):
+        """IdPoseVector: list of (unique id, pose)."""
+        n = C.c_int32()
+        capi.check(capi.lib().kh_spa_get_corrections(self._h, C.byref(n), None, None), "kh_spa_get_corrections")
+        ids = np.zeros(max(1, n.value), dtype=np.int32)
+        poses = np.zeros(max(1, n.value) * 3)
+        capi.check(capi.lib().kh_spa_get_corrections(self._h, C.byref(n), ids.ctypes.data_as(C.c_void_p),
+                                                     poses.ctypes.data_as(C.c_void_p)), "kh_spa_get_corrections")
+        return [(int(ids[i]), poses[3 * i:3 * i + 3].copy()) for i in range(n.value)]
+
+    def Clear(self):
+        capi.check(capi.lib().kh_spa_clear(self._h), "kh_spa_clear")
+
+    def Reset(self):
+        capi.check(capi.lib().kh_spa_reset(self._h), "kh_spa_reset")
+
+    def ModifyNode(self, unique_id: int, pose):
+        capi.lib().kh_spa_modify_node(self._h, int(unique_id), _d(pose))
+
+    def GetNodeOrientation(self, unique_id: int):
+        p = np.zeros(3)
+        rc = capi.lib().kh_spa_get_node(self._h, int(unique_id), p)
+        return None if rc != capi.KH_OK else float(p[2])
+
+    def getGraph(self):
+        """unordered_map<int, Eigen::Vector3d>: id -> (x, y, yaw) of every node."""
+        return {i: p for i, p in self._all_nodes()}
+
+    # ---- conveniences for tests / bench ---------------------------------------------------------
+    def _all_nodes(self):
+        out = []
+        for i in self._ids:
+            p = np.zeros(3)
+            if capi.lib().kh_spa_get_node(self._h, int(i), p) == capi.KH_OK:
+                out.append((int(i), p))
+        return out
+
+    _ids: list = []
+
+    def load(self, poses, edges, z, cov):
+        """SlamToolbox::loadSerializedPoseGraph (src/slam_toolbox_common.cpp:952-1017): Reset, AddNode for
+        every vertex, AddConstraint for every edge."""
+        self.Reset()
+        poses = _d(poses)
+        self._ids = list(range(poses.shape[0]))
+        L = capi.lib()
+        for i in range(poses.shape[0]):
+            capi.check(L.kh_spa_add_node(self._h, i, poses[i]), "kh_spa_add_node")
+        edges = np.asarray(edges)
+        z = _d(z)
+        cov = _d(cov).reshape(-1, 9)
+        for e in range(edges.shape[0]):
+            capi.check(L.kh_spa_add_constraint(self._h, int(edges[e, 0]), int(edges[e, 1]), z[e], cov[e]),
+                       "kh_spa_add_constraint")
+
+    def poses(self):
+        return np.asarray([p for _, p in self._all_nodes()])
+
+    def close(self):
+        if self._h:
+            capi.lib().kh_spa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
