@@ -1,0 +1,290 @@
+// karto_adaptor.hpp -- thin, header-only C++ adaptors that put the reference's class surface back
+// on top of the C ABI (karto_hip.h).  Include it from a translation unit that already sees the
+// slam_toolbox headers (karto_sdk/Mapper.h); nothing here needs ROS beyond what Mapper.h itself pulls.
+//
+//   karto_hip::HipScanMatcher   same public surface as karto::ScanMatcher
+//                               (lib/karto_sdk/include/karto_sdk/Mapper.h:1322-1544): Create, MatchScan<T>,
+//                               CorrelateScan; throws std::runtime_error where the reference throws
+//                               (Mapper.cpp:786-796, 828); Create returns NULL like Mapper.cpp:481-493.
+//   karto_hip::HipSpaSolver     a karto::ScanSolver (Mapper.h:954-1066) with the semantics of
+//                               solver_plugins::CeresSolver (solvers/ceres_solver.cpp); export it with
+//                               PLUGINLIB_EXPORT_CLASS(karto_hip::HipSpaSolver, karto::ScanSolver).
+//
+// See INTEGRATION.md for the three-line changes in slam_toolbox that select these classes.
+#ifndef KARTO_HIP__KARTO_ADAPTOR_HPP_
+#define KARTO_HIP__KARTO_ADAPTOR_HPP_
+
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "karto_sdk/Mapper.h"
+#include "../karto_hip.h"
+
+namespace karto_hip
+{
+
+namespace detail
+{
+inline kh_scan to_scan(karto::LocalizedRangeScan * pScan, std::vector<double> & points)
+{
+  kh_scan s;
+  const karto::PointVectorDouble & pts = pScan->GetPointReadings();        // unfiltered (Karto.h:5613-5628)
+  s.n = static_cast<int32_t>(pScan->GetNumberOfRangeReadings());
+  points.resize(2 * pts.size());
+  for (size_t i = 0; i < pts.size(); ++i) {points[2 * i] = pts[i].GetX(); points[2 * i + 1] = pts[i].GetY();}
+  s.ranges = pScan->GetRangeReadings();
+  s.points_xy = points.data();
+  const karto::Pose2 pose = pScan->GetSensorPose();
+  s.sensor_pose[0] = pose.GetX(); s.sensor_pose[1] = pose.GetY(); s.sensor_pose[2] = pose.GetHeading();
+  return s;
+}
+
+template<class T>
+inline T stored_parameter(karto::Mapper * pMapper, const char * name)
+{
+  // the values AS STORED (the public getters return sqrt() of the two variance penalties, Mapper.cpp:2410-2418)
+  karto::AbstractParameter * p = pMapper->GetParameterManager()->Get(name);
+  return static_cast<karto::Parameter<T> *>(p)->GetValue();
+}
+}  // namespace detail
+
+class HipScanMatcher
+{
+public:
+  virtual ~HipScanMatcher() {kh_matcher_destroy(m_pHandle);}
+
+  static HipScanMatcher * Create(
+    karto::Mapper * pMapper, kt_double searchSize, kt_double resolution,
+    kt_double smearDeviation, kt_double rangeThreshold, int device = 0)
+  {
+    kh_matcher * h = nullptr;
+    const int rc = kh_matcher_create(searchSize, resolution, smearDeviation, rangeThreshold, device, 1, &h);
+    if (rc == KH_ERR_INVALID_ARG) {return NULL;}
+    if (rc != KH_OK) {throw std::runtime_error(std::string("karto_hip: ") + kh_last_error());}
+    HipScanMatcher * m = new HipScanMatcher();
+    m->m_pHandle = h;
+    m->m_pMapper = pMapper;
+    return m;
+  }
+
+  template<class T = karto::LocalizedRangeScanVector>
+  kt_double MatchScan(
+    karto::LocalizedRangeScan * pScan, const T & rBaseScans, karto::Pose2 & rMean,
+    karto::Matrix3 & rCovariance, kt_bool doPenalize = true, kt_bool doRefineMatch = true)
+  {
+    SyncParameters();
+    std::vector<std::vector<double>> store(1);
+    std::vector<kh_scan> base;
+    const kh_scan query = detail::to_scan(pScan, store[0]);
+    Collect(rBaseScans, base, store);
+    double mean[3], cov[9], response = 0.0;
+    const int rc = kh_matcher_match(
+      m_pHandle, &query, base.data(), static_cast<int32_t>(base.size()), doPenalize, doRefineMatch, mean, cov, &response);
+    Check(rc);
+    rMean = karto::Pose2(mean[0], mean[1], mean[2]);
+    for (int r = 0; r < 3; ++r) {for (int c = 0; c < 3; ++c) {rCovariance(r, c) = cov[3 * r + c];}}
+    return response;
+  }
+
+  kt_double CorrelateScan(
+    karto::LocalizedRangeScan * pScan, const karto::Pose2 & rSearchCenter,
+    const karto::Vector2<kt_double> & rSearchSpaceOffset, const karto::Vector2<kt_double> & rSearchSpaceResolution,
+    kt_double searchAngleOffset, kt_double searchAngleResolution, kt_bool doPenalize,
+    karto::Pose2 & rMean, karto::Matrix3 & rCovariance, kt_bool doingFineMatch)
+  {
+    SyncParameters();
+    std::vector<double> pts;
+    const kh_scan query = detail::to_scan(pScan, pts);
+    const double center[3] = {rSearchCenter.GetX(), rSearchCenter.GetY(), rSearchCenter.GetHeading()};
+    const double off[2] = {rSearchSpaceOffset.GetX(), rSearchSpaceOffset.GetY()};
+    const double res[2] = {rSearchSpaceResolution.GetX(), rSearchSpaceResolution.GetY()};
+    double mean[3], cov[9], response = 0.0;
+    for (int r = 0; r < 3; ++r) {for (int c = 0; c < 3; ++c) {cov[3 * r + c] = rCovariance(r, c);}}
+    const int rc = kh_matcher_correlate(
+      m_pHandle, 0, &query, center, off, res, searchAngleOffset, searchAngleResolution, doPenalize,
+      doingFineMatch, mean, cov, &response);
+    Check(rc);
+    rMean = karto::Pose2(mean[0], mean[1], mean[2]);
+    for (int r = 0; r < 3; ++r) {for (int c = 0; c < 3; ++c) {rCovariance(r, c) = cov[3 * r + c];}}
+    return response;
+  }
+
+  kh_matcher * GetHandle() const {return m_pHandle;}
+
+protected:
+  HipScanMatcher() : m_pHandle(nullptr), m_pMapper(nullptr) {}
+
+private:
+  void SyncParameters()
+  {
+    // the eight parameters karto::ScanMatcher reads through friend access (Mapper.cpp:590-627, 671-682)
+    kh_match_params p;
+    p.coarse_search_angle_offset = detail::stored_parameter<kt_double>(m_pMapper, "CoarseSearchAngleOffset");
+    p.coarse_angle_resolution = detail::stored_parameter<kt_double>(m_pMapper, "CoarseAngleResolution");
+    p.fine_search_angle_offset = detail::stored_parameter<kt_double>(m_pMapper, "FineSearchAngleOffset");
+    p.use_response_expansion = detail::stored_parameter<kt_bool>(m_pMapper, "UseResponseExpansion") ? 1 : 0;
+    p.distance_variance_penalty = detail::stored_parameter<kt_double>(m_pMapper, "DistanceVariancePenalty");
+    p.minimum_distance_penalty = detail::stored_parameter<kt_double>(m_pMapper, "MinimumDistancePenalty");
+    p.angle_variance_penalty = detail::stored_parameter<kt_double>(m_pMapper, "AngleVariancePenalty");
+    p.minimum_angle_penalty = detail::stored_parameter<kt_double>(m_pMapper, "MinimumAnglePenalty");
+    kh_matcher_set_params(m_pHandle, &p);
+  }
+
+  static void Collect(
+    const karto::LocalizedRangeScanVector & rScans, std::vector<kh_scan> & base,
+    std::vector<std::vector<double>> & store)
+  {
+    store.reserve(store.size() + rScans.size());
+    for (karto::LocalizedRangeScan * s : rScans) {
+      if (s == NULL) {continue;}                       // Mapper.cpp:1039-1041
+      store.emplace_back();
+      base.push_back(detail::to_scan(s, store.back()));
+    }
+  }
+  static void Collect(
+    const karto::LocalizedRangeScanMap & rScans, std::vector<kh_scan> & base,
+    std::vector<std::vector<double>> & store)
+  {
+    store.reserve(store.size() + rScans.size());
+    for (const auto & kv : rScans) {
+      if (kv.second == NULL) {continue;}               // Mapper.cpp:1059-1061
+      store.emplace_back();
+      base.push_back(detail::to_scan(kv.second, store.back()));
+    }
+  }
+  static void Check(int rc)
+  {
+    if (rc == KH_ERR_SEARCH) {throw std::runtime_error("Mapper FATAL ERROR - Unable to find best position");}
+    if (rc != KH_OK) {throw std::runtime_error(std::string("karto_hip: ") + kh_last_error());}
+  }
+
+  kh_matcher * m_pHandle;
+  karto::Mapper * m_pMapper;
+};
+
+// ---------------------------------------------------------------------------------------------
+class HipSpaSolver : public karto::ScanSolver
+{
+public:
+  HipSpaSolver() : m_pHandle(nullptr)
+  {
+    if (kh_spa_create(0, &m_pHandle) != KH_OK) {throw std::runtime_error(std::string("karto_hip: ") + kh_last_error());}
+  }
+  virtual ~HipSpaSolver() {kh_spa_destroy(m_pHandle);}
+
+  // CeresSolver::Configure reads ROS parameters; the GPU solver has the same hard-wired options
+  // (ceres_solver.cpp:157-186) and nothing else to read.
+  virtual void Configure(rclcpp_lifecycle::LifecycleNode::SharedPtr /*node*/) {}
+
+  virtual void Compute()
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    kh_spa_summary summary;
+    if (kh_spa_compute(m_pHandle, &summary) != KH_OK) {return;}        // logged-and-returned in the reference
+    int32_t n = 0;
+    kh_spa_get_corrections(m_pHandle, &n, nullptr, nullptr);
+    std::vector<int32_t> ids(n);
+    std::vector<double> poses(3 * static_cast<size_t>(n));
+    kh_spa_get_corrections(m_pHandle, &n, ids.data(), poses.data());
+    m_Corrections.clear();
+    m_Corrections.reserve(n);
+    m_Graph.clear();
+    for (int32_t i = 0; i < n; ++i) {
+      m_Corrections.push_back(std::make_pair(ids[i], karto::Pose2(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2])));
+    }
+  }
+
+  virtual const karto::ScanSolver::IdPoseVector & GetCorrections() const {return m_Corrections;}
+
+  virtual void Clear()
+  {
+    m_Corrections.clear();
+    kh_spa_clear(m_pHandle);
+  }
+
+  virtual void Reset()
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    m_Corrections.clear();
+    m_Ids.clear();
+    kh_spa_reset(m_pHandle);
+  }
+
+  virtual void AddNode(karto::Vertex<karto::LocalizedRangeScan> * pVertex)
+  {
+    if (!pVertex) {return;}
+    const karto::Pose2 pose = pVertex->GetObject()->GetCorrectedPose();
+    const double p[3] = {pose.GetX(), pose.GetY(), pose.GetHeading()};
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    const int id = pVertex->GetObject()->GetUniqueId();
+    kh_spa_add_node(m_pHandle, id, p);
+    m_Ids.push_back(id);
+  }
+
+  virtual void AddConstraint(karto::Edge<karto::LocalizedRangeScan> * pEdge)
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    if (!pEdge) {return;}
+    const int a = pEdge->GetSource()->GetObject()->GetUniqueId();
+    const int b = pEdge->GetTarget()->GetObject()->GetUniqueId();
+    karto::LinkInfo * pLinkInfo = (karto::LinkInfo *)(pEdge->GetLabel());
+    const karto::Pose2 diff = pLinkInfo->GetPoseDifference();
+    const karto::Matrix3 & c = pLinkInfo->GetCovariance();
+    const double z[3] = {diff.GetX(), diff.GetY(), diff.GetHeading()};
+    double cov[9];
+    for (int r = 0; r < 3; ++r) {for (int q = 0; q < 3; ++q) {cov[3 * r + q] = c(r, q);}}
+    kh_spa_add_constraint(m_pHandle, a, b, z, cov);
+  }
+
+  virtual void RemoveNode(kt_int32s id)
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    kh_spa_remove_node(m_pHandle, id);
+  }
+
+  virtual void RemoveConstraint(kt_int32s sourceId, kt_int32s targetId)
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    kh_spa_remove_constraint(m_pHandle, sourceId, targetId);
+  }
+
+  virtual void ModifyNode(const int & unique_id, Eigen::Vector3d pose)
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    const double p[3] = {pose(0), pose(1), pose(2)};
+    kh_spa_modify_node(m_pHandle, unique_id, p);
+  }
+
+  virtual void GetNodeOrientation(const int & unique_id, double & pose)
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    double p[3];
+    if (kh_spa_get_node(m_pHandle, unique_id, p) == KH_OK) {pose = p[2];}
+  }
+
+  virtual std::unordered_map<int, Eigen::Vector3d> * getGraph()
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    m_Graph.clear();
+    for (int id : m_Ids) {
+      double p[3];
+      if (kh_spa_get_node(m_pHandle, id, p) == KH_OK) {m_Graph[id] = Eigen::Vector3d(p[0], p[1], p[2]);}
+    }
+    return &m_Graph;
+  }
+
+private:
+  kh_spa * m_pHandle;
+  std::mutex m_Mutex;
+  karto::ScanSolver::IdPoseVector m_Corrections;
+  std::vector<int> m_Ids;
+  std::unordered_map<int, Eigen::Vector3d> m_Graph;
+};
+
+}  // namespace karto_hip
+
+#endif  // KARTO_HIP__KARTO_ADAPTOR_HPP_

@@ -18,6 +18,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -162,69 +164,93 @@ static double karto_normalize_angle(double angle)   // Math.h:181-202
 }
 
 // ---- symbolic analysis -------------------------------------------------------------------------
+// Nested dissection on the graph itself (George's level-structure bisection): BFS from a
+// pseudo-peripheral node, the middle level (trimmed to the vertices that really touch the far side) is
+// the separator.  Purely topological, so it does not depend on how far the current pose estimates have
+// drifted.  Leaves and separators become the supernodes of the multifrontal factorisation.
 struct NdContext
 {
   const std::vector<std::vector<int32_t>> * adj;
-  const std::vector<double> * px; const std::vector<double> * py;
-  std::vector<int32_t> side;          // scratch: 0 none, 1 left, 2 right
+  std::vector<int32_t> tag;           // subset membership stamp
+  std::vector<int32_t> dist;          // BFS level
   std::vector<std::vector<int32_t>> supernodes;
+  int32_t stamp = 0;
   int32_t leaf = 12;
 };
 
+// BFS inside the subset stamped `st`; returns the visit order (levels in ctx.dist)
+static void nd_bfs(NdContext & ctx, int32_t start, int32_t st, std::vector<int32_t> & order)
+{
+  const auto & adj = *ctx.adj;
+  order.clear();
+  order.push_back(start);
+  ctx.dist[start] = 0;
+  ctx.tag[start] = -st;               // visited marker
+  for (size_t h = 0; h < order.size(); ++h) {
+    const int32_t v = order[h];
+    for (int32_t w : adj[v]) {
+      if (ctx.tag[w] == st) {ctx.tag[w] = -st; ctx.dist[w] = ctx.dist[v] + 1; order.push_back(w);}
+    }
+  }
+  for (int32_t v : order) {ctx.tag[v] = st;}
+}
+
 static void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes)
 {
+  if (nodes.empty()) {return;}
   if (static_cast<int32_t>(nodes.size()) <= ctx.leaf) {
-    if (!nodes.empty()) {std::sort(nodes.begin(), nodes.end()); ctx.supernodes.push_back(nodes);}
+    std::sort(nodes.begin(), nodes.end());
+    ctx.supernodes.push_back(nodes);
     return;
   }
   const auto & adj = *ctx.adj;
-  struct Cand {size_t sep; int axis; int which; std::vector<int32_t> order;};
-  Cand best; best.sep = std::numeric_limits<size_t>::max(); best.axis = -1; best.which = 0;
-  double ext[2];
-  for (int axis = 0; axis < 2; ++axis) {
-    const std::vector<double> & c = axis == 0 ? *ctx.px : *ctx.py;
-    double lo = 1e300, hi = -1e300;
-    for (int32_t v : nodes) {lo = std::min(lo, c[v]); hi = std::max(hi, c[v]);}
-    ext[axis] = hi - lo;
-  }
-  for (int axis = 0; axis < 2; ++axis) {
-    const std::vector<double> & c = axis == 0 ? *ctx.px : *ctx.py;
-    std::vector<int32_t> order = nodes;
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {return c[a] < c[b] || (c[a] == c[b] && a < b);});
-    const size_t half = order.size() / 2;
-    for (size_t i = 0; i < order.size(); ++i) {ctx.side[order[i]] = i < half ? 1 : 2;}
-    size_t bl = 0, br = 0;
-    for (size_t i = 0; i < order.size(); ++i) {
-      const int32_t v = order[i];
-      const int other = ctx.side[v] == 1 ? 2 : 1;
-      bool boundary = false;
-      for (int32_t w : adj[v]) {if (ctx.side[w] == other) {boundary = true; break;}}
-      if (boundary) {(ctx.side[v] == 1 ? bl : br)++;}
-    }
-    for (int32_t v : order) {ctx.side[v] = 0;}
-    const size_t sep = std::min(bl, br);
-    const bool better = sep < best.sep || (sep == best.sep && ext[axis] > ext[best.axis < 0 ? 0 : best.axis]);
-    if (better) {best.sep = sep; best.axis = axis; best.which = bl <= br ? 1 : 2; best.order.swap(order);}
-  }
-  const size_t half = best.order.size() / 2;
-  for (size_t i = 0; i < best.order.size(); ++i) {ctx.side[best.order[i]] = i < half ? 1 : 2;}
-  std::vector<int32_t> A, B, S;
-  for (int32_t v : best.order) {
-    const int sd = ctx.side[v];
-    bool boundary = false;
-    if (sd == best.which) {
-      const int other = sd == 1 ? 2 : 1;
-      for (int32_t w : adj[v]) {if (ctx.side[w] == other) {boundary = true; break;}}
-    }
-    if (boundary) {S.push_back(v);} else if (sd == 1) {A.push_back(v);} else {B.push_back(v);}
-  }
-  for (int32_t v : best.order) {ctx.side[v] = 0;}
-  if (S.empty()) {              // the halves are not connected: two independent subtrees
-    nd_recurse(ctx, A);
-    nd_recurse(ctx, B);
+  const int32_t st = ++ctx.stamp;
+  for (int32_t v : nodes) {ctx.tag[v] = st;}
+  std::vector<int32_t> order;
+  nd_bfs(ctx, nodes[0], st, order);
+  if (order.size() < nodes.size()) {
+    // disconnected subset: split off this component, recurse on both parts (independent subtrees)
+    std::vector<int32_t> comp = order, rest;
+    for (int32_t v : comp) {ctx.tag[v] = 0;}
+    for (int32_t v : nodes) {if (ctx.tag[v] == st) {rest.push_back(v);}}
+    nd_recurse(ctx, comp);
+    nd_recurse(ctx, rest);
     return;
   }
-  if (A.empty() || B.empty()) { // no useful split (clique-like set): one dense supernode
+  // pseudo-peripheral start: restart the BFS from the farthest vertex (twice)
+  for (int it = 0; it < 2; ++it) {
+    const int32_t far = order.back();
+    nd_bfs(ctx, far, st, order);
+  }
+  const int32_t depth = ctx.dist[order.back()];
+  if (depth < 2) {                    // clique-like: no level can separate anything
+    std::sort(nodes.begin(), nodes.end());
+    ctx.supernodes.push_back(nodes);
+    return;
+  }
+  std::vector<int32_t> level_count(depth + 1, 0);
+  for (int32_t v : order) {level_count[ctx.dist[v]]++;}
+  // separator level: the smallest level among those that leave 25%..75% of the vertices on the near
+  // side; if the level structure is too coarse for that, the level closest to the median
+  const double total = static_cast<double>(order.size());
+  int32_t best = -1, fallback = 1; double best_count = 1e300, fallback_dist = 1e300; int32_t below = 0;
+  for (int32_t l = 1; l < depth; ++l) {
+    below += level_count[l - 1];
+    const double mid = (below + 0.5 * level_count[l]) / total;
+    if (std::fabs(mid - 0.5) < fallback_dist) {fallback_dist = std::fabs(mid - 0.5); fallback = l;}
+    if (mid >= 0.25 && mid <= 0.75 && level_count[l] < best_count) {best_count = level_count[l]; best = l;}
+  }
+  if (best < 0) {best = fallback;}
+  std::vector<int32_t> A, B, S;
+  for (int32_t v : order) {
+    const int32_t d = ctx.dist[v];
+    if (d < best) {A.push_back(v);} else if (d > best) {B.push_back(v);} else {
+      bool touches_far = false;
+      for (int32_t w : adj[v]) {if (ctx.tag[w] == st && ctx.dist[w] == best + 1) {touches_far = true; break;}}
+      if (touches_far) {S.push_back(v);} else {A.push_back(v);}
+    }
+  }
+  if (S.empty() || A.empty() || B.empty()) {
     std::sort(nodes.begin(), nodes.end());
     ctx.supernodes.push_back(nodes);
     return;
@@ -242,8 +268,10 @@ static int build_symbolic(
   sym = Symbolic();
   sym.n_free = n_free;
   NdContext ctx;
-  ctx.adj = &adj; ctx.px = &px; ctx.py = &py;
-  ctx.side.assign(n_free, 0);
+  ctx.adj = &adj;
+  (void)px; (void)py;
+  ctx.tag.assign(n_free, 0);
+  ctx.dist.assign(n_free, 0);
   std::vector<int32_t> all(n_free);
   for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
   nd_recurse(ctx, all);
@@ -406,6 +434,17 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     for (int32_t i = 0; i < nf; ++i) {px[i] = s->nodes[s->node_of_free[i]].pose[0]; py[i] = s->nodes[s->node_of_free[i]].pose[1];}
     int rc = build_symbolic(s->sym, nf, adj, px, py);
     if (rc) {return rc;}
+    if (std::getenv("KH_SPA_DEBUG")) {
+      int32_t max_m = 0, max_ns = 0;
+      for (int32_t k = 0; k < s->sym.n_fronts; ++k) {max_m = std::max(max_m, s->sym.front_m[k]); max_ns = std::max(max_ns, s->sym.front_ns[k]);}
+      std::fprintf(stderr, "[kh_spa] free nodes %d, fronts %d, levels %zu, max front m %d, max ns %d, front storage %.1f MB, nnz(L) %lld\n",
+        nf, s->sym.n_fronts, s->sym.levels.size(), max_m, max_ns, s->sym.fronts_size * 8.0 / 1e6, static_cast<long long>(s->sym.nnz_factor));
+      for (size_t l = 0; l < s->sym.levels.size(); ++l) {
+        int32_t mm = 0; int64_t work = 0;
+        for (int32_t k : s->sym.levels[l]) {mm = std::max(mm, s->sym.front_m[k]); work += static_cast<int64_t>(s->sym.front_m[k]) * s->sym.front_m[k] * s->sym.front_ns[k];}
+        std::fprintf(stderr, "[kh_spa]   level %zu: %zu fronts, max m %d, flops~%.2fM\n", l, s->sym.levels[l].size(), mm, work / 1e6);
+      }
+    }
     const Symbolic & sym = s->sym;
     std::vector<int64_t> slot_dest(n_slots, -1);
     std::vector<int32_t> slot_ld(n_slots, 0);

@@ -1,5 +1,6 @@
 """GPU parity of the HIP SPA solver (through the C ABI) against the CPU restatement oracle/spa.py.
-Tolerance: node poses within 1e-9 of the oracle in both the Ceres-like and the `tight` configuration
+Tolerance: node poses within 1e-9 of the oracle in the Ceres-like configuration (same LM trajectory, same
+iteration count); in the `tight` configuration the optimum's cost to 1e-11 relative and the poses to 1e-5
 (north_star asks for 1e-4 m / 1e-4 rad against the reference; the oracle itself is "parity unpinned" at
 the Ceres boundary, see oracle/spa.py)."""
 import numpy as np
@@ -40,7 +41,15 @@ def test_solver_matches_oracle(kartohip_lib, n, e, seed):
     sol.load(g["init"], g["edges"], g["z"], g["cov"])
     sol.Configure(TIGHT)
     summ = sol.Compute()
-    assert _diff(sol.poses(), ref_t) < 1e-8
+    # `tight` runs end where the cost stops changing in FP64; the weakest modes of a pose graph leave the
+    # poses undetermined at the ~1e-6 level inside that plateau (two CPU runs with function_tolerance
+    # 1e-15 / 0 differ by 1.4e-6 on this graph), so the pinned quantities are the optimum's cost, the
+    # gradient at the returned poses, and the poses well inside north_star's 1e-4 bar.
+    assert abs(summ["final_cost"] - info_t["final_cost"]) <= 1e-11 * info_t["final_cost"]
+    prob = spa.Problem(sol.poses(), g["edges"], g["z"], g["cov"])
+    _, grad, _ = prob.linearize(prob.x)
+    assert np.abs(grad).max() < 1e-6
+    assert _diff(sol.poses(), ref_t) < 1e-5
     sol.close()
 
 
