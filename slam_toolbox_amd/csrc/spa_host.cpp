@@ -111,7 +111,8 @@ struct kh_spa
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
   int32_t n_slots = 0;
-  std::vector<int32_t> level_offsets;
+  std::vector<int32_t> level_offsets, level_max_m;
+  DevBuf<double> d_upd;
 };
 
 namespace kh
@@ -336,7 +337,7 @@ static int build_symbolic(
       static_cast<int64_t>(sym.front_ns[k]) * (sym.front_m[k] - sym.front_ns[k]);
     for (int32_t c : children[k]) {sym.level[k] = std::max(sym.level[k], sym.level[c] + 1);}
     max_level = std::max(max_level, sym.level[k]);
-    if (sym.front_ns[k] > 3072) {set_error("supernode too large for the triangular-solve kernel"); return KH_ERR_SOLVER;}
+    if (sym.front_m[k] > 8000) {set_error("front too large for the triangular-solve kernels (m > 8000)"); return KH_ERR_SOLVER;}
   }
   sym.fronts_size = off;
   sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);
@@ -469,9 +470,13 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     // level lists, concatenated
     std::vector<int32_t> level_fronts;
     s->level_offsets.assign(1, 0);
+    s->level_max_m.clear();
     for (auto & lv : sym.levels) {
       level_fronts.insert(level_fronts.end(), lv.begin(), lv.end());
       s->level_offsets.push_back(static_cast<int32_t>(level_fronts.size()));
+      int32_t mm = 0;
+      for (int32_t k : lv) {mm = std::max(mm, sym.front_m[k]);}
+      s->level_max_m.push_back(mm);
     }
     // uploads
     hipStream_t st = s->stream;
@@ -500,6 +505,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_scale.ensure(3 * nf); r2 |= s->d_diag.ensure(3 * nf); r2 |= s->d_rhs.ensure(3 * nf);
     r2 |= s->d_step.ensure(3 * nf); r2 |= s->d_delta.ensure(3 * nf);
     r2 |= s->d_fail.ensure(4);
+    r2 |= s->d_upd.ensure(static_cast<size_t>(3) * sym.rows_ptr[sym.n_fronts] + 16);
     if (r2) {return KH_ERR_HIP;}
     s->topology_dirty = false;
   }
@@ -587,7 +593,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_fail.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_H.release(); s->d_g.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
-  s->d_step.release(); s->d_delta.release(); s->d_scal.release();
+  s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release();
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
   if (s->h_fail) {(void)hipHostFree(s->h_fail);}
   if (s->stream) {(void)hipStreamDestroy(s->stream);}
@@ -852,17 +858,28 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       spa_launch_diag(dev, s->d_scale.p, s->d_diag.p, opt.min_lm_diagonal, opt.max_lm_diagonal, st);
       have_diagonal = true;
     }
+    static const bool dbg_sync = std::getenv("KH_SPA_SYNC") != nullptr;
+    auto dbg = [&](const char * what, int l) {
+      if (dbg_sync) {
+        hipError_t e = hipStreamSynchronize(st);
+        std::fprintf(stderr, "[kh_spa] %s level %d (max m %d): %s\n", what, l, l >= 0 ? s->level_max_m[l] : 0, hipGetErrorString(e));
+      }
+    };
     spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
     KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
+    dbg("assemble", -1);
     for (int l = 0; l < n_levels; ++l) {
-      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->d_fail.p, st);
+      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_fail.p, st);
+      dbg("factor", l);
     }
     spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, st);
     for (int l = 0; l < n_levels; ++l) {
-      spa_launch_forward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->d_rhs.p, st);
+      spa_launch_forward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_rhs.p, s->d_upd.p, st);
+      dbg("forward", l);
     }
     for (int l = n_levels - 1; l >= 0; --l) {
-      spa_launch_backward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->d_rhs.p, st);
+      spa_launch_backward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_rhs.p, st);
+      dbg("backward", l);
     }
     spa_launch_finish_step(dev, s->d_scale.p, s->d_rhs.p, s->d_step.p, s->d_delta.p, st);
     spa_launch_model(dev, s->d_scale.p, s->d_step.p, scal + 3, st);

@@ -14,6 +14,8 @@
 // CPU restatement, not bit equality).
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include "spa_internal.hpp"
 
 #pragma clang fp contract(fast)
@@ -298,175 +300,393 @@ void spa_launch_grad_norms(const SpaDev & d, const double * x, double * out2, vo
 
 // ---------------------------------------------------------------------------------------------
 // K6b: multifrontal partial Cholesky, one workgroup per front.
+//
+// Blocked right-looking factorisation of the front's first ns columns, panel width NB = 16:
+//   (a) 16x16 diagonal block: one wave, lane = row, registers + shuffles
+//   (b) panel solve X = A21 L11^-T: one thread per row; X goes back to the front (it is L21) and into
+//       an LDS panel (row stride 17 doubles: conflict-free for the MFMA operand reads)
+//   (c) trailing update of the lower triangle, C -= X X^T, in 16x16 tiles on the FP64 matrix cores:
+//       4 x v_mfma_f64_16x16x4_f64 per tile with both operands read from the LDS panel.  The MFMA "col"
+//       index (lane & 15) is mapped to the front's ROW so that every accumulator load/store of a
+//       column-major front is four contiguous 128-byte segments.
+// Dynamic LDS: panel of roundup16(m) rows (sized by the host for the largest front of the level).
 constexpr int NB = 16;
+constexpr int XS = NB + 1;
+typedef double v4d __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_factor(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// 16x16 diagonal block of a panel: lane l owns row l in registers, columns are broadcast with v_readlane.
+// Writes L back to the front, and L plus the reciprocal diagonal (column NB) to the LDS copy `ld`.
+// Rows/columns >= nb are padded with the identity.  Returns true when a pivot is not positive.
+__device__ __noinline__ bool factor_diag_block(double * F, int m, int jb, int nb, int lane, double * ld)
+{
+  double row[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    row[c] = (lane < nb && c < nb && c <= lane) ? F[(jb + lane) + (int64_t)(jb + c) * m] : ((c == lane) ? 1.0 : 0.0);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double djj = readlane_f64(row[j], j);
+    if (!(djj > 0.0)) {bad = true; djj = 1.0;}
+    const double sq = sqrt(djj);
+    const double inv = 1.0 / sq;
+    if (lane == j) {row[j] = sq;} else if (lane > j) {row[j] *= inv;}
+#pragma unroll
+    for (int c = j + 1; c < NB; ++c) {
+      const double lcj = readlane_f64(row[j], c);       // L[c][j]
+      if (lane >= c) {row[c] -= row[j] * lcj;}
+    }
+  }
+  if (lane < NB) {
+    double dg = 1.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      ld[lane * (NB + 1) + c] = row[c];
+      if (c == lane) {dg = row[c];}
+      if (lane < nb && c <= lane) {F[(jb + lane) + (int64_t)(jb + c) * m] = row[c];}
+    }
+    ld[lane * (NB + 1) + NB] = 1.0 / dg;
+  }
+  return bad && lane < nb;
+}
+
+// Panel solve of one row: x = a L11^-T for the nb (<= 16) columns of the panel; a = gcol[c * m].  x goes
+// back to the front and into the row's LDS panel slot (zero padded to 16).  nb = 0: padding row, only
+// the zero fill.  `ld` = 16 x 17 LDS copy of L11 with the reciprocal diagonal in column 16.
+__device__ __noinline__ void panel_row_solve(double * gcol, int m, int nb, const double * ld, double * xrow)
+{
+  double xr[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {xr[c] = (c < nb) ? gcol[(int64_t)c * m] : 0.0;}
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    // The address of row c of L11 is made to depend (through an opaque zero) on x[c-2]: without it the
+    // scheduler issues all 152 LDS reads of the unrolled solve up front (304 VGPRs -> spills); with it
+    // at most two rows are in flight, one ahead of the data dependency x[c] <- x[c-1] that serialises
+    // the columns anyway.
+    int zero = 0;
+    if (c >= 2) {asm volatile("v_mov_b32 %0, 0" : "=v"(zero) : "v"(__double2loint(xr[c - 2])));}
+    const double * lrow = ld + c * (NB + 1) + zero;
+    double v = xr[c];
+#pragma unroll
+    for (int q = 0; q < c; ++q) {v -= xr[q] * lrow[q];}
+    xr[c] = v * lrow[NB];
+  }
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    if (c < nb) {gcol[(int64_t)c * m] = xr[c];}
+    xrow[c] = xr[c];
+  }
+}
+
+constexpr int kMaxLdsRows = 1104;          // 1104 * 17 * 8 B = 150 KB of the CU's 160 KB LDS
+
+// C -= X X^T over the lower triangle of the trailing matrix, 16x16 tiles, one tile per wave at a time.
+// kLds: operands come from the LDS panel; otherwise from the panel columns just written to the front.
+template <bool kLds>
+__device__ __forceinline__ void trailing_update(double * F, const double * Xs, int m, int r0, int jb, int nb,
+                                                int nrows, int nrows_pad, int lane, int wave, int nwaves)
+{
+  const int nt = nrows_pad >> 4;
+  const int ntiles = nt * (nt + 1) / 2;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int t = wave; t < ntiles; t += nwaves) {
+    int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (I * (I + 1) / 2 > t) {--I;}
+    while ((I + 1) * (I + 2) / 2 <= t) {++I;}
+    const int J = t - I * (I + 1) / 2;
+    const int frow = 16 * I + lr;                 // row of the trailing matrix held by this lane
+    const int fcol0 = 16 * J + lk;                // its column for accumulator register 0 (+4 per register)
+    v4d acc;
+    double * cp = F + (r0 + frow) + (int64_t)(r0 + fcol0) * m;
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fc = fcol0 + 4 * r;
+      ok[r] = frow < nrows && fc < nrows && fc <= frow;
+      acc[r] = ok[r] ? cp[(int64_t)(4 * r) * m] : 0.0;
+    }
+    if (kLds) {
+      const double * xa = Xs + (16 * J + lr) * XS + lk;
+      const double * xb = Xs + (16 * I + lr) * XS + lk;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * kk], xb[4 * kk], acc, 0, 0, 0);
+      }
+    } else {
+      const int ra = 16 * J + lr, rb = 16 * I + lr;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kc = 4 * kk + lk;
+        const double a = (ra < nrows && kc < nb) ? F[(r0 + ra) + (int64_t)(jb + kc) * m] : 0.0;
+        const double b = (rb < nrows && kc < nb) ? F[(r0 + rb) + (int64_t)(jb + kc) * m] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (ok[r]) {cp[(int64_t)(4 * r) * m] = acc[r];}
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag, int dbg, long long * tbuf)
+{
+  int tcount = 0;
+#define TSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[1 + tcount++] = wall_clock64();} } while (0)
+  TSTAMP();
   const int k = level_fronts[blockIdx.x];
   const int m = d.front_m[k], ns = d.front_ns[k];
   double * F = d.fronts + d.front_off[k];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  extern __shared__ double smem[];
+  double * Xs = smem;                       // [rows below the panel, padded to 16][XS]
+  const bool use_lds = m <= kMaxLdsRows;    // larger fronts read the panel back from the front itself (L2)
+  __shared__ double Ld[NB][NB + 1];
+  __shared__ int s_fail;
 
-  // 1. extend-add the children's update matrices (lower triangles)
+  // 1. extend-add the children's update matrices (lower triangles).  Children are taken one after the
+  //    other (two children may add into the same entry); within a child every wave takes columns
+  //    four at a time with all loads issued before the first add, so the pass is bound by bandwidth and
+  //    not by a chain of dependent L2 round trips.  The scalar row positions inside this front
+  //    (3 * relpos + component) are staged in LDS once per child.
+  int * pos = reinterpret_cast<int *>(smem);
   for (int ci = d.child_ptr[k]; ci < d.child_ptr[k + 1]; ++ci) {
     const int c = d.child_list[ci];
     const int mc = d.front_m[c], nsc = d.front_ns[c], nuc = mc - nsc;
     const double * Uc = d.fronts + d.front_off[c] + nsc + (int64_t)nsc * mc;
     const int32_t * rp = d.relpos + d.relpos_ptr[c];
-    for (int idx = tid; idx < nuc * nuc; idx += 256) {
-      const int a = idx % nuc, b = idx / nuc;
-      if (a < b) {continue;}
-      const int pa = 3 * rp[a / 3] + a % 3, pb = 3 * rp[b / 3] + b % 3;
-      F[pa + (int64_t)pb * m] += Uc[a + (int64_t)b * mc];
+    for (int a = tid; a < nuc; a += nthreads) {pos[a] = 3 * rp[a / 3] + a % 3;}
+    __syncthreads();
+    constexpr int CB = 4;
+    for (int b0 = wave * CB; b0 < nuc; b0 += nwaves * CB) {
+      for (int a0 = b0; a0 < nuc; a0 += 64) {
+        const int a = a0 + lane;
+        double u[CB], f[CB];
+        double * dst[CB];
+        bool on[CB];
+        const int pa = a < nuc ? pos[a] : 0;
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+          const int b = b0 + q;
+          on[q] = a < nuc && b < nuc && a >= b;
+          dst[q] = F + pa + (int64_t)(on[q] ? pos[b] : 0) * m;
+          u[q] = on[q] ? Uc[a + (int64_t)b * mc] : 0.0;
+          f[q] = on[q] ? *dst[q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {if (on[q]) {*dst[q] = f[q] + u[q];}}
+      }
     }
     __syncthreads();
   }
 
+  TSTAMP();
   // 2. blocked right-looking partial Cholesky of the first ns columns
-  __shared__ double Ld[NB][NB + 1];
-  __shared__ int s_fail;
   if (tid == 0) {s_fail = 0;}
   __syncthreads();
   for (int jb = 0; jb < ns; jb += NB) {
     const int nb = min(NB, ns - jb);
-    // (a) diagonal block: wave 0, lane l owns row l of the nb x nb block in registers
-    if (tid < 64) {
-      double row[NB];
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        row[c] = (tid < nb && c < nb && c <= tid) ? F[(jb + tid) + (int64_t)(jb + c) * m] : ((c == tid) ? 1.0 : 0.0);
-      }
-      bool bad = false;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        double djj = __shfl(row[j], j);
-        if (!(djj > 0.0)) {bad = true; djj = 1.0;}
-        const double inv = 1.0 / sqrt(djj);
-        if (tid == j) {row[j] = sqrt(djj);} else if (tid > j) {row[j] *= inv;}
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-          const double lcj = __shfl(row[j], c);       // L[c][j]
-          if (tid >= c) {row[c] -= row[j] * lcj;}
-        }
-      }
-      if (tid < NB) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {Ld[tid][c] = row[c];}
-        if (tid < nb) {
-          for (int c = 0; c <= tid; ++c) {F[(jb + tid) + (int64_t)(jb + c) * m] = row[c];}
-        }
-      }
-      if (bad && tid < nb) {s_fail = 1;}
+    // (a) diagonal block: wave 0 (kept out of line: inlined, its unrolled register tile inflates the whole
+    //     kernel's allocation past the spill threshold)
+    if (wave == 0) {
+      if (factor_diag_block(F, m, jb, nb, lane, &Ld[0][0])) {s_fail = 1;}
     }
     __syncthreads();
+    TSTAMP();
     // (b) panel: X = F[rows, jb:jb+nb] * Ld^{-T}, rows below the diagonal block
     const int r0 = jb + nb;
-    for (int i = r0 + tid; i < m; i += 256) {
-      double xr[NB];
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {xr[c] = (c < nb) ? F[i + (int64_t)(jb + c) * m] : 0.0;}
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        if (c < nb) {
-          double v = xr[c];
-#pragma unroll
-          for (int q = 0; q < c; ++q) {v -= xr[q] * Ld[c][q];}
-          xr[c] = v / Ld[c][c];
+    const int nrows = m - r0;
+    const int nrows_pad = (nrows + 15) & ~15;
+    if (dbg & 1) {break;}
+    // One thread per row (out of line, see panel_row_solve); fronts too large for the LDS panel solve
+    // in place in the front instead.
+#pragma unroll 1
+    for (int i = tid; i < nrows_pad; i += nthreads) {
+      double * gcol = F + (r0 + i) + (int64_t)jb * m;       // F[r0 + i][jb + c] = gcol[c * m]
+      if (use_lds) {
+        panel_row_solve(gcol, m, i < nrows ? nb : 0, &Ld[0][0], Xs + i * XS);
+      } else if (i < nrows) {
+#pragma unroll 1
+        for (int c = 0; c < nb; ++c) {
+          const double * lrow = &Ld[c][0];
+          double v = gcol[(int64_t)c * m];
+#pragma unroll 4
+          for (int q = 0; q < c; ++q) {v -= gcol[(int64_t)q * m] * lrow[q];}
+          v *= lrow[NB];
+          gcol[(int64_t)c * m] = v;
         }
       }
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {if (c < nb) {F[i + (int64_t)(jb + c) * m] = xr[c];}}
     }
     __syncthreads();
-    // (c) trailing update (lower triangle): F[i][j] -= X[i,:] . X[j,:]   for r0 <= j <= i < m
-    for (int i = r0 + tid; i < m; i += 256) {
-      double xi[NB];
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {xi[c] = (c < nb) ? F[i + (int64_t)(jb + c) * m] : 0.0;}
-      for (int j = r0; j <= i; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {acc += xi[c] * ((c < nb) ? F[j + (int64_t)(jb + c) * m] : 0.0);}
-        F[i + (int64_t)j * m] -= acc;
-      }
+    TSTAMP();
+    // (c) trailing update of the lower triangle on the matrix cores
+    if (dbg & 2) {continue;}
+    if (dbg & 4) {
+      trailing_update<false>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
+    } else if (use_lds) {
+      trailing_update<true>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
+    } else {
+      trailing_update<false>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
     }
     __syncthreads();
+    TSTAMP();
   }
+  if (tbuf && blockIdx.x == 0 && threadIdx.x == 0) {tbuf[0] = tcount; tbuf[63] = ((long long)m << 32) | ns;}
   if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
 }
 
-void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t * fail_flag, void * stream)
+void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag, void * stream)
 {
   if (n <= 0) {return;}
-  hipLaunchKernelGGL(k_factor, dim3(n), dim3(256), 0, (hipStream_t)stream, d, level_fronts, fail_flag);
+  const int threads = max_m <= 96 ? 256 : (max_m <= 256 ? 512 : 1024);
+  const int lds_rows = ((max_m < kMaxLdsRows ? max_m : kMaxLdsRows) + 15) & ~15;
+  const size_t lds = sizeof(double) * (size_t)lds_rows * XS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double) * (size_t)kMaxLdsRows * XS));
+    attr_set = true;
+  }
+  static const int dbg = std::getenv("KH_SPA_FLAGS") ? std::atoi(std::getenv("KH_SPA_FLAGS")) : 0;
+  static long long * tbuf = nullptr;
+  static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
+  if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 64 * sizeof(long long), hipHostMallocDefault);}
+  hipLaunchKernelGGL(k_factor, dim3(n), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, dbg, timing ? tbuf : nullptr);
+  if (timing) {
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    std::fprintf(stderr, "[k_factor] n=%d max_m=%d front0 m=%lld ns=%lld stamps(x10ns):", n, max_m, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
+    for (int i = 1; i < (int)tbuf[0]; ++i) {std::fprintf(stderr, " %lld", tbuf[1 + i] - tbuf[i]);}
+    std::fprintf(stderr, "\n");
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6c: triangular solves, one 64-lane workgroup per front.  rhs is in elimination order.
-constexpr int kMaxNs = 3072;    // pivot columns of the largest supported front (host checks)
+// K6c: triangular solves, one workgroup (256 threads) per front, blocked by 16 like the factorisation.
+// rhs is in elimination order.  Forward: a front gathers its children's contributions (upd, one
+// segment per front = its struct rows) instead of scattering with atomics, so the solve is
+// bit-reproducible.  Dynamic LDS: m doubles.
+__device__ __forceinline__ void load_diag_block(const double * F, int m, int jb, int nb, int lane, double (&col)[NB])
+{
+  // lane c holds column c of the 16x16 diagonal block: col[j] = L[jb+j][jb+c] (j >= c)
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    col[j] = (lane < nb && j < nb && j >= lane) ? F[(jb + j) + (int64_t)(jb + lane) * m] : ((j == lane) ? 1.0 : 0.0);
+  }
+}
 
-__global__ __launch_bounds__(64) void k_forward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs)
+__global__ __launch_bounds__(256) void k_forward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs, double * upd)
 {
   const int k = level_fronts[blockIdx.x];
   const int m = d.front_m[k], ns = d.front_ns[k], nu = m - ns;
   const double * F = d.fronts + d.front_off[k];
   const int first = 3 * d.front_first[k];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ double sb[];
-  for (int t = tid; t < ns; t += 64) {sb[t] = rhs[first + t];}
+  for (int t = tid; t < m; t += 256) {sb[t] = t < ns ? rhs[first + t] : 0.0;}
   __syncthreads();
-  for (int j = 0; j < ns; ++j) {
-    const double yj = sb[j] / F[j + (int64_t)j * m];
-    __syncthreads();
-    if (tid == 0) {sb[j] = yj;}
-    for (int i = j + 1 + tid; i < ns; i += 64) {sb[i] -= F[i + (int64_t)j * m] * yj;}
+  for (int ci = d.child_ptr[k]; ci < d.child_ptr[k + 1]; ++ci) {
+    const int c = d.child_list[ci];
+    const int nuc = d.front_m[c] - d.front_ns[c];
+    const int32_t * rp = d.relpos + d.relpos_ptr[c];
+    const double * uc = upd + 3 * (int64_t)d.front_rows_ptr[c];
+    for (int q = tid; q < nuc; q += 256) {sb[3 * rp[q / 3] + q % 3] += uc[q];}
     __syncthreads();
   }
-  for (int t = tid; t < ns; t += 64) {rhs[first + t] = sb[t];}
-  const int32_t * rows = d.front_rows + d.front_rows_ptr[k];
-  for (int q = tid; q < nu; q += 64) {
-    double acc = 0.0;
-    for (int t = 0; t < ns; ++t) {acc += F[(ns + q) + (int64_t)t * m] * sb[t];}
-    atomicAdd(&rhs[3 * rows[q / 3] + q % 3], -acc);
+  for (int jb = 0; jb < ns; jb += NB) {
+    const int nb = min(NB, ns - jb);
+    if (wave == 0) {
+      // lane r holds row r of the diagonal block: rowv[j] = L[jb+r][jb+j]
+      double rowv[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        rowv[j] = (lane < nb && j < nb && j <= lane) ? F[(jb + lane) + (int64_t)(jb + j) * m] : ((j == lane) ? 1.0 : 0.0);
+      }
+      double v = lane < nb ? sb[jb + lane] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double yj = readlane_f64(v, j) / readlane_f64(rowv[j], j);
+        if (lane == j) {v = yj;} else if (lane > j) {v -= rowv[j] * yj;}
+      }
+      if (lane < nb) {sb[jb + lane] = v;}
+    }
+    __syncthreads();
+    const int r0 = jb + nb;
+    for (int i = r0 + tid; i < m; i += 256) {
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {if (c < nb) {acc += F[i + (int64_t)(jb + c) * m] * sb[jb + c];}}
+      sb[i] -= acc;
+    }
+    __syncthreads();
   }
+  for (int t = tid; t < ns; t += 256) {rhs[first + t] = sb[t];}
+  double * uk = upd + 3 * (int64_t)d.front_rows_ptr[k];
+  for (int q = tid; q < nu; q += 256) {uk[q] = sb[ns + q];}
 }
 
-__global__ __launch_bounds__(64) void k_backward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs)
+__global__ __launch_bounds__(256) void k_backward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs)
 {
   const int k = level_fronts[blockIdx.x];
   const int m = d.front_m[k], ns = d.front_ns[k], nu = m - ns;
   const double * F = d.fronts + d.front_off[k];
   const int first = 3 * d.front_first[k];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ double sb[];
   const int32_t * rows = d.front_rows + d.front_rows_ptr[k];
-  // w = y - L21^T x_struct
-  for (int t = tid; t < ns; t += 64) {
-    double acc = rhs[first + t];
-    const double * col = F + ns + (int64_t)t * m;
-    for (int q = 0; q < nu; ++q) {acc -= col[q] * rhs[3 * rows[q / 3] + q % 3];}
-    sb[t] = acc;
-  }
+  for (int t = tid; t < ns; t += 256) {sb[t] = rhs[first + t];}
+  for (int q = tid; q < nu; q += 256) {sb[ns + q] = rhs[3 * rows[q / 3] + q % 3];}
   __syncthreads();
-  for (int j = ns - 1; j >= 0; --j) {
-    const double xj = sb[j] / F[j + (int64_t)j * m];
+  const int nblk = (ns + NB - 1) / NB;
+  for (int blk = nblk - 1; blk >= 0; --blk) {
+    const int jb = blk * NB;
+    const int nb = min(NB, ns - jb);
+    const int r0 = jb + nb;
+    // w[t] = y[t] - sum_{i >= r0} L[i][t] x[i] : one wave per column, lanes over the rows
+    for (int c = wave; c < nb; c += 4) {
+      const double * col = F + (int64_t)(jb + c) * m;
+      double acc = 0.0;
+      for (int i = r0 + lane; i < m; i += 64) {acc += col[i] * sb[i];}
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) {acc += __shfl_xor(acc, s);}
+      if (lane == 0) {sb[jb + c] -= acc;}
+    }
     __syncthreads();
-    if (tid == 0) {sb[j] = xj;}
-    for (int i = tid; i < j; i += 64) {sb[i] -= F[j + (int64_t)i * m] * xj;}
+    if (wave == 0) {
+      double col[NB];
+      load_diag_block(F, m, jb, nb, lane, col);
+      double v = lane < nb ? sb[jb + lane] : 0.0;
+#pragma unroll
+      for (int j = NB - 1; j >= 0; --j) {
+        const double xj = readlane_f64(v, j) / readlane_f64(col[j], j);   // lane j: col[j] = L[jb+j][jb+j]
+        if (lane == j) {v = xj;} else if (lane < j) {v -= col[j] * xj;}    // lane c < j: col[j] = L[jb+j][jb+c]
+      }
+      if (lane < nb) {sb[jb + lane] = v;}
+    }
     __syncthreads();
   }
-  for (int t = tid; t < ns; t += 64) {rhs[first + t] = sb[t];}
+  for (int t = tid; t < ns; t += 256) {rhs[first + t] = sb[t];}
 }
 
-void spa_launch_forward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, double * rhs, void * stream)
+void spa_launch_forward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, double * upd, void * stream)
 {
   if (n <= 0) {return;}
-  hipLaunchKernelGGL(k_forward, dim3(n), dim3(64), sizeof(double) * kMaxNs, (hipStream_t)stream, d, level_fronts, rhs);
+  hipLaunchKernelGGL(k_forward, dim3(n), dim3(256), sizeof(double) * max_m, (hipStream_t)stream, d, level_fronts, rhs, upd);
 }
-void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, double * rhs, void * stream)
+void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, void * stream)
 {
   if (n <= 0) {return;}
-  hipLaunchKernelGGL(k_backward, dim3(n), dim3(64), sizeof(double) * kMaxNs, (hipStream_t)stream, d, level_fronts, rhs);
+  hipLaunchKernelGGL(k_backward, dim3(n), dim3(256), sizeof(double) * max_m, (hipStream_t)stream, d, level_fronts, rhs);
 }
 
 }  // namespace kh

@@ -53,6 +53,46 @@ def test_solver_matches_oracle(kartohip_lib, n, e, seed):
     sol.close()
 
 
+def _clique_graph(n_clique, n_chain, seed):
+    """n_clique mutually linked poses on a circle (one dense front of 3*n_clique - 3 pivots: every panel
+    width, partial last panel, partial MFMA tiles) followed by an odometry chain."""
+    import math
+    rng = np.random.default_rng(seed)
+    n = n_clique + n_chain
+    truth = np.zeros((n, 3))
+    for i in range(n_clique):
+        a = 2 * math.pi * i / n_clique
+        truth[i] = [3 * math.cos(a), 3 * math.sin(a), a + 1.0]
+    for i in range(n_clique, n):
+        truth[i] = truth[i - 1] + [0.4 * math.cos(0.1 * i), 0.4 * math.sin(0.1 * i), 0.05]
+    pairs = [(i, j) for i in range(n_clique) for j in range(i + 1, n_clique)]
+    pairs += [(i - 1, i) for i in range(n_clique, n)]
+    z = np.zeros((len(pairs), 3))
+    for e, (a, b) in enumerate(pairs):
+        c, s_ = math.cos(truth[a, 2]), math.sin(truth[a, 2])
+        dx, dy = truth[b, 0] - truth[a, 0], truth[b, 1] - truth[a, 1]
+        z[e] = [c * dx + s_ * dy + rng.normal(0, 0.01), -s_ * dx + c * dy + rng.normal(0, 0.01),
+                (truth[b, 2] - truth[a, 2] + rng.normal(0, 0.003) + math.pi) % (2 * math.pi) - math.pi]
+    cov = np.tile(np.diag([1e-3, 2e-3, 4e-4]).reshape(9), (len(pairs), 1))
+    init = truth + rng.normal(0, 0.05, truth.shape)
+    init[0] = truth[0]
+    return dict(init=init, edges=np.asarray(pairs, dtype=np.int32), z=z, cov=cov)
+
+
+@pytest.mark.parametrize("n_clique,n_chain", [(6, 0), (23, 5), (70, 40), (150, 3)])
+def test_dense_fronts(kartohip_lib, n_clique, n_chain):
+    from oracle import spa
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    g = _clique_graph(n_clique, n_chain, seed=n_clique)
+    ref_x, info = spa.solve(g["init"], g["edges"], g["z"], g["cov"])
+    sol = HipSpaSolver()
+    sol.load(g["init"], g["edges"], g["z"], g["cov"])
+    summ = sol.Compute()
+    assert summ["usable"] == 1 and summ["iterations"] == info["iterations"], (summ, info["iterations"])
+    assert _diff(sol.poses(), ref_x) < 1e-9
+    sol.close()
+
+
 def test_noise_free_graph_returns_ground_truth(kartohip_lib):
     from slam_toolbox_amd.scan_solver import HipSpaSolver, link_info
     g = synth.make_pose_graph(400, 900, seed=3)
