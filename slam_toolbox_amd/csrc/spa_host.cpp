@@ -362,6 +362,10 @@ static int build_symbolic(
   }
   sym.levels.assign(max_level + 1, {});
   for (int32_t k = 0; k < K; ++k) {sym.levels[sym.level[k]].push_back(k);}
+  // largest fronts first: they are the critical path of their level, so they should be dispatched first
+  for (auto & lv : sym.levels) {
+    std::stable_sort(lv.begin(), lv.end(), [&](int32_t a, int32_t b) {return sym.front_m[a] > sym.front_m[b];});
+  }
   return KH_OK;
 }
 
@@ -371,6 +375,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   const int32_t N = static_cast<int32_t>(s->nodes.size());
   const int32_t E = static_cast<int32_t>(s->cons.size());
   has_work = false;
+  const auto t_prep0 = std::chrono::steady_clock::now();
   // gauge: first inserted node is constant once it has parameter blocks (ceres_solver.cpp:228-241)
   std::vector<uint8_t> used(N, 0);
   std::vector<int32_t> ea(E), eb(E);
@@ -433,8 +438,14 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     // ordering + fronts
     std::vector<double> px(nf), py(nf);
     for (int32_t i = 0; i < nf; ++i) {px[i] = s->nodes[s->node_of_free[i]].pose[0]; py[i] = s->nodes[s->node_of_free[i]].pose[1];}
+    const auto t_sym0 = std::chrono::steady_clock::now();
     int rc = build_symbolic(s->sym, nf, adj, px, py);
     if (rc) {return rc;}
+    if (std::getenv("KH_SPA_DEBUG")) {
+      std::fprintf(stderr, "[kh_spa] host: pattern %.2f ms, symbolic %.2f ms\n",
+        std::chrono::duration<double, std::milli>(t_sym0 - t_prep0).count(),
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sym0).count());
+    }
     if (std::getenv("KH_SPA_DEBUG")) {
       int32_t max_m = 0, max_ns = 0;
       for (int32_t k = 0; k < s->sym.n_fronts; ++k) {max_m = std::max(max_m, s->sym.front_m[k]); max_ns = std::max(max_ns, s->sym.front_ns[k]);}
@@ -523,6 +534,10 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   r3 |= s->d_x.upload(x, s->stream); r3 |= s->d_cand.ensure(x.size()); r3 |= s->d_scal.ensure(32);
   if (r3) {return KH_ERR_HIP;}
   KS_HIP(hipStreamSynchronize(s->stream));   // the staging vectors above go out of scope
+  if (std::getenv("KH_SPA_DEBUG")) {
+    std::fprintf(stderr, "[kh_spa] host: prepare_problem total %.2f ms\n",
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count());
+  }
 
   const Symbolic & sym = s->sym;
   dev.n_nodes = N; dev.n_free = nf; dev.n_edges = E;

@@ -322,9 +322,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// 16x16 diagonal block of a panel: lane l owns row l in registers, columns are broadcast with v_readlane.
-// Writes L back to the front, and L plus the reciprocal diagonal (column NB) to the LDS copy `ld`.
-// Rows/columns >= nb are padded with the identity.  Returns true when a pivot is not positive.
+// 16x16 diagonal block of a panel: lane l owns row l in registers, pivot columns are broadcast with
+// v_readlane.  The pivot chain is the serial part of the whole factorisation, so it is kept short:
+// 1/sqrt(d) from v_rsq_f64 + two Newton steps (no f64 sqrt / divide expansions), no lane masks (the
+// upper-triangle garbage a lane computes is never read by another lane).  Writes L back to the front
+// and L plus the reciprocal diagonal (column NB) to the LDS copy `ld`.  Rows/columns >= nb are padded
+// with the identity.  Returns true when a pivot is not positive.
 __device__ __noinline__ bool factor_diag_block(double * F, int m, int jb, int nb, int lane, double * ld)
 {
   double row[NB];
@@ -333,28 +336,30 @@ __device__ __noinline__ bool factor_diag_block(double * F, int m, int jb, int nb
     row[c] = (lane < nb && c < nb && c <= lane) ? F[(jb + lane) + (int64_t)(jb + c) * m] : ((c == lane) ? 1.0 : 0.0);
   }
   bool bad = false;
+  double rdiag = 1.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     double djj = readlane_f64(row[j], j);
     if (!(djj > 0.0)) {bad = true; djj = 1.0;}
-    const double sq = sqrt(djj);
-    const double inv = 1.0 / sq;
-    if (lane == j) {row[j] = sq;} else if (lane > j) {row[j] *= inv;}
+    double r = __builtin_amdgcn_rsq(djj);
+    const double h = 0.5 * djj;
+    r = r * (1.5 - h * r * r);
+    r = r * (1.5 - h * r * r);
+    row[j] = (lane == j) ? djj * r : row[j] * r;
+    if (lane == j) {rdiag = r;}
 #pragma unroll
     for (int c = j + 1; c < NB; ++c) {
       const double lcj = readlane_f64(row[j], c);       // L[c][j]
-      if (lane >= c) {row[c] -= row[j] * lcj;}
+      row[c] -= row[j] * lcj;
     }
   }
   if (lane < NB) {
-    double dg = 1.0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      ld[lane * (NB + 1) + c] = row[c];
-      if (c == lane) {dg = row[c];}
+      ld[lane * (NB + 1) + c] = (c <= lane) ? row[c] : 0.0;
       if (lane < nb && c <= lane) {F[(jb + lane) + (int64_t)(jb + c) * m] = row[c];}
     }
-    ld[lane * (NB + 1) + NB] = 1.0 / dg;
+    ld[lane * (NB + 1) + NB] = rdiag;
   }
   return bad && lane < nb;
 }
@@ -396,51 +401,67 @@ template <bool kLds>
 __device__ __forceinline__ void trailing_update(double * F, const double * Xs, int m, int r0, int jb, int nb,
                                                 int nrows, int nrows_pad, int lane, int wave, int nwaves)
 {
+  constexpr int TU = 4;       // tiles in flight per wave: their accumulator loads are issued together
   const int nt = nrows_pad >> 4;
   const int ntiles = nt * (nt + 1) / 2;
   const int lr = lane & 15, lk = lane >> 4;
-  for (int t = wave; t < ntiles; t += nwaves) {
-    int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while (I * (I + 1) / 2 > t) {--I;}
-    while ((I + 1) * (I + 2) / 2 <= t) {++I;}
-    const int J = t - I * (I + 1) / 2;
-    const int frow = 16 * I + lr;                 // row of the trailing matrix held by this lane
-    const int fcol0 = 16 * J + lk;                // its column for accumulator register 0 (+4 per register)
-    v4d acc;
-    double * cp = F + (r0 + frow) + (int64_t)(r0 + fcol0) * m;
-    bool ok[4];
+  for (int t0 = wave; t0 < ntiles; t0 += nwaves * TU) {
+    v4d acc[TU];
+    double * cp[TU];
+    int tI[TU], tJ[TU];
+    bool ok[TU][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int fc = fcol0 + 4 * r;
-      ok[r] = frow < nrows && fc < nrows && fc <= frow;
-      acc[r] = ok[r] ? cp[(int64_t)(4 * r) * m] : 0.0;
-    }
-    if (kLds) {
-      const double * xa = Xs + (16 * J + lr) * XS + lk;
-      const double * xb = Xs + (16 * I + lr) * XS + lk;
+    for (int u = 0; u < TU; ++u) {
+      const int t = t0 + u * nwaves;
+      int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (I * (I + 1) / 2 > t) {--I;}
+      while ((I + 1) * (I + 2) / 2 <= t) {++I;}
+      const int J = t - I * (I + 1) / 2;
+      tI[u] = I; tJ[u] = J;
+      const int frow = 16 * I + lr;               // row of the trailing matrix held by this lane
+      const int fcol0 = 16 * J + lk;              // its column for accumulator register 0 (+4 per register)
+      cp[u] = F + (r0 + frow) + (int64_t)(r0 + fcol0) * m;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * kk], xb[4 * kk], acc, 0, 0, 0);
-      }
-    } else {
-      const int ra = 16 * J + lr, rb = 16 * I + lr;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int kc = 4 * kk + lk;
-        const double a = (ra < nrows && kc < nb) ? F[(r0 + ra) + (int64_t)(jb + kc) * m] : 0.0;
-        const double b = (rb < nrows && kc < nb) ? F[(r0 + rb) + (int64_t)(jb + kc) * m] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        const int fc = fcol0 + 4 * r;
+        ok[u][r] = t < ntiles && frow < nrows && fc < nrows && fc <= frow;
+        acc[u][r] = ok[u][r] ? cp[u][(int64_t)(4 * r) * m] : 0.0;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (ok[r]) {cp[(int64_t)(4 * r) * m] = acc[r];}
+    for (int u = 0; u < TU; ++u) {
+      if (t0 + u * nwaves >= ntiles) {continue;}       // wave-uniform
+      if (kLds) {
+        const double * xa = Xs + (16 * tJ[u] + lr) * XS + lk;
+        const double * xb = Xs + (16 * tI[u] + lr) * XS + lk;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * kk], xb[4 * kk], acc[u], 0, 0, 0);
+        }
+      } else {
+        const int ra = 16 * tJ[u] + lr, rb = 16 * tI[u] + lr;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int kc = 4 * kk + lk;
+          const double a = (ra < nrows && kc < nb) ? F[(r0 + ra) + (int64_t)(jb + kc) * m] : 0.0;
+          const double b = (rb < nrows && kc < nb) ? F[(r0 + rb) + (int64_t)(jb + kc) * m] : 0.0;
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc[u], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (ok[u][r]) {cp[u][(int64_t)(4 * r) * m] = acc[u][r];}
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag, int dbg, long long * tbuf)
+__global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag, long long * tbuf)
 {
+  // KH_SPA_TIMING=1: stage timestamps (100 MHz wall clock) of the level's largest front, printed by the host
   int tcount = 0;
 #define TSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[1 + tcount++] = wall_clock64();} } while (0)
   TSTAMP();
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     const int32_t * rp = d.relpos + d.relpos_ptr[c];
     for (int a = tid; a < nuc; a += nthreads) {pos[a] = 3 * rp[a / 3] + a % 3;}
     __syncthreads();
-    constexpr int CB = 4;
+    constexpr int CB = 8;
     for (int b0 = wave * CB; b0 < nuc; b0 += nwaves * CB) {
       for (int a0 = b0; a0 < nuc; a0 += 64) {
         const int a = a0 + lane;
@@ -497,8 +518,7 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
   __syncthreads();
   for (int jb = 0; jb < ns; jb += NB) {
     const int nb = min(NB, ns - jb);
-    // (a) diagonal block: wave 0 (kept out of line: inlined, its unrolled register tile inflates the whole
-    //     kernel's allocation past the spill threshold)
+    // (a) diagonal block: wave 0
     if (wave == 0) {
       if (factor_diag_block(F, m, jb, nb, lane, &Ld[0][0])) {s_fail = 1;}
     }
@@ -508,7 +528,6 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     const int r0 = jb + nb;
     const int nrows = m - r0;
     const int nrows_pad = (nrows + 15) & ~15;
-    if (dbg & 1) {break;}
     // One thread per row (out of line, see panel_row_solve); fronts too large for the LDS panel solve
     // in place in the front instead.
 #pragma unroll 1
@@ -531,10 +550,7 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     __syncthreads();
     TSTAMP();
     // (c) trailing update of the lower triangle on the matrix cores
-    if (dbg & 2) {continue;}
-    if (dbg & 4) {
-      trailing_update<false>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
-    } else if (use_lds) {
+    if (use_lds) {
       trailing_update<true>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
     } else {
       trailing_update<false>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
 void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag, void * stream)
 {
   if (n <= 0) {return;}
-  const int threads = max_m <= 96 ? 256 : (max_m <= 256 ? 512 : 1024);
+  const int threads = max_m <= 96 ? 256 : (max_m <= 192 ? 512 : 1024);
   const int lds_rows = ((max_m < kMaxLdsRows ? max_m : kMaxLdsRows) + 15) & ~15;
   const size_t lds = sizeof(double) * (size_t)lds_rows * XS;
   static bool attr_set = false;
@@ -558,11 +574,10 @@ void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int
                               (int)(sizeof(double) * (size_t)kMaxLdsRows * XS));
     attr_set = true;
   }
-  static const int dbg = std::getenv("KH_SPA_FLAGS") ? std::atoi(std::getenv("KH_SPA_FLAGS")) : 0;
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
   if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 64 * sizeof(long long), hipHostMallocDefault);}
-  hipLaunchKernelGGL(k_factor, dim3(n), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, dbg, timing ? tbuf : nullptr);
+  hipLaunchKernelGGL(k_factor, dim3(n), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, timing ? tbuf : nullptr);
   if (timing) {
     (void)hipStreamSynchronize((hipStream_t)stream);
     std::fprintf(stderr, "[k_factor] n=%d max_m=%d front0 m=%lld ns=%lld stamps(x10ns):", n, max_m, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
