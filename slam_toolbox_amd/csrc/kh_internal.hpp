@@ -10,8 +10,11 @@ namespace kh
 constexpr int32_t kInvalidScan = INT32_MAX;   // Math.h:47 INVALID_SCAN
 constexpr int32_t kOccupied = 100;            // GridStates_Occupied
 constexpr int32_t kTieCap = 2048;             // tie indices returned per CorrelateScan before the host falls back
-constexpr int32_t kGridPad = 256;             // zeroed slack after the grid so tile over-reads stay in bounds
-constexpr int32_t kTileBytes = 64;            // bytes of one grid row a scoring tile covers (16 lanes x dword)
+constexpr int32_t kGridPad = 256;             // zeroed slack before and after the grid so aligned tile reads stay in bounds
+constexpr int32_t kTileBytes = 64;            // bytes of one grid row a scoring tile reads (16 lanes x aligned dword)
+constexpr int32_t kTileSpan = 61;             // bytes of it that hold poses whatever the alignment class (64 - 3)
+constexpr int32_t kClasses = 4;               // alignment classes of a beam offset: (base0 + offset) & 3
+constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per class, [4] = slow beams
 
 // One rasterisation job (ScanMatcher::AddScans, Mapper.cpp:1032-1105) -- device visible.
 struct RasterJob
@@ -53,9 +56,10 @@ struct CorrJob
   const uint8_t * invalid;   // P: range reading is NaN/inf (Karto.h:6869-6875)
   // device scratch / outputs
   int32_t * table;           // na*P full lookup table (Karto.h:6844-6894)
-  int32_t * fast;            // na*P compacted offsets valid for every pose of the lattice
+  int32_t * fast;            // na*4*P compacted offsets valid for every pose of the lattice, bucketed by
+                             // alignment class (base0 + offset) & 3: list (a, c) starts at (a*4 + c)*P
   int32_t * slow;            // na*P compacted offsets needing the per-pose range check
-  int32_t * counts;          // na*2: {n_fast, n_slow}
+  int32_t * counts;          // na*8: {n_class0..3, n_slow, -, -, -}
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
   unsigned long long * out;  // result block, see below
@@ -72,6 +76,8 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
                   int32_t sx_variant, int32_t ry, void * stream);
+// poses per tile row of the scoring kernel for a lattice step of sx cells
+inline int32_t score_tile_poses(int32_t sx) {return sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;}
 void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, void * stream);
 
 }  // namespace kh

@@ -95,7 +95,8 @@ struct CorrHost
 
 struct Slot
 {
-  uint8_t * d_grid = nullptr;
+  uint8_t * d_grid = nullptr;        // first grid byte (256-byte aligned); the allocation has kGridPad zero bytes either side
+  uint8_t * d_grid_alloc = nullptr;
   double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
   // correlate scratch
   int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
@@ -557,11 +558,11 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
       if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_fast)); KH_HIP(hipFree(s.d_slow));}
       const size_t cap = std::max(tp, s.cap_table + s.cap_table / 2);
       KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_table), cap * 4));
-      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_fast), cap * 4));
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_fast), cap * 4 * kClasses));
       KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_slow), cap * 4));
       s.cap_table = cap;
     }
-    rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * 2, m->stream); if (rc) {return rc;}
+    rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * kCountsPerAngle, m->stream); if (rc) {return rc;}
     const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
     rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
     if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
@@ -574,7 +575,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     const int this_ry = pick_ry(c.ny);
     if (sx_variant < 0) {sx_variant = this_sx; ry = this_ry;}
     if (sx_variant != this_sx || ry != this_ry) {uniform_kernel = false;}
-    const int px = kTileBytes / this_sx;
+    const int px = score_tile_poses(this_sx);
     job->tiles_x = (c.nx + px - 1) / px;
     job->tiles_y = (c.ny + 4 * this_ry - 1) / (4 * this_ry);
     job->ry = this_ry;
@@ -848,8 +849,9 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
   m->slots.resize(max_batch);
   for (auto & s : m->slots) {
-    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid), static_cast<size_t>(m->data_size) + kGridPad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
-    if ((e = hipMemset(s.d_grid, 0, static_cast<size_t>(m->data_size) + kGridPad)) != hipSuccess) {return fail(e, "hipMemset grid");}
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid_alloc), static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
+    if ((e = hipMemset(s.d_grid_alloc, 0, static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMemset grid");}
+    s.d_grid = s.d_grid_alloc + kGridPad;
   }
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&m->h_rjobs), sizeof(RasterJob) * max_batch, hipHostMallocDefault)) != hipSuccess) {return fail(e, "hipHostMalloc");}
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_rjobs), sizeof(RasterJob) * max_batch)) != hipSuccess) {return fail(e, "hipMalloc");}
@@ -863,7 +865,7 @@ void kh_matcher_destroy(kh_matcher * m)
   hipSetDevice(m->device);
   if (m->stream) {hipStreamSynchronize(m->stream);}
   for (auto & s : m->slots) {
-    hipFree(s.d_grid); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
+    hipFree(s.d_grid_alloc); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
   }
   hipFree(m->d_kernel); hipFree(m->d_stage); hipFree(m->d_rjobs); hipFree(m->d_out);

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.y * stride);
   const int a = blockIdx.x;
   if (a >= job.na) {return;}
-  __shared__ int32_t s_counts[2];
-  if (threadIdx.x < 2) {s_counts[threadIdx.x] = 0;}
+  __shared__ int32_t s_counts[kClasses + 1];
+  if (threadIdx.x < kClasses + 1) {s_counts[threadIdx.x] = 0;}
   __syncthreads();
   const int P = job.n_points;
   const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   const int64_t bmin = job.base0;
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
   int32_t * table = job.table + (size_t)a * P;
-  int32_t * fast = job.fast + (size_t)a * P;
+  int32_t * fast = job.fast + (size_t)a * kClasses * P;
   int32_t * slow = job.slow + (size_t)a * P;
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
     int32_t idx;
@@ -134,14 +134,16 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
     if (job.linear) {
       if ((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size) {continue;}  // off the grid for every pose
       if ((int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size) {
-        fast[atomicAdd(&s_counts[0], 1)] = idx;
+        // alignment class of the window start: K3 reads class-c windows with aligned dwords
+        const int cls = (int)(((int64_t)idx + bmin) & (kClasses - 1));
+        fast[(size_t)cls * P + atomicAdd(&s_counts[cls], 1)] = idx;
         continue;
       }
     }
-    slow[atomicAdd(&s_counts[1], 1)] = idx;
+    slow[atomicAdd(&s_counts[kClasses], 1)] = idx;
   }
   __syncthreads();
-  if (threadIdx.x < 2) {job.counts[2 * a + threadIdx.x] = s_counts[threadIdx.x];}
+  if (threadIdx.x < kClasses + 1) {job.counts[kCountsPerAngle * a + threadIdx.x] = s_counts[threadIdx.x];}
 }
 
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream)
@@ -169,23 +171,41 @@ __device__ __forceinline__ double pose_response(const CorrJob & job, int32_t sum
 // global-address-space views: keeps the hot loads on global_load (vmcnt only) instead of flat_load
 typedef __attribute__((address_space(1))) uint8_t gbyte;
 typedef __attribute__((address_space(1))) int32_t gint;
-typedef __attribute__((address_space(1))) uint32_t gu32_unaligned __attribute__((aligned(1)));
+typedef __attribute__((address_space(1))) uint32_t gu32;
 __device__ __forceinline__ const gbyte * as_global(const uint8_t * p) {return (const gbyte *)p;}
 __device__ __forceinline__ const gint * as_global(const int32_t * p) {return (const gint *)p;}
 
 // K3.  SX = grid cells per lattice step in x (1: fine / full-resolution search, 2: coarse search).
-// Tile = 64 grid bytes (64 poses at SX=1, 32 at SX=2) x 4*RY lattice rows.
+// Tile = 64 aligned grid bytes x 4*RY lattice rows, of which 61 bytes (61 poses at SX=1, 31 at SX=2)
+// carry poses whatever the alignment.
+//
+// Alignment classes.  A window starts at an arbitrary byte, and a wave of *unaligned* dword loads
+// costs ~18 L1 (TCP) tag lookups per instruction -- measured: that, not HBM or VALU, bound the first
+// version of this kernel.  K2 therefore buckets every angle's beams by the alignment class
+// c = (window start) & 3, and wave c of the workgroup walks class c only: all of its loads are then
+// ALIGNED dwords (4-5 tag lookups), and the byte position of pose 0 inside the first dword (s) is a
+// wave constant that is applied once, in the epilogue, when the four waves' sums are merged in LDS.
+//
+// Block -> work mapping is XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so
+// id & 7 picks the XCD and each XCD walks whole units (a job, or a contiguous angle range of a job
+// when there are fewer than 8 jobs).  All angles of a unit then share one L2, where the windows of
+// neighbouring angles overlap by ~85 %.
 template <int SX, int RY>
-__global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stride)
+__global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stride, int n_jobs, int chunks,
+                                               int na_chunk, int tiles_max)
 {
-  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.z * stride);
-  const int a = blockIdx.y;
-  if (a >= job.na) {return;}
-  const int tile = blockIdx.x;
-  if (tile >= job.tiles_x * job.tiles_y) {return;}
-  constexpr int PX = kTileBytes / SX;   // poses per tile row
+  const int per_unit = na_chunk * tiles_max;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int unit = (q / per_unit) * 8 + xcd;
+  if (unit >= n_jobs * chunks) {return;}
+  const int within = q % per_unit;
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)(unit / chunks) * stride);
+  const int a = (unit % chunks) * na_chunk + within / tiles_max;
+  const int tile = within % tiles_max;
+  if (a >= job.na || tile >= job.tiles_x * job.tiles_y) {return;}
+  constexpr int PX = (SX == 1) ? kTileSpan : (kTileSpan + 1) / 2;   // poses per tile row
   constexpr int TY = 4 * RY;            // lattice rows per tile
-  constexpr int NB = (SX == 1) ? 4 : 2; // poses per lane per row
+  constexpr int NB = (SX == 1) ? 4 : 2; // byte positions per lane per row
   const int tx = tile % job.tiles_x, ty = tile / job.tiles_x;
   const int x0 = tx * PX, y0 = ty * TY;
   const int lane = threadIdx.x & 63;
@@ -197,9 +217,7 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stri
   __syncthreads();
 
   const int P = job.n_points;
-  const int n_fast = job.counts[2 * a], n_slow = job.counts[2 * a + 1];
-  const int32_t * fast = job.fast + (size_t)a * P;
-  const int32_t * slow = job.slow + (size_t)a * P;
+  const int n_slow = job.counts[kCountsPerAngle * a + kClasses];
 
   int32_t acc[RY][NB];
 #pragma unroll
@@ -208,6 +226,10 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stri
     for (int b = 0; b < NB; ++b) {acc[r][b] = 0;}
   }
 
+  // this wave's alignment class and the byte of its first dword that belongs to pose x0
+  const int cls = wave;
+  const int s = (cls + x0 * SX) & 3;
+  const int n_fast = job.counts[kCountsPerAngle * a + cls];
   if (n_fast > 0) {
     // per-lane byte offset of row r inside the window; rows beyond ny are clamped (sums discarded)
     uint32_t voff[RY];
@@ -215,36 +237,41 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stri
     for (int r = 0; r < RY; ++r) {
       int yi = y0 + r * 4 + ly;
       yi = yi < job.ny ? yi : job.ny - 1;
-      voff[r] = (uint32_t)(x0 * SX + 4 * lx) + (uint32_t)yi * (uint32_t)job.sy_ws;
+      voff[r] = (uint32_t)(4 * lx) + (uint32_t)yi * (uint32_t)job.sy_ws;
     }
-    const gbyte * gbase = as_global(job.grid) + job.base0;
-    const gint * gfast = as_global(fast);
-    // beams [j_begin, j_end) of this wave.  Offsets are fetched 64 at a time with one coalesced
-    // load and broadcast from the register with v_readlane, so the inner loop is: 1 SALU add for
-    // the window address, RY saddr-form dword loads, 4 VALU per dword.  Packed 16-bit partial
-    // sums are flushed every 512 beams (512 * 100 < 65536).
-    const int per = (n_fast + 3) / 4;
-    const int j_begin = wave * per;
-    const int j_end = min(n_fast, j_begin + per);
+    // scalar part of the address: first grid byte of the lattice + tile origin, moved back to the
+    // dword boundary (>= -3: the allocation has kGridPad zero bytes in front)
+    const gbyte * gbase = as_global(job.grid) + ((int64_t)job.base0 + x0 * SX - s);
+    const gint * gfast = as_global(job.fast + ((size_t)a * kClasses + cls) * P);
+    // SX == 2: poses sit on every other byte, the even or the odd ones depending on s
+    const uint32_t sel = (s & 1) ? 0x0c030c01u : 0x0c020c00u;
+    // Offsets are fetched 64 at a time with one coalesced load and broadcast from the register with
+    // v_readlane, so the inner loop is: 1 SALU add for the window address, RY saddr-form aligned
+    // dword loads, 4 VALU per dword (2 at SX == 2).  Packed 16-bit partial sums are flushed every
+    // 512 beams (512 * 100 < 65536).
     uint32_t lo[RY], hi[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {lo[r] = 0; hi[r] = 0;}
     int since_flush = 0;
-    for (int jc = j_begin; jc < j_end; jc += 64) {
-      const int cnt = min(64, j_end - jc);
+    for (int jc = 0; jc < n_fast; jc += 64) {
+      const int cnt = min(64, n_fast - jc);
       const int32_t mine = (lane < cnt) ? gfast[jc + lane] : 0;
       for (int k = 0; k < cnt; ++k) {
         const int32_t off = __builtin_amdgcn_readlane(mine, k);
         const gbyte * wbase = gbase + off;
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-          const uint32_t w = *reinterpret_cast<const gu32_unaligned *>(wbase + voff[r]);
-          lo[r] += w & 0x00ff00ffu;
-          if (SX == 1) {hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);}   // [0, b3, 0, b1]
+          const uint32_t w = *reinterpret_cast<const gu32 *>(wbase + voff[r]);
+          if (SX == 1) {
+            lo[r] += w & 0x00ff00ffu;                                // [0, b2, 0, b0]
+            hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);      // [0, b3, 0, b1]
+          } else {
+            lo[r] += __builtin_amdgcn_perm(0u, w, sel);
+          }
         }
       }
       since_flush += cnt;
-      if (since_flush + 64 > 512 || jc + 64 >= j_end) {
+      if (since_flush + 64 > 512 || jc + 64 >= n_fast) {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
           if (SX == 1) {
@@ -260,32 +287,31 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stri
     }
   }
 
-  if (n_slow > 0) {
-    // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197); also the path of
-    // non-linear lattices (bx/by are exact per-pose indices)
-    for (int j = wave; j < n_slow; j += 4) {
-      const int32_t off = slow[j];
-#pragma unroll
-      for (int r = 0; r < RY; ++r) {
-        const int yi = y0 + r * 4 + ly;
-        if (yi >= job.ny) {continue;}
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int xi = x0 + NB * lx + b;
-          if (xi >= job.nx) {continue;}
-          const int64_t idx = (int64_t)job.bx[xi] + (int64_t)job.by[yi] + off;
-          if (idx >= 0 && idx < job.data_size) {acc[r][b] += job.grid[idx];}
-        }
-      }
-    }
-  }
-
-  // merge the four waves' partial sums
+  // merge the four waves' partial sums: byte position j of the aligned tile row is pose (j - s) / SX
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      if (acc[r][b] != 0) {atomicAdd(&s_tile[(r * 4 + ly) * PX + NB * lx + b], acc[r][b]);}
+      const int j = 4 * lx + ((SX == 1) ? b : 2 * b + (s & 1));
+      const int x = (j - s) / SX;
+      if (j >= s && x < PX && acc[r][b] != 0) {atomicAdd(&s_tile[(r * 4 + ly) * PX + x], acc[r][b]);}
+    }
+  }
+
+  if (n_slow > 0) {
+    // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197); also the path of
+    // non-linear lattices (bx/by are exact per-pose indices).  One pose per thread.
+    const int32_t * slow = job.slow + (size_t)a * P;
+    for (int p = threadIdx.x; p < TY * PX; p += 256) {
+      const int xi = x0 + p % PX, yi = y0 + p / PX;
+      if (xi >= job.nx || yi >= job.ny) {continue;}
+      const int64_t pose = (int64_t)job.bx[xi] + (int64_t)job.by[yi];
+      int32_t sum = 0;
+      for (int j = 0; j < n_slow; ++j) {
+        const int64_t idx = pose + slow[j];
+        if (idx >= 0 && idx < job.data_size) {sum += job.grid[idx];}
+      }
+      if (sum != 0) {atomicAdd(&s_tile[p], sum);}
     }
   }
   __syncthreads();
@@ -309,8 +335,8 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t * jobs, size_t stri
   }
   // wave max -> one atomic per wave
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) {
-    const double o = __shfl_xor(best, s);
+  for (int sft = 32; sft > 0; sft >>= 1) {
+    const double o = __shfl_xor(best, sft);
     best = o > best ? o : best;
   }
   if (lane == 0 && best > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(best));}
@@ -320,17 +346,22 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
                   int32_t sx_variant, int32_t ry, void * stream)
 {
   if (n_jobs <= 0 || max_tiles <= 0 || max_na <= 0) {return;}
-  dim3 grid(max_tiles, max_na, n_jobs);
+  // units of XCD-local work: whole jobs, or contiguous angle ranges of a job when jobs are scarce
+  int chunks = 1;
+  while (n_jobs * chunks * 2 <= 8 && chunks * 2 <= max_na) {chunks *= 2;}
+  const int na_chunk = (max_na + chunks - 1) / chunks;
+  const int units = n_jobs * chunks;
+  const int units_per_xcd = (units + 7) / 8;
+  const long long blocks = 8ll * units_per_xcd * na_chunk * max_tiles;
+  dim3 grid((unsigned int)blocks);
   hipStream_t s = (hipStream_t)stream;
+#define KH_SCORE(SXV, RYV) hipLaunchKernelGGL((k_score<SXV, RYV>), grid, dim3(256), 0, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
   if (sx_variant == 2) {
-    if (ry == 8) {hipLaunchKernelGGL((k_score<2, 8>), grid, dim3(256), 0, s, d_jobs, stride);}
-    else if (ry == 4) {hipLaunchKernelGGL((k_score<2, 4>), grid, dim3(256), 0, s, d_jobs, stride);}
-    else {hipLaunchKernelGGL((k_score<2, 1>), grid, dim3(256), 0, s, d_jobs, stride);}
+    if (ry == 8) {KH_SCORE(2, 8);} else if (ry == 4) {KH_SCORE(2, 4);} else {KH_SCORE(2, 1);}
   } else {
-    if (ry == 8) {hipLaunchKernelGGL((k_score<1, 8>), grid, dim3(256), 0, s, d_jobs, stride);}
-    else if (ry == 4) {hipLaunchKernelGGL((k_score<1, 4>), grid, dim3(256), 0, s, d_jobs, stride);}
-    else {hipLaunchKernelGGL((k_score<1, 1>), grid, dim3(256), 0, s, d_jobs, stride);}
+    if (ry == 8) {KH_SCORE(1, 8);} else if (ry == 4) {KH_SCORE(1, 4);} else {KH_SCORE(1, 1);}
   }
+#undef KH_SCORE
 }
 
 // ---------------------------------------------------------------------------------------------
