@@ -31,6 +31,21 @@ C2 = dict(nx=61, ny=61, na=81)
 # B_corr = nPoses*P*(4+1) + nPoses*32 + A*P*4 bytes per CorrelateScan
 ALG_BYTES_C2 = C2["nx"] * C2["ny"] * C2["na"] * P_BEAMS * 5 + C2["nx"] * C2["ny"] * C2["na"] * 32 + C2["na"] * P_BEAMS * 4
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r1_k_score_pmc.json")
+
+
+def pmc_traffic(batch):
+    """HBM bytes per k_score launch from the committed rocprofv3 PMC passes of this same command
+    (tools/prof_bench.sh + tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE collected in separate passes and
+    corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed run, so
+    the figure is the recorded one, scaled to this run's batch when the batch differs."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        per_match = d["hbm_bytes_per_launch"] / float(d.get("matches_per_launch", 32))
+        return per_match * batch
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(reps_target_s=12.0):
@@ -169,10 +184,12 @@ def main():
                                    "(61x61x81 poses), 8087^2 grid", "matches_per_step_per_gpu": B,
                        "parallelism": f"{world} x independent match shards (no collective)"},
             "roofline": {"bound": "hbm", "kernel": "k_score<1,8>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B),
                          "algorithmic_bytes_per_launch": ALG_BYTES_C2 * B, "avg_launch_ms": k3_ms,
-                         "note": "algorithmic bytes = the reference's own access stream (SURVEY 8d); the windows are "
-                                 "L2/Infinity-Cache resident so frac may exceed 1 -- see DESIGN.md"},
+                         "note": "achieved = algorithmic bytes (the reference's own access stream, SURVEY 8d: 5 B per "
+                                 "lookup) / measured launch time; the windows are L2-resident (96.8 % hit), so frac exceeds 1 "
+                                 "and HBM does not bind: traffic = measured HBM bytes per launch (PMC), the binding resource "
+                                 "is the L2->L1 fill rate (31 % L1 hit) -- see DESIGN.md section 4"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -9,11 +9,17 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -213,6 +219,80 @@ static int ensure_pinned(T *& p, size_t & cap, size_t need, hipStream_t stream)
   return KH_OK;
 }
 
+
+// ---- host worker pool ---------------------------------------------------------------------------
+// The exact-arithmetic host half (tables, penalties, FindValidPoints, tie averaging, covariances) is
+// O(P + nX*nY + nA) per match and independent between the matches of a batch; with the scoring kernel at
+// ~30 us per match it is what bounds a batch, so it is spread over a few host threads
+// (KH_HOST_THREADS, default min(16, cores)).  Results do not depend on the thread count.
+class HostPool
+{
+public:
+  static HostPool & instance() {static HostPool p; return p;}
+  // runs fn(i) for i in [0, n); returns when all are done
+  void run(size_t n, const std::function<void(size_t)> & fn)
+  {
+    if (n == 0) {return;}
+    if (n == 1 || workers_.empty()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
+    std::lock_guard<std::mutex> serial(run_mu_);      // one parallel region at a time (handles may be on different threads)
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; next_.store(0); pending_ = workers_.size(); ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] {return pending_ == 0;});
+    fn_ = nullptr;
+  }
+  ~HostPool()
+  {
+    {std::lock_guard<std::mutex> lk(mu_); stop_ = true;}
+    cv_.notify_all();
+    for (auto & t : workers_) {t.join();}
+  }
+private:
+  HostPool()
+  {
+    unsigned want = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char * e = std::getenv("KH_HOST_THREADS")) {want = static_cast<unsigned>(std::max(1, std::atoi(e)));}
+    for (unsigned t = 1; t < want; ++t) {workers_.emplace_back([this] {loop();});}
+  }
+  void work()
+  {
+    for (;;) {
+      const size_t i = next_.fetch_add(1);
+      if (i >= n_) {break;}
+      (*fn_)(i);
+    }
+  }
+  void loop()
+  {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] {return stop_ || generation_ != seen;});
+        if (stop_) {return;}
+        seen = generation_;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--pending_ == 0) {done_cv_.notify_all();}
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(size_t)> * fn_ = nullptr;
+  size_t n_ = 0, pending_ = 0;
+  std::atomic<size_t> next_{0};
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
 // ---- rasterisation of n jobs (slots[i] <- base scans of job i) ------------------------------
 struct RasterReq {int32_t slot; const kh_scan * query; const kh_scan * base; int32_t n_base;};
 
@@ -224,7 +304,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   std::vector<std::vector<double>> pts(reqs.size());
   std::vector<std::vector<uint8_t>> act(reqs.size());
   size_t max_points = 0;
-  for (size_t r = 0; r < reqs.size(); ++r) {
+  HostPool::instance().run(reqs.size(), [&](size_t r) {
     Slot & s = m->slots[reqs[r].slot];
     const double * pose = reqs[r].query->sensor_pose;
     // MatchScan steps 1-4, Mapper.cpp:543-569
@@ -253,8 +333,8 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
         }
       }
     }
-    max_points = std::max(max_points, np);
-  }
+  });
+  for (auto & v : pts) {max_points = std::max(max_points, v.size() / 2);}
   // 2. stage + upload
   size_t total = 0;
   for (auto & v : pts) {total += v.size() / 2;}
@@ -456,7 +536,29 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   rc = ensure_device(m->d_out, m->cap_dout, out_words * n, m->stream);
   if (rc) {return rc;}
 
+  // device scratch of every slot first (allocation is serial); the tables themselves are filled by
+  // the host pool
   for (size_t i = 0; i < n; ++i) {
+    CorrHost & c = ctx[i];
+    Slot & s = m->slots[c.slot];
+    // device scratch for this slot
+    const size_t tp = static_cast<size_t>(c.na) * c.P;
+    if (tp > s.cap_table) {
+      if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_fast)); KH_HIP(hipFree(s.d_slow));}
+      const size_t cap = std::max(tp, s.cap_table + s.cap_table / 2);
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_table), cap * 4));
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_fast), cap * 4 * kClasses));
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_slow), cap * 4));
+      s.cap_table = cap;
+    }
+    rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * kCountsPerAngle, m->stream); if (rc) {return rc;}
+    const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
+    rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
+    if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
+
+  }
+  std::vector<int32_t> job_sx(n, 1), job_ry(n, 1), job_tiles(n, 1);
+  HostPool::instance().run(n, [&](size_t i) {
     CorrReq & q = reqs[i];
     CorrHost & c = ctx[i];
     Slot & s = m->slots[c.slot];
@@ -552,34 +654,17 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
       }
     }
 
-    // device scratch for this slot
-    const size_t tp = static_cast<size_t>(c.na) * c.P;
-    if (tp > s.cap_table) {
-      if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_fast)); KH_HIP(hipFree(s.d_slow));}
-      const size_t cap = std::max(tp, s.cap_table + s.cap_table / 2);
-      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_table), cap * 4));
-      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_fast), cap * 4 * kClasses));
-      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_slow), cap * 4));
-      s.cap_table = cap;
-    }
-    rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * kCountsPerAngle, m->stream); if (rc) {return rc;}
-    const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
-    rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
-    if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
-
     std::memset(job, 0, sizeof(CorrJob));
     job->grid = s.d_grid; job->data_size = m->data_size; job->ws = m->ws;
     job->n_points = c.P; job->nx = c.nx; job->ny = c.ny; job->na = c.na;
     job->linear = linear ? 1 : 0; job->sx = sx; job->sy_ws = sy_ws; job->base0 = c.bx[0] + c.by[0];
     const int this_sx = (linear && sx == 2) ? 2 : 1;
     const int this_ry = pick_ry(c.ny);
-    if (sx_variant < 0) {sx_variant = this_sx; ry = this_ry;}
-    if (sx_variant != this_sx || ry != this_ry) {uniform_kernel = false;}
     const int px = score_tile_poses(this_sx);
     job->tiles_x = (c.nx + px - 1) / px;
     job->tiles_y = (c.ny + 4 * this_ry - 1) / (4 * this_ry);
     job->ry = this_ry;
-    max_tiles = std::max(max_tiles, job->tiles_x * job->tiles_y);
+    job_sx[i] = this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
     job->do_penalize = q.penalize ? 1 : 0; job->coarse = q.fine ? 0 : 1;
     job->write_resp = m->keep_responses ? 1 : 0;
     job->denom = c.denom;
@@ -593,6 +678,11 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     job->invalid = db + L.invalid;
     job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
     job->sums = s.d_sums; job->resp = s.d_resp; job->out = m->d_out + out_words * i;
+  });
+  for (size_t i = 0; i < n; ++i) {
+    if (sx_variant < 0) {sx_variant = job_sx[i]; ry = job_ry[i];}
+    if (sx_variant != job_sx[i] || ry != job_ry[i]) {uniform_kernel = false;}
+    max_tiles = std::max(max_tiles, job_tiles[i]);
   }
 
   // ---- 2. upload, launch, download ----
@@ -621,7 +711,9 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   }
 
   // ---- 3. finalisation (Mapper.cpp:775-862) ----
-  for (size_t i = 0; i < n; ++i) {
+  std::vector<int> final_rc(n, KH_OK);
+  auto finalize = [&](size_t i) -> int {
+    int rc = KH_OK;
     CorrReq & q = reqs[i];
     CorrHost & c = ctx[i];
     Slot & s = m->slots[c.slot];
@@ -655,7 +747,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
         }
       }
     }
-    if (ties.empty()) {q.status = KH_ERR_SEARCH; continue;}     // Mapper.cpp:828
+    if (ties.empty()) {q.status = KH_ERR_SEARCH; return KH_OK;}     // Mapper.cpp:828
     // average all poses with the same highest response, Mapper.cpp:802-829
     double ax = 0.0, ay = 0.0, thetaX = 0.0, thetaY = 0.0;
     for (uint32_t t : ties) {
@@ -676,7 +768,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
       std::vector<double> lattice(plane);
       std::memcpy(lattice.data(), out + kOutHeaderWords, plane * 8);
       const int prc = positional_covariance(m, c, lattice, avg, best, q.cov);
-      if (prc != KH_OK) {q.status = prc; continue;}
+      if (prc != KH_OK) {q.status = prc; return KH_OK;}
     } else {
       // ComputeAngularCovariance, Mapper.cpp:977-1025
       const double bestAngle = normalize_angle_difference(avg[2], c.center[2]);
@@ -731,7 +823,20 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     q.mean[0] = avg[0]; q.mean[1] = avg[1]; q.mean[2] = avg[2];
     q.response = best > 1.0 ? 1.0 : best;
     s.last = c; s.has_last = true;
+    return KH_OK;
+  };
+  // the off-lattice re-score path re-uses the staging buffers and the stream: keep it off the pool
+  bool any_fine = false;
+  for (size_t i = 0; i < n; ++i) {any_fine = any_fine || ctx[i].fine;}
+  if (any_fine) {
+    for (size_t i = 0; i < n; ++i) {final_rc[i] = finalize(i);}
+  } else {
+    HostPool::instance().run(n, [&](size_t i) {
+      (void)hipSetDevice(m->device);
+      final_rc[i] = finalize(i);
+    });
   }
+  for (size_t i = 0; i < n; ++i) {if (final_rc[i] != KH_OK) {return final_rc[i];}}
   return KH_OK;
 }
 
