@@ -320,16 +320,26 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     if (m->footprint100.size() > 1) {
       // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon
       // as the smear kernel writes 100 off-centre: resolve the active set in reference order.
-      std::unordered_set<uint64_t> occupied;
-      occupied.reserve(np * m->footprint100.size() * 2);
+      // open-addressing set of occupied cells (keys = packed cell coordinates, never 0 after the +1)
+      size_t cap = 64;
+      while (cap < np * m->footprint100.size() * 2 + 16) {cap <<= 1;}
+      std::vector<uint64_t> table(cap, 0);
+      const size_t mask = cap - 1;
+      auto slot_of = [&](uint64_t key) {
+        size_t h = static_cast<size_t>((key * 0x9E3779B97F4A7C15ull) >> 20) & mask;
+        while (table[h] != 0 && table[h] != key) {h = (h + 1) & mask;}
+        return h;
+      };
+      auto pack = [](int32_t x, int32_t y) {
+        return ((static_cast<uint64_t>(static_cast<uint32_t>(y)) << 32) | static_cast<uint32_t>(x)) + 1;
+      };
       for (size_t p = 0; p < np; ++p) {
         const Cell c = world_to_grid(m->scale, s.off_x, s.off_y, v[2 * p], v[2 * p + 1]);
         if (!(c.x >= 0 && c.x < m->roi_w) || !(c.y >= 0 && c.y < m->roi_h)) {act[r][p] = 0; continue;}
-        const uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(c.y)) << 32) | static_cast<uint32_t>(c.x);
-        if (occupied.count(key)) {act[r][p] = 0; continue;}
+        if (table[slot_of(pack(c.x, c.y))] != 0) {act[r][p] = 0; continue;}
         for (const Cell & f : m->footprint100) {
-          occupied.insert((static_cast<uint64_t>(static_cast<uint32_t>(c.y + f.y)) << 32) |
-            static_cast<uint32_t>(c.x + f.x));
+          const uint64_t key = pack(c.x + f.x, c.y + f.y);
+          table[slot_of(key)] = key;
         }
       }
     }
@@ -703,6 +713,26 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   launch_ties(m->d_stage, stride, static_cast<int32_t>(n), max_poses, m->stream);
   KH_HIP(hipGetLastError());
   KH_HIP(hipMemcpyAsync(m->h_out, m->d_out, out_words * 8 * n, hipMemcpyDeviceToHost, m->stream));
+  // fine passes need the raw sums of every angle at the best cell (ComputeAngularCovariance): their
+  // volumes are tiny (3 x 3 x nA), so they ride along with the batch download instead of costing one
+  // synchronous copy per match afterwards
+  constexpr size_t kSmallVolume = 4096;
+  {
+    size_t n_small = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (ctx[i].fine && static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na <= kSmallVolume) {++n_small;}
+    }
+    if (n_small) {
+      rc = ensure_pinned(m->h_sums, m->cap_hsums, kSmallVolume * n, m->stream);
+      if (rc) {return rc;}
+      for (size_t i = 0; i < n; ++i) {
+        const size_t vol = static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na;
+        if (ctx[i].fine && vol <= kSmallVolume) {
+          KH_HIP(hipMemcpyAsync(m->h_sums + kSmallVolume * i, m->slots[ctx[i].slot].d_sums, vol * 4, hipMemcpyDeviceToHost, m->stream));
+        }
+      }
+    }
+  }
   KH_HIP(hipStreamSynchronize(m->stream));
   if (m->profiling) {
     float ms = 0;
@@ -783,7 +813,10 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
         }
       }
       std::vector<int32_t> col(c.na, 0);
-      if (fx >= 0) {
+      if (fx >= 0 && plane * c.na <= kSmallVolume) {
+        const int32_t * vol = m->h_sums + kSmallVolume * i;
+        for (int32_t a = 0; a < c.na; ++a) {col[a] = vol[static_cast<size_t>(a) * plane + static_cast<size_t>(fy) * c.nx + fx];}
+      } else if (fx >= 0) {
         KH_HIP(hipMemcpy2D(col.data(), 4, s.d_sums + static_cast<size_t>(fy) * c.nx + fx, plane * 4, 4, c.na, hipMemcpyDeviceToHost));
       } else {
         // off-lattice best pose: score the single cell through the generic (per-pose checked) path
@@ -825,10 +858,13 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     s.last = c; s.has_last = true;
     return KH_OK;
   };
-  // the off-lattice re-score path re-uses the staging buffers and the stream: keep it off the pool
-  bool any_fine = false;
-  for (size_t i = 0; i < n; ++i) {any_fine = any_fine || ctx[i].fine;}
-  if (any_fine) {
+  // big fine volumes and the off-lattice re-score path issue their own copies / launches on the
+  // stream: keep such batches off the pool
+  bool serial_final = false;
+  for (size_t i = 0; i < n; ++i) {
+    serial_final = serial_final || (ctx[i].fine && static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na > kSmallVolume);
+  }
+  if (serial_final) {
     for (size_t i = 0; i < n; ++i) {final_rc[i] = finalize(i);}
   } else {
     HostPool::instance().run(n, [&](size_t i) {

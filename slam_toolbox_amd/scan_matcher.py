@@ -127,7 +127,26 @@ class ScanMatcher:
         capi.check(rc, "kh_matcher_match")
         return resp.value, mean, cov.reshape(3, 3)
 
-    def MatchScanBatch(self, scans, base_lists, doPenalize=True, doRefineMatch=True):
+    @staticmethod
+    def pack_batch(scans, base_lists):
+        """ctypes marshalling of a MatchScanBatch input, reusable across calls (a C++ caller hands the
+        kh_scan arrays over directly; in Python building ~25 structs per pair costs more than the match)."""
+        flat = [b for lst in base_lists for b in lst]
+        begin = np.zeros(len(scans) + 1, dtype=np.int32)
+        begin[1:] = np.cumsum([len(lst) for lst in base_lists])
+        return (_scan_array(scans), _scan_array(flat), begin, len(scans), (scans, flat))
+
+    def MatchScanBatch(self, scans, base_lists, doPenalize=True, doRefineMatch=True, packed=None):
+        if packed is not None:
+            q_arr, b_arr, begin, n, _keep = packed
+            means = np.zeros(3 * n)
+            covs = np.zeros(9 * n)
+            resp = np.zeros(n)
+            status = np.zeros(n, dtype=np.int32)
+            capi.check(capi.lib().kh_matcher_match_batch(self._h, n, q_arr, b_arr, begin, int(doPenalize),
+                                                         int(doRefineMatch), means, covs, resp, status),
+                       "kh_matcher_match_batch")
+            return resp, means.reshape(n, 3), covs.reshape(n, 3, 3), status
         n = len(scans)
         flat = [b for lst in base_lists for b in lst]
         begin = np.zeros(n + 1, dtype=np.int32)
