@@ -1,0 +1,161 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into or called from the product library.
+//
+// Drop-in check of the solver plugin: the reference's OWN karto::Mapper (compiled in place from
+// /root/reference, see oracle/Makefile) processes a scan queue with karto_hip::HipSpaSolver attached through
+// Mapper::SetScanSolver -- i.e. the real karto::ScanSolver virtual interface (AddNode(Vertex*),
+// AddConstraint(Edge*), Compute, GetCorrections, Clear; Mapper.h:954-1066; call sites Mapper.cpp:1425-1427,
+// 1633-1635, 2015-2028).  A recording wrapper logs every call with its inputs and the corrections each
+// Compute() returned, so that the test can replay exactly the same graphs through the CPU oracle
+// (oracle/spa.py) and compare (tests/test_dropin_mapper_gpu.py).
+//
+// Mapper parameters = config/mapper_params_offline.yaml:31-66 (the offline_sync launch, BASELINE config[0]).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <shared_mutex>
+#include <mutex>
+#include <fstream>
+#include <unordered_map>
+#include <queue>
+#include <chrono>
+#include <algorithm>
+#include <memory>
+#include <atomic>
+#include <thread>
+#include <iomanip>
+
+#include "karto_sdk/Mapper.h"
+#include "karto_hip/karto_adaptor.hpp"
+
+using namespace karto;
+
+namespace
+{
+
+class RecordingSolver : public ScanSolver
+{
+public:
+  explicit RecordingSolver(FILE * log) : m_pLog(log) {}
+  virtual void Compute()
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    m_Inner.Compute();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const ScanSolver::IdPoseVector & c = m_Inner.GetCorrections();
+    std::fprintf(m_pLog, "X %zu %.6f\n", c.size(), ms);
+    for (const auto & ip : c) {
+      std::fprintf(m_pLog, "P %d %.17g %.17g %.17g\n", ip.first, ip.second.GetX(), ip.second.GetY(), ip.second.GetHeading());
+    }
+  }
+  virtual void Configure(rclcpp_lifecycle::LifecycleNode::SharedPtr node) {m_Inner.Configure(node);}
+  virtual const ScanSolver::IdPoseVector & GetCorrections() const {return m_Inner.GetCorrections();}
+  virtual void Clear() {std::fprintf(m_pLog, "K\n"); m_Inner.Clear();}
+  virtual void Reset() {std::fprintf(m_pLog, "R\n"); m_Inner.Reset();}
+  virtual void AddNode(Vertex<LocalizedRangeScan> * pVertex)
+  {
+    const Pose2 p = pVertex->GetObject()->GetCorrectedPose();
+    std::fprintf(m_pLog, "N %d %.17g %.17g %.17g\n", pVertex->GetObject()->GetUniqueId(), p.GetX(), p.GetY(), p.GetHeading());
+    m_Inner.AddNode(pVertex);
+  }
+  virtual void AddConstraint(Edge<LocalizedRangeScan> * pEdge)
+  {
+    LinkInfo * li = (LinkInfo *)(pEdge->GetLabel());
+    const Pose2 d = li->GetPoseDifference();
+    const Matrix3 & c = li->GetCovariance();
+    std::fprintf(m_pLog, "C %d %d %.17g %.17g %.17g", pEdge->GetSource()->GetObject()->GetUniqueId(),
+      pEdge->GetTarget()->GetObject()->GetUniqueId(), d.GetX(), d.GetY(), d.GetHeading());
+    for (int r = 0; r < 3; ++r) {for (int q = 0; q < 3; ++q) {std::fprintf(m_pLog, " %.17g", c(r, q));}}
+    std::fprintf(m_pLog, "\n");
+    m_Inner.AddConstraint(pEdge);
+  }
+  virtual void RemoveNode(kt_int32s id) {std::fprintf(m_pLog, "D %d\n", id); m_Inner.RemoveNode(id);}
+  virtual void RemoveConstraint(kt_int32s a, kt_int32s b) {std::fprintf(m_pLog, "E %d %d\n", a, b); m_Inner.RemoveConstraint(a, b);}
+private:
+  FILE * m_pLog;
+  karto_hip::HipSpaSolver m_Inner;
+};
+
+}  // namespace
+
+extern "C" {
+
+// Runs the scan queue through karto::Mapper::Process with the GPU solver plugin attached.  `ranges` is
+// n_scans x n_beams, `odom` n_scans x 3.  Writes the call log to `log_path` and the final corrected pose of
+// every ACCEPTED scan (id, x, y, heading) to `out` (capacity cap rows).  Returns the number of accepted
+// scans, or -1 when the plugin could not be constructed (no GPU).
+int ref_slam_run(
+  int n_scans, int n_beams, const double * ranges, const double * odom, double loop_search_distance,
+  const char * log_path, double * out, int cap)
+{
+  FILE * log = std::fopen(log_path, "w");
+  if (!log) {return -2;}
+  int accepted = 0;
+  try {
+    Mapper mapper;
+    // config/mapper_params_offline.yaml:31-66
+    mapper.setParamUseScanMatching(true);
+    mapper.setParamUseScanBarycenter(true);
+    mapper.setParamMinimumTravelDistance(0.5);
+    mapper.setParamMinimumTravelHeading(0.5);
+    mapper.setParamScanBufferSize(10);
+    mapper.setParamScanBufferMaximumScanDistance(10.0);
+    mapper.setParamLinkMatchMinimumResponseFine(0.1);
+    mapper.setParamLinkScanMaximumDistance(1.5);
+    mapper.setParamLoopSearchMaximumDistance(loop_search_distance);
+    mapper.setParamDoLoopClosing(true);
+    mapper.setParamLoopMatchMinimumChainSize(10);
+    mapper.setParamLoopMatchMaximumVarianceCoarse(3.0);
+    mapper.setParamLoopMatchMinimumResponseCoarse(0.35);
+    mapper.setParamLoopMatchMinimumResponseFine(0.45);
+    mapper.setParamCorrelationSearchSpaceDimension(0.5);
+    mapper.setParamCorrelationSearchSpaceResolution(0.01);
+    mapper.setParamCorrelationSearchSpaceSmearDeviation(0.1);
+    mapper.setParamLoopSearchSpaceDimension(8.0);
+    mapper.setParamLoopSearchSpaceResolution(0.05);
+    mapper.setParamLoopSearchSpaceSmearDeviation(0.03);
+    mapper.setParamDistanceVariancePenalty(0.5);
+    mapper.setParamAngleVariancePenalty(1.0);
+    mapper.setParamFineSearchAngleOffset(0.00349);
+    mapper.setParamCoarseSearchAngleOffset(0.349);
+    mapper.setParamCoarseAngleResolution(0.0349);
+    mapper.setParamMinimumAnglePenalty(0.9);
+    mapper.setParamMinimumDistancePenalty(0.5);
+    mapper.setParamUseResponseExpansion(true);
+    RecordingSolver solver(log);
+    mapper.SetScanSolver(&solver);
+    std::vector<LocalizedRangeScan *> kept;
+    for (int i = 0; i < n_scans; ++i) {
+      RangeReadingsVector r(ranges + static_cast<size_t>(i) * n_beams, ranges + static_cast<size_t>(i + 1) * n_beams);
+      LocalizedRangeScan * s = new LocalizedRangeScan(Name("laser0"), r);
+      const Pose2 p(odom[3 * i], odom[3 * i + 1], odom[3 * i + 2]);
+      s->SetOdometricPose(p);
+      s->SetCorrectedPose(p);
+      s->SetTime(0.1 * i);
+      Matrix3 cov;
+      if (mapper.Process(s, &cov)) {kept.push_back(s);} else {delete s;}
+    }
+    for (LocalizedRangeScan * s : kept) {
+      if (accepted < cap) {
+        const Pose2 p = s->GetCorrectedPose();
+        out[4 * accepted] = s->GetUniqueId(); out[4 * accepted + 1] = p.GetX();
+        out[4 * accepted + 2] = p.GetY(); out[4 * accepted + 3] = p.GetHeading();
+      }
+      ++accepted;
+    }
+    std::fprintf(log, "Z %d\n", accepted);
+  } catch (const std::exception & e) {
+    std::fprintf(log, "! %s\n", e.what());
+    std::fclose(log);
+    return -1;
+  }
+  std::fclose(log);
+  return accepted;
+}
+
+}  // extern "C"

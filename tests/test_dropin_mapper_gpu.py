@@ -1,0 +1,94 @@
+"""GPU: drop-in check of the solver plugin (BASELINE config[0] "offline_sync mapper").
+The reference's OWN karto::Mapper -- compiled in place from /root/reference into oracle/_ref/
+libkarto_ref_slam.so by oracle/Makefile (dev container only; the prebuilt .so travels to the GPU box) --
+processes a synthetic scan queue with karto_hip::HipSpaSolver attached through Mapper::SetScanSolver, i.e.
+through the real karto::ScanSolver virtual interface.  Every solver call is logged; the test replays the
+logged graphs through the CPU oracle (oracle/spa.py) and compares the corrections of every Compute()."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from slam_toolbox_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libkarto_ref_slam.so")
+
+
+def _replay(log_path):
+    """Yields (poses_in (N,3), ids, edges (E,2 index), z, cov, corrections {id: pose}) per Compute()."""
+    from collections import OrderedDict
+    nodes = OrderedDict()
+    cons = []
+    pending = None
+    out = []
+    with open(log_path) as f:
+        for line in f:
+            t = line.split()
+            if t[0] == "N":
+                nodes.setdefault(int(t[1]), np.array([float(v) for v in t[2:5]]))
+            elif t[0] == "C":
+                vals = [float(v) for v in t[3:]]
+                cons.append((int(t[1]), int(t[2]), np.array(vals[:3]), np.array(vals[3:12])))
+            elif t[0] == "X":
+                ids = list(nodes.keys())
+                index = {i: k for k, i in enumerate(ids)}
+                pending = dict(ids=ids, poses=np.array([nodes[i] for i in ids]),
+                               edges=np.array([[index[a], index[b]] for a, b, _, _ in cons], dtype=np.int32),
+                               z=np.array([c[2] for c in cons]), cov=np.array([c[3] for c in cons]), corr={},
+                               n=int(t[1]), ms=float(t[2]))
+                out.append(pending)
+            elif t[0] == "P":
+                pending["corr"][int(t[1])] = np.array([float(v) for v in t[2:5]])
+                nodes[int(t[1])] = pending["corr"][int(t[1])]     # the plugin keeps its solution as the next start
+            elif t[0] == "!":
+                raise RuntimeError("reference mapper threw: " + line)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libkarto_ref_slam.so not built (needs /root/reference)")
+def test_reference_mapper_runs_on_the_gpu_solver_plugin(kartohip_lib, tmp_path):
+    from oracle import spa
+    lib = C.CDLL(LIB)
+    lib.ref_init_laser.restype = C.c_int
+    lib.ref_init_laser.argtypes = [C.c_double] * 6
+    lib.ref_slam_run.restype = C.c_int
+    lib.ref_slam_run.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_char_p, C.c_void_p, C.c_int]
+    laser = synth.Laser()
+    n_beams = lib.ref_init_laser(laser.min_angle, laser.max_angle, laser.ang_res, laser.min_range, laser.max_range,
+                                 laser.range_threshold)
+    lib.ref_set_threads(min(32, os.cpu_count() or 1))
+    n_scans = 230                                    # three aisles of the synthetic warehouse: ~200 graph nodes
+    world = synth.make_world(12345)
+    truth, odom = synth.trajectory(n_scans)
+    rng = np.random.default_rng(4)
+    ranges = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], rng) for i in range(n_scans)]))
+    assert ranges.shape[1] == n_beams
+    odom = np.ascontiguousarray(odom)
+    out = np.zeros((n_scans, 4))
+    log = str(tmp_path / "solver_calls.log")
+    # loop_search_maximum_distance 5 m: the aisles are 4 m apart (offline.yaml has 3.0)
+    accepted = lib.ref_slam_run(n_scans, n_beams, ranges.ctypes.data, odom.ctypes.data, 5.0, log.encode(),
+                                out.ctypes.data, n_scans)
+    assert accepted > 150, accepted
+    computes = _replay(log)
+    print(f"accepted {accepted} scans, {len(computes)} Compute() calls, "
+          f"graph at the last one: {len(computes[-1]['ids']) if computes else 0} nodes / "
+          f"{len(computes[-1]['edges']) if computes else 0} edges, GPU solve ms {[round(c['ms'], 1) for c in computes]}")
+    assert len(computes) >= 1, "the run closed no loop: nothing exercised Compute()"
+    worst = 0.0
+    for c in computes:
+        assert c["n"] == len(c["ids"])                              # corrections cover all nodes (ceres_solver.cpp:256-268)
+        ref_x, info = spa.solve(c["poses"], c["edges"], c["z"], c["cov"])
+        got = np.array([c["corr"][i] for i in c["ids"]])
+        d = got - ref_x
+        d[:, 2] = (d[:, 2] + np.pi) % (2 * np.pi) - np.pi
+        worst = max(worst, float(np.abs(d).max()))
+    assert worst < 1e-6, worst
+    # the mapper applied the corrections: final scan poses = last corrections for the nodes that existed then
+    last = computes[-1]["corr"]
+    final = {int(r[0]): r[1:] for r in out[:accepted]}
+    common = [i for i in last if i in final]
+    assert common
