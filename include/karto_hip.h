@@ -191,6 +191,14 @@ typedef struct kh_spa_summary {
 } kh_spa_summary;
 
 KH_API int kh_spa_create(int32_t device, kh_spa ** out);
+/* Multi-GPU (one process per GPU, every rank holds the same graph): rank r linearises the edge block
+ * [E*r/world, E*(r+1)/world) into PARTIAL normal equations, and `allreduce` -- supplied by the host
+ * framework, e.g. RCCL through torch.distributed -- must sum `count` doubles at `device_buf` (H followed
+ * by g, one contiguous buffer) in place across the ranks, ordered after the work already queued on
+ * `hip_stream` (a hipStream_t) and complete, as far as that stream is concerned, when it returns 0.  The
+ * factorisation and the LM control stay replicated.  world = 1 (default) disables sharding. */
+typedef int (*kh_allreduce_fn)(void * user, double * device_buf, int64_t count, void * hip_stream);
+KH_API int kh_spa_set_sharding(kh_spa * s, int32_t rank, int32_t world, kh_allreduce_fn allreduce, void * user);
 KH_API void kh_spa_destroy(kh_spa * s);
 KH_API int kh_spa_set_options(kh_spa * s, const kh_spa_options * o);
 KH_API int kh_spa_reset(kh_spa * s);                                   /* ScanSolver::Reset  (ceres_solver.cpp:279-314) */

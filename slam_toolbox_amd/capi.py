@@ -64,8 +64,9 @@ SYMBOLS = [
     "kh_spa_options_default", "kh_spa_create", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
-    "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info",
+    "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
 ]
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 _lib = None
 
@@ -133,6 +134,7 @@ def lib():
         L.kh_spa_compute.argtypes = [vp, C.POINTER(KhSpaSummary)]
         L.kh_spa_get_corrections.argtypes = [vp, C.POINTER(i32), vp, vp]
         L.kh_link_info.argtypes = [dptr, dptr, dptr, dptr, dptr]
+        L.kh_spa_set_sharding.argtypes = [vp, i32, i32, ALLREDUCE_FN, vp]
     _lib = L
     return L
 

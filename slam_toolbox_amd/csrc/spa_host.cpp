@@ -107,12 +107,15 @@ struct kh_spa
     d_front_first, d_rows_ptr, d_rows, d_child_ptr, d_child_list, d_relpos_ptr, d_relpos, d_slot_ld,
     d_elim_of_free, d_free_of_elim, d_level_fronts, d_fail;
   DevBuf<int64_t> d_front_off, d_slot_dest;
-  DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_H, d_g, d_fronts, d_x, d_cand, d_scale,
+  DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
   int32_t n_slots = 0;
   std::vector<int32_t> level_offsets, level_max_m;
   DevBuf<double> d_upd;
+  // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
+  int32_t shard_rank = 0, shard_world = 1;
+  kh_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
 };
 
 namespace kh
@@ -511,7 +514,8 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     s->n_slots = n_slots;
     const size_t scratch = std::max<size_t>(static_cast<size_t>(21) * E, static_cast<size_t>(9) * nf + 16);
     r2 |= s->d_edge_lin.ensure(scratch); r2 |= s->d_edge_cost.ensure(std::max(E, 1));
-    r2 |= s->d_H.ensure(static_cast<size_t>(n_slots) * 9); r2 |= s->d_g.ensure(static_cast<size_t>(nf) * 3);
+    // H and g share one buffer so that a sharded run sums them across ranks with ONE all-reduce
+    r2 |= s->d_Hg.ensure(static_cast<size_t>(n_slots) * 9 + static_cast<size_t>(nf) * 3 + 8);
     r2 |= s->d_fronts.ensure(static_cast<size_t>(sym.fronts_size) + 16);
     r2 |= s->d_scale.ensure(3 * nf); r2 |= s->d_diag.ensure(3 * nf); r2 |= s->d_rhs.ensure(3 * nf);
     r2 |= s->d_step.ensure(3 * nf); r2 |= s->d_delta.ensure(3 * nf);
@@ -546,7 +550,8 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   dev.edge_lin = s->d_edge_lin.p; dev.edge_cost = s->d_edge_cost.p;
   dev.n_slots = s->n_slots; dev.slot_contrib_ptr = s->d_slot_contrib_ptr.p; dev.slot_contrib = s->d_slot_contrib.p;
   dev.bsr_row_ptr = s->d_bsr_row_ptr.p; dev.bsr_col = s->d_bsr_col.p; dev.bsr_diag_slot = s->d_bsr_diag.p;
-  dev.H = s->d_H.p; dev.node_contrib_ptr = s->d_node_contrib_ptr.p; dev.node_contrib = s->d_node_contrib.p; dev.g = s->d_g.p;
+  dev.H = s->d_Hg.p; dev.node_contrib_ptr = s->d_node_contrib_ptr.p; dev.node_contrib = s->d_node_contrib.p;
+  dev.g = s->d_Hg.p + static_cast<size_t>(s->n_slots) * 9;
   dev.n_fronts = sym.n_fronts; dev.front_off = s->d_front_off.p; dev.front_m = s->d_front_m.p; dev.front_ns = s->d_front_ns.p;
   dev.front_first = s->d_front_first.p; dev.front_rows_ptr = s->d_rows_ptr.p; dev.front_rows = s->d_rows.p;
   dev.child_ptr = s->d_child_ptr.p; dev.child_list = s->d_child_list.p; dev.relpos_ptr = s->d_relpos_ptr.p; dev.relpos = s->d_relpos.p;
@@ -606,7 +611,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_child_ptr.release(); s->d_child_list.release(); s->d_relpos_ptr.release(); s->d_relpos.release();
   s->d_slot_ld.release(); s->d_elim_of_free.release(); s->d_free_of_elim.release(); s->d_level_fronts.release();
   s->d_fail.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
-  s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_H.release(); s->d_g.release(); s->d_fronts.release();
+  s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
   s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release();
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
@@ -619,6 +624,13 @@ int kh_spa_set_options(kh_spa * s, const kh_spa_options * o)
 {
   if (!s || !o) {return KH_ERR_INVALID_ARG;}
   s->opt = *o;
+  return KH_OK;
+}
+
+int kh_spa_set_sharding(kh_spa * s, int32_t rank, int32_t world, kh_allreduce_fn fn, void * user)
+{
+  if (!s || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) {return KH_ERR_INVALID_ARG;}
+  s->shard_rank = rank; s->shard_world = world; s->allreduce = fn; s->allreduce_user = user;
   return KH_OK;
 }
 
@@ -825,7 +837,18 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
 
   // ---- iteration zero ----
   auto t0 = now();
-  spa_launch_linearize(dev, x, scal + 0, st);
+  const int32_t e_lo = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * s->shard_rank / s->shard_world);
+  const int32_t e_hi = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * (s->shard_rank + 1) / s->shard_world);
+  const int64_t hg_count = static_cast<int64_t>(s->n_slots) * 9 + static_cast<int64_t>(dev.n_free) * 3;
+  auto linearize = [&](const double * at) -> int {
+    spa_launch_linearize(dev, at, scal + 0, e_lo, e_hi, st);
+    if (s->shard_world > 1) {
+      if (!s->allreduce) {set_error("kh_spa: sharding enabled without an all-reduce callback"); return KH_ERR_INVALID_ARG;}
+      if (s->allreduce(s->allreduce_user, dev.H, hg_count, st) != 0) {set_error("kh_spa: all-reduce callback failed"); return KH_ERR_SOLVER;}
+    }
+    return KH_OK;
+  };
+  rc = linearize(x); if (rc) {return finish(rc);}
   if (opt.jacobi_scaling) {
     spa_launch_jacobi_scale(dev, s->d_scale.p, st);
   } else {
@@ -942,7 +965,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       std::swap(x, cand);
       x_norm = cand_norm;
       auto t2 = now();
-      spa_launch_linearize(dev, x, scal + 0, st);
+      rc = linearize(x); if (rc) {return finish(rc);}
       spa_launch_grad_norms(dev, x, scal + 1, st);
       rc = fetch(); if (rc) {return finish(rc);}
       lin_ms += ms_since(t2);

@@ -52,7 +52,8 @@ struct SpaDev
   int64_t fronts_size;
 };
 
-void spa_launch_linearize(const SpaDev & d, const double * x, double * cost_out, void * stream);
+// [e_lo, e_hi): edge block linearised by this rank (0, n_edges on a single GPU)
+void spa_launch_linearize(const SpaDev & d, const double * x, double * cost_out, int e_lo, int e_hi, void * stream);
 void spa_launch_cost(const SpaDev & d, const double * x, double * cost_out, void * stream);
 void spa_launch_diag(const SpaDev & d, const double * scale, double * diag_out, double min_diag, double max_diag, void * stream);
 void spa_launch_jacobi_scale(const SpaDev & d, double * scale_out, void * stream);

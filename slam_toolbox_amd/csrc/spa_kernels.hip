@@ -30,11 +30,20 @@ constexpr double kTwoPiD = 2.0 * kPiD;
 __device__ __forceinline__ double d_normalize_angle(double a) {return a - kTwoPiD * floor((a + kPiD) / kTwoPiD);}
 
 // ---------------------------------------------------------------------------------------------
+// [e_lo, e_hi) = the edge block this GPU linearises (all edges on one GPU); edges outside it get a zero
+// record, so the gather kernels below produce this rank's PARTIAL H and g, summed across ranks by the
+// caller's all-reduce.
 template <bool kJac>
-__global__ __launch_bounds__(256) void k_edge_lin(SpaDev d, const double * __restrict__ x)
+__global__ __launch_bounds__(256) void k_edge_lin(SpaDev d, const double * __restrict__ x, int e_lo, int e_hi)
 {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_edges) {return;}
+  if (kJac && (e < e_lo || e >= e_hi)) {
+    double * out = d.edge_lin + 21 * (size_t)e;
+#pragma unroll
+    for (int q = 0; q < 21; ++q) {out[q] = 0.0;}
+    return;
+  }
   const int a = d.edge_a[e], b = d.edge_b[e];
   const double xa = x[3 * a], ya = x[3 * a + 1], ta = x[3 * a + 2];
   const double xb = x[3 * b], yb = x[3 * b + 1], tb = x[3 * b + 2];
@@ -116,11 +125,15 @@ __global__ __launch_bounds__(1024) void k_sum(const double * __restrict__ in, in
   if (threadIdx.x == 0) {out[0] = factor * s[0];}
 }
 
-void spa_launch_linearize(const SpaDev & d, const double * x, double * cost_out, void * stream)
+void spa_launch_linearize(const SpaDev & d, const double * x, double * cost_out, int e_lo, int e_hi, void * stream)
 {
   hipStream_t s = (hipStream_t)stream;
   if (d.n_edges > 0) {
-    hipLaunchKernelGGL(k_edge_lin<true>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x);
+    if (e_lo > 0 || e_hi < d.n_edges) {
+      // sharded: the cost is still evaluated over all edges on every rank (E threads, microseconds)
+      hipLaunchKernelGGL(k_edge_lin<false>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, 0, d.n_edges);
+    }
+    hipLaunchKernelGGL(k_edge_lin<true>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, e_lo, e_hi);
     hipLaunchKernelGGL(k_gather_H, dim3((d.n_slots * 9 + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_gather_g, dim3((d.n_free * 3 + 255) / 256), dim3(256), 0, s, d);
   }
@@ -131,7 +144,7 @@ void spa_launch_cost(const SpaDev & d, const double * x, double * cost_out, void
 {
   hipStream_t s = (hipStream_t)stream;
   if (d.n_edges > 0) {
-    hipLaunchKernelGGL(k_edge_lin<false>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x);
+    hipLaunchKernelGGL(k_edge_lin<false>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, 0, d.n_edges);
   }
   hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, d.edge_cost, d.n_edges, 0.5, cost_out);
 }

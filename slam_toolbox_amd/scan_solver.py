@@ -116,6 +116,35 @@ class HipSpaSolver:
         """unordered_map<int, Eigen::Vector3d>: id -> (x, y, yaw) of every node."""
         return {i: p for i, p in self._all_nodes()}
 
+    # ---- multi-GPU -------------------------------------------------------------------------------
+    def enable_sharding(self, rank: int, world: int, group=None):
+        """Edge-block sharded linearisation: every rank holds the same graph,
+        rank r linearises edges [E r / world, E (r+1) / world) and the partial normal equations (H followed
+        by g, one device buffer) are summed in place by torch.distributed.all_reduce -- RCCL over xGMI with
+        backend "nccl", gloo in the single-GPU functional test.  Factorisation and LM control stay
+        replicated, so all ranks return the same poses."""
+        import torch
+        import torch.distributed as dist
+
+        class _DevView:                       # zero-copy view of the library's buffer as a torch tensor
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        def hook(_user, ptr, count, _stream):
+            try:
+                # the library's launches are on its own stream: order the collective after them on the host,
+                # run it on torch's stream, and hand the buffer back only when it is done
+                torch.cuda.synchronize()
+                t = torch.as_tensor(_DevView(int(ptr), int(count)), device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                torch.cuda.synchronize()
+                return 0
+            except Exception as exc:          # never raise through the C frame
+                self.last_warning = f"all-reduce failed: {exc}"
+                return 1
+        self._hook = capi.ALLREDUCE_FN(hook) if world > 1 else capi.ALLREDUCE_FN(0)
+        capi.check(capi.lib().kh_spa_set_sharding(self._h, int(rank), int(world), self._hook, None), "kh_spa_set_sharding")
+
     # ---- conveniences for tests / bench ---------------------------------------------------------
     def _all_nodes(self):
         out = []
