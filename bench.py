@@ -199,10 +199,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libkartohip has no CPU fallback")
+    # one process per GPU.  KH_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a single-GPU box (ranks
+    # then share the device); the driver's multi-GPU run uses the default, nccl = RCCL.
+    backend = os.environ.get("KH_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from common import C2_PARAMS, PRESETS, Scenario
     from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher, _scan_array
