@@ -141,3 +141,45 @@ def test_empty_grid_and_empty_scan(kartohip_lib):
     _assert_same(mean_o, mean_h, "mean")
     _assert_same(cov_o, cov_h, "cov")
     hm.close()
+
+
+def test_response_expansion_path(kartohip_lib):
+    """offline.yaml has use_response_expansion: a zero coarse response widens the angular search by 20 degrees up
+    to three times on the same grid (Mapper.cpp:594-619).  An empty grid forces all three rounds."""
+    sc = Scenario(seed=9, n_base=1, start=40)
+    oq, _ = sc.oracle_scans()
+    hq, _ = sc.hip_scans()
+    om = make_oracle_matcher("L")
+    hm = make_hip_matcher("L")
+    r_o, mean_o, cov_o = om.match_scan(oq, [], False, True)
+    r_h, mean_h, cov_h = hm.MatchScan(hq, [], False, True)
+    _assert_same(r_o, r_h, "response")
+    _assert_same(mean_o, mean_h, "mean")
+    _assert_same(cov_o, cov_h, "cov")
+    hm.close()
+
+
+@pytest.mark.parametrize("search_res", [0.015, 0.03, 0.007])
+def test_search_resolution_off_the_grid_pitch(kartohip_lib, search_res):
+    """CorrelateScan is public and takes any search resolution: when it is not 1x or 2x the grid pitch the
+    lattice's grid indices are no longer an arithmetic progression (or step by 3 cells) and the kernel's
+    per-pose exact path runs instead of the windowed one.  Every pose of the volume must still match."""
+    sc = Scenario(seed=6, n_base=6, start=90, perturb=(0.02, 0.03, 0.02))
+    oq, ob = sc.oracle_scans()
+    hq, hb = sc.hip_scans()
+    om = make_oracle_matcher("K")
+    hm = make_hip_matcher("K")
+    hm.set_debug(True)
+    om.add_scans(oq, ob)
+    hm.AddScans(hq, hb)
+    off = 6 * search_res
+    args = ((off, off), (search_res, search_res), 0.1, 0.02)
+    r_o, mean_o, cov_o = om.correlate_scan(oq, sc.query_pose, *args, True, True)
+    r_h, mean_h, cov_h = hm.CorrelateScan(hq, sc.query_pose, *args, True, None, True)
+    vol = om.volume()
+    sums, resp = hm.volume()
+    assert resp.shape == vol.shape[:3]
+    assert np.array_equal(bits(vol[..., 0]), bits(resp)), "response volume differs"
+    _assert_same(r_o, r_h, "response")
+    _assert_same(mean_o, mean_h, "mean")
+    hm.close()
