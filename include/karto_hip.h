@@ -147,9 +147,10 @@ KH_API int kh_matcher_read_lookup(kh_matcher * m, int32_t slot, int32_t * n_angl
  * raw integer sums (GetResponse numerator, Mapper.cpp:1200) and the penalised responses */
 KH_API int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, int32_t * ny,
                                   int32_t * na, int32_t * out_sums, double * out_responses);
-/* keep the penalised response volume of every CorrelateScan on the device so that
- * kh_matcher_read_volume can return it (parity tests); off by default */
-KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume);
+/* bit 0: keep the penalised response volume of every CorrelateScan on the device so that
+ * kh_matcher_read_volume can return it (parity tests); bit 1: score through the experimental
+ * LDS-staged kernel where the search shape allows it (same results, currently slower); off by default */
+KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t flags);
 /* HIP stream all kernels of this handle are launched on (hipStream_t as void*), so the caller can
  * bracket launches with HIP events on the right stream */
 KH_API void * kh_matcher_stream(kh_matcher * m);

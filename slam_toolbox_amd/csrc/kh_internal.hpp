@@ -15,6 +15,12 @@ constexpr int32_t kTileBytes = 64;            // bytes of one grid row a scoring
 constexpr int32_t kTileSpan = 61;             // bytes of it that hold poses whatever the alignment class (64 - 3)
 constexpr int32_t kClasses = 4;               // alignment classes of a beam offset: (base0 + offset) & 3
 constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per class, [4] = slow beams
+// LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; beams are taken in slots
+// of kSlotBeams consecutive beams, each slot split into sub-chunks whose window union fits the LDS budget
+constexpr int32_t kGroupAngles = 4;
+constexpr int32_t kSlotBeams = 32;
+constexpr int32_t kChunkWords = 8;            // int32 words per sub-chunk descriptor
+constexpr int32_t kLdsRegionBytes = 60 * 1024;
 
 // One rasterisation job (ScanMatcher::AddScans, Mapper.cpp:1032-1105) -- device visible.
 struct RasterJob
@@ -60,6 +66,12 @@ struct CorrJob
                              // alignment class (base0 + offset) & 3: list (a, c) starts at (a*4 + c)*P
   int32_t * slow;            // na*P compacted offsets needing the per-pose range check
   int32_t * counts;          // na*8: {n_class0..3, n_slow, -, -, -}
+  // LDS-staged path (lds_path != 0: linear lattice whose window fits 64 bytes x 64 rows)
+  int32_t lds_path;
+  int32_t sy_cells;          // grid rows per lattice step in y (sy_ws / ws)
+  int32_t * rel;             // na*P: byte offset of the beam's window start inside its sub-chunk's LDS region, or -1
+  int32_t * chunks;          // [groups][slots][kSlotBeams][kChunkWords]: sub-chunk descriptors
+  int32_t * chunk_counts;    // [groups][slots]: sub-chunks of the slot
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
   unsigned long long * out;  // result block, see below
@@ -78,6 +90,8 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
                   int32_t sx_variant, int32_t ry, void * stream);
 // poses per tile row of the scoring kernel for a lattice step of sx cells
 inline int32_t score_tile_poses(int32_t sx) {return sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;}
+void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
+void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream);
 void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, void * stream);
 
 }  // namespace kh

@@ -107,6 +107,7 @@ struct Slot
   // correlate scratch
   int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
   size_t cap_table = 0, cap_counts = 0;
+  int32_t * d_chunks = nullptr, * d_chunk_counts = nullptr; size_t cap_chunks = 0, cap_chunk_counts = 0;
   int32_t * d_sums = nullptr; double * d_resp = nullptr; size_t cap_volume = 0, cap_resp = 0;
   // raster staging
   double * d_rpoints = nullptr; uint8_t * d_ractive = nullptr; size_t cap_rpoints = 0, cap_ractive = 0;
@@ -142,6 +143,7 @@ struct kh_matcher
   RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
   int32_t * h_sums = nullptr; size_t cap_hsums = 0;
   bool keep_responses = false;
+  bool lds_score = false;          // experimental LDS-staged scoring path (kh_matcher_set_debug bit 1)
   // profiling
   bool profiling = false;
   double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0;
@@ -562,12 +564,21 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
       s.cap_table = cap;
     }
     rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * kCountsPerAngle, m->stream); if (rc) {return rc;}
+    {
+      const size_t groups = (static_cast<size_t>(c.na) + kGroupAngles - 1) / kGroupAngles;
+      const size_t slots = (static_cast<size_t>(c.P) + kSlotBeams - 1) / kSlotBeams;
+      rc = ensure_device(s.d_chunks, s.cap_chunks, groups * slots * kSlotBeams * kChunkWords, m->stream); if (rc) {return rc;}
+      rc = ensure_device(s.d_chunk_counts, s.cap_chunk_counts, groups * slots, m->stream); if (rc) {return rc;}
+    }
     const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
     rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
     if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
 
   }
-  std::vector<int32_t> job_sx(n, 1), job_ry(n, 1), job_tiles(n, 1);
+  std::vector<int32_t> job_sx(n, 1), job_ry(n, 1), job_tiles(n, 1), job_lds(n, 0);
+  // measured slower than the windowed kernel (VALU bound: 7 ops per dword + staging): opt-in
+  static const bool lds_env = std::getenv("KH_LDS_SCORE") != nullptr;
+  const bool lds_enabled = lds_env || m->lds_score;
   HostPool::instance().run(n, [&](size_t i) {
     CorrReq & q = reqs[i];
     CorrHost & c = ctx[i];
@@ -675,6 +686,13 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     job->tiles_y = (c.ny + 4 * this_ry - 1) / (4 * this_ry);
     job->ry = this_ry;
     job_sx[i] = this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
+    // LDS-staged scoring: linear lattice whose window fits 64 bytes x 64 rows
+    const bool lds_ok = lds_enabled && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
+      sy_ws % m->ws == 0 && (m->ws % 4) == 0 &&
+      static_cast<int64_t>((c.ny - 1) * (sy_ws / m->ws) + 1) * 4 * 48 <= kLdsRegionBytes;
+    job_lds[i] = lds_ok ? 1 : 0;
+    job->lds_path = job_lds[i]; job->sy_cells = sy_ws / m->ws;
+    job->rel = s.d_fast; job->chunks = s.d_chunks; job->chunk_counts = s.d_chunk_counts;
     job->do_penalize = q.penalize ? 1 : 0; job->coarse = q.fine ? 0 : 1;
     job->write_resp = m->keep_responses ? 1 : 0;
     job->denom = c.denom;
@@ -689,18 +707,27 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
     job->sums = s.d_sums; job->resp = s.d_resp; job->out = m->d_out + out_words * i;
   });
+  bool all_lds = true;
   for (size_t i = 0; i < n; ++i) {
     if (sx_variant < 0) {sx_variant = job_sx[i]; ry = job_ry[i];}
     if (sx_variant != job_sx[i] || ry != job_ry[i]) {uniform_kernel = false;}
     max_tiles = std::max(max_tiles, job_tiles[i]);
+    all_lds = all_lds && job_lds[i] != 0;
   }
+  const bool use_lds = all_lds && uniform_kernel;
 
   // ---- 2. upload, launch, download ----
   KH_HIP(hipMemcpyAsync(m->d_stage, m->h_stage, stride * n, hipMemcpyHostToDevice, m->stream));
   KH_HIP(hipMemsetAsync(m->d_out, 0, out_words * 8 * n, m->stream));
-  launch_offsets(m->d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
+  if (use_lds) {
+    launch_offsets_lds(m->d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
+  } else {
+    launch_offsets(m->d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
+  }
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[0], m->stream));}
-  if (uniform_kernel) {
+  if (use_lds) {
+    launch_score_lds(m->d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, m->stream);
+  } else if (uniform_kernel) {
     launch_score(m->d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, m->stream);
   } else {
     for (size_t i = 0; i < n; ++i) {
@@ -734,6 +761,28 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     }
   }
   KH_HIP(hipStreamSynchronize(m->stream));
+  if (use_lds && std::getenv("KH_LDS_DEBUG")) {
+    const CorrHost & c0 = ctx[0];
+    const Slot & s0 = m->slots[c0.slot];
+    const size_t groups = (static_cast<size_t>(c0.na) + kGroupAngles - 1) / kGroupAngles;
+    const size_t slots = (static_cast<size_t>(c0.P) + kSlotBeams - 1) / kSlotBeams;
+    std::vector<int32_t> cc(groups * slots), dd(groups * slots * kSlotBeams * kChunkWords);
+    KH_HIP(hipMemcpy(cc.data(), s0.d_chunk_counts, cc.size() * 4, hipMemcpyDeviceToHost));
+    KH_HIP(hipMemcpy(dd.data(), s0.d_chunks, dd.size() * 4, hipMemcpyDeviceToHost));
+    long total = 0, bytes = 0, beams = 0, maxb = 0;
+    for (size_t g = 0; g < groups; ++g) {
+      for (size_t sl = 0; sl < slots; ++sl) {
+        for (int32_t k = 0; k < cc[g * slots + sl]; ++k) {
+          const int32_t * d = dd.data() + ((g * slots + sl) * kSlotBeams + k) * kChunkWords;
+          ++total; bytes += static_cast<long>(d[4]) * d[5]; beams += d[1] - d[0];
+          maxb = std::max<long>(maxb, static_cast<long>(d[4]) * d[5]);
+        }
+      }
+    }
+    std::fprintf(stderr, "[kh lds] job 0: %zu groups x %zu slots, %ld sub-chunks (%.1f per group), mean region %.1f KB, max %.1f KB, mean beams %.1f\n",
+      groups, slots, total, static_cast<double>(total) / groups, bytes / 1024.0 / std::max(1l, total), maxb / 1024.0,
+      static_cast<double>(beams) / std::max(1l, total));
+  }
   if (m->profiling) {
     float ms = 0;
     KH_HIP(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
@@ -1007,6 +1056,7 @@ void kh_matcher_destroy(kh_matcher * m)
   if (m->stream) {hipStreamSynchronize(m->stream);}
   for (auto & s : m->slots) {
     hipFree(s.d_grid_alloc); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
+    hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
   }
   hipFree(m->d_kernel); hipFree(m->d_stage); hipFree(m->d_rjobs); hipFree(m->d_out);
@@ -1036,7 +1086,8 @@ int kh_matcher_set_params(kh_matcher * m, const kh_match_params * p)
 int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
 {
   if (!m) {return KH_ERR_INVALID_ARG;}
-  m->keep_responses = keep_response_volume != 0;
+  m->keep_responses = (keep_response_volume & 1) != 0;
+  m->lds_score = (keep_response_volume & 2) != 0;
   return KH_OK;
 }
 

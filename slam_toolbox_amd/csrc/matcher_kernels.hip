@@ -439,3 +439,426 @@ void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t 
 }
 
 }  // namespace kh
+
+// =============================================================================================
+// LDS-staged scoring path (windows of at most 64 bytes x 64 lattice rows: BASELINE config 2, the
+// sequential preset, every fine search).
+//
+// The windowed kernel above is bound by L2->L1 line fills: the 32 KB L1 cannot keep the windows of the
+// resident waves, so almost every window row is re-fetched from L2 although neighbouring beams and
+// neighbouring angles read nearly the same bytes.  Here the reuse is made explicit: a workgroup scores
+// kGroupAngles adjacent angles, takes the beams in scan order (= order along the scanned contour) in
+// sub-chunks whose windows' union -- a small rectangle of the grid -- fits in LDS, stages that rectangle
+// once with coalesced loads, and then every (angle, beam) window is read from LDS.
+//
+//   K2' k_offsets_lds  one workgroup per (angle group, job): bit-exact lookup table (as K2), then one
+//                      thread per slot of kSlotBeams beams splits the slot into sub-chunks by halving
+//                      until the union rectangle fits, and writes per-beam LDS-relative window offsets
+//   K3' k_score_lds    one workgroup (16 waves = 4 angles x 4 row quarters) per (angle group, job);
+//                      per sub-chunk: stage, barrier, RY ds_read2_b32 + v_alignbyte + 4 VALU per beam
+//                      and row group, barrier.  Each pose is owned by one lane: no merge step.
+// =============================================================================================
+namespace kh
+{
+
+struct ChunkDesc {int32_t beam_begin, beam_end, g0, n_dw, pitch, rows, pad0, pad1;};
+static_assert(sizeof(ChunkDesc) == kChunkWords * 4, "descriptor size");
+
+constexpr int kNotFast = INT32_MIN;
+
+__global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_t stride)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.y * stride);
+  const int group = blockIdx.x;
+  const int a0 = group * kGroupAngles;
+  if (a0 >= job.na) {return;}
+  const int P = job.n_points;
+  extern __shared__ int32_t s_xy[];              // [kGroupAngles][2][P]: gx, gy (gy = kNotFast: not a fast beam)
+  __shared__ int32_t s_slow[kGroupAngles];
+  if (threadIdx.x < kGroupAngles) {s_slow[threadIdx.x] = 0;}
+  __syncthreads();
+  const int64_t bmin = job.base0;
+  const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
+  for (int q = 0; q < kGroupAngles; ++q) {
+    const int a = a0 + q;
+    int32_t * sgx = s_xy + (size_t)(2 * q) * P;
+    int32_t * sgy = sgx + P;
+    if (a >= job.na) {
+      for (int i = threadIdx.x; i < P; i += blockDim.x) {sgx[i] = 0; sgy[i] = kNotFast;}
+      continue;
+    }
+    const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
+    int32_t * table = job.table + (size_t)a * P;
+    int32_t * slow = job.slow + (size_t)a * P;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+      int32_t idx, gx = 0, gy = kNotFast;
+      if (job.invalid[i]) {
+        idx = kInvalidScan;
+      } else {
+        const double lx = job.local[2 * i], ly = job.local[2 * i + 1];
+        // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
+        const double ox = cosine * lx - sine * ly;
+        const double oy = sine * lx + cosine * ly;
+        const double gxd = ((ox + job.grid_off_x) - job.grid_off_x) * job.scale;
+        const double gyd = ((oy + job.grid_off_y) - job.grid_off_y) * job.scale;
+        gx = d_to_int(d_round(gxd));
+        const int32_t gyi = d_to_int(d_round(gyd));
+        idx = (int32_t)((uint32_t)gx + (uint32_t)gyi * (uint32_t)job.ws);   // base Grid::GridIndex, no ROI
+        if (idx != kInvalidScan) {
+          const bool off_grid = (int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size;
+          const bool inside = (int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size;
+          // the rectangle arithmetic needs the linear index to be exactly gx + gy * ws
+          const bool exact = (int64_t)gx + (int64_t)gyi * job.ws == (int64_t)idx && gx > -(1 << 20) && gx < (1 << 20);
+          if (!off_grid) {
+            if (inside && exact) {gy = gyi;} else {slow[atomicAdd(&s_slow[q], 1)] = idx;}
+          }
+        }
+      }
+      table[i] = idx;
+      sgx[i] = gx; sgy[i] = gy;
+    }
+  }
+  __syncthreads();
+  // ---- one thread per slot: split into sub-chunks, write descriptors and relative offsets ----
+  const int n_slots = (P + kSlotBeams - 1) / kSlotBeams;
+  const int span_x = 68;                                   // bytes a wave may read past a window start (64 + dword slack)
+  const int span_rows = (job.ny - 1) * job.sy_cells + 1;   // grid rows a window covers
+  for (int slot = threadIdx.x; slot < n_slots; slot += blockDim.x) {
+    const int b_lo = slot * kSlotBeams, b_hi = min(P, b_lo + kSlotBeams);
+    ChunkDesc * out = reinterpret_cast<ChunkDesc *>(job.chunks) + ((size_t)group * n_slots + slot) * kSlotBeams;
+    int n_out = 0;
+    int begin = b_lo;
+    while (begin < b_hi) {
+      // largest power-of-two-ish run [begin, end) whose rectangle fits: try the rest of the slot, then halve
+      int end = b_hi;
+      int x0 = 0, y0 = 0, n_dw = 0, pitch = 0, rows = 0;
+      bool any = false;
+      for (;;) {
+        int xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
+        for (int q = 0; q < kGroupAngles; ++q) {
+          const int32_t * sgx = s_xy + (size_t)(2 * q) * P;
+          const int32_t * sgy = sgx + P;
+          for (int i = begin; i < end; ++i) {
+            if (sgy[i] == kNotFast) {continue;}
+            xmin = min(xmin, sgx[i]); xmax = max(xmax, sgx[i]);
+            ymin = min(ymin, sgy[i]); ymax = max(ymax, sgy[i]);
+          }
+        }
+        any = xmin != INT32_MAX;
+        if (!any) {break;}
+        const int al = (int)(((int64_t)job.base0 + xmin) & 3);          // ws % 4 == 0: the same for every row
+        x0 = xmin - al; y0 = ymin;
+        n_dw = (xmax - x0 + span_x + 3) >> 2;
+        int pitch_dw = n_dw;
+        pitch_dw += (16 - (pitch_dw & 31)) & 31;                       // == 16 (mod 32): rows land on disjoint LDS banks
+        pitch = 4 * pitch_dw;
+        rows = (ymax - y0) + span_rows;
+        if ((int64_t)rows * pitch <= kLdsRegionBytes || end - begin == 1) {break;}
+        end = begin + (end - begin + 1) / 2;
+      }
+      if (any) {
+        ChunkDesc d;
+        d.beam_begin = begin; d.beam_end = end;
+        d.g0 = y0 * job.ws + x0;
+        d.n_dw = n_dw; d.pitch = pitch; d.rows = rows; d.pad0 = 0; d.pad1 = 0;
+        // one beam whose windows at the group's angles are too far apart for the LDS budget (long
+        // ranges x coarse angle steps): its windows go through the exact per-pose path instead
+        const bool fits = (int64_t)rows * pitch <= kLdsRegionBytes;
+        if (fits) {out[n_out++] = d;}
+        for (int q = 0; q < kGroupAngles; ++q) {
+          const int a = a0 + q;
+          if (a >= job.na) {continue;}
+          const int32_t * sgx = s_xy + (size_t)(2 * q) * P;
+          const int32_t * sgy = sgx + P;
+          int32_t * rel = job.rel + (size_t)a * P;
+          for (int i = begin; i < end; ++i) {
+            if (sgy[i] == kNotFast) {rel[i] = -1; continue;}
+            if (fits) {
+              rel[i] = (sgy[i] - y0) * pitch + (sgx[i] - x0);
+            } else {
+              rel[i] = -1;
+              (job.slow + (size_t)a * P)[atomicAdd(&s_slow[q], 1)] = sgx[i] + sgy[i] * job.ws;
+            }
+          }
+        }
+      } else {
+        for (int q = 0; q < kGroupAngles; ++q) {
+          const int a = a0 + q;
+          if (a >= job.na) {continue;}
+          int32_t * rel = job.rel + (size_t)a * P;
+          for (int i = begin; i < end; ++i) {rel[i] = -1;}
+        }
+      }
+      begin = end;
+    }
+    job.chunk_counts[(size_t)group * n_slots + slot] = n_out;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGroupAngles && a0 + (int)threadIdx.x < job.na) {
+    job.counts[kCountsPerAngle * (a0 + threadIdx.x) + kClasses] = s_slow[threadIdx.x];
+  }
+}
+
+void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream)
+{
+  if (n_jobs <= 0 || max_na <= 0) {return;}
+  const int groups = (max_na + kGroupAngles - 1) / kGroupAngles;
+  // dynamic LDS: gx, gy of kGroupAngles angles; the host guarantees P <= 2048 on this path
+  const size_t lds = sizeof(int32_t) * 2 * kGroupAngles * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_offsets_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_offsets_lds, dim3(groups, n_jobs), dim3(256), lds, (hipStream_t)stream, d_jobs, stride);
+}
+
+// K3'.  SX = grid cells per lattice step in x.  16 waves: wave = (angle q = wave / 4, row quarter = wave % 4);
+// lane = (lx = lane & 15: 4 consecutive window bytes, ly = lane >> 4); rows yi = 16 * quarter + 4 * r + ly.
+//
+// Pipeline per sub-chunk c: [barrier] registers -> LDS (region c) [barrier] issue the global loads of region
+// c + 1 into registers, then score region c from LDS while they are in flight.  Descriptors are preloaded
+// into LDS, a slot's relative offsets into a register per lane.  A window row is ONE aligned ds_read_b32 per
+// lane; the following dword comes from the neighbouring lane (DPP row_shl:1), v_alignbyte shifts the pair
+// to the window's byte alignment (window byte 60 is the last one that never needs a 17th dword).
+constexpr int kMaxLdsDescs = 160;
+constexpr int kStageRegs = 15;                 // 60 KB / 1024 lanes / 4 B
+
+template <int SX>
+__global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
+{
+  constexpr int RY = 4;
+  constexpr int NB = (SX == 1) ? 4 : 2;
+  int job_index, group;
+  if (xcd_map) {
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    job_index = (qb / groups_max) * 8 + xcd;               // XCD-aware: a job's angle groups share one L2
+    group = qb % groups_max;
+  } else {                                                 // fewer jobs than XCDs: spread the groups over all of them
+    job_index = blockIdx.x / groups_max;
+    group = blockIdx.x % groups_max;
+  }
+  if (job_index >= n_jobs) {return;}
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)job_index * stride);
+  if (group * kGroupAngles >= job.na) {return;}
+  extern __shared__ uint32_t s_region[];
+  __shared__ ChunkDesc s_desc[kMaxLdsDescs];
+  __shared__ int s_ndesc;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 15, ly = lane >> 4;
+  const int q = wave >> 2, quarter = wave & 3;
+  const int a = group * kGroupAngles + q;
+  const bool live = a < job.na;
+  const int P = job.n_points;
+  const int n_slots = (P + kSlotBeams - 1) / kSlotBeams;
+
+  // ---- compact the group's sub-chunk descriptors into LDS (slot order) ----
+  {
+    const ChunkDesc * descs = reinterpret_cast<const ChunkDesc *>(job.chunks) + (size_t)group * n_slots * kSlotBeams;
+    const int32_t * counts = job.chunk_counts + (size_t)group * n_slots;
+    if (wave == 0) {
+      // exclusive scan of the per-slot counts (n_slots <= 64 on this path: P <= 2048)
+      const int cnt = lane < n_slots ? counts[lane] : 0;
+      int incl = cnt;
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) {
+        const int o = __shfl_up(incl, sft);
+        if (lane >= sft) {incl += o;}
+      }
+      const int excl = incl - cnt;
+      for (int k = 0; k < cnt; ++k) {
+        if (excl + k < kMaxLdsDescs) {s_desc[excl + k] = descs[(size_t)lane * kSlotBeams + k];}
+      }
+      if (lane == 63) {s_ndesc = incl;}
+    }
+  }
+  __syncthreads();
+  const int n_desc = min(s_ndesc, kMaxLdsDescs);
+  const bool overflow = s_ndesc > kMaxLdsDescs;       // pathological scans: handled below through the exact path
+
+  int row_cells[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    int yi = 16 * quarter + 4 * r + ly;
+    yi = yi < job.ny ? yi : job.ny - 1;
+    row_cells[r] = yi * job.sy_cells;
+  }
+  int32_t acc[RY][NB];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {acc[r][b] = 0;}
+  }
+  uint32_t lo[RY], hi[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {lo[r] = 0; hi[r] = 0;}
+  int since_flush = 0;
+
+  const gbyte * gwin = as_global(job.grid) + job.base0;
+  const gint * grel = as_global(job.rel + (size_t)(live ? a : 0) * P);
+
+  uint32_t stage[kStageRegs];
+  auto issue_loads = [&](const ChunkDesc & d) {
+    const gbyte * src = gwin + d.g0;
+    const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)d.n_dw - 1) / (uint32_t)d.n_dw);
+    const int total = d.rows * d.n_dw;
+#pragma unroll
+    for (int u = 0; u < kStageRegs; ++u) {
+      const int t = tid + 1024 * u;
+      const int row = (int)__umulhi((uint32_t)t, magic);
+      const int col = t - row * d.n_dw;
+      stage[u] = t < total ? *reinterpret_cast<const gu32 *>(src + (int64_t)row * job.ws + 4 * col) : 0u;
+    }
+  };
+  auto store_region = [&](const ChunkDesc & d) {
+    const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)d.n_dw - 1) / (uint32_t)d.n_dw);
+    const int total = d.rows * d.n_dw;
+    const int pitch_dw = d.pitch >> 2;
+#pragma unroll
+    for (int u = 0; u < kStageRegs; ++u) {
+      const int t = tid + 1024 * u;
+      const int row = (int)__umulhi((uint32_t)t, magic);
+      const int col = t - row * d.n_dw;
+      if (t < total) {s_region[row * pitch_dw + col] = stage[u];}
+    }
+  };
+
+  if (n_desc > 0) {issue_loads(s_desc[0]);}
+  int32_t slot_rel = -1;
+  int cur_slot = -1;
+  for (int c = 0; c < n_desc; ++c) {
+    const ChunkDesc d = s_desc[c];
+    __syncthreads();                                 // everybody is done reading the previous region
+    store_region(d);
+    __syncthreads();
+    if (c + 1 < n_desc) {issue_loads(s_desc[c + 1]);}
+    if (!live) {continue;}
+    const int slot = d.beam_begin / kSlotBeams;
+    if (slot != cur_slot) {                          // wave-uniform
+      cur_slot = slot;
+      const int i = slot * kSlotBeams + lane;
+      slot_rel = (lane < kSlotBeams && i < P) ? grel[i] : -1;
+    }
+    int row_off[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {row_off[r] = (row_cells[r] * d.pitch + 4 * lx) >> 2;}
+    const int k_lo = d.beam_begin - slot * kSlotBeams, k_hi = d.beam_end - slot * kSlotBeams;
+    for (int k = k_lo; k < k_hi; ++k) {
+      const int32_t rel = __builtin_amdgcn_readlane(slot_rel, k);
+      if (rel < 0) {continue;}                       // wave-uniform
+      const int sh = rel & 3;
+      const uint32_t * pw = s_region + (rel >> 2);
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        const uint32_t w0 = pw[row_off[r]];
+        // dword of lane lx + 1 of the same row (lane 15 of a row gets 0: only window bytes > 60 need it)
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x101, 0xf, 0xf, true);   // row_shl:1
+        const uint32_t w = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        lo[r] += w & 0x00ff00ffu;                                           // [0, b2, 0, b0]
+        if (SX == 1) {hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);}   // [0, b3, 0, b1]
+      }
+      if (++since_flush == 512) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+          if (SX == 1) {
+            acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
+            acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
+          } else {
+            acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
+          }
+          lo[r] = 0; hi[r] = 0;
+        }
+        since_flush = 0;
+      }
+    }
+  }
+  if (!live) {return;}
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    if (SX == 1) {
+      acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
+      acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
+    } else {
+      acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
+    }
+  }
+
+  // epilogue: every pose is owned by exactly one lane
+  const int n_slow = job.counts[kCountsPerAngle * a + kClasses];
+  const int32_t * slow = job.slow + (size_t)a * P;
+  double best = 0.0;
+  const size_t plane = (size_t)job.nx * job.ny;
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    const int yi = 16 * quarter + 4 * r + ly;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int xi = NB * lx + b;
+      if (xi >= job.nx || yi >= job.ny) {continue;}
+      int32_t sum = acc[r][b];
+      const int64_t pose = (int64_t)job.bx[xi] + (int64_t)job.by[yi];
+      if (n_slow > 0) {
+        // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197)
+        for (int j = 0; j < n_slow; ++j) {
+          const int64_t idx = pose + slow[j];
+          if (idx >= 0 && idx < job.data_size) {sum += job.grid[idx];}
+        }
+      }
+      if (overflow) {
+        // more sub-chunks than descriptor slots in LDS: the remaining beams go through the table
+        const ChunkDesc * descs = reinterpret_cast<const ChunkDesc *>(job.chunks) + (size_t)group * n_slots * kSlotBeams;
+        const int32_t * counts = job.chunk_counts + (size_t)group * n_slots;
+        const int32_t * table = job.table + (size_t)a * P;
+        int seen = 0;
+        for (int sl = 0; sl < n_slots; ++sl) {
+          for (int k = 0; k < counts[sl]; ++k, ++seen) {
+            if (seen < kMaxLdsDescs) {continue;}
+            const ChunkDesc dd = descs[(size_t)sl * kSlotBeams + k];
+            for (int i = dd.beam_begin; i < dd.beam_end; ++i) {
+              if (grel[i] >= 0) {sum += job.grid[pose + table[i]];}
+            }
+          }
+        }
+      }
+      const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
+      job.sums[o] = sum;
+      const double response = pose_response(job, sum, a, yi, xi);
+      if (job.write_resp) {job.resp[o] = response;}
+      best = response > best ? response : best;
+      if (job.coarse && response > 0.0) {
+        atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
+      }
+    }
+  }
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) {
+    const double o = __shfl_xor(best, sft);
+    best = o > best ? o : best;
+  }
+  if (lane == 0 && best > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(best));}
+}
+
+void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream)
+{
+  if (n_jobs <= 0 || max_na <= 0) {return;}
+  const int groups = (max_na + kGroupAngles - 1) / kGroupAngles;
+  const int xcd_map = n_jobs >= 8 ? 1 : 0;
+  const int jobs_per_xcd = (n_jobs + 7) / 8;
+  const long long blocks = xcd_map ? 8ll * jobs_per_xcd * groups : (long long)n_jobs * groups;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRegionBytes + 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRegionBytes + 256);
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (sx_variant == 2) {
+    hipLaunchKernelGGL(k_score_lds<2>, dim3((unsigned int)blocks), dim3(1024), kLdsRegionBytes + 256, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
+  } else {
+    hipLaunchKernelGGL(k_score_lds<1>, dim3((unsigned int)blocks), dim3(1024), kLdsRegionBytes + 256, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
+  }
+}
+
+}  // namespace kh

@@ -183,3 +183,38 @@ def test_search_resolution_off_the_grid_pitch(kartohip_lib, search_res):
     _assert_same(r_o, r_h, "response")
     _assert_same(mean_o, mean_h, "mean")
     hm.close()
+
+
+@pytest.mark.parametrize("preset,fine", [("K", False), ("S", False), ("S", True), ("C2", False)])
+def test_lds_staged_scoring_path(kartohip_lib, preset, fine):
+    """The experimental LDS-staged scoring kernels (k_offsets_lds / k_score_lds: window unions of beam
+    sub-chunks staged through LDS, 4 adjacent angles per workgroup) must produce the same volume bit for
+    bit; K also exercises the fallback of beams whose windows are too far apart for the LDS budget."""
+    import math
+    sc = Scenario(seed=5, n_base=8, start=60, perturb=(-0.04, 0.06, -0.03))
+    oq, ob = sc.oracle_scans()
+    hq, hb = sc.hip_scans()
+    om = make_oracle_matcher(preset, threads=8)
+    hm = make_hip_matcher(preset)
+    hm.set_debug(True, lds_score=True)
+    om.add_scans(oq, ob)
+    hm.AddScans(hq, hb)
+    res = 1.0 / om.grid_info()["scale"]
+    p = PRESETS[preset]["params"]
+    if preset == "C2":
+        args = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+    elif fine:
+        args = ((res, res), (res, res), 0.5 * p["coarse_angle_resolution"], p["fine_search_angle_offset"])
+    else:
+        side = PRESETS[preset]["create"][0]
+        off = 0.5 * round(side / res) * res
+        args = ((off, off), (2 * res, 2 * res), p["coarse_search_angle_offset"], p["coarse_angle_resolution"])
+    r_o, mean_o, cov_o = om.correlate_scan(oq, sc.query_pose, *args, True, fine)
+    r_h, mean_h, cov_h = hm.CorrelateScan(hq, sc.query_pose, *args, True, None, fine)
+    vol = om.volume()
+    sums, resp = hm.volume()
+    assert np.array_equal(om.lookup_table(), hm.lookup_table())
+    assert np.array_equal(bits(vol[..., 0]), bits(resp)), "response volume differs"
+    _assert_same(r_o, r_h, "response")
+    _assert_same(mean_o, mean_h, "mean")
+    hm.close()
