@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -24,6 +25,7 @@
 #include <limits>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -174,71 +176,86 @@ static double karto_normalize_angle(double angle)   // Math.h:181-202
 // drifted.  Leaves and separators become the supernodes of the multifrontal factorisation.
 struct NdContext
 {
-  const std::vector<std::vector<int32_t>> * adj;
+  // adjacency in CSR form (contiguous: the three BFS passes per subset are the cost of the ordering)
+  std::vector<int32_t> adj_ptr, adj_idx;
   std::vector<int32_t> tag;           // subset membership stamp
   std::vector<int32_t> dist;          // BFS level
-  std::vector<std::vector<int32_t>> supernodes;
-  int32_t stamp = 0;
+  std::atomic<int32_t> stamp{0};      // sibling subsets are dissected concurrently on disjoint vertices
   int32_t leaf = 12;
+  int32_t parallel_depth = 3;         // recursion levels whose two halves run on separate threads
 };
+using SupernodeList = std::vector<std::vector<int32_t>>;
 
 // BFS inside the subset stamped `st`; returns the visit order (levels in ctx.dist)
 static void nd_bfs(NdContext & ctx, int32_t start, int32_t st, std::vector<int32_t> & order)
 {
-  const auto & adj = *ctx.adj;
   order.clear();
   order.push_back(start);
   ctx.dist[start] = 0;
   ctx.tag[start] = -st;               // visited marker
   for (size_t h = 0; h < order.size(); ++h) {
     const int32_t v = order[h];
-    for (int32_t w : adj[v]) {
-      if (ctx.tag[w] == st) {ctx.tag[w] = -st; ctx.dist[w] = ctx.dist[v] + 1; order.push_back(w);}
+    const int32_t dv = ctx.dist[v] + 1;
+    for (int32_t k = ctx.adj_ptr[v]; k < ctx.adj_ptr[v + 1]; ++k) {
+      const int32_t w = ctx.adj_idx[k];
+      if (ctx.tag[w] == st) {ctx.tag[w] = -st; ctx.dist[w] = dv; order.push_back(w);}
     }
   }
   for (int32_t v : order) {ctx.tag[v] = st;}
 }
 
-static void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes)
+// appends the supernodes of `nodes` to `out` in elimination order (A's, B's, then the separator)
+static void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & out, int depth)
 {
   if (nodes.empty()) {return;}
   if (static_cast<int32_t>(nodes.size()) <= ctx.leaf) {
     std::sort(nodes.begin(), nodes.end());
-    ctx.supernodes.push_back(nodes);
+    out.push_back(nodes);
     return;
   }
-  const auto & adj = *ctx.adj;
   const int32_t st = ++ctx.stamp;
   for (int32_t v : nodes) {ctx.tag[v] = st;}
   std::vector<int32_t> order;
+  order.reserve(nodes.size());
   nd_bfs(ctx, nodes[0], st, order);
+  auto both = [&](std::vector<int32_t> & A, std::vector<int32_t> & B) {
+    if (depth < ctx.parallel_depth && A.size() > 256 && B.size() > 256) {
+      SupernodeList out_b;
+      std::thread tb([&] {nd_recurse(ctx, B, out_b, depth + 1);});
+      nd_recurse(ctx, A, out, depth + 1);
+      tb.join();
+      for (auto & sn : out_b) {out.push_back(std::move(sn));}
+    } else {
+      nd_recurse(ctx, A, out, depth + 1);
+      nd_recurse(ctx, B, out, depth + 1);
+    }
+  };
   if (order.size() < nodes.size()) {
     // disconnected subset: split off this component, recurse on both parts (independent subtrees)
     std::vector<int32_t> comp = order, rest;
     for (int32_t v : comp) {ctx.tag[v] = 0;}
     for (int32_t v : nodes) {if (ctx.tag[v] == st) {rest.push_back(v);}}
-    nd_recurse(ctx, comp);
-    nd_recurse(ctx, rest);
+    both(comp, rest);
     return;
   }
-  // pseudo-peripheral start: restart the BFS from the farthest vertex (twice)
-  for (int it = 0; it < 2; ++it) {
+  // pseudo-peripheral start: restart the BFS from the farthest vertex
+  {
     const int32_t far = order.back();
     nd_bfs(ctx, far, st, order);
   }
-  const int32_t depth = ctx.dist[order.back()];
-  if (depth < 2) {                    // clique-like: no level can separate anything
+  const int32_t depth_bfs = ctx.dist[order.back()];
+  if (depth_bfs < 2) {                // clique-like: no level can separate anything
     std::sort(nodes.begin(), nodes.end());
-    ctx.supernodes.push_back(nodes);
+    out.push_back(nodes);
     return;
   }
-  std::vector<int32_t> level_count(depth + 1, 0);
+  std::vector<int32_t> level_count(depth_bfs + 1, 0);
   for (int32_t v : order) {level_count[ctx.dist[v]]++;}
   // separator level: the smallest level among those that leave 25%..75% of the vertices on the near
   // side; if the level structure is too coarse for that, the level closest to the median
   const double total = static_cast<double>(order.size());
   int32_t best = -1, fallback = 1; double best_count = 1e300, fallback_dist = 1e300; int32_t below = 0;
-  for (int32_t l = 1; l < depth; ++l) {
+  for (int32_t l = 1; l < depth_bfs; ++l) {
     below += level_count[l - 1];
     const double mid = (below + 0.5 * level_count[l]) / total;
     if (std::fabs(mid - 0.5) < fallback_dist) {fallback_dist = std::fabs(mid - 0.5); fallback = l;}
@@ -250,19 +267,21 @@ static void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes)
     const int32_t d = ctx.dist[v];
     if (d < best) {A.push_back(v);} else if (d > best) {B.push_back(v);} else {
       bool touches_far = false;
-      for (int32_t w : adj[v]) {if (ctx.tag[w] == st && ctx.dist[w] == best + 1) {touches_far = true; break;}}
+      for (int32_t k = ctx.adj_ptr[v]; k < ctx.adj_ptr[v + 1]; ++k) {
+        const int32_t w = ctx.adj_idx[k];
+        if (ctx.tag[w] == st && ctx.dist[w] == best + 1) {touches_far = true; break;}
+      }
       if (touches_far) {S.push_back(v);} else {A.push_back(v);}
     }
   }
   if (S.empty() || A.empty() || B.empty()) {
     std::sort(nodes.begin(), nodes.end());
-    ctx.supernodes.push_back(nodes);
+    out.push_back(nodes);
     return;
   }
-  nd_recurse(ctx, A);
-  nd_recurse(ctx, B);
+  both(A, B);
   std::sort(S.begin(), S.end());
-  ctx.supernodes.push_back(S);
+  out.push_back(S);
 }
 
 static int build_symbolic(
@@ -272,14 +291,18 @@ static int build_symbolic(
   sym = Symbolic();
   sym.n_free = n_free;
   NdContext ctx;
-  ctx.adj = &adj;
   (void)px; (void)py;
+  ctx.adj_ptr.assign(n_free + 1, 0);
+  for (int32_t i = 0; i < n_free; ++i) {ctx.adj_ptr[i + 1] = ctx.adj_ptr[i] + static_cast<int32_t>(adj[i].size());}
+  ctx.adj_idx.resize(ctx.adj_ptr[n_free]);
+  for (int32_t i = 0; i < n_free; ++i) {std::copy(adj[i].begin(), adj[i].end(), ctx.adj_idx.begin() + ctx.adj_ptr[i]);}
   ctx.tag.assign(n_free, 0);
   ctx.dist.assign(n_free, 0);
   std::vector<int32_t> all(n_free);
   for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
-  nd_recurse(ctx, all);
-  const int32_t K = static_cast<int32_t>(ctx.supernodes.size());
+  SupernodeList supernodes;
+  nd_recurse(ctx, all, supernodes, 0);
+  const int32_t K = static_cast<int32_t>(supernodes.size());
   sym.n_fronts = K;
   sym.elim_of_free.assign(n_free, -1);
   sym.free_of_elim.assign(n_free, -1);
@@ -288,7 +311,7 @@ static int build_symbolic(
   int32_t pos = 0;
   for (int32_t k = 0; k < K; ++k) {
     sym.sn_first[k] = pos;
-    for (int32_t v : ctx.supernodes[k]) {
+    for (int32_t v : supernodes[k]) {
       sym.elim_of_free[v] = pos; sym.free_of_elim[pos] = v; sym.sn_of_elim[pos] = k; ++pos;
     }
   }
@@ -404,20 +427,32 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     }
     const int32_t nf = static_cast<int32_t>(s->node_of_free.size());
     if (nf == 0 || E == 0) {s->topology_dirty = true; return KH_OK;}
-    // adjacency + BSR pattern over the free nodes
-    std::vector<std::vector<int32_t>> adj(nf);
+    // adjacency + BSR pattern over the free nodes (flat CSR arrays, counting passes: no per-row vectors)
+    std::vector<int32_t> deg(nf + 1, 0);
     for (int32_t e = 0; e < E; ++e) {
       const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
-      if (fa >= 0 && fb >= 0 && fa != fb) {adj[fa].push_back(fb); adj[fb].push_back(fa);}
+      if (fa >= 0 && fb >= 0 && fa != fb) {++deg[fa + 1]; ++deg[fb + 1];}
     }
+    for (int32_t i = 0; i < nf; ++i) {deg[i + 1] += deg[i];}
+    std::vector<int32_t> nbr(deg[nf]), fill(deg.begin(), deg.end() - 1);
+    for (int32_t e = 0; e < E; ++e) {
+      const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
+      if (fa >= 0 && fb >= 0 && fa != fb) {nbr[fill[fa]++] = fb; nbr[fill[fb]++] = fa;}
+    }
+    std::vector<std::vector<int32_t>> adj(nf);
     std::vector<int32_t> row_ptr(nf + 1, 0), col, diag(nf), slot_row;
+    col.reserve(deg[nf] + nf); slot_row.reserve(deg[nf] + nf);
     for (int32_t i = 0; i < nf; ++i) {
-      auto & a = adj[i];
-      std::sort(a.begin(), a.end());
-      a.erase(std::unique(a.begin(), a.end()), a.end());
-      std::vector<int32_t> r = a;
-      r.insert(std::lower_bound(r.begin(), r.end(), i), i);
-      for (int32_t j : r) {if (j == i) {diag[i] = static_cast<int32_t>(col.size());} col.push_back(j); slot_row.push_back(i);}
+      int32_t * b = nbr.data() + deg[i], * e2 = nbr.data() + deg[i + 1];
+      std::sort(b, e2);
+      e2 = std::unique(b, e2);
+      adj[i].assign(b, e2);
+      bool placed = false;
+      for (int32_t * q = b; q < e2; ++q) {
+        if (!placed && *q > i) {diag[i] = static_cast<int32_t>(col.size()); col.push_back(i); slot_row.push_back(i); placed = true;}
+        col.push_back(*q); slot_row.push_back(i);
+      }
+      if (!placed) {diag[i] = static_cast<int32_t>(col.size()); col.push_back(i); slot_row.push_back(i);}
       row_ptr[i + 1] = static_cast<int32_t>(col.size());
     }
     const int32_t n_slots = static_cast<int32_t>(col.size());
@@ -425,19 +460,31 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       const auto b = col.begin() + row_ptr[i], e2 = col.begin() + row_ptr[i + 1];
       return static_cast<int32_t>(std::lower_bound(b, e2, j) - col.begin());
     };
-    std::vector<std::vector<int32_t>> sc(n_slots), nc(nf);
+    // contribution lists of the gather kernels: two counting passes in edge order (same order as before:
+    // ascending edge index within every slot / node)
+    std::vector<int32_t> scp(n_slots + 1, 0), ncp(nf + 1, 0);
+    std::vector<int32_t> e_slots(static_cast<size_t>(E) * 4, -1);
     for (int32_t e = 0; e < E; ++e) {
       const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
-      if (fa >= 0) {sc[slot_of(fa, fa)].push_back(e * 4 + 0); nc[fa].push_back(e * 2 + 0);}
-      if (fb >= 0) {sc[slot_of(fb, fb)].push_back(e * 4 + 1); nc[fb].push_back(e * 2 + 1);}
+      if (fa >= 0) {e_slots[4 * e + 0] = diag[fa]; ++scp[diag[fa] + 1]; ++ncp[fa + 1];}
+      if (fb >= 0) {e_slots[4 * e + 1] = diag[fb]; ++scp[diag[fb] + 1]; ++ncp[fb + 1];}
       if (fa >= 0 && fb >= 0 && fa != fb) {
-        sc[slot_of(fa, fb)].push_back(e * 4 + 2);
-        sc[slot_of(fb, fa)].push_back(e * 4 + 3);
+        e_slots[4 * e + 2] = slot_of(fa, fb); e_slots[4 * e + 3] = slot_of(fb, fa);
+        ++scp[e_slots[4 * e + 2] + 1]; ++scp[e_slots[4 * e + 3] + 1];
       }
     }
-    std::vector<int32_t> scp(n_slots + 1, 0), scl, ncp(nf + 1, 0), ncl;
-    for (int32_t k = 0; k < n_slots; ++k) {scl.insert(scl.end(), sc[k].begin(), sc[k].end()); scp[k + 1] = static_cast<int32_t>(scl.size());}
-    for (int32_t i = 0; i < nf; ++i) {ncl.insert(ncl.end(), nc[i].begin(), nc[i].end()); ncp[i + 1] = static_cast<int32_t>(ncl.size());}
+    for (int32_t k = 0; k < n_slots; ++k) {scp[k + 1] += scp[k];}
+    for (int32_t i = 0; i < nf; ++i) {ncp[i + 1] += ncp[i];}
+    std::vector<int32_t> scl(scp[n_slots]), ncl(ncp[nf]), sfill(scp.begin(), scp.end() - 1), nfill(ncp.begin(), ncp.end() - 1);
+    for (int32_t e = 0; e < E; ++e) {
+      const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
+      for (int kind = 0; kind < 4; ++kind) {
+        const int32_t sl = e_slots[4 * e + kind];
+        if (sl >= 0) {scl[sfill[sl]++] = e * 4 + kind;}
+      }
+      if (fa >= 0) {ncl[nfill[fa]++] = e * 2 + 0;}
+      if (fb >= 0) {ncl[nfill[fb]++] = e * 2 + 1;}
+    }
     // ordering + fronts
     std::vector<double> px(nf), py(nf);
     for (int32_t i = 0; i < nf; ++i) {px[i] = s->nodes[s->node_of_free[i]].pose[0]; py[i] = s->nodes[s->node_of_free[i]].pose[1];}
