@@ -181,6 +181,39 @@ def loop_leg(device=0, n_pairs=256, distinct=32, batch=64):
                              f"{sum(t[1] for t in table)} of them passing the gate -> preset S coarse+fine"}
 
 
+def enumeration_leg(device=0, n_scans=10000, n_queries=256):
+    """Next row f-1: loop-candidate enumeration -- FindNearLinkedScans + every chain
+    FindPossibleLoopClosure returns -- for a batch of query scans on the 10k-node graph (odometry chain + a
+    tenth of the near-pair links, so revisited aisles hold unlinked runs).  Extra keys, rank 0."""
+    from slam_toolbox_amd import synth
+    from slam_toolbox_amd.loop_search import MapperGraphSearch
+    g = synth.make_pose_graph(n_scans, 3 * n_scans, seed=12345)
+    xy = g["truth"][:, :2].copy()
+    edges = np.concatenate([g["edges"][:n_scans - 1], g["edges"][n_scans - 1::10]])
+    nbr = [[] for _ in range(n_scans)]
+    for a, b in edges:
+        nbr[a].append(b)
+        nbr[b].append(a)
+    ptr = np.zeros(n_scans + 1, dtype=np.int32)
+    ptr[1:] = np.cumsum([len(v) for v in nbr])
+    idx = np.asarray([w for v in nbr for w in v], dtype=np.int32)
+    s = MapperGraphSearch(device)
+    s.SetGraph(xy, ptr, idx)
+    queries = np.linspace(0, n_scans - 1, n_queries).astype(np.int32)
+    s.FindPossibleLoopClosures(queries, 3.0, 10)
+    times, kernel = [], []
+    for _ in range(10):
+        t = time.perf_counter()
+        out = s.FindPossibleLoopClosures(queries, 3.0, 10)
+        times.append(time.perf_counter() - t)
+        kernel.append(s.last_kernel_ms())
+    s.close()
+    med = float(np.median(times))
+    return {"loop_enumeration_queries_per_s": n_queries / med, "loop_enumeration_kernel_ms": float(np.median(kernel)),
+            "loop_enumeration_workload": f"{n_queries} query scans x {n_scans}-scan graph ({len(edges)} edges), "
+                                         f"{sum(len(c) for c in out)} chains, loop_search_maximum_distance 3.0, chain >= 10"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,6 +315,7 @@ def main():
             out.update(solver_out)
         if world == 1 and not args.no_loop:
             out.update(loop_leg(local_rank))
+            out.update(enumeration_leg(local_rank))
         print(json.dumps(out))
     hm.close()
     if world > 1:

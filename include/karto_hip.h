@@ -222,6 +222,29 @@ KH_API int kh_spa_get_corrections(kh_spa * s, int32_t * n, int32_t * ids, double
 KH_API int kh_link_info(const double pose1[3], const double pose2[3], const double cov[9],
                         double pose_difference[3], double cov_out[9]);
 
+/* ---------------------------------------------------------------- loop-candidate enumeration (next row f-1) */
+/* GPU-resident copy of what karto::MapperGraph's candidate search reads: the reference position
+ * GetReferencePose(use_scan_barycenter) of every scan of a sensor in scan-list order (NULL scans left out:
+ * the reference skips them, Mapper.cpp:1980-1982) and the adjacency of the pose graph in CSR form with the
+ * neighbours in Vertex::GetAdjacentVertices order (Mapper.h:338-361).  Indices are positions in that list. */
+typedef struct kh_graph kh_graph;
+KH_API int kh_graph_create(int32_t device, kh_graph ** out);
+KH_API void kh_graph_destroy(kh_graph * g);
+KH_API int kh_graph_set(kh_graph * g, int32_t n_scans, const double * ref_xy /* 2n */,
+                        const int32_t * adj_ptr /* n+1 */, const int32_t * adj_idx);
+KH_API int kh_graph_set_positions(kh_graph * g, int32_t n_scans, const double * ref_xy);   /* after CorrectPoses */
+/* For every query scan: all the chains successive MapperGraph::FindPossibleLoopClosure calls return
+ * (Mapper.cpp:1960-2010, enumerated like TryCloseLoop does, Mapper.cpp:1500-1560), FindNearLinkedScans
+ * (Mapper.cpp:1795-1806) included, for the CURRENT graph state (speculative batch).
+ * Chains are runs of consecutive scans: chains[2k], chains[2k+1] = first, last index; query i owns
+ * chains chain_begin[i] .. chain_begin[i+1]-1 (n_queries+1 entries).  *n_chains is the total even when it
+ * exceeds cap_chains (then only the first cap_chains are written). */
+KH_API int kh_graph_find_loop_candidates(kh_graph * g, int32_t n_queries, const int32_t * query_scans,
+                                         double loop_search_maximum_distance, int32_t loop_match_minimum_chain_size,
+                                         int32_t * chain_begin, int32_t * chains, int32_t cap_chains,
+                                         int32_t * n_chains);
+KH_API double kh_graph_last_kernel_ms(kh_graph * g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,11 @@
 #include <thread>
 #include <iomanip>
 
+#define private public
+#define protected public
 #include "karto_sdk/Mapper.h"
+#undef private
+#undef protected
 #include "karto_hip/karto_adaptor.hpp"
 
 using namespace karto;
@@ -81,9 +85,106 @@ private:
   karto_hip::HipSpaSolver m_Inner;
 };
 
+// config/mapper_params_offline.yaml:31-66
+void configure_offline(Mapper & mapper, double loop_search_distance)
+{
+  mapper.setParamUseScanMatching(true);
+  mapper.setParamUseScanBarycenter(true);
+  mapper.setParamMinimumTravelDistance(0.5);
+  mapper.setParamMinimumTravelHeading(0.5);
+  mapper.setParamScanBufferSize(10);
+  mapper.setParamScanBufferMaximumScanDistance(10.0);
+  mapper.setParamLinkMatchMinimumResponseFine(0.1);
+  mapper.setParamLinkScanMaximumDistance(1.5);
+  mapper.setParamLoopSearchMaximumDistance(loop_search_distance);
+  mapper.setParamDoLoopClosing(true);
+  mapper.setParamLoopMatchMinimumChainSize(10);
+  mapper.setParamLoopMatchMaximumVarianceCoarse(3.0);
+  mapper.setParamLoopMatchMinimumResponseCoarse(0.35);
+  mapper.setParamLoopMatchMinimumResponseFine(0.45);
+  mapper.setParamCorrelationSearchSpaceDimension(0.5);
+  mapper.setParamCorrelationSearchSpaceResolution(0.01);
+  mapper.setParamCorrelationSearchSpaceSmearDeviation(0.1);
+  mapper.setParamLoopSearchSpaceDimension(8.0);
+  mapper.setParamLoopSearchSpaceResolution(0.05);
+  mapper.setParamLoopSearchSpaceSmearDeviation(0.03);
+  mapper.setParamDistanceVariancePenalty(0.5);
+  mapper.setParamAngleVariancePenalty(1.0);
+  mapper.setParamFineSearchAngleOffset(0.00349);
+  mapper.setParamCoarseSearchAngleOffset(0.349);
+  mapper.setParamCoarseAngleResolution(0.0349);
+  mapper.setParamMinimumAnglePenalty(0.9);
+  mapper.setParamMinimumDistancePenalty(0.5);
+  mapper.setParamUseResponseExpansion(true);
+}
+
 }  // namespace
 
 extern "C" {
+
+// Golden data for the loop-candidate enumeration: runs the scan queue through the
+// reference Mapper WITHOUT a solver (CorrectPoses is then a no-op, Mapper.cpp:2016; loop closures still add
+// their edges), then dumps the graph -- reference positions GetReferencePose(useScanBarycenter) in scan
+// list order, adjacency in Vertex::GetAdjacentVertices order (Mapper.h:338-361) -- and, for every scan as
+// query, FindNearLinkedScans (Mapper.cpp:1795-1806) and the chains successive FindPossibleLoopClosure calls
+// return (Mapper.cpp:1960-2010, driven like TryCloseLoop does, Mapper.cpp:1500-1560).
+int ref_slam_enumerate(
+  int n_scans, int n_beams, const double * ranges, const double * odom, double loop_search_distance,
+  const char * out_path)
+{
+  FILE * out = std::fopen(out_path, "w");
+  if (!out) {return -2;}
+  int accepted = 0;
+  try {
+    Mapper mapper;
+    configure_offline(mapper, loop_search_distance);
+    for (int i = 0; i < n_scans; ++i) {
+      RangeReadingsVector r(ranges + static_cast<size_t>(i) * n_beams, ranges + static_cast<size_t>(i + 1) * n_beams);
+      LocalizedRangeScan * s = new LocalizedRangeScan(Name("laser0"), r);
+      const Pose2 p(odom[3 * i], odom[3 * i + 1], odom[3 * i + 2]);
+      s->SetOdometricPose(p);
+      s->SetCorrectedPose(p);
+      s->SetTime(0.1 * i);
+      Matrix3 cov;
+      if (mapper.Process(s, &cov)) {++accepted;} else {delete s;}
+    }
+    const Name sensor("laser0");
+    MapperGraph * graph = mapper.m_pGraph;
+    const kt_bool bary = mapper.m_pUseScanBarycenter->GetValue();
+    // MapperSensorManager::GetScans is an inline of Mapper.cpp; GetAllScans returns the same scans in scan-id order
+    const LocalizedRangeScanVector scans = mapper.m_pMapperSensorManager->GetAllScans();
+    std::fprintf(out, "G %d %.17g %u\n", accepted, loop_search_distance, mapper.m_pLoopMatchMinimumChainSize->GetValue());
+    for (LocalizedRangeScan * s : scans) {
+      const Pose2 p = s->GetReferencePose(bary);
+      std::fprintf(out, "S %d %.17g %.17g\n", s->GetStateId(), p.GetX(), p.GetY());
+      std::vector<Vertex<LocalizedRangeScan> *> adj = graph->GetVertex(s)->GetAdjacentVertices();
+      std::fprintf(out, "A %d %zu", s->GetStateId(), adj.size());
+      for (auto * v : adj) {std::fprintf(out, " %d", v->GetObject()->GetStateId());}
+      std::fprintf(out, "\n");
+    }
+    for (LocalizedRangeScan * q : scans) {
+      const LocalizedRangeScanVector linked = graph->FindNearLinkedScans(q, loop_search_distance);
+      std::fprintf(out, "L %d %zu", q->GetStateId(), linked.size());
+      for (auto * s : linked) {std::fprintf(out, " %d", s->GetStateId());}
+      std::fprintf(out, "\n");
+      kt_int32u start = 0;
+      LocalizedRangeScanVector chain = graph->FindPossibleLoopClosure(q, sensor, start);
+      while (!chain.empty()) {
+        std::fprintf(out, "H %d %u %zu", q->GetStateId(), start, chain.size());
+        for (auto * s : chain) {std::fprintf(out, " %d", s->GetStateId());}
+        std::fprintf(out, "\n");
+        chain = graph->FindPossibleLoopClosure(q, sensor, start);
+      }
+    }
+  } catch (const std::exception & e) {
+    std::fprintf(out, "! %s\n", e.what());
+    std::fclose(out);
+    return -1;
+  }
+  std::fclose(out);
+  return accepted;
+}
+
 
 // Runs the scan queue through karto::Mapper::Process with the GPU solver plugin attached.  `ranges` is
 // n_scans x n_beams, `odom` n_scans x 3.  Writes the call log to `log_path` and the final corrected pose of
@@ -98,35 +199,7 @@ int ref_slam_run(
   int accepted = 0;
   try {
     Mapper mapper;
-    // config/mapper_params_offline.yaml:31-66
-    mapper.setParamUseScanMatching(true);
-    mapper.setParamUseScanBarycenter(true);
-    mapper.setParamMinimumTravelDistance(0.5);
-    mapper.setParamMinimumTravelHeading(0.5);
-    mapper.setParamScanBufferSize(10);
-    mapper.setParamScanBufferMaximumScanDistance(10.0);
-    mapper.setParamLinkMatchMinimumResponseFine(0.1);
-    mapper.setParamLinkScanMaximumDistance(1.5);
-    mapper.setParamLoopSearchMaximumDistance(loop_search_distance);
-    mapper.setParamDoLoopClosing(true);
-    mapper.setParamLoopMatchMinimumChainSize(10);
-    mapper.setParamLoopMatchMaximumVarianceCoarse(3.0);
-    mapper.setParamLoopMatchMinimumResponseCoarse(0.35);
-    mapper.setParamLoopMatchMinimumResponseFine(0.45);
-    mapper.setParamCorrelationSearchSpaceDimension(0.5);
-    mapper.setParamCorrelationSearchSpaceResolution(0.01);
-    mapper.setParamCorrelationSearchSpaceSmearDeviation(0.1);
-    mapper.setParamLoopSearchSpaceDimension(8.0);
-    mapper.setParamLoopSearchSpaceResolution(0.05);
-    mapper.setParamLoopSearchSpaceSmearDeviation(0.03);
-    mapper.setParamDistanceVariancePenalty(0.5);
-    mapper.setParamAngleVariancePenalty(1.0);
-    mapper.setParamFineSearchAngleOffset(0.00349);
-    mapper.setParamCoarseSearchAngleOffset(0.349);
-    mapper.setParamCoarseAngleResolution(0.0349);
-    mapper.setParamMinimumAnglePenalty(0.9);
-    mapper.setParamMinimumDistancePenalty(0.5);
-    mapper.setParamUseResponseExpansion(true);
+    configure_offline(mapper, loop_search_distance);
     RecordingSolver solver(log);
     mapper.SetScanSolver(&solver);
     std::vector<LocalizedRangeScan *> kept;

@@ -65,6 +65,8 @@ SYMBOLS = [
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
     "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
+    "kh_graph_create", "kh_graph_destroy", "kh_graph_set", "kh_graph_set_positions", "kh_graph_find_loop_candidates",
+    "kh_graph_last_kernel_ms",
 ]
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
@@ -135,6 +137,15 @@ def lib():
         L.kh_spa_get_corrections.argtypes = [vp, C.POINTER(i32), vp, vp]
         L.kh_link_info.argtypes = [dptr, dptr, dptr, dptr, dptr]
         L.kh_spa_set_sharding.argtypes = [vp, i32, i32, ALLREDUCE_FN, vp]
+    if hasattr(L, "kh_graph_create"):
+        L.kh_graph_create.argtypes = [i32, C.POINTER(vp)]
+        L.kh_graph_destroy.argtypes = [vp]
+        L.kh_graph_destroy.restype = None
+        L.kh_graph_set.argtypes = [vp, i32, dptr, iptr, iptr]
+        L.kh_graph_set_positions.argtypes = [vp, i32, dptr]
+        L.kh_graph_find_loop_candidates.argtypes = [vp, i32, iptr, dbl, i32, iptr, iptr, i32, C.POINTER(i32)]
+        L.kh_graph_last_kernel_ms.argtypes = [vp]
+        L.kh_graph_last_kernel_ms.restype = dbl
     _lib = L
     return L
 

@@ -1,0 +1,74 @@
+"""Generates tests/golden/loop_candidates.npz from the reference build (oracle/_ref/libkarto_ref_slam.so, made
+by oracle/Makefile from /root/reference): the reference Mapper processes a synthetic scan queue (no solver
+attached), then for EVERY scan of the resulting graph as query the fixture records what
+MapperGraph::FindNearLinkedScans and successive MapperGraph::FindPossibleLoopClosure calls return
+(Mapper.cpp:1795-1806, 1960-2010).  Run in the dev container: python tests/golden/make_golden_loops.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from slam_toolbox_amd import synth  # noqa: E402
+
+
+def main():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libkarto_ref_slam.so"))
+    lib.ref_init_laser.restype = C.c_int
+    lib.ref_init_laser.argtypes = [C.c_double] * 6
+    lib.ref_slam_enumerate.restype = C.c_int
+    lib.ref_slam_enumerate.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_char_p]
+    laser = synth.Laser()
+    n_beams = lib.ref_init_laser(laser.min_angle, laser.max_angle, laser.ang_res, laser.min_range, laser.max_range,
+                                 laser.range_threshold)
+    lib.ref_set_threads(os.cpu_count() or 1)
+    n_scans = 330                                     # four aisles + turnarounds of the synthetic warehouse
+    world = synth.make_world(12345)
+    truth, odom = synth.trajectory(n_scans)
+    rng = np.random.default_rng(4)
+    ranges = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], rng) for i in range(n_scans)]))
+    odom = np.ascontiguousarray(odom)
+    path = "/tmp/loop_enumeration.txt"
+    loop_dist = 5.0                                   # the aisles are 4 m apart
+    n = lib.ref_slam_enumerate(n_scans, n_beams, ranges.ctypes.data, odom.ctypes.data, loop_dist, path.encode())
+    assert n > 0, n
+    xy, adj, linked, chains = {}, {}, {}, {}
+    for line in open(path):
+        t = line.split()
+        if t[0] == "G":
+            min_chain = int(t[3])
+        elif t[0] == "S":
+            xy[int(t[1])] = (float(t[2]), float(t[3]))
+        elif t[0] == "A":
+            adj[int(t[1])] = [int(v) for v in t[3:]]
+        elif t[0] == "L":
+            linked[int(t[1])] = [int(v) for v in t[3:]]
+        elif t[0] == "H":
+            chains.setdefault(int(t[1]), []).append([int(v) for v in t[4:]])
+        elif t[0] == "!":
+            raise RuntimeError(line)
+    ids = sorted(xy)
+    assert ids == list(range(len(ids)))
+    adj_ptr = np.zeros(len(ids) + 1, dtype=np.int32)
+    adj_ptr[1:] = np.cumsum([len(adj[i]) for i in ids])
+    adj_idx = np.asarray([v for i in ids for v in adj[i]], dtype=np.int32)
+    link_ptr = np.zeros(len(ids) + 1, dtype=np.int32)
+    link_ptr[1:] = np.cumsum([len(linked[i]) for i in ids])
+    link_idx = np.asarray([v for i in ids for v in linked[i]], dtype=np.int32)
+    # chains as (query, first id, last id): every chain is a run of consecutive scan ids
+    rows = []
+    for q in ids:
+        for ch in chains.get(q, []):
+            assert ch == list(range(ch[0], ch[-1] + 1))
+            rows.append((q, ch[0], ch[-1]))
+    out = os.path.join(ROOT, "tests", "golden", "loop_candidates.npz")
+    np.savez_compressed(out, ref_xy=np.asarray([xy[i] for i in ids]), adj_ptr=adj_ptr, adj_idx=adj_idx,
+                        link_ptr=link_ptr, link_idx=link_idx, chains=np.asarray(rows, dtype=np.int32).reshape(-1, 3),
+                        loop_search_maximum_distance=loop_dist, loop_match_minimum_chain_size=min_chain)
+    print(out, len(ids), "scans,", len(adj_idx) // 2, "edges,", len(rows), "chains over", len({r[0] for r in rows}), "queries")
+
+
+if __name__ == "__main__":
+    main()
