@@ -214,6 +214,48 @@ def enumeration_leg(device=0, n_scans=10000, n_queries=256):
                                          f"{sum(len(c) for c in out)} chains, loop_search_maximum_distance 3.0, chain >= 10"}
 
 
+def occupancy_leg(device=0, n_scans=1000):
+    """Next row f-2: OccupancyGrid::CreateFromScans of `n_scans` 1081-beam scans at 5 cm (extra keys, rank 0).
+    The C ABI takes host buffers, so the call time includes packing + H2D; the trace kernel time is reported
+    next to it.  CPU: the C oracle (one core) on a 100-scan sample of the same queue."""
+    from common import LASER
+    from slam_toolbox_amd import synth
+    from slam_toolbox_amd.occupancy_grid import OccupancyGrid
+    from slam_toolbox_amd.scan_matcher import LocalizedRangeScan
+    world = synth.make_world(12345)
+    truth, _ = synth.trajectory(2000)
+    rng = np.random.default_rng(5)
+    base = [synth.make_scan(world, truth[i], rng) for i in range(0, 2000, 20)]          # 100 distinct range vectors
+    idx = np.linspace(0, 1999, n_scans).astype(int)
+    scans = [LocalizedRangeScan(base[k % len(base)], truth[i], LASER.min_angle, LASER.ang_res) for k, i in enumerate(idx)]
+    g = OccupancyGrid.CreateFromScans(scans, 0.05, LASER, device)                         # warm-up + dimensions
+    times = []
+    for _ in range(5):
+        g.Clear()
+        t0 = g.stats()["trace_ms"]
+        t = time.perf_counter()
+        g.AddScans(scans, LASER)
+        g.Update()
+        times.append((time.perf_counter() - t, g.stats()["trace_ms"] - t0))
+    cells = g.cells()
+    g.close()
+    wall = float(np.median([a for a, _ in times]))
+    kern = float(np.median([b for _, b in times]))
+    out = {"occupancy_scans_per_s": n_scans / wall, "occupancy_call_ms": wall * 1e3, "occupancy_trace_kernel_ms": kern,
+           "occupancy_workload": f"{n_scans} scans x {P_BEAMS} beams, {cells.shape[1]} x {cells.shape[0]} cells at 5 cm, "
+                                 f"{int((cells == 100).sum())} occupied / {int((cells == 255).sum())} free"}
+    try:
+        from oracle import karto
+        sample = [karto.Scan(s.ranges, s.GetSensorPose(), LASER) for s in scans[:100]]
+        t = time.perf_counter()
+        karto.occupancy_from_scans(cells.shape[1], cells.shape[0], g.offset, 0.05, sample, LASER)
+        out["occupancy_cpu_scans_per_s"] = 100 / (time.perf_counter() - t)
+        out["occupancy_cpu_kind"] = "port (C oracle, 1 core, 100-scan sample)"
+    except Exception:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,6 +358,7 @@ def main():
         if world == 1 and not args.no_loop:
             out.update(loop_leg(local_rank))
             out.update(enumeration_leg(local_rank))
+            out.update(occupancy_leg(local_rank))
         print(json.dumps(out))
     hm.close()
     if world > 1:

@@ -245,6 +245,29 @@ KH_API int kh_graph_find_loop_candidates(kh_graph * g, int32_t n_queries, const 
                                          int32_t * n_chains);
 KH_API double kh_graph_last_kernel_ms(kh_graph * g);
 
+/* ---------------------------------------------------------------- occupancy grid (next row f-2) */
+/* karto::OccupancyGrid::CreateFromScans (Karto.h:5947-5962, 6118-6274).  Scans are handed over like to the
+ * matcher (ranges + UNFILTERED point readings + sensor pose, GetPointReadings(false) at Karto.h:6157). */
+typedef struct kh_occupancy kh_occupancy;
+/* OccupancyGrid::ComputeDimensions (Karto.h:6086-6112) from the scans' bounding boxes (Karto.h:5694-5700) */
+KH_API int kh_occupancy_compute_dimensions(int32_t n_scans, const kh_scan * scans, double min_range,
+                                           double range_threshold, double resolution, int32_t * width,
+                                           int32_t * height, double offset[2]);
+KH_API int kh_occupancy_create(int32_t width, int32_t height, double offset_x, double offset_y, double resolution,
+                               int32_t device, kh_occupancy ** out);
+KH_API void kh_occupancy_destroy(kh_occupancy * g);
+KH_API int kh_occupancy_clear(kh_occupancy * g);
+/* AddScan for every scan (Karto.h:6148-6189): pass / hit counters only */
+KH_API int kh_occupancy_add_scans(kh_occupancy * g, int32_t n_scans, const kh_scan * scans, double range_threshold,
+                                  double min_range, double max_range);
+/* Update (Karto.h:6257-6274); karto defaults: min_pass_through 2, occupancy_threshold 0.1 (Karto.h:5920-5921) */
+KH_API int kh_occupancy_update(kh_occupancy * g, uint32_t min_pass_through, double occupancy_threshold);
+/* cells: width_step * height bytes (0 unknown, 100 occupied, 255 free, Karto.h:4379-4381); pass / hits: the
+ * counter grids (same layout, uint32); any pointer may be NULL */
+KH_API int kh_occupancy_read(kh_occupancy * g, uint8_t * cells, uint32_t * pass, uint32_t * hits);
+KH_API int kh_occupancy_info(kh_occupancy * g, int32_t * width, int32_t * height, int32_t * width_step,
+                             double * trace_ms, int64_t * beams_traced);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ class KoPoseResponse(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("karto_oracle.c", "spa_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("karto_oracle.c", "spa_oracle.c", "occupancy_oracle.c")]
     if force or not os.path.exists(_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_PATH) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libkarto_oracle.so"])
     return _PATH
@@ -210,3 +210,23 @@ class Matcher:
             lib().ko_matcher_destroy(self.h)
         except Exception:
             pass
+
+
+def occupancy_from_scans(width, height, offset, resolution, scans, laser, min_pass_through=2, occupancy_threshold=0.1):
+    """OccupancyGrid::CreateFromScans (occupancy_oracle.c): returns (cells, pass_counts, hit_counts), each
+    (height, width_step) with width_step = align8(width)."""
+    L = lib()
+    ws = (int(width) + 7) & ~7
+    size = ws * int(height)
+    passes = np.zeros(size, dtype=np.uint32)
+    hits = np.zeros(size, dtype=np.uint32)
+    cells = np.zeros(size, dtype=np.uint8)
+    fn = L.ko_occupancy_from_scans
+    fn.restype = None
+    fn.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(KoScan), C.c_double,
+                   C.c_double, C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    arr = _arr(scans)
+    fn(int(width), int(height), float(offset[0]), float(offset[1]), float(resolution), len(scans), arr,
+       float(laser.range_threshold), float(laser.min_range), float(laser.max_range), int(min_pass_through),
+       float(occupancy_threshold), passes.ctypes.data, hits.ctypes.data, cells.ctypes.data)
+    return cells.reshape(height, ws), passes.reshape(height, ws), hits.reshape(height, ws)

@@ -303,4 +303,27 @@ void ref_matrix3_inverse(const double * a, double * out)
   fill_cov(c.Inverse(), out);
 }
 
+// OccupancyGrid::CreateFromScans (Karto.h:5947-5962) on the given scans: dims = {width, height, width step},
+// offset = grid offset; cells / pass / hits are copied out when the capacity allows.  Returns the data size.
+int ref_occupancy_from_scans(
+  void ** scans, int n, double resolution, int * dims, double * offset, uint8_t * cells, uint32_t * pass,
+  uint32_t * hits, int cap)
+{
+  LocalizedRangeScanVector v;
+  for (int i = 0; i < n; ++i) {v.push_back(static_cast<LocalizedRangeScan *>(scans[i]));}
+  OccupancyGrid * g = OccupancyGrid::CreateFromScans(v, resolution);
+  if (g == NULL) {return 0;}
+  dims[0] = g->GetWidth(); dims[1] = g->GetHeight(); dims[2] = g->GetWidthStep();
+  offset[0] = g->GetCoordinateConverter()->GetOffset().GetX();
+  offset[1] = g->GetCoordinateConverter()->GetOffset().GetY();
+  const int size = g->GetDataSize();
+  if (size <= cap) {
+    std::memcpy(cells, g->GetDataPointer(), size);
+    std::memcpy(pass, g->m_pCellPassCnt->GetDataPointer(), static_cast<size_t>(size) * 4);
+    std::memcpy(hits, g->m_pCellHitsCnt->GetDataPointer(), static_cast<size_t>(size) * 4);
+  }
+  delete g;
+  return size;
+}
+
 }  // extern "C"

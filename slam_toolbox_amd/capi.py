@@ -67,6 +67,8 @@ SYMBOLS = [
     "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
     "kh_graph_create", "kh_graph_destroy", "kh_graph_set", "kh_graph_set_positions", "kh_graph_find_loop_candidates",
     "kh_graph_last_kernel_ms",
+    "kh_occupancy_compute_dimensions", "kh_occupancy_create", "kh_occupancy_destroy", "kh_occupancy_clear",
+    "kh_occupancy_add_scans", "kh_occupancy_update", "kh_occupancy_read", "kh_occupancy_info",
 ]
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
@@ -146,6 +148,16 @@ def lib():
         L.kh_graph_find_loop_candidates.argtypes = [vp, i32, iptr, dbl, i32, iptr, iptr, i32, C.POINTER(i32)]
         L.kh_graph_last_kernel_ms.argtypes = [vp]
         L.kh_graph_last_kernel_ms.restype = dbl
+    if hasattr(L, "kh_occupancy_create"):
+        L.kh_occupancy_compute_dimensions.argtypes = [i32, C.POINTER(KhScan), dbl, dbl, dbl, C.POINTER(i32), C.POINTER(i32), dptr]
+        L.kh_occupancy_create.argtypes = [i32, i32, dbl, dbl, dbl, i32, C.POINTER(vp)]
+        L.kh_occupancy_destroy.argtypes = [vp]
+        L.kh_occupancy_destroy.restype = None
+        L.kh_occupancy_clear.argtypes = [vp]
+        L.kh_occupancy_add_scans.argtypes = [vp, i32, C.POINTER(KhScan), dbl, dbl, dbl]
+        L.kh_occupancy_update.argtypes = [vp, C.c_uint32, dbl]
+        L.kh_occupancy_read.argtypes = [vp, vp, vp, vp]
+        L.kh_occupancy_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(dbl), C.POINTER(C.c_int64)]
     _lib = L
     return L
 
