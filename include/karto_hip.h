@@ -268,6 +268,37 @@ KH_API int kh_occupancy_read(kh_occupancy * g, uint8_t * cells, uint32_t * pass,
 KH_API int kh_occupancy_info(kh_occupancy * g, int32_t * width, int32_t * height, int32_t * width_step,
                              double * trace_ms, int64_t * beams_traced);
 
+/* ---------------------------------------------------------------- lifelong node-decay scoring (next row f-4) */
+/* LifelongSlamToolbox::computeScores (src/experimental/slam_toolbox_lifelong.cpp:295-329) with the metrics
+ * of :373-478 and the objective of :199-250.  A kh_scan_box is what the scoring reads from a scan / vertex:
+ * GetBarycenterPose(), GetBoundingBox().GetSize(), the FILTERED point readings GetPointReadings(true), the
+ * unique id, the vertex's edge count and its current score. */
+typedef struct kh_scan_box {
+  double barycenter[2];
+  double bbox_size[2];            /* width, height */
+  int32_t unique_id;
+  int32_t n_edges;                /* Vertex::GetEdges().size() */
+  double score;                   /* Vertex::GetScore() */
+  int32_t n_points;
+  const double * points_xy;       /* filtered point readings, host memory */
+} kh_scan_box;
+typedef struct kh_decay_params {
+  double iou_thresh;              /* lifelong_minimum_score          0.10 */
+  double iou_match;               /* lifelong_iou_match              0.85 */
+  double removal_score;           /* lifelong_node_removal_score     0.10 (used by the caller, :166) */
+  double overlap_scale;           /* lifelong_overlap_score_scale    0.5  */
+  double constraint_scale;        /* lifelong_constraint_multiplier  0.05 */
+  double nearby_penalty;          /* lifelong_nearby_penalty         0.001 */
+  double candidates_scale;        /* lifelong_candidates_scale       0.03 (computed but unused upstream, :231-240) */
+  int32_t scan_buffer_size;       /* mapper scan_buffer_size */
+} kh_decay_params;
+KH_API void kh_decay_params_default(kh_decay_params * p);
+/* kept[k] = 0 for candidates computeScores erases (IoU below iou_thresh or fewer than 2 edges); scores[k] is
+ * computeScore's return for the kept ones.  Output pointers may be NULL. */
+KH_API int kh_lifelong_scores(int32_t device, const kh_scan_box * reference, int32_t n, const kh_scan_box * candidates,
+                              const kh_decay_params * params, int32_t * kept, double * iou, double * area_overlap,
+                              double * reading_overlap, double * scores);
+
 #ifdef __cplusplus
 }
 #endif

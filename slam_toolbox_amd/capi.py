@@ -69,7 +69,20 @@ SYMBOLS = [
     "kh_graph_last_kernel_ms",
     "kh_occupancy_compute_dimensions", "kh_occupancy_create", "kh_occupancy_destroy", "kh_occupancy_clear",
     "kh_occupancy_add_scans", "kh_occupancy_update", "kh_occupancy_read", "kh_occupancy_info",
+    "kh_decay_params_default", "kh_lifelong_scores",
 ]
+
+
+class KhScanBox(C.Structure):
+    _fields_ = [("barycenter", C.c_double * 2), ("bbox_size", C.c_double * 2), ("unique_id", C.c_int32),
+                ("n_edges", C.c_int32), ("score", C.c_double), ("n_points", C.c_int32),
+                ("points_xy", C.POINTER(C.c_double))]
+
+
+class KhDecayParams(C.Structure):
+    _fields_ = [("iou_thresh", C.c_double), ("iou_match", C.c_double), ("removal_score", C.c_double),
+                ("overlap_scale", C.c_double), ("constraint_scale", C.c_double), ("nearby_penalty", C.c_double),
+                ("candidates_scale", C.c_double), ("scan_buffer_size", C.c_int32)]
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 _lib = None
@@ -148,6 +161,11 @@ def lib():
         L.kh_graph_find_loop_candidates.argtypes = [vp, i32, iptr, dbl, i32, iptr, iptr, i32, C.POINTER(i32)]
         L.kh_graph_last_kernel_ms.argtypes = [vp]
         L.kh_graph_last_kernel_ms.restype = dbl
+    if hasattr(L, "kh_lifelong_scores"):
+        L.kh_decay_params_default.argtypes = [C.POINTER(KhDecayParams)]
+        L.kh_decay_params_default.restype = None
+        L.kh_lifelong_scores.argtypes = [i32, C.POINTER(KhScanBox), i32, C.POINTER(KhScanBox), C.POINTER(KhDecayParams),
+                                         vp, vp, vp, vp, vp]
     if hasattr(L, "kh_occupancy_create"):
         L.kh_occupancy_compute_dimensions.argtypes = [i32, C.POINTER(KhScan), dbl, dbl, dbl, C.POINTER(i32), C.POINTER(i32), dptr]
         L.kh_occupancy_create.argtypes = [i32, i32, dbl, dbl, dbl, i32, C.POINTER(vp)]
