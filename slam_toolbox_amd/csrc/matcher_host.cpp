@@ -99,6 +99,25 @@ struct CorrHost
   double denom = 1.0;
 };
 
+struct StageLayout {size_t bx, by, dist_pen, ang_pen, cos_sin, local, invalid, total;};
+
+// Staging and bookkeeping of one in-flight sub-batch of CorrelateScan jobs (a handle owns two: pipelining)
+struct CorrBatch
+{
+  std::vector<CorrHost> ctx;
+  std::vector<StageLayout> lay;
+  size_t stride = 0, out_words = 0;
+  int32_t max_na = 0, max_tiles = 0, max_poses = 0, sx_variant = -1, ry = -1;
+  bool uniform_kernel = true, use_lds = false;
+  // staging (pinned host + device mirror) for the jobs; pinned result mirror; small fine-pass volumes
+  uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_stage = 0, cap_dstage = 0;
+  unsigned long long * h_out = nullptr; size_t cap_hout = 0;   // words
+  unsigned long long * d_out = nullptr; size_t cap_dout = 0;   // words: one contiguous result block per job
+  int32_t * h_sums = nullptr; size_t cap_hsums = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};      // around the scoring kernel (profiling)
+  hipEvent_t done = nullptr;                  // everything of the sub-batch, downloads included
+};
+
 struct Slot
 {
   uint8_t * d_grid = nullptr;        // first grid byte (256-byte aligned); the allocation has kGridPad zero bytes either side
@@ -133,20 +152,15 @@ struct kh_matcher
   hipStream_t stream = nullptr;
   uint8_t * d_kernel = nullptr;
   std::vector<Slot> slots;
-  // staging (pinned host + device mirror) for correlate jobs
-  uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_stage = 0, cap_dstage = 0;
-  // pinned result mirror
-  unsigned long long * h_out = nullptr; size_t cap_hout = 0;   // words
-  unsigned long long * d_out = nullptr; size_t cap_dout = 0;   // words: one contiguous result block per job
+  CorrBatch batch[2];
   // raster staging (pinned) + jobs
   double * h_rpoints = nullptr; uint8_t * h_ractive = nullptr; size_t cap_hrpoints = 0, cap_hractive = 0;
   RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
-  int32_t * h_sums = nullptr; size_t cap_hsums = 0;
   bool keep_responses = false;
   bool lds_score = false;          // experimental LDS-staged scoring path (kh_matcher_set_debug bit 1)
   // profiling
   bool profiling = false;
-  double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0;
+  double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0, score_jobs = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
   double grid_resolution() const {return 1.0 / scale;}   // Karto.h:4518-4521
@@ -404,7 +418,6 @@ struct CorrReq
   double mean[3]; double cov[9]; double response; int status;
 };
 
-struct StageLayout {size_t bx, by, dist_pen, ang_pen, cos_sin, local, invalid, total;};
 static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na)
 {
   StageLayout L;
@@ -497,17 +510,25 @@ static inline double host_response(const CorrHost & c, int32_t sum, int a, int y
   return response;
 }
 
-static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
+// One sub-batch of CorrelateScan jobs in two phases so that two sub-batches can be pipelined on the handle's
+// stream: phase 0 = host preparation + upload + kernels + download, all enqueued, ending with an event;
+// phase 1 = wait for that event + finalisation.  Everything phase 1 needs lives in the CorrBatch.
+static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch & B, int phase)
 {
-  const size_t n = reqs.size();
   if (n == 0) {return KH_OK;}
   const kh_match_params & mp = m->params;
-  std::vector<CorrHost> ctx(n);
-  std::vector<StageLayout> lay(n);
-  size_t stride = 0, out_words = 0;
-  int32_t max_na = 0, max_tiles = 0, max_poses = 0;
-  int32_t sx_variant = -1, ry = -1;
-  bool uniform_kernel = true;
+  std::vector<CorrHost> & ctx = B.ctx;
+  std::vector<StageLayout> & lay = B.lay;
+  size_t & stride = B.stride; size_t & out_words = B.out_words;
+  int32_t & max_na = B.max_na; int32_t & max_tiles = B.max_tiles; int32_t & max_poses = B.max_poses;
+  int32_t & sx_variant = B.sx_variant; int32_t & ry = B.ry;
+  bool & uniform_kernel = B.uniform_kernel;
+  bool & use_lds = B.use_lds;
+  constexpr size_t kSmallVolume = 4096;
+  int rc = KH_OK;
+  if (phase == 0) {
+  ctx.assign(n, CorrHost()); lay.assign(n, StageLayout());
+  stride = 0; out_words = 0; max_na = 0; max_tiles = 0; max_poses = 0; sx_variant = -1; ry = -1; uniform_kernel = true;
 
   // ---- 1. host preparation (exact reference arithmetic) ----
   for (size_t i = 0; i < n; ++i) {
@@ -539,13 +560,13 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     max_poses = std::max(max_poses, c.nx * c.ny * c.na);
   }
   out_words = align_up(out_words, 32);
-  int rc = ensure_pinned(m->h_stage, m->cap_stage, stride * n, m->stream);
+  rc = ensure_pinned(B.h_stage, B.cap_stage, stride * n, m->stream);
   if (rc) {return rc;}
-  rc = ensure_device(m->d_stage, m->cap_dstage, m->cap_stage, m->stream);
+  rc = ensure_device(B.d_stage, B.cap_dstage, B.cap_stage, m->stream);
   if (rc) {return rc;}
-  rc = ensure_pinned(m->h_out, m->cap_hout, out_words * n, m->stream);
+  rc = ensure_pinned(B.h_out, B.cap_hout, out_words * n, m->stream);
   if (rc) {return rc;}
-  rc = ensure_device(m->d_out, m->cap_dout, out_words * n, m->stream);
+  rc = ensure_device(B.d_out, B.cap_dout, out_words * n, m->stream);
   if (rc) {return rc;}
 
   // device scratch of every slot first (allocation is serial); the tables themselves are filled by
@@ -584,8 +605,8 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     CorrHost & c = ctx[i];
     Slot & s = m->slots[c.slot];
     const StageLayout & L = lay[i];
-    uint8_t * hb = m->h_stage + stride * i;
-    uint8_t * db = m->d_stage + stride * i;
+    uint8_t * hb = B.h_stage + stride * i;
+    uint8_t * db = B.d_stage + stride * i;
     CorrJob * job = reinterpret_cast<CorrJob *>(hb);
     int32_t * bx = reinterpret_cast<int32_t *>(hb + L.bx);
     int32_t * by = reinterpret_cast<int32_t *>(hb + L.by);
@@ -705,7 +726,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     job->local = reinterpret_cast<const double *>(db + L.local);
     job->invalid = db + L.invalid;
     job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
-    job->sums = s.d_sums; job->resp = s.d_resp; job->out = m->d_out + out_words * i;
+    job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i;
   });
   bool all_lds = true;
   for (size_t i = 0; i < n; ++i) {
@@ -714,53 +735,55 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     max_tiles = std::max(max_tiles, job_tiles[i]);
     all_lds = all_lds && job_lds[i] != 0;
   }
-  const bool use_lds = all_lds && uniform_kernel;
+  use_lds = all_lds && uniform_kernel;
 
   // ---- 2. upload, launch, download ----
-  KH_HIP(hipMemcpyAsync(m->d_stage, m->h_stage, stride * n, hipMemcpyHostToDevice, m->stream));
-  KH_HIP(hipMemsetAsync(m->d_out, 0, out_words * 8 * n, m->stream));
+  KH_HIP(hipMemcpyAsync(B.d_stage, B.h_stage, stride * n, hipMemcpyHostToDevice, m->stream));
+  KH_HIP(hipMemsetAsync(B.d_out, 0, out_words * 8 * n, m->stream));
   if (use_lds) {
-    launch_offsets_lds(m->d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
+    launch_offsets_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
   } else {
-    launch_offsets(m->d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
+    launch_offsets(B.d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
   }
-  if (m->profiling) {KH_HIP(hipEventRecord(m->ev[0], m->stream));}
+  if (m->profiling) {KH_HIP(hipEventRecord(B.ev[0], m->stream));}
   if (use_lds) {
-    launch_score_lds(m->d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, m->stream);
+    launch_score_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, m->stream);
   } else if (uniform_kernel) {
-    launch_score(m->d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, m->stream);
+    launch_score(B.d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, m->stream);
   } else {
     for (size_t i = 0; i < n; ++i) {
-      const CorrJob * job = reinterpret_cast<const CorrJob *>(m->h_stage + stride * i);
-      launch_score(m->d_stage + stride * i, stride, 1, job->tiles_x * job->tiles_y, job->na,
+      const CorrJob * job = reinterpret_cast<const CorrJob *>(B.h_stage + stride * i);
+      launch_score(B.d_stage + stride * i, stride, 1, job->tiles_x * job->tiles_y, job->na,
         (job->linear && job->sx == 2) ? 2 : 1, job->ry, m->stream);
     }
   }
-  if (m->profiling) {KH_HIP(hipEventRecord(m->ev[1], m->stream));}
-  launch_ties(m->d_stage, stride, static_cast<int32_t>(n), max_poses, m->stream);
+  if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], m->stream));}
+  launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, m->stream);
   KH_HIP(hipGetLastError());
-  KH_HIP(hipMemcpyAsync(m->h_out, m->d_out, out_words * 8 * n, hipMemcpyDeviceToHost, m->stream));
+  KH_HIP(hipMemcpyAsync(B.h_out, B.d_out, out_words * 8 * n, hipMemcpyDeviceToHost, m->stream));
   // fine passes need the raw sums of every angle at the best cell (ComputeAngularCovariance): their
   // volumes are tiny (3 x 3 x nA), so they ride along with the batch download instead of costing one
   // synchronous copy per match afterwards
-  constexpr size_t kSmallVolume = 4096;
   {
     size_t n_small = 0;
     for (size_t i = 0; i < n; ++i) {
       if (ctx[i].fine && static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na <= kSmallVolume) {++n_small;}
     }
     if (n_small) {
-      rc = ensure_pinned(m->h_sums, m->cap_hsums, kSmallVolume * n, m->stream);
+      rc = ensure_pinned(B.h_sums, B.cap_hsums, kSmallVolume * n, m->stream);
       if (rc) {return rc;}
       for (size_t i = 0; i < n; ++i) {
         const size_t vol = static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na;
         if (ctx[i].fine && vol <= kSmallVolume) {
-          KH_HIP(hipMemcpyAsync(m->h_sums + kSmallVolume * i, m->slots[ctx[i].slot].d_sums, vol * 4, hipMemcpyDeviceToHost, m->stream));
+          KH_HIP(hipMemcpyAsync(B.h_sums + kSmallVolume * i, m->slots[ctx[i].slot].d_sums, vol * 4, hipMemcpyDeviceToHost, m->stream));
         }
       }
     }
   }
-  KH_HIP(hipStreamSynchronize(m->stream));
+  KH_HIP(hipEventRecord(B.done, m->stream));
+  return KH_OK;
+  }   // phase 0
+  KH_HIP(hipEventSynchronize(B.done));
   if (use_lds && std::getenv("KH_LDS_DEBUG")) {
     const CorrHost & c0 = ctx[0];
     const Slot & s0 = m->slots[c0.slot];
@@ -785,8 +808,8 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   }
   if (m->profiling) {
     float ms = 0;
-    KH_HIP(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
-    m->score_ms += ms; m->score_launches += 1;
+    KH_HIP(hipEventElapsedTime(&ms, B.ev[0], B.ev[1]));
+    m->score_ms += ms; m->score_launches += 1; m->score_jobs += static_cast<int64_t>(n);
   }
 
   // ---- 3. finalisation (Mapper.cpp:775-862) ----
@@ -796,7 +819,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     CorrReq & q = reqs[i];
     CorrHost & c = ctx[i];
     Slot & s = m->slots[c.slot];
-    const unsigned long long * out = m->h_out + out_words * i;
+    const unsigned long long * out = B.h_out + out_words * i;
     double best;
     std::memcpy(&best, &out[0], 8);
     const uint64_t tie_count = out[1];
@@ -863,13 +886,13 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
       }
       std::vector<int32_t> col(c.na, 0);
       if (fx >= 0 && plane * c.na <= kSmallVolume) {
-        const int32_t * vol = m->h_sums + kSmallVolume * i;
+        const int32_t * vol = B.h_sums + kSmallVolume * i;
         for (int32_t a = 0; a < c.na; ++a) {col[a] = vol[static_cast<size_t>(a) * plane + static_cast<size_t>(fy) * c.nx + fx];}
       } else if (fx >= 0) {
         KH_HIP(hipMemcpy2D(col.data(), 4, s.d_sums + static_cast<size_t>(fy) * c.nx + fx, plane * 4, 4, c.na, hipMemcpyDeviceToHost));
       } else {
         // off-lattice best pose: score the single cell through the generic (per-pose checked) path
-        CorrJob * job = reinterpret_cast<CorrJob *>(m->h_stage + stride * i);
+        CorrJob * job = reinterpret_cast<CorrJob *>(B.h_stage + stride * i);
         CorrJob one = *job;
         one.nx = 1; one.ny = 1; one.linear = 0; one.sx = 1; one.sy_ws = m->ws; one.base0 = gridIndex;
         one.tiles_x = 1; one.tiles_y = 1; one.ry = 1; one.do_penalize = 0; one.coarse = 0; one.write_resp = 0;
@@ -877,9 +900,9 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
         int32_t one_bx = gridIndex, one_by = 0;
         KH_HIP(hipMemcpy(const_cast<int32_t *>(job->bx), &one_bx, 4, hipMemcpyHostToDevice));
         KH_HIP(hipMemcpy(const_cast<int32_t *>(job->by), &one_by, 4, hipMemcpyHostToDevice));
-        KH_HIP(hipMemcpy(m->d_stage + stride * i, &one, sizeof(CorrJob), hipMemcpyHostToDevice));
-        launch_offsets(m->d_stage + stride * i, stride, 1, one.na, m->stream);
-        launch_score(m->d_stage + stride * i, stride, 1, 1, one.na, 1, 1, m->stream);
+        KH_HIP(hipMemcpy(B.d_stage + stride * i, &one, sizeof(CorrJob), hipMemcpyHostToDevice));
+        launch_offsets(B.d_stage + stride * i, stride, 1, one.na, m->stream);
+        launch_score(B.d_stage + stride * i, stride, 1, 1, one.na, 1, 1, m->stream);
         KH_HIP(hipStreamSynchronize(m->stream));
         KH_HIP(hipMemcpy(col.data(), s.d_sums, sizeof(int32_t) * c.na, hipMemcpyDeviceToHost));
         // NOTE: the slot's stored volume now holds this 1x1 search (introspection only)
@@ -923,6 +946,28 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   }
   for (size_t i = 0; i < n; ++i) {if (final_rc[i] != KH_OK) {return final_rc[i];}}
   return KH_OK;
+}
+
+static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
+{
+  const size_t n = reqs.size();
+  if (n == 0) {return KH_OK;}
+  // Optional (KH_PIPELINE=1): two sub-batches, the host half of one overlapping the kernels of the other
+  // (multiples of 8 jobs keep the XCD-aware block map balanced).  Measured on config 1: 1.28 ms per 32 matches
+  // against 1.20 ms unsplit -- the half-size kernels lose more than the overlap wins -- so it is off by default;
+  // callers that want the overlap run two handles from two threads instead (bench.py --streams 2).
+  static const bool pipeline = std::getenv("KH_PIPELINE") != nullptr;
+  const size_t half = (pipeline && n >= 16) ? ((n / 2 + 7) / 8) * 8 : n;
+  int rc = correlate_stage(m, reqs.data(), half, m->batch[0], 0);
+  if (rc) {return rc;}
+  if (half < n) {
+    rc = correlate_stage(m, reqs.data() + half, n - half, m->batch[1], 0);
+    if (rc) {(void)hipStreamSynchronize(m->stream); return rc;}
+  }
+  rc = correlate_stage(m, reqs.data(), half, m->batch[0], 1);
+  int rc2 = KH_OK;
+  if (half < n) {rc2 = correlate_stage(m, reqs.data() + half, n - half, m->batch[1], 1);}
+  return rc ? rc : rc2;
 }
 
 }  // namespace kh
@@ -1035,6 +1080,12 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   for (auto & ev : m->ev) {
     if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
   }
+  for (auto & b : m->batch) {
+    for (auto & ev : b.ev) {
+      if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
+    }
+    if ((e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
+  }
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
   m->slots.resize(max_batch);
@@ -1059,9 +1110,15 @@ void kh_matcher_destroy(kh_matcher * m)
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
   }
-  hipFree(m->d_kernel); hipFree(m->d_stage); hipFree(m->d_rjobs); hipFree(m->d_out);
-  if (m->h_stage) {hipHostFree(m->h_stage);}
-  if (m->h_out) {hipHostFree(m->h_out);}
+  hipFree(m->d_kernel); hipFree(m->d_rjobs);
+  for (auto & b : m->batch) {
+    hipFree(b.d_stage); hipFree(b.d_out);
+    if (b.h_stage) {hipHostFree(b.h_stage);}
+    if (b.h_out) {hipHostFree(b.h_out);}
+    if (b.h_sums) {hipHostFree(b.h_sums);}
+    for (auto & ev : b.ev) {if (ev) {hipEventDestroy(ev);}}
+    if (b.done) {hipEventDestroy(b.done);}
+  }
   if (m->h_rpoints) {hipHostFree(m->h_rpoints);}
   if (m->h_ractive) {hipHostFree(m->h_ractive);}
   if (m->h_rjobs) {hipHostFree(m->h_rjobs);}
@@ -1365,7 +1422,7 @@ int kh_matcher_profile(kh_matcher * m, int32_t enable, double * score_ms, int64_
   if (raster_ms) {*raster_ms = m->raster_ms;}
   if (raster_launches) {*raster_launches = m->raster_launches;}
   m->profiling = enable != 0;
-  m->score_ms = 0; m->raster_ms = 0; m->score_launches = 0; m->raster_launches = 0;
+  m->score_ms = 0; m->raster_ms = 0; m->score_launches = 0; m->raster_launches = 0; m->score_jobs = 0;
   return KH_OK;
 }
 
