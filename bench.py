@@ -360,7 +360,10 @@ def main():
         if world > 1:
             dist.barrier()
         if world > 1 or rank == 0:
-            solver_out = solver_leg(local_rank, rank, world)
+            try:
+                solver_out = solver_leg(local_rank, rank, world)
+            except Exception as exc:      # the headline line must survive a failure of the extra leg
+                solver_out = {"solver_leg_error": repr(exc)[:200]}
     if rank == 0:
         k3_ms = prof["score_ms"] / max(1, prof["score_launches"])
         # a step's batch is scored in sub-batches (pipelined with the host half): matches per k_score launch

@@ -324,7 +324,7 @@ void spa_launch_grad_norms(const SpaDev & d, const double * x, double * out2, vo
 //       column-major front is four contiguous 128-byte segments.
 // Dynamic LDS: panel of roundup16(m) rows (sized by the host for the largest front of the level).
 constexpr int NB = 16;
-constexpr int XS = NB + 1;
+constexpr int XS = 2 * NB + 1;               // LDS panel row stride: two 16-column panels + 1 (conflict-free MFMA operand reads)
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -406,17 +406,23 @@ __device__ __noinline__ void panel_row_solve(double * gcol, int m, int nb, const
   }
 }
 
-constexpr int kMaxLdsRows = 1104;          // 1104 * 17 * 8 B = 150 KB of the CU's 160 KB LDS
+constexpr int kMaxLdsRows = 568;           // 568 * 33 * 8 B = 150 KB of the CU's 160 KB LDS
 
-// C -= X X^T over the lower triangle of the trailing matrix, 16x16 tiles, one tile per wave at a time.
-// kLds: operands come from the LDS panel; otherwise from the panel columns just written to the front.
-template <bool kLds>
-__device__ __forceinline__ void trailing_update(double * F, const double * Xs, int m, int r0, int jb, int nb,
-                                                int nrows, int nrows_pad, int lane, int wave, int nwaves)
+// C -= X X^T on 16x16 tiles of the trailing matrix whose row/column 0 is global row `rb`.  X has KD = 16 or 32
+// columns: the LDS panel (row stride XS; columns 16..31 = the second panel of a pair) or, for fronts too large
+// for it, the panel columns jb .. jb+KD-1 of the front itself.  thin: only tile column 0 (what the second panel
+// of a pair needs before it can be factored); otherwise tile columns >= 1 (thin must have run first), or all
+// columns when `all` is set (single panel).
+template <bool kLds, int KD>
+__device__ __forceinline__ void trailing_update(double * F, const double * Xs, int m, int rb, int jb, int nb_a, int nb_b,
+                                                int nrows, int nrows_pad, bool thin, bool all,
+                                                int lane, int wave, int nwaves)
 {
   constexpr int TU = 4;       // tiles in flight per wave: their accumulator loads are issued together
   const int nt = nrows_pad >> 4;
-  const int ntiles = nt * (nt + 1) / 2;
+  const int ntri = all ? nt : nt - 1;             // side of the triangle of tiles walked when not thin
+  const int ntiles = thin ? nt : ntri * (ntri + 1) / 2;
+  const int shift = (thin || all) ? 0 : 1;
   const int lr = lane & 15, lk = lane >> 4;
   for (int t0 = wave; t0 < ntiles; t0 += nwaves * TU) {
     v4d acc[TU];
@@ -426,14 +432,20 @@ __device__ __forceinline__ void trailing_update(double * F, const double * Xs, i
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
       const int t = t0 + u * nwaves;
-      int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (I * (I + 1) / 2 > t) {--I;}
-      while ((I + 1) * (I + 2) / 2 <= t) {++I;}
-      const int J = t - I * (I + 1) / 2;
+      int I, J;
+      if (thin) {
+        I = t; J = 0;
+      } else {
+        I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (I * (I + 1) / 2 > t) {--I;}
+        while ((I + 1) * (I + 2) / 2 <= t) {++I;}
+        J = t - I * (I + 1) / 2;
+        I += shift; J += shift;
+      }
       tI[u] = I; tJ[u] = J;
       const int frow = 16 * I + lr;               // row of the trailing matrix held by this lane
       const int fcol0 = 16 * J + lk;              // its column for accumulator register 0 (+4 per register)
-      cp[u] = F + (r0 + frow) + (int64_t)(r0 + fcol0) * m;
+      cp[u] = F + (rb + frow) + (int64_t)(rb + fcol0) * m;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int fc = fcol0 + 4 * r;
@@ -448,16 +460,18 @@ __device__ __forceinline__ void trailing_update(double * F, const double * Xs, i
         const double * xa = Xs + (16 * tJ[u] + lr) * XS + lk;
         const double * xb = Xs + (16 * tI[u] + lr) * XS + lk;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KD / 4; ++kk) {
           acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * kk], xb[4 * kk], acc[u], 0, 0, 0);
         }
       } else {
-        const int ra = 16 * tJ[u] + lr, rb = 16 * tI[u] + lr;
+        const int ra = 16 * tJ[u] + lr, rbw = 16 * tI[u] + lr;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KD / 4; ++kk) {
           const int kc = 4 * kk + lk;
-          const double a = (ra < nrows && kc < nb) ? F[(r0 + ra) + (int64_t)(jb + kc) * m] : 0.0;
-          const double b = (rb < nrows && kc < nb) ? F[(r0 + rb) + (int64_t)(jb + kc) * m] : 0.0;
+          // panel A = columns jb .. jb+15, panel B = jb+16 .. ; B has no rows 0..15 (its own diagonal block)
+          const bool kv = kc < 16 ? kc < nb_a : (kc - 16) < nb_b;
+          const double a = (ra < nrows && kv && (kc < 16 || ra >= 16)) ? F[(rb + ra) + (int64_t)(jb + kc) * m] : 0.0;
+          const double b = (rbw < nrows && kv && (kc < 16 || rbw >= 16)) ? F[(rb + rbw) + (int64_t)(jb + kc) * m] : 0.0;
           acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc[u], 0, 0, 0);
         }
       }
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   extern __shared__ double smem[];
-  double * Xs = smem;                       // [rows below the panel, padded to 16][XS]
+  double * Xs = smem;                       // [rows below the first panel of a pair, padded to 16][XS]
   const bool use_lds = m <= kMaxLdsRows;    // larger fronts read the panel back from the front itself (L2)
   __shared__ double Ld[NB][NB + 1];
   __shared__ int s_fail;
@@ -529,25 +543,26 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
   // 2. blocked right-looking partial Cholesky of the first ns columns
   if (tid == 0) {s_fail = 0;}
   __syncthreads();
-  for (int jb = 0; jb < ns; jb += NB) {
-    const int nb = min(NB, ns - jb);
+  // Panels are taken in pairs with a delayed update: after panel A only the next 16 columns of the trailing
+  // matrix are updated (thin), panel B is factored, and then BOTH panels are applied to the rest in one pass
+  // with K = 32 -- half as many sweeps over the trailing matrix, twice the flops per accumulator load/store.
+  auto panel = [&](int jb, int nb, int rb, double * xcols) {
     // (a) diagonal block: wave 0
     if (wave == 0) {
       if (factor_diag_block(F, m, jb, nb, lane, &Ld[0][0])) {s_fail = 1;}
     }
     __syncthreads();
     TSTAMP();
-    // (b) panel: X = F[rows, jb:jb+nb] * Ld^{-T}, rows below the diagonal block
+    // (b) panel: X = F[rows, jb:jb+nb] * Ld^{-T}, rows below the diagonal block; one thread per row (out of
+    //     line, see panel_row_solve); fronts too large for the LDS panel solve in place in the front instead
     const int r0 = jb + nb;
     const int nrows = m - r0;
     const int nrows_pad = (nrows + 15) & ~15;
-    // One thread per row (out of line, see panel_row_solve); fronts too large for the LDS panel solve
-    // in place in the front instead.
 #pragma unroll 1
     for (int i = tid; i < nrows_pad; i += nthreads) {
       double * gcol = F + (r0 + i) + (int64_t)jb * m;       // F[r0 + i][jb + c] = gcol[c * m]
       if (use_lds) {
-        panel_row_solve(gcol, m, i < nrows ? nb : 0, &Ld[0][0], Xs + i * XS);
+        panel_row_solve(gcol, m, i < nrows ? nb : 0, &Ld[0][0], xcols + (size_t)(r0 - rb + i) * XS);
       } else if (i < nrows) {
 #pragma unroll 1
         for (int c = 0; c < nb; ++c) {
@@ -562,14 +577,47 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     }
     __syncthreads();
     TSTAMP();
-    // (c) trailing update of the lower triangle on the matrix cores
+  };
+  for (int jb = 0; jb < ns; ) {
+    const int nb_a = min(NB, ns - jb);
+    const int rb = jb + nb_a;                 // first row / column of the trailing matrix of this pair
+    const int nrows = m - rb;
+    const int nrows_pad = (nrows + 15) & ~15;
+    // only two FULL panels pair up: the thin update covers exactly the 16 columns of the second panel, so a
+    // partial second panel would leave the non-pivot columns of that tile column without its contribution
+    const bool pair = jb + 2 * NB <= ns;
     if (use_lds) {
-      trailing_update<true>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
+      // the second panel has no rows 0..15 (they are its diagonal block): zero that corner once per pair
+      for (int t = tid; t < 16 * NB; t += nthreads) {Xs[(t >> 4) * XS + NB + (t & 15)] = 0.0;}
+    }
+    panel(jb, nb_a, rb, Xs);
+    if (!pair) {
+      if (use_lds) {
+        trailing_update<true, 16>(F, Xs, m, rb, jb, nb_a, 0, nrows, nrows_pad, false, true, lane, wave, nwaves);
+      } else {
+        trailing_update<false, 16>(F, Xs, m, rb, jb, nb_a, 0, nrows, nrows_pad, false, true, lane, wave, nwaves);
+      }
+      __syncthreads();
+      TSTAMP();
+      jb += NB;
+      continue;
+    }
+    if (use_lds) {
+      trailing_update<true, 16>(F, Xs, m, rb, jb, nb_a, 0, nrows, nrows_pad, true, false, lane, wave, nwaves);
     } else {
-      trailing_update<false>(F, Xs, m, r0, jb, nb, nrows, nrows_pad, lane, wave, nwaves);
+      trailing_update<false, 16>(F, Xs, m, rb, jb, nb_a, 0, nrows, nrows_pad, true, false, lane, wave, nwaves);
+    }
+    __syncthreads();
+    const int nb_b = NB;
+    panel(jb + NB, nb_b, rb, Xs + NB);
+    if (use_lds) {
+      trailing_update<true, 32>(F, Xs, m, rb, jb, nb_a, nb_b, nrows, nrows_pad, false, false, lane, wave, nwaves);
+    } else {
+      trailing_update<false, 32>(F, Xs, m, rb, jb, nb_a, nb_b, nrows, nrows_pad, false, false, lane, wave, nwaves);
     }
     __syncthreads();
     TSTAMP();
+    jb += 2 * NB;
   }
   if (tbuf && blockIdx.x == 0 && threadIdx.x == 0) {tbuf[0] = tcount; tbuf[63] = ((long long)m << 32) | ns;}
   if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
