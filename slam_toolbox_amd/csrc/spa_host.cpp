@@ -953,14 +953,12 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
     KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
     dbg("assemble", -1);
-    for (int l = 0; l < n_levels; ++l) {
-      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_fail.p, st);
-      dbg("factor", l);
-    }
+    // factorisation and forward solve are one kernel per level (the forward step of a panel runs while its
+    // L11 / L21 are still in LDS), so the right-hand side has to be in place first
     spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, st);
     for (int l = 0; l < n_levels; ++l) {
-      spa_launch_forward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_rhs.p, s->d_upd.p, st);
-      dbg("forward", l);
+      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
+      dbg("factor+forward", l);
     }
     for (int l = n_levels - 1; l >= 0; --l) {
       spa_launch_backward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_rhs.p, st);

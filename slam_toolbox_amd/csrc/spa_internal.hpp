@@ -59,9 +59,10 @@ void spa_launch_diag(const SpaDev & d, const double * scale, double * diag_out, 
 void spa_launch_jacobi_scale(const SpaDev & d, double * scale_out, void * stream);
 void spa_launch_assemble(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, void * stream);
 // max_m = largest front dimension of the level (sizes the LDS panel / vector)
-void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag, void * stream);
+// also does the forward solve of the level: rhs (elimination order) in, y out; upd as for the backward level
+void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag,
+                             double * rhs, double * upd, void * stream);
 // upd: per-front forward-solve contributions to the ancestors, 3 * front_rows_ptr[n_fronts] doubles
-void spa_launch_forward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, double * upd, void * stream);
 void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, void * stream);
 // rhs (elimination order) <- scale * g ; and back: step = -y (free order), delta = step * scale
 void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, void * stream);

@@ -13,6 +13,7 @@
 // Numerics here are FP64 with FMA contraction allowed (parity bar for the solver is 1e-9 against the
 // CPU restatement, not bit equality).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -341,7 +342,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // upper-triangle garbage a lane computes is never read by another lane).  Writes L back to the front
 // and L plus the reciprocal diagonal (column NB) to the LDS copy `ld`.  Rows/columns >= nb are padded
 // with the identity.  Returns true when a pivot is not positive.
-__device__ __noinline__ bool factor_diag_block(double * F, int m, int jb, int nb, int lane, double * ld)
+__device__ __noinline__ bool factor_diag_block(double * F, int m, int jb, int nb, int lane, double * ld, double * rhs_seg)
 {
   double row[NB];
 #pragma unroll
@@ -374,13 +375,24 @@ __device__ __noinline__ bool factor_diag_block(double * F, int m, int jb, int nb
     }
     ld[lane * (NB + 1) + NB] = rdiag;
   }
+  // fused forward solve: y = L11^-1 b for this panel's segment of the front's right-hand side (LDS)
+  {
+    double v = lane < nb ? rhs_seg[lane] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const double yj = readlane_f64(v, j) * readlane_f64(rdiag, j);
+      if (lane == j) {v = yj;} else if (lane > j) {v -= row[j] * yj;}
+    }
+    if (lane < nb) {rhs_seg[lane] = v;}
+  }
   return bad && lane < nb;
 }
 
 // Panel solve of one row: x = a L11^-T for the nb (<= 16) columns of the panel; a = gcol[c * m].  x goes
 // back to the front and into the row's LDS panel slot (zero padded to 16).  nb = 0: padding row, only
 // the zero fill.  `ld` = 16 x 17 LDS copy of L11 with the reciprocal diagonal in column 16.
-__device__ __noinline__ void panel_row_solve(double * gcol, int m, int nb, const double * ld, double * xrow)
+__device__ __noinline__ void panel_row_solve(double * gcol, int m, int nb, const double * ld, double * xrow,
+                                             const double * y, double * rhs_row)
 {
   double xr[NB];
 #pragma unroll
@@ -399,11 +411,13 @@ __device__ __noinline__ void panel_row_solve(double * gcol, int m, int nb, const
     for (int q = 0; q < c; ++q) {v -= xr[q] * lrow[q];}
     xr[c] = v * lrow[NB];
   }
+  double dot = 0.0;
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    if (c < nb) {gcol[(int64_t)c * m] = xr[c];}
+    if (c < nb) {gcol[(int64_t)c * m] = xr[c]; dot += xr[c] * y[c];}
     xrow[c] = xr[c];
   }
+  if (nb > 0) {*rhs_row -= dot;}          // fused forward solve: b_i -= L21[i, :] . y
 }
 
 constexpr int kMaxLdsRows = 568;           // 568 * 33 * 8 B = 150 KB of the CU's 160 KB LDS
@@ -486,7 +500,8 @@ __device__ __forceinline__ void trailing_update(double * F, const double * Xs, i
   }
 }
 
-__global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag, long long * tbuf)
+__global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag, long long * tbuf,
+              double * rhs, double * upd, int lds_rows)
 {
   // KH_SPA_TIMING=1: stage timestamps (100 MHz wall clock) of the level's largest front, printed by the host
   int tcount = 0;
@@ -502,13 +517,20 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
   const bool use_lds = m <= kMaxLdsRows;    // larger fronts read the panel back from the front itself (L2)
   __shared__ double Ld[NB][NB + 1];
   __shared__ int s_fail;
+  // Fused forward solve (K6c, first half): the front's slice of the right-hand side lives in LDS next to the
+  // panel -- pivots from rhs (elimination order), struct rows accumulate the children's contributions -- and
+  // every panel applies y = L11^-1 b, b_below -= L21 y while L11 and L21 are still on chip.
+  double * sb = use_lds ? smem + (size_t)lds_rows * XS : smem;
+  const int first = 3 * d.front_first[k];
+  for (int t = tid; t < m; t += nthreads) {sb[t] = t < ns ? rhs[first + t] : 0.0;}
+  __syncthreads();
 
   // 1. extend-add the children's update matrices (lower triangles).  Children are taken one after the
   //    other (two children may add into the same entry); within a child every wave takes columns
   //    four at a time with all loads issued before the first add, so the pass is bound by bandwidth and
   //    not by a chain of dependent L2 round trips.  The scalar row positions inside this front
   //    (3 * relpos + component) are staged in LDS once per child.
-  int * pos = reinterpret_cast<int *>(smem);
+  int * pos = use_lds ? reinterpret_cast<int *>(smem) : reinterpret_cast<int *>(smem + m);
   for (int ci = d.child_ptr[k]; ci < d.child_ptr[k + 1]; ++ci) {
     const int c = d.child_list[ci];
     const int mc = d.front_m[c], nsc = d.front_ns[c], nuc = mc - nsc;
@@ -516,6 +538,10 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     const int32_t * rp = d.relpos + d.relpos_ptr[c];
     for (int a = tid; a < nuc; a += nthreads) {pos[a] = 3 * rp[a / 3] + a % 3;}
     __syncthreads();
+    {
+      const double * uc = upd + 3 * (int64_t)d.front_rows_ptr[c];      // the child's forward-solve contribution
+      for (int a = tid; a < nuc; a += nthreads) {sb[pos[a]] += uc[a];}
+    }
     constexpr int CB = 8;
     for (int b0 = wave * CB; b0 < nuc; b0 += nwaves * CB) {
       for (int a0 = b0; a0 < nuc; a0 += 64) {
@@ -549,7 +575,7 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
   auto panel = [&](int jb, int nb, int rb, double * xcols) {
     // (a) diagonal block: wave 0
     if (wave == 0) {
-      if (factor_diag_block(F, m, jb, nb, lane, &Ld[0][0])) {s_fail = 1;}
+      if (factor_diag_block(F, m, jb, nb, lane, &Ld[0][0], sb + jb)) {s_fail = 1;}
     }
     __syncthreads();
     TSTAMP();
@@ -562,8 +588,10 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     for (int i = tid; i < nrows_pad; i += nthreads) {
       double * gcol = F + (r0 + i) + (int64_t)jb * m;       // F[r0 + i][jb + c] = gcol[c * m]
       if (use_lds) {
-        panel_row_solve(gcol, m, i < nrows ? nb : 0, &Ld[0][0], xcols + (size_t)(r0 - rb + i) * XS);
+        panel_row_solve(gcol, m, i < nrows ? nb : 0, &Ld[0][0], xcols + (size_t)(r0 - rb + i) * XS, sb + jb,
+                        sb + min(r0 + i, m - 1));
       } else if (i < nrows) {
+        double dot = 0.0;
 #pragma unroll 1
         for (int c = 0; c < nb; ++c) {
           const double * lrow = &Ld[c][0];
@@ -572,7 +600,9 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
           for (int q = 0; q < c; ++q) {v -= gcol[(int64_t)q * m] * lrow[q];}
           v *= lrow[NB];
           gcol[(int64_t)c * m] = v;
+          dot += v * sb[jb + c];
         }
+        sb[r0 + i] -= dot;
       }
     }
     __syncthreads();
@@ -619,26 +649,36 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     TSTAMP();
     jb += 2 * NB;
   }
+  // forward-solve results: y of the pivots back to rhs, the struct rows' partial sums to this front's slot
+  for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = sb[t];}
+  {
+    double * uk = upd + 3 * (int64_t)d.front_rows_ptr[k];
+    for (int q = tid; q < m - ns; q += nthreads) {uk[q] = sb[ns + q];}
+  }
   if (tbuf && blockIdx.x == 0 && threadIdx.x == 0) {tbuf[0] = tcount; tbuf[63] = ((long long)m << 32) | ns;}
   if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
 }
 
-void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag, void * stream)
+void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag,
+                             double * rhs, double * upd, void * stream)
 {
   if (n <= 0) {return;}
   const int threads = max_m <= 96 ? 256 : (max_m <= 192 ? 512 : 1024);
   const int lds_rows = ((max_m < kMaxLdsRows ? max_m : kMaxLdsRows) + 15) & ~15;
-  const size_t lds = sizeof(double) * (size_t)lds_rows * XS;
+  // panel + the front's right-hand side behind it; fronts beyond the LDS panel keep only the rhs (+ the
+  // extend-add position table) in LDS
+  const int small_m = max_m < kMaxLdsRows ? max_m : kMaxLdsRows;
+  const size_t lds = sizeof(double) * std::max((size_t)lds_rows * XS + small_m, (size_t)max_m + (max_m + 1) / 2 + 8);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(double) * (size_t)kMaxLdsRows * XS));
+                              (int)(sizeof(double) * ((size_t)kMaxLdsRows * XS + kMaxLdsRows + 16)));
     attr_set = true;
   }
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
   if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 64 * sizeof(long long), hipHostMallocDefault);}
-  hipLaunchKernelGGL(k_factor, dim3(n), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, timing ? tbuf : nullptr);
+  hipLaunchKernelGGL(k_factor, dim3(n), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, timing ? tbuf : nullptr, rhs, upd, lds_rows);
   if (timing) {
     (void)hipStreamSynchronize((hipStream_t)stream);
     std::fprintf(stderr, "[k_factor] n=%d max_m=%d front0 m=%lld ns=%lld stamps(x10ns):", n, max_m, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
@@ -648,10 +688,10 @@ void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6c: triangular solves, one workgroup (256 threads) per front, blocked by 16 like the factorisation.
-// rhs is in elimination order.  Forward: a front gathers its children's contributions (upd, one
-// segment per front = its struct rows) instead of scattering with atomics, so the solve is
-// bit-reproducible.  Dynamic LDS: m doubles.
+// K6c: backward triangular solve, one workgroup (256 threads) per front, blocked by 16 like the
+// factorisation (the forward solve is fused into k_factor: a front gathers its children's contributions --
+// upd, one segment per front = its struct rows -- instead of scattering with atomics, so the solve is
+// bit-reproducible).  rhs is in elimination order.  Dynamic LDS: m doubles.
 __device__ __forceinline__ void load_diag_block(const double * F, int m, int jb, int nb, int lane, double (&col)[NB])
 {
   // lane c holds column c of the 16x16 diagonal block: col[j] = L[jb+j][jb+c] (j >= c)
@@ -659,56 +699,6 @@ __device__ __forceinline__ void load_diag_block(const double * F, int m, int jb,
   for (int j = 0; j < NB; ++j) {
     col[j] = (lane < nb && j < nb && j >= lane) ? F[(jb + j) + (int64_t)(jb + lane) * m] : ((j == lane) ? 1.0 : 0.0);
   }
-}
-
-__global__ __launch_bounds__(256) void k_forward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs, double * upd)
-{
-  const int k = level_fronts[blockIdx.x];
-  const int m = d.front_m[k], ns = d.front_ns[k], nu = m - ns;
-  const double * F = d.fronts + d.front_off[k];
-  const int first = 3 * d.front_first[k];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  extern __shared__ double sb[];
-  for (int t = tid; t < m; t += 256) {sb[t] = t < ns ? rhs[first + t] : 0.0;}
-  __syncthreads();
-  for (int ci = d.child_ptr[k]; ci < d.child_ptr[k + 1]; ++ci) {
-    const int c = d.child_list[ci];
-    const int nuc = d.front_m[c] - d.front_ns[c];
-    const int32_t * rp = d.relpos + d.relpos_ptr[c];
-    const double * uc = upd + 3 * (int64_t)d.front_rows_ptr[c];
-    for (int q = tid; q < nuc; q += 256) {sb[3 * rp[q / 3] + q % 3] += uc[q];}
-    __syncthreads();
-  }
-  for (int jb = 0; jb < ns; jb += NB) {
-    const int nb = min(NB, ns - jb);
-    if (wave == 0) {
-      // lane r holds row r of the diagonal block: rowv[j] = L[jb+r][jb+j]
-      double rowv[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        rowv[j] = (lane < nb && j < nb && j <= lane) ? F[(jb + lane) + (int64_t)(jb + j) * m] : ((j == lane) ? 1.0 : 0.0);
-      }
-      double v = lane < nb ? sb[jb + lane] : 0.0;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const double yj = readlane_f64(v, j) / readlane_f64(rowv[j], j);
-        if (lane == j) {v = yj;} else if (lane > j) {v -= rowv[j] * yj;}
-      }
-      if (lane < nb) {sb[jb + lane] = v;}
-    }
-    __syncthreads();
-    const int r0 = jb + nb;
-    for (int i = r0 + tid; i < m; i += 256) {
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {if (c < nb) {acc += F[i + (int64_t)(jb + c) * m] * sb[jb + c];}}
-      sb[i] -= acc;
-    }
-    __syncthreads();
-  }
-  for (int t = tid; t < ns; t += 256) {rhs[first + t] = sb[t];}
-  double * uk = upd + 3 * (int64_t)d.front_rows_ptr[k];
-  for (int q = tid; q < nu; q += 256) {uk[q] = sb[ns + q];}
 }
 
 __global__ __launch_bounds__(256) void k_backward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs)
@@ -754,11 +744,6 @@ __global__ __launch_bounds__(256) void k_backward(SpaDev d, const int32_t * __re
   for (int t = tid; t < ns; t += 256) {rhs[first + t] = sb[t];}
 }
 
-void spa_launch_forward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, double * upd, void * stream)
-{
-  if (n <= 0) {return;}
-  hipLaunchKernelGGL(k_forward, dim3(n), dim3(256), sizeof(double) * max_m, (hipStream_t)stream, d, level_fronts, rhs, upd);
-}
 void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, void * stream)
 {
   if (n <= 0) {return;}
