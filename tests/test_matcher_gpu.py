@@ -218,3 +218,34 @@ def test_lds_staged_scoring_path(kartohip_lib, preset, fine):
     _assert_same(r_o, r_h, "response")
     _assert_same(mean_o, mean_h, "mean")
     hm.close()
+
+
+def test_ragged_batch_and_all_invalid_scan(kartohip_lib):
+    """One batch mixing scans of different beam counts and chain lengths, plus a query whose ranges are all NaN /
+    inf (every table entry INVALID_SCAN, response 0 everywhere -> the tie fallback): each result must equal the
+    oracle's for that pair alone."""
+    from common import LASER
+    from oracle import karto
+    from slam_toolbox_amd.scan_matcher import LocalizedRangeScan
+    om = make_oracle_matcher("K")
+    hmb = make_hip_matcher("K", max_batch=4)
+    qs, bs, expect = [], [], []
+    for i, (n_base, keep) in enumerate([(3, 1081), (12, 541), (7, 1081), (5, 700)]):
+        sc = Scenario(seed=40 + i, n_base=n_base, start=25 * i + 3, perturb=(0.02 * i, 0.01, -0.01 * i))
+        ranges_q = sc.query_ranges[:keep].copy()
+        if i == 2:
+            ranges_q[::2] = np.nan
+            ranges_q[1::2] = np.inf
+        oq = karto.Scan(ranges_q, sc.query_pose, LASER)
+        ob = [karto.Scan(sc.ranges[k][:keep], sc.base_poses[k], LASER) for k in range(n_base)]
+        qs.append(LocalizedRangeScan(ranges_q, sc.query_pose, LASER.min_angle, LASER.ang_res))
+        bs.append([LocalizedRangeScan(sc.ranges[k][:keep], sc.base_poses[k], LASER.min_angle, LASER.ang_res) for k in range(n_base)])
+        expect.append(om.match_scan(oq, ob, True, True))
+    resp, means, covs, status = hmb.MatchScanBatch(qs, bs)
+    assert (status == 0).all()
+    for i, (r, m, c) in enumerate(expect):
+        _assert_same(r, resp[i], f"response {i}")
+        _assert_same(m, means[i], f"mean {i}")
+        _assert_same(c, covs[i], f"cov {i}")
+    assert resp[2] == 0.0
+    hmb.close()

@@ -155,3 +155,34 @@ def test_link_info_golden(kartohip_lib):
         d, c = link_info(g["pose1"][i], g["pose2"][i], g["cov"][i])
         assert np.array_equal(d, g["diff"][i])
         assert np.array_equal(c, g["cov_out"][i])
+
+
+def test_disconnected_components_and_topology_edits(kartohip_lib):
+    """Two components (only the first holds the gauge node: the second is held by the LM damping alone, like in
+    Ceres) and a solve after RemoveConstraint / RemoveNode changed the topology: same poses as the oracle."""
+    from oracle import spa
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    g1 = synth.make_pose_graph(120, 260, seed=51)
+    g2 = synth.make_pose_graph(90, 190, seed=52)
+    init = np.concatenate([g1["init"], g2["init"] + [100.0, 0.0, 0.0]])
+    edges = np.concatenate([g1["edges"], g2["edges"] + 120])
+    z = np.concatenate([g1["z"], g2["z"]])
+    cov = np.concatenate([g1["cov"], g2["cov"]])
+    sol = HipSpaSolver()
+    sol.load(init, edges, z, cov)
+    summ = sol.Compute()
+    ref_x, info = spa.solve(init, edges, z, cov)
+    assert summ["usable"] == 1 and summ["iterations"] == info["iterations"]
+    assert _diff(sol.poses(), ref_x) < POSE_TOL
+    # drop the last 40 constraints and the last node, solve again from the current state
+    cur = sol.poses()
+    for a, b in edges[-40:]:
+        sol.RemoveConstraint(int(a), int(b))
+    sol.RemoveNode(209)
+    sol._ids = list(range(209))
+    keep = [k for k in range(len(edges) - 40) if 209 not in (edges[k, 0], edges[k, 1])]
+    summ = sol.Compute()
+    ref_x, info = spa.solve(cur[:209], edges[keep], z[keep], cov[keep])
+    assert summ["usable"] == 1 and summ["iterations"] == info["iterations"]
+    assert _diff(sol.poses(), ref_x) < POSE_TOL
+    sol.close()
