@@ -10,17 +10,19 @@ namespace kh
 constexpr int32_t kInvalidScan = INT32_MAX;   // Math.h:47 INVALID_SCAN
 constexpr int32_t kOccupied = 100;            // GridStates_Occupied
 constexpr int32_t kTieCap = 2048;             // tie indices returned per CorrelateScan before the host falls back
-constexpr int32_t kGridPad = 256;             // zeroed slack before and after the grid so aligned tile reads stay in bounds
+constexpr int32_t kGridPad = 512;             // zeroed slack before and after the grid so aligned tile reads stay in bounds
 constexpr int32_t kTileBytes = 64;            // bytes of one grid row a scoring tile reads (16 lanes x aligned dword)
 constexpr int32_t kTileSpan = 61;             // bytes of it that hold poses whatever the alignment class (64 - 3)
 constexpr int32_t kClasses = 4;               // alignment classes of a beam offset: (base0 + offset) & 3
 constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per class, [4] = slow beams
 // LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; beams are taken in slots
 // of kSlotBeams consecutive beams, each slot split into sub-chunks whose window union fits the LDS budget
-constexpr int32_t kGroupAngles = 4;
+constexpr int32_t kGroupAngles = 2;
 constexpr int32_t kSlotBeams = 32;
 constexpr int32_t kChunkWords = 8;            // int32 words per sub-chunk descriptor
-constexpr int32_t kLdsRegionBytes = 60 * 1024;
+constexpr int32_t kLdsPitch = 256;            // bytes per staged grid row: one LDS-DMA wave instruction = 4 rows
+constexpr int32_t kLdsRows = 240;             // rows of one staged region
+constexpr int32_t kLdsRegionBytes = kLdsRows * kLdsPitch;   // 60 KB, double buffered
 
 // One rasterisation job (ScanMatcher::AddScans, Mapper.cpp:1032-1105) -- device visible.
 struct RasterJob

@@ -709,8 +709,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job_sx[i] = this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
     // LDS-staged scoring: linear lattice whose window fits 64 bytes x 64 rows
     const bool lds_ok = lds_enabled && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
-      sy_ws % m->ws == 0 && (m->ws % 4) == 0 &&
-      static_cast<int64_t>((c.ny - 1) * (sy_ws / m->ws) + 1) * 4 * 48 <= kLdsRegionBytes;
+      sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && (c.ny - 1) * sx + 1 <= kLdsRows;
     job_lds[i] = lds_ok ? 1 : 0;
     job->lds_path = job_lds[i]; job->sy_cells = sy_ws / m->ws;
     job->rel = s.d_fast; job->chunks = s.d_chunks; job->chunk_counts = s.d_chunk_counts;
@@ -797,8 +796,8 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       for (size_t sl = 0; sl < slots; ++sl) {
         for (int32_t k = 0; k < cc[g * slots + sl]; ++k) {
           const int32_t * d = dd.data() + ((g * slots + sl) * kSlotBeams + k) * kChunkWords;
-          ++total; bytes += static_cast<long>(d[4]) * d[5]; beams += d[1] - d[0];
-          maxb = std::max<long>(maxb, static_cast<long>(d[4]) * d[5]);
+          ++total; bytes += static_cast<long>(d[3]) * kLdsPitch; beams += d[1] - d[0];
+          maxb = std::max<long>(maxb, static_cast<long>(d[3]) * kLdsPitch);
         }
       }
     }

@@ -441,30 +441,45 @@ void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t 
 }  // namespace kh
 
 // =============================================================================================
-// LDS-staged scoring path (windows of at most 64 bytes x 64 lattice rows: BASELINE config 2, the
-// sequential preset, every fine search).
+// LDS-staged scoring path (windows of at most 61 bytes x 64 lattice rows: BASELINE config 2, the
+// sequential preset, every fine search).  Experimental, opt-in (kh_matcher_set_debug bit 1).
 //
 // The windowed kernel above is bound by L2->L1 line fills: the 32 KB L1 cannot keep the windows of the
 // resident waves, so almost every window row is re-fetched from L2 although neighbouring beams and
-// neighbouring angles read nearly the same bytes.  Here the reuse is made explicit: a workgroup scores
+// neighbouring angles read nearly the same bytes.  Here the reuse is explicit: a workgroup scores
 // kGroupAngles adjacent angles, takes the beams in scan order (= order along the scanned contour) in
-// sub-chunks whose windows' union -- a small rectangle of the grid -- fits in LDS, stages that rectangle
-// once with coalesced loads, and then every (angle, beam) window is read from LDS.
+// sub-chunks whose windows' union -- a rectangle of at most 240 rows x 256 bytes of the grid -- is staged
+// in LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers), double buffered, and every
+// (angle, beam) window is then read from LDS.
 //
-//   K2' k_offsets_lds  one workgroup per (angle group, job): bit-exact lookup table (as K2), then one
-//                      thread per slot of kSlotBeams beams splits the slot into sub-chunks by halving
-//                      until the union rectangle fits, and writes per-beam LDS-relative window offsets
-//   K3' k_score_lds    one workgroup (16 waves = 4 angles x 4 row quarters) per (angle group, job);
-//                      per sub-chunk: stage, barrier, RY ds_read2_b32 + v_alignbyte + 4 VALU per beam
-//                      and row group, barrier.  Each pose is owned by one lane: no merge step.
+//   K2' k_offsets_lds  one workgroup per (angle group, job): bit-exact lookup table (as K2); one WAVE per
+//                      slot of 32 beams (lane = beam) splits the slot by halving until the rectangle fits and
+//                      writes the LDS-relative window offsets, sorted by alignment class, per angle
+//   K3' k_score_lds    16 waves = 2 angles x 4 alignment classes x 2 row halves.  Per sub-chunk:
+//                      [barrier] issue the DMA of the next region, then score the current one: one aligned
+//                      ds_read_b32 (row offsets are immediates: the pitch is fixed) + 4 VALU per 4 lookups.
 // =============================================================================================
 namespace kh
 {
 
-struct ChunkDesc {int32_t beam_begin, beam_end, g0, n_dw, pitch, rows, pad0, pad1;};
+struct ChunkDesc {int32_t beam_begin, beam_end, g0, rows, cnt[kGroupAngles], pad0, pad1;};
 static_assert(sizeof(ChunkDesc) == kChunkWords * 4, "descriptor size");
+static_assert(kGroupAngles == 2, "the wave roles below assume two angles per workgroup");
 
 constexpr int kNotFast = INT32_MIN;
+
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {const int o = __shfl_xor(v, s); v = o < v ? o : v;}
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {const int o = __shfl_xor(v, s); v = o > v ? o : v;}
+  return v;
+}
 
 __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_t stride)
 {
@@ -519,79 +534,86 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
     }
   }
   __syncthreads();
-  // ---- one thread per slot: split into sub-chunks, write descriptors and relative offsets ----
+  // ---- one wave per slot, lane = beam: split into sub-chunks, write descriptors and class-sorted offsets ----
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_slots = (P + kSlotBeams - 1) / kSlotBeams;
   const int span_x = 68;                                   // bytes a wave may read past a window start (64 + dword slack)
   const int span_rows = (job.ny - 1) * job.sy_cells + 1;   // grid rows a window covers
-  for (int slot = threadIdx.x; slot < n_slots; slot += blockDim.x) {
-    const int b_lo = slot * kSlotBeams, b_hi = min(P, b_lo + kSlotBeams);
+  for (int slot = wave; slot < n_slots; slot += 4) {
+    const int b_lo = slot * kSlotBeams;
+    const int n_in = min(P - b_lo, kSlotBeams);
+    int gx[kGroupAngles], gy[kGroupAngles];
+#pragma unroll
+    for (int q = 0; q < kGroupAngles; ++q) {
+      const int32_t * sgx = s_xy + (size_t)(2 * q) * P;
+      gx[q] = lane < n_in ? sgx[b_lo + lane] : 0;
+      gy[q] = lane < n_in ? sgx[P + b_lo + lane] : kNotFast;
+    }
     ChunkDesc * out = reinterpret_cast<ChunkDesc *>(job.chunks) + ((size_t)group * n_slots + slot) * kSlotBeams;
     int n_out = 0;
-    int begin = b_lo;
-    while (begin < b_hi) {
-      // largest power-of-two-ish run [begin, end) whose rectangle fits: try the rest of the slot, then halve
-      int end = b_hi;
-      int x0 = 0, y0 = 0, n_dw = 0, pitch = 0, rows = 0;
-      bool any = false;
+    int begin = 0;
+    while (begin < n_in) {
+      int end = n_in;
+      int x0 = 0, y0 = 0, rows = 0;
+      bool any = false, fits = false;
       for (;;) {
+        const bool in = lane >= begin && lane < end;
         int xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
+#pragma unroll
         for (int q = 0; q < kGroupAngles; ++q) {
-          const int32_t * sgx = s_xy + (size_t)(2 * q) * P;
-          const int32_t * sgy = sgx + P;
-          for (int i = begin; i < end; ++i) {
-            if (sgy[i] == kNotFast) {continue;}
-            xmin = min(xmin, sgx[i]); xmax = max(xmax, sgx[i]);
-            ymin = min(ymin, sgy[i]); ymax = max(ymax, sgy[i]);
+          if (in && gy[q] != kNotFast) {
+            xmin = min(xmin, gx[q]); xmax = max(xmax, gx[q]); ymin = min(ymin, gy[q]); ymax = max(ymax, gy[q]);
           }
         }
+        xmin = wave_min(xmin); xmax = wave_max(xmax); ymin = wave_min(ymin); ymax = wave_max(ymax);
         any = xmin != INT32_MAX;
         if (!any) {break;}
-        const int al = (int)(((int64_t)job.base0 + xmin) & 3);          // ws % 4 == 0: the same for every row
+        const int al = (int)(((int64_t)job.base0 + xmin) & 15);          // ws % 16 == 0: the same for every row
         x0 = xmin - al; y0 = ymin;
-        n_dw = (xmax - x0 + span_x + 3) >> 2;
-        int pitch_dw = n_dw;
-        pitch_dw += (16 - (pitch_dw & 31)) & 31;                       // == 16 (mod 32): rows land on disjoint LDS banks
-        pitch = 4 * pitch_dw;
         rows = (ymax - y0) + span_rows;
-        if ((int64_t)rows * pitch <= kLdsRegionBytes || end - begin == 1) {break;}
+        fits = (xmax - x0 + span_x <= kLdsPitch) && rows <= kLdsRows;
+        if (fits || end - begin == 1) {break;}
         end = begin + (end - begin + 1) / 2;
       }
       if (any) {
+        const bool in = lane >= begin && lane < end;
         ChunkDesc d;
-        d.beam_begin = begin; d.beam_end = end;
-        d.g0 = y0 * job.ws + x0;
-        d.n_dw = n_dw; d.pitch = pitch; d.rows = rows; d.pad0 = 0; d.pad1 = 0;
-        // one beam whose windows at the group's angles are too far apart for the LDS budget (long
-        // ranges x coarse angle steps): its windows go through the exact per-pose path instead
-        const bool fits = (int64_t)rows * pitch <= kLdsRegionBytes;
-        if (fits) {out[n_out++] = d;}
+        d.beam_begin = b_lo + begin; d.beam_end = b_lo + end;
+        d.g0 = y0 * job.ws + x0; d.rows = rows; d.pad0 = 0; d.pad1 = 0;
+#pragma unroll
         for (int q = 0; q < kGroupAngles; ++q) {
           const int a = a0 + q;
-          if (a >= job.na) {continue;}
-          const int32_t * sgx = s_xy + (size_t)(2 * q) * P;
-          const int32_t * sgy = sgx + P;
-          int32_t * rel = job.rel + (size_t)a * P;
-          for (int i = begin; i < end; ++i) {
-            if (sgy[i] == kNotFast) {rel[i] = -1; continue;}
-            if (fits) {
-              rel[i] = (sgy[i] - y0) * pitch + (sgx[i] - x0);
-            } else {
-              rel[i] = -1;
-              (job.slow + (size_t)a * P)[atomicAdd(&s_slow[q], 1)] = sgx[i] + sgy[i] * job.ws;
+          d.cnt[q] = 0;
+          if (a >= job.na) {continue;}                           // wave-uniform
+          const bool mine = in && gy[q] != kNotFast;
+          const int rel = (gy[q] - y0) * kLdsPitch + (gx[q] - x0);
+          if (fits) {
+            // sort the sub-chunk's offsets of this angle by alignment class: four contiguous segments
+            const int cls = rel & 3;
+            int offset = 0, my_rank = 0, packed = 0;
+#pragma unroll
+            for (int c = 0; c < kClasses; ++c) {
+              const unsigned long long mask = __ballot(mine && cls == c);
+              const int cnt = __popcll(mask);
+              if (cls == c) {my_rank = offset + __popcll(mask & ((1ull << lane) - 1ull));}
+              offset += cnt;
+              packed |= cnt << (8 * c);
             }
+            d.cnt[q] = packed;
+            if (mine) {job.rel[(size_t)a * P + b_lo + begin + my_rank] = rel;}
+          } else if (mine) {
+            // a single beam whose windows at the two angles are too far apart: exact per-pose path
+            (job.slow + (size_t)a * P)[atomicAdd(&s_slow[q], 1)] = gx[q] + gy[q] * job.ws;
           }
         }
-      } else {
-        for (int q = 0; q < kGroupAngles; ++q) {
-          const int a = a0 + q;
-          if (a >= job.na) {continue;}
-          int32_t * rel = job.rel + (size_t)a * P;
-          for (int i = begin; i < end; ++i) {rel[i] = -1;}
+        if (fits) {
+          if (lane == 0) {out[n_out] = d;}
+          ++n_out;
         }
       }
       begin = end;
     }
-    job.chunk_counts[(size_t)group * n_slots + slot] = n_out;
+    if (lane == 0) {job.chunk_counts[(size_t)group * n_slots + slot] = n_out;}
   }
   __syncthreads();
   if (threadIdx.x < kGroupAngles && a0 + (int)threadIdx.x < job.na) {
@@ -605,30 +627,22 @@ void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, i
   const int groups = (max_na + kGroupAngles - 1) / kGroupAngles;
   // dynamic LDS: gx, gy of kGroupAngles angles; the host guarantees P <= 2048 on this path
   const size_t lds = sizeof(int32_t) * 2 * kGroupAngles * 2048;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_offsets_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(k_offsets_lds, dim3(groups, n_jobs), dim3(256), lds, (hipStream_t)stream, d_jobs, stride);
 }
 
-// K3'.  SX = grid cells per lattice step in x.  16 waves: wave = (angle q = wave / 4, row quarter = wave % 4);
-// lane = (lx = lane & 15: 4 consecutive window bytes, ly = lane >> 4); rows yi = 16 * quarter + 4 * r + ly.
-//
-// Pipeline per sub-chunk c: [barrier] registers -> LDS (region c) [barrier] issue the global loads of region
-// c + 1 into registers, then score region c from LDS while they are in flight.  Descriptors are preloaded
-// into LDS, a slot's relative offsets into a register per lane.  A window row is ONE aligned ds_read_b32 per
-// lane; the following dword comes from the neighbouring lane (DPP row_shl:1), v_alignbyte shifts the pair
-// to the window's byte alignment (window byte 60 is the last one that never needs a 17th dword).
+// K3'.  S = grid cells per lattice step (x and y).  16 waves: wave = q * 8 + cls * 2 + half:
+// angle q of the group, alignment class cls, rows 32 * half .. 32 * half + 31; lane = (lx = lane & 15:
+// one aligned dword of the 64-byte tile row, ly = lane >> 4); rows yi = 32 * half + 4 * k + ly, k < 8.
 constexpr int kMaxLdsDescs = 160;
-constexpr int kStageRegs = 15;                 // 60 KB / 1024 lanes / 4 B
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) const void gvoid;
 
-template <int SX>
+template <int S>
 __global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
 {
-  constexpr int RY = 4;
-  constexpr int NB = (SX == 1) ? 4 : 2;
+  constexpr int RY = 8;
+  constexpr int NB = (S == 1) ? 4 : 2;
+  constexpr int PX = (S == 1) ? kTileSpan : (kTileSpan + 1) / 2;
   int job_index, group;
   if (xcd_map) {
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
@@ -641,50 +655,19 @@ __global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t
   if (job_index >= n_jobs) {return;}
   const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)job_index * stride);
   if (group * kGroupAngles >= job.na) {return;}
-  extern __shared__ uint32_t s_region[];
+  extern __shared__ uint32_t s_region[];                   // two regions of kLdsRegionBytes
   __shared__ ChunkDesc s_desc[kMaxLdsDescs];
-  __shared__ int s_ndesc;
+  __shared__ int s_ndesc, s_first_slot;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lx = lane & 15, ly = lane >> 4;
-  const int q = wave >> 2, quarter = wave & 3;
+  const int q = wave >> 3, cls = (wave >> 1) & 3, half = wave & 1;
   const int a = group * kGroupAngles + q;
   const bool live = a < job.na;
   const int P = job.n_points;
   const int n_slots = (P + kSlotBeams - 1) / kSlotBeams;
 
-  // ---- compact the group's sub-chunk descriptors into LDS (slot order) ----
-  {
-    const ChunkDesc * descs = reinterpret_cast<const ChunkDesc *>(job.chunks) + (size_t)group * n_slots * kSlotBeams;
-    const int32_t * counts = job.chunk_counts + (size_t)group * n_slots;
-    if (wave == 0) {
-      // exclusive scan of the per-slot counts (n_slots <= 64 on this path: P <= 2048)
-      const int cnt = lane < n_slots ? counts[lane] : 0;
-      int incl = cnt;
-#pragma unroll
-      for (int sft = 1; sft < 64; sft <<= 1) {
-        const int o = __shfl_up(incl, sft);
-        if (lane >= sft) {incl += o;}
-      }
-      const int excl = incl - cnt;
-      for (int k = 0; k < cnt; ++k) {
-        if (excl + k < kMaxLdsDescs) {s_desc[excl + k] = descs[(size_t)lane * kSlotBeams + k];}
-      }
-      if (lane == 63) {s_ndesc = incl;}
-    }
-  }
-  __syncthreads();
-  const int n_desc = min(s_ndesc, kMaxLdsDescs);
-  const bool overflow = s_ndesc > kMaxLdsDescs;       // pathological scans: handled below through the exact path
-
-  int row_cells[RY];
-#pragma unroll
-  for (int r = 0; r < RY; ++r) {
-    int yi = 16 * quarter + 4 * r + ly;
-    yi = yi < job.ny ? yi : job.ny - 1;
-    row_cells[r] = yi * job.sy_cells;
-  }
   int32_t acc[RY][NB];
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
@@ -695,74 +678,64 @@ __global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t
 #pragma unroll
   for (int r = 0; r < RY; ++r) {lo[r] = 0; hi[r] = 0;}
   int since_flush = 0;
+  // S == 2: poses sit on every other window byte; the window starts at byte cls of its first dword
+  const uint32_t sel = (cls & 1) ? 0x0c030c01u : 0x0c020c00u;
+  // byte offset of this lane's first row inside a window (the other rows are immediates: fixed pitch)
+  const int lanebase = 4 * lx + (32 * half + ly) * S * kLdsPitch;
 
   const gbyte * gwin = as_global(job.grid) + job.base0;
   const gint * grel = as_global(job.rel + (size_t)(live ? a : 0) * P);
+  const ChunkDesc * descs = reinterpret_cast<const ChunkDesc *>(job.chunks) + (size_t)group * n_slots * kSlotBeams;
+  const int32_t * counts = job.chunk_counts + (size_t)group * n_slots;
 
-  uint32_t stage[kStageRegs];
-  auto issue_loads = [&](const ChunkDesc & d) {
+  // LDS-DMA of one region: a wave instruction moves 4 rows x 256 B (lane = 16 bytes: row = lane >> 4, column
+  // block = lane & 15) to 1 KB of LDS starting at a wave-uniform address
+  auto issue_dma = [&](const ChunkDesc & d, int buf) {
     const gbyte * src = gwin + d.g0;
-    const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)d.n_dw - 1) / (uint32_t)d.n_dw);
-    const int total = d.rows * d.n_dw;
-#pragma unroll
-    for (int u = 0; u < kStageRegs; ++u) {
-      const int t = tid + 1024 * u;
-      const int row = (int)__umulhi((uint32_t)t, magic);
-      const int col = t - row * d.n_dw;
-      stage[u] = t < total ? *reinterpret_cast<const gu32 *>(src + (int64_t)row * job.ws + 4 * col) : 0u;
+    const int nblk = (d.rows + 3) >> 2;
+    for (int blk = wave; blk < nblk; blk += 16) {
+      int row = 4 * blk + (lane >> 4);
+      row = row < d.rows ? row : d.rows - 1;                // the tail block re-reads the last row: stays in bounds
+      const gbyte * g = src + (int64_t)row * job.ws + 16 * (lane & 15);
+      lds_u32 * dst = (lds_u32 *)s_region + buf * (kLdsRegionBytes / 4) + blk * (4 * kLdsPitch / 4);
+      __builtin_amdgcn_global_load_lds((gvoid *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     }
   };
-  auto store_region = [&](const ChunkDesc & d) {
-    const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)d.n_dw - 1) / (uint32_t)d.n_dw);
-    const int total = d.rows * d.n_dw;
-    const int pitch_dw = d.pitch >> 2;
+  // this wave's offsets of a sub-chunk: segment `cls` of angle q's class-sorted run
+  auto seg_of = [&](const ChunkDesc & d, int & off, int & cnt) {
+    const int packed = d.cnt[q];
+    off = 0;
 #pragma unroll
-    for (int u = 0; u < kStageRegs; ++u) {
-      const int t = tid + 1024 * u;
-      const int row = (int)__umulhi((uint32_t)t, magic);
-      const int col = t - row * d.n_dw;
-      if (t < total) {s_region[row * pitch_dw + col] = stage[u];}
-    }
+    for (int c = 0; c < kClasses; ++c) {if (c < cls) {off += (packed >> (8 * c)) & 0xff;}}
+    cnt = (packed >> (8 * cls)) & 0xff;
   };
-
-  if (n_desc > 0) {issue_loads(s_desc[0]);}
-  int32_t slot_rel = -1;
-  int cur_slot = -1;
-  for (int c = 0; c < n_desc; ++c) {
-    const ChunkDesc d = s_desc[c];
-    __syncthreads();                                 // everybody is done reading the previous region
-    store_region(d);
-    __syncthreads();
-    if (c + 1 < n_desc) {issue_loads(s_desc[c + 1]);}
-    if (!live) {continue;}
-    const int slot = d.beam_begin / kSlotBeams;
-    if (slot != cur_slot) {                          // wave-uniform
-      cur_slot = slot;
-      const int i = slot * kSlotBeams + lane;
-      slot_rel = (lane < kSlotBeams && i < P) ? grel[i] : -1;
-    }
-    int row_off[RY];
-#pragma unroll
-    for (int r = 0; r < RY; ++r) {row_off[r] = (row_cells[r] * d.pitch + 4 * lx) >> 2;}
-    const int k_lo = d.beam_begin - slot * kSlotBeams, k_hi = d.beam_end - slot * kSlotBeams;
-    for (int k = k_lo; k < k_hi; ++k) {
-      const int32_t rel = __builtin_amdgcn_readlane(slot_rel, k);
-      if (rel < 0) {continue;}                       // wave-uniform
-      const int sh = rel & 3;
-      const uint32_t * pw = s_region + (rel >> 2);
+  auto load_rel = [&](const ChunkDesc & d) -> int32_t {
+    int off, cnt;
+    seg_of(d, off, cnt);
+    return (live && lane < cnt) ? grel[d.beam_begin + off + lane] : 0;
+  };
+  auto score = [&](const ChunkDesc & d, int buf, int32_t rels) {
+    if (!live) {return;}
+    int off, cnt;
+    seg_of(d, off, cnt);
+    const char * base = reinterpret_cast<const char *>(s_region) + buf * kLdsRegionBytes + lanebase;
+    for (int k = 0; k < cnt; ++k) {
+      const int32_t rel = __builtin_amdgcn_readlane(rels, k);
+      const uint32_t * pw = reinterpret_cast<const uint32_t *>(base + (rel & ~3));
 #pragma unroll
       for (int r = 0; r < RY; ++r) {
-        const uint32_t w0 = pw[row_off[r]];
-        // dword of lane lx + 1 of the same row (lane 15 of a row gets 0: only window bytes > 60 need it)
-        const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x101, 0xf, 0xf, true);   // row_shl:1
-        const uint32_t w = __builtin_amdgcn_alignbyte(w1, w0, sh);
-        lo[r] += w & 0x00ff00ffu;                                           // [0, b2, 0, b0]
-        if (SX == 1) {hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);}   // [0, b3, 0, b1]
+        const uint32_t w = pw[r * (4 * S * kLdsPitch / 4)];
+        if (S == 1) {
+          lo[r] += w & 0x00ff00ffu;                                // [0, b2, 0, b0]
+          hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);      // [0, b3, 0, b1]
+        } else {
+          lo[r] += __builtin_amdgcn_perm(0u, w, sel);
+        }
       }
       if (++since_flush == 512) {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-          if (SX == 1) {
+          if (S == 1) {
             acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
             acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
           } else {
@@ -773,63 +746,97 @@ __global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t
         since_flush = 0;
       }
     }
-  }
-  if (!live) {return;}
+  };
+
+  // descriptors are walked in batches of kMaxLdsDescs (LDS copy), slot by slot
+  int slot_next = 0;
+  while (slot_next < n_slots) {
+    __syncthreads();
+    if (wave == 0) {
+      // take as many whole slots as fit: exclusive scan of the per-slot counts from slot_next on
+      const int sl = slot_next + lane;
+      const int cnt = sl < n_slots ? counts[sl] : 0;
+      int incl = cnt;
 #pragma unroll
-  for (int r = 0; r < RY; ++r) {
-    if (SX == 1) {
-      acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
-      acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
-    } else {
-      acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
+      for (int sft = 1; sft < 64; sft <<= 1) {
+        const int o = __shfl_up(incl, sft);
+        if (lane >= sft) {incl += o;}
+      }
+      const bool take = incl <= kMaxLdsDescs && sl < n_slots;
+      const unsigned long long tmask = __ballot(take);
+      const int n_take = (tmask == ~0ull) ? 64 : __ffsll((long long)~tmask) - 1;     // leading run of takeable slots
+      const int excl = incl - cnt;
+      if (lane < n_take) {
+        for (int k = 0; k < cnt; ++k) {s_desc[excl + k] = descs[(size_t)sl * kSlotBeams + k];}
+      }
+      const int total = __shfl(incl, max(n_take - 1, 0));
+      if (lane == 0) {s_ndesc = n_take > 0 ? total : 0; s_first_slot = slot_next + max(n_take, 1);}
+    }
+    __syncthreads();
+    const int n_desc = s_ndesc;
+    slot_next = s_first_slot;       // a slot with more than kMaxLdsDescs sub-chunks cannot occur (<= 32 per slot)
+    if (n_desc == 0) {continue;}
+    // software pipeline, two descriptors per trip so that the prefetched offsets alternate between two registers
+    issue_dma(s_desc[0], 0);
+    int32_t rel_a = load_rel(s_desc[0]), rel_b = 0;
+    for (int c = 0; c < n_desc; c += 2) {
+      __syncthreads();                               // region c landed (the barrier drains the DMA); region c-1 is free
+      if (c + 1 < n_desc) {issue_dma(s_desc[c + 1], 1); rel_b = load_rel(s_desc[c + 1]);}
+      score(s_desc[c], 0, rel_a);
+      if (c + 1 >= n_desc) {break;}
+      __syncthreads();
+      if (c + 2 < n_desc) {issue_dma(s_desc[c + 2], 0); rel_a = load_rel(s_desc[c + 2]);}
+      score(s_desc[c + 1], 1, rel_b);
     }
   }
+  __syncthreads();
 
-  // epilogue: every pose is owned by exactly one lane
+  // merge the eight waves of an angle (4 classes x 2 halves) in LDS, then one pose per thread
+  int32_t * s_tile = reinterpret_cast<int32_t *>(s_region) + q * (64 * PX);
+  for (int i = tid & 511; i < 64 * PX; i += 512) {s_tile[i] = 0;}
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      if (S == 1) {
+        acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
+        acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
+      } else {
+        acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = 4 * lx + ((S == 1) ? b : 2 * b + (cls & 1));     // byte position inside the aligned tile row
+        const int x = (j - cls) / S;
+        if (j >= cls && x < PX && acc[r][b] != 0) {atomicAdd(&s_tile[(32 * half + 4 * r + ly) * PX + x], acc[r][b]);}
+      }
+    }
+  }
+  __syncthreads();
+  if (!live) {return;}
   const int n_slow = job.counts[kCountsPerAngle * a + kClasses];
   const int32_t * slow = job.slow + (size_t)a * P;
   double best = 0.0;
   const size_t plane = (size_t)job.nx * job.ny;
-#pragma unroll
-  for (int r = 0; r < RY; ++r) {
-    const int yi = 16 * quarter + 4 * r + ly;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int xi = NB * lx + b;
-      if (xi >= job.nx || yi >= job.ny) {continue;}
-      int32_t sum = acc[r][b];
+  for (int p = tid & 511; p < 64 * PX; p += 512) {
+    const int yi = p / PX, xi = p % PX;
+    if (xi >= job.nx || yi >= job.ny) {continue;}
+    int32_t sum = s_tile[p];
+    if (n_slow > 0) {
+      // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197)
       const int64_t pose = (int64_t)job.bx[xi] + (int64_t)job.by[yi];
-      if (n_slow > 0) {
-        // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197)
-        for (int j = 0; j < n_slow; ++j) {
-          const int64_t idx = pose + slow[j];
-          if (idx >= 0 && idx < job.data_size) {sum += job.grid[idx];}
-        }
+      for (int j = 0; j < n_slow; ++j) {
+        const int64_t idx = pose + slow[j];
+        if (idx >= 0 && idx < job.data_size) {sum += job.grid[idx];}
       }
-      if (overflow) {
-        // more sub-chunks than descriptor slots in LDS: the remaining beams go through the table
-        const ChunkDesc * descs = reinterpret_cast<const ChunkDesc *>(job.chunks) + (size_t)group * n_slots * kSlotBeams;
-        const int32_t * counts = job.chunk_counts + (size_t)group * n_slots;
-        const int32_t * table = job.table + (size_t)a * P;
-        int seen = 0;
-        for (int sl = 0; sl < n_slots; ++sl) {
-          for (int k = 0; k < counts[sl]; ++k, ++seen) {
-            if (seen < kMaxLdsDescs) {continue;}
-            const ChunkDesc dd = descs[(size_t)sl * kSlotBeams + k];
-            for (int i = dd.beam_begin; i < dd.beam_end; ++i) {
-              if (grel[i] >= 0) {sum += job.grid[pose + table[i]];}
-            }
-          }
-        }
-      }
-      const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
-      job.sums[o] = sum;
-      const double response = pose_response(job, sum, a, yi, xi);
-      if (job.write_resp) {job.resp[o] = response;}
-      best = response > best ? response : best;
-      if (job.coarse && response > 0.0) {
-        atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
-      }
+    }
+    const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
+    job.sums[o] = sum;
+    const double response = pose_response(job, sum, a, yi, xi);
+    if (job.write_resp) {job.resp[o] = response;}
+    best = response > best ? response : best;
+    if (job.coarse && response > 0.0) {
+      atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
     }
   }
 #pragma unroll
@@ -847,17 +854,20 @@ void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int
   const int xcd_map = n_jobs >= 8 ? 1 : 0;
   const int jobs_per_xcd = (n_jobs + 7) / 8;
   const long long blocks = xcd_map ? 8ll * jobs_per_xcd * groups : (long long)n_jobs * groups;
+  constexpr int kDyn = 2 * kLdsRegionBytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRegionBytes + 256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRegionBytes + 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_offsets_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(int32_t) * 2 * kGroupAngles * 2048));
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
   if (sx_variant == 2) {
-    hipLaunchKernelGGL(k_score_lds<2>, dim3((unsigned int)blocks), dim3(1024), kLdsRegionBytes + 256, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
+    hipLaunchKernelGGL(k_score_lds<2>, dim3((unsigned int)blocks), dim3(1024), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
   } else {
-    hipLaunchKernelGGL(k_score_lds<1>, dim3((unsigned int)blocks), dim3(1024), kLdsRegionBytes + 256, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
+    hipLaunchKernelGGL(k_score_lds<1>, dim3((unsigned int)blocks), dim3(1024), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
   }
 }
 
