@@ -48,6 +48,23 @@ def pmc_traffic(batch):
         return None
 
 
+class _StdoutToStderr:
+    """The reference's karto_sdk prints to stdout ("Registering sensor: ..."); bench.py must print ONE JSON line, so
+    file descriptor 1 is pointed at stderr while the CPU baseline runs."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def cpu_baseline(reps_target_s=12.0):
     """The reference's own CorrelateScan (oracle/_ref, row-parallel thread-pool stand-in for
     tbb::parallel_for_each) -- or the C restatement when _ref is absent -- on all host cores."""
@@ -262,12 +279,15 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="matcher handles (each its own HIP stream and host thread) a rank drives concurrently; "
-                         "a step is still ONE batch of --batch matches on one of them")
+                         "a step is still ONE batch of --batch matches on one of them.  The default 1 keeps the "
+                         "per-launch kernel time of the roofline unambiguous; 2 overlaps the host half of one step "
+                         "with the kernels of another and is reported as the extra key two_stream_value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solver", action="store_true")
     ap.add_argument("--no-loop", action="store_true")
+    ap.add_argument("--no-two-stream", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -291,6 +311,7 @@ def main():
 
     from common import C2_PARAMS, PRESETS, Scenario
     from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher, _scan_array
+    from slam_toolbox_amd import shard
     B = args.batch
     S = max(1, args.streams)
     # B independent (query, chain of 10 base scans) pairs along the synthetic warehouse trajectory,
@@ -347,11 +368,38 @@ def main():
     dt = time.perf_counter() - t0
     profs = [h.profile(False) for h in handles]
     prof = {k: sum(p[k] for p in profs) for k in profs[0]}
+    two_stream = None
+    if S == 1 and not args.no_two_stream:
+        # extra key: the same steps dealt to TWO handles on two host threads (not the headline: the kernels of the two
+        # streams overlap, so per-launch event times are no longer those of an isolated kernel)
+        h2 = ScanMatcher.Create(MapperParams(**C2_PARAMS), *PRESETS["C2"]["create"], device=local_rank, max_batch=B)
+        for b in range(B):
+            h2.AddScans(queries[b], bases[b], slot=b)
+        pair = [handles[0], h2]
+        for h in pair:
+            step(h)
+
+        def worker2(k):
+            for _ in range(k, args.steps, 2):
+                step(pair[k])
+        th = [threading.Thread(target=worker2, args=(k,)) for k in range(2)]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        two_stream = shard.max_over_ranks(time.perf_counter() - t2, device="cuda") if world > 1 else time.perf_counter() - t2
+        h2.close()
     for out in results:
         if out is not None:
             resp, means, covs, status = out
             assert (status == 0).all() and (resp > 0.1).all(), "matches failed"
-    from slam_toolbox_amd import shard
     dt = shard.max_over_ranks(dt, device="cuda")
 
     solver_out = None
@@ -388,7 +436,11 @@ def main():
                                  "is the L2->L1 fill rate (31 % L1 hit) -- see DESIGN.md section 4"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            with _StdoutToStderr():
+                out["cpu_baseline"] = cpu_baseline()
+        if two_stream:
+            out["two_stream_value"] = world * B * args.steps / two_stream
+            out["two_stream_ms_per_step"] = two_stream / args.steps * 1e3
         if solver_out:
             out.update(solver_out)
         if world == 1 and not args.no_loop:
