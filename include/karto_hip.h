@@ -178,7 +178,13 @@ typedef struct kh_spa_options {
   int32_t use_nonmonotonic_steps;              /* true */
   int32_t max_consecutive_nonmonotonic_steps;  /* 3 */
   int32_t jacobi_scaling;                      /* true */
+  /* `ceres_loss_function` (ceres_solver.cpp:60-94): KH_LOSS_NONE (squared loss, the default), KH_LOSS_HUBER =
+   * ceres::HuberLoss(loss_scale), KH_LOSS_CAUCHY = ceres::CauchyLoss(loss_scale); the reference hard-wires
+   * the scale 0.7 for both */
+  int32_t loss_function;
+  double loss_scale;                           /* 0.7 */
 } kh_spa_options;
+enum { KH_LOSS_NONE = 0, KH_LOSS_HUBER = 1, KH_LOSS_CAUCHY = 2 };
 KH_API void kh_spa_options_default(kh_spa_options * o);
 
 typedef struct kh_spa_summary {

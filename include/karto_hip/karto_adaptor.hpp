@@ -176,9 +176,32 @@ public:
   }
   virtual ~HipSpaSolver() {kh_spa_destroy(m_pHandle);}
 
-  // CeresSolver::Configure reads ROS parameters; the GPU solver has the same hard-wired options
-  // (ceres_solver.cpp:157-186) and nothing else to read.
-  virtual void Configure(rclcpp_lifecycle::LifecycleNode::SharedPtr /*node*/) {}
+  // CeresSolver::Configure (ceres_solver.cpp:27-186) reads ROS parameters.  The trust-region options it
+  // hard-wires (:157-186) are the library's defaults; of the string parameters only `ceres_loss_function`
+  // changes the result (:60-94) and is honoured here.  The linear-solver / preconditioner / dogleg choices
+  // select among Ceres back ends and have no counterpart: the GPU solver is Levenberg-Marquardt over a sparse
+  // multifrontal Cholesky, the reference's default combination (:96-155).
+  virtual void Configure(rclcpp_lifecycle::LifecycleNode::SharedPtr node)
+  {
+#ifdef KARTO_HIP_READ_ROS_PARAMETERS   // set by the plugin target inside slam_toolbox (needs the real rclcpp)
+    if (!node->has_parameter("ceres_loss_function")) {
+      node->declare_parameter("ceres_loss_function", rclcpp::ParameterValue(std::string("None")));
+    }
+    SetLossFunction(node->get_parameter("ceres_loss_function").as_string());
+#else
+    (void)node;
+#endif
+  }
+
+  // "None" (squared loss) | "HuberLoss" | "CauchyLoss", scale 0.7 like ceres_solver.cpp:82-94; any other
+  // string keeps the squared loss, as in the reference.
+  void SetLossFunction(const std::string & name)
+  {
+    kh_spa_options o;
+    kh_spa_options_default(&o);
+    if (name == "HuberLoss") {o.loss_function = KH_LOSS_HUBER;} else if (name == "CauchyLoss") {o.loss_function = KH_LOSS_CAUCHY;}
+    kh_spa_set_options(m_pHandle, &o);
+  }
 
   virtual void Compute()
   {

@@ -51,6 +51,8 @@ class Options:
     use_nonmonotonic_steps: bool = True
     max_consecutive_nonmonotonic_steps: int = 3
     jacobi_scaling: bool = True
+    loss_function: str = "None"      # ceres_solver.cpp:60-94: "None" | "HuberLoss" | "CauchyLoss"
+    loss_scale: float = 0.7          # the scale the plugin hard-wires for both
 
     @staticmethod
     def tight():
@@ -152,10 +154,28 @@ def _jacobians(c, s, dx, dy, U):
     return np.einsum("eij,ejk->eik", U, Ja), np.einsum("eij,ejk->eik", U, Jb)
 
 
+def _loss(sq, kind, a):
+    """rho(s), rho'(s) of the plugin's loss functions (ceres/loss_function.cc: HuberLoss::Evaluate,
+    CauchyLoss::Evaluate).  Both have rho'' <= 0, so Ceres' Corrector (corrector.cc) reduces to scaling the
+    residual and the Jacobian rows by sqrt(rho') -- the alpha term only exists for rho'' > 0."""
+    tiny = np.finfo(np.float64).tiny
+    if kind in (None, "None"):
+        return sq, np.ones_like(sq)
+    b = a * a
+    if kind == "HuberLoss":
+        r = np.sqrt(np.where(sq > b, sq, 1.0))
+        return np.where(sq > b, 2.0 * a * r - b, sq), np.where(sq > b, np.maximum(tiny, a / r), 1.0)
+    if kind == "CauchyLoss":
+        tot = 1.0 + sq * (1.0 / b)
+        return b * np.log(tot), np.maximum(tiny, 1.0 / tot)
+    raise ValueError(kind)
+
+
 class Problem:
     """State the plugin keeps: nodes in insertion order, constraints, gauge node."""
 
-    def __init__(self, poses, edges, z, cov, fixed=0):
+    def __init__(self, poses, edges, z, cov, fixed=0, loss="None", loss_scale=0.7):
+        self.loss, self.loss_scale = loss, loss_scale
         self.x = np.asarray(poses, dtype=np.float64).copy()
         self.edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
         self.z = np.asarray(z, dtype=np.float64).reshape(-1, 3)
@@ -174,14 +194,25 @@ class Problem:
 
     def cost(self, x):
         r, _ = _residuals(x, self.edges[:, 0], self.edges[:, 1], self.z, self.U)
-        return 0.5 * float(np.sum(r * r))
+        if self.loss in (None, "None"):
+            return 0.5 * float(np.sum(r * r))
+        rho, _ = _loss(np.sum(r * r, axis=1), self.loss, self.loss_scale)
+        return 0.5 * float(np.sum(rho))
 
     def linearize(self, x):
         """cost, gradient g = J^T r and H = J^T J over the free parameters (unscaled)."""
         ea, eb = self.edges[:, 0], self.edges[:, 1]
         r, (c, s, dx, dy) = _residuals(x, ea, eb, self.z, self.U)
         Ja, Jb = _jacobians(c, s, dx, dy, self.U)
-        cost = 0.5 * float(np.sum(r * r))
+        if self.loss in (None, "None"):
+            cost = 0.5 * float(np.sum(r * r))
+        else:
+            rho, rho1 = _loss(np.sum(r * r, axis=1), self.loss, self.loss_scale)
+            cost = 0.5 * float(np.sum(rho))
+            w = np.sqrt(rho1)
+            r = r * w[:, None]
+            Ja = Ja * w[:, None, None]
+            Jb = Jb * w[:, None, None]
         n3 = 3 * self.nfree
         g = np.zeros(n3)
         ca, cb = self.col_of[ea], self.col_of[eb]
@@ -227,7 +258,7 @@ def solve(poses, edges, z, cov, options: Options = None, fixed=0):
     """CeresSolver::Compute (ceres_solver.cpp:214-269) with Ceres' trust-region LM restated.
     Returns (poses (N,3), info dict)."""
     opt = options or Options()
-    prob = Problem(poses, edges, z, cov, fixed)
+    prob = Problem(poses, edges, z, cov, fixed, opt.loss_function, opt.loss_scale)
     info = dict(iterations=0, successful_steps=0, termination="NO_CONVERGENCE", usable=True, message="", costs=[])
     x = prob.x.copy()
     if prob.nfree == 0 or len(prob.edges) == 0:

@@ -37,6 +37,9 @@ class KhGridInfo(C.Structure):
                [(k, C.c_double) for k in ("offset_x", "offset_y", "scale")]
 
 
+KH_LOSS_NONE, KH_LOSS_HUBER, KH_LOSS_CAUCHY = 0, 1, 2
+
+
 class KhSpaOptions(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int32), ("function_tolerance", C.c_double),
                 ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
@@ -44,7 +47,8 @@ class KhSpaOptions(C.Structure):
                 ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("max_num_consecutive_invalid_steps", C.c_int32), ("use_nonmonotonic_steps", C.c_int32),
-                ("max_consecutive_nonmonotonic_steps", C.c_int32), ("jacobi_scaling", C.c_int32)]
+                ("max_consecutive_nonmonotonic_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
+                ("loss_function", C.c_int32), ("loss_scale", C.c_double)]
 
 
 class KhSpaSummary(C.Structure):

@@ -624,6 +624,7 @@ void kh_spa_options_default(kh_spa_options * o)
   o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
   o->max_num_consecutive_invalid_steps = 3; o->use_nonmonotonic_steps = 1;
   o->max_consecutive_nonmonotonic_steps = 3; o->jacobi_scaling = 1;
+  o->loss_function = KH_LOSS_NONE; o->loss_scale = 0.7;
 }
 
 int kh_spa_create(int32_t device, kh_spa ** out)
@@ -884,6 +885,11 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
 
   // ---- iteration zero ----
   auto t0 = now();
+  if (opt.loss_function != KH_LOSS_NONE && !(opt.loss_scale > 0.0)) {
+    set_error("kh_spa: loss_scale must be positive");
+    return finish(KH_ERR_INVALID_ARG);
+  }
+  dev.loss_kind = opt.loss_function; dev.loss_b = opt.loss_scale * opt.loss_scale; dev.loss_a = opt.loss_scale;
   const int32_t e_lo = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * s->shard_rank / s->shard_world);
   const int32_t e_hi = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * (s->shard_rank + 1) / s->shard_world);
   const int64_t hg_count = static_cast<int64_t>(s->n_slots) * 9 + static_cast<int64_t>(dev.n_free) * 3;

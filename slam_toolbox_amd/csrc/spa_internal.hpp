@@ -20,6 +20,9 @@ struct SpaDev
   // per-edge linearisation scratch: r(3) Ja(9) Jb(9), row-major
   double * edge_lin;
   double * edge_cost;
+  // robust loss rho(s) on s = |U r|^2 (ceres_solver.cpp:82-94): 0 none, 1 Huber(a), 2 Cauchy(a); b = a^2
+  int32_t loss_kind;
+  double loss_a, loss_b;
   // BSR normal matrix over the free nodes (full symmetric pattern), 9 doubles per block, row-major blocks
   int32_t n_slots;
   const int32_t * slot_contrib_ptr;   // n_slots+1

@@ -56,24 +56,41 @@ __global__ __launch_bounds__(256) void k_edge_lin(SpaDev d, const double * __res
   const double r1 = -s * dx + c * dy - z[1];
   const double r2 = d_normalize_angle((tb - ta) - z[2]);
   // f = U r (U upper triangular)
-  const double f0 = U[0] * r0 + U[1] * r1 + U[2] * r2;
-  const double f1 = U[4] * r1 + U[5] * r2;
-  const double f2 = U[8] * r2;
-  d.edge_cost[e] = f0 * f0 + f1 * f1 + f2 * f2;
+  double f0 = U[0] * r0 + U[1] * r1 + U[2] * r2;
+  double f1 = U[4] * r1 + U[5] * r2;
+  double f2 = U[8] * r2;
+  const double sq = f0 * f0 + f1 * f1 + f2 * f2;
+  // Robust loss, as Ceres' ResidualBlock::Evaluate + Corrector apply it: cost 0.5 rho(s); both losses the
+  // plugin offers have rho'' <= 0, for which the corrector degenerates to scaling the residual and the
+  // Jacobian rows by sqrt(rho'(s)).
+  double rho0 = sq, w = 1.0;
+  if (d.loss_kind == 1) {            // ceres::HuberLoss: s <= b -> (s, 1); else (2 a sqrt(s) - b, a / sqrt(s))
+    if (sq > d.loss_b) {
+      const double r = sqrt(sq);
+      rho0 = 2.0 * d.loss_a * r - d.loss_b;
+      w = sqrt(fmax(2.2250738585072014e-308, d.loss_a / r));
+    }
+  } else if (d.loss_kind == 2) {     // ceres::CauchyLoss: b log(1 + s/b), 1 / (1 + s/b)
+    const double sum = 1.0 + sq * (1.0 / d.loss_b);
+    rho0 = d.loss_b * log(sum);
+    w = sqrt(fmax(2.2250738585072014e-308, 1.0 / sum));
+  }
+  d.edge_cost[e] = rho0;
   if (!kJac) {return;}
   double * out = d.edge_lin + 21 * (size_t)e;
+  f0 *= w; f1 *= w; f2 *= w;
   out[0] = f0; out[1] = f1; out[2] = f2;
   // raw Jacobians (rows = residual, cols = xa, ya, ta | xb, yb, tb)
   const double ja[9] = {-c, -s, -s * dx + c * dy, s, -c, -c * dx - s * dy, 0.0, 0.0, -1.0};
   const double jb[9] = {c, s, 0.0, -s, c, 0.0, 0.0, 0.0, 1.0};
 #pragma unroll
   for (int col = 0; col < 3; ++col) {
-    out[3 + 0 + col] = U[0] * ja[col] + U[1] * ja[3 + col] + U[2] * ja[6 + col];
-    out[3 + 3 + col] = U[4] * ja[3 + col] + U[5] * ja[6 + col];
-    out[3 + 6 + col] = U[8] * ja[6 + col];
-    out[12 + 0 + col] = U[0] * jb[col] + U[1] * jb[3 + col] + U[2] * jb[6 + col];
-    out[12 + 3 + col] = U[4] * jb[3 + col] + U[5] * jb[6 + col];
-    out[12 + 6 + col] = U[8] * jb[6 + col];
+    out[3 + 0 + col] = w * (U[0] * ja[col] + U[1] * ja[3 + col] + U[2] * ja[6 + col]);
+    out[3 + 3 + col] = w * (U[4] * ja[3 + col] + U[5] * ja[6 + col]);
+    out[3 + 6 + col] = w * (U[8] * ja[6 + col]);
+    out[12 + 0 + col] = w * (U[0] * jb[col] + U[1] * jb[3 + col] + U[2] * jb[6 + col]);
+    out[12 + 3 + col] = w * (U[4] * jb[3 + col] + U[5] * jb[6 + col]);
+    out[12 + 6 + col] = w * (U[8] * jb[6 + col]);
   }
 }
 

@@ -47,6 +47,9 @@ class HipSpaSolver:
         for k, v in options.items():
             if not hasattr(o, k):
                 raise KeyError(k)
+            if k == "loss_function" and isinstance(v, str):
+                # the `ceres_loss_function` strings of ceres_solver.cpp:82-94; anything else = squared loss
+                v = {"HuberLoss": capi.KH_LOSS_HUBER, "CauchyLoss": capi.KH_LOSS_CAUCHY}.get(v, capi.KH_LOSS_NONE)
             setattr(o, k, v)
         capi.check(capi.lib().kh_spa_set_options(self._h, C.byref(o)), "kh_spa_set_options")
 

@@ -186,3 +186,31 @@ def test_disconnected_components_and_topology_edits(kartohip_lib):
     assert summ["usable"] == 1 and summ["iterations"] == info["iterations"]
     assert _diff(sol.poses(), ref_x) < POSE_TOL
     sol.close()
+
+
+@pytest.mark.parametrize("loss", ["HuberLoss", "CauchyLoss"])
+def test_robust_loss_matches_oracle(kartohip_lib, loss):
+    """`ceres_loss_function` (ceres_solver.cpp:82-94) with false loop closures in the graph: same LM
+    trajectory as the oracle's corrected linearisation."""
+    from oracle import spa
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    g = synth.make_pose_graph(300, 700, seed=41)
+    rng = np.random.default_rng(42)
+    z = g["z"].copy()
+    loops = np.flatnonzero(np.abs(g["edges"][:, 0] - g["edges"][:, 1]) > 1)
+    bad = rng.choice(loops, size=20, replace=False)
+    z[bad, :2] += rng.normal(0, 1.5, (20, 2))
+    z[bad, 2] += rng.normal(0, 0.4, 20)
+    opt = spa.Options(); opt.loss_function = loss
+    ref_x, info = spa.solve(g["init"], g["edges"], z, g["cov"], opt)
+    sol = HipSpaSolver(options=dict(loss_function=loss))
+    sol.load(g["init"], g["edges"], z, g["cov"])
+    summ = sol.Compute()
+    assert summ["usable"] == 1 and summ["iterations"] == info["iterations"], (summ, info["iterations"])
+    assert abs(summ["initial_cost"] - info["initial_cost"]) <= 1e-12 * info["initial_cost"]
+    assert abs(summ["final_cost"] - info["final_cost"]) <= 1e-9 * info["final_cost"]
+    assert _diff(sol.poses(), ref_x) < POSE_TOL
+    # and it is not the squared-loss answer
+    ref_sq, _ = spa.solve(g["init"], g["edges"], z, g["cov"])
+    assert _diff(ref_sq, ref_x) > 1e-3
+    sol.close()

@@ -59,3 +59,43 @@ def test_ceres_like_options_stop_early_and_gauge_is_fixed():
     assert info["termination"] == "CONVERGENCE" and info["iterations"] < 50
     assert np.array_equal(x[0], g["init"][0])                 # first node constant (ceres_solver.cpp:228-241)
     assert info["final_cost"] < info["initial_cost"]
+
+
+def _with_outliers(g, n_bad, seed):
+    """Corrupt n_bad non-odometry constraints (false loop closures)."""
+    rng = np.random.default_rng(seed)
+    z = g["z"].copy()
+    loops = np.flatnonzero(np.abs(g["edges"][:, 0] - g["edges"][:, 1]) > 1)
+    bad = rng.choice(loops, size=min(n_bad, len(loops)), replace=False)
+    z[bad, :2] += rng.normal(0, 1.5, (len(bad), 2))
+    z[bad, 2] += rng.normal(0, 0.4, len(bad))
+    return z, bad
+
+
+@pytest.mark.parametrize("loss", ["HuberLoss", "CauchyLoss"])
+def test_robust_loss_gradient_and_optimum(loss):
+    """ceres_solver.cpp:82-94.  The corrected linearisation must be the gradient of 0.5 sum rho(|U r|^2)
+    (checked by central differences, both branches of the loss active), the LM run must end at a stationary
+    point of that cost, and false loop closures must pull the result less than under the squared loss."""
+    g = synth.make_pose_graph(150, 330, seed=31)
+    z, bad = _with_outliers(g, 12, seed=32)
+    prob = spa.Problem(g["init"], g["edges"], z, g["cov"], loss=loss)
+    r, _ = spa._residuals(g["init"], prob.edges[:, 0], prob.edges[:, 1], prob.z, prob.U)
+    sq = np.sum(r * r, axis=1)
+    assert (sq > 0.49).any() and (sq < 0.49).any()
+    _, grad, H = prob.linearize(g["init"])
+    g0 = np.abs(grad).max()
+    rng = np.random.default_rng(1)
+    for k in rng.choice(grad.size, 25, replace=False):
+        d = np.zeros(grad.size); d[k] = 1e-6
+        num = (prob.cost(prob.plus(g["init"], d)) - prob.cost(prob.plus(g["init"], -d))) / 2e-6
+        assert abs(num - grad[k]) <= 1e-5 * max(1.0, abs(grad[k]))
+    assert abs(H - H.T).max() < 1e-9
+    opt = spa.Options.tight(); opt.loss_function = loss
+    x, info = spa.solve(g["init"], g["edges"], z, g["cov"], opt)
+    _, grad, _ = spa.Problem(x, g["edges"], z, g["cov"], loss=loss).linearize(x)
+    assert np.abs(grad).max() < 1e-6 * g0     # Gauss-Newton on a robustified cost converges linearly
+    x2, _ = spa.solve(g["init"], g["edges"], z, g["cov"], spa.Options.tight())
+    err_robust = np.abs(x[:, :2] - g["truth"][:, :2]).max()
+    err_square = np.abs(x2[:, :2] - g["truth"][:, :2]).max()
+    assert err_robust < err_square
