@@ -92,3 +92,38 @@ def test_reference_mapper_runs_on_the_gpu_solver_plugin(kartohip_lib, tmp_path):
     final = {int(r[0]): r[1:] for r in out[:accepted]}
     common = [i for i in last if i in final]
     assert common
+
+
+LIB_GPU_MATCHER = os.path.join(ROOT, "oracle", "_ref", "libkarto_ref_slam_gpu.so")
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(LIB_GPU_MATCHER)),
+                    reason="oracle/_ref/libkarto_ref_slam{,_gpu}.so not built (needs /root/reference)")
+def test_reference_mapper_runs_identically_on_the_gpu_matcher(kartohip_lib, tmp_path):
+    """Both halves of the drop-in at once.  The unmodified reference Mapper.cpp processes the same scan queue
+    twice: with its own CPU ScanMatcher, and with every MatchScan call site (sequential match Mapper.cpp:2714,
+    loop coarse / fine :1511-1535, near chains :1653, :1472) bound to karto_hip::HipScanMatcher
+    (oracle/ref_gpu_matcher_shim.cpp); the GPU solver plugin is attached in both.  The GPU matcher is bit-exact,
+    so the two runs must be IDENTICAL: same accepted scans, same nodes, same constraints with the same
+    measurement and covariance bits, same corrections, same final poses."""
+    import subprocess
+    import sys
+    runner = os.path.join(ROOT, "tests", "ref_slam_runner.py")
+    res = {}
+    for key, lib in (("cpu", LIB), ("gpu", LIB_GPU_MATCHER)):
+        prefix = str(tmp_path / key)
+        subprocess.run([sys.executable, runner, lib, "230", "5.0", prefix], check=True, timeout=900)
+        with open(prefix + ".log") as f:
+            # 'X <n> <ms>' carries the solve wall time: keep the count only
+            lines = [" ".join(l.split()[:2]) if l.startswith("X ") else l.rstrip("\n") for l in f]
+        res[key] = (np.load(prefix + ".npz"), lines)
+    (cpu, cpu_log), (gpu, gpu_log) = res["cpu"], res["gpu"]
+    assert int(gpu["gpu_matcher_calls"]) > int(cpu["accepted"]) > 150      # the Mapper really went through the shim
+    assert int(cpu["gpu_matcher_calls"]) == -1
+    assert not any(l.startswith("!") for l in cpu_log + gpu_log)
+    assert sum(l.startswith("X ") for l in cpu_log) >= 1                    # loops were closed
+    assert int(cpu["accepted"]) == int(gpu["accepted"])
+    assert cpu_log == gpu_log
+    assert np.array_equal(cpu["poses"], gpu["poses"])
+    print(f"accepted {int(cpu['accepted'])} scans; Mapper::Process wall: reference matcher {float(cpu['seconds']):.2f} s, "
+          f"GPU matcher {float(gpu['seconds']):.2f} s ({int(gpu['gpu_matcher_calls'])} MatchScan calls)")
