@@ -118,17 +118,27 @@ def solver_leg(device=0, rank=0, world=1):
     sol = HipSpaSolver(device=device)
     if world > 1:
         sol.enable_sharding(rank, world)
+    # config[3] says "serialized pose graph": the graph goes through the library's own file format
+    # (kh_spa_save / kh_spa_load, binary) before every solve, like loadSerializedPoseGraph rebuilds the plugin
+    import tempfile
     sol.load(g["init"], g["edges"], g["z"], g["cov"])
-    sol.Compute()                       # warm-up (symbolic analysis + allocation)
-    times = []
-    summ = None
-    for _ in range(5):
-        sol.load(g["init"], g["edges"], g["z"], g["cov"])
-        t = time.time()
-        summ = sol.Compute()
-        times.append(time.time() - t)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, f"config4_rank{rank}.khpg")
+        sol.save_graph(path, binary=True)
+        sol.load_graph(path)
+        sol.Compute()                       # warm-up (symbolic analysis + allocation)
+        times, loads = [], []
+        summ = None
+        for _ in range(5):
+            t = time.time()
+            sol.load_graph(path)
+            loads.append(time.time() - t)
+            t = time.time()
+            summ = sol.Compute()
+            times.append(time.time() - t)
     key = "solve_ms" if world == 1 else "solve_ms_edge_sharded"
-    return {key: float(np.median(times)) * 1e3, "solve_iterations": int(summ["iterations"]),
+    return {key: float(np.median(times)) * 1e3, "solve_graph_load_ms": float(np.median(loads)) * 1e3,
+            "solve_iterations": int(summ["iterations"]),
             "solve_final_cost": float(summ["final_cost"]), "solve_graph": "10000 nodes / 30000 edges",
             "solve_parallelism": "1 GPU" if world == 1 else f"{world} GPUs: edge-block linearisation + all-reduce(H, g), replicated factorisation"}
 

@@ -36,7 +36,8 @@ enum {
   KH_ERR_HIP = 3,           /* a HIP runtime call failed (kh_last_error() has the text) */
   KH_ERR_SEARCH = 4,        /* the reference throws std::runtime_error (Mapper.cpp:786-796, 828) */
   KH_ERR_NOT_FOUND = 5,     /* unknown node / constraint id (reference logs and returns) */
-  KH_ERR_SOLVER = 6         /* solution not usable (ceres_solver.cpp:249-254): state left unchanged */
+  KH_ERR_SOLVER = 6,        /* solution not usable (ceres_solver.cpp:249-254): state left unchanged */
+  KH_ERR_IO = 7             /* a pose-graph file could not be read / written */
 };
 
 KH_API const char * kh_last_error(void);
@@ -224,6 +225,29 @@ KH_API int32_t kh_spa_num_constraints(kh_spa * s);
 KH_API int kh_spa_compute(kh_spa * s, kh_spa_summary * summary);       /* Compute (ceres_solver.cpp:214-269) */
 /* GetCorrections (ceres_solver.cpp:272): pass ids=NULL to query the count */
 KH_API int kh_spa_get_corrections(kh_spa * s, int32_t * n, int32_t * ids, double * poses /* 3n */);
+/* ---- pose-graph files.  The reference persists a Boost binary archive of the whole
+ * Mapper (Mapper.cpp:2635-2651, serialization.hpp:38-82; not readable without Boost) and rebuilds the solver from it
+ * with Reset / AddNode* / AddConstraint* (slam_toolbox_common.cpp:959-1016).  Here the solver's own state is the file:
+ *   text    g2o SE2 records   VERTEX_SE2 id x y theta            (AddNode order; the first one is the gauge)
+ *                             FIX id                             (optional; must name the first vertex)
+ *                             EDGE_SE2 a b dx dy dtheta  i00 i01 i02 i11 i12 i22   (upper triangle of the information)
+ *           '#' comments and blank lines are skipped; numbers are written with 17 significant digits, so a
+ *           save / load round trip is bit-exact;
+ *   binary  "KHPG\1\0\0\0", int64 n, int64 m, int32 id[n], f64 pose[3n], int32 a[m], int32 b[m], f64 z[3m],
+ *           f64 info[6m], little endian.
+ * kh_spa_load parses and validates the whole file first (KH_ERR_IO / KH_ERR_INVALID_ARG leave the current graph in
+ * place), then Reset + AddNode + AddConstraint in file order; the format is detected from the first 8 bytes. */
+enum { KH_GRAPH_TEXT = 0, KH_GRAPH_BINARY = 1 };
+KH_API int kh_spa_save(kh_spa * s, const char * path, int32_t format);
+KH_API int kh_spa_load(kh_spa * s, const char * path);
+/* AddConstraint for callers that hold the information matrix (upper triangle 00 01 02 11 12 22, what EDGE_SE2
+ * carries) instead of LinkInfo's covariance: skips the inverse of ceres_solver.cpp:364-375, same llt() after it */
+KH_API int kh_spa_add_constraint_information(kh_spa * s, int32_t id_a, int32_t id_b, const double z[3],
+                                             const double info_upper[6]);
+/* enumeration in insertion order (what the files hold); KH_ERR_NOT_FOUND past the end */
+KH_API int kh_spa_get_node_at(kh_spa * s, int32_t index, int32_t * id, double pose[3]);
+KH_API int kh_spa_get_constraint(kh_spa * s, int32_t index, int32_t * id_a, int32_t * id_b, double z[3],
+                                 double info_upper[6]);
 /* LinkInfo::Update (Mapper.h:174-188) for callers without karto objects */
 KH_API int kh_link_info(const double pose1[3], const double pose2[3], const double cov[9],
                         double pose_difference[3], double cov_out[9]);

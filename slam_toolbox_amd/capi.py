@@ -12,7 +12,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkartohip.so")
 
-KH_OK, KH_ERR_INVALID_ARG, KH_ERR_NO_DEVICE, KH_ERR_HIP, KH_ERR_SEARCH, KH_ERR_NOT_FOUND, KH_ERR_SOLVER = range(7)
+KH_OK, KH_ERR_INVALID_ARG, KH_ERR_NO_DEVICE, KH_ERR_HIP, KH_ERR_SEARCH, KH_ERR_NOT_FOUND, KH_ERR_SOLVER, KH_ERR_IO = range(8)
+KH_GRAPH_TEXT, KH_GRAPH_BINARY = 0, 1
 
 dptr = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 iptr = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -69,6 +70,7 @@ SYMBOLS = [
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
     "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
+    "kh_spa_save", "kh_spa_load", "kh_spa_add_constraint_information", "kh_spa_get_node_at", "kh_spa_get_constraint",
     "kh_graph_create", "kh_graph_destroy", "kh_graph_set", "kh_graph_set_positions", "kh_graph_find_loop_candidates",
     "kh_graph_last_kernel_ms",
     "kh_occupancy_compute_dimensions", "kh_occupancy_create", "kh_occupancy_destroy", "kh_occupancy_clear",
@@ -156,6 +158,11 @@ def lib():
         L.kh_spa_get_corrections.argtypes = [vp, C.POINTER(i32), vp, vp]
         L.kh_link_info.argtypes = [dptr, dptr, dptr, dptr, dptr]
         L.kh_spa_set_sharding.argtypes = [vp, i32, i32, ALLREDUCE_FN, vp]
+        L.kh_spa_save.argtypes = [vp, C.c_char_p, i32]
+        L.kh_spa_load.argtypes = [vp, C.c_char_p]
+        L.kh_spa_add_constraint_information.argtypes = [vp, i32, i32, dptr, dptr]
+        L.kh_spa_get_node_at.argtypes = [vp, i32, C.POINTER(i32), dptr]
+        L.kh_spa_get_constraint.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), dptr, dptr]
     if hasattr(L, "kh_graph_create"):
         L.kh_graph_create.argtypes = [i32, C.POINTER(vp)]
         L.kh_graph_destroy.argtypes = [vp]

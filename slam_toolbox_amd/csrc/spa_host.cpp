@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -46,7 +47,7 @@ void set_error(const std::string & s);
   } while (0)
 
 struct Node {int32_t id; double pose[3];};
-struct Constraint {int32_t a, b; double z[3]; double u[9];};
+struct Constraint {int32_t a, b; double z[3]; double u[9]; double omega[6];};   // omega: upper triangle of the information
 
 struct Symbolic
 {
@@ -141,12 +142,18 @@ static void matrix3_inverse(const double * m, double * inv)    // Karto.h:2533-2
   for (int i = 0; i < 9; ++i) {inv[i] *= inv_det;}
 }
 
-// AddConstraint, ceres_solver.cpp:364-376: information = symmetrised inverse; U = llt().matrixU()
-static void sqrt_information(const double * cov, double * U)
+// AddConstraint, ceres_solver.cpp:364-376: information = symmetrised inverse (its upper triangle, row-major:
+// 00 01 02 11 12 22); U = llt().matrixU()
+static void information_from_covariance(const double * cov, double * omega)
 {
   double p[9];
   matrix3_inverse(cov, p);
-  const double a00 = p[0], a01 = p[1], a02 = p[2], a11 = p[4], a12 = p[5], a22 = p[8];
+  omega[0] = p[0]; omega[1] = p[1]; omega[2] = p[2]; omega[3] = p[4]; omega[4] = p[5]; omega[5] = p[8];
+}
+
+static void sqrt_information(const double * omega, double * U)
+{
+  const double a00 = omega[0], a01 = omega[1], a02 = omega[2], a11 = omega[3], a12 = omega[4], a22 = omega[5];
   const double l00 = std::sqrt(a00);
   const double l10 = a01 / l00, l20 = a02 / l00;
   const double l11 = std::sqrt(a11 - l10 * l10);
@@ -710,19 +717,258 @@ int kh_spa_add_node(kh_spa * s, int32_t id, const double pose[3])    // ceres_so
   return KH_OK;
 }
 
-int kh_spa_add_constraint(kh_spa * s, int32_t id_a, int32_t id_b, const double z[3], const double cov[9])   // :339-392
+static int add_constraint_information(kh_spa * s, int32_t id_a, int32_t id_b, const double * z, const double * omega)
 {
-  if (!s || !z || !cov) {return KH_ERR_INVALID_ARG;}
   if (!s->index_of.count(id_a) || !s->index_of.count(id_b) || id_a == id_b) {
     set_error("CeresSolver: Failed to add constraint, could not find nodes.");
     return KH_ERR_NOT_FOUND;
   }
   Constraint c; c.a = id_a; c.b = id_b;
   std::copy(z, z + 3, c.z);
-  sqrt_information(cov, c.u);
+  std::copy(omega, omega + 6, c.omega);
+  sqrt_information(c.omega, c.u);
   s->con_of.insert({{id_a, id_b}, static_cast<int32_t>(s->cons.size())});
   s->cons.push_back(c);
   s->topology_dirty = true;
+  return KH_OK;
+}
+
+int kh_spa_add_constraint(kh_spa * s, int32_t id_a, int32_t id_b, const double z[3], const double cov[9])   // :339-392
+{
+  if (!s || !z || !cov) {return KH_ERR_INVALID_ARG;}
+  double omega[6];
+  information_from_covariance(cov, omega);
+  return add_constraint_information(s, id_a, id_b, z, omega);
+}
+
+int kh_spa_add_constraint_information(kh_spa * s, int32_t id_a, int32_t id_b, const double z[3], const double info_upper[6])
+{
+  if (!s || !z || !info_upper) {return KH_ERR_INVALID_ARG;}
+  return add_constraint_information(s, id_a, id_b, z, info_upper);
+}
+
+int kh_spa_get_constraint(kh_spa * s, int32_t index, int32_t * id_a, int32_t * id_b, double z[3], double info_upper[6])
+{
+  if (!s || index < 0) {return KH_ERR_INVALID_ARG;}
+  if (index >= static_cast<int32_t>(s->cons.size())) {return KH_ERR_NOT_FOUND;}
+  const Constraint & c = s->cons[index];
+  if (id_a) {*id_a = c.a;}
+  if (id_b) {*id_b = c.b;}
+  if (z) {std::copy(c.z, c.z + 3, z);}
+  if (info_upper) {std::copy(c.omega, c.omega + 6, info_upper);}
+  return KH_OK;
+}
+
+int kh_spa_get_node_at(kh_spa * s, int32_t index, int32_t * id, double pose[3])
+{
+  if (!s || index < 0) {return KH_ERR_INVALID_ARG;}
+  if (index >= static_cast<int32_t>(s->nodes.size())) {return KH_ERR_NOT_FOUND;}
+  if (id) {*id = s->nodes[index].id;}
+  if (pose) {std::copy(s->nodes[index].pose, s->nodes[index].pose + 3, pose);}
+  return KH_OK;
+}
+
+// ---- pose-graph files --------------------------------------------------------------
+// The reference persists the graph as a Boost binary archive of the whole Mapper (Mapper.cpp:2635-2651,
+// serialization.hpp:38-82) and rebuilds the solver from it with Reset / AddNode* / AddConstraint*
+// (slam_toolbox_common.cpp:959-1016).  Boost archives are neither portable nor readable without Boost, so
+// the solver's own state is stored instead: g2o SE2 text (VERTEX_SE2 / EDGE_SE2 / FIX), or the same arrays
+// as a little-endian binary blob.
+namespace
+{
+const char kBinaryMagic[8] = {'K', 'H', 'P', 'G', 1, 0, 0, 0};
+
+struct GraphFile
+{
+  std::vector<Node> nodes;
+  std::vector<Constraint> cons;      // a, b, z, omega filled
+  bool has_fix = false; int32_t fix_id = 0;
+};
+
+bool read_all(const char * path, std::string & out)
+{
+  FILE * f = std::fopen(path, "rb");
+  if (!f) {return false;}
+  char buf[1 << 16];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) {out.append(buf, n);}
+  const bool ok = !std::ferror(f);
+  std::fclose(f);
+  return ok;
+}
+
+// one whitespace-separated token of [p, end); returns false at end of line
+bool next_token(const char *& p, const char * end, const char *& tok, size_t & len)
+{
+  while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) {++p;}
+  if (p >= end) {return false;}
+  tok = p;
+  while (p < end && *p != ' ' && *p != '\t' && *p != '\r') {++p;}
+  len = static_cast<size_t>(p - tok);
+  return true;
+}
+
+bool parse_numbers(const char *& p, const char * end, int n_int, int32_t * iv, int n_dbl, double * dv)
+{
+  const char * tok; size_t len; char tmp[64];
+  for (int k = 0; k < n_int + n_dbl; ++k) {
+    if (!next_token(p, end, tok, len) || len >= sizeof(tmp)) {return false;}
+    std::memcpy(tmp, tok, len); tmp[len] = 0;
+    char * stop = nullptr;
+    if (k < n_int) {
+      const long v = std::strtol(tmp, &stop, 10);
+      if (stop != tmp + len || v < INT32_MIN || v > INT32_MAX) {return false;}
+      iv[k] = static_cast<int32_t>(v);
+    } else {
+      dv[k - n_int] = std::strtod(tmp, &stop);
+      if (stop != tmp + len) {return false;}
+    }
+  }
+  return true;
+}
+
+int parse_text(const std::string & data, GraphFile & g)
+{
+  const char * p = data.data();
+  const char * const end_all = p + data.size();
+  int line_no = 0;
+  char msg[160];
+  while (p < end_all) {
+    const char * eol = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end_all - p)));
+    const char * end = eol ? eol : end_all;
+    ++line_no;
+    const char * q = p; const char * tok; size_t len;
+    p = eol ? eol + 1 : end_all;
+    if (!next_token(q, end, tok, len) || tok[0] == '#') {continue;}
+    const std::string tag(tok, len);
+    bool ok = true;
+    if (tag == "VERTEX_SE2") {
+      Node n;
+      ok = parse_numbers(q, end, 1, &n.id, 3, n.pose);
+      if (ok) {g.nodes.push_back(n);}
+    } else if (tag == "EDGE_SE2") {
+      Constraint c; int32_t ab[2]; double v[9];
+      ok = parse_numbers(q, end, 2, ab, 9, v);
+      if (ok) {
+        c.a = ab[0]; c.b = ab[1];
+        std::copy(v, v + 3, c.z); std::copy(v + 3, v + 9, c.omega);
+        g.cons.push_back(c);
+      }
+    } else if (tag == "FIX") {
+      int32_t id;
+      ok = parse_numbers(q, end, 1, &id, 0, nullptr);
+      if (ok && g.has_fix && g.fix_id != id) {
+        set_error("kh_spa_load: more than one FIX vertex (the plugin holds exactly the first-added node, ceres_solver.cpp:228-241)");
+        return KH_ERR_INVALID_ARG;
+      }
+      if (ok) {g.has_fix = true; g.fix_id = id;}
+    } else {
+      std::snprintf(msg, sizeof(msg), "kh_spa_load: line %d: unsupported record '%.40s'", line_no, tag.c_str());
+      set_error(msg);
+      return KH_ERR_INVALID_ARG;
+    }
+    if (ok && next_token(q, end, tok, len)) {ok = false;}       // trailing fields
+    if (!ok) {
+      std::snprintf(msg, sizeof(msg), "kh_spa_load: line %d: malformed %.40s record", line_no, tag.c_str());
+      set_error(msg);
+      return KH_ERR_INVALID_ARG;
+    }
+  }
+  return KH_OK;
+}
+
+int parse_binary(const std::string & data, GraphFile & g)
+{
+  const size_t header = 8 + 16;
+  int64_t n = 0, m = 0;
+  if (data.size() >= header) {std::memcpy(&n, data.data() + 8, 8); std::memcpy(&m, data.data() + 16, 8);}
+  if (data.size() < header || n < 0 || m < 0 || n > INT32_MAX || m > INT32_MAX ||
+    data.size() != header + static_cast<size_t>(n) * (4 + 24) + static_cast<size_t>(m) * (8 + 24 + 48))
+  {
+    set_error("kh_spa_load: truncated or oversized binary pose-graph file");
+    return KH_ERR_INVALID_ARG;
+  }
+  const char * p = data.data() + header;
+  g.nodes.resize(n); g.cons.resize(m);
+  for (int64_t i = 0; i < n; ++i) {std::memcpy(&g.nodes[i].id, p + 4 * i, 4);}
+  p += 4 * n;
+  for (int64_t i = 0; i < n; ++i) {std::memcpy(g.nodes[i].pose, p + 24 * i, 24);}
+  p += 24 * n;
+  for (int64_t k = 0; k < m; ++k) {std::memcpy(&g.cons[k].a, p + 4 * k, 4);}
+  p += 4 * m;
+  for (int64_t k = 0; k < m; ++k) {std::memcpy(&g.cons[k].b, p + 4 * k, 4);}
+  p += 4 * m;
+  for (int64_t k = 0; k < m; ++k) {std::memcpy(g.cons[k].z, p + 24 * k, 24);}
+  p += 24 * m;
+  for (int64_t k = 0; k < m; ++k) {std::memcpy(g.cons[k].omega, p + 48 * k, 48);}
+  return KH_OK;
+}
+}  // namespace
+
+int kh_spa_save(kh_spa * s, const char * path, int32_t format)
+{
+  if (!s || !path || (format != KH_GRAPH_TEXT && format != KH_GRAPH_BINARY)) {return KH_ERR_INVALID_ARG;}
+  FILE * f = std::fopen(path, format == KH_GRAPH_BINARY ? "wb" : "w");
+  if (!f) {set_error("kh_spa_save: cannot open the file for writing"); return KH_ERR_IO;}
+  bool ok = true;
+  if (format == KH_GRAPH_TEXT) {
+    ok &= std::fprintf(f, "# kartohip pose graph: g2o SE2 records, nodes in AddNode order, the first one is the gauge\n") > 0;
+    for (const Node & n : s->nodes) {
+      ok &= std::fprintf(f, "VERTEX_SE2 %d %.17g %.17g %.17g\n", n.id, n.pose[0], n.pose[1], n.pose[2]) > 0;
+    }
+    if (s->has_first && !s->nodes.empty()) {ok &= std::fprintf(f, "FIX %d\n", s->first_id) > 0;}
+    for (const Constraint & c : s->cons) {
+      ok &= std::fprintf(f, "EDGE_SE2 %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", c.a, c.b,
+          c.z[0], c.z[1], c.z[2], c.omega[0], c.omega[1], c.omega[2], c.omega[3], c.omega[4], c.omega[5]) > 0;
+    }
+  } else {
+    const int64_t n = static_cast<int64_t>(s->nodes.size()), m = static_cast<int64_t>(s->cons.size());
+    std::string blob(kBinaryMagic, 8);
+    blob.append(reinterpret_cast<const char *>(&n), 8); blob.append(reinterpret_cast<const char *>(&m), 8);
+    for (const Node & nd : s->nodes) {blob.append(reinterpret_cast<const char *>(&nd.id), 4);}
+    for (const Node & nd : s->nodes) {blob.append(reinterpret_cast<const char *>(nd.pose), 24);}
+    for (const Constraint & c : s->cons) {blob.append(reinterpret_cast<const char *>(&c.a), 4);}
+    for (const Constraint & c : s->cons) {blob.append(reinterpret_cast<const char *>(&c.b), 4);}
+    for (const Constraint & c : s->cons) {blob.append(reinterpret_cast<const char *>(c.z), 24);}
+    for (const Constraint & c : s->cons) {blob.append(reinterpret_cast<const char *>(c.omega), 48);}
+    ok &= std::fwrite(blob.data(), 1, blob.size(), f) == blob.size();
+  }
+  ok &= std::fclose(f) == 0;
+  if (!ok) {set_error("kh_spa_save: write failed"); return KH_ERR_IO;}
+  return KH_OK;
+}
+
+int kh_spa_load(kh_spa * s, const char * path)
+{
+  if (!s || !path) {return KH_ERR_INVALID_ARG;}
+  std::string data;
+  if (!read_all(path, data)) {set_error("kh_spa_load: cannot read the file"); return KH_ERR_IO;}
+  GraphFile g;
+  const bool binary = data.size() >= 8 && std::memcmp(data.data(), kBinaryMagic, 8) == 0;
+  const int rc = binary ? parse_binary(data, g) : parse_text(data, g);
+  if (rc) {return rc;}
+  // validate before touching the solver: a bad file leaves the current graph in place
+  std::unordered_map<int32_t, int32_t> seen;
+  for (const Node & n : g.nodes) {
+    if (!seen.insert({n.id, 0}).second) {set_error("kh_spa_load: duplicate vertex id"); return KH_ERR_INVALID_ARG;}
+  }
+  for (const Constraint & c : g.cons) {
+    if (!seen.count(c.a) || !seen.count(c.b) || c.a == c.b) {
+      set_error("kh_spa_load: edge between unknown vertices"); return KH_ERR_INVALID_ARG;
+    }
+    double u[9];
+    sqrt_information(c.omega, u);
+    if (!(u[0] > 0.0 && u[4] > 0.0 && u[8] > 0.0)) {     // also false for NaN
+      set_error("kh_spa_load: information matrix is not positive definite"); return KH_ERR_INVALID_ARG;
+    }
+  }
+  if (g.has_fix && (g.nodes.empty() || g.fix_id != g.nodes.front().id)) {
+    set_error("kh_spa_load: FIX must name the first vertex (the plugin holds the first-added node, ceres_solver.cpp:228-241)");
+    return KH_ERR_INVALID_ARG;
+  }
+  kh_spa_reset(s);                                     // loadSerializedPoseGraph: Reset, AddNode*, AddConstraint*
+  for (const Node & n : g.nodes) {kh_spa_add_node(s, n.id, n.pose);}
+  for (const Constraint & c : g.cons) {add_constraint_information(s, c.a, c.b, c.z, c.omega);}
   return KH_OK;
 }
 

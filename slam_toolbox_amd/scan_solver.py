@@ -8,6 +8,7 @@ RCLCPP_WARN-and-return paths of ceres_solver.cpp:219-225, 249-254, 354-361, 420-
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -177,6 +178,39 @@ class HipSpaSolver:
 
     def poses(self):
         return np.asarray([p for _, p in self._all_nodes()])
+
+    # ---- pose-graph files (the reference's counterpart is the Boost archive read by
+    # SlamToolbox::loadSerializedPoseGraph, src/slam_toolbox_common.cpp:952-1017) ------------------------
+    def save_graph(self, path: str, binary: bool = False):
+        capi.check(capi.lib().kh_spa_save(self._h, os.fsencode(path),
+                                          capi.KH_GRAPH_BINARY if binary else capi.KH_GRAPH_TEXT), "kh_spa_save")
+
+    def load_graph(self, path: str):
+        """Reset, then AddNode / AddConstraint for every record of the file (text or binary, detected)."""
+        capi.check(capi.lib().kh_spa_load(self._h, os.fsencode(path)), "kh_spa_load")
+        self._ids = [i for i, _ in self.nodes_in_order()]
+
+    def nodes_in_order(self):
+        out, L, i = [], capi.lib(), C.c_int32()
+        for k in range(L.kh_spa_num_nodes(self._h)):
+            p = np.zeros(3)
+            capi.check(L.kh_spa_get_node_at(self._h, k, C.byref(i), p), "kh_spa_get_node_at")
+            out.append((i.value, p))
+        return out
+
+    def constraints_in_order(self):
+        """[(id_a, id_b, z (3), information upper triangle (6))] in AddConstraint order."""
+        out, L, a, b = [], capi.lib(), C.c_int32(), C.c_int32()
+        for k in range(L.kh_spa_num_constraints(self._h)):
+            z, w = np.zeros(3), np.zeros(6)
+            capi.check(L.kh_spa_get_constraint(self._h, k, C.byref(a), C.byref(b), z, w), "kh_spa_get_constraint")
+            out.append((a.value, b.value, z, w))
+        return out
+
+    def AddConstraintInformation(self, source_id: int, target_id: int, pose_difference, information_upper):
+        capi.check(capi.lib().kh_spa_add_constraint_information(self._h, int(source_id), int(target_id),
+                                                                _d(pose_difference), _d(information_upper)),
+                   "kh_spa_add_constraint_information")
 
     def close(self):
         if self._h:
