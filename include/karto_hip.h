@@ -150,7 +150,9 @@ KH_API int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, in
                                   int32_t * na, int32_t * out_sums, double * out_responses);
 /* bit 0: keep the penalised response volume of every CorrelateScan on the device so that
  * kh_matcher_read_volume can return it (parity tests); bit 1: score through the experimental
- * LDS-staged kernel where the search shape allows it (same results, currently slower); off by default */
+ * LDS-staged kernel where the search shape allows it (same results, currently slower); bit 2: dense scoring --
+ * do not leave out the beams whose whole search window lies in grid blocks no scan point was stamped into
+ * (they add 0 to every pose, so the results are identical either way; for measurements); all off by default */
 KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t flags);
 /* HIP stream all kernels of this handle are launched on (hipStream_t as void*), so the caller can
  * bracket launches with HIP events on the right stream */

@@ -14,6 +14,7 @@ constexpr int32_t kGridPad = 512;             // zeroed slack before and after t
 constexpr int32_t kTileBytes = 64;            // bytes of one grid row a scoring tile reads (16 lanes x aligned dword)
 constexpr int32_t kTileSpan = 61;             // bytes of it that hold poses whatever the alignment class (64 - 3)
 constexpr int32_t kClasses = 4;               // alignment classes of a beam offset: (base0 + offset) & 3
+constexpr int32_t kBlockShift = 5;             // occupancy block map: one byte per 32 x 32 grid cells ("a stamp touched this block")
 constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per class, [4] = slow beams
 // LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; beams are taken in slots
 // of kSlotBeams consecutive beams, each slot split into sub-chunks whose window union fits the LDS budget
@@ -34,7 +35,20 @@ struct RasterJob
   int32_t ws, roi_x, roi_y, roi_w, roi_h;
   int32_t kernel_size;
   double off_x, off_y, scale;   // CoordinateConverter (Karto.h:4421-4436)
+  uint8_t * blockmap;        // bm_w * bm_h bytes, cleared together with the grid: 1 = some stamp's footprint overlaps the block
+  int32_t bm_w;
+  // tiled stamping (k_raster_*): kRasterTile x kRasterTile cell tiles, points binned to the <= 2 x 2 tiles
+  // their footprint overlaps.  All int32 scratch, zeroed with the grid where noted.
+  int32_t tiles_w, tiles_h, height;
+  int32_t * tile_count;      // tiles_w * tiles_h   (zeroed) incidences per tile
+  int32_t * tile_start;      // tiles_w * tiles_h   first list entry of the tile
+  int32_t * tile_cursor;     // tiles_w * tiles_h   (zeroed) fill cursor
+  int32_t * work;            // tiles_w * tiles_h   non-empty tiles
+  int32_t * n_work;          // 1                   (written by the scan)
+  int32_t * cell_xy;         // 2 * n_points        grid cell of every kept point, x < 0 = dropped
+  int32_t * list;            // 4 * n_points        point indices, tile after tile
 };
+constexpr int32_t kRasterTile = 64;
 
 // One CorrelateScan job (Mapper.cpp:712-862) -- device visible.  All pointers are device pointers.
 struct CorrJob
@@ -74,6 +88,9 @@ struct CorrJob
   int32_t * rel;             // na*P: byte offset of the beam's window start inside its sub-chunk's LDS region, or -1
   int32_t * chunks;          // [groups][slots][kSlotBeams][kChunkWords]: sub-chunk descriptors
   int32_t * chunk_counts;    // [groups][slots]: sub-chunks of the slot
+  // empty-window skipping: a beam whose whole window lies in blocks no stamp touched adds 0 to every pose
+  const uint8_t * blockmap;  // see RasterJob; nullptr = do not skip
+  int32_t bm_w;
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
   unsigned long long * out;  // result block, see below
@@ -86,7 +103,7 @@ struct CorrJob
 //   [2+cap/2 .. )    probs: nx*ny doubles as bits, max over angle (Mapper.cpp:781-799)
 constexpr size_t kOutHeaderWords = 2 + kTieCap / 2;
 
-void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, const uint8_t * d_kernel, void * stream);
+void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
                   int32_t sx_variant, int32_t ry, void * stream);

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -122,6 +123,7 @@ struct Slot
 {
   uint8_t * d_grid = nullptr;        // first grid byte (256-byte aligned); the allocation has kGridPad zero bytes either side
   uint8_t * d_grid_alloc = nullptr;
+  uint8_t * d_blockmap = nullptr;    // bm_w x bm_h occupancy blocks of this grid (cleared and marked with it)
   double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
   // correlate scratch
   int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
@@ -130,6 +132,8 @@ struct Slot
   int32_t * d_sums = nullptr; double * d_resp = nullptr; size_t cap_volume = 0, cap_resp = 0;
   // raster staging
   double * d_rpoints = nullptr; uint8_t * d_ractive = nullptr; size_t cap_rpoints = 0, cap_ractive = 0;
+  int32_t * d_rtiles = nullptr;      // tile_count | tile_cursor | n_work(+pad) | tile_start | work   (first three zeroed per raster)
+  int32_t * d_rlists = nullptr; size_t cap_rlists = 0;   // cell_xy (2 np) | list (4 np)
   // last correlate (for the introspection calls)
   CorrHost last;
   bool has_last = false;
@@ -157,6 +161,9 @@ struct kh_matcher
   double * h_rpoints = nullptr; uint8_t * h_ractive = nullptr; size_t cap_hrpoints = 0, cap_hractive = 0;
   RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
   bool keep_responses = false;
+  bool dense_score = false;        // kh_matcher_set_debug bit 2: do not skip beams whose window is empty
+  int32_t bm_w = 0, bm_h = 0;
+  int32_t rt_w = 0, rt_h = 0;      // rasteriser tiles over the grid
   bool lds_score = false;          // experimental LDS-staged scoring path (kh_matcher_set_debug bit 1)
   // profiling
   bool profiling = false;
@@ -376,6 +383,8 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     if (rc) {return rc;}
     rc = ensure_device(s.d_ractive, s.cap_ractive, std::max<size_t>(np, 1), m->stream);
     if (rc) {return rc;}
+    rc = ensure_device(s.d_rlists, s.cap_rlists, std::max<size_t>(np, 1) * 6, m->stream);
+    if (rc) {return rc;}
     if (np) {
       std::memcpy(m->h_rpoints + 2 * cursor, pts[r].data(), sizeof(double) * 2 * np);
       std::memcpy(m->h_ractive + cursor, act[r].data(), np);
@@ -386,6 +395,12 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.grid = s.d_grid; j.points = s.d_rpoints; j.active = s.d_ractive; j.n_points = static_cast<int32_t>(np);
     j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
     j.kernel_size = m->kernel_size; j.off_x = s.off_x; j.off_y = s.off_y; j.scale = m->scale;
+    j.blockmap = s.d_blockmap; j.bm_w = m->bm_w;
+    const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
+    j.tiles_w = m->rt_w; j.tiles_h = m->rt_h; j.height = m->data_size / m->ws;
+    j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
+    j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
+    j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * std::max<size_t>(np, 1);
     cursor += np;
   }
   KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * reqs.size(), hipMemcpyHostToDevice, m->stream));
@@ -393,8 +408,10 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   // 3. Grid::Clear (Karto.h:4612-4615) + stamps
   for (size_t r = 0; r < reqs.size(); ++r) {
     KH_HIP(hipMemsetAsync(m->slots[reqs[r].slot].d_grid, 0, static_cast<size_t>(m->data_size), m->stream));
+    KH_HIP(hipMemsetAsync(m->slots[reqs[r].slot].d_blockmap, 0, static_cast<size_t>(m->bm_w) * m->bm_h, m->stream));
+    KH_HIP(hipMemsetAsync(m->slots[reqs[r].slot].d_rtiles, 0, (2 * static_cast<size_t>(m->rt_w) * m->rt_h + 4) * sizeof(int32_t), m->stream));
   }
-  launch_raster(m->d_rjobs, static_cast<int32_t>(reqs.size()), static_cast<int32_t>(max_points), m->d_kernel, m->stream);
+  launch_raster(m->d_rjobs, static_cast<int32_t>(reqs.size()), static_cast<int32_t>(max_points), m->rt_w * m->rt_h, m->d_kernel, m->stream);
   KH_HIP(hipGetLastError());
   if (m->profiling) {
     KH_HIP(hipEventRecord(m->ev[3], m->stream));
@@ -526,6 +543,13 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   bool & use_lds = B.use_lds;
   constexpr size_t kSmallVolume = 4096;
   int rc = KH_OK;
+  // KH_MATCH_TIMING=1: wall split of the stages, printed every 64 calls (diagnostics only)
+  static const bool timing = std::getenv("KH_MATCH_TIMING") != nullptr;
+  static double t_acc[4] = {0, 0, 0, 0}; static long t_calls = 0;
+  const auto t_enter = std::chrono::steady_clock::now();
+  auto lap = [&](int slot, std::chrono::steady_clock::time_point from) {
+    if (timing) {t_acc[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - from).count();}
+  };
   if (phase == 0) {
   ctx.assign(n, CorrHost()); lay.assign(n, StageLayout());
   stride = 0; out_words = 0; max_na = 0; max_tiles = 0; max_poses = 0; sx_variant = -1; ry = -1; uniform_kernel = true;
@@ -726,6 +750,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->invalid = db + L.invalid;
     job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
     job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i;
+    job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w;
   });
   bool all_lds = true;
   for (size_t i = 0; i < n; ++i) {
@@ -737,6 +762,8 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   use_lds = all_lds && uniform_kernel;
 
   // ---- 2. upload, launch, download ----
+  lap(0, t_enter);
+  const auto t_enqueue = std::chrono::steady_clock::now();
   KH_HIP(hipMemcpyAsync(B.d_stage, B.h_stage, stride * n, hipMemcpyHostToDevice, m->stream));
   KH_HIP(hipMemsetAsync(B.d_out, 0, out_words * 8 * n, m->stream));
   if (use_lds) {
@@ -780,9 +807,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     }
   }
   KH_HIP(hipEventRecord(B.done, m->stream));
+  lap(1, t_enqueue);
   return KH_OK;
   }   // phase 0
   KH_HIP(hipEventSynchronize(B.done));
+  lap(2, t_enter);
+  const auto t_final = std::chrono::steady_clock::now();
   if (use_lds && std::getenv("KH_LDS_DEBUG")) {
     const CorrHost & c0 = ctx[0];
     const Slot & s0 = m->slots[c0.slot];
@@ -943,6 +973,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       final_rc[i] = finalize(i);
     });
   }
+  lap(3, t_final);
+  if (timing && ++t_calls % 64 == 0) {
+    std::fprintf(stderr, "[kh match] per call: prepare %.3f ms, enqueue %.3f ms, wait %.3f ms, finalize %.3f ms (n = %zu, stage %zu B/job)\n",
+      t_acc[0] / 64, t_acc[1] / 64, t_acc[2] / 64, t_acc[3] / 64, n, stride);
+    t_acc[0] = t_acc[1] = t_acc[2] = t_acc[3] = 0;
+  }
   for (size_t i = 0; i < n; ++i) {if (final_rc[i] != KH_OK) {return final_rc[i];}}
   return KH_OK;
 }
@@ -1087,11 +1123,18 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   }
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
+  m->rt_w = (m->ws + kRasterTile - 1) / kRasterTile;
+  m->rt_h = (m->data_size / m->ws + kRasterTile - 1) / kRasterTile;
+  m->bm_w = (m->ws >> kBlockShift) + 1;
+  m->bm_h = (m->data_size / m->ws >> kBlockShift) + 2;
   m->slots.resize(max_batch);
   for (auto & s : m->slots) {
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid_alloc), static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
     if ((e = hipMemset(s.d_grid_alloc, 0, static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMemset grid");}
     s.d_grid = s.d_grid_alloc + kGridPad;
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_blockmap), static_cast<size_t>(m->bm_w) * m->bm_h)) != hipSuccess) {return fail(e, "hipMalloc block map");}
+    if ((e = hipMemset(s.d_blockmap, 0, static_cast<size_t>(m->bm_w) * m->bm_h)) != hipSuccess) {return fail(e, "hipMemset block map");}
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_rtiles), (4 * static_cast<size_t>(m->rt_w) * m->rt_h + 8) * sizeof(int32_t))) != hipSuccess) {return fail(e, "hipMalloc raster tiles");}
   }
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&m->h_rjobs), sizeof(RasterJob) * max_batch, hipHostMallocDefault)) != hipSuccess) {return fail(e, "hipHostMalloc");}
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_rjobs), sizeof(RasterJob) * max_batch)) != hipSuccess) {return fail(e, "hipMalloc");}
@@ -1105,7 +1148,7 @@ void kh_matcher_destroy(kh_matcher * m)
   hipSetDevice(m->device);
   if (m->stream) {hipStreamSynchronize(m->stream);}
   for (auto & s : m->slots) {
-    hipFree(s.d_grid_alloc); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
+    hipFree(s.d_grid_alloc); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
   }
@@ -1144,6 +1187,7 @@ int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
   if (!m) {return KH_ERR_INVALID_ARG;}
   m->keep_responses = (keep_response_volume & 1) != 0;
   m->lds_score = (keep_response_volume & 2) != 0;
+  m->dense_score = (keep_response_volume & 4) != 0;
   return KH_OK;
 }
 

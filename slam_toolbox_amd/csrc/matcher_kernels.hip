@@ -17,7 +17,9 @@
 // byte loads.  The 4 waves of a workgroup split the beam list and merge through LDS.  The
 // arithmetic is exact integer; the FP64 penalty is applied once per pose in the epilogue.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include "kh_internal.hpp"
 
 #ifndef KH_UB8
@@ -47,16 +49,26 @@ __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: one wave per valid point; lanes = 4 kernel rows x 16 grid words; word-wise CAS "max".
-// The stamp is a commutative max, so the parallel result equals the sequential one; the only
-// order-dependent part of AddScan (skip if the cell is already 100) is resolved on the host
-// into `active` when the kernel holds 100 off-centre (see matcher_host.cpp).
-__global__ __launch_bounds__(256) void k_raster(const RasterJob * jobs, const uint8_t * __restrict__ kernel)
+// K1: AddScans after Grid::Clear.  The stamp is a commutative byte-wise max (SmearPoint, Mapper.h:1152-1183),
+// so the parallel result equals the sequential one; the only order-dependent part of AddScan ("skip if the
+// cell is already 100", Mapper.cpp:1093-1096) is resolved on the host into `active` when the kernel holds
+// 100 off-centre (see matcher_host.cpp).  Tiled so that the read-modify-write traffic stays in LDS:
+//
+//   k_raster_bin    thread per point: WorldToGrid, ROI test, duplicate test (a second point in the same cell
+//                   stamps the same footprint: dropped), occupancy-block marks, incidence counts of the
+//                   <= 2 x 2 tiles of 64 x 64 cells the k x k footprint overlaps (k <= 41)
+//   k_raster_scan   workgroup per job: exclusive scan of the counts -> list starts, list of non-empty tiles
+//   k_raster_fill   thread per point: point index into the lists of its tiles
+//   k_raster_tile   workgroup per non-empty tile: max-stamps its points into an LDS tile (ds_max_u32 per
+//                   cell), then writes the tile's bytes once, coalesced.  HBM sees the grid clear, one
+//                   4 KB write per touched tile and the point records -- not k^2 atomics per point.
+__global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.y];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + wave;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= job.n_points) {return;}
+  int32_t * cell = job.cell_xy + 2 * (size_t)p;
+  cell[0] = -1; cell[1] = -1;
   if (!job.active[p]) {return;}
   // CoordinateConverter::WorldToGrid, Karto.h:4421-4436
   const double wx = job.points[2 * p], wy = job.points[2 * p + 1];
@@ -65,40 +77,143 @@ __global__ __launch_bounds__(256) void k_raster(const RasterJob * jobs, const ui
   const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
   // Mapper.cpp:1083-1088
   if (!(gx >= 0 && gx < job.roi_w) || !(gy >= 0 && gy < job.roi_h)) {return;}
-  const int k = job.kernel_size, hk = k / 2;
-  const int lrow = lane >> 4, lword = lane & 15;
-  uint32_t * words = reinterpret_cast<uint32_t *>(job.grid);
-  for (int j0 = 0; j0 < k; j0 += 4) {
-    const int j = j0 + lrow;
-    if (j >= k) {continue;}
-    // first byte of kernel row j in the grid (CorrelationGrid::GridIndex, Mapper.h:1122-1128)
-    const int32_t s = (gx - hk + job.roi_x) + (gy + (j - hk) + job.roi_y) * job.ws;
-    const int32_t w0 = s >> 2, w1 = (s + k - 1) >> 2;
-    for (int32_t w = w0 + lword; w <= w1; w += 16) {
-      uint32_t stamp = 0;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int kx = (w << 2) + b - s;
-        if (kx >= 0 && kx < k) {stamp |= (uint32_t)kernel[j * k + kx] << (8 * b);}
-      }
-      if (stamp == 0) {continue;}
-      uint32_t old = words[w];
-      while (true) {
-        const uint32_t neu = bytemax4(old, stamp);
-        if (neu == old) {break;}
-        const uint32_t prev = atomicCAS(&words[w], old, neu);
-        if (prev == old) {break;}
-        old = prev;
-      }
+  const int cx = gx + job.roi_x, cy = gy + job.roi_y;      // CorrelationGrid::GridIndex, Mapper.h:1122-1128
+  // the kernel's centre is 100 = its maximum: write it now and use the byte as the "cell already stamped" flag
+  const int32_t index = cx + cy * job.ws;
+  uint32_t * word = reinterpret_cast<uint32_t *>(job.grid) + (index >> 2);
+  const uint32_t bit = (uint32_t)kOccupied << (8 * (index & 3));
+  const uint32_t old = atomicOr(word, bit);
+  if (((old >> (8 * (index & 3))) & 0xffu) != 0) {return;}
+  cell[0] = cx; cell[1] = cy;
+  const int hk = job.kernel_size / 2;
+  {
+    const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
+    const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
+    for (int by = fy0; by <= fy1; ++by) {
+      for (int bx = fx0; bx <= fx1; ++bx) {job.blockmap[(size_t)by * job.bm_w + bx] = 1;}
+    }
+  }
+  const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
+  const int ty0 = (cy - hk) / kRasterTile, ty1 = (cy + hk) / kRasterTile;
+  for (int ty = ty0; ty <= ty1; ++ty) {
+    for (int tx = tx0; tx <= tx1; ++tx) {atomicAdd(&job.tile_count[ty * job.tiles_w + tx], 1);}
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_raster_scan(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.x];
+  const int n = job.tiles_w * job.tiles_h;
+  const int per = (n + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(n, lo + per);
+  __shared__ int32_t s_sum[1024], s_cnt[1024];
+  int32_t sum = 0, cnt = 0;
+  for (int t = lo; t < hi; ++t) {const int32_t c = job.tile_count[t]; sum += c; cnt += c != 0;}
+  s_sum[threadIdx.x] = sum; s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  // Hillis-Steele inclusive scan of the per-thread totals
+  for (int d = 1; d < 1024; d <<= 1) {
+    int32_t a = 0, b = 0;
+    if ((int)threadIdx.x >= d) {a = s_sum[threadIdx.x - d]; b = s_cnt[threadIdx.x - d];}
+    __syncthreads();
+    s_sum[threadIdx.x] += a; s_cnt[threadIdx.x] += b;
+    __syncthreads();
+  }
+  int32_t run = s_sum[threadIdx.x] - sum, w = s_cnt[threadIdx.x] - cnt;
+  for (int t = lo; t < hi; ++t) {
+    const int32_t c = job.tile_count[t];
+    job.tile_start[t] = run;
+    if (c != 0) {job.work[w++] = t;}
+    run += c;
+  }
+  if (threadIdx.x == 1023) {job.n_work[0] = s_cnt[1023];}
+}
+
+__global__ __launch_bounds__(256) void k_raster_fill(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= job.n_points) {return;}
+  const int cx = job.cell_xy[2 * (size_t)p], cy = job.cell_xy[2 * (size_t)p + 1];
+  if (cx < 0) {return;}
+  const int hk = job.kernel_size / 2;
+  const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
+  const int ty0 = (cy - hk) / kRasterTile, ty1 = (cy + hk) / kRasterTile;
+  for (int ty = ty0; ty <= ty1; ++ty) {
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const int t = ty * job.tiles_w + tx;
+      job.list[job.tile_start[t] + atomicAdd(&job.tile_cursor[t], 1)] = p;
     }
   }
 }
 
-void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, const uint8_t * d_kernel, void * stream)
+__global__ __launch_bounds__(1024) void k_raster_tile(const RasterJob * jobs, const uint8_t * __restrict__ kernel)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  __shared__ uint32_t s_tile[kRasterTile * kRasterTile];
+  __shared__ uint8_t s_kernel[41 * 41 + 3];
+  const int k = job.kernel_size, hk = k / 2, kk = k * k;
+  for (int i = threadIdx.x; i < kk; i += blockDim.x) {s_kernel[i] = kernel[i];}
+  const int n_work = job.n_work[0];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int kWaves = 16;
+  // lanes over footprint cells.  kk >= 64: one point per wave pass, lane walks cells lane, lane + 64, ... with
+  // (row, col) advanced incrementally.  kk < 64: 64 / kk points per wave pass, one cell per lane.
+  const int ppw = kk >= 64 ? 1 : 64 / kk;                 // points per wave pass
+  const int sub = kk >= 64 ? 0 : lane / kk;               // which of them this lane works for
+  const int c0 = kk >= 64 ? lane : lane - sub * kk;       // first cell of this lane
+  const bool lane_on = kk >= 64 || sub < ppw;
+  const int row0 = c0 / k, col0 = c0 - row0 * k;
+  const int drow = 64 / k, dcol = 64 - drow * k;
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int t = job.work[w];
+    const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
+    const int ox = tx * kRasterTile, oy = ty * kRasterTile;       // grid cell of the tile's corner
+    for (int i = threadIdx.x; i < kRasterTile * kRasterTile; i += blockDim.x) {s_tile[i] = 0;}
+    __syncthreads();
+    const int begin = job.tile_start[t], count = job.tile_count[t];
+    for (int q = wave * ppw + sub; q < count; q += kWaves * ppw) {
+      if (!lane_on) {break;}
+      const int p = job.list[begin + q];
+      // footprint corner relative to the tile
+      const int fx = job.cell_xy[2 * (size_t)p] - hk - ox, fy = job.cell_xy[2 * (size_t)p + 1] - hk - oy;
+      int row = row0, col = col0;
+      for (int c = c0; c < kk; c += 64) {
+        const int x = fx + col, y = fy + row;
+        if ((unsigned)x < (unsigned)kRasterTile && (unsigned)y < (unsigned)kRasterTile) {
+          const uint32_t v = s_kernel[c];
+          if (v != 0) {atomicMax(&s_tile[y * kRasterTile + x], v);}
+        }
+        col += dcol; row += drow;
+        if (col >= k) {col -= k; ++row;}
+      }
+    }
+    __syncthreads();
+    // write the tile: 64 rows x 16 words (clipped to the grid)
+    uint32_t * words = reinterpret_cast<uint32_t *>(job.grid);
+    for (int i = threadIdx.x; i < kRasterTile * kRasterTile / 4; i += blockDim.x) {
+      const int row = i >> 4, wcol = i & 15;
+      const int y = oy + row, x = ox + 4 * wcol;
+      if (y >= job.height || x >= job.ws) {continue;}
+      const uint32_t * src = &s_tile[row * kRasterTile + 4 * wcol];
+      const uint32_t packed = src[0] | (src[1] << 8) | (src[2] << 16) | (src[3] << 24);
+      words[((size_t)y * job.ws + x) >> 2] = packed;
+    }
+    __syncthreads();
+  }
+}
+
+void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream)
 {
   if (n_jobs <= 0 || max_points <= 0) {return;}
-  dim3 grid((max_points + 3) / 4, n_jobs);
-  hipLaunchKernelGGL(k_raster, grid, dim3(256), 0, (hipStream_t)stream, d_jobs, d_kernel);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 per_point((max_points + 255) / 256, n_jobs);
+  hipLaunchKernelGGL(k_raster_bin, per_point, dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_raster_scan, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_raster_fill, per_point, dim3(256), 0, s, d_jobs);
+  // non-empty tiles <= 4 per point and <= all tiles; a workgroup walks several when there are more
+  int blocks = std::min(std::min(max_tiles, 4 * max_points), 2048);
+  hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(1024), 0, s, d_jobs, d_kernel);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -138,6 +253,24 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
     if (job.linear) {
       if ((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size) {continue;}  // off the grid for every pose
       if ((int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size) {
+        if (job.blockmap) {
+          // the window of this beam: x0 .. x0 + xs - 1 bytes of grid rows y0 .. y0 + ys - 1.  If no stamp
+          // footprint overlaps any of its 32 x 32 blocks, every byte of it is 0 and the beam adds nothing
+          // to any pose of this angle: leave it out (bit-identical sums).  Windows that wrap around the row
+          // end (beams beyond the range threshold, Appendix A.3) are kept.
+          const int32_t start = (int32_t)((int64_t)idx + bmin);
+          const int32_t wy0 = start / job.ws, wx0 = start - wy0 * job.ws;
+          const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;
+          if (wx0 + xs <= job.ws) {
+            const int bx0 = wx0 >> kBlockShift, bx1 = (wx0 + xs - 1) >> kBlockShift;
+            const int by0 = wy0 >> kBlockShift, by1 = (wy0 + ys - 1) >> kBlockShift;
+            bool any = false;
+            for (int by = by0; by <= by1 && !any; ++by) {
+              for (int bx = bx0; bx <= bx1; ++bx) {any = any || job.blockmap[(size_t)by * job.bm_w + bx] != 0;}
+            }
+            if (!any) {continue;}
+          }
+        }
         // alignment class of the window start: K3 reads class-c windows with aligned dwords
         const int cls = (int)(((int64_t)idx + bmin) & (kClasses - 1));
         fast[(size_t)cls * P + atomicAdd(&s_counts[cls], 1)] = idx;
@@ -395,7 +528,8 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
   const long long blocks = 8ll * units_per_xcd * na_chunk * max_tiles;
   dim3 grid((unsigned int)blocks);
   hipStream_t s = (hipStream_t)stream;
-#define KH_SCORE(SXV, RYV) hipLaunchKernelGGL((k_score<SXV, RYV, AW>), grid, dim3(256 * AW), 0, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
+  static const int lds_pad = std::getenv("KH_K3_LDS_PAD") ? std::atoi(std::getenv("KH_K3_LDS_PAD")) : 0;   // occupancy experiment
+#define KH_SCORE(SXV, RYV) hipLaunchKernelGGL((k_score<SXV, RYV, AW>), grid, dim3(256 * AW), lds_pad, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
   if (sx_variant == 2) {
     if (ry == 8) {KH_SCORE(2, 8);} else if (ry == 4) {KH_SCORE(2, 4);} else {KH_SCORE(2, 1);}
   } else {

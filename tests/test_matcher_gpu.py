@@ -220,6 +220,54 @@ def test_lds_staged_scoring_path(kartohip_lib, preset, fine):
     hm.close()
 
 
+@pytest.mark.parametrize("preset", ["S", "L", "C2"])
+def test_empty_window_skipping_is_invisible(kartohip_lib, preset):
+    """K2 leaves out the beams whose whole search window lies in 32 x 32 grid blocks no scan point was stamped
+    into (they add 0 to every pose).  Default (skipping) and dense scoring (kh_matcher_set_debug bit 2) must give
+    the same integer sums, both equal to the oracle's volume; a query far away from every base scan (all windows
+    empty) must come back with response 0 exactly like the oracle."""
+    import math
+    sc = Scenario(seed=15, n_base=9, start=40, perturb=(0.03, -0.05, 0.04))
+    oq, ob = sc.oracle_scans()
+    hq, hb = sc.hip_scans()
+    om = make_oracle_matcher(preset, threads=8)
+    res = None
+    vols = []
+    for dense in (False, True):
+        hm = make_hip_matcher(preset)
+        hm.set_debug(True, dense_score=dense)
+        hm.AddScans(hq, hb)
+        if res is None:
+            om.add_scans(oq, ob)
+            res = 1.0 / om.grid_info()["scale"]
+            p = PRESETS[preset]["params"]
+            if preset == "C2":
+                args = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+            else:
+                side = PRESETS[preset]["create"][0]
+                off = 0.5 * round(side / res) * res
+                args = ((off, off), (2 * res, 2 * res), p["coarse_search_angle_offset"], p["coarse_angle_resolution"])
+            r_o, mean_o, cov_o = om.correlate_scan(oq, sc.query_pose, *args, True, False)
+            vol = om.volume()
+        r_h, mean_h, cov_h = hm.CorrelateScan(hq, sc.query_pose, *args, True, None, False)
+        sums, resp = hm.volume()
+        assert np.array_equal(bits(vol[..., 0]), bits(resp)), "response volume differs"
+        _assert_same(r_o, r_h, "response")
+        _assert_same(mean_o, mean_h, "mean")
+        _assert_same(cov_o, cov_h, "covariance")
+        vols.append(sums)
+        # a search centred 15 m away from the map: nothing but zeros in every window
+        far = sc.query_pose + np.array([15.0, 15.0, 0.3])
+        r_of, mean_of, cov_of = om.correlate_scan(oq, far, *args, True, False)
+        r_hf, mean_hf, cov_hf = hm.CorrelateScan(hq, far, *args, True, None, False)
+        _assert_same(r_of, r_hf, "far response")
+        _assert_same(mean_of, mean_hf, "far mean")
+        _assert_same(cov_of, cov_hf, "far covariance")
+        hm.close()
+    assert np.array_equal(vols[0], vols[1])
+    assert vols[0].max() > 0
+
+
 def test_ragged_batch_and_all_invalid_scan(kartohip_lib):
     """One batch mixing scans of different beam counts and chain lengths, plus a query whose ranges are all NaN /
     inf (every table entry INVALID_SCAN, response 0 everywhere -> the tie fallback): each result must equal the
