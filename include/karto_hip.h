@@ -248,6 +248,8 @@ KH_API int kh_spa_add_constraint_information(kh_spa * s, int32_t id_a, int32_t i
                                              const double info_upper[6]);
 /* enumeration in insertion order (what the files hold); KH_ERR_NOT_FOUND past the end */
 KH_API int kh_spa_get_node_at(kh_spa * s, int32_t index, int32_t * id, double pose[3]);
+/* all nodes at once, insertion order: ids[kh_spa_num_nodes], poses[3 * kh_spa_num_nodes] (either may be NULL) */
+KH_API int kh_spa_get_nodes(kh_spa * s, int32_t * ids, double * poses);
 KH_API int kh_spa_get_constraint(kh_spa * s, int32_t index, int32_t * id_a, int32_t * id_b, double z[3],
                                  double info_upper[6]);
 /* LinkInfo::Update (Mapper.h:174-188) for callers without karto objects */

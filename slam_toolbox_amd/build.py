@@ -31,7 +31,7 @@ def needs_build() -> bool:
 def build(force: bool = False) -> str:
     if force or needs_build():
         srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-        cmd = [hipcc()] + FLAGS + ["-o", LIB] + srcs
+        cmd = [hipcc()] + FLAGS + os.environ.get("KH_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB] + srcs
         subprocess.check_call(cmd)
     return LIB
 

@@ -70,7 +70,7 @@ SYMBOLS = [
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
     "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
-    "kh_spa_save", "kh_spa_load", "kh_spa_add_constraint_information", "kh_spa_get_node_at", "kh_spa_get_constraint",
+    "kh_spa_save", "kh_spa_load", "kh_spa_add_constraint_information", "kh_spa_get_node_at", "kh_spa_get_constraint", "kh_spa_get_nodes",
     "kh_graph_create", "kh_graph_destroy", "kh_graph_set", "kh_graph_set_positions", "kh_graph_find_loop_candidates",
     "kh_graph_last_kernel_ms",
     "kh_occupancy_compute_dimensions", "kh_occupancy_create", "kh_occupancy_destroy", "kh_occupancy_clear",
@@ -162,6 +162,7 @@ def lib():
         L.kh_spa_load.argtypes = [vp, C.c_char_p]
         L.kh_spa_add_constraint_information.argtypes = [vp, i32, i32, dptr, dptr]
         L.kh_spa_get_node_at.argtypes = [vp, i32, C.POINTER(i32), dptr]
+        L.kh_spa_get_nodes.argtypes = [vp, vp, vp]
         L.kh_spa_get_constraint.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), dptr, dptr]
     if hasattr(L, "kh_graph_create"):
         L.kh_graph_create.argtypes = [i32, C.POINTER(vp)]

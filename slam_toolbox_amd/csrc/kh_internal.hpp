@@ -36,7 +36,7 @@ struct RasterJob
   int32_t kernel_size;
   double off_x, off_y, scale;   // CoordinateConverter (Karto.h:4421-4436)
   uint8_t * blockmap;        // bm_w * bm_h bytes, cleared together with the grid: 1 = some stamp's footprint overlaps the block
-  int32_t bm_w;
+  int32_t bm_w, bm_h;
   // tiled stamping (k_raster_*): kRasterTile x kRasterTile cell tiles, points binned to the <= 2 x 2 tiles
   // their footprint overlaps.  All int32 scratch, zeroed with the grid where noted.
   int32_t tiles_w, tiles_h, height;
@@ -78,8 +78,10 @@ struct CorrJob
   const uint8_t * invalid;   // P: range reading is NaN/inf (Karto.h:6869-6875)
   // device scratch / outputs
   int32_t * table;           // na*P full lookup table (Karto.h:6844-6894)
-  int32_t * fast;            // na*4*P compacted offsets valid for every pose of the lattice, bucketed by
-                             // alignment class (base0 + offset) & 3: list (a, c) starts at (a*4 + c)*P
+  int32_t * fast;            // na*4*lt*P compacted offsets valid for every pose of the lattice, bucketed by alignment
+                             // class (base0 + offset) & 3 and scoring tile: list (a, c, t) starts at ((a*4 + c)*lt + t)*P
+  int32_t * tcounts;         // na*4*lt list lengths
+  int32_t list_tiles;        // lt: tiles_x * tiles_y when <= 32, else 1 (one list per (a, c) shared by all tiles)
   int32_t * slow;            // na*P compacted offsets needing the per-pose range check
   int32_t * counts;          // na*8: {n_class0..3, n_slow, -, -, -}
   // LDS-staged path (lds_path != 0: linear lattice whose window fits 64 bytes x 64 rows)
@@ -90,7 +92,8 @@ struct CorrJob
   int32_t * chunk_counts;    // [groups][slots]: sub-chunks of the slot
   // empty-window skipping: a beam whose whole window lies in blocks no stamp touched adds 0 to every pose
   const uint8_t * blockmap;  // see RasterJob; nullptr = do not skip
-  int32_t bm_w;
+  int32_t bm_w, bm_h;
+  double * tile_best;        // [na][tiles_y * tiles_x] best response of every scoring tile (K3 -> K4); nullptr = K4 scans everything
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
   unsigned long long * out;  // result block, see below
@@ -104,6 +107,7 @@ struct CorrJob
 constexpr size_t kOutHeaderWords = 2 + kTieCap / 2;
 
 void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
+void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream);
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
                   int32_t sx_variant, int32_t ry, void * stream);
@@ -111,6 +115,6 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
 inline int32_t score_tile_poses(int32_t sx) {return sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;}
 void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream);
-void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, void * stream);
+void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, int32_t tile_pairs, void * stream);
 
 }  // namespace kh

@@ -96,6 +96,7 @@ struct CorrHost
   double off_x = 0, off_y = 0, res_x = 0, res_y = 0, ang_off = 0, ang_res = 0;
   bool fine = false, penalize = false;
   std::vector<double> x_poses, y_poses, angles, dist_pen, ang_pen;
+  int32_t lt_alloc = 1;          // tile lists the slot's `fast` buffer was sized for
   std::vector<int32_t> bx, by;
   double denom = 1.0;
 };
@@ -108,6 +109,7 @@ struct CorrBatch
   std::vector<CorrHost> ctx;
   std::vector<StageLayout> lay;
   size_t stride = 0, out_words = 0;
+  int32_t tile_pairs = 0;
   int32_t max_na = 0, max_tiles = 0, max_poses = 0, sx_variant = -1, ry = -1;
   bool uniform_kernel = true, use_lds = false;
   // staging (pinned host + device mirror) for the jobs; pinned result mirror; small fine-pass volumes
@@ -127,11 +129,13 @@ struct Slot
   double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
   // correlate scratch
   int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
+  int32_t * d_tcounts = nullptr; size_t cap_tcounts = 0, cap_fast = 0;
   size_t cap_table = 0, cap_counts = 0;
   int32_t * d_chunks = nullptr, * d_chunk_counts = nullptr; size_t cap_chunks = 0, cap_chunk_counts = 0;
   int32_t * d_sums = nullptr; double * d_resp = nullptr; size_t cap_volume = 0, cap_resp = 0;
   // raster staging
   double * d_rpoints = nullptr; uint8_t * d_ractive = nullptr; size_t cap_rpoints = 0, cap_ractive = 0;
+  double * d_tile_best = nullptr; size_t cap_tile_best = 0;
   int32_t * d_rtiles = nullptr;      // tile_count | tile_cursor | n_work(+pad) | tile_start | work   (first three zeroed per raster)
   int32_t * d_rlists = nullptr; size_t cap_rlists = 0;   // cell_xy (2 np) | list (4 np)
   // last correlate (for the introspection calls)
@@ -395,7 +399,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.grid = s.d_grid; j.points = s.d_rpoints; j.active = s.d_ractive; j.n_points = static_cast<int32_t>(np);
     j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
     j.kernel_size = m->kernel_size; j.off_x = s.off_x; j.off_y = s.off_y; j.scale = m->scale;
-    j.blockmap = s.d_blockmap; j.bm_w = m->bm_w;
+    j.blockmap = s.d_blockmap; j.bm_w = m->bm_w; j.bm_h = m->bm_h;
     const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
     j.tiles_w = m->rt_w; j.tiles_h = m->rt_h; j.height = m->data_size / m->ws;
     j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
@@ -406,11 +410,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * reqs.size(), hipMemcpyHostToDevice, m->stream));
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[2], m->stream));}
   // 3. Grid::Clear (Karto.h:4612-4615) + stamps
-  for (size_t r = 0; r < reqs.size(); ++r) {
-    KH_HIP(hipMemsetAsync(m->slots[reqs[r].slot].d_grid, 0, static_cast<size_t>(m->data_size), m->stream));
-    KH_HIP(hipMemsetAsync(m->slots[reqs[r].slot].d_blockmap, 0, static_cast<size_t>(m->bm_w) * m->bm_h, m->stream));
-    KH_HIP(hipMemsetAsync(m->slots[reqs[r].slot].d_rtiles, 0, (2 * static_cast<size_t>(m->rt_w) * m->rt_h + 4) * sizeof(int32_t), m->stream));
-  }
+  launch_raster_clear(m->d_rjobs, static_cast<int32_t>(reqs.size()), m->stream);
   launch_raster(m->d_rjobs, static_cast<int32_t>(reqs.size()), static_cast<int32_t>(max_points), m->rt_w * m->rt_h, m->d_kernel, m->stream);
   KH_HIP(hipGetLastError());
   if (m->profiling) {
@@ -601,14 +601,22 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     // device scratch for this slot
     const size_t tp = static_cast<size_t>(c.na) * c.P;
     if (tp > s.cap_table) {
-      if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_fast)); KH_HIP(hipFree(s.d_slow));}
+      if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_slow));}
       const size_t cap = std::max(tp, s.cap_table + s.cap_table / 2);
       KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_table), cap * 4));
-      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_fast), cap * 4 * kClasses));
       KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_slow), cap * 4));
       s.cap_table = cap;
     }
     rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * kCountsPerAngle, m->stream); if (rc) {return rc;}
+    {
+      // one compacted list per (angle, alignment class, scoring tile): bound of the tile count, the job's real
+      // one (<= it) is set with the rest of the job below
+      size_t lt = static_cast<size_t>((c.nx + 30) / 31) * ((c.ny + 4 * pick_ry(c.ny) - 1) / (4 * pick_ry(c.ny)));
+      if (lt > 32) {lt = 1;}
+      c.lt_alloc = static_cast<int32_t>(lt);
+      rc = ensure_device(s.d_fast, s.cap_fast, tp * kClasses * lt, m->stream); if (rc) {return rc;}
+      rc = ensure_device(s.d_tcounts, s.cap_tcounts, static_cast<size_t>(c.na) * kClasses * lt, m->stream); if (rc) {return rc;}
+    }
     {
       const size_t groups = (static_cast<size_t>(c.na) + kGroupAngles - 1) / kGroupAngles;
       const size_t slots = (static_cast<size_t>(c.P) + kSlotBeams - 1) / kSlotBeams;
@@ -617,6 +625,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     }
     const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
     rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
+    // best response per scoring tile: at most ceil(nx / 31) x ceil(ny / 4) tiles per angle
+    rc = ensure_device(s.d_tile_best, s.cap_tile_best,
+        static_cast<size_t>(c.na) * ((c.nx + 30) / 31) * ((c.ny + 3) / 4), m->stream); if (rc) {return rc;}
     if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
 
   }
@@ -749,8 +760,10 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->local = reinterpret_cast<const double *>(db + L.local);
     job->invalid = db + L.invalid;
     job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
+    job->tcounts = s.d_tcounts; job->list_tiles = job->tiles_x * job->tiles_y <= c.lt_alloc ? job->tiles_x * job->tiles_y : 1;
     job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i;
-    job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w;
+    job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
+    job->tile_best = s.d_tile_best;
   });
   bool all_lds = true;
   for (size_t i = 0; i < n; ++i) {
@@ -760,6 +773,14 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     all_lds = all_lds && job_lds[i] != 0;
   }
   use_lds = all_lds && uniform_kernel;
+  int32_t tile_pairs = 0;
+  for (size_t i = 0; i < n; ++i) {
+    CorrJob * job = reinterpret_cast<CorrJob *>(B.h_stage + stride * i);
+    if (use_lds) {job->tile_best = nullptr;}            // the LDS-staged kernel does not report tile bests
+    tile_pairs = std::max(tile_pairs, job->na * job->tiles_x * job->tiles_y);
+  }
+  if (use_lds) {tile_pairs = 0;}
+  B.tile_pairs = tile_pairs;
 
   // ---- 2. upload, launch, download ----
   lap(0, t_enter);
@@ -784,7 +805,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     }
   }
   if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], m->stream));}
-  launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, m->stream);
+  launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, B.tile_pairs, m->stream);
   KH_HIP(hipGetLastError());
   KH_HIP(hipMemcpyAsync(B.h_out, B.d_out, out_words * 8 * n, hipMemcpyDeviceToHost, m->stream));
   // fine passes need the raw sums of every angle at the best cell (ComputeAngularCovariance): their
@@ -1148,7 +1169,7 @@ void kh_matcher_destroy(kh_matcher * m)
   hipSetDevice(m->device);
   if (m->stream) {hipStreamSynchronize(m->stream);}
   for (auto & s : m->slots) {
-    hipFree(s.d_grid_alloc); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_slow); hipFree(s.d_counts);
+    hipFree(s.d_grid_alloc); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_tile_best); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_tcounts); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
   }

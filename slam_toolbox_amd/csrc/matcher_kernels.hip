@@ -62,6 +62,32 @@ __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
 //   k_raster_tile   workgroup per non-empty tile: max-stamps its points into an LDS tile (ds_max_u32 per
 //                   cell), then writes the tile's bytes once, coalesced.  HBM sees the grid clear, one
 //                   4 KB write per touched tile and the point records -- not k^2 atomics per point.
+// Grid::Clear (Karto.h:4612-4615) of every job of the batch in ONE launch: the grid, its occupancy block map and
+// the zero-initialised part of the tile scratch (a memset per buffer per job costs more in launches than in bytes).
+__global__ __launch_bounds__(256) void k_raster_clear(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  // the grid base is 256-byte aligned and ws is a multiple of 8: whole uint2 words, then the tail
+  const size_t bytes = (size_t)job.ws * job.height;
+  uint4 * g16 = reinterpret_cast<uint4 *>(job.grid);
+  const size_t n16 = bytes / 16;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (size_t i = tid; i < n16; i += nth) {g16[i] = zero;}
+  for (size_t i = n16 * 16 + tid; i < bytes; i += nth) {job.grid[i] = 0;}
+  const size_t bm = (size_t)job.bm_w * job.bm_h;
+  for (size_t i = tid; i < bm; i += nth) {job.blockmap[i] = 0;}
+  // tile_count | tile_cursor | n_work (+3 pad) are contiguous
+  const size_t nz = 2 * (size_t)job.tiles_w * job.tiles_h + 4;
+  for (size_t i = tid; i < nz; i += nth) {job.tile_count[i] = 0;}
+}
+
+void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream)
+{
+  if (n_jobs <= 0) {return;}
+  hipLaunchKernelGGL(k_raster_clear, dim3(512, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs);
+}
+
 __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.y];
@@ -224,7 +250,17 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   const int a = blockIdx.x;
   if (a >= job.na) {return;}
   __shared__ int32_t s_counts[kClasses + 1];
+  __shared__ int32_t s_tcounts[kClasses * 32];
+  __shared__ uint8_t s_bm[4096];
   if (threadIdx.x < kClasses + 1) {s_counts[threadIdx.x] = 0;}
+  if (threadIdx.x < kClasses * 32) {s_tcounts[threadIdx.x] = 0;}
+  const int lt = job.list_tiles;
+  // small occupancy maps (coarse grids) are read from LDS: the per-tile tests make ~100 probes per beam
+  const uint8_t * bmp = job.blockmap;
+  if (bmp && job.bm_w * job.bm_h <= 4096) {
+    for (int i = threadIdx.x; i < job.bm_w * job.bm_h; i += blockDim.x) {s_bm[i] = job.blockmap[i];}
+    bmp = s_bm;
+  }
   __syncthreads();
   const int P = job.n_points;
   const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
@@ -232,7 +268,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   const int64_t bmin = job.base0;
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
   int32_t * table = job.table + (size_t)a * P;
-  int32_t * fast = job.fast + (size_t)a * kClasses * P;
+  int32_t * fast = job.fast + (size_t)a * kClasses * lt * P;
   int32_t * slow = job.slow + (size_t)a * P;
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
     int32_t idx;
@@ -253,27 +289,49 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
     if (job.linear) {
       if ((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size) {continue;}  // off the grid for every pose
       if ((int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size) {
+        uint32_t tmask = lt > 1 ? (0xffffffffu >> (32 - lt)) : 1u;
         if (job.blockmap) {
           // the window of this beam: x0 .. x0 + xs - 1 bytes of grid rows y0 .. y0 + ys - 1.  If no stamp
           // footprint overlaps any of its 32 x 32 blocks, every byte of it is 0 and the beam adds nothing
-          // to any pose of this angle: leave it out (bit-identical sums).  Windows that wrap around the row
-          // end (beams beyond the range threshold, Appendix A.3) are kept.
+          // to any pose of this angle: leave it out (bit-identical sums).  The same test per scoring tile
+          // decides which tile lists the beam joins (large windows are rarely empty as a whole, their tiles
+          // often are).  Windows that wrap around the row end (beams beyond the range threshold, Appendix
+          // A.3) are kept everywhere.
           const int32_t start = (int32_t)((int64_t)idx + bmin);
           const int32_t wy0 = start / job.ws, wx0 = start - wy0 * job.ws;
           const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;
           if (wx0 + xs <= job.ws) {
-            const int bx0 = wx0 >> kBlockShift, bx1 = (wx0 + xs - 1) >> kBlockShift;
-            const int by0 = wy0 >> kBlockShift, by1 = (wy0 + ys - 1) >> kBlockShift;
-            bool any = false;
-            for (int by = by0; by <= by1 && !any; ++by) {
-              for (int bx = bx0; bx <= bx1; ++bx) {any = any || job.blockmap[(size_t)by * job.bm_w + bx] != 0;}
+            auto any_block = [&](int x_lo, int y_lo, int x_hi, int y_hi) {
+              const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
+              const int by0 = y_lo >> kBlockShift, by1 = y_hi >> kBlockShift;
+              for (int by = by0; by <= by1; ++by) {
+                for (int bx = bx0; bx <= bx1; ++bx) {if (bmp[(size_t)by * job.bm_w + bx] != 0) {return true;}}
+              }
+              return false;
+            };
+            if (!any_block(wx0, wy0, wx0 + xs - 1, wy0 + ys - 1)) {continue;}
+            if (lt > 1) {
+              const int px = (job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan, ty_rows = 4 * job.ry;
+              tmask = 0;
+              for (int t = 0; t < lt; ++t) {
+                const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+                const int p0 = tx * px, p1 = min(job.nx, p0 + px) - 1;         // poses of the tile
+                const int r0 = ty * ty_rows, r1 = min(job.ny, r0 + ty_rows) - 1;
+                if (any_block(wx0 + p0 * job.sx, wy0 + r0 * job.sy_cells, wx0 + p1 * job.sx, wy0 + r1 * job.sy_cells)) {
+                  tmask |= 1u << t;
+                }
+              }
             }
-            if (!any) {continue;}
           }
         }
         // alignment class of the window start: K3 reads class-c windows with aligned dwords
         const int cls = (int)(((int64_t)idx + bmin) & (kClasses - 1));
-        fast[(size_t)cls * P + atomicAdd(&s_counts[cls], 1)] = idx;
+        while (tmask) {
+          const int t = __builtin_ctz(tmask);
+          tmask &= tmask - 1;
+          const int li = cls * lt + t;
+          fast[(size_t)li * P + atomicAdd(&s_tcounts[li], 1)] = idx;
+        }
         continue;
       }
     }
@@ -281,6 +339,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   }
   __syncthreads();
   if (threadIdx.x < kClasses + 1) {job.counts[kCountsPerAngle * a + threadIdx.x] = s_counts[threadIdx.x];}
+  if ((int)threadIdx.x < kClasses * lt) {job.tcounts[(size_t)a * kClasses * lt + threadIdx.x] = s_tcounts[threadIdx.x];}
 }
 
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream)
@@ -376,7 +435,10 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
   // this wave's alignment class and the byte of its first dword that belongs to pose x0
   const int cls = wave & 3;
   const int s = (cls + x0 * SX) & 3;
-  const int n_fast = live ? job.counts[kCountsPerAngle * a + cls] : 0;
+  // K2 keeps one list per (angle, class, scoring tile): the beams whose window has something in that tile
+  const int lt = job.list_tiles;                 // tiles with lists of their own (1 = one list for all tiles)
+  const size_t list_id = ((size_t)a * kClasses + cls) * lt + (lt > 1 ? tile : 0);
+  const int n_fast = live ? job.tcounts[list_id] : 0;
   if (n_fast > 0) {
     // per-lane byte offset of row r inside the window; rows beyond ny are clamped (sums discarded)
     uint32_t voff[RY];
@@ -389,7 +451,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
     // scalar part of the address: first grid byte of the lattice + tile origin, moved back to the
     // dword boundary (>= -3: the allocation has kGridPad zero bytes in front)
     const gbyte * gbase = as_global(job.grid) + ((int64_t)job.base0 + x0 * SX - s);
-    const gint * gfast = as_global(job.fast + ((size_t)a * kClasses + cls) * P);
+    const gint * gfast = as_global(job.fast + list_id * P);
     // SX == 2: poses sit on every other byte, the even or the odd ones depending on s
     const uint32_t sel = (s & 1) ? 0x0c030c01u : 0x0c020c00u;
     // Offsets are fetched 64 at a time with one coalesced load and broadcast from the register with
@@ -503,13 +565,22 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
       atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
     }
   }
-  // wave max -> one atomic per wave
+  // wave max -> workgroup (= tile of one angle) max -> one atomic per workgroup
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) {
     const double o = __shfl_xor(best, sft);
     best = o > best ? o : best;
   }
-  if (lane == 0 && best > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(best));}
+  __shared__ double s_best[4 * AW];
+  if (lane == 0) {s_best[wave] = best;}
+  __syncthreads();
+  if (live && (threadIdx.x & 255) == 0) {
+    const double * wb = s_best + 4 * sub;
+    double b = wb[0];
+    b = wb[1] > b ? wb[1] : b; b = wb[2] > b ? wb[2] : b; b = wb[3] > b ? wb[3] : b;
+    if (job.tile_best) {job.tile_best[(size_t)a * (job.tiles_x * job.tiles_y) + tile] = b;}   // K4 skips tiles without ties
+    if (b > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(b));}
+  }
 }
 
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
@@ -545,13 +616,10 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
 {
   const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.y * stride);
   const size_t plane = (size_t)job.nx * job.ny;
-  const size_t total = plane * job.na;
   const double best = __longlong_as_double((long long)job.out[0]);
   uint32_t * tie_idx = reinterpret_cast<uint32_t *>(job.out + 2);
-  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
-    const int a = (int)(o / plane);
-    const int rem = (int)(o - (size_t)a * plane);
-    const int yi = rem / job.nx, xi = rem - yi * job.nx;
+  auto consider = [&](int a, int yi, int xi) {
+    const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
     const double response = pose_response(job, job.sums[o], a, yi, xi);
     const double delta = response - best;
     const bool tie = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;
@@ -561,13 +629,37 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
         tie_idx[slot] = (uint32_t)(((size_t)yi * job.nx + xi) * job.na + a);
       }
     }
+  };
+  if (job.tile_best) {
+    // only the scoring tiles whose own best response ties with the global one can hold a tie
+    const int tiles = job.tiles_x * job.tiles_y;
+    const int px = (job.linear && job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan, ty_rows = 4 * job.ry;
+    for (int pi = blockIdx.x; pi < job.na * tiles; pi += gridDim.x) {
+      const double delta = job.tile_best[pi] - best;
+      if (!(delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06)) {continue;}
+      const int a = pi / tiles, tile = pi - a * tiles;
+      const int x0 = (tile % job.tiles_x) * px, y0 = (tile / job.tiles_x) * ty_rows;
+      for (int p = threadIdx.x; p < ty_rows * px; p += blockDim.x) {
+        const int xi = x0 + p % px, yi = y0 + p / px;
+        if (xi < job.nx && yi < job.ny) {consider(a, yi, xi);}
+      }
+    }
+    return;
+  }
+  const size_t total = plane * job.na;
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    const int a = (int)(o / plane);
+    const int rem = (int)(o - (size_t)a * plane);
+    const int yi = rem / job.nx, xi = rem - yi * job.nx;
+    consider(a, yi, xi);
   }
 }
 
-void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, void * stream)
+void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, int32_t tile_pairs, void * stream)
 {
   if (n_jobs <= 0 || max_poses <= 0) {return;}
   int blocks = (max_poses + 255) / 256;
+  if (tile_pairs > 0) {blocks = std::min(tile_pairs, 64);}    // every job of the launch has tile bests: pairs per job are few
   if (blocks > 1024) {blocks = 1024;}
   hipLaunchKernelGGL(k_ties, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs, stride);
 }

@@ -759,6 +759,16 @@ int kh_spa_get_constraint(kh_spa * s, int32_t index, int32_t * id_a, int32_t * i
   return KH_OK;
 }
 
+int kh_spa_get_nodes(kh_spa * s, int32_t * ids, double * poses)
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  for (size_t k = 0; k < s->nodes.size(); ++k) {
+    if (ids) {ids[k] = s->nodes[k].id;}
+    if (poses) {std::copy(s->nodes[k].pose, s->nodes[k].pose + 3, poses + 3 * k);}
+  }
+  return KH_OK;
+}
+
 int kh_spa_get_node_at(kh_spa * s, int32_t index, int32_t * id, double pose[3])
 {
   if (!s || index < 0) {return KH_ERR_INVALID_ARG;}

@@ -188,7 +188,15 @@ class HipSpaSolver:
     def load_graph(self, path: str):
         """Reset, then AddNode / AddConstraint for every record of the file (text or binary, detected)."""
         capi.check(capi.lib().kh_spa_load(self._h, os.fsencode(path)), "kh_spa_load")
-        self._ids = [i for i, _ in self.nodes_in_order()]
+        self._ids = self.node_arrays()[0].tolist()
+
+    def node_arrays(self):
+        """(ids (n,), poses (n, 3)) of every node in AddNode order, one call."""
+        n = capi.lib().kh_spa_num_nodes(self._h)
+        ids, poses = np.zeros(max(n, 1), dtype=np.int32), np.zeros((max(n, 1), 3))
+        capi.check(capi.lib().kh_spa_get_nodes(self._h, ids.ctypes.data_as(C.c_void_p), poses.ctypes.data_as(C.c_void_p)),
+                   "kh_spa_get_nodes")
+        return ids[:n], poses[:n]
 
     def nodes_in_order(self):
         out, L, i = [], capi.lib(), C.c_int32()
