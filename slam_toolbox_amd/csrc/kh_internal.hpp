@@ -35,7 +35,8 @@ struct RasterJob
   int32_t ws, roi_x, roi_y, roi_w, roi_h;
   int32_t kernel_size;
   double off_x, off_y, scale;   // CoordinateConverter (Karto.h:4421-4436)
-  uint8_t * blockmap;        // bm_w * bm_h bytes, cleared together with the grid: 1 = some stamp's footprint overlaps the block
+  uint32_t * blockmap;       // bm_h rows of bm_w words, one BIT per 32 x 32-cell block (bit bx & 31 of word bx >> 5; the last
+                             // word of a row is padding), cleared with the grid: 1 = some stamp's footprint overlaps the block
   int32_t bm_w, bm_h;
   // tiled stamping (k_raster_*): kRasterTile x kRasterTile cell tiles, points binned to the <= 2 x 2 tiles
   // their footprint overlaps.  All int32 scratch, zeroed with the grid where noted.
@@ -91,7 +92,7 @@ struct CorrJob
   int32_t * chunks;          // [groups][slots][kSlotBeams][kChunkWords]: sub-chunk descriptors
   int32_t * chunk_counts;    // [groups][slots]: sub-chunks of the slot
   // empty-window skipping: a beam whose whole window lies in blocks no stamp touched adds 0 to every pose
-  const uint8_t * blockmap;  // see RasterJob; nullptr = do not skip
+  const uint32_t * blockmap; // see RasterJob; nullptr = do not skip
   int32_t bm_w, bm_h;
   double * tile_best;        // [na][tiles_y * tiles_x] best response of every scoring tile (K3 -> K4); nullptr = K4 scans everything
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)

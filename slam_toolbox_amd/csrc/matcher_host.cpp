@@ -125,7 +125,7 @@ struct Slot
 {
   uint8_t * d_grid = nullptr;        // first grid byte (256-byte aligned); the allocation has kGridPad zero bytes either side
   uint8_t * d_grid_alloc = nullptr;
-  uint8_t * d_blockmap = nullptr;    // bm_w x bm_h occupancy blocks of this grid (cleared and marked with it)
+  uint32_t * d_blockmap = nullptr;   // bm_w x bm_h occupancy blocks of this grid (cleared and marked with it)
   double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
   // correlate scratch
   int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
@@ -760,7 +760,11 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->local = reinterpret_cast<const double *>(db + L.local);
     job->invalid = db + L.invalid;
     job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
-    job->tcounts = s.d_tcounts; job->list_tiles = job->tiles_x * job->tiles_y <= c.lt_alloc ? job->tiles_x * job->tiles_y : 1;
+    job->tcounts = s.d_tcounts; {
+      // tile lists pay for themselves when the window is several tiles large (the tests cost K2 time per tile)
+      const int32_t tiles = job->tiles_x * job->tiles_y;
+      job->list_tiles = (tiles >= 4 && tiles <= c.lt_alloc) ? tiles : 1;
+    }
     job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i;
     job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
     job->tile_best = s.d_tile_best;
@@ -1146,15 +1150,15 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
   m->rt_w = (m->ws + kRasterTile - 1) / kRasterTile;
   m->rt_h = (m->data_size / m->ws + kRasterTile - 1) / kRasterTile;
-  m->bm_w = (m->ws >> kBlockShift) + 1;
+  m->bm_w = (((m->ws >> kBlockShift) + 1) + 31) / 32 + 1;     // words per block row (+1 padding word)
   m->bm_h = (m->data_size / m->ws >> kBlockShift) + 2;
   m->slots.resize(max_batch);
   for (auto & s : m->slots) {
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid_alloc), static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
     if ((e = hipMemset(s.d_grid_alloc, 0, static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMemset grid");}
     s.d_grid = s.d_grid_alloc + kGridPad;
-    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_blockmap), static_cast<size_t>(m->bm_w) * m->bm_h)) != hipSuccess) {return fail(e, "hipMalloc block map");}
-    if ((e = hipMemset(s.d_blockmap, 0, static_cast<size_t>(m->bm_w) * m->bm_h)) != hipSuccess) {return fail(e, "hipMemset block map");}
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_blockmap), static_cast<size_t>(m->bm_w) * m->bm_h * 4)) != hipSuccess) {return fail(e, "hipMalloc block map");}
+    if ((e = hipMemset(s.d_blockmap, 0, static_cast<size_t>(m->bm_w) * m->bm_h * 4)) != hipSuccess) {return fail(e, "hipMemset block map");}
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_rtiles), (4 * static_cast<size_t>(m->rt_w) * m->rt_h + 8) * sizeof(int32_t))) != hipSuccess) {return fail(e, "hipMalloc raster tiles");}
   }
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&m->h_rjobs), sizeof(RasterJob) * max_batch, hipHostMallocDefault)) != hipSuccess) {return fail(e, "hipHostMalloc");}

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_raster_clear(const RasterJob * jobs)
   for (size_t i = tid; i < n16; i += nth) {g16[i] = zero;}
   for (size_t i = n16 * 16 + tid; i < bytes; i += nth) {job.grid[i] = 0;}
   const size_t bm = (size_t)job.bm_w * job.bm_h;
-  for (size_t i = tid; i < bm; i += nth) {job.blockmap[i] = 0;}
+  for (size_t i = tid; i < bm; i += nth) {job.blockmap[i] = 0u;}
   // tile_count | tile_cursor | n_work (+3 pad) are contiguous
   const size_t nz = 2 * (size_t)job.tiles_w * job.tiles_h + 4;
   for (size_t i = tid; i < nz; i += nth) {job.tile_count[i] = 0;}
@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
     const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
     const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
     for (int by = fy0; by <= fy1; ++by) {
-      for (int bx = fx0; bx <= fx1; ++bx) {job.blockmap[(size_t)by * job.bm_w + bx] = 1;}
+      for (int bx = fx0; bx <= fx1; ++bx) {
+        uint32_t * word = job.blockmap + (size_t)by * job.bm_w + (bx >> 5);
+        const uint32_t bit = 1u << (bx & 31);
+        if ((*word & bit) == 0) {atomicOr(word, bit);}
+      }
     }
   }
   const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
@@ -251,18 +255,28 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   if (a >= job.na) {return;}
   __shared__ int32_t s_counts[kClasses + 1];
   __shared__ int32_t s_tcounts[kClasses * 32];
-  __shared__ uint8_t s_bm[4096];
+  __shared__ uint32_t s_bm[4096];
+  __shared__ int4 s_tile_rect[32];       // per scoring tile: first / last cell (x, y) relative to the window start
   if (threadIdx.x < kClasses + 1) {s_counts[threadIdx.x] = 0;}
+  if ((int)threadIdx.x < job.list_tiles && job.list_tiles > 1) {
+    const int t = threadIdx.x;
+    const int px = (job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan, ty_rows = 4 * job.ry;
+    const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+    const int p0 = tx * px, p1 = min(job.nx, p0 + px) - 1;         // poses of the tile
+    const int r0 = ty * ty_rows, r1 = min(job.ny, r0 + ty_rows) - 1;
+    s_tile_rect[t] = make_int4(p0 * job.sx, r0 * job.sy_cells, p1 * job.sx, r1 * job.sy_cells);
+  }
   if (threadIdx.x < kClasses * 32) {s_tcounts[threadIdx.x] = 0;}
   const int lt = job.list_tiles;
   // small occupancy maps (coarse grids) are read from LDS: the per-tile tests make ~100 probes per beam
-  const uint8_t * bmp = job.blockmap;
+  const uint32_t * bmp = job.blockmap;
   if (bmp && job.bm_w * job.bm_h <= 4096) {
     for (int i = threadIdx.x; i < job.bm_w * job.bm_h; i += blockDim.x) {s_bm[i] = job.blockmap[i];}
     bmp = s_bm;
   }
   __syncthreads();
   const int P = job.n_points;
+  const float inv_ws = 1.0f / (float)job.ws;
   const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
   // index range of the lattice (real poses only)
   const int64_t bmin = job.base0;
@@ -298,28 +312,34 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
           // often are).  Windows that wrap around the row end (beams beyond the range threshold, Appendix
           // A.3) are kept everywhere.
           const int32_t start = (int32_t)((int64_t)idx + bmin);
-          const int32_t wy0 = start / job.ws, wx0 = start - wy0 * job.ws;
+          int32_t wy0 = (int32_t)((float)start * inv_ws);       // start / ws, fixed up below (start < 2^31, ws >= 8)
+          int32_t wx0 = start - wy0 * job.ws;
+          while (wx0 < 0) {wx0 += job.ws; --wy0;}
+          while (wx0 >= job.ws) {wx0 -= job.ws; ++wy0;}
           const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;
           if (wx0 + xs <= job.ws) {
             auto any_block = [&](int x_lo, int y_lo, int x_hi, int y_hi) {
               const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
               const int by0 = y_lo >> kBlockShift, by1 = y_hi >> kBlockShift;
+              // bits bx0 .. bx1 of every block row: two adjacent words cover them (the rows carry a padding
+              // word).  No early exit: the probes are independent loads.
+              const int wi = bx0 >> 5, sh = bx0 & 31, nb = bx1 - bx0 + 1;
+              if (nb > 32) {return true;}                       // wider than two words can show: never skipped
+              const unsigned long long span = (1ull << nb) - 1ull;
+              unsigned long long any = 0;
               for (int by = by0; by <= by1; ++by) {
-                for (int bx = bx0; bx <= bx1; ++bx) {if (bmp[(size_t)by * job.bm_w + bx] != 0) {return true;}}
+                const uint32_t * row = bmp + (size_t)by * job.bm_w + wi;
+                any |= (((unsigned long long)row[1] << 32) | row[0]) >> sh;
               }
-              return false;
+              any &= span;
+              return any != 0;
             };
             if (!any_block(wx0, wy0, wx0 + xs - 1, wy0 + ys - 1)) {continue;}
             if (lt > 1) {
-              const int px = (job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan, ty_rows = 4 * job.ry;
               tmask = 0;
               for (int t = 0; t < lt; ++t) {
-                const int tx = t % job.tiles_x, ty = t / job.tiles_x;
-                const int p0 = tx * px, p1 = min(job.nx, p0 + px) - 1;         // poses of the tile
-                const int r0 = ty * ty_rows, r1 = min(job.ny, r0 + ty_rows) - 1;
-                if (any_block(wx0 + p0 * job.sx, wy0 + r0 * job.sy_cells, wx0 + p1 * job.sx, wy0 + r1 * job.sy_cells)) {
-                  tmask |= 1u << t;
-                }
+                const int4 g = s_tile_rect[t];                    // cells relative to the window start
+                if (any_block(wx0 + g.x, wy0 + g.y, wx0 + g.z, wy0 + g.w)) {tmask |= 1u << t;}
               }
             }
           }
