@@ -34,6 +34,16 @@ HBM_PEAK_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "r1_k_score_pmc.json")
 
 
+def pmc_rates():
+    """(L2 hit rate, L1 hit rate) of k_score from the same committed PMC passes, for the roofline note."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        return 100.0 * d["l2_hit_rate"], 100.0 * d["l1_hit_rate"]
+    except (OSError, KeyError, ValueError):
+        return float("nan"), float("nan")
+
+
 def pmc_traffic(batch):
     """HBM bytes per k_score launch from the committed rocprofv3 PMC passes of this same command
     (tools/prof_bench.sh + tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE collected in separate passes and
@@ -441,9 +451,11 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_C2 * per_launch, "matches_per_launch": per_launch,
                          "avg_launch_ms": k3_ms,
                          "note": "achieved = algorithmic bytes (the reference's own access stream, SURVEY 8d: 5 B per "
-                                 "lookup) / measured launch time; the windows are L2-resident (96.8 % hit), so frac exceeds 1 "
-                                 "and HBM does not bind: traffic = measured HBM bytes per launch (PMC), the binding resource "
-                                 "is the L2->L1 fill rate (31 % L1 hit) -- see DESIGN.md section 4"},
+                                 "lookup, every lookup) / measured launch time; the kernel reads cache-resident windows "
+                                 "(L2 hit %.1f %%, L1 hit %.1f %%), 4 lookups per dword, and skips windows that hold only zeros, "
+                                 "so frac exceeds 1 and HBM does not bind: traffic = measured HBM bytes per launch (PMC), the "
+                                 "binding resource is the L1 (TCP) tag-lookup + data-return rate -- see DESIGN.md section 4"
+                                 % pmc_rates()},
         }
         if world == 1 and not args.no_cpu_baseline:
             with _StdoutToStderr():
