@@ -310,6 +310,10 @@ def main():
     ap.add_argument("--no-two-stream", action="store_true")
     args = ap.parse_args()
 
+    # last resort against a stuck collective or a teardown that never returns: after KH_BENCH_WATCHDOG seconds
+    # (default 30 min, far beyond any default run) every thread's Python stack goes to stderr and the process exits
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("KH_BENCH_WATCHDOG", "1800")), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -324,10 +328,13 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=300)       # a collective that waits longer than this has lost a peer
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
 
     from common import C2_PARAMS, PRESETS, Scenario
     from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher, _scan_array
@@ -469,11 +476,17 @@ def main():
             out.update(loop_leg(local_rank))
             out.update(enumeration_leg(local_rank))
             out.update(occupancy_leg(local_rank))
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     for h in handles:
         h.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    # the line is out and every handle is closed: leave without the interpreter / HIP runtime / thread-pool teardown
+    # (an N = 2 run was once seen to sit in it until the launcher's timeout)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":
