@@ -278,6 +278,20 @@ KH_API int kh_graph_find_loop_candidates(kh_graph * g, int32_t n_queries, const 
                                          int32_t * chain_begin, int32_t * chains, int32_t cap_chains,
                                          int32_t * n_chains);
 KH_API double kh_graph_last_kernel_ms(kh_graph * g);
+/* The rest of the row -- neighbourhood-sized, exact host arithmetic, no kernel:
+ * MapperGraph::FindNearChains (Mapper.cpp:1683-1793) for one scan of the current graph: the maximal runs of
+ * consecutive scans within link_scan_maximum_distance of it that hold a near linked scan (FindNearLinkedScans,
+ * Mapper.cpp:1795-1806), in the order the breadth-first traversal meets them, without the run that contains the scan
+ * itself.  chains[2k], chains[2k+1] = first, last index; *n_chains is the total even beyond cap_chains. */
+KH_API int kh_graph_find_near_chains(kh_graph * g, int32_t query_scan, double link_scan_maximum_distance,
+                                     int32_t * chains, int32_t cap_chains, int32_t * n_chains);
+/* MapperGraph::GetClosestScanToPose (Mapper.cpp:1563-1582): first scan of the list with the smallest squared
+ * distance of its reference position to pose_xy; -1 for an empty list */
+KH_API int kh_graph_closest_scan_to_pose(kh_graph * g, const int32_t * scans, int32_t n, const double pose_xy[2],
+                                         int32_t * closest);
+/* MapperGraph::ComputeWeightedMean (Mapper.cpp:1914-1958): inverse-covariance weighted mean of n poses (means 3n,
+ * covariances 9n row-major), heading = atan2 of the mean sine and cosine */
+KH_API int kh_weighted_mean(int32_t n, const double * means, const double * covariances, double mean[3]);
 
 /* ---------------------------------------------------------------- occupancy grid (next row f-2) */
 /* karto::OccupancyGrid::CreateFromScans (Karto.h:5947-5962, 6118-6274).  Scans are handed over like to the

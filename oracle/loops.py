@@ -74,3 +74,86 @@ def find_possible_loop_closures(q, ref_xy, adj_ptr, adj_idx, max_distance, min_c
         if not returned:
             break                                            # end of the scan list: the next call returns empty
     return out
+
+
+def find_near_chains(q, ref_xy, adj_ptr, adj_idx, link_max_distance):
+    """MapperGraph::FindNearChains (Mapper.cpp:1683-1793) as (first, last) runs, in the reference's order."""
+    lim = link_max_distance * link_max_distance + KT_TOLERANCE          # Mapper.cpp:1735-1737
+    n = ref_xy.shape[0]
+    pose = ref_xy[q]
+    processed = set()
+    out = []
+    for near in near_linked_scans(q, ref_xy, adj_ptr, adj_idx, link_max_distance):
+        if near == q or near in processed:
+            continue
+        processed.add(near)
+        valid = True
+        first = last = near
+        c = near - 1
+        while c >= 0:
+            if c == q:
+                valid = False
+            if squared_distance(pose, ref_xy[c]) < lim:
+                first = c
+                processed.add(c)
+            else:
+                break
+            c -= 1
+        c = near + 1
+        while c < n:
+            if c == q:
+                valid = False
+            if squared_distance(pose, ref_xy[c]) < lim:
+                last = c
+                processed.add(c)
+            else:
+                break
+            c += 1
+        if valid:
+            out.append((first, last))
+    return out
+
+
+def closest_scan_to_pose(scans, ref_xy, pose_xy):
+    """MapperGraph::GetClosestScanToPose (Mapper.cpp:1563-1582): the first strictly smaller distance wins."""
+    best, best_d = -1, float("inf")
+    for s in scans:
+        d = squared_distance(pose_xy, ref_xy[s])
+        if d < best_d:
+            best, best_d = int(s), d
+    return best
+
+
+def compute_weighted_mean(means, covariances):
+    """MapperGraph::ComputeWeightedMean (Mapper.cpp:1914-1958) with Matrix3::Inverse (Karto.h:2533-2577), the 3x3
+    product (Karto.h:2634-2647) and matrix * pose (Karto.h:2654-2666) in the reference's operation order."""
+    import math
+
+    def inverse(m):
+        inv = [m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
+               m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
+               m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3]]
+        det = m[0] * inv[0] + m[1] * inv[3] + m[2] * inv[6]
+        if abs(det) <= 1e-14:
+            return inv
+        inv_det = 1.0 / det
+        return [v * inv_det for v in inv]
+    means = np.asarray(means, dtype=np.float64).reshape(-1, 3)
+    covs = np.asarray(covariances, dtype=np.float64).reshape(-1, 9)
+    inverses = [inverse([float(v) for v in c]) for c in covs]
+    total = [0.0] * 9
+    for inv in inverses:
+        total = [a + b for a, b in zip(total, inv)]
+    inv_sum = inverse(total)
+    ax = ay = tx = ty = 0.0
+    for p, inv in zip(means, inverses):
+        x, y, h = float(p[0]), float(p[1]), float(p[2])
+        tx += math.cos(h)
+        ty += math.sin(h)
+        w = [inv_sum[3 * r] * inv[c] + inv_sum[3 * r + 1] * inv[3 + c] + inv_sum[3 * r + 2] * inv[6 + c]
+             for r in range(3) for c in range(3)]
+        ax += w[0] * x + w[1] * y + w[2] * h
+        ay += w[3] * x + w[4] * y + w[5] * h
+    tx /= float(len(means))
+    ty /= float(len(means))
+    return np.array([ax, ay, math.atan2(ty, tx)])

@@ -167,6 +167,16 @@ int ref_slam_enumerate(
       std::fprintf(out, "L %d %zu", q->GetStateId(), linked.size());
       for (auto * s : linked) {std::fprintf(out, " %d", s->GetStateId());}
       std::fprintf(out, "\n");
+      // FindNearChains (Mapper.cpp:1683-1793) with the mapper's link_scan_maximum_distance, and for every chain the
+      // scan GetClosestScanToPose (Mapper.cpp:1563-1582) picks for the query's reference pose
+      {
+        const std::vector<LocalizedRangeScanVector> near = graph->FindNearChains(q);
+        const Pose2 qp = q->GetReferencePose(bary);
+        for (const LocalizedRangeScanVector & c : near) {
+          std::fprintf(out, "N %d %d %d %d\n", q->GetStateId(), c.front()->GetStateId(), c.back()->GetStateId(),
+            graph->GetClosestScanToPose(c, qp)->GetStateId());
+        }
+      }
       kt_int32u start = 0;
       LocalizedRangeScanVector chain = graph->FindPossibleLoopClosure(q, sensor, start);
       while (!chain.empty()) {
@@ -174,6 +184,27 @@ int ref_slam_enumerate(
         for (auto * s : chain) {std::fprintf(out, " %d", s->GetStateId());}
         std::fprintf(out, "\n");
         chain = graph->FindPossibleLoopClosure(q, sensor, start);
+      }
+    }
+    // ComputeWeightedMean (Mapper.cpp:1914-1958) known answers: deterministic pose / covariance sets
+    {
+      uint64_t lcg = 88172645463325252ull;
+      auto rnd = [&]() {lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (lcg >> 11) * (1.0 / 9007199254740992.0);};
+      for (int t = 0; t < 12; ++t) {
+        const int k = 1 + t % 5;
+        Pose2Vector means;
+        std::vector<Matrix3> covs;
+        std::fprintf(out, "W %d", k);
+        for (int i = 0; i < k; ++i) {
+          const Pose2 p(20.0 * rnd() - 10.0, 20.0 * rnd() - 10.0, 6.0 * rnd() - 3.0);
+          const double a = 0.01 + rnd(), b = 0.01 + rnd(), c = 0.01 + 0.2 * rnd(), r = 0.3 * rnd() * std::sqrt(a * b);
+          Matrix3 m;
+          m(0, 0) = a; m(1, 1) = b; m(2, 2) = c; m(0, 1) = r; m(1, 0) = r;
+          means.push_back(p); covs.push_back(m);
+          std::fprintf(out, " %.17g %.17g %.17g %.17g %.17g %.17g %.17g", p.GetX(), p.GetY(), p.GetHeading(), a, b, c, r);
+        }
+        const Pose2 w = graph->ComputeWeightedMean(means, covs);
+        std::fprintf(out, " | %.17g %.17g %.17g\n", w.GetX(), w.GetY(), w.GetHeading());
       }
     }
   } catch (const std::exception & e) {

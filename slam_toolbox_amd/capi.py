@@ -72,7 +72,7 @@ SYMBOLS = [
     "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
     "kh_spa_save", "kh_spa_load", "kh_spa_add_constraint_information", "kh_spa_get_node_at", "kh_spa_get_constraint", "kh_spa_get_nodes",
     "kh_graph_create", "kh_graph_destroy", "kh_graph_set", "kh_graph_set_positions", "kh_graph_find_loop_candidates",
-    "kh_graph_last_kernel_ms",
+    "kh_graph_last_kernel_ms", "kh_graph_find_near_chains", "kh_graph_closest_scan_to_pose", "kh_weighted_mean",
     "kh_occupancy_compute_dimensions", "kh_occupancy_create", "kh_occupancy_destroy", "kh_occupancy_clear",
     "kh_occupancy_add_scans", "kh_occupancy_update", "kh_occupancy_read", "kh_occupancy_info",
     "kh_decay_params_default", "kh_lifelong_scores",
@@ -172,6 +172,9 @@ def lib():
         L.kh_graph_set_positions.argtypes = [vp, i32, dptr]
         L.kh_graph_find_loop_candidates.argtypes = [vp, i32, iptr, dbl, i32, iptr, iptr, i32, C.POINTER(i32)]
         L.kh_graph_last_kernel_ms.argtypes = [vp]
+        L.kh_graph_find_near_chains.argtypes = [vp, i32, dbl, iptr, i32, C.POINTER(i32)]
+        L.kh_graph_closest_scan_to_pose.argtypes = [vp, iptr, i32, dptr, C.POINTER(i32)]
+        L.kh_weighted_mean.argtypes = [i32, dptr, dptr, dptr]
         L.kh_graph_last_kernel_ms.restype = dbl
     if hasattr(L, "kh_lifelong_scores"):
         L.kh_decay_params_default.argtypes = [C.POINTER(KhDecayParams)]

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -148,6 +149,9 @@ struct kh_graph
   int32_t * d_chains = nullptr; size_t cap_chains = 0;
   double last_ms = 0.0;
   hipEvent_t ev[2] = {nullptr, nullptr};
+  // host copy of the store: the neighbourhood walks of FindNearChains touch tens of vertices (no kernel)
+  std::vector<double> h_xy;
+  std::vector<int32_t> h_adj_ptr, h_adj_idx;
 };
 
 extern "C" {
@@ -210,6 +214,9 @@ int kh_graph_set(kh_graph * g, int32_t n_scans, const double * ref_xy, const int
     }
   }
   g->n = n_scans;
+  g->h_xy.assign(ref_xy, ref_xy + 2 * n);
+  g->h_adj_ptr.assign(adj_ptr, adj_ptr + (n ? n + 1 : 0));
+  g->h_adj_idx.assign(adj_idx, adj_idx + n_adj);
   return KH_OK;
 }
 
@@ -221,6 +228,7 @@ int kh_graph_set_positions(kh_graph * g, int32_t n_scans, const double * ref_xy)
     set_error("kh_graph_set_positions: upload failed");
     return KH_ERR_HIP;
   }
+  g->h_xy.assign(ref_xy, ref_xy + 2 * static_cast<size_t>(n_scans));
   return KH_OK;
 }
 
@@ -283,5 +291,151 @@ int kh_graph_find_loop_candidates(
 }
 
 double kh_graph_last_kernel_ms(kh_graph * g) {return g ? g->last_ms : 0.0;}
+
+// ---- host-side members of the row (exact reference arithmetic, O(neighbourhood) work) ---------------------
+namespace
+{
+constexpr double kTolerance = 1e-06;      // KT_TOLERANCE, Math.h:41
+
+inline double squared_distance(const double * a, const double * b)     // Vector2::SquaredDistance
+{
+  const double dx = a[0] - b[0], dy = a[1] - b[1];
+  return dx * dx + dy * dy;
+}
+
+// BreadthFirstTraversal::TraverseForVertices with NearScanVisitor (Mapper.cpp:1263-1297, 1311-1333): valid
+// vertices in visit order; the start vertex is visited like any other
+void near_linked(const kh_graph * g, int32_t q, double max_distance, std::vector<int32_t> & valid)
+{
+  const double lim = max_distance * max_distance - kTolerance;       // Visit(): squaredDistance <= max^2 - tol
+  const double * centre = &g->h_xy[2 * static_cast<size_t>(q)];
+  std::vector<int32_t> queue(1, q);
+  std::vector<uint8_t> seen(static_cast<size_t>(g->n), 0);
+  seen[q] = 1;
+  for (size_t h = 0; h < queue.size(); ++h) {
+    const int32_t v = queue[h];
+    if (squared_distance(&g->h_xy[2 * static_cast<size_t>(v)], centre) <= lim) {
+      valid.push_back(v);
+      for (int32_t k = g->h_adj_ptr[v]; k < g->h_adj_ptr[v + 1]; ++k) {
+        const int32_t w = g->h_adj_idx[k];
+        if (!seen[w]) {seen[w] = 1; queue.push_back(w);}
+      }
+    }
+  }
+}
+
+void matrix3_inverse(const double * m, double * inv)    // Karto.h:2533-2577 (row-major 3x3)
+{
+  inv[0] = m[4] * m[8] - m[5] * m[7];
+  inv[1] = m[2] * m[7] - m[1] * m[8];
+  inv[2] = m[1] * m[5] - m[2] * m[4];
+  inv[3] = m[5] * m[6] - m[3] * m[8];
+  inv[4] = m[0] * m[8] - m[2] * m[6];
+  inv[5] = m[2] * m[3] - m[0] * m[5];
+  inv[6] = m[3] * m[7] - m[4] * m[6];
+  inv[7] = m[1] * m[6] - m[0] * m[7];
+  inv[8] = m[0] * m[4] - m[1] * m[3];
+  const double det = m[0] * inv[0] + m[1] * inv[3] + m[2] * inv[6];
+  if (std::fabs(det) <= 1e-14) {return;}      // assert(false) is compiled out in Release
+  const double inv_det = 1.0 / det;
+  for (int i = 0; i < 9; ++i) {inv[i] *= inv_det;}
+}
+
+double normalize_angle(double angle)   // math::NormalizeAngle, Math.h:181-202
+{
+  const double pi = 3.14159265358979323846, two_pi = 6.28318530717958647692;
+  while (angle < -pi) {
+    if (angle < -two_pi) {angle += static_cast<uint32_t>(angle / -two_pi) * two_pi;} else {angle += two_pi;}
+  }
+  while (angle > pi) {
+    if (angle > two_pi) {angle -= static_cast<uint32_t>(angle / two_pi) * two_pi;} else {angle -= two_pi;}
+  }
+  return angle;
+}
+}  // namespace
+
+int kh_graph_find_near_chains(
+  kh_graph * g, int32_t query_scan, double link_scan_maximum_distance, int32_t * chains, int32_t cap_chains,
+  int32_t * n_chains)
+{
+  if (!g || !n_chains || query_scan < 0 || query_scan >= g->n || (cap_chains > 0 && !chains)) {return KH_ERR_INVALID_ARG;}
+  const double * pose = &g->h_xy[2 * static_cast<size_t>(query_scan)];
+  const double lim = link_scan_maximum_distance * link_scan_maximum_distance + kTolerance;     // Mapper.cpp:1735-1737
+  std::vector<int32_t> linked;
+  near_linked(g, query_scan, link_scan_maximum_distance, linked);
+  std::vector<uint8_t> processed(static_cast<size_t>(g->n), 0);
+  int32_t total = 0;
+  for (int32_t near : linked) {
+    if (near == query_scan || processed[near]) {continue;}
+    processed[near] = 1;
+    bool valid = true;
+    int32_t first = near, last = near;
+    for (int32_t c = near - 1; c >= 0; --c) {                        // scans before (Mapper.cpp:1715-1746)
+      if (c == query_scan) {valid = false;}
+      if (squared_distance(pose, &g->h_xy[2 * static_cast<size_t>(c)]) < lim) {first = c; processed[c] = 1;} else {break;}
+    }
+    for (int32_t c = near + 1; c < g->n; ++c) {                      // scans after (Mapper.cpp:1751-1780)
+      if (c == query_scan) {valid = false;}
+      if (squared_distance(pose, &g->h_xy[2 * static_cast<size_t>(c)]) < lim) {last = c; processed[c] = 1;} else {break;}
+    }
+    if (valid) {
+      if (total < cap_chains) {chains[2 * total] = first; chains[2 * total + 1] = last;}
+      ++total;
+    }
+  }
+  *n_chains = total;
+  return KH_OK;
+}
+
+int kh_graph_closest_scan_to_pose(kh_graph * g, const int32_t * scans, int32_t n, const double pose_xy[2], int32_t * closest)
+{
+  if (!g || !closest || !pose_xy || n < 0 || (n > 0 && !scans)) {return KH_ERR_INVALID_ARG;}
+  int32_t best = -1;
+  double best_d = 1.7976931348623157e308;                            // DBL_MAX
+  for (int32_t k = 0; k < n; ++k) {
+    if (scans[k] < 0 || scans[k] >= g->n) {return KH_ERR_INVALID_ARG;}
+    const double d = squared_distance(pose_xy, &g->h_xy[2 * static_cast<size_t>(scans[k])]);
+    if (d < best_d) {best_d = d; best = scans[k];}
+  }
+  *closest = best;                                                   // NULL (-1) for an empty chain
+  return KH_OK;
+}
+
+int kh_weighted_mean(int32_t n, const double * means, const double * covariances, double mean[3])
+{
+  if (n <= 0 || !means || !covariances || !mean) {return KH_ERR_INVALID_ARG;}
+  std::vector<double> inverses(9 * static_cast<size_t>(n));
+  double sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int32_t k = 0; k < n; ++k) {
+    double * inv = &inverses[9 * static_cast<size_t>(k)];
+    for (int i = 0; i < 9; ++i) {inv[i] = 0.0;}
+    matrix3_inverse(covariances + 9 * static_cast<size_t>(k), inv);
+    for (int i = 0; i < 9; ++i) {sum[i] += inv[i];}
+  }
+  double inv_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  matrix3_inverse(sum, inv_sum);
+  double ax = 0.0, ay = 0.0, ah = 0.0, theta_x = 0.0, theta_y = 0.0;
+  for (int32_t k = 0; k < n; ++k) {
+    const double * p = means + 3 * static_cast<size_t>(k);
+    const double * inv = &inverses[9 * static_cast<size_t>(k)];
+    theta_x += std::cos(p[2]);
+    theta_y += std::sin(p[2]);
+    double w[9];                                                     // inverseOfSumOfInverses * inverse, Karto.h:2634-2647
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        w[3 * r + c] = inv_sum[3 * r] * inv[c] + inv_sum[3 * r + 1] * inv[3 + c] + inv_sum[3 * r + 2] * inv[6 + c];
+      }
+    }
+    // weight * pose (Karto.h:2654-2666), then Pose2::operator+= (Karto.h:2196-2200)
+    ax += w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+    ay += w[3] * p[0] + w[4] * p[1] + w[5] * p[2];
+    ah = normalize_angle(ah + (w[6] * p[0] + w[7] * p[1] + w[8] * p[2]));
+  }
+  theta_x /= static_cast<double>(static_cast<size_t>(n));
+  theta_y /= static_cast<double>(static_cast<size_t>(n));
+  (void)ah;
+  mean[0] = ax; mean[1] = ay; mean[2] = std::atan2(theta_y, theta_x);
+  return KH_OK;
+}
 
 }  // extern "C"

@@ -50,6 +50,28 @@ class MapperGraphSearch:
         chains = chains.reshape(-1, 2)
         return [[(int(a), int(b)) for a, b in chains[begin[i]: begin[i + 1]]] for i in range(q.size)]
 
+    def FindNearChains(self, query_scan, link_scan_maximum_distance):
+        """MapperGraph::FindNearChains (Mapper.cpp:1683-1793) -> [(first, last), ...] in the reference's order."""
+        cap = 64
+        total = C.c_int32(0)
+        while True:
+            chains = np.zeros(2 * cap, dtype=np.int32)
+            capi.check(capi.lib().kh_graph_find_near_chains(self._h, int(query_scan), float(link_scan_maximum_distance),
+                                                            chains, cap, C.byref(total)), "kh_graph_find_near_chains")
+            if total.value <= cap:
+                break
+            cap = total.value
+        return [(int(a), int(b)) for a, b in chains.reshape(-1, 2)[:total.value]]
+
+    def GetClosestScanToPose(self, scans, pose_xy):
+        """MapperGraph::GetClosestScanToPose (Mapper.cpp:1563-1582); -1 for an empty list."""
+        scans = np.ascontiguousarray(scans, dtype=np.int32)
+        out = C.c_int32(-1)
+        capi.check(capi.lib().kh_graph_closest_scan_to_pose(self._h, scans if scans.size else np.zeros(1, dtype=np.int32),
+                                                            scans.size, np.ascontiguousarray(pose_xy, dtype=np.float64)[:2].copy(),
+                                                            C.byref(out)), "kh_graph_closest_scan_to_pose")
+        return out.value
+
     def last_kernel_ms(self):
         return capi.lib().kh_graph_last_kernel_ms(self._h)
 
@@ -63,3 +85,12 @@ class MapperGraphSearch:
             self.close()
         except Exception:
             pass
+
+
+def ComputeWeightedMean(means, covariances):
+    """MapperGraph::ComputeWeightedMean (Mapper.cpp:1914-1958)."""
+    means = np.ascontiguousarray(means, dtype=np.float64).reshape(-1, 3)
+    covs = np.ascontiguousarray(covariances, dtype=np.float64).reshape(-1, 9)
+    out = np.zeros(3)
+    capi.check(capi.lib().kh_weighted_mean(means.shape[0], means.reshape(-1), covs.reshape(-1), out), "kh_weighted_mean")
+    return out

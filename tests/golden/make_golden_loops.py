@@ -35,6 +35,7 @@ def main():
     n = lib.ref_slam_enumerate(n_scans, n_beams, ranges.ctypes.data, odom.ctypes.data, loop_dist, path.encode())
     assert n > 0, n
     xy, adj, linked, chains = {}, {}, {}, {}
+    near_rows, wm_rows = [], []
     for line in open(path):
         t = line.split()
         if t[0] == "G":
@@ -47,6 +48,13 @@ def main():
             linked[int(t[1])] = [int(v) for v in t[3:]]
         elif t[0] == "H":
             chains.setdefault(int(t[1]), []).append([int(v) for v in t[4:]])
+        elif t[0] == "N":          # FindNearChains: query, first, last, GetClosestScanToPose of the chain
+            near_rows.append([int(v) for v in t[1:5]])
+        elif t[0] == "W":          # ComputeWeightedMean: k poses (x y h a b c r) | result
+            k = int(t[1])
+            vals = [float(v) for v in t[2:2 + 7 * k]]
+            res = [float(v) for v in t[3 + 7 * k:6 + 7 * k]]
+            wm_rows.append((k, vals, res))
         elif t[0] == "!":
             raise RuntimeError(line)
     ids = sorted(xy)
@@ -63,10 +71,18 @@ def main():
         for ch in chains.get(q, []):
             assert ch == list(range(ch[0], ch[-1] + 1))
             rows.append((q, ch[0], ch[-1]))
+    # weighted means: padded to 5 poses per case
+    wm_k = np.asarray([k for k, _, _ in wm_rows], dtype=np.int32)
+    wm_in = np.zeros((len(wm_rows), 5, 7))
+    for i, (k, vals, _) in enumerate(wm_rows):
+        wm_in[i, :k] = np.asarray(vals).reshape(k, 7)
+    wm_out = np.asarray([r for _, _, r in wm_rows])
     out = os.path.join(ROOT, "tests", "golden", "loop_candidates.npz")
-    np.savez_compressed(out, ref_xy=np.asarray([xy[i] for i in ids]), adj_ptr=adj_ptr, adj_idx=adj_idx,
+    np.savez_compressed(out, near_chains=np.asarray(near_rows, dtype=np.int32).reshape(-1, 4), link_scan_maximum_distance=1.5,
+                        wm_k=wm_k, wm_in=wm_in, wm_out=wm_out, ref_xy=np.asarray([xy[i] for i in ids]), adj_ptr=adj_ptr, adj_idx=adj_idx,
                         link_ptr=link_ptr, link_idx=link_idx, chains=np.asarray(rows, dtype=np.int32).reshape(-1, 3),
                         loop_search_maximum_distance=loop_dist, loop_match_minimum_chain_size=min_chain)
+    print(len(near_rows), "near chains,", len(wm_rows), "weighted means")
     print(out, len(ids), "scans,", len(adj_idx) // 2, "edges,", len(rows), "chains over", len({r[0] for r in rows}), "queries")
 
 

@@ -60,3 +60,28 @@ def test_large_graph_against_the_oracle(kartohip_lib, max_distance, min_chain):
     for k, q in enumerate(queries[:8]):
         assert got2[k] == loops.find_possible_loop_closures(int(q), xy2, ptr, idx, max_distance, min_chain)
     s.close()
+
+
+def test_near_chains_closest_scan_and_weighted_mean_match_the_reference(kartohip_lib):
+    """The neighbourhood-sized members of the row through the C ABI (host arithmetic inside the library):
+    FindNearChains with its chain order, GetClosestScanToPose, ComputeWeightedMean -- against what the
+    reference's own functions returned (tests/golden/loop_candidates.npz)."""
+    import os
+    from slam_toolbox_amd.loop_search import ComputeWeightedMean, MapperGraphSearch
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "loop_candidates.npz"))
+    s = MapperGraphSearch()
+    s.SetGraph(G["ref_xy"], G["adj_ptr"], G["adj_idx"])
+    d = float(G["link_scan_maximum_distance"])
+    rows = []
+    for q in range(G["ref_xy"].shape[0]):
+        for first, last in s.FindNearChains(q, d):
+            rows.append((q, first, last, s.GetClosestScanToPose(np.arange(first, last + 1), G["ref_xy"][q])))
+    assert np.array_equal(np.asarray(rows, dtype=np.int32).reshape(-1, 4), G["near_chains"])
+    assert s.GetClosestScanToPose([], [0.0, 0.0]) == -1
+    s.close()
+    for k, row, want in zip(G["wm_k"], G["wm_in"], G["wm_out"]):
+        k = int(k)
+        covs = np.zeros((k, 9))
+        covs[:, 0] = row[:k, 3]; covs[:, 4] = row[:k, 4]; covs[:, 8] = row[:k, 5]
+        covs[:, 1] = row[:k, 6]; covs[:, 3] = row[:k, 6]
+        assert np.array_equal(ComputeWeightedMean(row[:k, :3], covs), want)
