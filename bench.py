@@ -298,7 +298,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--streams", type=int, default=1,
                     help="matcher handles (each its own HIP stream and host thread) a rank drives concurrently; "
                          "a step is still ONE batch of --batch matches on one of them.  The default 1 keeps the "
@@ -482,11 +482,13 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    # the line is out and every handle is closed: leave without the interpreter / HIP runtime / thread-pool teardown
-    # (an N = 2 run was once seen to sit in it until the launcher's timeout)
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    if world > 1:
+        # the line is out and every handle is closed: leave without the interpreter / HIP runtime / thread-pool
+        # teardown (an N = 2 run was once seen to sit in it until the launcher's timeout).  Single-process runs exit
+        # normally so that a profiler wrapped around them (rocprofv3) can write its output.
+        os._exit(0)
 
 
 if __name__ == "__main__":

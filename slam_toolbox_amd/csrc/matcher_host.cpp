@@ -119,6 +119,7 @@ struct CorrBatch
   int32_t * h_sums = nullptr; size_t cap_hsums = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};      // around the scoring kernel (profiling)
   hipEvent_t done = nullptr;                  // everything of the sub-batch, downloads included
+  hipEvent_t up = nullptr, kdone = nullptr;   // chunked batches: tables uploaded (copy stream) / kernels finished (main stream)
 };
 
 struct Slot
@@ -158,6 +159,7 @@ struct kh_matcher
   kh_match_params params;
   int32_t device = 0, max_batch = 1;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // chunked batches: uploads / downloads of one chunk under the kernels of another
   uint8_t * d_kernel = nullptr;
   std::vector<Slot> slots;
   CorrBatch batch[2];
@@ -530,7 +532,7 @@ static inline double host_response(const CorrHost & c, int32_t sum, int a, int y
 // One sub-batch of CorrelateScan jobs in two phases so that two sub-batches can be pipelined on the handle's
 // stream: phase 0 = host preparation + upload + kernels + download, all enqueued, ending with an event;
 // phase 1 = wait for that event + finalisation.  Everything phase 1 needs lives in the CorrBatch.
-static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch & B, int phase)
+static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch & B, int phase, bool overlap = false)
 {
   if (n == 0) {return KH_OK;}
   const kh_match_params & mp = m->params;
@@ -789,7 +791,14 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   // ---- 2. upload, launch, download ----
   lap(0, t_enter);
   const auto t_enqueue = std::chrono::steady_clock::now();
-  KH_HIP(hipMemcpyAsync(B.d_stage, B.h_stage, stride * n, hipMemcpyHostToDevice, m->stream));
+  // overlap (chunked batches): the copies go on the copy stream, ordered against the kernels by events, so the PCIe
+  // transfers of one chunk run under the kernels of its neighbours
+  hipStream_t cs = overlap ? m->copy_stream : m->stream;
+  KH_HIP(hipMemcpyAsync(B.d_stage, B.h_stage, stride * n, hipMemcpyHostToDevice, cs));
+  if (overlap) {
+    KH_HIP(hipEventRecord(B.up, cs));
+    KH_HIP(hipStreamWaitEvent(m->stream, B.up, 0));
+  }
   KH_HIP(hipMemsetAsync(B.d_out, 0, out_words * 8 * n, m->stream));
   if (use_lds) {
     launch_offsets_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
@@ -811,7 +820,11 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], m->stream));}
   launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, B.tile_pairs, m->stream);
   KH_HIP(hipGetLastError());
-  KH_HIP(hipMemcpyAsync(B.h_out, B.d_out, out_words * 8 * n, hipMemcpyDeviceToHost, m->stream));
+  if (overlap) {
+    KH_HIP(hipEventRecord(B.kdone, m->stream));
+    KH_HIP(hipStreamWaitEvent(cs, B.kdone, 0));
+  }
+  KH_HIP(hipMemcpyAsync(B.h_out, B.d_out, out_words * 8 * n, hipMemcpyDeviceToHost, cs));
   // fine passes need the raw sums of every angle at the best cell (ComputeAngularCovariance): their
   // volumes are tiny (3 x 3 x nA), so they ride along with the batch download instead of costing one
   // synchronous copy per match afterwards
@@ -826,12 +839,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       for (size_t i = 0; i < n; ++i) {
         const size_t vol = static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na;
         if (ctx[i].fine && vol <= kSmallVolume) {
-          KH_HIP(hipMemcpyAsync(B.h_sums + kSmallVolume * i, m->slots[ctx[i].slot].d_sums, vol * 4, hipMemcpyDeviceToHost, m->stream));
+          KH_HIP(hipMemcpyAsync(B.h_sums + kSmallVolume * i, m->slots[ctx[i].slot].d_sums, vol * 4, hipMemcpyDeviceToHost, cs));
         }
       }
     }
   }
-  KH_HIP(hipEventRecord(B.done, m->stream));
+  KH_HIP(hipEventRecord(B.done, cs));
   lap(1, t_enqueue);
   return KH_OK;
   }   // phase 0
@@ -1012,22 +1025,32 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
 {
   const size_t n = reqs.size();
   if (n == 0) {return KH_OK;}
-  // Optional (KH_PIPELINE=1): two sub-batches, the host half of one overlapping the kernels of the other
-  // (multiples of 8 jobs keep the XCD-aware block map balanced).  Measured on config 1: 1.28 ms per 32 matches
-  // against 1.20 ms unsplit -- the half-size kernels lose more than the overlap wins -- so it is off by default;
-  // callers that want the overlap run two handles from two threads instead (bench.py --streams 2).
-  static const bool pipeline = std::getenv("KH_PIPELINE") != nullptr;
-  const size_t half = (pipeline && n >= 16) ? ((n / 2 + 7) / 8) * 8 : n;
-  int rc = correlate_stage(m, reqs.data(), half, m->batch[0], 0);
-  if (rc) {return rc;}
-  if (half < n) {
-    rc = correlate_stage(m, reqs.data() + half, n - half, m->batch[1], 0);
-    if (rc) {(void)hipStreamSynchronize(m->stream); return rc;}
+  // Large batches go through in chunks of kChunk jobs on the two staging sets of the handle: while the kernels of
+  // chunk i run, the host prepares chunk i + 1 and finalises chunk i - 1 (the exact host half costs ~5 us per match
+  // on the worker pool, the scoring kernel ~13 us).  Chunks of 64 keep the scoring launches at full efficiency;
+  // splitting a batch of 32 into halves was measured slower than not splitting (0.85 against 0.76 ms), so batches
+  // below 2 * kChunk are not split.  KH_PIPELINE=0 switches the chunking off.
+  constexpr size_t kChunk = 64;
+  static const bool pipeline = !(std::getenv("KH_PIPELINE") && std::atoi(std::getenv("KH_PIPELINE")) == 0);
+  if (!pipeline || n < 2 * kChunk) {
+    int rc = correlate_stage(m, reqs.data(), n, m->batch[0], 0);
+    if (rc) {return rc;}
+    return correlate_stage(m, reqs.data(), n, m->batch[0], 1);
   }
-  rc = correlate_stage(m, reqs.data(), half, m->batch[0], 1);
-  int rc2 = KH_OK;
-  if (half < n) {rc2 = correlate_stage(m, reqs.data() + half, n - half, m->batch[1], 1);}
-  return rc ? rc : rc2;
+  const size_t chunks = (n + kChunk - 1) / kChunk;
+  auto begin_of = [&](size_t c) {return c * kChunk;};
+  auto size_of = [&](size_t c) {return std::min(kChunk, n - c * kChunk);};
+  int first_rc = KH_OK;
+  int rc = correlate_stage(m, reqs.data(), size_of(0), m->batch[0], 0, true);
+  if (rc) {return rc;}
+  for (size_t c = 1; c < chunks; ++c) {
+    rc = correlate_stage(m, reqs.data() + begin_of(c), size_of(c), m->batch[c & 1], 0, true);
+    if (rc) {(void)hipStreamSynchronize(m->stream); (void)hipStreamSynchronize(m->copy_stream); return rc;}
+    rc = correlate_stage(m, reqs.data() + begin_of(c - 1), size_of(c - 1), m->batch[(c - 1) & 1], 1, true);
+    if (rc && !first_rc) {first_rc = rc;}
+  }
+  rc = correlate_stage(m, reqs.data() + begin_of(chunks - 1), size_of(chunks - 1), m->batch[(chunks - 1) & 1], 1, true);
+  return first_rc ? first_rc : rc;
 }
 
 }  // namespace kh
@@ -1137,6 +1160,7 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) {return fail(e, "hipSetDevice");}
   if ((e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
+  if ((e = hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
   for (auto & ev : m->ev) {
     if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
   }
@@ -1145,6 +1169,8 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
       if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
     }
     if ((e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
+    if ((e = hipEventCreateWithFlags(&b.up, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
+    if ((e = hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
   }
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
@@ -1172,6 +1198,7 @@ void kh_matcher_destroy(kh_matcher * m)
   if (!m) {return;}
   hipSetDevice(m->device);
   if (m->stream) {hipStreamSynchronize(m->stream);}
+  if (m->copy_stream) {hipStreamSynchronize(m->copy_stream);}
   for (auto & s : m->slots) {
     hipFree(s.d_grid_alloc); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_tile_best); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_tcounts); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
@@ -1185,11 +1212,14 @@ void kh_matcher_destroy(kh_matcher * m)
     if (b.h_sums) {hipHostFree(b.h_sums);}
     for (auto & ev : b.ev) {if (ev) {hipEventDestroy(ev);}}
     if (b.done) {hipEventDestroy(b.done);}
+    if (b.up) {hipEventDestroy(b.up);}
+    if (b.kdone) {hipEventDestroy(b.kdone);}
   }
   if (m->h_rpoints) {hipHostFree(m->h_rpoints);}
   if (m->h_ractive) {hipHostFree(m->h_ractive);}
   if (m->h_rjobs) {hipHostFree(m->h_rjobs);}
   for (auto & ev : m->ev) {if (ev) {hipEventDestroy(ev);}}
+  if (m->copy_stream) {hipStreamDestroy(m->copy_stream);}
   if (m->stream) {hipStreamDestroy(m->stream);}
   delete m;
 }

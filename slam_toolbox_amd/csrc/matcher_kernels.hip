@@ -1,7 +1,7 @@
 // gfx950 (MI355X / CDNA4) kernels of the karto correlative scan matcher.
 //
-//   k_raster   K1  AddScans/AddScan/SmearPoint      Mapper.cpp:1032-1105, Mapper.h:1152-1183
-//   k_offsets  K2  GridIndexLookup::ComputeOffsets  Karto.h:6844-6894 (+ per-lattice compaction)
+//   k_raster_* K1  AddScans/AddScan/SmearPoint      Mapper.cpp:1032-1105, Mapper.h:1152-1183 (clear, bin, scan, fill, tile)
+//   k_offsets  K2  GridIndexLookup::ComputeOffsets  Karto.h:6844-6894 (+ per-lattice compaction, empty-window skipping)
 //   k_score    K3  operator()(y) + GetResponse      Mapper.cpp:641-694, 1172-1208
 //   k_ties     K4  best-response tie collection     Mapper.cpp:802-817
 //
@@ -12,10 +12,11 @@
 // lattice reads grid[base(x, y) + off[a][i]], and base is linear in (x, y): the nX x nY poses read
 // one contiguous window of the grid per beam.  So a wave owns a 64-byte x 4*RY-row window
 // (16 lanes x dword across, 4 lanes down, RY rows per lane), walks the beam list once with the
-// offset in an SGPR, issues ONE unaligned dword load per lane per row (4 lookups) and
-// accumulates the four bytes in two packed 2x16-bit registers -- no per-lookup address math, no
-// byte loads.  The 4 waves of a workgroup split the beam list and merge through LDS.  The
-// arithmetic is exact integer; the FP64 penalty is applied once per pose in the epilogue.
+// offset in an SGPR, issues ONE aligned dword load per lane per row (4 lookups) and accumulates
+// the four bytes in two packed 2x16-bit registers -- no per-lookup address math, no byte loads.
+// The 4 waves of a workgroup take the beams of one alignment class each ((window start) & 3, see
+// k_score) and merge through LDS.  The arithmetic is exact integer; the FP64 penalty is applied
+// once per pose in the epilogue.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -37,17 +38,6 @@ __device__ __forceinline__ int32_t d_to_int(double v)
   if (!(v > -2147483649.0 && v < 2147483648.0)) {return INT32_MIN;}   // cvttsd2si "integer indefinite"
   return (int32_t)v;
 }
-__device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
-{
-  uint32_t r = 0;
-#pragma unroll
-  for (int s = 0; s < 32; s += 8) {
-    uint32_t x = (a >> s) & 0xffu, y = (b >> s) & 0xffu;
-    r |= (x > y ? x : y) << s;
-  }
-  return r;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1: AddScans after Grid::Clear.  The stamp is a commutative byte-wise max (SmearPoint, Mapper.h:1152-1183),
 // so the parallel result equals the sequential one; the only order-dependent part of AddScan ("skip if the
@@ -57,7 +47,7 @@ __device__ __forceinline__ uint32_t bytemax4(uint32_t a, uint32_t b)
 //   k_raster_bin    thread per point: WorldToGrid, ROI test, duplicate test (a second point in the same cell
 //                   stamps the same footprint: dropped), occupancy-block marks, incidence counts of the
 //                   <= 2 x 2 tiles of 64 x 64 cells the k x k footprint overlaps (k <= 41)
-//   k_raster_scan   workgroup per job: exclusive scan of the counts -> list starts, list of non-empty tiles
+//   k_raster_scan   workgroup per job: exclusive scan of the counts of the non-empty tiles (listed by k_raster_bin) -> list starts
 //   k_raster_fill   thread per point: point index into the lists of its tiles
 //   k_raster_tile   workgroup per non-empty tile: max-stamps its points into an LDS tile (ds_max_u32 per
 //                   cell), then writes the tile's bytes once, coalesced.  HBM sees the grid clear, one
@@ -126,37 +116,39 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
   const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
   const int ty0 = (cy - hk) / kRasterTile, ty1 = (cy + hk) / kRasterTile;
   for (int ty = ty0; ty <= ty1; ++ty) {
-    for (int tx = tx0; tx <= tx1; ++tx) {atomicAdd(&job.tile_count[ty * job.tiles_w + tx], 1);}
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const int t = ty * job.tiles_w + tx;
+      if (atomicAdd(&job.tile_count[t], 1) == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}   // first point of the tile lists it
+    }
   }
 }
 
 __global__ __launch_bounds__(1024) void k_raster_scan(const RasterJob * jobs)
 {
+  // exclusive scan of the incidence counts over the NON-EMPTY tiles only (k_raster_bin listed them in `work` when
+  // their count left zero): a few hundred entries, not the 16 k tiles of a 8087^2 grid
   const RasterJob & job = jobs[blockIdx.x];
-  const int n = job.tiles_w * job.tiles_h;
+  const int n = job.n_work[0];
   const int per = (n + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = min(n, lo + per);
-  __shared__ int32_t s_sum[1024], s_cnt[1024];
-  int32_t sum = 0, cnt = 0;
-  for (int t = lo; t < hi; ++t) {const int32_t c = job.tile_count[t]; sum += c; cnt += c != 0;}
-  s_sum[threadIdx.x] = sum; s_cnt[threadIdx.x] = cnt;
+  const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+  __shared__ int32_t s_sum[1024];
+  int32_t sum = 0;
+  for (int w = lo; w < hi; ++w) {sum += job.tile_count[job.work[w]];}
+  s_sum[threadIdx.x] = sum;
   __syncthreads();
-  // Hillis-Steele inclusive scan of the per-thread totals
-  for (int d = 1; d < 1024; d <<= 1) {
-    int32_t a = 0, b = 0;
-    if ((int)threadIdx.x >= d) {a = s_sum[threadIdx.x - d]; b = s_cnt[threadIdx.x - d];}
+  for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan of the per-thread totals
+    int32_t a = 0;
+    if ((int)threadIdx.x >= d) {a = s_sum[threadIdx.x - d];}
     __syncthreads();
-    s_sum[threadIdx.x] += a; s_cnt[threadIdx.x] += b;
+    s_sum[threadIdx.x] += a;
     __syncthreads();
   }
-  int32_t run = s_sum[threadIdx.x] - sum, w = s_cnt[threadIdx.x] - cnt;
-  for (int t = lo; t < hi; ++t) {
-    const int32_t c = job.tile_count[t];
+  int32_t run = s_sum[threadIdx.x] - sum;
+  for (int w = lo; w < hi; ++w) {
+    const int t = job.work[w];
     job.tile_start[t] = run;
-    if (c != 0) {job.work[w++] = t;}
-    run += c;
+    run += job.tile_count[t];
   }
-  if (threadIdx.x == 1023) {job.n_work[0] = s_cnt[1023];}
 }
 
 __global__ __launch_bounds__(256) void k_raster_fill(const RasterJob * jobs)
@@ -619,7 +611,8 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
   const long long blocks = 8ll * units_per_xcd * na_chunk * max_tiles;
   dim3 grid((unsigned int)blocks);
   hipStream_t s = (hipStream_t)stream;
-  static const int lds_pad = std::getenv("KH_K3_LDS_PAD") ? std::atoi(std::getenv("KH_K3_LDS_PAD")) : 0;   // occupancy experiment
+  // KH_K3_LDS_PAD=<bytes>: dynamic LDS nobody uses, to cap the workgroups per CU (occupancy experiment of DESIGN.md section 4)
+  static const int lds_pad = std::getenv("KH_K3_LDS_PAD") ? std::atoi(std::getenv("KH_K3_LDS_PAD")) : 0;
 #define KH_SCORE(SXV, RYV) hipLaunchKernelGGL((k_score<SXV, RYV, AW>), grid, dim3(256 * AW), lds_pad, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
   if (sx_variant == 2) {
     if (ry == 8) {KH_SCORE(2, 8);} else if (ry == 4) {KH_SCORE(2, 4);} else {KH_SCORE(2, 1);}

@@ -117,6 +117,33 @@ def test_batch_equals_single(kartohip_lib):
     hmb.close()
 
 
+def test_chunked_batch_equals_single(kartohip_lib):
+    """Batches of >= 128 matches go through the library in chunks of 64 on two staging sets, the host half of one
+    chunk overlapping the kernels of another (matcher_host.cpp::correlate_batch).  150 matches (8 distinct pairs,
+    tiled; the last chunk is partial) must come back exactly as one-at-a-time calls return them."""
+    scs = [Scenario(seed=60 + i, n_base=5 + i % 4, start=23 * i + 2, perturb=(0.02 * i, -0.01 * i, 0.005 * i)) for i in range(8)]
+    hm1 = make_hip_matcher("K")
+    singles, pairs = [], []
+    for sc in scs:
+        q, b = sc.hip_scans()
+        pairs.append((q, b))
+        singles.append(hm1.MatchScan(q, b))
+    hm1.close()
+    n = 150
+    hmb = make_hip_matcher("K", max_batch=n)
+    qs = [pairs[i % 8][0] for i in range(n)]
+    bs = [pairs[i % 8][1] for i in range(n)]
+    for _ in range(2):                                   # second pass: staging sets and slots reused
+        resp, means, covs, status = hmb.MatchScanBatch(qs, bs)
+        assert (status == 0).all()
+        for i in range(n):
+            r, m, c = singles[i % 8]
+            _assert_same(r, resp[i], "response")
+            _assert_same(m, means[i], "mean")
+            _assert_same(c, covs[i], "cov")
+    hmb.close()
+
+
 def test_empty_grid_and_empty_scan(kartohip_lib):
     """No base scans -> every pose ties at response 0 (host fallback path); empty query scan -> the
     reference's early return (Mapper.cpp:547-557)."""
