@@ -119,7 +119,8 @@ struct CorrBatch
   int32_t * h_sums = nullptr; size_t cap_hsums = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};      // around the scoring kernel (profiling)
   hipEvent_t done = nullptr;                  // everything of the sub-batch, downloads included
-  hipEvent_t up = nullptr, kdone = nullptr;   // chunked batches: tables uploaded (copy stream) / kernels finished (main stream)
+  hipEvent_t up = nullptr, kdone = nullptr;   // chunked batches: tables + lists ready (side stream) / scoring finished (main stream)
+  hipStream_t side = nullptr;                 // side stream of this staging set (uploads, K2, K4, downloads of its chunks)
 };
 
 struct Slot
@@ -159,7 +160,6 @@ struct kh_matcher
   kh_match_params params;
   int32_t device = 0, max_batch = 1;
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;   // chunked batches: uploads / downloads of one chunk under the kernels of another
   uint8_t * d_kernel = nullptr;
   std::vector<Slot> slots;
   CorrBatch batch[2];
@@ -791,19 +791,20 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   // ---- 2. upload, launch, download ----
   lap(0, t_enter);
   const auto t_enqueue = std::chrono::steady_clock::now();
-  // overlap (chunked batches): the copies go on the copy stream, ordered against the kernels by events, so the PCIe
-  // transfers of one chunk run under the kernels of its neighbours
-  hipStream_t cs = overlap ? m->copy_stream : m->stream;
+  // overlap (chunked batches): the uploads, the table / list kernel K2, the tie scan K4 and the downloads go on the
+  // side stream, ordered against the scoring kernel by events: the main stream then runs K3 after K3, and everything
+  // else of a chunk happens under the scoring of its neighbours
+  hipStream_t cs = overlap ? B.side : m->stream;
   KH_HIP(hipMemcpyAsync(B.d_stage, B.h_stage, stride * n, hipMemcpyHostToDevice, cs));
+  KH_HIP(hipMemsetAsync(B.d_out, 0, out_words * 8 * n, cs));
+  if (use_lds) {
+    launch_offsets_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, cs);
+  } else {
+    launch_offsets(B.d_stage, stride, static_cast<int32_t>(n), max_na, cs);
+  }
   if (overlap) {
     KH_HIP(hipEventRecord(B.up, cs));
     KH_HIP(hipStreamWaitEvent(m->stream, B.up, 0));
-  }
-  KH_HIP(hipMemsetAsync(B.d_out, 0, out_words * 8 * n, m->stream));
-  if (use_lds) {
-    launch_offsets_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
-  } else {
-    launch_offsets(B.d_stage, stride, static_cast<int32_t>(n), max_na, m->stream);
   }
   if (m->profiling) {KH_HIP(hipEventRecord(B.ev[0], m->stream));}
   if (use_lds) {
@@ -818,12 +819,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     }
   }
   if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], m->stream));}
-  launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, B.tile_pairs, m->stream);
-  KH_HIP(hipGetLastError());
   if (overlap) {
     KH_HIP(hipEventRecord(B.kdone, m->stream));
     KH_HIP(hipStreamWaitEvent(cs, B.kdone, 0));
   }
+  launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, B.tile_pairs, cs);
+  KH_HIP(hipGetLastError());
   KH_HIP(hipMemcpyAsync(B.h_out, B.d_out, out_words * 8 * n, hipMemcpyDeviceToHost, cs));
   // fine passes need the raw sums of every angle at the best cell (ComputeAngularCovariance): their
   // volumes are tiny (3 x 3 x nA), so they ride along with the batch download instead of costing one
@@ -1037,15 +1038,23 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     if (rc) {return rc;}
     return correlate_stage(m, reqs.data(), n, m->batch[0], 1);
   }
-  const size_t chunks = (n + kChunk - 1) / kChunk;
-  auto begin_of = [&](size_t c) {return c * kChunk;};
-  auto size_of = [&](size_t c) {return std::min(kChunk, n - c * kChunk);};
+  // the side streams start behind everything already queued on the main stream (the rasteriser writes the grids
+  // and the occupancy block maps K2 reads); they are drained before this call returns (every chunk's `done` is
+  // waited for), so later main-stream work needs no edge back
+  KH_HIP(hipEventRecord(m->batch[0].kdone, m->stream));
+  for (auto & b : m->batch) {KH_HIP(hipStreamWaitEvent(b.side, m->batch[0].kdone, 0));}
+  std::vector<size_t> bounds;
+  for (size_t at = 0; at < n; at += kChunk) {bounds.push_back(at);}
+  bounds.push_back(n);
+  const size_t chunks = bounds.size() - 1;
+  auto begin_of = [&](size_t c) {return bounds[c];};
+  auto size_of = [&](size_t c) {return bounds[c + 1] - bounds[c];};
   int first_rc = KH_OK;
   int rc = correlate_stage(m, reqs.data(), size_of(0), m->batch[0], 0, true);
   if (rc) {return rc;}
   for (size_t c = 1; c < chunks; ++c) {
     rc = correlate_stage(m, reqs.data() + begin_of(c), size_of(c), m->batch[c & 1], 0, true);
-    if (rc) {(void)hipStreamSynchronize(m->stream); (void)hipStreamSynchronize(m->copy_stream); return rc;}
+    if (rc) {(void)hipStreamSynchronize(m->stream); for (auto & b : m->batch) {(void)hipStreamSynchronize(b.side);} return rc;}
     rc = correlate_stage(m, reqs.data() + begin_of(c - 1), size_of(c - 1), m->batch[(c - 1) & 1], 1, true);
     if (rc && !first_rc) {first_rc = rc;}
   }
@@ -1160,7 +1169,6 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) {return fail(e, "hipSetDevice");}
   if ((e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
-  if ((e = hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
   for (auto & ev : m->ev) {
     if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
   }
@@ -1171,6 +1179,7 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
     if ((e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
     if ((e = hipEventCreateWithFlags(&b.up, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
     if ((e = hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
+    if ((e = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
   }
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
@@ -1198,7 +1207,6 @@ void kh_matcher_destroy(kh_matcher * m)
   if (!m) {return;}
   hipSetDevice(m->device);
   if (m->stream) {hipStreamSynchronize(m->stream);}
-  if (m->copy_stream) {hipStreamSynchronize(m->copy_stream);}
   for (auto & s : m->slots) {
     hipFree(s.d_grid_alloc); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_tile_best); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_tcounts); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
@@ -1214,12 +1222,12 @@ void kh_matcher_destroy(kh_matcher * m)
     if (b.done) {hipEventDestroy(b.done);}
     if (b.up) {hipEventDestroy(b.up);}
     if (b.kdone) {hipEventDestroy(b.kdone);}
+    if (b.side) {hipStreamSynchronize(b.side); hipStreamDestroy(b.side);}
   }
   if (m->h_rpoints) {hipHostFree(m->h_rpoints);}
   if (m->h_ractive) {hipHostFree(m->h_ractive);}
   if (m->h_rjobs) {hipHostFree(m->h_rjobs);}
   for (auto & ev : m->ev) {if (ev) {hipEventDestroy(ev);}}
-  if (m->copy_stream) {hipStreamDestroy(m->copy_stream);}
   if (m->stream) {hipStreamDestroy(m->stream);}
   delete m;
 }
