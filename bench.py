@@ -307,7 +307,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solver", action="store_true")
     ap.add_argument("--no-loop", action="store_true")
-    ap.add_argument("--no-two-stream", action="store_true")
+    ap.add_argument("--no-two-stream", action="store_true", help="(default) kept for old command lines")
+    ap.add_argument("--two-stream", action="store_true",
+                    help="also time the same steps dealt to two handles on two host threads (extra key two_stream_value); since "
+                         "one handle pipelines its own chunks this no longer beats the single handle")
     args = ap.parse_args()
 
     # last resort against a stuck collective or a teardown that never returns: after KH_BENCH_WATCHDOG seconds
@@ -396,7 +399,7 @@ def main():
     profs = [h.profile(False) for h in handles]
     prof = {k: sum(p[k] for p in profs) for k in profs[0]}
     two_stream = None
-    if S == 1 and not args.no_two_stream:
+    if S == 1 and args.two_stream and not args.no_two_stream:
         # extra key: the same steps dealt to TWO handles on two host threads (not the headline: the kernels of the two
         # streams overlap, so per-launch event times are no longer those of an isolated kernel)
         h2 = ScanMatcher.Create(MapperParams(**C2_PARAMS), *PRESETS["C2"]["create"], device=local_rank, max_batch=B)
