@@ -167,6 +167,7 @@ struct kh_matcher
   double * h_rpoints = nullptr; uint8_t * h_ractive = nullptr; size_t cap_hrpoints = 0, cap_hractive = 0;
   RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
   bool keep_responses = false;
+  bool force_chunks = false;       // kh_matcher_set_debug bit 3: chunk every batch of >= 128 (tests)
   bool dense_score = false;        // kh_matcher_set_debug bit 2: do not skip beams whose window is empty
   int32_t bm_w = 0, bm_h = 0;
   int32_t rt_w = 0, rt_h = 0;      // rasteriser tiles over the grid
@@ -1033,7 +1034,13 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   // below 2 * kChunk are not split.  KH_PIPELINE=0 switches the chunking off.
   constexpr size_t kChunk = 64;
   static const bool pipeline = !(std::getenv("KH_PIPELINE") && std::atoi(std::getenv("KH_PIPELINE")) == 0);
-  if (!pipeline || n < 2 * kChunk) {
+  // ... and only searches whose scoring kernel dwarfs the hand-overs between the streams: a chunk of 64 config-2
+  // searches scores for 0.85 ms, a chunk of loop-closure coarse searches (half the lookups, a quarter of the loads)
+  // for 0.2 ms, and batches of those were measured 25 % slower chunked than whole
+  const CorrReq & r0 = reqs[0];
+  const double work0 = (round_half_away(r0.off_x * 2.0 / r0.res_x) + 1) * (round_half_away(r0.off_y * 2.0 / r0.res_y) + 1) *
+    (round_half_away(r0.ang_off * 2.0 / r0.ang_res) + 1) * static_cast<double>(r0.scan->n);
+  if (!pipeline || n < 2 * kChunk || (work0 < 2.5e8 && !m->force_chunks)) {
     int rc = correlate_stage(m, reqs.data(), n, m->batch[0], 0);
     if (rc) {return rc;}
     return correlate_stage(m, reqs.data(), n, m->batch[0], 1);
@@ -1251,6 +1258,7 @@ int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
   m->keep_responses = (keep_response_volume & 1) != 0;
   m->lds_score = (keep_response_volume & 2) != 0;
   m->dense_score = (keep_response_volume & 4) != 0;
+  m->force_chunks = (keep_response_volume & 8) != 0;
   return KH_OK;
 }
 

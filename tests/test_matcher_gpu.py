@@ -131,6 +131,7 @@ def test_chunked_batch_equals_single(kartohip_lib):
     hm1.close()
     n = 150
     hmb = make_hip_matcher("K", max_batch=n)
+    hmb.set_debug(False, force_chunks=True)              # small searches are not chunked on their own
     qs = [pairs[i % 8][0] for i in range(n)]
     bs = [pairs[i % 8][1] for i in range(n)]
     for _ in range(2):                                   # second pass: staging sets and slots reused
@@ -142,6 +143,33 @@ def test_chunked_batch_equals_single(kartohip_lib):
             _assert_same(m, means[i], "mean")
             _assert_same(c, covs[i], "cov")
     hmb.close()
+
+
+def test_chunked_config2_batch_equals_single(kartohip_lib):
+    """The bench path: 130 config-2 CorrelateScans in one call (chunked by the library on its own: 64 + 64 + 2)
+    against the same searches one at a time, rasterised grids resident in their slots."""
+    import math
+    from slam_toolbox_amd.scan_matcher import _scan_array
+    n = 130
+    scs = [Scenario(seed=70 + i, n_base=6, start=41 * i + 3, perturb=(0.03 * (i - 1), 0.02 * i, 0.01 * (i - 2))) for i in range(4)]
+    hm = make_hip_matcher("C2", max_batch=n)
+    queries, centers = [], []
+    for b in range(n):
+        q, base = scs[b % 4].hip_scans()
+        hm.AddScans(q, base, slot=b)
+        queries.append(q)
+        centers.append(scs[b % 4].query_pose)
+    corr = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+    singles = [hm.CorrelateScan(queries[b], centers[b], *corr, True, None, False, slot=b) for b in range(4)]
+    resp, means, covs, status = hm.CorrelateScanBatch(None, np.asarray(centers), *corr, True, False,
+                                                      scan_array=(_scan_array(queries), n))
+    assert (status == 0).all()
+    for b in range(n):
+        r, m, c = singles[b % 4]
+        _assert_same(r, resp[b], "response")
+        _assert_same(m, means[b], "mean")
+        _assert_same(c, covs[b], "cov")
+    hm.close()
 
 
 def test_empty_grid_and_empty_scan(kartohip_lib):
