@@ -153,7 +153,7 @@ def solver_leg(device=0, rank=0, world=1):
             "solve_parallelism": "1 GPU" if world == 1 else f"{world} GPUs: edge-block linearisation + all-reduce(H, g), replicated factorisation"}
 
 
-def loop_leg(device=0, n_pairs=256, distinct=32, batch=64):
+def loop_leg(device=0, n_pairs=256, distinct=32, batch=256):
     """BASELINE config[2]: loop-closure candidate batch -- 256 (query scan, candidate chain) pairs on the
     2k-node trajectory, chain length 10-40 scans; each pair = preset L coarse MatchScan (doPenalize=False,
     doRefineMatch=False, Mapper.cpp:1511-1512) and, for those passing the coarse gate (response > 0.35, both

@@ -189,7 +189,8 @@ static int32_t half_kernel_size(double smear, double resolution)   // Mapper.h:1
 }
 
 // FindValidPoints, Mapper.cpp:1113-1164: appends the kept points of `scan` to `out`
-static void find_valid_points(const kh_scan & scan, const double viewpoint[2], std::vector<double> & out)
+// appends to out[2 * count ...]; the caller provides room for scan.n more points
+static void find_valid_points(const kh_scan & scan, const double viewpoint[2], double * out, size_t & count)
 {
   const double min_square_distance = 0.1 * 0.1;
   int32_t trailing = 0;
@@ -212,8 +213,9 @@ static void find_valid_points(const kh_scan & scan, const double viewpoint[2], s
         trailing = it;
       } else {
         for (; trailing != it; ++trailing) {
-          out.push_back(pts[2 * trailing]);
-          out.push_back(pts[2 * trailing + 1]);
+          out[2 * count] = pts[2 * trailing];
+          out[2 * count + 1] = pts[2 * trailing + 1];
+          ++count;
         }
       }
     }
@@ -330,9 +332,21 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
 {
   if (reqs.empty()) {return KH_OK;}
   const double res = m->grid_resolution();
-  // 1. centre grids, FindValidPoints (host, sequential per scan), optional order-dependent filter
-  std::vector<std::vector<double>> pts(reqs.size());
-  std::vector<std::vector<uint8_t>> act(reqs.size());
+  // 1. centre grids, FindValidPoints (host, sequential per scan), optional order-dependent filter.  Every job
+  // writes its points and flags straight into its region of the pinned staging buffers (regions sized by the
+  // upper bound "every reading of every base scan is valid"): no per-job vectors, no gather copy afterwards.
+  std::vector<size_t> region(reqs.size() + 1, 0), n_valid(reqs.size(), 0);
+  for (size_t r = 0; r < reqs.size(); ++r) {
+    size_t bound = 0;
+    for (int32_t b = 0; b < reqs[r].n_base; ++b) {
+      if (reqs[r].base[b].points_xy != nullptr) {bound += static_cast<size_t>(std::max(0, reqs[r].base[b].n));}
+    }
+    region[r + 1] = region[r] + bound;
+  }
+  int rc = ensure_pinned(m->h_rpoints, m->cap_hrpoints, std::max<size_t>(region.back(), 1) * 2, m->stream);
+  if (rc) {return rc;}
+  rc = ensure_pinned(m->h_ractive, m->cap_hractive, std::max<size_t>(region.back(), 1), m->stream);
+  if (rc) {return rc;}
   size_t max_points = 0;
   HostPool::instance().run(reqs.size(), [&](size_t r) {
     Slot & s = m->slots[reqs[r].slot];
@@ -340,52 +354,55 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     // MatchScan steps 1-4, Mapper.cpp:543-569
     s.off_x = pose[0] - (0.5 * (m->roi_w - 1) * res);
     s.off_y = pose[1] - (0.5 * (m->roi_h - 1) * res);
-    std::vector<double> & v = pts[r];
+    double * v = m->h_rpoints + 2 * region[r];
+    uint8_t * active = m->h_ractive + region[r];
+    size_t np = 0;
     for (int32_t b = 0; b < reqs[r].n_base; ++b) {
       if (reqs[r].base[b].points_xy == nullptr) {continue;}    // NULL scan: skipped (Mapper.cpp:1039-1041)
-      find_valid_points(reqs[r].base[b], pose, v);
+      find_valid_points(reqs[r].base[b], pose, v, np);
     }
-    const size_t np = v.size() / 2;
-    act[r].assign(np, 1);
+    n_valid[r] = np;
+    std::memset(active, 1, np);
     if (m->footprint100.size() > 1) {
       // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon
       // as the smear kernel writes 100 off-centre: resolve the active set in reference order.
-      // open-addressing set of occupied cells (keys = packed cell coordinates, never 0 after the +1)
+      // Open-addressing set of occupied cells (keys = packed cell coordinates), kept per worker thread and
+      // emptied by bumping a generation stamp instead of clearing megabytes per job.
+      thread_local std::vector<uint64_t> keys;
+      thread_local std::vector<uint32_t> stamp;
+      thread_local uint32_t generation = 0;
       size_t cap = 64;
       while (cap < np * m->footprint100.size() * 2 + 16) {cap <<= 1;}
-      std::vector<uint64_t> table(cap, 0);
+      if (keys.size() < cap) {keys.assign(cap, 0); stamp.assign(cap, 0); generation = 0;}
+      if (++generation == 0) {std::fill(stamp.begin(), stamp.end(), 0u); generation = 1;}
       const size_t mask = cap - 1;
+      const uint32_t gen = generation;
+      // returns the slot of `key`, or of the empty slot where it belongs
       auto slot_of = [&](uint64_t key) {
         size_t h = static_cast<size_t>((key * 0x9E3779B97F4A7C15ull) >> 20) & mask;
-        while (table[h] != 0 && table[h] != key) {h = (h + 1) & mask;}
+        while (stamp[h] == gen && keys[h] != key) {h = (h + 1) & mask;}
         return h;
       };
       auto pack = [](int32_t x, int32_t y) {
-        return ((static_cast<uint64_t>(static_cast<uint32_t>(y)) << 32) | static_cast<uint32_t>(x)) + 1;
+        return (static_cast<uint64_t>(static_cast<uint32_t>(y)) << 32) | static_cast<uint32_t>(x);
       };
       for (size_t p = 0; p < np; ++p) {
         const Cell c = world_to_grid(m->scale, s.off_x, s.off_y, v[2 * p], v[2 * p + 1]);
-        if (!(c.x >= 0 && c.x < m->roi_w) || !(c.y >= 0 && c.y < m->roi_h)) {act[r][p] = 0; continue;}
-        if (table[slot_of(pack(c.x, c.y))] != 0) {act[r][p] = 0; continue;}
+        if (!(c.x >= 0 && c.x < m->roi_w) || !(c.y >= 0 && c.y < m->roi_h)) {active[p] = 0; continue;}
+        if (stamp[slot_of(pack(c.x, c.y))] == gen) {active[p] = 0; continue;}
         for (const Cell & f : m->footprint100) {
           const uint64_t key = pack(c.x + f.x, c.y + f.y);
-          table[slot_of(key)] = key;
+          const size_t h = slot_of(key);
+          keys[h] = key; stamp[h] = gen;
         }
       }
     }
   });
-  for (auto & v : pts) {max_points = std::max(max_points, v.size() / 2);}
-  // 2. stage + upload
-  size_t total = 0;
-  for (auto & v : pts) {total += v.size() / 2;}
-  int rc = ensure_pinned(m->h_rpoints, m->cap_hrpoints, std::max<size_t>(total, 1) * 2, m->stream);
-  if (rc) {return rc;}
-  rc = ensure_pinned(m->h_ractive, m->cap_hractive, std::max<size_t>(total, 1), m->stream);
-  if (rc) {return rc;}
-  size_t cursor = 0;
+  for (size_t r = 0; r < reqs.size(); ++r) {max_points = std::max(max_points, n_valid[r]);}
+  // 2. upload
   for (size_t r = 0; r < reqs.size(); ++r) {
     Slot & s = m->slots[reqs[r].slot];
-    const size_t np = pts[r].size() / 2;
+    const size_t np = n_valid[r], cursor = region[r];
     rc = ensure_device(s.d_rpoints, s.cap_rpoints, std::max<size_t>(np, 1) * 2, m->stream);
     if (rc) {return rc;}
     rc = ensure_device(s.d_ractive, s.cap_ractive, std::max<size_t>(np, 1), m->stream);
@@ -393,8 +410,6 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     rc = ensure_device(s.d_rlists, s.cap_rlists, std::max<size_t>(np, 1) * 6, m->stream);
     if (rc) {return rc;}
     if (np) {
-      std::memcpy(m->h_rpoints + 2 * cursor, pts[r].data(), sizeof(double) * 2 * np);
-      std::memcpy(m->h_ractive + cursor, act[r].data(), np);
       KH_HIP(hipMemcpyAsync(s.d_rpoints, m->h_rpoints + 2 * cursor, sizeof(double) * 2 * np, hipMemcpyHostToDevice, m->stream));
       KH_HIP(hipMemcpyAsync(s.d_ractive, m->h_ractive + cursor, np, hipMemcpyHostToDevice, m->stream));
     }
@@ -408,7 +423,6 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
     j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
     j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * std::max<size_t>(np, 1);
-    cursor += np;
   }
   KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * reqs.size(), hipMemcpyHostToDevice, m->stream));
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[2], m->stream));}
