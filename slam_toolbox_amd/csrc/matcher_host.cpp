@@ -366,36 +366,29 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     if (m->footprint100.size() > 1) {
       // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon
       // as the smear kernel writes 100 off-centre: resolve the active set in reference order.
-      // Open-addressing set of occupied cells (keys = packed cell coordinates), kept per worker thread and
-      // emptied by bumping a generation stamp instead of clearing megabytes per job.
-      thread_local std::vector<uint64_t> keys;
-      thread_local std::vector<uint32_t> stamp;
-      thread_local uint32_t generation = 0;
-      size_t cap = 64;
-      while (cap < np * m->footprint100.size() * 2 + 16) {cap <<= 1;}
-      if (keys.size() < cap) {keys.assign(cap, 0); stamp.assign(cap, 0); generation = 0;}
-      if (++generation == 0) {std::fill(stamp.begin(), stamp.end(), 0u); generation = 1;}
-      const size_t mask = cap - 1;
-      const uint32_t gen = generation;
-      // returns the slot of `key`, or of the empty slot where it belongs
-      auto slot_of = [&](uint64_t key) {
-        size_t h = static_cast<size_t>((key * 0x9E3779B97F4A7C15ull) >> 20) & mask;
-        while (stamp[h] == gen && keys[h] != key) {h = (h + 1) & mask;}
-        return h;
-      };
-      auto pack = [](int32_t x, int32_t y) {
-        return (static_cast<uint64_t>(static_cast<uint32_t>(y)) << 32) | static_cast<uint32_t>(x);
-      };
+      // Set of occupied cells = one bit per ROI cell, kept per worker thread; only the words a job touched are
+      // cleared after it (a few thousand), not the whole map.
+      thread_local std::vector<uint64_t> occupied;
+      thread_local std::vector<uint32_t> touched;
+      const size_t words = (static_cast<size_t>(m->roi_w) * m->roi_h + 63) / 64;
+      if (occupied.size() < words) {occupied.assign(words, 0);}
+      touched.clear();
+      const int32_t rw = m->roi_w, rh = m->roi_h;
       for (size_t p = 0; p < np; ++p) {
         const Cell c = world_to_grid(m->scale, s.off_x, s.off_y, v[2 * p], v[2 * p + 1]);
-        if (!(c.x >= 0 && c.x < m->roi_w) || !(c.y >= 0 && c.y < m->roi_h)) {active[p] = 0; continue;}
-        if (stamp[slot_of(pack(c.x, c.y))] == gen) {active[p] = 0; continue;}
+        if (!(c.x >= 0 && c.x < rw) || !(c.y >= 0 && c.y < rh)) {active[p] = 0; continue;}
+        const size_t cell = static_cast<size_t>(c.y) * rw + c.x;
+        if ((occupied[cell >> 6] >> (cell & 63)) & 1ull) {active[p] = 0; continue;}
         for (const Cell & f : m->footprint100) {
-          const uint64_t key = pack(c.x + f.x, c.y + f.y);
-          const size_t h = slot_of(key);
-          keys[h] = key; stamp[h] = gen;
+          const int32_t fx = c.x + f.x, fy = c.y + f.y;
+          if (fx < 0 || fx >= rw || fy < 0 || fy >= rh) {continue;}     // no point can land there (ROI test above)
+          const size_t fc = static_cast<size_t>(fy) * rw + fx;
+          uint64_t & w = occupied[fc >> 6];
+          if (w == 0) {touched.push_back(static_cast<uint32_t>(fc >> 6));}
+          w |= 1ull << (fc & 63);
         }
       }
+      for (uint32_t w : touched) {occupied[w] = 0;}
     }
   });
   for (size_t r = 0; r < reqs.size(); ++r) {max_points = std::max(max_points, n_valid[r]);}
