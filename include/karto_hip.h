@@ -163,6 +163,12 @@ KH_API void * kh_matcher_stream(kh_matcher * m);
 KH_API int kh_matcher_profile(kh_matcher * m, int32_t enable, double * score_ms, int64_t * score_launches,
                               double * raster_ms, int64_t * raster_launches);
 
+/* wave-level dword-load instructions (256 B each: 16 lanes x 4 B across, 4 grid rows down) the scoring kernel issued
+ * for the searches run while profiling was enabled, tallied on the device by K2 from the beam lists it hands to K3
+ * (slow-path beams, which need the per-pose range check, are not included).  This is the L1 (TCP) side of the
+ * roofline: bytes = 256 * wave_loads.  reset != 0 zeroes the tally after reading it. */
+KH_API int kh_matcher_score_loads(kh_matcher * m, int64_t * wave_loads, int32_t reset);
+
 /* ---------------------------------------------------------------- SPA solver (B) */
 typedef struct kh_spa kh_spa;
 
@@ -199,6 +205,15 @@ typedef struct kh_spa_summary {
   double initial_cost, final_cost;
   double linearize_ms, solve_ms, total_ms;   /* GPU/host wall split of Compute() */
   int64_t nnz_factor;           /* scalar non-zeros of the Cholesky factor */
+  /* measurement (HIP events on the solver's stream, summed over the LM iterations of this Compute()) */
+  int64_t factor_flops;         /* floating-point operations of ONE numeric factorisation: sum over the fronts of
+                                   sum_{j < ns} (m - j)^2 (partial dense Cholesky of ns pivots of an m x m front) */
+  int32_t factorizations;       /* numeric factorisations executed (= LM iterations) */
+  int32_t levels;               /* elimination-tree levels = dependent launches per factorisation */
+  double factor_gpu_ms;         /* assemble + factor + forward sweeps */
+  double backward_gpu_ms;       /* backward sweeps + step evaluation */
+  double linearize_gpu_ms;      /* edge linearisation + gathers of H and g (every evaluation point) */
+  double symbolic_ms;           /* host: pattern + ordering + symbolic factorisation + uploads (0 when the topology was cached) */
 } kh_spa_summary;
 
 KH_API int kh_spa_create(int32_t device, kh_spa ** out);

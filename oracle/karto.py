@@ -25,7 +25,7 @@ class KoPoseResponse(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("karto_oracle.c", "spa_oracle.c", "occupancy_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("karto_oracle.c", "occupancy_oracle.c")]
     if force or not os.path.exists(_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_PATH) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libkarto_oracle.so"])
     return _PATH

@@ -56,7 +56,9 @@ class KhSpaSummary(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32),
                 ("usable", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("linearize_ms", C.c_double), ("solve_ms", C.c_double), ("total_ms", C.c_double),
-                ("nnz_factor", C.c_int64)]
+                ("nnz_factor", C.c_int64), ("factor_flops", C.c_int64), ("factorizations", C.c_int32),
+                ("levels", C.c_int32), ("factor_gpu_ms", C.c_double), ("backward_gpu_ms", C.c_double),
+                ("linearize_gpu_ms", C.c_double), ("symbolic_ms", C.c_double)]
 
 
 # every symbol include/karto_hip.h declares (tests check that the built library exports all of them)
@@ -65,7 +67,7 @@ SYMBOLS = [
     "kh_matcher_create", "kh_matcher_destroy", "kh_matcher_set_params", "kh_matcher_match",
     "kh_matcher_match_batch", "kh_matcher_add_scans", "kh_matcher_correlate", "kh_matcher_correlate_batch",
     "kh_matcher_grid_info", "kh_matcher_read_grid", "kh_matcher_read_kernel", "kh_matcher_read_lookup",
-    "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile",
+    "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile", "kh_matcher_score_loads",
     "kh_spa_options_default", "kh_spa_create", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
@@ -138,6 +140,7 @@ def lib():
     L.kh_matcher_stream.argtypes = [vp]
     L.kh_matcher_stream.restype = vp
     L.kh_matcher_profile.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(C.c_int64), C.POINTER(dbl), C.POINTER(C.c_int64)]
+    L.kh_matcher_score_loads.argtypes = [vp, C.POINTER(C.c_int64), i32]
     if hasattr(L, "kh_spa_create"):
         L.kh_spa_options_default.argtypes = [C.POINTER(KhSpaOptions)]
         L.kh_spa_create.argtypes = [i32, C.POINTER(vp)]

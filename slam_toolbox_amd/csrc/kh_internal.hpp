@@ -98,6 +98,8 @@ struct CorrJob
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
   unsigned long long * out;  // result block, see below
+  unsigned long long * load_counter;   // handle-wide tally of the row loads K3 will issue for the fast lists K2 builds (wave-level
+                                       // dword-load instructions, 256 B each): the L1 side of the roofline; nullptr = not counted
 };
 
 // Result block layout (unsigned long long words) per job, zeroed before every CorrelateScan:

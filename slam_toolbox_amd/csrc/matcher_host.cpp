@@ -176,6 +176,7 @@ struct kh_matcher
   bool profiling = false;
   double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0, score_jobs = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long * d_load_counter = nullptr;    // see CorrJob::load_counter (only handed to the jobs while profiling)
 
   double grid_resolution() const {return 1.0 / scale;}   // Karto.h:4518-4521
 };
@@ -779,6 +780,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i;
     job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
     job->tile_best = s.d_tile_best;
+    job->load_counter = m->profiling ? m->d_load_counter : nullptr;
   });
   bool all_lds = true;
   for (size_t i = 0; i < n; ++i) {
@@ -1197,6 +1199,8 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
     if ((e = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
   }
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
+  if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_load_counter), 8)) != hipSuccess) {return fail(e, "hipMalloc counter");}
+  if ((e = hipMemset(m->d_load_counter, 0, 8)) != hipSuccess) {return fail(e, "hipMemset counter");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
   m->rt_w = (m->ws + kRasterTile - 1) / kRasterTile;
   m->rt_h = (m->data_size / m->ws + kRasterTile - 1) / kRasterTile;
@@ -1227,7 +1231,7 @@ void kh_matcher_destroy(kh_matcher * m)
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
   }
-  hipFree(m->d_kernel); hipFree(m->d_rjobs);
+  hipFree(m->d_kernel); hipFree(m->d_rjobs); hipFree(m->d_load_counter);
   for (auto & b : m->batch) {
     hipFree(b.d_stage); hipFree(b.d_out);
     if (b.h_stage) {hipHostFree(b.h_stage);}
@@ -1545,6 +1549,19 @@ int kh_matcher_profile(kh_matcher * m, int32_t enable, double * score_ms, int64_
   if (raster_launches) {*raster_launches = m->raster_launches;}
   m->profiling = enable != 0;
   m->score_ms = 0; m->raster_ms = 0; m->score_launches = 0; m->raster_launches = 0; m->score_jobs = 0;
+  return KH_OK;
+}
+
+int kh_matcher_score_loads(kh_matcher * m, int64_t * wave_loads, int32_t reset)
+{
+  if (!m || !wave_loads) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  KH_HIP(hipStreamSynchronize(m->stream));
+  for (auto & b : m->batch) {KH_HIP(hipStreamSynchronize(b.side));}
+  unsigned long long v = 0;
+  KH_HIP(hipMemcpy(&v, m->d_load_counter, 8, hipMemcpyDeviceToHost));
+  *wave_loads = static_cast<int64_t>(v);
+  if (reset) {KH_HIP(hipMemset(m->d_load_counter, 0, 8));}
   return KH_OK;
 }
 

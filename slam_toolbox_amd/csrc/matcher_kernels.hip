@@ -352,6 +352,13 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   __syncthreads();
   if (threadIdx.x < kClasses + 1) {job.counts[kCountsPerAngle * a + threadIdx.x] = s_counts[threadIdx.x];}
   if ((int)threadIdx.x < kClasses * lt) {job.tcounts[(size_t)a * kClasses * lt + threadIdx.x] = s_tcounts[threadIdx.x];}
+  if (threadIdx.x == 0 && job.load_counter) {
+    // every entry of a list costs K3 `ry` wave-level dword loads in each scoring tile that walks the list
+    long long entries = 0;
+    for (int li = 0; li < kClasses * lt; ++li) {entries += s_tcounts[li];}
+    const long long tiles_per_list = lt > 1 ? 1 : (long long)job.tiles_x * job.tiles_y;
+    atomicAdd(job.load_counter, (unsigned long long)(entries * tiles_per_list * job.ry));
+  }
 }
 
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream)

@@ -60,6 +60,7 @@ struct Symbolic
   std::vector<std::vector<int32_t>> levels;
   int64_t fronts_size = 0;
   int64_t nnz_factor = 0;
+  int64_t factor_flops = 0;      // sum over the fronts of sum_{j < ns} (m - j)^2
 };
 
 template <class T>
@@ -119,6 +120,11 @@ struct kh_spa
   // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
   int32_t shard_rank = 0, shard_world = 1;
   kh_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
+  // measurement: event pairs around the phases of an LM iteration (kMaxTimed iterations are timed, the rest only counted)
+  static constexpr int kMaxTimed = 64;
+  hipEvent_t ev_phase[kMaxTimed][4] = {};     // factor begin, factor end = backward begin, backward end, (spare)
+  hipEvent_t ev_lin[2 * kMaxTimed + 2][2] = {};
+  double last_symbolic_ms = 0.0;
 };
 
 namespace kh
@@ -368,6 +374,9 @@ static int build_symbolic(
     off += static_cast<int64_t>(sym.front_m[k]) * sym.front_m[k];
     sym.nnz_factor += static_cast<int64_t>(sym.front_ns[k]) * (sym.front_ns[k] + 1) / 2 +
       static_cast<int64_t>(sym.front_ns[k]) * (sym.front_m[k] - sym.front_ns[k]);
+    for (int32_t j = 0; j < sym.front_ns[k]; ++j) {
+      sym.factor_flops += static_cast<int64_t>(sym.front_m[k] - j) * (sym.front_m[k] - j);
+    }
     for (int32_t c : children[k]) {sym.level[k] = std::max(sym.level[k], sym.level[c] + 1);}
     max_level = std::max(max_level, sym.level[k]);
     if (sym.front_m[k] > 8000) {set_error("front too large for the triangular-solve kernels (m > 8000)"); return KH_ERR_SOLVER;}
@@ -408,6 +417,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   const int32_t N = static_cast<int32_t>(s->nodes.size());
   const int32_t E = static_cast<int32_t>(s->cons.size());
   has_work = false;
+  s->last_symbolic_ms = 0.0;
   const auto t_prep0 = std::chrono::steady_clock::now();
   // gauge: first inserted node is constant once it has parameter blocks (ceres_solver.cpp:228-241)
   std::vector<uint8_t> used(N, 0);
@@ -576,7 +586,10 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_fail.ensure(4);
     r2 |= s->d_upd.ensure(static_cast<size_t>(3) * sym.rows_ptr[sym.n_fronts] + 16);
     if (r2) {return KH_ERR_HIP;}
+    // the uploads above read pageable host vectors of this block: they must have landed before the block ends
+    KS_HIP(hipStreamSynchronize(st));
     s->topology_dirty = false;
+    s->last_symbolic_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count();
   }
   const int32_t nf = static_cast<int32_t>(s->node_of_free.size());
   if (nf == 0 || E == 0) {return KH_OK;}
@@ -650,6 +663,8 @@ int kh_spa_create(int32_t device, kh_spa ** out)
   KS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_scal), sizeof(double) * 32, hipHostMallocDefault));
   KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_fail), sizeof(int32_t) * 4, hipHostMallocDefault));
+  for (auto & row : s->ev_phase) {for (auto & e : row) {KS_HIP(hipEventCreate(&e));}}
+  for (auto & row : s->ev_lin) {for (auto & e : row) {KS_HIP(hipEventCreate(&e));}}
   *out = s;
   return KH_OK;
 }
@@ -669,6 +684,8 @@ void kh_spa_destroy(kh_spa * s)
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
   s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release();
+  for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
+  for (auto & row : s->ev_lin) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
   if (s->h_fail) {(void)hipHostFree(s->h_fail);}
   if (s->stream) {(void)hipStreamDestroy(s->stream);}
@@ -727,6 +744,10 @@ static int add_constraint_information(kh_spa * s, int32_t id_a, int32_t id_b, co
   std::copy(z, z + 3, c.z);
   std::copy(omega, omega + 6, c.omega);
   sqrt_information(c.omega, c.u);
+  if (!(c.u[0] > 0.0 && c.u[4] > 0.0 && c.u[8] > 0.0)) {     // also false for NaN: llt() of a matrix that is not positive definite
+    set_error("CeresSolver: constraint information matrix is not positive definite");
+    return KH_ERR_INVALID_ARG;
+  }
   s->con_of.insert({{id_a, id_b}, static_cast<int32_t>(s->cons.size())});
   s->cons.push_back(c);
   s->topology_dirty = true;
@@ -1004,6 +1025,10 @@ int kh_spa_remove_node(kh_spa * s, int32_t id)     // ceres_solver.cpp:395-427 (
   for (size_t k = 0; k < s->cons.size(); ++k) {if (s->cons[k].a == id || s->cons[k].b == id) {doomed.push_back(static_cast<int32_t>(k));}}
   erase_constraints(s, doomed);
   s->nodes.erase(s->nodes.begin() + it->second);
+  // ceres_solver.cpp:395-427 erases the node and its parameter blocks; first_node_ keeps pointing at the erased entry
+  // there (never dereferenced again once the blocks were set constant).  Here the gauge simply ends with the node: no
+  // later node takes it over, and the pose-graph files stop naming it.
+  if (s->has_first && id == s->first_id) {s->has_first = false;}
   s->index_of.clear();
   for (size_t k = 0; k < s->nodes.size(); ++k) {s->index_of[s->nodes[k].id] = static_cast<int32_t>(k);}
   s->topology_dirty = true;
@@ -1149,8 +1174,12 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   const int32_t e_lo = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * s->shard_rank / s->shard_world);
   const int32_t e_hi = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * (s->shard_rank + 1) / s->shard_world);
   const int64_t hg_count = static_cast<int64_t>(s->n_slots) * 9 + static_cast<int64_t>(dev.n_free) * 3;
+  int n_lin = 0, n_timed = 0;
   auto linearize = [&](const double * at) -> int {
+    const bool timed = n_lin < 2 * kh_spa::kMaxTimed + 2;
+    if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
     spa_launch_linearize(dev, at, scal + 0, e_lo, e_hi, st);
+    if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
     if (s->shard_world > 1) {
       if (!s->allreduce) {set_error("kh_spa: sharding enabled without an all-reduce callback"); return KH_ERR_INVALID_ARG;}
       if (s->allreduce(s->allreduce_user, dev.H, hg_count, st) != 0) {set_error("kh_spa: all-reduce callback failed"); return KH_ERR_SOLVER;}
@@ -1212,6 +1241,8 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
         std::fprintf(stderr, "[kh_spa] %s level %d (max m %d): %s\n", what, l, l >= 0 ? s->level_max_m[l] : 0, hipGetErrorString(e));
       }
     };
+    const bool timed = n_timed < kh_spa::kMaxTimed;
+    if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][0], st));}
     spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
     KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
     dbg("assemble", -1);
@@ -1222,6 +1253,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
       dbg("factor+forward", l);
     }
+    if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][1], st));}
     for (int l = n_levels - 1; l >= 0; --l) {
       spa_launch_backward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_rhs.p, st);
       dbg("backward", l);
@@ -1230,6 +1262,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     spa_launch_model(dev, s->d_scale.p, s->d_step.p, scal + 3, st);
     spa_launch_plus(dev, x, s->d_delta.p, cand, scal + 6, st);
     spa_launch_cost(dev, cand, scal + 8, st);
+    if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
     KS_HIP(hipGetLastError());
     rc = fetch(); if (rc) {return finish(rc);}
     solve_ms += ms_since(t1);
@@ -1305,6 +1338,19 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   sum.iterations = iteration;
   sum.final_cost = minimum_cost;
   sum.linearize_ms = lin_ms; sum.solve_ms = solve_ms;
+  sum.factor_flops = sym.factor_flops; sum.factorizations = iteration; sum.levels = n_levels;
+  sum.symbolic_ms = s->last_symbolic_ms;
+  {
+    // every recorded event has completed: each iteration ended with a stream synchronisation
+    float ms = 0.0f;
+    for (int k = 0; k < n_timed; ++k) {
+      if (hipEventElapsedTime(&ms, s->ev_phase[k][0], s->ev_phase[k][1]) == hipSuccess) {sum.factor_gpu_ms += ms;}
+      if (hipEventElapsedTime(&ms, s->ev_phase[k][1], s->ev_phase[k][2]) == hipSuccess) {sum.backward_gpu_ms += ms;}
+    }
+    for (int k = 0; k < n_lin; ++k) {
+      if (hipEventElapsedTime(&ms, s->ev_lin[k][0], s->ev_lin[k][1]) == hipSuccess) {sum.linearize_gpu_ms += ms;}
+    }
+  }
   if (!sum.usable) {
     sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     set_error("CeresSolver: Ceres could not find a usable solution to optimize.");

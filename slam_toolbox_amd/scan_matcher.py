@@ -248,6 +248,12 @@ class ScanMatcher:
                    "kh_matcher_profile")
         return {"score_ms": sm.value, "score_launches": sl.value, "raster_ms": rm.value, "raster_launches": rl.value}
 
+    def score_loads(self, reset=True):
+        """wave-level dword-load instructions (256 B each) K3 issued for the searches run while profiling was on"""
+        n = C.c_int64()
+        capi.check(capi.lib().kh_matcher_score_loads(self._h, C.byref(n), int(reset)), "kh_matcher_score_loads")
+        return n.value
+
     def close(self):
         if self._h:
             capi.lib().kh_matcher_destroy(self._h)

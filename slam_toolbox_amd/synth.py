@@ -215,3 +215,75 @@ def make_pose_graph(n_nodes: int, n_edges: int, seed: int = 12345, max_link_dist
         S = R @ np.diag([1e-3, 1e-3, 4e-4]) @ R.T
         cov[e] = (0.5 * (S + S.T)).reshape(9)
     return {"truth": truth, "init": odom.copy(), "edges": edges, "z": z, "cov": cov}
+
+
+def trajectory_laps(n_nodes: int, spacing: float = 0.5, seed: int = 12345, aisles=(0, 1), drift_xy=0.02,
+                    drift_theta_deg=0.5):
+    """Closed circuit driven lap after lap ("multiple passes", BASELINE config 5): up aisle aisles[0], across the
+    top, down aisle aisles[1], across the bottom, again.  Every lap after the first revisits the poses of the one
+    before within centimetres, so loop closure fires with the shipped loop_search_maximum_distance of 3 m
+    (config/mapper_params_offline.yaml:40).  Returns truth (n,3) and drifting odometry (n,3) like trajectory()."""
+    rng = np.random.default_rng(seed + 7)
+    xa, xb = 2.5 + 4.0 * aisles[0], 2.5 + 4.0 * aisles[1]
+    corners = [(xa, 3.0), (xa, 37.0), (xb, 37.0), (xb, 3.0)]
+    poses = []
+    cur = np.array(corners[0], dtype=np.float64)
+    tgt = 1
+    heading = math.atan2(corners[1][1] - corners[0][1], corners[1][0] - corners[0][0])
+    while len(poses) < n_nodes:
+        poses.append((cur[0], cur[1], heading))
+        d = np.array(corners[tgt]) - cur
+        dist = float(np.hypot(*d))
+        if dist < spacing:
+            cur = np.array(corners[tgt], dtype=np.float64)
+            tgt = (tgt + 1) % 4
+            d = np.array(corners[tgt]) - cur
+            heading = math.atan2(d[1], d[0])
+        else:
+            cur = cur + d / dist * spacing
+            heading = math.atan2(d[1], d[0])
+    truth = np.asarray(poses, dtype=np.float64)
+    odom = np.zeros_like(truth)
+    odom[0] = truth[0]
+    for j in range(1, n_nodes):
+        c, s = math.cos(truth[j - 1, 2]), math.sin(truth[j - 1, 2])
+        dxw, dyw = truth[j, 0] - truth[j - 1, 0], truth[j, 1] - truth[j - 1, 1]
+        dxl = c * dxw + s * dyw + rng.normal(0.0, drift_xy)
+        dyl = -s * dxw + c * dyw + rng.normal(0.0, drift_xy)
+        dth = truth[j, 2] - truth[j - 1, 2]
+        dth = (dth + math.pi) % (2 * math.pi) - math.pi + rng.normal(0.0, math.radians(drift_theta_deg))
+        c2, s2 = math.cos(odom[j - 1, 2]), math.sin(odom[j - 1, 2])
+        odom[j, 0] = odom[j - 1, 0] + c2 * dxl - s2 * dyl
+        odom[j, 1] = odom[j - 1, 1] + s2 * dxl + c2 * dyl
+        odom[j, 2] = (odom[j - 1, 2] + dth + math.pi) % (2 * math.pi) - math.pi
+    return truth, odom
+
+
+def loop_batch(n_pairs: int = 256, seed: int = 99, n_traj: int = 2000, world_seed: int = 12345):
+    """BASELINE config 2 ("loop-closure batch: 256 candidate pairs on a 2k-node graph"): n_pairs DISTINCT (query scan,
+    candidate chain of 10..40 consecutive scans) pairs on the 2000-node warehouse trajectory; the chain is centred on
+    the trajectory node nearest to the query among those at least 80 nodes away along the graph, the query pose is
+    perturbed by up to (0.15 m, 0.1 m, 0.06 rad).  Returns dict(ranges {node: (P,)}, truth (n,3),
+    pairs [(query node, query pose (3,), [chain nodes])]) -- raw data; callers wrap it into their scan type."""
+    world = make_world(world_seed)
+    truth, _ = trajectory(n_traj)
+    rng = np.random.default_rng(seed)
+    ranges = {}
+
+    def need(i):
+        if i not in ranges:
+            ranges[i] = make_scan(world, truth[i], rng)
+    pairs = []
+    for k in range(n_pairs):
+        q = 150 + (53 * k) % (n_traj - 300)
+        d = np.hypot(truth[:, 0] - truth[q, 0], truth[:, 1] - truth[q, 1])
+        d[max(0, q - 80): q + 80] = 1e9
+        j = int(np.argmin(d))
+        length = 10 + (7 * k) % 31
+        lo = max(0, min(n_traj - length, j - length // 2))
+        chain = list(range(lo, lo + length))
+        for i in chain + [q]:
+            need(i)
+        pose = truth[q] + np.array([0.15 * math.sin(k), -0.1 * math.cos(k), 0.03 * ((k % 5) - 2)])
+        pairs.append((q, pose, chain))
+    return {"ranges": ranges, "truth": truth, "pairs": pairs}

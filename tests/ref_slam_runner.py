@@ -1,6 +1,8 @@
 """Helper process of tests/test_dropin_mapper_gpu.py: runs the synthetic scan queue through the reference's own
 karto::Mapper in ONE of the oracle/_ref builds (each build carries its own copy of the karto singletons, so each
-run gets a process of its own).  usage: ref_slam_runner.py <lib.so> <n_scans> <loop_search_distance> <out_prefix>"""
+run gets a process of its own).  usage: ref_slam_runner.py <lib.so> <n_scans> <loop_search_distance> <out_prefix> [sweep|laps]
+sweep = one boustrophedon pass through the aisles (4 m apart: needs a 5 m loop search distance to close anything);
+laps = the same two aisles driven lap after lap (closes loops with the shipped 3.0 m, offline.yaml:40)."""
 import ctypes as C
 import os
 import sys
@@ -14,6 +16,7 @@ from slam_toolbox_amd import synth  # noqa: E402
 
 def main():
     lib_path, n_scans, loop_dist, prefix = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
+    kind = sys.argv[5] if len(sys.argv) > 5 else "sweep"
     lib = C.CDLL(lib_path)
     lib.ref_init_laser.restype = C.c_int
     lib.ref_init_laser.argtypes = [C.c_double] * 6
@@ -24,7 +27,7 @@ def main():
                                  laser.range_threshold)
     lib.ref_set_threads(min(32, os.cpu_count() or 1))
     world = synth.make_world(12345)
-    truth, odom = synth.trajectory(n_scans)
+    truth, odom = synth.trajectory_laps(n_scans) if kind == "laps" else synth.trajectory(n_scans)
     rng = np.random.default_rng(4)
     ranges = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], rng) for i in range(n_scans)]))
     assert ranges.shape[1] == n_beams

@@ -1,0 +1,184 @@
+"""GPU parity at the shapes BASELINE.json names (configs[1..3]) and straight against the committed golden vectors.
+
+  * golden fixtures (tests/golden/match_{K,S,L}.npz, corr_C2.npz -- made from the reference build by
+    tests/golden/make_golden.py) fed to the HIP path through the C ABI: no oracle in between;
+  * config[2]: the 256-pair loop-closure batch of bench.py::loop_leg through kh_matcher_match_batch -- every
+    response / mean / covariance of the preset-L coarse match, every gate decision, and every preset-S coarse+fine
+    result bit-equal to the C oracle; a 32-pair subset also against the reference itself (oracle/_ref);
+  * config[3]: the 10 000-node / 30 000-edge pose graph, Ceres-like and tight options, against oracle/spa.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN_NAMES, LASER, OFFLINE_PARAMS, PRESETS, Golden, bits, make_hip_matcher, make_oracle_matcher
+from slam_toolbox_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _row(r, mean, cov):
+    return np.concatenate([[r], np.asarray(mean).reshape(3), np.asarray(cov).reshape(9)])
+
+
+# ------------------------------------------------------------------ golden vectors -> HIP, directly
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_golden_vectors_on_the_hip_path(kartohip_lib, name):
+    g = Golden(name)
+    q, base = g.hip_scans()
+    hm = make_hip_matcher(g.preset)
+    gi = hm.grid_info()
+    geom = [gi[k] for k in ("width", "height", "width_step", "roi_x", "roi_y", "roi_w", "roi_h", "kernel_size", "data_size")]
+    assert geom == [int(v) for v in g.d["grid_geom"]]
+    assert np.array_equal(hm.kernel().reshape(-1), np.asarray(g.d["kernel"]).reshape(-1))
+    assert np.array_equal(bits(q.points), bits(g.d["query_points"]))
+    # MatchScan (penalise, refine) x 3 as the generator ran them on the reference
+    for row, (pen, refine) in zip(g.d["match_results"], [(True, True), (False, True), (False, False)]):
+        r, mean, cov = hm.MatchScan(q, base, pen, refine)
+        assert np.array_equal(bits(_row(r, mean, cov)), bits(row)), (name, pen, refine, _row(r, mean, cov), row)
+    assert np.array_equal(hm.GetCorrelationGrid(), g.dense_grid()), "rasterised grid differs from the reference's"
+    gi = hm.grid_info()
+    assert np.array_equal(bits([gi["offset_x"], gi["offset_y"], gi["scale"]]), bits(g.d["grid_offset"]))
+    # CorrelateScan on the grid left by AddScans, with the fixture's own arguments
+    hm.AddScans(q, base)
+    off, res, ang_off, ang_res, pen, fine = g.correlate_args()
+    r, mean, cov = hm.CorrelateScan(q, g.query_pose, off, res, ang_off, ang_res, pen, None, fine)
+    assert np.array_equal(bits(_row(r, mean, cov)), bits(g.d["correlate_result"]))
+    assert np.array_equal(hm.lookup_table(), g.d["lookup"]), "lookup table differs from the reference's"
+    # raw GetResponse values the generator sampled (Mapper.cpp:1172-1208): integer sums / (P * 100)
+    sums, _ = hm.volume(responses=False)
+    ny, nx, na = sums.shape
+    if nx % 2 == 1 and ny % 2 == 1:
+        # the generator sampled the search centre, (+1, 0) and (-1, +1) lattice steps from it: lattice poses when the
+        # lattice has a centre (presets L and C2)
+        cx, cy = nx // 2, ny // 2
+        denom = float(q.ranges.shape[0] * 100)
+        raw = np.asarray([sums[cy + dy, cx + dx, :] / denom for dx, dy in [(0, 0), (1, 0), (-1, 1)]])
+        assert np.array_equal(bits(raw), bits(g.d["raw_responses"])), "raw GetResponse values differ from the reference's"
+    hm.close()
+
+
+# ------------------------------------------------------------------ config[2]: 256-pair loop batch
+N_PAIRS = 256
+
+
+def _loop_batch_scans():
+    from oracle import karto
+    from slam_toolbox_amd.scan_matcher import LocalizedRangeScan
+    lb = synth.loop_batch(N_PAIRS)
+    hq, hb, oq, ob = [], [], [], []
+    cache_h, cache_o = {}, {}
+
+    def h_scan(i):
+        if i not in cache_h:
+            cache_h[i] = LocalizedRangeScan(lb["ranges"][i], lb["truth"][i], LASER.min_angle, LASER.ang_res)
+        return cache_h[i]
+
+    def o_scan(i):
+        if i not in cache_o:
+            cache_o[i] = karto.Scan(lb["ranges"][i], lb["truth"][i], LASER)
+        return cache_o[i]
+    for q, pose, chain in lb["pairs"]:
+        hq.append(LocalizedRangeScan(lb["ranges"][q], pose, LASER.min_angle, LASER.ang_res))
+        oq.append(karto.Scan(lb["ranges"][q], pose, LASER))
+        hb.append([h_scan(i) for i in chain])
+        ob.append([o_scan(i) for i in chain])
+    return lb, hq, hb, oq, ob
+
+
+def _gate(resp, cov):
+    # Mapper.cpp:1514-1517 with offline.yaml:43-45 (loop_match_minimum_response_coarse 0.35,
+    # loop_match_maximum_variance_coarse 3.0 -> squared by the setter: 9.0)
+    return bool(resp > 0.35 and cov[0, 0] < 9.0 and cov[1, 1] < 9.0)
+
+
+def test_config2_loop_batch_256_pairs(kartohip_lib):
+    from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher
+    lb, hq, hb, oq, ob = _loop_batch_scans()
+    mp = MapperParams(**OFFLINE_PARAMS)
+    mL = ScanMatcher.Create(mp, *PRESETS["L"]["create"], max_batch=N_PAIRS)
+    mS = ScanMatcher.Create(mp, *PRESETS["S"]["create"], max_batch=N_PAIRS)
+    # the batch exactly as bench.py::loop_leg issues it
+    resp, means, covs, st = mL.MatchScanBatch(hq, hb, False, False)
+    assert (st == 0).all()
+    ok = [i for i in range(N_PAIRS) if _gate(resp[i], covs[i])]
+    assert 0 < len(ok) < N_PAIRS, f"the workload should exercise both sides of the gate, {len(ok)} pass"
+    respS, meansS, covsS, stS = mS.MatchScanBatch([hq[i] for i in ok], [hb[i] for i in ok], False, True)
+    assert (stS == 0).all()
+    # oracle: one matcher per preset, pairs one after another (row-parallel inside like the reference's TBB loop)
+    threads = min(64, os.cpu_count() or 1)
+    oL = make_oracle_matcher("L", threads=threads)
+    oS = make_oracle_matcher("S", threads=threads)
+    n_gate_diff = 0
+    for i in range(N_PAIRS):
+        r, mean, cov = oL.match_scan(oq[i], ob[i], False, False)
+        assert np.array_equal(bits(_row(r, mean, cov)), bits(_row(resp[i], means[i], covs[i]))), \
+            f"pair {i}: preset L coarse match differs: {_row(r, mean, cov)} vs {_row(resp[i], means[i], covs[i])}"
+        n_gate_diff += int(_gate(r, cov) != (i in set(ok)))
+    assert n_gate_diff == 0
+    for k, i in enumerate(ok):
+        r, mean, cov = oS.match_scan(oq[i], ob[i], False, True)
+        assert np.array_equal(bits(_row(r, mean, cov)), bits(_row(respS[k], meansS[k], covsS[k]))), \
+            f"pair {i}: preset S coarse+fine match differs"
+    print(f"config[2]: {N_PAIRS} pairs, {len(ok)} pass the coarse gate; all L results, gate decisions and S results bit-equal")
+    # a 32-pair subset against the reference itself
+    from oracle import ref
+    if ref.available():
+        ref.init_laser(LASER)
+        ref.lib().ref_set_threads(threads)
+        rL = ref.RefMatcher(*PRESETS["L"]["create"], OFFLINE_PARAMS)
+        rS = ref.RefMatcher(*PRESETS["S"]["create"], OFFLINE_PARAMS)
+        sub = list(range(0, N_PAIRS, N_PAIRS // 32))
+        for i in sub:
+            q, pose, chain = lb["pairs"][i]
+            rq = ref.RefScan(lb["ranges"][q], pose)
+            rb = [ref.RefScan(lb["ranges"][c], lb["truth"][c]) for c in chain]
+            r, mean, cov = rL.match_scan(rq, rb, False, False)
+            assert np.array_equal(bits(_row(r, mean, cov)), bits(_row(resp[i], means[i], covs[i]))), f"pair {i} vs reference (L)"
+            if i in ok:
+                k = ok.index(i)
+                r, mean, cov = rS.match_scan(rq, rb, False, True)
+                assert np.array_equal(bits(_row(r, mean, cov)), bits(_row(respS[k], meansS[k], covsS[k]))), f"pair {i} vs reference (S)"
+    mL.close()
+    mS.close()
+
+
+# ------------------------------------------------------------------ config[3]: 10k nodes / 30k edges
+TIGHT = dict(max_num_iterations=200, function_tolerance=1e-15, gradient_tolerance=1e-14, parameter_tolerance=1e-14)
+
+
+def _diff(a, b):
+    d = np.asarray(a) - np.asarray(b)
+    d[:, 2] = (d[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    return float(np.abs(d).max())
+
+
+def test_config3_spa_10k_nodes_30k_edges(kartohip_lib):
+    from oracle import spa
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    g = synth.make_pose_graph(10000, 30000, seed=12345)          # bench.py::solver_leg's graph
+    ref_x, info = spa.solve(g["init"], g["edges"], g["z"], g["cov"])
+    sol = HipSpaSolver()
+    sol.load(g["init"], g["edges"], g["z"], g["cov"])
+    summ = sol.Compute()
+    assert summ["usable"] == 1
+    assert summ["iterations"] == info["iterations"], (summ, info["iterations"], info["message"])
+    d = _diff(sol.poses(), ref_x)
+    assert d < 1e-7, d                                            # north_star's bar is 1e-4 m / 1e-4 rad
+    assert abs(summ["final_cost"] - info["final_cost"]) <= 1e-9 * max(1.0, info["final_cost"])
+    print(f"config[3] Ceres-like: {summ['iterations']} iterations, max |pose - oracle| {d:.2e}, cost {summ['final_cost']:.9g}, "
+          f"nnz(L) {summ.get('nnz_factor')}")
+    # tight: the optimum itself
+    ref_t, info_t = spa.solve(g["init"], g["edges"], g["z"], g["cov"], spa.Options.tight())
+    sol.load(g["init"], g["edges"], g["z"], g["cov"])
+    sol.Configure(TIGHT)
+    summ = sol.Compute()
+    assert abs(summ["final_cost"] - info_t["final_cost"]) <= 1e-11 * info_t["final_cost"]
+    prob = spa.Problem(sol.poses(), g["edges"], g["z"], g["cov"])
+    _, grad, _ = prob.linearize(prob.x)
+    assert np.abs(grad).max() < 1e-5
+    dt = _diff(sol.poses(), ref_t)
+    assert dt < 1e-5, dt
+    print(f"config[3] tight: {summ['iterations']} iterations, max |pose - oracle| {dt:.2e}")
+    sol.close()

@@ -5,12 +5,16 @@ import csv
 import json
 import os
 
+import glob
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
+# the newest round's line (profiles/rN_bench_line.json) with the rocprof / PMC summaries of the same round
+ROUND = sorted(os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(PROF, "r*_bench_line.json")))[-1]
 
 
 def _line():
-    with open(os.path.join(PROF, "r1_bench_line.json")) as f:
+    with open(os.path.join(PROF, f"{ROUND}_bench_line.json")) as f:
         return json.load(f)
 
 
@@ -25,8 +29,12 @@ def test_line_has_the_contract_keys():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    # "l1" / "l2": the dominant kernel is a cache-resident gather (report the resource that binds)
+    assert r["bound"] in ("hbm", "mfma", "l1", "l2") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    if ROUND != "r1":
+        assert 0.0 < r["frac"] <= 1.0, "a roofline fraction is a fraction"
+        assert r["hbm_frac"] is None or 0.0 < r["hbm_frac"] <= 1.0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -38,14 +46,14 @@ def test_line_has_the_contract_keys():
 
 def test_kernel_time_agrees_with_the_rocprof_summary():
     d = _line()
-    with open(os.path.join(PROF, "r1_bench_kernel_stats.csv")) as f:
+    with open(os.path.join(PROF, f"{ROUND}_bench_kernel_stats.csv")) as f:
         rows = [r for r in csv.DictReader(f) if "k_score<1, 8, 1>" in r["Name"]]
     assert len(rows) == 1
     avg_ms = float(rows[0]["AverageNs"]) * 1e-6
     assert abs(avg_ms - d["roofline"]["avg_launch_ms"]) / avg_ms < 0.05
-    with open(os.path.join(PROF, "r1_k_score_pmc.json")) as f:
+    with open(os.path.join(PROF, f"{ROUND}_k_score_pmc.json")) as f:
         p = json.load(f)
-    assert abs(p["avg_ns"] * 1e-6 - avg_ms) < 1e-9
+    assert abs(p["avg_ns"] * 1e-6 - avg_ms) / avg_ms < 0.05
     # traffic = PMC HBM bytes per launch, scaled to the matches one launch of the run scored
     want = p["hbm_bytes_per_launch"] / p["matches_per_launch"] * d["roofline"]["matches_per_launch"]
     assert abs(d["roofline"]["traffic"] - want) / want < 0.02

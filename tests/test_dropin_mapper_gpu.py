@@ -48,8 +48,15 @@ def _replay(log_path):
     return out
 
 
+# (scans, loop_search_maximum_distance, trajectory): BASELINE config[0] = 500 scans with the shipped offline.yaml values
+# (loop_search_maximum_distance 3.0, config/mapper_params_offline.yaml:40) on the lap circuit; the single sweep
+# through three aisles needs 5 m to close a loop across the 4 m aisle pitch and is kept as a second topology
+QUEUES = [(500, 3.0, "laps"), (230, 5.0, "sweep")]
+
+
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libkarto_ref_slam.so not built (needs /root/reference)")
-def test_reference_mapper_runs_on_the_gpu_solver_plugin(kartohip_lib, tmp_path):
+@pytest.mark.parametrize("n_scans,loop_dist,kind", QUEUES)
+def test_reference_mapper_runs_on_the_gpu_solver_plugin(kartohip_lib, tmp_path, n_scans, loop_dist, kind):
     from oracle import spa
     lib = C.CDLL(LIB)
     lib.ref_init_laser.restype = C.c_int
@@ -60,17 +67,15 @@ def test_reference_mapper_runs_on_the_gpu_solver_plugin(kartohip_lib, tmp_path):
     n_beams = lib.ref_init_laser(laser.min_angle, laser.max_angle, laser.ang_res, laser.min_range, laser.max_range,
                                  laser.range_threshold)
     lib.ref_set_threads(min(32, os.cpu_count() or 1))
-    n_scans = 230                                    # three aisles of the synthetic warehouse: ~200 graph nodes
     world = synth.make_world(12345)
-    truth, odom = synth.trajectory(n_scans)
+    truth, odom = synth.trajectory_laps(n_scans) if kind == "laps" else synth.trajectory(n_scans)
     rng = np.random.default_rng(4)
     ranges = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], rng) for i in range(n_scans)]))
     assert ranges.shape[1] == n_beams
     odom = np.ascontiguousarray(odom)
     out = np.zeros((n_scans, 4))
     log = str(tmp_path / "solver_calls.log")
-    # loop_search_maximum_distance 5 m: the aisles are 4 m apart (offline.yaml has 3.0)
-    accepted = lib.ref_slam_run(n_scans, n_beams, ranges.ctypes.data, odom.ctypes.data, 5.0, log.encode(),
+    accepted = lib.ref_slam_run(n_scans, n_beams, ranges.ctypes.data, odom.ctypes.data, loop_dist, log.encode(),
                                 out.ctypes.data, n_scans)
     assert accepted > 150, accepted
     computes = _replay(log)
@@ -99,7 +104,8 @@ LIB_GPU_MATCHER = os.path.join(ROOT, "oracle", "_ref", "libkarto_ref_slam_gpu.so
 
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(LIB_GPU_MATCHER)),
                     reason="oracle/_ref/libkarto_ref_slam{,_gpu}.so not built (needs /root/reference)")
-def test_reference_mapper_runs_identically_on_the_gpu_matcher(kartohip_lib, tmp_path):
+@pytest.mark.parametrize("n_scans,loop_dist,kind", QUEUES)
+def test_reference_mapper_runs_identically_on_the_gpu_matcher(kartohip_lib, tmp_path, n_scans, loop_dist, kind):
     """Both halves of the drop-in at once.  The unmodified reference Mapper.cpp processes the same scan queue
     twice: with its own CPU ScanMatcher, and with every MatchScan call site (sequential match Mapper.cpp:2714,
     loop coarse / fine :1511-1535, near chains :1653, :1472) bound to karto_hip::HipScanMatcher
@@ -112,7 +118,7 @@ def test_reference_mapper_runs_identically_on_the_gpu_matcher(kartohip_lib, tmp_
     res = {}
     for key, lib in (("cpu", LIB), ("gpu", LIB_GPU_MATCHER)):
         prefix = str(tmp_path / key)
-        subprocess.run([sys.executable, runner, lib, "230", "5.0", prefix], check=True, timeout=900)
+        subprocess.run([sys.executable, runner, lib, str(n_scans), str(loop_dist), prefix, kind], check=True, timeout=900)
         with open(prefix + ".log") as f:
             # 'X <n> <ms>' carries the solve wall time: keep the count only
             lines = [" ".join(l.split()[:2]) if l.startswith("X ") else l.rstrip("\n") for l in f]
