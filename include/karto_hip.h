@@ -225,6 +225,12 @@ KH_API int kh_spa_create(int32_t device, kh_spa ** out);
  * factorisation and the LM control stay replicated.  world = 1 (default) disables sharding. */
 typedef int (*kh_allreduce_fn)(void * user, double * device_buf, int64_t count, void * hip_stream);
 KH_API int kh_spa_set_sharding(kh_spa * s, int32_t rank, int32_t world, kh_allreduce_fn allreduce, void * user);
+/* The same sharding with the collective INSIDE the library: ncclAllReduce(sum, f64) of RCCL on `comm` (see kh_comm_*
+ * below), rank and world taken from the communicator, which must live on the solver's device and outlive the solver's
+ * use of it.  comm = NULL returns to the unsharded solver.  With a one-rank communicator the (identity) all-reduce is
+ * still issued, so a single-GPU box exercises the whole path. */
+typedef struct kh_comm kh_comm;
+KH_API int kh_spa_set_comm(kh_spa * s, kh_comm * comm);
 KH_API void kh_spa_destroy(kh_spa * s);
 KH_API int kh_spa_set_options(kh_spa * s, const kh_spa_options * o);
 KH_API int kh_spa_reset(kh_spa * s);                                   /* ScanSolver::Reset  (ceres_solver.cpp:279-314) */
@@ -271,6 +277,24 @@ KH_API int kh_spa_get_constraint(kh_spa * s, int32_t index, int32_t * id_a, int3
 /* LinkInfo::Update (Mapper.h:174-188) for callers without karto objects */
 KH_API int kh_link_info(const double pose1[3], const double pose2[3], const double cov[9],
                         double pose_difference[3], double cov_out[9]);
+
+/* ---------------------------------------------------------------- multi-GPU communicator (RCCL over xGMI) */
+/* One process per GPU.  Rank 0 makes an id with kh_comm_unique_id and hands the 128 bytes to the other ranks by whatever
+ * the launcher offers (MPI, a torch.distributed store, a file); every rank then calls kh_comm_create with its device,
+ * its rank and the world size (collective: returns when all ranks have joined, like ncclCommInitRank).  librccl is
+ * bound at run time, so single-GPU users never load it; KH_ERR_NO_DEVICE when it cannot be found. */
+#define KH_COMM_ID_BYTES 128
+KH_API int kh_comm_unique_id(uint8_t id[KH_COMM_ID_BYTES]);
+KH_API int kh_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t id[KH_COMM_ID_BYTES], kh_comm ** out);
+KH_API void kh_comm_destroy(kh_comm * c);
+KH_API int32_t kh_comm_rank(const kh_comm * c);
+KH_API int32_t kh_comm_world(const kh_comm * c);
+/* in-place sum of `count` doubles at device_buf across the ranks, enqueued on hip_stream (a hipStream_t) */
+KH_API int kh_comm_allreduce_sum_f64(kh_comm * c, double * device_buf, int64_t count, void * hip_stream);
+/* every rank contributes count_per_rank doubles; device_recv (world * count_per_rank) holds them in rank order.  What the
+ * sharded candidate matcher uses to collect the 13 result doubles of every pair */
+KH_API int kh_comm_allgather_f64(kh_comm * c, const double * device_send, double * device_recv, int64_t count_per_rank,
+                                 void * hip_stream);
 
 /* ---------------------------------------------------------------- loop-candidate enumeration (next row f-1) */
 /* GPU-resident copy of what karto::MapperGraph's candidate search reads: the reference position

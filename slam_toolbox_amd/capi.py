@@ -78,6 +78,8 @@ SYMBOLS = [
     "kh_occupancy_compute_dimensions", "kh_occupancy_create", "kh_occupancy_destroy", "kh_occupancy_clear",
     "kh_occupancy_add_scans", "kh_occupancy_update", "kh_occupancy_read", "kh_occupancy_info",
     "kh_decay_params_default", "kh_lifelong_scores",
+    "kh_spa_set_comm", "kh_comm_unique_id", "kh_comm_create", "kh_comm_destroy", "kh_comm_rank", "kh_comm_world",
+    "kh_comm_allreduce_sum_f64", "kh_comm_allgather_f64",
 ]
 
 
@@ -167,6 +169,16 @@ def lib():
         L.kh_spa_get_node_at.argtypes = [vp, i32, C.POINTER(i32), dptr]
         L.kh_spa_get_nodes.argtypes = [vp, vp, vp]
         L.kh_spa_get_constraint.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), dptr, dptr]
+    if hasattr(L, "kh_comm_create"):
+        L.kh_comm_unique_id.argtypes = [bptr]
+        L.kh_comm_create.argtypes = [i32, i32, i32, bptr, C.POINTER(vp)]
+        L.kh_comm_destroy.argtypes = [vp]
+        L.kh_comm_destroy.restype = None
+        L.kh_comm_rank.argtypes = [vp]
+        L.kh_comm_world.argtypes = [vp]
+        L.kh_comm_allreduce_sum_f64.argtypes = [vp, vp, C.c_int64, vp]
+        L.kh_comm_allgather_f64.argtypes = [vp, vp, vp, C.c_int64, vp]
+        L.kh_spa_set_comm.argtypes = [vp, vp]
     if hasattr(L, "kh_graph_create"):
         L.kh_graph_create.argtypes = [i32, C.POINTER(vp)]
         L.kh_graph_destroy.argtypes = [vp]

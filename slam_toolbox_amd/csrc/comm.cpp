@@ -1,0 +1,150 @@
+// RCCL inside the library: the collectives of the multi-GPU paths (one process per GPU).
+//
+//   (B) SPA linearisation  every rank linearises its block of the edges; the partial normal equations H || g are summed
+//                          with ONE ncclAllReduce(sum, f64) per evaluation point; the
+//                          reference has a single ceres::Solve on one host (solvers/ceres_solver.cpp:243-244)
+//   (A) candidate matches  independent units, no data-path collective; the 13 result doubles per pair are collected with
+//                          one fixed-size ncclAllGather
+//
+// librccl is bound at run time (dlopen) the first time a communicator is asked for: a single-GPU user of libkartohip
+// never loads it, and a process that already holds an RCCL (e.g. the one PyTorch ships) shares it through the soname.
+// xGMI is point to point; the 5 MB of H || g ride one ring all-reduce -- no call pattern of the reference is
+// translated here, there is none.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/karto_hip.h"
+
+namespace kh
+{
+void set_error(const std::string & s);
+
+namespace
+{
+struct RcclApi
+{
+  void * handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char * (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+};
+
+RcclApi & rccl()
+{
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char * n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle) {break;}
+    }
+    if (!api.handle) {api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return;}
+    auto sym = [&](const char * name) {
+      void * p = dlsym(api.handle, name);
+      if (!p && api.why.empty()) {api.why = std::string("librccl lacks ") + name;}
+      return p;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  return api;
+}
+
+int rccl_fail(const char * what, ncclResult_t r)
+{
+  RcclApi & api = rccl();
+  set_error(std::string(what) + ": " + (api.GetErrorString ? api.GetErrorString(r) : "RCCL error"));
+  return KH_ERR_HIP;
+}
+}  // namespace
+}  // namespace kh
+
+struct kh_comm
+{
+  ncclComm_t comm = nullptr;
+  int32_t device = 0, rank = 0, world = 1;
+};
+
+extern "C" {
+
+int kh_comm_unique_id(uint8_t id[KH_COMM_ID_BYTES])
+{
+  if (!id) {return KH_ERR_INVALID_ARG;}
+  static_assert(KH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "kh_comm id size");
+  kh::RcclApi & api = kh::rccl();
+  if (!api.why.empty()) {kh::set_error(api.why); return KH_ERR_NO_DEVICE;}
+  ncclUniqueId u;
+  const ncclResult_t r = api.GetUniqueId(&u);
+  if (r != ncclSuccess) {return kh::rccl_fail("ncclGetUniqueId", r);}
+  std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return KH_OK;
+}
+
+int kh_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t id[KH_COMM_ID_BYTES], kh_comm ** out)
+{
+  if (!out || !id || world < 1 || rank < 0 || rank >= world) {return KH_ERR_INVALID_ARG;}
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    kh::set_error("no usable HIP device (libkartohip has no CPU fallback)");
+    return KH_ERR_NO_DEVICE;
+  }
+  kh::RcclApi & api = kh::rccl();
+  if (!api.why.empty()) {kh::set_error(api.why); return KH_ERR_NO_DEVICE;}
+  if (hipSetDevice(device) != hipSuccess) {kh::set_error("hipSetDevice failed"); return KH_ERR_HIP;}
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  kh_comm * c = new kh_comm();
+  c->device = device; c->rank = rank; c->world = world;
+  const ncclResult_t r = api.CommInitRank(&c->comm, world, u, rank);
+  if (r != ncclSuccess) {delete c; return kh::rccl_fail("ncclCommInitRank", r);}
+  *out = c;
+  return KH_OK;
+}
+
+void kh_comm_destroy(kh_comm * c)
+{
+  if (!c) {return;}
+  if (c->comm) {(void)hipSetDevice(c->device); (void)kh::rccl().CommDestroy(c->comm);}
+  delete c;
+}
+
+int32_t kh_comm_rank(const kh_comm * c) {return c ? c->rank : -1;}
+int32_t kh_comm_world(const kh_comm * c) {return c ? c->world : 0;}
+
+int kh_comm_allreduce_sum_f64(kh_comm * c, double * device_buf, int64_t count, void * hip_stream)
+{
+  if (!c || !device_buf || count < 0) {return KH_ERR_INVALID_ARG;}
+  if (count == 0) {return KH_OK;}
+  const ncclResult_t r = kh::rccl().AllReduce(device_buf, device_buf, static_cast<size_t>(count), ncclFloat64, ncclSum, c->comm,
+      static_cast<hipStream_t>(hip_stream));
+  if (r != ncclSuccess) {return kh::rccl_fail("ncclAllReduce", r);}
+  return KH_OK;
+}
+
+int kh_comm_allgather_f64(kh_comm * c, const double * device_send, double * device_recv, int64_t count_per_rank, void * hip_stream)
+{
+  if (!c || !device_send || !device_recv || count_per_rank < 0) {return KH_ERR_INVALID_ARG;}
+  if (count_per_rank == 0) {return KH_OK;}
+  const ncclResult_t r = kh::rccl().AllGather(device_send, device_recv, static_cast<size_t>(count_per_rank), ncclFloat64, c->comm,
+      static_cast<hipStream_t>(hip_stream));
+  if (r != ncclSuccess) {return kh::rccl_fail("ncclAllGather", r);}
+  return KH_OK;
+}
+
+}  // extern "C"

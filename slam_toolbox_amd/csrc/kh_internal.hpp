@@ -26,12 +26,22 @@ constexpr int32_t kLdsRows = 240;             // rows of one staged region
 constexpr int32_t kLdsRegionBytes = kLdsRows * kLdsPitch;   // 60 KB, double buffered
 
 // One rasterisation job (ScanMatcher::AddScans, Mapper.cpp:1032-1105) -- device visible.
+// The base scans' UNFILTERED point readings live once per distinct scan in the batch's arena; a job names its scans
+// (container order).  Job point p = beam p - scan_prefix[k] of base scan k, scan_prefix[k] <= p < scan_prefix[k + 1]:
+// the order FindValidPoints / AddScan visit them in.
+constexpr int32_t kMaxFootprint = 4;      // kernel cells equal to 100 besides the centre (sigma / res >= 9.9875: the 4-neighbours)
+constexpr uint32_t kHashEmpty = 0xffffffffu;
 struct RasterJob
 {
   uint8_t * grid;            // data_size + kGridPad bytes
-  const double * points;     // 2 * n_points world coordinates (FindValidPoints output, container order)
-  const uint8_t * active;    // n_points flags (0 = skipped by the "already occupied" filter, Mapper.cpp:1093-1096)
-  int32_t n_points;
+  const double * arena;      // x0, y0, x1, y1, ... of every distinct base scan of the batch
+  const int32_t * scan_pt;   // n_scans: first point of base scan k in the arena
+  const int32_t * scan_prefix;   // n_scans + 1: first job point of base scan k
+  int32_t n_scans;
+  double view_x, view_y;     // FindValidPoints' viewpoint = the query scan's sensor position (Mapper.cpp:572)
+  uint8_t * active;          // n_points: 1 = the point is stamped.  Written by k_find_valid (FindValidPoints, Mapper.cpp:1113-1164),
+                             // narrowed by the order-dependent "cell already occupied" rule (Mapper.cpp:1093-1096) when n_foot > 0
+  int32_t n_points;          // sum of the scans' reading counts
   int32_t ws, roi_x, roi_y, roi_w, roi_h;
   int32_t kernel_size;
   double off_x, off_y, scale;   // CoordinateConverter (Karto.h:4421-4436)
@@ -48,6 +58,15 @@ struct RasterJob
   int32_t * n_work;          // 1                   (written by the scan)
   int32_t * cell_xy;         // 2 * n_points        grid cell of every kept point, x < 0 = dropped
   int32_t * list;            // 4 * n_points        point indices, tile after tile
+  // order-dependent rule (only when the smear kernel holds 100 off-centre): per-job open-addressing table over the ROI
+  // cells the valid points fall into
+  int32_t n_foot;            // off-centre kernel cells equal to 100 (0 = the rule cannot fire between different cells)
+  int32_t foot_dx[kMaxFootprint], foot_dy[kMaxFootprint];
+  int32_t hcap;              // slots, a power of two >= 2 * n_points
+  uint32_t * hkeys;          // hcap: ROI cell index gy * roi_w + gx, kHashEmpty = free (reset by k_raster_clear)
+  int32_t * hvals;           // hcap: smallest job point index that falls into the cell (reset to INT32_MAX)
+  uint8_t * hstate;          // hcap: 0 undecided, 1 active, 2 inactive
+  int32_t * hnbr;            // hcap * kMaxFootprint: slot of the neighbouring cell's entry, -1 = none
 };
 constexpr int32_t kRasterTile = 64;
 
@@ -109,6 +128,10 @@ struct CorrJob
 //   [2+cap/2 .. )    probs: nx*ny doubles as bits, max over angle (Mapper.cpp:781-799)
 constexpr size_t kOutHeaderWords = 2 + kTieCap / 2;
 
+// one (job, base scan) pair of a batch: k_find_valid walks one scan per lane
+struct ValidItem {int32_t job, scan;};
+void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, void * stream);
+void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, void * stream);
 void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
 void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream);
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);

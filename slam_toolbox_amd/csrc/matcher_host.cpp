@@ -21,6 +21,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -135,8 +136,10 @@ struct Slot
   size_t cap_table = 0, cap_counts = 0;
   int32_t * d_chunks = nullptr, * d_chunk_counts = nullptr; size_t cap_chunks = 0, cap_chunk_counts = 0;
   int32_t * d_sums = nullptr; double * d_resp = nullptr; size_t cap_volume = 0, cap_resp = 0;
-  // raster staging
-  double * d_rpoints = nullptr; uint8_t * d_ractive = nullptr; size_t cap_rpoints = 0, cap_ractive = 0;
+  // raster scratch: per-point stamp flags (K0 FindValidPoints + the order-dependent rule), cell table of the order-dependent rule
+  uint8_t * d_ractive = nullptr; size_t cap_ractive = 0;
+  uint32_t * d_hkeys = nullptr; int32_t * d_hvals = nullptr; uint8_t * d_hstate = nullptr; int32_t * d_hnbr = nullptr;
+  size_t cap_hkeys = 0, cap_hvals = 0, cap_hstate = 0, cap_hnbr = 0;
   double * d_tile_best = nullptr; size_t cap_tile_best = 0;
   int32_t * d_rtiles = nullptr;      // tile_count | tile_cursor | n_work(+pad) | tile_start | work   (first three zeroed per raster)
   int32_t * d_rlists = nullptr; size_t cap_rlists = 0;   // cell_xy (2 np) | list (4 np)
@@ -163,8 +166,10 @@ struct kh_matcher
   uint8_t * d_kernel = nullptr;
   std::vector<Slot> slots;
   CorrBatch batch[2];
-  // raster staging (pinned) + jobs
-  double * h_rpoints = nullptr; uint8_t * h_ractive = nullptr; size_t cap_hrpoints = 0, cap_hractive = 0;
+  // raster staging: the distinct base scans' unfiltered points (pinned mirror + device arena), the jobs' scan lists and
+  // the (job, scan) work items of K0 (one int32 block), the jobs
+  double * h_arena = nullptr; double * d_arena = nullptr; size_t cap_harena = 0, cap_darena = 0;
+  int32_t * h_meta = nullptr; int32_t * d_meta = nullptr; size_t cap_hmeta = 0, cap_dmeta = 0;
   RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
   bool keep_responses = false;
   bool force_chunks = false;       // kh_matcher_set_debug bit 3: chunk every batch of >= 128 (tests)
@@ -187,40 +192,6 @@ namespace kh
 static int32_t half_kernel_size(double smear, double resolution)   // Mapper.h:1275-1280
 {
   return static_cast<int32_t>(round_half_away(2.0 * smear / resolution));
-}
-
-// FindValidPoints, Mapper.cpp:1113-1164: appends the kept points of `scan` to `out`
-// appends to out[2 * count ...]; the caller provides room for scan.n more points
-static void find_valid_points(const kh_scan & scan, const double viewpoint[2], double * out, size_t & count)
-{
-  const double min_square_distance = 0.1 * 0.1;
-  int32_t trailing = 0;
-  double first_x = 0.0, first_y = 0.0;
-  bool first_time = true;
-  const double * pts = scan.points_xy;
-  for (int32_t it = 0; it < scan.n; ++it) {
-    const double cx = pts[2 * it], cy = pts[2 * it + 1];
-    if (first_time && !std::isnan(cx) && !std::isnan(cy)) {
-      first_x = cx; first_y = cy; first_time = false;
-    }
-    const double dx = first_x - cx, dy = first_y - cy;
-    if (dx * dx + dy * dy > min_square_distance) {
-      const double a = viewpoint[1] - first_y;
-      const double b = first_x - viewpoint[0];
-      const double c = first_y * viewpoint[0] - first_x * viewpoint[1];
-      const double ss = cx * a + cy * b + c;
-      first_x = cx; first_y = cy;
-      if (ss < 0.0) {
-        trailing = it;
-      } else {
-        for (; trailing != it; ++trailing) {
-          out[2 * count] = pts[2 * trailing];
-          out[2 * count + 1] = pts[2 * trailing + 1];
-          ++count;
-        }
-      }
-    }
-  }
 }
 
 template <class T>
@@ -334,82 +305,83 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
 {
   if (reqs.empty()) {return KH_OK;}
   const double res = m->grid_resolution();
-  // 1. centre grids, FindValidPoints (host, sequential per scan), optional order-dependent filter.  Every job
-  // writes its points and flags straight into its region of the pinned staging buffers (regions sized by the
-  // upper bound "every reading of every base scan is valid"): no per-job vectors, no gather copy afterwards.
-  std::vector<size_t> region(reqs.size() + 1, 0), n_valid(reqs.size(), 0);
-  for (size_t r = 0; r < reqs.size(); ++r) {
-    size_t bound = 0;
+  const size_t n_jobs = reqs.size();
+  static const bool timing = std::getenv("KH_MATCH_TIMING") != nullptr;
+  const auto t_enter = std::chrono::steady_clock::now();
+  // 1. The base scans' unfiltered point readings go to the device ONCE per distinct scan of the batch (loop-closure
+  // chains overlap heavily: 256 pairs name ~6400 scans, ~1600 of them distinct); FindValidPoints, WorldToGrid and the
+  // order-dependent "cell already occupied" rule all run on the GPU (K0 / K1).  The host only lists who reads what.
+  struct Copy {const double * src; size_t dst; int32_t n;};
+  std::vector<Copy> copies;
+  std::unordered_map<const double *, int32_t> arena_of;        // points_xy -> first point in the arena
+  arena_of.reserve(256);
+  size_t arena_points = 0, meta_words = 0, n_items = 0;
+  std::vector<size_t> meta_at(n_jobs), scans_of(n_jobs, 0);
+  std::vector<int32_t> points_of(n_jobs, 0);
+  for (size_t r = 0; r < n_jobs; ++r) {
+    int64_t pts = 0;
     for (int32_t b = 0; b < reqs[r].n_base; ++b) {
-      if (reqs[r].base[b].points_xy != nullptr) {bound += static_cast<size_t>(std::max(0, reqs[r].base[b].n));}
+      const kh_scan & sc = reqs[r].base[b];
+      if (sc.points_xy == nullptr || sc.n <= 0) {continue;}      // NULL scan: skipped (Mapper.cpp:1039-1041)
+      ++scans_of[r]; pts += sc.n;
+      auto it = arena_of.find(sc.points_xy);
+      if (it == arena_of.end()) {
+        arena_of.emplace(sc.points_xy, static_cast<int32_t>(arena_points));
+        copies.push_back(Copy{sc.points_xy, arena_points, sc.n});
+        arena_points += static_cast<size_t>(sc.n);
+      }
     }
-    region[r + 1] = region[r] + bound;
+    if (pts > (1 << 30) || arena_points > (1u << 30)) {set_error("too many base scan points in one batch"); return KH_ERR_INVALID_ARG;}
+    points_of[r] = static_cast<int32_t>(pts);
+    meta_at[r] = meta_words;
+    meta_words += 2 * scans_of[r] + 1;
+    n_items += scans_of[r];
   }
-  int rc = ensure_pinned(m->h_rpoints, m->cap_hrpoints, std::max<size_t>(region.back(), 1) * 2, m->stream);
-  if (rc) {return rc;}
-  rc = ensure_pinned(m->h_ractive, m->cap_hractive, std::max<size_t>(region.back(), 1), m->stream);
-  if (rc) {return rc;}
-  size_t max_points = 0;
-  HostPool::instance().run(reqs.size(), [&](size_t r) {
+  const size_t items_at = meta_words;
+  meta_words += 2 * n_items;
+  int rc = ensure_pinned(m->h_arena, m->cap_harena, std::max<size_t>(arena_points, 1) * 2, m->stream); if (rc) {return rc;}
+  rc = ensure_device(m->d_arena, m->cap_darena, std::max<size_t>(arena_points, 1) * 2, m->stream); if (rc) {return rc;}
+  rc = ensure_pinned(m->h_meta, m->cap_hmeta, std::max<size_t>(meta_words, 1), m->stream); if (rc) {return rc;}
+  rc = ensure_device(m->d_meta, m->cap_dmeta, std::max<size_t>(meta_words, 1), m->stream); if (rc) {return rc;}
+  // the pinned mirrors are reused by every call: the previous call's uploads must have left them
+  KH_HIP(hipStreamSynchronize(m->stream));
+  HostPool::instance().run(copies.size(), [&](size_t i) {
+    std::memcpy(m->h_arena + 2 * copies[i].dst, copies[i].src, sizeof(double) * 2 * static_cast<size_t>(copies[i].n));
+  });
+  const int32_t n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
+  int32_t max_points = 0;
+  ValidItem * items = reinterpret_cast<ValidItem *>(m->h_meta + items_at);
+  size_t item = 0;
+  for (size_t r = 0; r < n_jobs; ++r) {
     Slot & s = m->slots[reqs[r].slot];
     const double * pose = reqs[r].query->sensor_pose;
     // MatchScan steps 1-4, Mapper.cpp:543-569
     s.off_x = pose[0] - (0.5 * (m->roi_w - 1) * res);
     s.off_y = pose[1] - (0.5 * (m->roi_h - 1) * res);
-    double * v = m->h_rpoints + 2 * region[r];
-    uint8_t * active = m->h_ractive + region[r];
-    size_t np = 0;
+    int32_t * scan_pt = m->h_meta + meta_at[r];
+    int32_t * scan_prefix = scan_pt + scans_of[r];
+    int32_t k = 0, run = 0;
     for (int32_t b = 0; b < reqs[r].n_base; ++b) {
-      if (reqs[r].base[b].points_xy == nullptr) {continue;}    // NULL scan: skipped (Mapper.cpp:1039-1041)
-      find_valid_points(reqs[r].base[b], pose, v, np);
+      const kh_scan & sc = reqs[r].base[b];
+      if (sc.points_xy == nullptr || sc.n <= 0) {continue;}
+      scan_pt[k] = arena_of.at(sc.points_xy);
+      scan_prefix[k] = run;
+      run += sc.n;
+      items[item].job = static_cast<int32_t>(r); items[item].scan = k; ++item;
+      ++k;
     }
-    n_valid[r] = np;
-    std::memset(active, 1, np);
-    if (m->footprint100.size() > 1) {
-      // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon
-      // as the smear kernel writes 100 off-centre: resolve the active set in reference order.
-      // Set of occupied cells = one bit per ROI cell, kept per worker thread; only the words a job touched are
-      // cleared after it (a few thousand), not the whole map.
-      thread_local std::vector<uint64_t> occupied;
-      thread_local std::vector<uint32_t> touched;
-      const size_t words = (static_cast<size_t>(m->roi_w) * m->roi_h + 63) / 64;
-      if (occupied.size() < words) {occupied.assign(words, 0);}
-      touched.clear();
-      const int32_t rw = m->roi_w, rh = m->roi_h;
-      for (size_t p = 0; p < np; ++p) {
-        const Cell c = world_to_grid(m->scale, s.off_x, s.off_y, v[2 * p], v[2 * p + 1]);
-        if (!(c.x >= 0 && c.x < rw) || !(c.y >= 0 && c.y < rh)) {active[p] = 0; continue;}
-        const size_t cell = static_cast<size_t>(c.y) * rw + c.x;
-        if ((occupied[cell >> 6] >> (cell & 63)) & 1ull) {active[p] = 0; continue;}
-        for (const Cell & f : m->footprint100) {
-          const int32_t fx = c.x + f.x, fy = c.y + f.y;
-          if (fx < 0 || fx >= rw || fy < 0 || fy >= rh) {continue;}     // no point can land there (ROI test above)
-          const size_t fc = static_cast<size_t>(fy) * rw + fx;
-          uint64_t & w = occupied[fc >> 6];
-          if (w == 0) {touched.push_back(static_cast<uint32_t>(fc >> 6));}
-          w |= 1ull << (fc & 63);
-        }
-      }
-      for (uint32_t w : touched) {occupied[w] = 0;}
-    }
-  });
-  for (size_t r = 0; r < reqs.size(); ++r) {max_points = std::max(max_points, n_valid[r]);}
-  // 2. upload
-  for (size_t r = 0; r < reqs.size(); ++r) {
-    Slot & s = m->slots[reqs[r].slot];
-    const size_t np = n_valid[r], cursor = region[r];
-    rc = ensure_device(s.d_rpoints, s.cap_rpoints, std::max<size_t>(np, 1) * 2, m->stream);
-    if (rc) {return rc;}
-    rc = ensure_device(s.d_ractive, s.cap_ractive, std::max<size_t>(np, 1), m->stream);
-    if (rc) {return rc;}
-    rc = ensure_device(s.d_rlists, s.cap_rlists, std::max<size_t>(np, 1) * 6, m->stream);
-    if (rc) {return rc;}
-    if (np) {
-      KH_HIP(hipMemcpyAsync(s.d_rpoints, m->h_rpoints + 2 * cursor, sizeof(double) * 2 * np, hipMemcpyHostToDevice, m->stream));
-      KH_HIP(hipMemcpyAsync(s.d_ractive, m->h_ractive + cursor, np, hipMemcpyHostToDevice, m->stream));
-    }
+    scan_prefix[k] = run;
+    const size_t np = static_cast<size_t>(points_of[r]);
+    max_points = std::max(max_points, points_of[r]);
+    rc = ensure_device(s.d_ractive, s.cap_ractive, std::max<size_t>(np, 1), m->stream); if (rc) {return rc;}
+    rc = ensure_device(s.d_rlists, s.cap_rlists, std::max<size_t>(np, 1) * 6, m->stream); if (rc) {return rc;}
     RasterJob & j = m->h_rjobs[r];
-    j.grid = s.d_grid; j.points = s.d_rpoints; j.active = s.d_ractive; j.n_points = static_cast<int32_t>(np);
+    std::memset(&j, 0, sizeof(j));
+    j.grid = s.d_grid; j.arena = m->d_arena;
+    j.scan_pt = m->d_meta + meta_at[r]; j.scan_prefix = m->d_meta + meta_at[r] + scans_of[r];
+    j.n_scans = static_cast<int32_t>(scans_of[r]);
+    j.view_x = pose[0]; j.view_y = pose[1];
+    j.active = s.d_ractive; j.n_points = points_of[r];
     j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
     j.kernel_size = m->kernel_size; j.off_x = s.off_x; j.off_y = s.off_y; j.scale = m->scale;
     j.blockmap = s.d_blockmap; j.bm_w = m->bm_w; j.bm_h = m->bm_h;
@@ -418,13 +390,45 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
     j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
     j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * std::max<size_t>(np, 1);
+    j.n_foot = n_foot;
+    if (n_foot > 0) {
+      // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon as the smear kernel
+      // writes 100 off-centre: cell table for k_cell_first / k_active_set
+      size_t cap = 1024;
+      while (cap < 2 * std::max<size_t>(np, 1)) {cap <<= 1;}
+      rc = ensure_device(s.d_hkeys, s.cap_hkeys, cap, m->stream); if (rc) {return rc;}
+      rc = ensure_device(s.d_hvals, s.cap_hvals, cap, m->stream); if (rc) {return rc;}
+      rc = ensure_device(s.d_hstate, s.cap_hstate, cap, m->stream); if (rc) {return rc;}
+      rc = ensure_device(s.d_hnbr, s.cap_hnbr, cap * kMaxFootprint, m->stream); if (rc) {return rc;}
+      j.hcap = static_cast<int32_t>(cap);
+      j.hkeys = s.d_hkeys; j.hvals = s.d_hvals; j.hstate = s.d_hstate; j.hnbr = s.d_hnbr;
+      int32_t f = 0;
+      for (const Cell & c : m->footprint100) {
+        if (c.x == 0 && c.y == 0) {continue;}
+        j.foot_dx[f] = c.x; j.foot_dy[f] = c.y; ++f;
+      }
+    }
   }
-  KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * reqs.size(), hipMemcpyHostToDevice, m->stream));
+  // 2. upload: arena, scan lists + work items, jobs
+  if (arena_points) {
+    KH_HIP(hipMemcpyAsync(m->d_arena, m->h_arena, sizeof(double) * 2 * arena_points, hipMemcpyHostToDevice, m->stream));
+  }
+  if (meta_words) {
+    KH_HIP(hipMemcpyAsync(m->d_meta, m->h_meta, sizeof(int32_t) * meta_words, hipMemcpyHostToDevice, m->stream));
+  }
+  KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * n_jobs, hipMemcpyHostToDevice, m->stream));
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[2], m->stream));}
-  // 3. Grid::Clear (Karto.h:4612-4615) + stamps
-  launch_raster_clear(m->d_rjobs, static_cast<int32_t>(reqs.size()), m->stream);
-  launch_raster(m->d_rjobs, static_cast<int32_t>(reqs.size()), static_cast<int32_t>(max_points), m->rt_w * m->rt_h, m->d_kernel, m->stream);
+  // 3. Grid::Clear (Karto.h:4612-4615), FindValidPoints, stamps
+  launch_raster_clear(m->d_rjobs, static_cast<int32_t>(n_jobs), m->stream);
+  launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), m->stream);
+  if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->stream);}
+  launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->stream);
   KH_HIP(hipGetLastError());
+  if (timing) {
+    std::fprintf(stderr, "[kh raster] host %.3f ms: %zu jobs, %zu (job, scan) items, %zu distinct scans, %.1f MB of points uploaded\n",
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(), n_jobs, n_items, copies.size(),
+      arena_points * 16.0 / 1e6);
+  }
   if (m->profiling) {
     KH_HIP(hipEventRecord(m->ev[3], m->stream));
     KH_HIP(hipEventSynchronize(m->ev[3]));
@@ -1024,9 +1028,10 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     });
   }
   lap(3, t_final);
-  if (timing && ++t_calls % 64 == 0) {
+  static const long period = (std::getenv("KH_MATCH_TIMING") && std::atoi(std::getenv("KH_MATCH_TIMING")) > 1) ? 1 : 64;
+  if (timing && ++t_calls % period == 0) {
     std::fprintf(stderr, "[kh match] per call: prepare %.3f ms, enqueue %.3f ms, wait %.3f ms, finalize %.3f ms (n = %zu, stage %zu B/job)\n",
-      t_acc[0] / 64, t_acc[1] / 64, t_acc[2] / 64, t_acc[3] / 64, n, stride);
+      t_acc[0] / period, t_acc[1] / period, t_acc[2] / period, t_acc[3] / period, n, stride);
     t_acc[0] = t_acc[1] = t_acc[2] = t_acc[3] = 0;
   }
   for (size_t i = 0; i < n; ++i) {if (final_rc[i] != KH_OK) {return final_rc[i];}}
@@ -1178,6 +1183,10 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
     }
   }
 
+  if (m->footprint100.size() > static_cast<size_t>(kMaxFootprint) + 1) {
+    // cannot happen inside [0.5, 10] x resolution: the diagonal neighbours reach 99 at sigma / res = 10
+    delete m; set_error("smear kernel with more than five cells of 100"); return KH_ERR_INVALID_ARG;
+  }
   auto fail = [&](hipError_t e, const char * what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
     kh_matcher_destroy(m);
@@ -1229,7 +1238,8 @@ void kh_matcher_destroy(kh_matcher * m)
   for (auto & s : m->slots) {
     hipFree(s.d_grid_alloc); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_tile_best); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_tcounts); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
-    hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_rpoints); hipFree(s.d_ractive);
+    hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_ractive);
+    hipFree(s.d_hkeys); hipFree(s.d_hvals); hipFree(s.d_hstate); hipFree(s.d_hnbr);
   }
   hipFree(m->d_kernel); hipFree(m->d_rjobs); hipFree(m->d_load_counter);
   for (auto & b : m->batch) {
@@ -1243,8 +1253,9 @@ void kh_matcher_destroy(kh_matcher * m)
     if (b.kdone) {hipEventDestroy(b.kdone);}
     if (b.side) {hipStreamSynchronize(b.side); hipStreamDestroy(b.side);}
   }
-  if (m->h_rpoints) {hipHostFree(m->h_rpoints);}
-  if (m->h_ractive) {hipHostFree(m->h_ractive);}
+  hipFree(m->d_arena); hipFree(m->d_meta);
+  if (m->h_arena) {hipHostFree(m->h_arena);}
+  if (m->h_meta) {hipHostFree(m->h_meta);}
   if (m->h_rjobs) {hipHostFree(m->h_rjobs);}
   for (auto & ev : m->ev) {if (ev) {hipEventDestroy(ev);}}
   if (m->stream) {hipStreamDestroy(m->stream);}

@@ -39,10 +39,69 @@ __device__ __forceinline__ int32_t d_to_int(double v)
   return (int32_t)v;
 }
 // ---------------------------------------------------------------------------------------------
+// K0: FindValidPoints (Mapper.cpp:1113-1164) for every (job, base scan) pair of a batch, one LANE per pair.  The walk is
+// a sequential state machine (each 0.1 m trigger depends on the previous trigger's point), but the pairs are independent:
+// a loop-closure batch holds thousands of them.  Plain IEEE double operations in the reference's order (no libm), so the
+// kept set is bit-identical to the host's.  Pass 1 leaves a code per reading (0 no trigger, 1 trigger on the wrong side,
+// 2 trigger on the viewpoint's side); the run [previous trigger, this trigger) is emitted iff the trigger's side test
+// passes, and the tail after the last trigger never is, so pass 2 walks back and hands every reading the verdict of the
+// first trigger behind it.
+__global__ __launch_bounds__(64) void k_find_valid(const RasterJob * jobs, const ValidItem * items, int n_items)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items) {return;}
+  const RasterJob & job = jobs[items[t].job];
+  const int k = items[t].scan;
+  const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
+  const double2 * pts = reinterpret_cast<const double2 *>(job.arena) + job.scan_pt[k];
+  uint8_t * out = job.active + job.scan_prefix[k];
+  const double vx = job.view_x, vy = job.view_y;
+  const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
+  double fx = 0.0, fy = 0.0;
+  bool first_time = true;
+  constexpr int kAhead = 4;                              // readings fetched before the state machine consumes them
+  for (int base = 0; base < n; base += kAhead) {
+    double2 c[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {c[u] = pts[min(base + u, n - 1)];}
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int it = base + u;
+      if (it >= n) {break;}
+      const double cx = c[u].x, cy = c[u].y;
+      if (first_time && !isnan(cx) && !isnan(cy)) {fx = cx; fy = cy; first_time = false;}
+      const double dx = fx - cx, dy = fy - cy;
+      uint8_t code = 0;
+      if (dx * dx + dy * dy > min_square_distance) {
+        const double a = vy - fy;
+        const double b = fx - vx;
+        const double cc = fy * vx - fx * vy;
+        const double ss = cx * a + cy * b + cc;
+        fx = cx; fy = cy;
+        code = ss < 0.0 ? 1 : 2;
+      }
+      out[it] = code;
+    }
+  }
+  uint8_t carry = 0;
+  for (int it = n - 1; it >= 0; --it) {
+    const uint8_t code = out[it];
+    out[it] = carry;
+    if (code) {carry = code == 2 ? 1 : 0;}
+  }
+}
+
+void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, void * stream)
+{
+  if (n_items <= 0) {return;}
+  hipLaunchKernelGGL(k_find_valid, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_jobs, d_items, (int)n_items);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1: AddScans after Grid::Clear.  The stamp is a commutative byte-wise max (SmearPoint, Mapper.h:1152-1183),
 // so the parallel result equals the sequential one; the only order-dependent part of AddScan ("skip if the
-// cell is already 100", Mapper.cpp:1093-1096) is resolved on the host into `active` when the kernel holds
-// 100 off-centre (see matcher_host.cpp).  Tiled so that the read-modify-write traffic stays in LDS:
+// cell is already 100", Mapper.cpp:1093-1096) matters when the kernel holds 100 off-centre and is resolved by
+// k_cell_first / k_active_set below.  Tiled so that the read-modify-write traffic stays in LDS:
 //
 //   k_raster_bin    thread per point: WorldToGrid, ROI test, duplicate test (a second point in the same cell
 //                   stamps the same footprint: dropped), occupancy-block marks, incidence counts of the
@@ -70,12 +129,141 @@ __global__ __launch_bounds__(256) void k_raster_clear(const RasterJob * jobs)
   // tile_count | tile_cursor | n_work (+3 pad) are contiguous
   const size_t nz = 2 * (size_t)job.tiles_w * job.tiles_h + 4;
   for (size_t i = tid; i < nz; i += nth) {job.tile_count[i] = 0;}
+  if (job.n_foot > 0) {
+    for (size_t i = tid; i < (size_t)job.hcap; i += nth) {job.hkeys[i] = kHashEmpty; job.hvals[i] = INT32_MAX;}
+  }
 }
 
 void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream)
 {
   if (n_jobs <= 0) {return;}
   hipLaunchKernelGGL(k_raster_clear, dim3(512, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs);
+}
+
+// job point p -> its world coordinates: base scan by bisection of the prefix (<= a few dozen scans), then the arena
+__device__ __forceinline__ double2 job_point(const RasterJob & job, int p)
+{
+  int lo = 0, hi = job.n_scans;                 // scan_prefix[lo] <= p < scan_prefix[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (job.scan_prefix[mid] <= p) {lo = mid;} else {hi = mid;}
+  }
+  return reinterpret_cast<const double2 *>(job.arena)[job.scan_pt[lo] + (p - job.scan_prefix[lo])];
+}
+// CoordinateConverter::WorldToGrid (Karto.h:4421-4436) + the ROI test of AddScan (Mapper.cpp:1083-1088)
+__device__ __forceinline__ bool roi_cell(const RasterJob & job, double2 w, int32_t & gx, int32_t & gy)
+{
+  const double gxd = (w.x - job.off_x) * job.scale;
+  const double gyd = (w.y - job.off_y) * job.scale;
+  gx = d_to_int(d_round(gxd)); gy = d_to_int(d_round(gyd));
+  return (gx >= 0 && gx < job.roi_w) && (gy >= 0 && gy < job.roi_h);
+}
+__device__ __forceinline__ uint32_t hash_slot(const RasterJob & job, uint32_t key)
+{
+  return (key * 0x9E3779B1u) & (uint32_t)(job.hcap - 1);
+}
+// slot of `key` in the job's cell table, -1 when the cell holds no valid point
+__device__ __forceinline__ int32_t hash_find(const RasterJob & job, uint32_t key)
+{
+  uint32_t h = hash_slot(job, key);
+  for (;;) {
+    const uint32_t k = job.hkeys[h];
+    if (k == key) {return (int32_t)h;}
+    if (k == kHashEmpty) {return -1;}
+    h = (h + 1) & (uint32_t)(job.hcap - 1);
+  }
+}
+
+// Order-dependent rule, step 1 (only when the kernel holds 100 off-centre): the FIRST valid point of every ROI cell.
+// Whatever happens to it, the cell is 100 once it has been visited (either it was 100 already, or the point sets it),
+// so every later point of the cell is skipped; only the firsts are candidates for stamping.
+__global__ __launch_bounds__(256) void k_cell_first(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= job.n_points || job.n_foot <= 0 || !job.active[p]) {return;}
+  int32_t gx, gy;
+  if (!roi_cell(job, job_point(job, p), gx, gy)) {return;}
+  const uint32_t key = (uint32_t)gy * (uint32_t)job.roi_w + (uint32_t)gx;
+  uint32_t h = hash_slot(job, key);
+  for (;;) {
+    const uint32_t old = atomicCAS(&job.hkeys[h], kHashEmpty, key);
+    if (old == kHashEmpty || old == key) {atomicMin(&job.hvals[h], p); return;}
+    h = (h + 1) & (uint32_t)(job.hcap - 1);
+  }
+}
+
+// Step 2: the reference visits the points in order and stamps one iff its cell is not 100 yet, i.e. iff no EARLIER
+// STAMPED point has the cell in its 100-footprint (the centre and, for sigma / res >= 9.9875, the four neighbours).
+// Over the candidates that is the greedy independent set in visiting order.  A candidate's fate is fixed as soon as all
+// its earlier neighbours are decided, decisions never change, so sweeping until nothing is undecided reaches the
+// sequential answer whatever the sweep order (measured: 7-20 sweeps on the loop-closure chains).  One workgroup per job.
+__global__ __launch_bounds__(1024) void k_active_set(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.x];
+  if (job.n_foot <= 0) {return;}
+  __shared__ int32_t s_n;
+  __shared__ int32_t s_left;
+  if (threadIdx.x == 0) {s_n = 0;}
+  __syncthreads();
+  int32_t * cand = job.list;                     // free until k_raster_fill: 4 * n_points ints >= the candidates
+  for (int h = threadIdx.x; h < job.hcap; h += blockDim.x) {
+    const uint32_t key = job.hkeys[h];
+    if (key == kHashEmpty) {continue;}
+    const int32_t gy = (int32_t)(key / (uint32_t)job.roi_w), gx = (int32_t)(key - (uint32_t)gy * (uint32_t)job.roi_w);
+    for (int f = 0; f < kMaxFootprint; ++f) {
+      int32_t ns = -1;
+      if (f < job.n_foot) {
+        const int32_t nx = gx + job.foot_dx[f], ny = gy + job.foot_dy[f];
+        if (nx >= 0 && nx < job.roi_w && ny >= 0 && ny < job.roi_h) {
+          ns = hash_find(job, (uint32_t)ny * (uint32_t)job.roi_w + (uint32_t)nx);
+        }
+      }
+      job.hnbr[(size_t)h * kMaxFootprint + f] = ns;
+    }
+    job.hstate[h] = 0;
+    cand[atomicAdd(&s_n, 1)] = h;
+  }
+  __syncthreads();
+  const int n = s_n;
+  for (int sweep = 0; sweep < 1 << 20; ++sweep) {
+    if (threadIdx.x == 0) {s_left = 0;}
+    __syncthreads();
+    int left = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int h = cand[i];
+      if (__hip_atomic_load(&job.hstate[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {continue;}
+      const int32_t mine = job.hvals[h];
+      bool blocked = false, waiting = false;
+      for (int f = 0; f < job.n_foot; ++f) {
+        const int32_t ns = job.hnbr[(size_t)h * kMaxFootprint + f];
+        if (ns < 0 || job.hvals[ns] > mine) {continue;}           // no valid point there, or it comes later
+        const uint8_t st = __hip_atomic_load(&job.hstate[ns], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        blocked = blocked || st == 1;
+        waiting = waiting || st == 0;
+      }
+      if (blocked) {
+        __hip_atomic_store(&job.hstate[h], (uint8_t)2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (!waiting) {
+        __hip_atomic_store(&job.hstate[h], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        ++left;
+      }
+    }
+    if (left) {atomicAdd(&s_left, left);}
+    __syncthreads();
+    const int total = s_left;
+    __syncthreads();
+    if (total == 0) {break;}
+  }
+}
+
+void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, void * stream)
+{
+  if (n_jobs <= 0 || max_points <= 0) {return;}
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_cell_first, dim3((max_points + 255) / 256, n_jobs), dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_active_set, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
 }
 
 __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
@@ -86,13 +274,13 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
   int32_t * cell = job.cell_xy + 2 * (size_t)p;
   cell[0] = -1; cell[1] = -1;
   if (!job.active[p]) {return;}
-  // CoordinateConverter::WorldToGrid, Karto.h:4421-4436
-  const double wx = job.points[2 * p], wy = job.points[2 * p + 1];
-  const double gxd = (wx - job.off_x) * job.scale;
-  const double gyd = (wy - job.off_y) * job.scale;
-  const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
-  // Mapper.cpp:1083-1088
-  if (!(gx >= 0 && gx < job.roi_w) || !(gy >= 0 && gy < job.roi_h)) {return;}
+  int32_t gx, gy;
+  if (!roi_cell(job, job_point(job, p), gx, gy)) {return;}
+  if (job.n_foot > 0) {
+    // the order-dependent rule: only the first valid point of a cell can stamp, and only if k_active_set let it
+    const int32_t h = hash_find(job, (uint32_t)gy * (uint32_t)job.roi_w + (uint32_t)gx);
+    if (h < 0 || job.hvals[h] != p || job.hstate[h] != 1) {return;}
+  }
   const int cx = gx + job.roi_x, cy = gy + job.roi_y;      // CorrelationGrid::GridIndex, Mapper.h:1122-1128
   // the kernel's centre is 100 = its maximum: write it now and use the byte as the "cell already stamped" flag
   const int32_t index = cx + cy * job.ws;
@@ -169,16 +357,22 @@ __global__ __launch_bounds__(256) void k_raster_fill(const RasterJob * jobs)
   }
 }
 
-__global__ __launch_bounds__(1024) void k_raster_tile(const RasterJob * jobs, const uint8_t * __restrict__ kernel)
+// Workgroups of 256 threads, up to 8 per CU (18 KB of LDS each): a tile is a few dependent memory latencies long (work
+// list -> point list -> cells), so what a CU needs is many tiles in flight, not many threads on one tile (1024-thread
+// workgroups, 2 per CU, took 14 us per tile of the loop-closure batch).  The tile's points are staged in LDS in
+// chunks of 256 with coalesced loads before any wave starts stamping.
+__global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, const uint8_t * __restrict__ kernel)
 {
   const RasterJob & job = jobs[blockIdx.y];
   __shared__ uint32_t s_tile[kRasterTile * kRasterTile];
   __shared__ uint8_t s_kernel[41 * 41 + 3];
+  __shared__ int32_t s_px[256], s_py[256];
   const int k = job.kernel_size, hk = k / 2, kk = k * k;
-  for (int i = threadIdx.x; i < kk; i += blockDim.x) {s_kernel[i] = kernel[i];}
   const int n_work = job.n_work[0];
+  if ((int)blockIdx.x >= n_work) {return;}
+  for (int i = threadIdx.x; i < kk; i += blockDim.x) {s_kernel[i] = kernel[i];}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int kWaves = 16;
+  constexpr int kWaves = 4;
   // lanes over footprint cells.  kk >= 64: one point per wave pass, lane walks cells lane, lane + 64, ... with
   // (row, col) advanced incrementally.  kk < 64: 64 / kk points per wave pass, one cell per lane.
   const int ppw = kk >= 64 ? 1 : 64 / kk;                 // points per wave pass
@@ -192,22 +386,30 @@ __global__ __launch_bounds__(1024) void k_raster_tile(const RasterJob * jobs, co
     const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
     const int ox = tx * kRasterTile, oy = ty * kRasterTile;       // grid cell of the tile's corner
     for (int i = threadIdx.x; i < kRasterTile * kRasterTile; i += blockDim.x) {s_tile[i] = 0;}
-    __syncthreads();
     const int begin = job.tile_start[t], count = job.tile_count[t];
-    for (int q = wave * ppw + sub; q < count; q += kWaves * ppw) {
-      if (!lane_on) {break;}
-      const int p = job.list[begin + q];
-      // footprint corner relative to the tile
-      const int fx = job.cell_xy[2 * (size_t)p] - hk - ox, fy = job.cell_xy[2 * (size_t)p + 1] - hk - oy;
-      int row = row0, col = col0;
-      for (int c = c0; c < kk; c += 64) {
-        const int x = fx + col, y = fy + row;
-        if ((unsigned)x < (unsigned)kRasterTile && (unsigned)y < (unsigned)kRasterTile) {
-          const uint32_t v = s_kernel[c];
-          if (v != 0) {atomicMax(&s_tile[y * kRasterTile + x], v);}
+    for (int chunk = 0; chunk < count; chunk += 256) {
+      const int here = min(256, count - chunk);
+      __syncthreads();                                            // s_tile zeroed / previous chunk consumed
+      if ((int)threadIdx.x < here) {
+        const int p = job.list[begin + chunk + threadIdx.x];
+        // footprint corner relative to the tile
+        s_px[threadIdx.x] = job.cell_xy[2 * (size_t)p] - hk - ox;
+        s_py[threadIdx.x] = job.cell_xy[2 * (size_t)p + 1] - hk - oy;
+      }
+      __syncthreads();
+      for (int q = wave * ppw + sub; q < here; q += kWaves * ppw) {
+        if (!lane_on) {break;}
+        const int fx = s_px[q], fy = s_py[q];
+        int row = row0, col = col0;
+        for (int c = c0; c < kk; c += 64) {
+          const int x = fx + col, y = fy + row;
+          if ((unsigned)x < (unsigned)kRasterTile && (unsigned)y < (unsigned)kRasterTile) {
+            const uint32_t v = s_kernel[c];
+            if (v != 0) {atomicMax(&s_tile[y * kRasterTile + x], v);}
+          }
+          col += dcol; row += drow;
+          if (col >= k) {col -= k; ++row;}
         }
-        col += dcol; row += drow;
-        if (col >= k) {col -= k; ++row;}
       }
     }
     __syncthreads();
@@ -235,7 +437,7 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
   hipLaunchKernelGGL(k_raster_fill, per_point, dim3(256), 0, s, d_jobs);
   // non-empty tiles <= 4 per point and <= all tiles; a workgroup walks several when there are more
   int blocks = std::min(std::min(max_tiles, 4 * max_points), 2048);
-  hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(1024), 0, s, d_jobs, d_kernel);
+  hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -120,6 +120,7 @@ struct kh_spa
   // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
   int32_t shard_rank = 0, shard_world = 1;
   kh_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
+  kh_comm * comm = nullptr;                    // RCCL communicator of kh_spa_set_comm: the all-reduce happens in the library
   // measurement: event pairs around the phases of an LM iteration (kMaxTimed iterations are timed, the rest only counted)
   static constexpr int kMaxTimed = 64;
   hipEvent_t ev_phase[kMaxTimed][4] = {};     // factor begin, factor end = backward begin, backward end, (spare)
@@ -702,7 +703,16 @@ int kh_spa_set_options(kh_spa * s, const kh_spa_options * o)
 int kh_spa_set_sharding(kh_spa * s, int32_t rank, int32_t world, kh_allreduce_fn fn, void * user)
 {
   if (!s || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) {return KH_ERR_INVALID_ARG;}
-  s->shard_rank = rank; s->shard_world = world; s->allreduce = fn; s->allreduce_user = user;
+  s->shard_rank = rank; s->shard_world = world; s->allreduce = fn; s->allreduce_user = user; s->comm = nullptr;
+  return KH_OK;
+}
+
+int kh_spa_set_comm(kh_spa * s, kh_comm * comm)
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  s->comm = comm; s->allreduce = nullptr; s->allreduce_user = nullptr;
+  s->shard_rank = comm ? kh_comm_rank(comm) : 0;
+  s->shard_world = comm ? kh_comm_world(comm) : 1;
   return KH_OK;
 }
 
@@ -1180,8 +1190,12 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
     spa_launch_linearize(dev, at, scal + 0, e_lo, e_hi, st);
     if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
-    if (s->shard_world > 1) {
-      if (!s->allreduce) {set_error("kh_spa: sharding enabled without an all-reduce callback"); return KH_ERR_INVALID_ARG;}
+    if (s->comm) {
+      // H || g of this rank's edge block -> sums over all ranks, on the solver's stream (RCCL over xGMI)
+      const int arc = kh_comm_allreduce_sum_f64(s->comm, dev.H, hg_count, st);
+      if (arc) {return arc;}
+    } else if (s->shard_world > 1) {
+      if (!s->allreduce) {set_error("kh_spa: sharding enabled without a communicator or an all-reduce callback"); return KH_ERR_INVALID_ARG;}
       if (s->allreduce(s->allreduce_user, dev.H, hg_count, st) != 0) {set_error("kh_spa: all-reduce callback failed"); return KH_ERR_SOLVER;}
     }
     return KH_OK;
