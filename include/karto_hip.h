@@ -296,6 +296,13 @@ KH_API int kh_comm_allreduce_sum_f64(kh_comm * c, double * device_buf, int64_t c
 KH_API int kh_comm_allgather_f64(kh_comm * c, const double * device_send, double * device_recv, int64_t count_per_rank,
                                  void * hip_stream);
 
+/* device buffers for callers without a HIP binding of their own (the two collectives take device pointers); download
+ * waits for all work queued on the device first */
+KH_API int kh_device_malloc(int32_t device, int64_t bytes, void ** out);
+KH_API void kh_device_free(void * p);
+KH_API int kh_device_upload(void * device_dst, const void * host_src, int64_t bytes);
+KH_API int kh_device_download(void * host_dst, const void * device_src, int64_t bytes);
+
 /* ---------------------------------------------------------------- loop-candidate enumeration (next row f-1) */
 /* GPU-resident copy of what karto::MapperGraph's candidate search reads: the reference position
  * GetReferencePose(use_scan_barycenter) of every scan of a sensor in scan-list order (NULL scans left out:

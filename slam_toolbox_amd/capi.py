@@ -80,6 +80,7 @@ SYMBOLS = [
     "kh_decay_params_default", "kh_lifelong_scores",
     "kh_spa_set_comm", "kh_comm_unique_id", "kh_comm_create", "kh_comm_destroy", "kh_comm_rank", "kh_comm_world",
     "kh_comm_allreduce_sum_f64", "kh_comm_allgather_f64",
+    "kh_device_malloc", "kh_device_free", "kh_device_upload", "kh_device_download",
 ]
 
 
@@ -179,6 +180,11 @@ def lib():
         L.kh_comm_allreduce_sum_f64.argtypes = [vp, vp, C.c_int64, vp]
         L.kh_comm_allgather_f64.argtypes = [vp, vp, vp, C.c_int64, vp]
         L.kh_spa_set_comm.argtypes = [vp, vp]
+        L.kh_device_malloc.argtypes = [i32, C.c_int64, C.POINTER(vp)]
+        L.kh_device_free.argtypes = [vp]
+        L.kh_device_free.restype = None
+        L.kh_device_upload.argtypes = [vp, vp, C.c_int64]
+        L.kh_device_download.argtypes = [vp, vp, C.c_int64]
     if hasattr(L, "kh_graph_create"):
         L.kh_graph_create.argtypes = [i32, C.POINTER(vp)]
         L.kh_graph_destroy.argtypes = [vp]

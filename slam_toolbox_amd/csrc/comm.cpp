@@ -46,7 +46,7 @@ RcclApi & rccl()
   std::call_once(once, [] {
     const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char * n : names) {
-      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (api.handle) {break;}
     }
     if (!api.handle) {api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return;}
@@ -144,6 +144,39 @@ int kh_comm_allgather_f64(kh_comm * c, const double * device_send, double * devi
   const ncclResult_t r = kh::rccl().AllGather(device_send, device_recv, static_cast<size_t>(count_per_rank), ncclFloat64, c->comm,
       static_cast<hipStream_t>(hip_stream));
   if (r != ncclSuccess) {return kh::rccl_fail("ncclAllGather", r);}
+  return KH_OK;
+}
+
+// ---- device buffers for callers that have no HIP binding of their own (the collectives above take device pointers) ----
+int kh_device_malloc(int32_t device, int64_t bytes, void ** out)
+{
+  if (!out || bytes < 0) {return KH_ERR_INVALID_ARG;}
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    kh::set_error("no usable HIP device (libkartohip has no CPU fallback)");
+    return KH_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(out, static_cast<size_t>(bytes > 0 ? bytes : 1)) != hipSuccess) {
+    kh::set_error("hipMalloc failed"); return KH_ERR_HIP;
+  }
+  return KH_OK;
+}
+
+void kh_device_free(void * p) {if (p) {(void)hipFree(p);}}
+
+int kh_device_upload(void * device_dst, const void * host_src, int64_t bytes)
+{
+  if (!device_dst || !host_src || bytes < 0) {return KH_ERR_INVALID_ARG;}
+  if (hipMemcpy(device_dst, host_src, static_cast<size_t>(bytes), hipMemcpyHostToDevice) != hipSuccess) {kh::set_error("hipMemcpy H2D failed"); return KH_ERR_HIP;}
+  return KH_OK;
+}
+
+int kh_device_download(void * host_dst, const void * device_src, int64_t bytes)
+{
+  if (!host_dst || !device_src || bytes < 0) {return KH_ERR_INVALID_ARG;}
+  if (hipDeviceSynchronize() != hipSuccess ||
+    hipMemcpy(host_dst, device_src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost) != hipSuccess) {kh::set_error("hipMemcpy D2H failed"); return KH_ERR_HIP;}
   return KH_OK;
 }
 

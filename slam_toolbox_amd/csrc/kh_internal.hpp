@@ -131,7 +131,7 @@ constexpr size_t kOutHeaderWords = 2 + kTieCap / 2;
 // one (job, base scan) pair of a batch: k_find_valid walks one scan per lane
 struct ValidItem {int32_t job, scan;};
 void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, void * stream);
-void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, void * stream);
+void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_cap, void * stream);
 void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
 void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream);
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
@@ -141,6 +141,7 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
 inline int32_t score_tile_poses(int32_t sx) {return sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;}
 void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream);
+void launch_gather_small(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t * d_out, int32_t small_stride, void * stream);
 void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, int32_t tile_pairs, void * stream);
 
 }  // namespace kh

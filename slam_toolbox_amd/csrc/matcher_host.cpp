@@ -117,7 +117,8 @@ struct CorrBatch
   uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_stage = 0, cap_dstage = 0;
   unsigned long long * h_out = nullptr; size_t cap_hout = 0;   // words
   unsigned long long * d_out = nullptr; size_t cap_dout = 0;   // words: one contiguous result block per job
-  int32_t * h_sums = nullptr; size_t cap_hsums = 0;
+  int32_t * h_sums = nullptr; size_t cap_hsums = 0;          // fine passes: packed small volumes (pinned) ...
+  int32_t * d_small = nullptr; size_t cap_dsmall = 0; size_t small_stride = 0;   // ... and their device staging
   hipEvent_t ev[2] = {nullptr, nullptr};      // around the scoring kernel (profiling)
   hipEvent_t done = nullptr;                  // everything of the sub-batch, downloads included
   hipEvent_t up = nullptr, kdone = nullptr;   // chunked batches: tables + lists ready (side stream) / scoring finished (main stream)
@@ -349,7 +350,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     std::memcpy(m->h_arena + 2 * copies[i].dst, copies[i].src, sizeof(double) * 2 * static_cast<size_t>(copies[i].n));
   });
   const int32_t n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
-  int32_t max_points = 0;
+  int32_t max_points = 0, max_cap = 0;
   ValidItem * items = reinterpret_cast<ValidItem *>(m->h_meta + items_at);
   size_t item = 0;
   for (size_t r = 0; r < n_jobs; ++r) {
@@ -401,6 +402,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
       rc = ensure_device(s.d_hstate, s.cap_hstate, cap, m->stream); if (rc) {return rc;}
       rc = ensure_device(s.d_hnbr, s.cap_hnbr, cap * kMaxFootprint, m->stream); if (rc) {return rc;}
       j.hcap = static_cast<int32_t>(cap);
+      max_cap = std::max(max_cap, j.hcap);
       j.hkeys = s.d_hkeys; j.hvals = s.d_hvals; j.hstate = s.d_hstate; j.hnbr = s.d_hnbr;
       int32_t f = 0;
       for (const Cell & c : m->footprint100) {
@@ -421,7 +423,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   // 3. Grid::Clear (Karto.h:4612-4615), FindValidPoints, stamps
   launch_raster_clear(m->d_rjobs, static_cast<int32_t>(n_jobs), m->stream);
   launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), m->stream);
-  if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->stream);}
+  if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
   launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->stream);
   KH_HIP(hipGetLastError());
   if (timing) {
@@ -845,19 +847,17 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   // volumes are tiny (3 x 3 x nA), so they ride along with the batch download instead of costing one
   // synchronous copy per match afterwards
   {
-    size_t n_small = 0;
+    size_t max_small = 0;
     for (size_t i = 0; i < n; ++i) {
-      if (ctx[i].fine && static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na <= kSmallVolume) {++n_small;}
+      const size_t vol = static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na;
+      if (ctx[i].fine && vol <= kSmallVolume) {max_small = std::max(max_small, vol);}
     }
-    if (n_small) {
-      rc = ensure_pinned(B.h_sums, B.cap_hsums, kSmallVolume * n, m->stream);
-      if (rc) {return rc;}
-      for (size_t i = 0; i < n; ++i) {
-        const size_t vol = static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na;
-        if (ctx[i].fine && vol <= kSmallVolume) {
-          KH_HIP(hipMemcpyAsync(B.h_sums + kSmallVolume * i, m->slots[ctx[i].slot].d_sums, vol * 4, hipMemcpyDeviceToHost, cs));
-        }
-      }
+    B.small_stride = align_up(max_small, 32);
+    if (max_small) {
+      rc = ensure_pinned(B.h_sums, B.cap_hsums, B.small_stride * n, m->stream); if (rc) {return rc;}
+      rc = ensure_device(B.d_small, B.cap_dsmall, B.small_stride * n, m->stream); if (rc) {return rc;}
+      launch_gather_small(B.d_stage, stride, static_cast<int32_t>(n), B.d_small, static_cast<int32_t>(B.small_stride), cs);
+      KH_HIP(hipMemcpyAsync(B.h_sums, B.d_small, B.small_stride * n * 4, hipMemcpyDeviceToHost, cs));
     }
   }
   KH_HIP(hipEventRecord(B.done, cs));
@@ -969,7 +969,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       }
       std::vector<int32_t> col(c.na, 0);
       if (fx >= 0 && plane * c.na <= kSmallVolume) {
-        const int32_t * vol = B.h_sums + kSmallVolume * i;
+        const int32_t * vol = B.h_sums + B.small_stride * i;
         for (int32_t a = 0; a < c.na; ++a) {col[a] = vol[static_cast<size_t>(a) * plane + static_cast<size_t>(fy) * c.nx + fx];}
       } else if (fx >= 0) {
         KH_HIP(hipMemcpy2D(col.data(), 4, s.d_sums + static_cast<size_t>(fy) * c.nx + fx, plane * 4, 4, c.na, hipMemcpyDeviceToHost));
@@ -1243,7 +1243,7 @@ void kh_matcher_destroy(kh_matcher * m)
   }
   hipFree(m->d_kernel); hipFree(m->d_rjobs); hipFree(m->d_load_counter);
   for (auto & b : m->batch) {
-    hipFree(b.d_stage); hipFree(b.d_out);
+    hipFree(b.d_stage); hipFree(b.d_out); hipFree(b.d_small);
     if (b.h_stage) {hipHostFree(b.h_stage);}
     if (b.h_out) {hipHostFree(b.h_out);}
     if (b.h_sums) {hipHostFree(b.h_sums);}

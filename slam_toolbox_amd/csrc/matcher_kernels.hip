@@ -46,20 +46,25 @@ __device__ __forceinline__ int32_t d_to_int(double v)
 // 2 trigger on the viewpoint's side); the run [previous trigger, this trigger) is emitted iff the trigger's side test
 // passes, and the tail after the last trigger never is, so pass 2 walks back and hands every reading the verdict of the
 // first trigger behind it.
+constexpr int kCodeWords = 128;      // 2-bit codes of up to 2048 readings per lane live in LDS between the two passes
 __global__ __launch_bounds__(64) void k_find_valid(const RasterJob * jobs, const ValidItem * items, int n_items)
 {
+  __shared__ uint32_t s_codes[kCodeWords][64];           // [word][lane]: conflict-free
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_items) {return;}
+  const int lane = threadIdx.x;
   const RasterJob & job = jobs[items[t].job];
   const int k = items[t].scan;
   const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
   const double2 * pts = reinterpret_cast<const double2 *>(job.arena) + job.scan_pt[k];
   uint8_t * out = job.active + job.scan_prefix[k];
+  const bool in_lds = n <= 16 * kCodeWords;              // longer scans keep their codes in `out` (global) instead
   const double vx = job.view_x, vy = job.view_y;
   const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
   double fx = 0.0, fy = 0.0;
   bool first_time = true;
-  constexpr int kAhead = 4;                              // readings fetched before the state machine consumes them
+  constexpr int kAhead = 8;                              // readings fetched before the state machine consumes them
+  uint32_t word = 0;
   for (int base = 0; base < n; base += kAhead) {
     double2 c[kAhead];
 #pragma unroll
@@ -71,23 +76,44 @@ __global__ __launch_bounds__(64) void k_find_valid(const RasterJob * jobs, const
       const double cx = c[u].x, cy = c[u].y;
       if (first_time && !isnan(cx) && !isnan(cy)) {fx = cx; fy = cy; first_time = false;}
       const double dx = fx - cx, dy = fy - cy;
-      uint8_t code = 0;
+      uint32_t code = 0;
       if (dx * dx + dy * dy > min_square_distance) {
         const double a = vy - fy;
         const double b = fx - vx;
         const double cc = fy * vx - fx * vy;
         const double ss = cx * a + cy * b + cc;
         fx = cx; fy = cy;
-        code = ss < 0.0 ? 1 : 2;
+        code = ss < 0.0 ? 1u : 2u;
       }
-      out[it] = code;
+      if (in_lds) {
+        word |= code << (2 * (it & 15));
+        if ((it & 15) == 15) {s_codes[it >> 4][lane] = word; word = 0;}
+      } else {
+        out[it] = (uint8_t)code;
+      }
     }
   }
-  uint8_t carry = 0;
-  for (int it = n - 1; it >= 0; --it) {
-    const uint8_t code = out[it];
-    out[it] = carry;
-    if (code) {carry = code == 2 ? 1 : 0;}
+  if (in_lds && (n & 15) != 0) {s_codes[n >> 4][lane] = word;}
+  uint32_t carry = 0;
+  if (in_lds) {
+    for (int w = (n - 1) >> 4; w >= 0; --w) {
+      const uint32_t codes = s_codes[w][lane];
+#pragma unroll
+      for (int b = 15; b >= 0; --b) {
+        const int it = 16 * w + b;
+        if (it < n) {
+          const uint32_t code = (codes >> (2 * b)) & 3u;
+          out[it] = (uint8_t)carry;
+          if (code) {carry = code == 2u ? 1u : 0u;}
+        }
+      }
+    }
+  } else {
+    for (int it = n - 1; it >= 0; --it) {
+      const uint8_t code = out[it];
+      out[it] = (uint8_t)carry;
+      if (code) {carry = code == 2 ? 1u : 0u;}
+    }
   }
 }
 
@@ -193,7 +219,46 @@ __global__ __launch_bounds__(256) void k_cell_first(const RasterJob * jobs)
   }
 }
 
-// Step 2: the reference visits the points in order and stamps one iff its cell is not 100 yet, i.e. iff no EARLIER
+// Step 2a (grid-wide, thread per table slot): every occupied slot becomes a candidate; the slots of the cells in its
+// 100-footprint that hold an EARLIER first point are looked up once (later ones can never block it: -1).
+__global__ __launch_bounds__(256) void k_cell_links(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (job.n_foot <= 0) {return;}
+  const uint32_t key = h < job.hcap ? job.hkeys[h] : kHashEmpty;
+  const bool mine_is_candidate = key != kHashEmpty;
+  if (mine_is_candidate) {
+    const int32_t mine = job.hvals[h];
+    const int32_t gy = (int32_t)(key / (uint32_t)job.roi_w), gx = (int32_t)(key - (uint32_t)gy * (uint32_t)job.roi_w);
+    int32_t nbr[kMaxFootprint];
+#pragma unroll
+    for (int f = 0; f < kMaxFootprint; ++f) {
+      int32_t ns = -1;
+      if (f < job.n_foot) {
+        const int32_t nx = gx + job.foot_dx[f], ny = gy + job.foot_dy[f];
+        if (nx >= 0 && nx < job.roi_w && ny >= 0 && ny < job.roi_h) {
+          ns = hash_find(job, (uint32_t)ny * (uint32_t)job.roi_w + (uint32_t)nx);
+          if (ns >= 0 && job.hvals[ns] > mine) {ns = -1;}
+        }
+      }
+      nbr[f] = ns;
+    }
+    *reinterpret_cast<int4 *>(job.hnbr + (size_t)h * kMaxFootprint) = make_int4(nbr[0], nbr[1], nbr[2], nbr[3]);
+    job.hstate[h] = 0;
+  }
+  // candidate list (`list` is free until k_raster_fill, n_work[1] was zeroed by the clear): one atomic per wave
+  const unsigned long long mask = __ballot(mine_is_candidate);
+  if (mask == 0) {return;}
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(mask);
+  int base = 0;
+  if (lane == leader) {base = atomicAdd(&job.n_work[1], __builtin_popcountll(mask));}
+  base = __shfl(base, leader);
+  if (mine_is_candidate) {job.list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = h;}
+}
+
+// Step 2b: the reference visits the points in order and stamps one iff its cell is not 100 yet, i.e. iff no EARLIER
 // STAMPED point has the cell in its 100-footprint (the centre and, for sigma / res >= 9.9875, the four neighbours).
 // Over the candidates that is the greedy independent set in visiting order.  A candidate's fate is fixed as soon as all
 // its earlier neighbours are decided, decisions never change, so sweeping until nothing is undecided reaches the
@@ -202,30 +267,9 @@ __global__ __launch_bounds__(1024) void k_active_set(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.x];
   if (job.n_foot <= 0) {return;}
-  __shared__ int32_t s_n;
   __shared__ int32_t s_left;
-  if (threadIdx.x == 0) {s_n = 0;}
-  __syncthreads();
-  int32_t * cand = job.list;                     // free until k_raster_fill: 4 * n_points ints >= the candidates
-  for (int h = threadIdx.x; h < job.hcap; h += blockDim.x) {
-    const uint32_t key = job.hkeys[h];
-    if (key == kHashEmpty) {continue;}
-    const int32_t gy = (int32_t)(key / (uint32_t)job.roi_w), gx = (int32_t)(key - (uint32_t)gy * (uint32_t)job.roi_w);
-    for (int f = 0; f < kMaxFootprint; ++f) {
-      int32_t ns = -1;
-      if (f < job.n_foot) {
-        const int32_t nx = gx + job.foot_dx[f], ny = gy + job.foot_dy[f];
-        if (nx >= 0 && nx < job.roi_w && ny >= 0 && ny < job.roi_h) {
-          ns = hash_find(job, (uint32_t)ny * (uint32_t)job.roi_w + (uint32_t)nx);
-        }
-      }
-      job.hnbr[(size_t)h * kMaxFootprint + f] = ns;
-    }
-    job.hstate[h] = 0;
-    cand[atomicAdd(&s_n, 1)] = h;
-  }
-  __syncthreads();
-  const int n = s_n;
+  const int32_t * cand = job.list;
+  const int n = job.n_work[1];
   for (int sweep = 0; sweep < 1 << 20; ++sweep) {
     if (threadIdx.x == 0) {s_left = 0;}
     __syncthreads();
@@ -233,12 +277,13 @@ __global__ __launch_bounds__(1024) void k_active_set(const RasterJob * jobs)
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const int h = cand[i];
       if (__hip_atomic_load(&job.hstate[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {continue;}
-      const int32_t mine = job.hvals[h];
+      const int4 nb4 = *reinterpret_cast<const int4 *>(job.hnbr + (size_t)h * kMaxFootprint);
+      const int32_t nb[kMaxFootprint] = {nb4.x, nb4.y, nb4.z, nb4.w};
       bool blocked = false, waiting = false;
-      for (int f = 0; f < job.n_foot; ++f) {
-        const int32_t ns = job.hnbr[(size_t)h * kMaxFootprint + f];
-        if (ns < 0 || job.hvals[ns] > mine) {continue;}           // no valid point there, or it comes later
-        const uint8_t st = __hip_atomic_load(&job.hstate[ns], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int f = 0; f < kMaxFootprint; ++f) {
+        if (nb[f] < 0) {continue;}
+        const uint8_t st = __hip_atomic_load(&job.hstate[nb[f]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         blocked = blocked || st == 1;
         waiting = waiting || st == 0;
       }
@@ -258,11 +303,12 @@ __global__ __launch_bounds__(1024) void k_active_set(const RasterJob * jobs)
   }
 }
 
-void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, void * stream)
+void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_cap, void * stream)
 {
   if (n_jobs <= 0 || max_points <= 0) {return;}
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_cell_first, dim3((max_points + 255) / 256, n_jobs), dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_cell_links, dim3((max_cap + 255) / 256, n_jobs), dim3(256), 0, s, d_jobs);
   hipLaunchKernelGGL(k_active_set, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
 }
 
@@ -875,6 +921,24 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
     const int yi = rem / job.nx, xi = rem - yi * job.nx;
     consider(a, yi, xi);
   }
+}
+
+// Fine passes: the host needs the raw sums of every angle at the best cell (ComputeAngularCovariance, Mapper.cpp:977-1025).
+// Their volumes are tiny (3 x 3 x nA), so all of a batch's are packed into one buffer for ONE download instead of a
+// copy per match (224 copies cost the stream 1.4 ms and the host 2.3 ms of enqueueing in the loop-closure batch).
+__global__ __launch_bounds__(256) void k_gather_small(const uint8_t * jobs, size_t stride, int32_t * out, int small_stride)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.x * stride);
+  const int vol = job.nx * job.ny * job.na;
+  if (job.coarse || vol > small_stride) {return;}
+  int32_t * dst = out + (size_t)blockIdx.x * small_stride;
+  for (int i = threadIdx.x; i < vol; i += blockDim.x) {dst[i] = job.sums[i];}
+}
+
+void launch_gather_small(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t * d_out, int32_t small_stride, void * stream)
+{
+  if (n_jobs <= 0 || small_stride <= 0) {return;}
+  hipLaunchKernelGGL(k_gather_small, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs, stride, d_out, (int)small_stride);
 }
 
 void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, int32_t tile_pairs, void * stream)

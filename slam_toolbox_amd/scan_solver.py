@@ -121,6 +121,13 @@ class HipSpaSolver:
         return {i: p for i, p in self._all_nodes()}
 
     # ---- multi-GPU -------------------------------------------------------------------------------
+    def SetCommunicator(self, comm):
+        """Edge-block sharded linearisation with the all-reduce INSIDE the library: ncclAllReduce of RCCL on `comm`
+        (slam_toolbox_amd.comm.Communicator; None switches sharding off).  The communicator must outlive the solver's
+        use of it."""
+        self._comm = comm
+        capi.check(capi.lib().kh_spa_set_comm(self._h, comm.handle if comm is not None else None), "kh_spa_set_comm")
+
     def enable_sharding(self, rank: int, world: int, group=None):
         """Edge-block sharded linearisation: every rank holds the same graph,
         rank r linearises edges [E r / world, E (r+1) / world) and the partial normal equations (H followed
