@@ -324,6 +324,14 @@ KH_API int kh_graph_find_loop_candidates(kh_graph * g, int32_t n_queries, const 
                                          double loop_search_maximum_distance, int32_t loop_match_minimum_chain_size,
                                          int32_t * chain_begin, int32_t * chains, int32_t cap_chains,
                                          int32_t * n_chains);
+/* The same with TryCloseLoop's resume index: query i enumerates as successive FindPossibleLoopClosure calls starting at
+ * rStartNum = start_scans[i] do (Mapper.cpp:1963, 1976: the chain under construction is empty at the resume point, so a
+ * run of candidate scans that straddles it counts from there).  What the speculative batch re-issues after a closure
+ * moved the poses.  start_scans = NULL: all zero. */
+KH_API int kh_graph_find_loop_candidates_from(kh_graph * g, int32_t n_queries, const int32_t * query_scans,
+                                              const int32_t * start_scans, double loop_search_maximum_distance,
+                                              int32_t loop_match_minimum_chain_size, int32_t * chain_begin, int32_t * chains,
+                                              int32_t cap_chains, int32_t * n_chains);
 KH_API double kh_graph_last_kernel_ms(kh_graph * g);
 /* The rest of the row -- neighbourhood-sized, exact host arithmetic, no kernel:
  * MapperGraph::FindNearChains (Mapper.cpp:1683-1793) for one scan of the current graph: the maximal runs of
@@ -393,6 +401,59 @@ KH_API void kh_decay_params_default(kh_decay_params * p);
 KH_API int kh_lifelong_scores(int32_t device, const kh_scan_box * reference, int32_t n, const kh_scan_box * candidates,
                               const kh_decay_params * params, int32_t * kept, double * iou, double * area_overlap,
                               double * reading_overlap, double * scores);
+
+/* ---------------------------------------------------------------- mapper front end (BASELINE configs 1 and 5) */
+/* ROS-free restatement of what karto::Mapper::Process does around the scan matcher and the solver plugin
+ * (lib/karto_sdk/src/Mapper.cpp:2679-2748 with MapperGraph::AddEdges / LinkNearChains / TryCloseLoop / CorrectPoses,
+ * :1434-1561, 1641-1681, 2012-2030), for replaying a scan queue end to end on the GPU: sequential match against the running
+ * scans, links to the previous scan, the running chain and the near chains (matched as one batch), loop closure as
+ * speculative batches (all candidate chains enumerated by kh_graph_find_loop_candidates_from, coarse-matched in one
+ * kh_matcher_match_batch, the ones passing the coarse gate fine-matched in a second, results consumed in the reference's
+ * order up to the first accepted closure, then kh_spa_compute and re-enumeration behind it).  One laser, zero mount
+ * offset, mapping mode.  The values are AS STORED by karto::Mapper (loop_match_maximum_variance_coarse and the two
+ * variance penalties of `match` are the squared values). */
+typedef struct kh_mapper kh_mapper;
+typedef struct kh_laser {                       /* karto::LaserRangeFinder (Karto.h:4060-4330) */
+  int32_t n_beams;
+  double minimum_angle, angular_resolution, minimum_range, maximum_range, range_threshold;
+} kh_laser;
+typedef struct kh_mapper_params {               /* Mapper::InitializeParameters (Mapper.cpp:2086-2297) */
+  int32_t use_scan_matching, use_scan_barycenter;
+  double minimum_time_interval, minimum_travel_distance, minimum_travel_heading;
+  int32_t scan_buffer_size;
+  double scan_buffer_maximum_scan_distance;
+  double link_match_minimum_response_fine, link_scan_maximum_distance, loop_search_maximum_distance;
+  int32_t do_loop_closing, loop_match_minimum_chain_size;
+  double loop_match_maximum_variance_coarse, loop_match_minimum_response_coarse, loop_match_minimum_response_fine;
+  double correlation_search_space_dimension, correlation_search_space_resolution, correlation_search_space_smear_deviation;
+  double loop_search_space_dimension, loop_search_space_resolution, loop_search_space_smear_deviation;
+  kh_match_params match;
+} kh_mapper_params;
+typedef struct kh_mapper_stats {
+  int64_t scans_processed, matches, loop_candidates, loop_closures, speculation_discarded;
+  double process_ms, match_ms, solver_ms, update_ms;
+} kh_mapper_stats;
+/* config/mapper_params_offline.yaml:31-66 */
+KH_API void kh_mapper_params_default(kh_mapper_params * p);
+/* max_candidates = capacity of one matcher batch (near chains / loop candidates beyond it go in further batches) */
+KH_API int kh_mapper_create(const kh_mapper_params * params, const kh_laser * laser, int32_t device, int32_t max_candidates,
+                            kh_mapper ** out);
+KH_API void kh_mapper_destroy(kh_mapper * m);
+/* Mapper::Process for one scan: `ranges` = laser->n_beams readings, the odometric pose of the robot, the time stamp.
+ * *accepted = 0 when the scan is dropped by HasMovedEnough (Mapper.cpp:3110-3142).  corrected_pose / covariance may be NULL. */
+KH_API int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometric_pose[3], double time,
+                             int32_t * accepted, double corrected_pose[3], double covariance[9]);
+KH_API int32_t kh_mapper_num_scans(const kh_mapper * m);
+KH_API int64_t kh_mapper_num_edges(const kh_mapper * m);
+KH_API int kh_mapper_get_poses(const kh_mapper * m, double * corrected_poses /* 3 * num_scans */);
+/* scan `index` as the matcher / occupancy grid / lifelong scoring read it (pointers stay valid until the next process) */
+KH_API int kh_mapper_get_scan(const kh_mapper * m, int32_t index, kh_scan * scan, kh_scan_box * box);
+KH_API int kh_mapper_get_stats(const kh_mapper * m, kh_mapper_stats * out);
+/* the solver plugin instance the mapper drives (RemoveNode / save / load ... ); owned by the mapper */
+KH_API kh_spa * kh_mapper_solver(kh_mapper * m);
+/* every solver call the mapper makes, one line each, in the format oracle/ref_slam_driver.cpp logs the reference
+ * Mapper's calls with (N id pose, C a b z cov, X n ms, P id pose, K): the two logs of one scan queue must agree */
+KH_API int kh_mapper_set_log(kh_mapper * m, const char * path);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,10 @@ SYMBOLS = [
     "kh_spa_set_comm", "kh_comm_unique_id", "kh_comm_create", "kh_comm_destroy", "kh_comm_rank", "kh_comm_world",
     "kh_comm_allreduce_sum_f64", "kh_comm_allgather_f64",
     "kh_device_malloc", "kh_device_free", "kh_device_upload", "kh_device_download",
+    "kh_graph_find_loop_candidates_from",
+    "kh_mapper_params_default", "kh_mapper_create", "kh_mapper_destroy", "kh_mapper_process", "kh_mapper_num_scans",
+    "kh_mapper_num_edges", "kh_mapper_get_poses", "kh_mapper_get_scan", "kh_mapper_get_stats", "kh_mapper_solver",
+    "kh_mapper_set_log",
 ]
 
 
@@ -94,6 +98,32 @@ class KhDecayParams(C.Structure):
     _fields_ = [("iou_thresh", C.c_double), ("iou_match", C.c_double), ("removal_score", C.c_double),
                 ("overlap_scale", C.c_double), ("constraint_scale", C.c_double), ("nearby_penalty", C.c_double),
                 ("candidates_scale", C.c_double), ("scan_buffer_size", C.c_int32)]
+
+
+class KhLaser(C.Structure):
+    _fields_ = [("n_beams", C.c_int32), ("minimum_angle", C.c_double), ("angular_resolution", C.c_double),
+                ("minimum_range", C.c_double), ("maximum_range", C.c_double), ("range_threshold", C.c_double)]
+
+
+class KhMapperParams(C.Structure):
+    _fields_ = [("use_scan_matching", C.c_int32), ("use_scan_barycenter", C.c_int32),
+                ("minimum_time_interval", C.c_double), ("minimum_travel_distance", C.c_double),
+                ("minimum_travel_heading", C.c_double), ("scan_buffer_size", C.c_int32),
+                ("scan_buffer_maximum_scan_distance", C.c_double), ("link_match_minimum_response_fine", C.c_double),
+                ("link_scan_maximum_distance", C.c_double), ("loop_search_maximum_distance", C.c_double),
+                ("do_loop_closing", C.c_int32), ("loop_match_minimum_chain_size", C.c_int32),
+                ("loop_match_maximum_variance_coarse", C.c_double), ("loop_match_minimum_response_coarse", C.c_double),
+                ("loop_match_minimum_response_fine", C.c_double), ("correlation_search_space_dimension", C.c_double),
+                ("correlation_search_space_resolution", C.c_double), ("correlation_search_space_smear_deviation", C.c_double),
+                ("loop_search_space_dimension", C.c_double), ("loop_search_space_resolution", C.c_double),
+                ("loop_search_space_smear_deviation", C.c_double), ("match", KhMatchParams)]
+
+
+class KhMapperStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("scans_processed", "matches", "loop_candidates", "loop_closures", "speculation_discarded")] + \
+               [(k, C.c_double) for k in ("process_ms", "match_ms", "solver_ms", "update_ms")]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 _lib = None
@@ -197,6 +227,23 @@ def lib():
         L.kh_graph_closest_scan_to_pose.argtypes = [vp, iptr, i32, dptr, C.POINTER(i32)]
         L.kh_weighted_mean.argtypes = [i32, dptr, dptr, dptr]
         L.kh_graph_last_kernel_ms.restype = dbl
+    if hasattr(L, "kh_mapper_create"):
+        L.kh_graph_find_loop_candidates_from.argtypes = [vp, i32, iptr, vp, dbl, i32, iptr, iptr, i32, C.POINTER(i32)]
+        L.kh_mapper_params_default.argtypes = [C.POINTER(KhMapperParams)]
+        L.kh_mapper_params_default.restype = None
+        L.kh_mapper_create.argtypes = [C.POINTER(KhMapperParams), C.POINTER(KhLaser), i32, i32, C.POINTER(vp)]
+        L.kh_mapper_destroy.argtypes = [vp]
+        L.kh_mapper_destroy.restype = None
+        L.kh_mapper_process.argtypes = [vp, dptr, dptr, dbl, C.POINTER(i32), dptr, dptr]
+        L.kh_mapper_num_scans.argtypes = [vp]
+        L.kh_mapper_num_edges.argtypes = [vp]
+        L.kh_mapper_num_edges.restype = C.c_int64
+        L.kh_mapper_get_poses.argtypes = [vp, dptr]
+        L.kh_mapper_get_scan.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScanBox)]
+        L.kh_mapper_get_stats.argtypes = [vp, C.POINTER(KhMapperStats)]
+        L.kh_mapper_solver.argtypes = [vp]
+        L.kh_mapper_solver.restype = vp
+        L.kh_mapper_set_log.argtypes = [vp, C.c_char_p]
     if hasattr(L, "kh_lifelong_scores"):
         L.kh_decay_params_default.argtypes = [C.POINTER(KhDecayParams)]
         L.kh_decay_params_default.restype = None

@@ -44,11 +44,14 @@ struct GraphDev
 };
 
 __global__ __launch_bounds__(256) void k_loop_candidates(
-  GraphDev g, const int32_t * __restrict__ queries, double max_sq_plus, double max_sq_minus, int32_t min_chain,
-  uint8_t * flags_all, int32_t * frontier_all, int32_t * chain_count, int32_t * chains, int32_t cap_per_query)
+  GraphDev g, const int32_t * __restrict__ queries, const int32_t * __restrict__ starts, double max_sq_plus, double max_sq_minus,
+  int32_t min_chain, uint8_t * flags_all, int32_t * frontier_all, int32_t * chain_count, int32_t * chains, int32_t cap_per_query)
 {
   const int qi = blockIdx.x;
   const int q = queries[qi];
+  // FindPossibleLoopClosure resumes at rStartNum with an EMPTY chain (Mapper.cpp:1966, 1976): scans before it neither
+  // form chains nor extend one
+  const int start = starts ? starts[qi] : 0;
   const int n = g.n;
   uint8_t * flags = flags_all + (size_t)qi * ((n + 3) & ~3);       // word-aligned rows: bits are set with 32-bit atomics
   int32_t * cur = frontier_all + (size_t)qi * 2 * n;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void k_loop_candidates(
   int32_t * out = chains + (size_t)qi * cap_per_query * 2;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const uint8_t f = flags[i];
-    const bool good = (f & kInRange) && !(f & kLinked);
+    const bool good = i >= start && (f & kInRange) && !(f & kLinked);
     if (!good) {continue;}
     bool emit;
     int len_needed;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void k_loop_candidates(
     }
     if (!emit) {continue;}
     int s = i;
-    while (s > 0) {
+    while (s > start) {
       const uint8_t fp = flags[s - 1];
       if ((fp & kInRange) && !(fp & kLinked)) {--s;} else {break;}
     }
@@ -236,6 +239,14 @@ int kh_graph_find_loop_candidates(
   kh_graph * g, int32_t n_queries, const int32_t * query_scans, double max_distance, int32_t min_chain_size,
   int32_t * chain_begin, int32_t * chains, int32_t cap_chains, int32_t * n_chains)
 {
+  return kh_graph_find_loop_candidates_from(g, n_queries, query_scans, nullptr, max_distance, min_chain_size, chain_begin, chains,
+           cap_chains, n_chains);
+}
+
+int kh_graph_find_loop_candidates_from(
+  kh_graph * g, int32_t n_queries, const int32_t * query_scans, const int32_t * start_scans, double max_distance,
+  int32_t min_chain_size, int32_t * chain_begin, int32_t * chains, int32_t cap_chains, int32_t * n_chains)
+{
   if (!g || n_queries < 0 || !chain_begin || !n_chains || (n_queries > 0 && !query_scans) || cap_chains < 0 || (cap_chains > 0 && !chains)) {
     return KH_ERR_INVALID_ARG;
   }
@@ -250,18 +261,22 @@ int kh_graph_find_loop_candidates(
   const size_t nq = static_cast<size_t>(n_queries), n = static_cast<size_t>(g->n);
   // a run needs at least one terminator, so a query has at most n / 2 + 1 chains; min_chain bounds it further
   const int32_t per_query = static_cast<int32_t>(std::min<size_t>(n / std::max(1, min_chain_size + 1) + 2, n / 2 + 1));
-  int rc = ensure(g->d_queries, g->cap_q, nq); if (rc) {return rc;}
+  int rc = ensure(g->d_queries, g->cap_q, 2 * nq); if (rc) {return rc;}
   rc = ensure(g->d_flags, g->cap_flags, nq * ((n + 3) & ~static_cast<size_t>(3)) + 4); if (rc) {return rc;}
   rc = ensure(g->d_frontier, g->cap_frontier, nq * 2 * n); if (rc) {return rc;}
   rc = ensure(g->d_count, g->cap_count, nq); if (rc) {return rc;}
   rc = ensure(g->d_chains, g->cap_chains, nq * per_query * 2); if (rc) {return rc;}
   if (hipMemcpyAsync(g->d_queries, query_scans, nq * sizeof(int32_t), hipMemcpyHostToDevice, g->stream) != hipSuccess) {return KH_ERR_HIP;}
+  if (start_scans) {
+    for (size_t i = 0; i < nq; ++i) {if (start_scans[i] < 0) {set_error("kh_graph_find_loop_candidates_from: negative start"); return KH_ERR_INVALID_ARG;}}
+    if (hipMemcpyAsync(g->d_queries + nq, start_scans, nq * sizeof(int32_t), hipMemcpyHostToDevice, g->stream) != hipSuccess) {return KH_ERR_HIP;}
+  }
   // Mapper.cpp:1988-1990 and 1326-1327: Square(maxDistance) +/- KT_TOLERANCE
   const double sq = max_distance * max_distance;
   GraphDev dev{g->n, g->d_xy, g->d_adj_ptr, g->d_adj_idx};
   (void)hipEventRecord(g->ev[0], g->stream);
   hipLaunchKernelGGL(k_loop_candidates, dim3(static_cast<unsigned>(nq)), dim3(256), 0, g->stream, dev, g->d_queries,
-    sq + kTol, sq - kTol, min_chain_size, g->d_flags, g->d_frontier, g->d_count, g->d_chains, per_query);
+    start_scans ? g->d_queries + nq : nullptr, sq + kTol, sq - kTol, min_chain_size, g->d_flags, g->d_frontier, g->d_count, g->d_chains, per_query);
   (void)hipEventRecord(g->ev[1], g->stream);
   std::vector<int32_t> counts(nq), all(nq * per_query * 2);
   if (hipMemcpyAsync(counts.data(), g->d_count, nq * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||

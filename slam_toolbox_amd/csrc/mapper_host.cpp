@@ -1,0 +1,665 @@
+// ROS-free mapper front end over the GPU hot path: what karto::Mapper::Process does around the scan matcher and the
+// solver plugin, so that a scan queue can be replayed end to end (BASELINE configs 1 and 5) without the reference's
+// object model.  Everything numeric goes through the library's own entry points -- kh_matcher_* (sequential and loop
+// matcher), kh_spa_* (solver plugin), kh_graph_* (candidate enumeration) -- and this file keeps the control flow and the
+// small exact host arithmetic (poses, transforms, running-scan buffer, link bookkeeping) in the reference's operation
+// order so that the run is comparable call by call with karto::Mapper driving the same queue.
+//
+// Reference: lib/karto_sdk/src/Mapper.cpp  Process :2679-2748, HasMovedEnough :3110-3142, ScanManager::AddRunningScan
+// :183-206, MapperGraph::AddVertex :1418-1432, AddEdges :1434-1498, TryCloseLoop :1500-1561, LinkScans :1620-1639,
+// LinkNearChains :1641-1663, LinkChainToScan :1665-1681, CorrectPoses :2012-2030; Karto.h LocalizedRangeScan::Update
+// :5644-5704, GetSensorAt / GetCorrectedAt :5566-5586, Transform :2946-3041, Matrix3::FromAxisAngle :2482-2511.
+//
+// TryCloseLoop is where the GPU changes the SHAPE of the computation without changing its result: the reference matches
+// one candidate chain after another; here all chains FindPossibleLoopClosure would return for the current poses are
+// enumerated in one kernel, coarse-matched in one kh_matcher_match_batch, the ones passing the coarse gate fine-matched
+// in a second batch, and the results consumed in the reference's order up to the first accepted closure.  CorrectPoses
+// then moves every pose, so what was computed for later chains is discarded and the enumeration resumes behind the
+// accepted chain with the new poses (closures are rare, the speculation almost always commits).
+//
+// Scope: one laser with zero mount offset, mapping mode (no localization buffer, no scan removal).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/karto_hip.h"
+
+namespace kh
+{
+void set_error(const std::string & s);
+void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
+
+namespace
+{
+constexpr double kTolerance = 1e-06;                  // KT_TOLERANCE, Math.h:41
+constexpr double kPi = 3.14159265358979323846;        // Math.h:31
+constexpr double k2Pi = 6.28318530717958647692;       // Math.h:32
+
+double normalize_angle(double angle)                  // math::NormalizeAngle, Math.h:181-202
+{
+  while (angle < -kPi) {
+    if (angle < -k2Pi) {angle += static_cast<uint32_t>(angle / -k2Pi) * k2Pi;} else {angle += k2Pi;}
+  }
+  while (angle > kPi) {
+    if (angle > k2Pi) {angle -= static_cast<uint32_t>(angle / k2Pi) * k2Pi;} else {angle -= k2Pi;}
+  }
+  return angle;
+}
+
+struct Pose {double x = 0.0, y = 0.0, h = 0.0;};
+inline bool same_pose(const Pose & a, const Pose & b) {return a.x == b.x && a.y == b.y && a.h == b.h;}   // Karto.h:2180-2183
+
+struct Mat3
+{
+  double m[3][3];
+  void identity() {std::memset(m, 0, sizeof(m)); m[0][0] = m[1][1] = m[2][2] = 1.0;}
+  void from_axis_angle(double x, double y, double z, double radians)      // Karto.h:2482-2511
+  {
+    const double cosRadians = std::cos(radians), sinRadians = std::sin(radians), oneMinusCos = 1.0 - cosRadians;
+    const double xx = x * x, yy = y * y, zz = z * z;
+    const double xyMCos = x * y * oneMinusCos, xzMCos = x * z * oneMinusCos, yzMCos = y * z * oneMinusCos;
+    const double xSin = x * sinRadians, ySin = y * sinRadians, zSin = z * sinRadians;
+    m[0][0] = xx * oneMinusCos + cosRadians; m[0][1] = xyMCos - zSin; m[0][2] = xzMCos + ySin;
+    m[1][0] = xyMCos + zSin; m[1][1] = yy * oneMinusCos + cosRadians; m[1][2] = yzMCos - xSin;
+    m[2][0] = xzMCos - ySin; m[2][1] = yzMCos + xSin; m[2][2] = zz * oneMinusCos + cosRadians;
+  }
+  Pose mul(const Pose & p) const                                          // Matrix3 * Pose2, Karto.h:2654-2666
+  {
+    Pose r;
+    r.x = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.h;
+    r.y = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.h;
+    r.h = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.h;
+    return r;
+  }
+};
+
+// karto::Transform(rPose1, rPose2).TransformPose(src), Karto.h:2946-3024
+Pose transform_pose(const Pose & p1, const Pose & p2, const Pose & src)
+{
+  Mat3 rot;
+  Pose t;
+  if (same_pose(p1, p2)) {
+    rot.identity();
+  } else {
+    rot.from_axis_angle(0, 0, 1, p2.h - p1.h);
+    if (p1.x != 0.0 || p1.y != 0.0) {
+      const Pose r = rot.mul(p1);
+      t.x = p2.x - r.x; t.y = p2.y - r.y;
+    } else {
+      t.x = p2.x; t.y = p2.y;
+    }
+    t.h = p2.h - p1.h;
+  }
+  const Pose r = rot.mul(src);
+  Pose out;
+  out.x = t.x + r.x; out.y = t.y + r.y;
+  out.h = normalize_angle(src.h + t.h);
+  return out;
+}
+
+// One processed scan: what LocalizedRangeScan holds (zero mount offset: the sensor pose is the corrected pose with its
+// heading normalised, GetSensorAt / GetCorrectedAt Karto.h:5566-5586)
+struct MScan
+{
+  int32_t id = -1;
+  double time = 0.0;
+  Pose odometric, corrected;
+  std::vector<double> ranges;
+  std::vector<double> points;        // unfiltered point readings, x0 y0 x1 y1 ...
+  double barycenter[2] = {0.0, 0.0};
+  double bbox[4] = {0.0, 0.0, 0.0, 0.0};   // min x, min y, max x, max y of the sensor position and the filtered readings
+  int32_t n_filtered = 0;
+  Pose sensor_pose() const {Pose p = corrected; p.h = normalize_angle(corrected.h); return p;}
+};
+
+struct Laser {int32_t n = 0; double min_angle = 0, ang_res = 0, min_range = 0, max_range = 0, range_threshold = 0;};
+
+// LocalizedRangeScan::Update, Karto.h:5644-5704
+void update_scan(MScan & s, const Laser & L)
+{
+  const Pose sp = s.sensor_pose();
+  s.points.resize(2 * static_cast<size_t>(L.n));
+  double sum_x = 0.0, sum_y = 0.0;
+  int32_t n_filtered = 0;
+  double bb[4] = {sp.x, sp.y, sp.x, sp.y};
+  for (int32_t i = 0; i < L.n; ++i) {
+    const double r = s.ranges[i];
+    const double angle = sp.h + L.min_angle + static_cast<uint32_t>(i) * L.ang_res;
+    const double px = sp.x + (r * std::cos(angle));
+    const double py = sp.y + (r * std::sin(angle));
+    s.points[2 * i] = px; s.points[2 * i + 1] = py;
+    if (r >= L.min_range && r <= L.range_threshold) {          // math::InRange
+      sum_x += px; sum_y += py; ++n_filtered;
+      bb[0] = std::min(bb[0], px); bb[1] = std::min(bb[1], py); bb[2] = std::max(bb[2], px); bb[3] = std::max(bb[3], py);
+    }
+  }
+  const double n_points = static_cast<double>(n_filtered);
+  if (n_points != 0.0) {
+    s.barycenter[0] = sum_x / n_points; s.barycenter[1] = sum_y / n_points;
+  } else {
+    s.barycenter[0] = sp.x; s.barycenter[1] = sp.y;
+  }
+  s.n_filtered = n_filtered;
+  std::copy(bb, bb + 4, s.bbox);
+}
+
+}  // namespace
+}  // namespace kh
+
+using namespace kh;
+
+struct kh_mapper
+{
+  kh_mapper_params p;
+  Laser laser;
+  int32_t device = 0, max_candidates = 64;
+  kh_matcher * seq = nullptr;
+  kh_matcher * loop = nullptr;
+  kh_spa * solver = nullptr;
+  kh_graph * graph = nullptr;
+  std::vector<std::unique_ptr<MScan>> scans;             // processed scans, index = state id = unique id
+  std::vector<int32_t> running;
+  int32_t last = -1;
+  std::vector<std::vector<int32_t>> adj;                 // Vertex::GetAdjacentVertices order (Mapper.h:338-361)
+  std::vector<std::vector<int32_t>> out_edges;           // targets of the edges whose SOURCE is the vertex (AddEdge's duplicate test)
+  int64_t n_edges = 0;
+  bool graph_dirty = true;
+  FILE * log = nullptr;
+  kh_mapper_stats stats;
+};
+
+namespace kh
+{
+namespace
+{
+
+kh_scan as_kh_scan(const MScan & s)
+{
+  kh_scan k;
+  k.n = static_cast<int32_t>(s.ranges.size());
+  k.ranges = s.ranges.data();
+  k.points_xy = s.points.data();
+  const Pose sp = s.sensor_pose();
+  k.sensor_pose[0] = sp.x; k.sensor_pose[1] = sp.y; k.sensor_pose[2] = sp.h;
+  return k;
+}
+
+void reference_xy(const kh_mapper * m, const MScan & s, double xy[2])     // GetReferencePose(useScanBarycenter)
+{
+  if (m->p.use_scan_barycenter) {xy[0] = s.barycenter[0]; xy[1] = s.barycenter[1];} else {const Pose sp = s.sensor_pose(); xy[0] = sp.x; xy[1] = sp.y;}
+}
+
+// the graph store the enumeration kernels and the near-chain walks read: reference positions + adjacency of ALL scans
+int sync_graph(kh_mapper * m)
+{
+  const size_t n = m->scans.size();
+  std::vector<double> xy(2 * n);
+  std::vector<int32_t> ptr(n + 1, 0), idx;
+  for (size_t i = 0; i < n; ++i) {
+    reference_xy(m, *m->scans[i], &xy[2 * i]);
+    ptr[i + 1] = ptr[i] + static_cast<int32_t>(m->adj[i].size());
+  }
+  idx.reserve(static_cast<size_t>(ptr[n]));
+  for (size_t i = 0; i < n; ++i) {idx.insert(idx.end(), m->adj[i].begin(), m->adj[i].end());}
+  const int rc = kh_graph_set(m->graph, static_cast<int32_t>(n), xy.data(), ptr.data(), idx.data());
+  if (rc == KH_OK) {m->graph_dirty = false;}
+  return rc;
+}
+
+// SetSensorPose (Karto.h:5552-5557): corrected = GetCorrectedAt(pose), then Update
+void set_sensor_pose(kh_mapper * m, MScan & s, const double pose[3])
+{
+  // GetCorrectedAt: sPose - worldSensorOffset with a zero offset: position unchanged, NormalizeAngle(heading - 0)
+  s.corrected.x = pose[0]; s.corrected.y = pose[1]; s.corrected.h = normalize_angle(pose[2]);
+  update_scan(s, m->laser);
+  m->graph_dirty = true;
+}
+
+// MapperGraph::LinkScans (Mapper.cpp:1620-1639) incl. AddEdge's "edge already exists" test (:1585-1618)
+int link_scans(kh_mapper * m, int32_t from, int32_t to, const double mean[3], const double cov[9])
+{
+  for (int32_t t : m->out_edges[from]) {if (t == to) {return KH_OK;}}     // not a new edge: nothing is attached
+  m->out_edges[from].push_back(to);
+  m->adj[from].push_back(to);
+  m->adj[to].push_back(from);
+  ++m->n_edges;
+  m->graph_dirty = true;
+  // LinkInfo(pFromScan->GetCorrectedPose(), pToScan->GetCorrectedAt(rMean), rCovariance)
+  const MScan & f = *m->scans[from];
+  const double pose1[3] = {f.corrected.x, f.corrected.y, f.corrected.h};
+  const double pose2[3] = {mean[0], mean[1], normalize_angle(mean[2])};
+  double diff[3], cov_out[9];
+  int rc = kh_link_info(pose1, pose2, cov, diff, cov_out);
+  if (rc) {return rc;}
+  if (m->log) {
+    std::fprintf(m->log, "C %d %d %.17g %.17g %.17g", from, to, diff[0], diff[1], diff[2]);
+    for (int k = 0; k < 9; ++k) {std::fprintf(m->log, " %.17g", cov_out[k]);}
+    std::fprintf(m->log, "\n");
+  }
+  rc = kh_spa_add_constraint(m->solver, from, to, diff, cov_out);
+  // the plugin logs and carries on when it cannot add a constraint (ceres_solver.cpp:354-361)
+  return (rc == KH_OK || rc == KH_ERR_NOT_FOUND || rc == KH_ERR_INVALID_ARG) ? KH_OK : rc;
+}
+
+// MapperGraph::LinkChainToScan (Mapper.cpp:1665-1681)
+int link_chain_to_scan(kh_mapper * m, const std::vector<int32_t> & chain, int32_t scan, const double mean[3], const double cov[9])
+{
+  double pose[2];
+  reference_xy(m, *m->scans[scan], pose);
+  // GetClosestScanToPose (Mapper.cpp:1563-1582)
+  int32_t closest = -1;
+  double best = 1.7976931348623157e308;
+  for (int32_t c : chain) {
+    double xy[2];
+    reference_xy(m, *m->scans[c], xy);
+    const double dx = pose[0] - xy[0], dy = pose[1] - xy[1];
+    const double d = dx * dx + dy * dy;
+    if (d < best) {best = d; closest = c;}
+  }
+  if (closest < 0) {return KH_OK;}
+  double cxy[2];
+  reference_xy(m, *m->scans[closest], cxy);
+  const double dx = pose[0] - cxy[0], dy = pose[1] - cxy[1];
+  const double squaredDistance = dx * dx + dy * dy;
+  if (squaredDistance < m->p.link_scan_maximum_distance * m->p.link_scan_maximum_distance + kTolerance) {
+    return link_scans(m, closest, scan, mean, cov);
+  }
+  return KH_OK;
+}
+
+// MapperGraph::CorrectPoses (Mapper.cpp:2012-2030)
+int correct_poses(kh_mapper * m)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  kh_spa_summary sum;
+  const int rc = kh_spa_compute(m->solver, &sum);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  m->stats.solver_ms += ms; m->stats.loop_closures += 1;
+  if (rc != KH_OK && rc != KH_ERR_SOLVER && rc != KH_ERR_NOT_FOUND) {return rc;}
+  int32_t n = 0;
+  kh_spa_get_corrections(m->solver, &n, nullptr, nullptr);
+  std::vector<int32_t> ids(static_cast<size_t>(n));
+  std::vector<double> poses(3 * static_cast<size_t>(n));
+  if (n) {kh_spa_get_corrections(m->solver, &n, ids.data(), poses.data());}
+  if (m->log) {
+    std::fprintf(m->log, "X %d %.6f\n", n, ms);
+    for (int32_t k = 0; k < n; ++k) {std::fprintf(m->log, "P %d %.17g %.17g %.17g\n", ids[k], poses[3 * k], poses[3 * k + 1], poses[3 * k + 2]);}
+  }
+  // SetCorrectedPoseAndUpdate of every scan: N x P cos / sin in libm (the reference does the same, serially)
+  const auto t1 = std::chrono::steady_clock::now();
+  host_parallel_for(static_cast<size_t>(n), [&](size_t k) {
+    const int32_t id = ids[k];
+    if (id < 0 || id >= static_cast<int32_t>(m->scans.size())) {return;}
+    MScan & s = *m->scans[id];
+    s.corrected.x = poses[3 * k]; s.corrected.y = poses[3 * k + 1]; s.corrected.h = poses[3 * k + 2];
+    update_scan(s, m->laser);
+  });
+  m->stats.update_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+  m->graph_dirty = true;
+  if (m->log) {std::fprintf(m->log, "K\n");}
+  return kh_spa_clear(m->solver);
+}
+
+struct MatchOut {double response; double mean[3]; double cov[9];};
+
+// n independent MatchScan calls (query i against chain i) on `matcher`, in batches of the matcher's capacity
+int match_chains(kh_mapper * m, kh_matcher * matcher, const std::vector<kh_scan> & queries, const std::vector<std::vector<int32_t>> & chains,
+  bool penalize, bool refine, std::vector<MatchOut> & out)
+{
+  const size_t n = chains.size();
+  out.assign(n, MatchOut());
+  const size_t cap = static_cast<size_t>(m->max_candidates);
+  for (size_t at = 0; at < n; at += cap) {
+    const size_t nb = std::min(cap, n - at);
+    std::vector<kh_scan> base;
+    std::vector<int32_t> begin(nb + 1, 0);
+    for (size_t i = 0; i < nb; ++i) {
+      for (int32_t c : chains[at + i]) {base.push_back(as_kh_scan(*m->scans[c]));}
+      begin[i + 1] = static_cast<int32_t>(base.size());
+    }
+    std::vector<double> means(3 * nb), covs(9 * nb), resp(nb);
+    std::vector<int32_t> status(nb, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = kh_matcher_match_batch(matcher, static_cast<int32_t>(nb), queries.data() + at, base.data(), begin.data(),
+        penalize ? 1 : 0, refine ? 1 : 0, means.data(), covs.data(), resp.data(), status.data());
+    m->stats.match_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m->stats.matches += static_cast<int64_t>(nb);
+    if (rc) {return rc;}
+    for (size_t i = 0; i < nb; ++i) {
+      if (status[i] != KH_OK) {return status[i];}             // the reference throws (Mapper.cpp:786-796, 828)
+      out[at + i].response = resp[i];
+      std::copy(means.begin() + 3 * i, means.begin() + 3 * i + 3, out[at + i].mean);
+      std::copy(covs.begin() + 9 * i, covs.begin() + 9 * i + 9, out[at + i].cov);
+    }
+  }
+  return KH_OK;
+}
+
+std::vector<int32_t> run_of(int32_t first, int32_t last)
+{
+  std::vector<int32_t> v;
+  for (int32_t i = first; i <= last; ++i) {v.push_back(i);}
+  return v;
+}
+
+// MapperGraph::TryCloseLoop (Mapper.cpp:1500-1561), speculative batches
+int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
+{
+  closed = false;
+  int32_t start = 0;
+  const int32_t n_scans = static_cast<int32_t>(m->scans.size());
+  while (start < n_scans) {
+    if (m->graph_dirty) {const int rc = sync_graph(m); if (rc) {return rc;}}
+    // every chain successive FindPossibleLoopClosure calls would return from `start` on, for the CURRENT poses
+    std::vector<int32_t> chain_begin(2, 0), flat(2 * static_cast<size_t>(m->max_candidates));
+    int32_t n_chains = 0;
+    int rc = kh_graph_find_loop_candidates_from(m->graph, 1, &scan_id, &start, m->p.loop_search_maximum_distance,
+        m->p.loop_match_minimum_chain_size, chain_begin.data(), flat.data(), m->max_candidates, &n_chains);
+    if (rc) {return rc;}
+    if (n_chains > m->max_candidates) {
+      flat.resize(2 * static_cast<size_t>(n_chains));
+      rc = kh_graph_find_loop_candidates_from(m->graph, 1, &scan_id, &start, m->p.loop_search_maximum_distance,
+          m->p.loop_match_minimum_chain_size, chain_begin.data(), flat.data(), n_chains, &n_chains);
+      if (rc) {return rc;}
+    }
+    if (n_chains == 0) {break;}
+    m->stats.loop_candidates += n_chains;
+    std::vector<std::vector<int32_t>> chains(static_cast<size_t>(n_chains));
+    for (int32_t c = 0; c < n_chains; ++c) {chains[c] = run_of(flat[2 * c], flat[2 * c + 1]);}
+    MScan & scan = *m->scans[scan_id];
+    // coarse: m_pLoopScanMatcher->MatchScan(pScan, candidateChain, bestPose, covariance, false, false), all chains at once
+    std::vector<MatchOut> coarse;
+    rc = match_chains(m, m->loop, std::vector<kh_scan>(chains.size(), as_kh_scan(scan)), chains, false, false, coarse);
+    if (rc) {return rc;}
+    std::vector<int32_t> passing;
+    for (int32_t c = 0; c < n_chains; ++c) {
+      if (coarse[c].response > m->p.loop_match_minimum_response_coarse &&
+        coarse[c].cov[0] < m->p.loop_match_maximum_variance_coarse && coarse[c].cov[4] < m->p.loop_match_maximum_variance_coarse)
+      {
+        passing.push_back(c);
+      }
+    }
+    // fine: tmpScan at the coarse pose against the same chain on the sequential matcher (doPenalize false), again one batch
+    std::vector<std::unique_ptr<MScan>> tmp;
+    std::vector<kh_scan> fine_queries;
+    std::vector<std::vector<int32_t>> fine_chains;
+    for (int32_t c : passing) {
+      std::unique_ptr<MScan> t(new MScan());
+      t->ranges = scan.ranges; t->corrected = scan.corrected;
+      t->corrected.x = coarse[c].mean[0]; t->corrected.y = coarse[c].mean[1]; t->corrected.h = normalize_angle(coarse[c].mean[2]);
+      update_scan(*t, m->laser);
+      fine_queries.push_back(as_kh_scan(*t));
+      fine_chains.push_back(chains[c]);
+      tmp.push_back(std::move(t));
+    }
+    std::vector<MatchOut> fine;
+    rc = match_chains(m, m->seq, fine_queries, fine_chains, false, true, fine);
+    if (rc) {return rc;}
+    // consume in the reference's order up to the first accepted closure
+    int32_t accepted = -1;
+    for (size_t i = 0; i < passing.size(); ++i) {
+      if (!(fine[i].response < m->p.loop_match_minimum_response_fine)) {accepted = static_cast<int32_t>(i); break;}
+    }
+    if (accepted < 0) {break;}                       // every chain was looked at with the poses it would have seen
+    const int32_t c = passing[accepted];
+    set_sensor_pose(m, scan, fine[accepted].mean);
+    rc = link_chain_to_scan(m, chains[c], scan_id, fine[accepted].mean, fine[accepted].cov);
+    if (rc) {return rc;}
+    rc = correct_poses(m);
+    if (rc) {return rc;}
+    closed = true;
+    // FindPossibleLoopClosure returned this chain at its terminating scan (rStartNum stays there): resume behind it
+    start = flat[2 * c + 1] + 1;
+    m->stats.speculation_discarded += n_chains - (c + 1);
+  }
+  return KH_OK;
+}
+
+}  // namespace
+}  // namespace kh
+
+extern "C" {
+
+void kh_mapper_params_default(kh_mapper_params * p)
+{
+  if (!p) {return;}
+  // config/mapper_params_offline.yaml:31-66 (the offline / sync launches)
+  p->use_scan_matching = 1; p->use_scan_barycenter = 1;
+  p->minimum_time_interval = 3600.0;                 // Mapper.cpp:2108-2118 (not in the yaml)
+  p->minimum_travel_distance = 0.5; p->minimum_travel_heading = 0.5;
+  p->scan_buffer_size = 10; p->scan_buffer_maximum_scan_distance = 10.0;
+  p->link_match_minimum_response_fine = 0.1; p->link_scan_maximum_distance = 1.5;
+  p->loop_search_maximum_distance = 3.0; p->do_loop_closing = 1;
+  p->loop_match_minimum_chain_size = 10;
+  p->loop_match_maximum_variance_coarse = 3.0 * 3.0;  // the setter squares it (Mapper.cpp:2512-2515)
+  p->loop_match_minimum_response_coarse = 0.35; p->loop_match_minimum_response_fine = 0.45;
+  p->correlation_search_space_dimension = 0.5; p->correlation_search_space_resolution = 0.01;
+  p->correlation_search_space_smear_deviation = 0.1;
+  p->loop_search_space_dimension = 8.0; p->loop_search_space_resolution = 0.05; p->loop_search_space_smear_deviation = 0.03;
+  p->match.coarse_search_angle_offset = 0.349; p->match.coarse_angle_resolution = 0.0349;
+  p->match.fine_search_angle_offset = 0.00349; p->match.use_response_expansion = 1;
+  p->match.distance_variance_penalty = 0.5 * 0.5; p->match.minimum_distance_penalty = 0.5;
+  p->match.angle_variance_penalty = 1.0 * 1.0; p->match.minimum_angle_penalty = 0.9;
+}
+
+int kh_mapper_create(const kh_mapper_params * params, const kh_laser * laser, int32_t device, int32_t max_candidates, kh_mapper ** out)
+{
+  if (!out || !params || !laser || laser->n_beams <= 0 || max_candidates < 1) {return KH_ERR_INVALID_ARG;}
+  *out = nullptr;
+  std::unique_ptr<kh_mapper> m(new kh_mapper());
+  m->p = *params; m->device = device; m->max_candidates = max_candidates;
+  m->laser.n = laser->n_beams; m->laser.min_angle = laser->minimum_angle; m->laser.ang_res = laser->angular_resolution;
+  m->laser.min_range = laser->minimum_range; m->laser.max_range = laser->maximum_range; m->laser.range_threshold = laser->range_threshold;
+  std::memset(&m->stats, 0, sizeof(m->stats));
+  auto fail = [&](int rc) {kh_mapper_destroy(m.release()); return rc;};
+  // Mapper::Initialize (Mapper.cpp:2606-2631): the sequential matcher; MapperGraph's constructor: the loop matcher (:1397-1400)
+  int rc = kh_matcher_create(params->correlation_search_space_dimension, params->correlation_search_space_resolution,
+      params->correlation_search_space_smear_deviation, laser->range_threshold, device, max_candidates, &m->seq);
+  if (rc) {return fail(rc);}
+  rc = kh_matcher_create(params->loop_search_space_dimension, params->loop_search_space_resolution,
+      params->loop_search_space_smear_deviation, laser->range_threshold, device, max_candidates, &m->loop);
+  if (rc) {return fail(rc);}
+  rc = kh_matcher_set_params(m->seq, &params->match); if (rc) {return fail(rc);}
+  rc = kh_matcher_set_params(m->loop, &params->match); if (rc) {return fail(rc);}
+  rc = kh_spa_create(device, &m->solver); if (rc) {return fail(rc);}
+  rc = kh_graph_create(device, &m->graph); if (rc) {return fail(rc);}
+  *out = m.release();
+  return KH_OK;
+}
+
+void kh_mapper_destroy(kh_mapper * m)
+{
+  if (!m) {return;}
+  if (m->log) {std::fclose(m->log);}
+  kh_matcher_destroy(m->seq); kh_matcher_destroy(m->loop);
+  kh_spa_destroy(m->solver); kh_graph_destroy(m->graph);
+  delete m;
+}
+
+int kh_mapper_set_log(kh_mapper * m, const char * path)
+{
+  if (!m) {return KH_ERR_INVALID_ARG;}
+  if (m->log) {std::fclose(m->log); m->log = nullptr;}
+  if (path) {
+    m->log = std::fopen(path, "w");
+    if (!m->log) {kh::set_error("kh_mapper_set_log: cannot open the file"); return KH_ERR_IO;}
+  }
+  return KH_OK;
+}
+
+kh_spa * kh_mapper_solver(kh_mapper * m) {return m ? m->solver : nullptr;}
+
+// Mapper::Process (Mapper.cpp:2679-2748)
+int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometric_pose[3], double time, int32_t * accepted,
+  double corrected_pose[3], double covariance[9])
+{
+  if (!m || !ranges || !odometric_pose || !accepted) {return KH_ERR_INVALID_ARG;}
+  *accepted = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  std::unique_ptr<MScan> scan(new MScan());
+  scan->ranges.assign(ranges, ranges + m->laser.n);
+  scan->time = time;
+  scan->odometric.x = odometric_pose[0]; scan->odometric.y = odometric_pose[1]; scan->odometric.h = odometric_pose[2];
+  scan->corrected = scan->odometric;                      // the caller's SetCorrectedPose(odometric pose)
+  MScan * last = m->last >= 0 ? m->scans[m->last].get() : nullptr;
+  // update the scan's corrected pose based on the last correction (:2699-2703)
+  if (last) {scan->corrected = transform_pose(last->odometric, last->corrected, scan->odometric);}
+  // HasMovedEnough (:3110-3142)
+  if (last) {
+    bool moved = false;
+    if (scan->time - last->time >= m->p.minimum_time_interval) {moved = true;}
+    if (!moved) {
+      // GetSensorAt(odometric pose) with a zero mount offset: the pose with its heading normalised
+      const double deltaHeading = normalize_angle(normalize_angle(scan->odometric.h) - normalize_angle(last->odometric.h));
+      if (std::fabs(deltaHeading) >= m->p.minimum_travel_heading) {moved = true;}
+    }
+    if (!moved) {
+      const double dx = last->odometric.x - scan->odometric.x, dy = last->odometric.y - scan->odometric.y;
+      if (dx * dx + dy * dy >= m->p.minimum_travel_distance * m->p.minimum_travel_distance - kTolerance) {moved = true;}
+    }
+    if (!moved) {return KH_OK;}
+  }
+  update_scan(*scan, m->laser);
+  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  // correct the scan against the running scans (:2713-2724)
+  if (m->p.use_scan_matching && last) {
+    const kh_scan q = as_kh_scan(*scan);
+    std::vector<kh_scan> base;
+    for (int32_t r : m->running) {base.push_back(as_kh_scan(*m->scans[r]));}
+    double mean[3], response = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = kh_matcher_match(m->seq, &q, base.data(), static_cast<int32_t>(base.size()), 1, 1, mean, cov, &response);
+    m->stats.match_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m->stats.matches += 1;
+    if (rc) {return rc;}
+    set_sensor_pose(m, *scan, mean);
+  }
+  // AddScan: state id = unique id = position in the list (:2727)
+  const int32_t id = static_cast<int32_t>(m->scans.size());
+  scan->id = id;
+  m->scans.push_back(std::move(scan));
+  m->adj.emplace_back(); m->out_edges.emplace_back();
+  m->graph_dirty = true;
+  MScan & s = *m->scans[id];
+  if (m->p.use_scan_matching) {
+    // AddVertex (:1418-1432): the solver node carries the corrected pose
+    const double node[3] = {s.corrected.x, s.corrected.y, s.corrected.h};
+    if (m->log) {std::fprintf(m->log, "N %d %.17g %.17g %.17g\n", id, node[0], node[1], node[2]);}
+    int rc = kh_spa_add_node(m->solver, id, node);
+    if (rc) {return rc;}
+    // AddEdges (:1434-1498)
+    std::vector<double> means, covs;
+    if (last) {
+      const Pose sp = s.sensor_pose();
+      const double scan_pose[3] = {sp.x, sp.y, sp.h};
+      rc = link_scans(m, id - 1, id, scan_pose, cov); if (rc) {return rc;}
+      means.insert(means.end(), scan_pose, scan_pose + 3);
+      covs.insert(covs.end(), cov, cov + 9);
+      rc = link_chain_to_scan(m, m->running, id, scan_pose, cov); if (rc) {return rc;}
+    }
+    // LinkNearChains (:1641-1663): the near chains are independent matches of the same scan -> one batch
+    {
+      if (m->graph_dirty) {rc = sync_graph(m); if (rc) {return rc;}}
+      std::vector<int32_t> flat(2 * static_cast<size_t>(m->max_candidates));
+      int32_t n_chains = 0;
+      rc = kh_graph_find_near_chains(m->graph, id, m->p.link_scan_maximum_distance, flat.data(), m->max_candidates, &n_chains);
+      if (rc) {return rc;}
+      if (n_chains > m->max_candidates) {
+        flat.resize(2 * static_cast<size_t>(n_chains));
+        rc = kh_graph_find_near_chains(m->graph, id, m->p.link_scan_maximum_distance, flat.data(), n_chains, &n_chains);
+        if (rc) {return rc;}
+      }
+      std::vector<std::vector<int32_t>> chains;
+      for (int32_t c = 0; c < n_chains; ++c) {
+        if (flat[2 * c + 1] - flat[2 * c] + 1 < m->p.loop_match_minimum_chain_size) {continue;}
+        chains.push_back(run_of(flat[2 * c], flat[2 * c + 1]));
+      }
+      std::vector<MatchOut> res;
+      rc = match_chains(m, m->seq, std::vector<kh_scan>(chains.size(), as_kh_scan(s)), chains, false, true, res);
+      if (rc) {return rc;}
+      for (size_t c = 0; c < chains.size(); ++c) {
+        if (res[c].response > m->p.link_match_minimum_response_fine - kTolerance) {
+          means.insert(means.end(), res[c].mean, res[c].mean + 3);
+          covs.insert(covs.end(), res[c].cov, res[c].cov + 9);
+          rc = link_chain_to_scan(m, chains[c], id, res[c].mean, res[c].cov); if (rc) {return rc;}
+        }
+      }
+    }
+    if (!means.empty()) {
+      double wm[3];
+      rc = kh_weighted_mean(static_cast<int32_t>(means.size() / 3), means.data(), covs.data(), wm); if (rc) {return rc;}
+      set_sensor_pose(m, s, wm);
+    }
+    // AddRunningScan (:183-206)
+    m->running.push_back(id);
+    {
+      auto sq = [&]() {
+        const Pose f = m->scans[m->running.front()]->sensor_pose(), b = m->scans[m->running.back()]->sensor_pose();
+        const double dx = f.x - b.x, dy = f.y - b.y;
+        return dx * dx + dy * dy;
+      };
+      double squaredDistance = sq();
+      while (m->running.size() > static_cast<size_t>(m->p.scan_buffer_size) ||
+        squaredDistance > m->p.scan_buffer_maximum_scan_distance * m->p.scan_buffer_maximum_scan_distance - kTolerance)
+      {
+        m->running.erase(m->running.begin());
+        squaredDistance = sq();
+      }
+    }
+    if (m->p.do_loop_closing) {
+      bool closed = false;
+      rc = kh::try_close_loop(m, id, closed);
+      if (rc) {return rc;}
+    }
+  }
+  m->last = id;
+  *accepted = 1;
+  if (corrected_pose) {corrected_pose[0] = s.corrected.x; corrected_pose[1] = s.corrected.y; corrected_pose[2] = s.corrected.h;}
+  if (covariance) {std::copy(cov, cov + 9, covariance);}
+  m->stats.scans_processed += 1;
+  m->stats.process_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return KH_OK;
+}
+
+int32_t kh_mapper_num_scans(const kh_mapper * m) {return m ? static_cast<int32_t>(m->scans.size()) : 0;}
+int64_t kh_mapper_num_edges(const kh_mapper * m) {return m ? m->n_edges : 0;}
+
+int kh_mapper_get_poses(const kh_mapper * m, double * corrected_poses)
+{
+  if (!m || !corrected_poses) {return KH_ERR_INVALID_ARG;}
+  for (size_t i = 0; i < m->scans.size(); ++i) {
+    corrected_poses[3 * i] = m->scans[i]->corrected.x; corrected_poses[3 * i + 1] = m->scans[i]->corrected.y;
+    corrected_poses[3 * i + 2] = m->scans[i]->corrected.h;
+  }
+  return KH_OK;
+}
+
+int kh_mapper_get_scan(const kh_mapper * m, int32_t index, kh_scan * scan, kh_scan_box * box)
+{
+  if (!m || index < 0 || index >= static_cast<int32_t>(m->scans.size())) {return KH_ERR_NOT_FOUND;}
+  const MScan & s = *m->scans[index];
+  if (scan) {*scan = kh::as_kh_scan(s);}
+  if (box) {
+    std::memset(box, 0, sizeof(*box));
+    box->barycenter[0] = s.barycenter[0]; box->barycenter[1] = s.barycenter[1];
+    box->bbox_size[0] = s.bbox[2] - s.bbox[0]; box->bbox_size[1] = s.bbox[3] - s.bbox[1];
+    box->unique_id = s.id; box->n_edges = static_cast<int32_t>(m->adj[index].size());
+  }
+  return KH_OK;
+}
+
+int kh_mapper_get_stats(const kh_mapper * m, kh_mapper_stats * out)
+{
+  if (!m || !out) {return KH_ERR_INVALID_ARG;}
+  *out = m->stats;
+  return KH_OK;
+}
+
+}  // extern "C"

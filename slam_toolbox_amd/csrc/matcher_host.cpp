@@ -299,6 +299,8 @@ private:
   bool stop_ = false;
 };
 
+void host_parallel_for(size_t n, const std::function<void(size_t)> & fn) {HostPool::instance().run(n, fn);}
+
 // ---- rasterisation of n jobs (slots[i] <- base scans of job i) ------------------------------
 struct RasterReq {int32_t slot; const kh_scan * query; const kh_scan * base; int32_t n_base;};
 

@@ -1,0 +1,83 @@
+"""Host-side mirror of karto::Mapper's processing entry point (lib/karto_sdk/src/Mapper.cpp:2679-2748) over the mapper
+front end of libkartohip.so (kh_mapper_*): a ROS-free way to replay a scan queue end to end on the GPU.
+
+    mapper = Mapper(laser, loop_search_maximum_distance=3.0)        # parameters of config/mapper_params_offline.yaml
+    accepted, pose, cov = mapper.Process(ranges, odometric_pose, time)
+    poses = mapper.poses()
+
+Nothing here computes: every call lands in the library."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Mapper:
+    def __init__(self, laser, device: int = 0, max_candidates: int = 32, log_path: str = None, **params):
+        """laser: anything with n_beams, min_angle, ang_res, min_range, max_range, range_threshold (synth.Laser);
+        params: fields of kh_mapper_params to override (AS STORED by karto::Mapper: variances squared)."""
+        p = capi.KhMapperParams()
+        capi.lib().kh_mapper_params_default(C.byref(p))
+        match_fields = {k for k, _ in capi.KhMatchParams._fields_}
+        for k, v in params.items():
+            if k in match_fields:
+                setattr(p.match, k, v)
+            elif hasattr(p, k):
+                setattr(p, k, v)
+            else:
+                raise KeyError(k)
+        L = capi.KhLaser(laser.n_beams, laser.min_angle, laser.ang_res, laser.min_range, laser.max_range, laser.range_threshold)
+        self._h = C.c_void_p()
+        capi.check(capi.lib().kh_mapper_create(C.byref(p), C.byref(L), device, max_candidates, C.byref(self._h)), "kh_mapper_create")
+        self.n_beams = laser.n_beams
+        if log_path:
+            capi.check(capi.lib().kh_mapper_set_log(self._h, log_path.encode()), "kh_mapper_set_log")
+
+    def Process(self, ranges, odometric_pose, time: float = 0.0):
+        ranges = np.ascontiguousarray(ranges, dtype=np.float64)
+        assert ranges.shape == (self.n_beams,)
+        acc = C.c_int32(0)
+        pose, cov = np.zeros(3), np.zeros(9)
+        capi.check(capi.lib().kh_mapper_process(self._h, ranges, np.ascontiguousarray(odometric_pose, dtype=np.float64), float(time),
+                                                C.byref(acc), pose, cov), "kh_mapper_process")
+        return bool(acc.value), pose, cov.reshape(3, 3)
+
+    def num_scans(self) -> int:
+        return capi.lib().kh_mapper_num_scans(self._h)
+
+    def num_edges(self) -> int:
+        return capi.lib().kh_mapper_num_edges(self._h)
+
+    def poses(self) -> np.ndarray:
+        out = np.zeros((self.num_scans(), 3))
+        if out.size:
+            capi.check(capi.lib().kh_mapper_get_poses(self._h, out.reshape(-1)), "kh_mapper_get_poses")
+        return out
+
+    def scan(self, index: int):
+        """(kh_scan, kh_scan_box) views of scan `index`: what the occupancy grid and the lifelong scoring read"""
+        s, b = capi.KhScan(), capi.KhScanBox()
+        capi.check(capi.lib().kh_mapper_get_scan(self._h, index, C.byref(s), C.byref(b)), "kh_mapper_get_scan")
+        return s, b
+
+    def stats(self) -> dict:
+        st = capi.KhMapperStats()
+        capi.check(capi.lib().kh_mapper_get_stats(self._h, C.byref(st)), "kh_mapper_get_stats")
+        return {k: getattr(st, k) for k, _ in capi.KhMapperStats._fields_}
+
+    def set_log(self, path):
+        capi.check(capi.lib().kh_mapper_set_log(self._h, path.encode() if path else None), "kh_mapper_set_log")
+
+    def close(self):
+        if self._h:
+            capi.lib().kh_mapper_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,66 @@
+"""GPU: the mapper front end of the library (kh_mapper_*: sequential match, links, near chains, SPECULATIVE TryCloseLoop,
+CorrectPoses) against the reference's own karto::Mapper processing the same scan queue (oracle/_ref/libkarto_ref_slam.so:
+reference Mapper.cpp + reference CPU ScanMatcher, GPU solver plugin attached through karto::ScanSolver).  Both sides log
+every solver call -- AddNode with its pose, AddConstraint with the LinkInfo measurement and covariance, every Compute()
+with all corrections -- and the two logs must agree line by line: same accepted scans, same edges in the same order with
+the same measurement bits, same closures at the same scans, same corrected poses.  That is BASELINE config[0] run through
+the speculative batches instead of one MatchScan at a time (Mapper.cpp:1500-1561)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from slam_toolbox_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libkarto_ref_slam.so")
+
+
+def _queue(n_scans, kind):
+    world = synth.make_world(12345)
+    truth, odom = synth.trajectory_laps(n_scans) if kind == "laps" else synth.trajectory(n_scans)
+    rng = np.random.default_rng(4)
+    ranges = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], rng) for i in range(n_scans)]))
+    return ranges, np.ascontiguousarray(odom)
+
+
+def _lines(path):
+    with open(path) as f:
+        return [" ".join(l.split()[:2]) if l.startswith("X ") else l.rstrip("\n") for l in f if not l.startswith("Z ")]
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libkarto_ref_slam.so not built (needs /root/reference)")
+@pytest.mark.parametrize("n_scans,loop_dist,kind", [(500, 3.0, "laps"), (230, 5.0, "sweep")])
+def test_mapper_front_end_equals_the_reference_mapper(kartohip_lib, tmp_path, n_scans, loop_dist, kind):
+    from slam_toolbox_amd.mapper import Mapper
+    runner = os.path.join(ROOT, "tests", "ref_slam_runner.py")
+    prefix = str(tmp_path / "ref")
+    subprocess.run([sys.executable, runner, LIB, str(n_scans), str(loop_dist), prefix, kind], check=True, timeout=900)
+    ref = np.load(prefix + ".npz")
+    ref_log = _lines(prefix + ".log")
+    ranges, odom = _queue(n_scans, kind)
+    log = str(tmp_path / "hip.log")
+    m = Mapper(synth.Laser(), loop_search_maximum_distance=loop_dist, log_path=log)
+    accepted = 0
+    for i in range(n_scans):
+        ok, _, _ = m.Process(ranges[i], odom[i], 0.1 * i)
+        accepted += int(ok)
+    poses = m.poses()
+    st = m.stats()
+    m.set_log(None)
+    hip_log = _lines(log)
+    m.close()
+    print(f"{kind}: accepted {accepted} (reference {int(ref['accepted'])}), {st['loop_closures']} closures, "
+          f"{st['loop_candidates']} candidate chains, {st['speculation_discarded']} speculative results discarded, "
+          f"{st['matches']} matches in {st['match_ms']:.0f} ms, solver {st['solver_ms']:.0f} ms, pose updates {st['update_ms']:.0f} ms, "
+          f"Process total {st['process_ms']:.0f} ms; reference Mapper::Process {float(ref['seconds']) * 1e3:.0f} ms")
+    assert accepted == int(ref["accepted"])
+    assert sum(l.startswith("X ") for l in ref_log) >= 1, "the queue closed no loop"
+    # first difference, if any, with context
+    for k, (a, b) in enumerate(zip(ref_log, hip_log)):
+        assert a == b, f"solver-call logs diverge at line {k}:\n  reference: {a}\n  mapper   : {b}"
+    assert len(ref_log) == len(hip_log)
+    assert np.array_equal(ref["poses"][:, 1:], poses), "final corrected poses differ"
