@@ -333,6 +333,14 @@ KH_API int kh_graph_find_loop_candidates_from(kh_graph * g, int32_t n_queries, c
                                               int32_t loop_match_minimum_chain_size, int32_t * chain_begin, int32_t * chains,
                                               int32_t cap_chains, int32_t * n_chains);
 KH_API double kh_graph_last_kernel_ms(kh_graph * g);
+/* After scans were removed (lifelong mode) the reference's candidate walks stop at the SIZE of its scan map, which has
+ * fallen behind the largest scan id (Mapper.cpp:1974-1976, 1751-1756): only the first n_visit scans of the list are
+ * visited as chain members (all of them still count for the breadth-first "linked" test).  kh_graph_set resets it to n. */
+KH_API int kh_graph_set_scan_limit(kh_graph * g, int32_t n_visit);
+/* MapperGraph::FindNearLinkedVertices (Mapper.cpp:1808-1819): the vertices a breadth-first traversal from the scan
+ * reaches through vertices within max_distance of it, in visiting order (the scan itself first).  *n_found is the total. */
+KH_API int kh_graph_find_near_linked(kh_graph * g, int32_t query_scan, double max_distance, int32_t * scans, int32_t cap,
+                                     int32_t * n_found);
 /* The rest of the row -- neighbourhood-sized, exact host arithmetic, no kernel:
  * MapperGraph::FindNearChains (Mapper.cpp:1683-1793) for one scan of the current graph: the maximal runs of
  * consecutive scans within link_scan_maximum_distance of it that hold a near linked scan (FindNearLinkedScans,
@@ -430,8 +438,8 @@ typedef struct kh_mapper_params {               /* Mapper::InitializeParameters 
   kh_match_params match;
 } kh_mapper_params;
 typedef struct kh_mapper_stats {
-  int64_t scans_processed, matches, loop_candidates, loop_closures, speculation_discarded;
-  double process_ms, match_ms, solver_ms, update_ms;
+  int64_t scans_processed, matches, loop_candidates, loop_closures, speculation_discarded, nodes_removed;
+  double process_ms, match_ms, solver_ms, update_ms, lifelong_ms;
 } kh_mapper_stats;
 /* config/mapper_params_offline.yaml:31-66 */
 KH_API void kh_mapper_params_default(kh_mapper_params * p);
@@ -449,6 +457,17 @@ KH_API int kh_mapper_get_poses(const kh_mapper * m, double * corrected_poses /* 
 /* scan `index` as the matcher / occupancy grid / lifelong scoring read it (pointers stay valid until the next process) */
 KH_API int kh_mapper_get_scan(const kh_mapper * m, int32_t index, kh_scan * scan, kh_scan_box * box);
 KH_API int kh_mapper_get_stats(const kh_mapper * m, kh_mapper_stats * out);
+/* Mapper::RemoveNodeFromGraph + MapperSensorManager::RemoveScan (Mapper.cpp:2964-3021, :208-218; what
+ * LifelongSlamToolbox::removeFromSlamGraph does, slam_toolbox_lifelong.cpp:330-342): the scan's edges leave its
+ * neighbours, the graph and the solver (RemoveConstraint), the node leaves the solver (RemoveNode) and the scan list. */
+KH_API int kh_mapper_remove_node(kh_mapper * m, int32_t scan_id);
+/* LifelongSlamToolbox::evaluateNodeDepreciation after every accepted scan (slam_toolbox_lifelong.cpp:149-178):
+ * FindNearLinkedVertices within half the diagonal of the scan's bounding box, kh_lifelong_scores over them, removal of the
+ * ones scoring below params->removal_score, the new score stored on the others.  params = NULL switches it off. */
+KH_API int kh_mapper_set_lifelong(kh_mapper * m, const kh_decay_params * params);
+/* ids of the scans still in the graph, ascending (ids[kh_mapper_num_alive]) */
+KH_API int32_t kh_mapper_num_alive(const kh_mapper * m);
+KH_API int kh_mapper_get_alive(const kh_mapper * m, int32_t * ids);
 /* the solver plugin instance the mapper drives (RemoveNode / save / load ... ); owned by the mapper */
 KH_API kh_spa * kh_mapper_solver(kh_mapper * m);
 /* every solver call the mapper makes, one line each, in the format oracle/ref_slam_driver.cpp logs the reference

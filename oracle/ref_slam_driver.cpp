@@ -219,11 +219,14 @@ int ref_slam_enumerate(
 
 // Runs the scan queue through karto::Mapper::Process with the GPU solver plugin attached.  `ranges` is
 // n_scans x n_beams, `odom` n_scans x 3.  Writes the call log to `log_path` and the final corrected pose of
-// every ACCEPTED scan (id, x, y, heading) to `out` (capacity cap rows).  Returns the number of accepted
-// scans, or -1 when the plugin could not be constructed (no GPU).
-int ref_slam_run(
+// every ACCEPTED scan still in the graph (id, x, y, heading) to `out` (capacity cap rows).  Returns the number of
+// those scans, or -1 when the plugin could not be constructed (no GPU).
+// Removal schedule (lifelong mode's graph edits, without its policy): after queue scan remove_at[r] has been processed,
+// the node of scan id remove_id[r] is taken out the way LifelongSlamToolbox::removeFromSlamGraph does it
+// (src/experimental/slam_toolbox_lifelong.cpp:330-342): Mapper::RemoveNodeFromGraph + MapperSensorManager::RemoveScan.
+static int run_queue(
   int n_scans, int n_beams, const double * ranges, const double * odom, double loop_search_distance,
-  const char * log_path, double * out, int cap)
+  const char * log_path, double * out, int cap, const int * remove_at, const int * remove_id, int n_remove)
 {
   FILE * log = std::fopen(log_path, "w");
   if (!log) {return -2;}
@@ -243,6 +246,17 @@ int ref_slam_run(
       s->SetTime(0.1 * i);
       Matrix3 cov;
       if (mapper.Process(s, &cov)) {kept.push_back(s);} else {delete s;}
+      for (int r2 = 0; r2 < n_remove; ++r2) {
+        if (remove_at[r2] != i) {continue;}
+        LocalizedRangeScan * victim = mapper.m_pMapperSensorManager->GetScan(remove_id[r2]);
+        if (!victim) {std::fprintf(log, "! schedule names unknown scan %d\n", remove_id[r2]); continue;}
+        Vertex<LocalizedRangeScan> * vertex = mapper.m_pGraph->GetVertex(victim);
+        mapper.RemoveNodeFromGraph(vertex);
+        mapper.m_pMapperSensorManager->RemoveScan(victim);
+        vertex->RemoveObject();
+        delete vertex;
+        kept.erase(std::find(kept.begin(), kept.end(), victim));
+      }
     }
     for (LocalizedRangeScan * s : kept) {
       if (accepted < cap) {
@@ -260,6 +274,20 @@ int ref_slam_run(
   }
   std::fclose(log);
   return accepted;
+}
+
+int ref_slam_run(
+  int n_scans, int n_beams, const double * ranges, const double * odom, double loop_search_distance,
+  const char * log_path, double * out, int cap)
+{
+  return run_queue(n_scans, n_beams, ranges, odom, loop_search_distance, log_path, out, cap, nullptr, nullptr, 0);
+}
+
+int ref_slam_run_schedule(
+  int n_scans, int n_beams, const double * ranges, const double * odom, double loop_search_distance,
+  const char * log_path, double * out, int cap, const int * remove_at, const int * remove_id, int n_remove)
+{
+  return run_queue(n_scans, n_beams, ranges, odom, loop_search_distance, log_path, out, cap, remove_at, remove_id, n_remove);
 }
 
 }  // extern "C"

@@ -84,7 +84,8 @@ SYMBOLS = [
     "kh_graph_find_loop_candidates_from",
     "kh_mapper_params_default", "kh_mapper_create", "kh_mapper_destroy", "kh_mapper_process", "kh_mapper_num_scans",
     "kh_mapper_num_edges", "kh_mapper_get_poses", "kh_mapper_get_scan", "kh_mapper_get_stats", "kh_mapper_solver",
-    "kh_mapper_set_log",
+    "kh_mapper_set_log", "kh_mapper_remove_node", "kh_mapper_set_lifelong", "kh_mapper_num_alive", "kh_mapper_get_alive",
+    "kh_graph_set_scan_limit", "kh_graph_find_near_linked",
 ]
 
 
@@ -120,8 +121,8 @@ class KhMapperParams(C.Structure):
 
 
 class KhMapperStats(C.Structure):
-    _fields_ = [(k, C.c_int64) for k in ("scans_processed", "matches", "loop_candidates", "loop_closures", "speculation_discarded")] + \
-               [(k, C.c_double) for k in ("process_ms", "match_ms", "solver_ms", "update_ms")]
+    _fields_ = [(k, C.c_int64) for k in ("scans_processed", "matches", "loop_candidates", "loop_closures", "speculation_discarded", "nodes_removed")] + \
+               [(k, C.c_double) for k in ("process_ms", "match_ms", "solver_ms", "update_ms", "lifelong_ms")]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -244,6 +245,12 @@ def lib():
         L.kh_mapper_solver.argtypes = [vp]
         L.kh_mapper_solver.restype = vp
         L.kh_mapper_set_log.argtypes = [vp, C.c_char_p]
+        L.kh_mapper_remove_node.argtypes = [vp, i32]
+        L.kh_mapper_set_lifelong.argtypes = [vp, C.POINTER(KhDecayParams)]
+        L.kh_mapper_num_alive.argtypes = [vp]
+        L.kh_mapper_get_alive.argtypes = [vp, iptr]
+        L.kh_graph_set_scan_limit.argtypes = [vp, i32]
+        L.kh_graph_find_near_linked.argtypes = [vp, i32, dbl, iptr, i32, C.POINTER(i32)]
     if hasattr(L, "kh_lifelong_scores"):
         L.kh_decay_params_default.argtypes = [C.POINTER(KhDecayParams)]
         L.kh_decay_params_default.restype = None

@@ -45,7 +45,7 @@ struct GraphDev
 
 __global__ __launch_bounds__(256) void k_loop_candidates(
   GraphDev g, const int32_t * __restrict__ queries, const int32_t * __restrict__ starts, double max_sq_plus, double max_sq_minus,
-  int32_t min_chain, uint8_t * flags_all, int32_t * frontier_all, int32_t * chain_count, int32_t * chains, int32_t cap_per_query)
+  int32_t min_chain, int32_t n_visit, uint8_t * flags_all, int32_t * frontier_all, int32_t * chain_count, int32_t * chains, int32_t cap_per_query)
 {
   const int qi = blockIdx.x;
   const int q = queries[qi];
@@ -92,13 +92,15 @@ __global__ __launch_bounds__(256) void k_loop_candidates(
   }
   // (3) chains = maximal runs of good scans with the right terminator
   int32_t * out = chains + (size_t)qi * cap_per_query * 2;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  // the walk ends at n_visit (the reference's loop bound is the scan MAP's size, which falls behind the largest id
+  // once scans have been removed, Mapper.cpp:1974-1976): whatever chain is open there is returned
+  for (int i = threadIdx.x; i < n_visit; i += blockDim.x) {
     const uint8_t f = flags[i];
     const bool good = i >= start && (f & kInRange) && !(f & kLinked);
     if (!good) {continue;}
     bool emit;
     int len_needed;
-    if (i == n - 1) {
+    if (i == n_visit - 1) {
       emit = true; len_needed = 1;                       // end of the list: whatever is left is returned
     } else {
       const uint8_t fn = flags[i + 1];
@@ -142,6 +144,7 @@ struct kh_graph
   int32_t device = 0;
   hipStream_t stream = nullptr;
   int32_t n = 0;
+  int32_t n_visit = 0;     // scans the candidate walks visit (kh_graph_set_scan_limit; = n unless scans were removed)
   double * d_xy = nullptr; size_t cap_xy = 0;
   int32_t * d_adj_ptr = nullptr; size_t cap_ptr = 0;
   int32_t * d_adj_idx = nullptr; size_t cap_idx = 0;
@@ -216,7 +219,7 @@ int kh_graph_set(kh_graph * g, int32_t n_scans, const double * ref_xy, const int
       return KH_ERR_HIP;
     }
   }
-  g->n = n_scans;
+  g->n = n_scans; g->n_visit = n_scans;
   g->h_xy.assign(ref_xy, ref_xy + 2 * n);
   g->h_adj_ptr.assign(adj_ptr, adj_ptr + (n ? n + 1 : 0));
   g->h_adj_idx.assign(adj_idx, adj_idx + n_adj);
@@ -276,7 +279,7 @@ int kh_graph_find_loop_candidates_from(
   GraphDev dev{g->n, g->d_xy, g->d_adj_ptr, g->d_adj_idx};
   (void)hipEventRecord(g->ev[0], g->stream);
   hipLaunchKernelGGL(k_loop_candidates, dim3(static_cast<unsigned>(nq)), dim3(256), 0, g->stream, dev, g->d_queries,
-    start_scans ? g->d_queries + nq : nullptr, sq + kTol, sq - kTol, min_chain_size, g->d_flags, g->d_frontier, g->d_count, g->d_chains, per_query);
+    start_scans ? g->d_queries + nq : nullptr, sq + kTol, sq - kTol, min_chain_size, g->n_visit, g->d_flags, g->d_frontier, g->d_count, g->d_chains, per_query);
   (void)hipEventRecord(g->ev[1], g->stream);
   std::vector<int32_t> counts(nq), all(nq * per_query * 2);
   if (hipMemcpyAsync(counts.data(), g->d_count, nq * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
@@ -306,6 +309,13 @@ int kh_graph_find_loop_candidates_from(
 }
 
 double kh_graph_last_kernel_ms(kh_graph * g) {return g ? g->last_ms : 0.0;}
+
+int kh_graph_set_scan_limit(kh_graph * g, int32_t n_visit)
+{
+  if (!g || n_visit < 0 || n_visit > g->n) {return KH_ERR_INVALID_ARG;}
+  g->n_visit = n_visit;
+  return KH_OK;
+}
 
 // ---- host-side members of the row (exact reference arithmetic, O(neighbourhood) work) ---------------------
 namespace
@@ -389,7 +399,7 @@ int kh_graph_find_near_chains(
       if (c == query_scan) {valid = false;}
       if (squared_distance(pose, &g->h_xy[2 * static_cast<size_t>(c)]) < lim) {first = c; processed[c] = 1;} else {break;}
     }
-    for (int32_t c = near + 1; c < g->n; ++c) {                      // scans after (Mapper.cpp:1751-1780)
+    for (int32_t c = near + 1; c < g->n_visit; ++c) {                // scans after (Mapper.cpp:1751-1780); bound = scan map size
       if (c == query_scan) {valid = false;}
       if (squared_distance(pose, &g->h_xy[2 * static_cast<size_t>(c)]) < lim) {last = c; processed[c] = 1;} else {break;}
     }
@@ -399,6 +409,16 @@ int kh_graph_find_near_chains(
     }
   }
   *n_chains = total;
+  return KH_OK;
+}
+
+int kh_graph_find_near_linked(kh_graph * g, int32_t query_scan, double max_distance, int32_t * scans, int32_t cap, int32_t * n_found)
+{
+  if (!g || !n_found || query_scan < 0 || query_scan >= g->n || (cap > 0 && !scans)) {return KH_ERR_INVALID_ARG;}
+  std::vector<int32_t> valid;
+  near_linked(g, query_scan, max_distance, valid);
+  *n_found = static_cast<int32_t>(valid.size());
+  for (int32_t k = 0; k < *n_found && k < cap; ++k) {scans[k] = valid[k];}
   return KH_OK;
 }
 

@@ -113,6 +113,8 @@ struct MScan
   Pose odometric, corrected;
   std::vector<double> ranges;
   std::vector<double> points;        // unfiltered point readings, x0 y0 x1 y1 ...
+  std::vector<double> filtered;      // point readings with the range inside [minimum range, range threshold]
+  double score = 1.0;                // Vertex::GetScore (Mapper.h: vertices start at 1.0)
   double barycenter[2] = {0.0, 0.0};
   double bbox[4] = {0.0, 0.0, 0.0, 0.0};   // min x, min y, max x, max y of the sensor position and the filtered readings
   int32_t n_filtered = 0;
@@ -126,6 +128,7 @@ void update_scan(MScan & s, const Laser & L)
 {
   const Pose sp = s.sensor_pose();
   s.points.resize(2 * static_cast<size_t>(L.n));
+  s.filtered.clear();
   double sum_x = 0.0, sum_y = 0.0;
   int32_t n_filtered = 0;
   double bb[4] = {sp.x, sp.y, sp.x, sp.y};
@@ -137,6 +140,7 @@ void update_scan(MScan & s, const Laser & L)
     s.points[2 * i] = px; s.points[2 * i + 1] = py;
     if (r >= L.min_range && r <= L.range_threshold) {          // math::InRange
       sum_x += px; sum_y += py; ++n_filtered;
+      s.filtered.push_back(px); s.filtered.push_back(py);
       bb[0] = std::min(bb[0], px); bb[1] = std::min(bb[1], py); bb[2] = std::max(bb[2], px); bb[3] = std::max(bb[3], py);
     }
   }
@@ -164,7 +168,11 @@ struct kh_mapper
   kh_matcher * loop = nullptr;
   kh_spa * solver = nullptr;
   kh_graph * graph = nullptr;
-  std::vector<std::unique_ptr<MScan>> scans;             // processed scans, index = state id = unique id
+  std::vector<std::unique_ptr<MScan>> scans;             // processed scans, index = state id = unique id; null once removed
+  std::vector<int32_t> alive;                            // ids still in the scan map, ascending: the graph store's scan list
+  std::vector<int32_t> compact_of;                       // id -> position in `alive`, -1 when removed
+  bool lifelong = false;
+  kh_decay_params decay;
   std::vector<int32_t> running;
   int32_t last = -1;
   std::vector<std::vector<int32_t>> adj;                 // Vertex::GetAdjacentVertices order (Mapper.h:338-361)
@@ -196,19 +204,31 @@ void reference_xy(const kh_mapper * m, const MScan & s, double xy[2])     // Get
   if (m->p.use_scan_barycenter) {xy[0] = s.barycenter[0]; xy[1] = s.barycenter[1];} else {const Pose sp = s.sensor_pose(); xy[0] = sp.x; xy[1] = sp.y;}
 }
 
-// the graph store the enumeration kernels and the near-chain walks read: reference positions + adjacency of ALL scans
+// the graph store the enumeration kernels and the near-chain walks read: reference positions + adjacency of the scans
+// still in the map, in id order (a removed scan is a NULL entry the reference's walks skip)
 int sync_graph(kh_mapper * m)
 {
-  const size_t n = m->scans.size();
+  m->alive.clear();
+  m->compact_of.assign(m->scans.size(), -1);
+  for (size_t i = 0; i < m->scans.size(); ++i) {
+    if (m->scans[i]) {m->compact_of[i] = static_cast<int32_t>(m->alive.size()); m->alive.push_back(static_cast<int32_t>(i));}
+  }
+  const size_t n = m->alive.size();
   std::vector<double> xy(2 * n);
   std::vector<int32_t> ptr(n + 1, 0), idx;
-  for (size_t i = 0; i < n; ++i) {
-    reference_xy(m, *m->scans[i], &xy[2 * i]);
-    ptr[i + 1] = ptr[i] + static_cast<int32_t>(m->adj[i].size());
+  for (size_t c = 0; c < n; ++c) {
+    reference_xy(m, *m->scans[m->alive[c]], &xy[2 * c]);
+    ptr[c + 1] = ptr[c] + static_cast<int32_t>(m->adj[m->alive[c]].size());
   }
   idx.reserve(static_cast<size_t>(ptr[n]));
-  for (size_t i = 0; i < n; ++i) {idx.insert(idx.end(), m->adj[i].begin(), m->adj[i].end());}
-  const int rc = kh_graph_set(m->graph, static_cast<int32_t>(n), xy.data(), ptr.data(), idx.data());
+  for (size_t c = 0; c < n; ++c) {
+    for (int32_t w : m->adj[m->alive[c]]) {idx.push_back(m->compact_of[w]);}
+  }
+  int rc = kh_graph_set(m->graph, static_cast<int32_t>(n), xy.data(), ptr.data(), idx.data());
+  if (rc) {return rc;}
+  // the reference bounds its candidate walks by the scan map's SIZE, in id space (Mapper.cpp:1974-1976, 1751-1756)
+  const int32_t n_visit = static_cast<int32_t>(std::lower_bound(m->alive.begin(), m->alive.end(), static_cast<int32_t>(n)) - m->alive.begin());
+  rc = kh_graph_set_scan_limit(m->graph, n_visit);
   if (rc == KH_OK) {m->graph_dirty = false;}
   return rc;
 }
@@ -296,7 +316,7 @@ int correct_poses(kh_mapper * m)
   const auto t1 = std::chrono::steady_clock::now();
   host_parallel_for(static_cast<size_t>(n), [&](size_t k) {
     const int32_t id = ids[k];
-    if (id < 0 || id >= static_cast<int32_t>(m->scans.size())) {return;}
+    if (id < 0 || id >= static_cast<int32_t>(m->scans.size()) || !m->scans[id]) {return;}
     MScan & s = *m->scans[id];
     s.corrected.x = poses[3 * k]; s.corrected.y = poses[3 * k + 1]; s.corrected.h = poses[3 * k + 2];
     update_scan(s, m->laser);
@@ -342,10 +362,11 @@ int match_chains(kh_mapper * m, kh_matcher * matcher, const std::vector<kh_scan>
   return KH_OK;
 }
 
-std::vector<int32_t> run_of(int32_t first, int32_t last)
+// scan ids of the run [first, last] of the graph store's scan list
+std::vector<int32_t> run_of(const kh_mapper * m, int32_t first, int32_t last)
 {
   std::vector<int32_t> v;
-  for (int32_t i = first; i <= last; ++i) {v.push_back(i);}
+  for (int32_t i = first; i <= last; ++i) {v.push_back(m->alive[i]);}
   return v;
 }
 
@@ -353,26 +374,29 @@ std::vector<int32_t> run_of(int32_t first, int32_t last)
 int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
 {
   closed = false;
-  int32_t start = 0;
+  int32_t start_id = 0;                            // rStartNum, in id space
   const int32_t n_scans = static_cast<int32_t>(m->scans.size());
-  while (start < n_scans) {
+  while (start_id < n_scans) {
     if (m->graph_dirty) {const int rc = sync_graph(m); if (rc) {return rc;}}
+    // positions in the graph store's scan list (= the scans still alive, in id order)
+    const int32_t query = m->compact_of[scan_id];
+    int32_t start = static_cast<int32_t>(std::lower_bound(m->alive.begin(), m->alive.end(), start_id) - m->alive.begin());
     // every chain successive FindPossibleLoopClosure calls would return from `start` on, for the CURRENT poses
     std::vector<int32_t> chain_begin(2, 0), flat(2 * static_cast<size_t>(m->max_candidates));
     int32_t n_chains = 0;
-    int rc = kh_graph_find_loop_candidates_from(m->graph, 1, &scan_id, &start, m->p.loop_search_maximum_distance,
+    int rc = kh_graph_find_loop_candidates_from(m->graph, 1, &query, &start, m->p.loop_search_maximum_distance,
         m->p.loop_match_minimum_chain_size, chain_begin.data(), flat.data(), m->max_candidates, &n_chains);
     if (rc) {return rc;}
     if (n_chains > m->max_candidates) {
       flat.resize(2 * static_cast<size_t>(n_chains));
-      rc = kh_graph_find_loop_candidates_from(m->graph, 1, &scan_id, &start, m->p.loop_search_maximum_distance,
+      rc = kh_graph_find_loop_candidates_from(m->graph, 1, &query, &start, m->p.loop_search_maximum_distance,
           m->p.loop_match_minimum_chain_size, chain_begin.data(), flat.data(), n_chains, &n_chains);
       if (rc) {return rc;}
     }
     if (n_chains == 0) {break;}
     m->stats.loop_candidates += n_chains;
     std::vector<std::vector<int32_t>> chains(static_cast<size_t>(n_chains));
-    for (int32_t c = 0; c < n_chains; ++c) {chains[c] = run_of(flat[2 * c], flat[2 * c + 1]);}
+    for (int32_t c = 0; c < n_chains; ++c) {chains[c] = run_of(m, flat[2 * c], flat[2 * c + 1]);}
     MScan & scan = *m->scans[scan_id];
     // coarse: m_pLoopScanMatcher->MatchScan(pScan, candidateChain, bestPose, covariance, false, false), all chains at once
     std::vector<MatchOut> coarse;
@@ -416,9 +440,91 @@ int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
     if (rc) {return rc;}
     closed = true;
     // FindPossibleLoopClosure returned this chain at its terminating scan (rStartNum stays there): resume behind it
-    start = flat[2 * c + 1] + 1;
+    start_id = m->alive[flat[2 * c + 1]] + 1;
     m->stats.speculation_discarded += n_chains - (c + 1);
   }
+  return KH_OK;
+}
+
+// Mapper::RemoveNodeFromGraph (Mapper.cpp:2964-3021) + MapperSensorManager::RemoveScan (:208-218)
+int remove_node(kh_mapper * m, int32_t id)
+{
+  if (id < 0 || id >= static_cast<int32_t>(m->scans.size()) || !m->scans[id]) {
+    set_error("RemoveNode: Failed to find node matching id");
+    return KH_ERR_NOT_FOUND;
+  }
+  // 1) the edges leave the adjacent vertices, the graph and the optimizer
+  const std::vector<int32_t> neighbours = m->adj[id];
+  for (int32_t a : neighbours) {
+    auto pos = std::find(m->adj[a].begin(), m->adj[a].end(), id);
+    if (pos == m->adj[a].end()) {continue;}                    // "Failed to find any edge in adj. vertex"
+    m->adj[a].erase(pos);
+    int32_t source = id, target = a;
+    auto out = std::find(m->out_edges[a].begin(), m->out_edges[a].end(), id);
+    if (out != m->out_edges[a].end()) {source = a; target = id; m->out_edges[a].erase(out);}
+    if (m->log) {std::fprintf(m->log, "E %d %d\n", source, target);}
+    const int rc = kh_spa_remove_constraint(m->solver, source, target);
+    if (rc != KH_OK && rc != KH_ERR_NOT_FOUND) {return rc;}
+    --m->n_edges;
+  }
+  // 2) the vertex leaves the optimizer, 3) the graph and the scan map
+  if (m->log) {std::fprintf(m->log, "D %d\n", id);}
+  const int rc = kh_spa_remove_node(m->solver, id);
+  if (rc != KH_OK && rc != KH_ERR_NOT_FOUND) {return rc;}
+  m->adj[id].clear(); m->out_edges[id].clear();
+  m->scans[id].reset();
+  m->graph_dirty = true;
+  m->stats.nodes_removed += 1;
+  return KH_OK;
+}
+
+kh_scan_box box_of(const kh_mapper * m, const MScan & s)
+{
+  kh_scan_box b;
+  std::memset(&b, 0, sizeof(b));
+  b.barycenter[0] = s.barycenter[0]; b.barycenter[1] = s.barycenter[1];
+  b.bbox_size[0] = s.bbox[2] - s.bbox[0]; b.bbox_size[1] = s.bbox[3] - s.bbox[1];     // BoundingBox2::GetSize
+  b.unique_id = s.id; b.n_edges = static_cast<int32_t>(m->adj[s.id].size()); b.score = s.score;
+  b.n_points = static_cast<int32_t>(s.filtered.size() / 2); b.points_xy = s.filtered.data();
+  return b;
+}
+
+// LifelongSlamToolbox::evaluateNodeDepreciation (slam_toolbox_lifelong.cpp:149-178), lifelong_search_use_tree false
+int lifelong_step(kh_mapper * m, int32_t id)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  const MScan & s = *m->scans[id];
+  const double w = s.bbox[2] - s.bbox[0], h = s.bbox[3] - s.bbox[1];
+  const double radius = std::sqrt(w * w + h * h) / 2.0;
+  if (m->graph_dirty) {const int rc = sync_graph(m); if (rc) {return rc;}}
+  std::vector<int32_t> near(64);
+  int32_t n = 0;
+  int rc = kh_graph_find_near_linked(m->graph, m->compact_of[id], radius, near.data(), static_cast<int32_t>(near.size()), &n);
+  if (rc) {return rc;}
+  if (n > static_cast<int32_t>(near.size())) {
+    near.resize(static_cast<size_t>(n));
+    rc = kh_graph_find_near_linked(m->graph, m->compact_of[id], radius, near.data(), n, &n);
+    if (rc) {return rc;}
+  }
+  near.resize(static_cast<size_t>(n));
+  for (int32_t & c : near) {c = m->alive[c];}                     // graph store positions -> scan ids
+  const kh_scan_box ref = box_of(m, s);
+  std::vector<kh_scan_box> cands;
+  for (int32_t c : near) {cands.push_back(box_of(m, *m->scans[c]));}
+  std::vector<int32_t> kept(near.size(), 0);
+  std::vector<double> scores(near.size(), 0.0);
+  rc = kh_lifelong_scores(m->device, &ref, n, cands.data(), &m->decay, kept.data(), nullptr, nullptr, nullptr, scores.data());
+  if (rc) {return rc;}
+  for (size_t k = 0; k < near.size(); ++k) {
+    if (!kept[k]) {continue;}
+    if (scores[k] < m->decay.removal_score) {
+      rc = remove_node(m, near[k]);
+      if (rc) {return rc;}
+    } else {
+      m->scans[near[k]]->score = scores[k];
+    }
+  }
+  m->stats.lifelong_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return KH_OK;
 }
 
@@ -556,7 +662,8 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     if (rc) {return rc;}
     // AddEdges (:1434-1498)
     std::vector<double> means, covs;
-    if (last) {
+    const bool previous_gone = last && !m->scans[id - 1];       // AddEdges returns at once (Mapper.cpp:1444-1447)
+    if (last && !previous_gone) {
       const Pose sp = s.sensor_pose();
       const double scan_pose[3] = {sp.x, sp.y, sp.h};
       rc = link_scans(m, id - 1, id, scan_pose, cov); if (rc) {return rc;}
@@ -565,21 +672,22 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
       rc = link_chain_to_scan(m, m->running, id, scan_pose, cov); if (rc) {return rc;}
     }
     // LinkNearChains (:1641-1663): the near chains are independent matches of the same scan -> one batch
-    {
+    if (!previous_gone) {
       if (m->graph_dirty) {rc = sync_graph(m); if (rc) {return rc;}}
       std::vector<int32_t> flat(2 * static_cast<size_t>(m->max_candidates));
       int32_t n_chains = 0;
-      rc = kh_graph_find_near_chains(m->graph, id, m->p.link_scan_maximum_distance, flat.data(), m->max_candidates, &n_chains);
+      const int32_t query = m->compact_of[id];
+      rc = kh_graph_find_near_chains(m->graph, query, m->p.link_scan_maximum_distance, flat.data(), m->max_candidates, &n_chains);
       if (rc) {return rc;}
       if (n_chains > m->max_candidates) {
         flat.resize(2 * static_cast<size_t>(n_chains));
-        rc = kh_graph_find_near_chains(m->graph, id, m->p.link_scan_maximum_distance, flat.data(), n_chains, &n_chains);
+        rc = kh_graph_find_near_chains(m->graph, query, m->p.link_scan_maximum_distance, flat.data(), n_chains, &n_chains);
         if (rc) {return rc;}
       }
       std::vector<std::vector<int32_t>> chains;
       for (int32_t c = 0; c < n_chains; ++c) {
         if (flat[2 * c + 1] - flat[2 * c] + 1 < m->p.loop_match_minimum_chain_size) {continue;}
-        chains.push_back(run_of(flat[2 * c], flat[2 * c + 1]));
+        chains.push_back(run_of(m, flat[2 * c], flat[2 * c + 1]));
       }
       std::vector<MatchOut> res;
       rc = match_chains(m, m->seq, std::vector<kh_scan>(chains.size(), as_kh_scan(s)), chains, false, true, res);
@@ -620,6 +728,10 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     }
   }
   m->last = id;
+  if (m->lifelong && m->p.use_scan_matching) {
+    const int rc = kh::lifelong_step(m, id);
+    if (rc) {return rc;}
+  }
   *accepted = 1;
   if (corrected_pose) {corrected_pose[0] = s.corrected.x; corrected_pose[1] = s.corrected.y; corrected_pose[2] = s.corrected.h;}
   if (covariance) {std::copy(cov, cov + 9, covariance);}
@@ -635,6 +747,7 @@ int kh_mapper_get_poses(const kh_mapper * m, double * corrected_poses)
 {
   if (!m || !corrected_poses) {return KH_ERR_INVALID_ARG;}
   for (size_t i = 0; i < m->scans.size(); ++i) {
+    if (!m->scans[i]) {corrected_poses[3 * i] = corrected_poses[3 * i + 1] = corrected_poses[3 * i + 2] = std::nan(""); continue;}   // removed
     corrected_poses[3 * i] = m->scans[i]->corrected.x; corrected_poses[3 * i + 1] = m->scans[i]->corrected.y;
     corrected_poses[3 * i + 2] = m->scans[i]->corrected.h;
   }
@@ -643,15 +756,39 @@ int kh_mapper_get_poses(const kh_mapper * m, double * corrected_poses)
 
 int kh_mapper_get_scan(const kh_mapper * m, int32_t index, kh_scan * scan, kh_scan_box * box)
 {
-  if (!m || index < 0 || index >= static_cast<int32_t>(m->scans.size())) {return KH_ERR_NOT_FOUND;}
+  if (!m || index < 0 || index >= static_cast<int32_t>(m->scans.size()) || !m->scans[index]) {return KH_ERR_NOT_FOUND;}
   const MScan & s = *m->scans[index];
   if (scan) {*scan = kh::as_kh_scan(s);}
-  if (box) {
-    std::memset(box, 0, sizeof(*box));
-    box->barycenter[0] = s.barycenter[0]; box->barycenter[1] = s.barycenter[1];
-    box->bbox_size[0] = s.bbox[2] - s.bbox[0]; box->bbox_size[1] = s.bbox[3] - s.bbox[1];
-    box->unique_id = s.id; box->n_edges = static_cast<int32_t>(m->adj[index].size());
-  }
+  if (box) {*box = kh::box_of(m, s);}
+  return KH_OK;
+}
+
+int kh_mapper_remove_node(kh_mapper * m, int32_t scan_id)
+{
+  if (!m) {return KH_ERR_INVALID_ARG;}
+  return kh::remove_node(m, scan_id);
+}
+
+int kh_mapper_set_lifelong(kh_mapper * m, const kh_decay_params * params)
+{
+  if (!m) {return KH_ERR_INVALID_ARG;}
+  m->lifelong = params != nullptr;
+  if (params) {m->decay = *params; m->decay.scan_buffer_size = m->p.scan_buffer_size;}
+  return KH_OK;
+}
+
+int32_t kh_mapper_num_alive(const kh_mapper * m)
+{
+  int32_t n = 0;
+  if (m) {for (const auto & s : m->scans) {n += s ? 1 : 0;}}
+  return n;
+}
+
+int kh_mapper_get_alive(const kh_mapper * m, int32_t * ids)
+{
+  if (!m || !ids) {return KH_ERR_INVALID_ARG;}
+  int32_t n = 0;
+  for (size_t i = 0; i < m->scans.size(); ++i) {if (m->scans[i]) {ids[n++] = static_cast<int32_t>(i);}}
   return KH_OK;
 }
 

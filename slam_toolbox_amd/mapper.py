@@ -63,6 +63,28 @@ class Mapper:
         capi.check(capi.lib().kh_mapper_get_scan(self._h, index, C.byref(s), C.byref(b)), "kh_mapper_get_scan")
         return s, b
 
+    def RemoveNode(self, scan_id: int):
+        """Mapper::RemoveNodeFromGraph + MapperSensorManager::RemoveScan (what lifelong mode does to a decayed node)"""
+        capi.check(capi.lib().kh_mapper_remove_node(self._h, int(scan_id)), "kh_mapper_remove_node")
+
+    def SetLifelong(self, enabled: bool = True, **decay):
+        """LifelongSlamToolbox::evaluateNodeDepreciation after every accepted scan; decay = kh_decay_params overrides"""
+        if not enabled:
+            capi.check(capi.lib().kh_mapper_set_lifelong(self._h, None), "kh_mapper_set_lifelong")
+            return
+        p = capi.KhDecayParams()
+        capi.lib().kh_decay_params_default(C.byref(p))
+        for k, v in decay.items():
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+        capi.check(capi.lib().kh_mapper_set_lifelong(self._h, C.byref(p)), "kh_mapper_set_lifelong")
+
+    def alive(self) -> np.ndarray:
+        ids = np.zeros(max(1, capi.lib().kh_mapper_num_alive(self._h)), dtype=np.int32)
+        capi.check(capi.lib().kh_mapper_get_alive(self._h, ids), "kh_mapper_get_alive")
+        return ids[:capi.lib().kh_mapper_num_alive(self._h)]
+
     def stats(self) -> dict:
         st = capi.KhMapperStats()
         capi.check(capi.lib().kh_mapper_get_stats(self._h, C.byref(st)), "kh_mapper_get_stats")

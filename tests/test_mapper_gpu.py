@@ -64,3 +64,61 @@ def test_mapper_front_end_equals_the_reference_mapper(kartohip_lib, tmp_path, n_
         assert a == b, f"solver-call logs diverge at line {k}:\n  reference: {a}\n  mapper   : {b}"
     assert len(ref_log) == len(hip_log)
     assert np.array_equal(ref["poses"][:, 1:], poses), "final corrected poses differ"
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libkarto_ref_slam.so not built (needs /root/reference)")
+def test_node_removal_equals_the_reference_graph_edits(kartohip_lib, tmp_path):
+    """Lifelong mode's graph edits without its policy: the same nodes are removed at the same points of the queue from the
+    reference Mapper (Mapper::RemoveNodeFromGraph + MapperSensorManager::RemoveScan, the way
+    LifelongSlamToolbox::removeFromSlamGraph does it) and from the library's mapper (kh_mapper_remove_node); afterwards the
+    two keep producing the same solver calls -- RemoveConstraint / RemoveNode included -- the same closures and poses, with
+    the reference's walks bounded by the shrunken scan map (Mapper.cpp:1974-1976)."""
+    from slam_toolbox_amd.mapper import Mapper
+    n_scans, loop_dist, kind = 500, 3.0, "laps"
+    schedule = [(200, 40), (200, 41), (200, 60), (300, 100), (300, 101), (300, 102), (300, 103), (300, 150), (380, 5), (380, 200)]
+    runner = os.path.join(ROOT, "tests", "ref_slam_runner.py")
+    prefix = str(tmp_path / "ref")
+    subprocess.run([sys.executable, runner, LIB, str(n_scans), str(loop_dist), prefix, kind,
+                    ",".join(f"{a}:{i}" for a, i in schedule)], check=True, timeout=900)
+    ref = np.load(prefix + ".npz")
+    ref_log = _lines(prefix + ".log")
+    assert not any(l.startswith("!") for l in ref_log), [l for l in ref_log if l.startswith("!")]
+    ranges, odom = _queue(n_scans, kind)
+    log = str(tmp_path / "hip.log")
+    m = Mapper(synth.Laser(), loop_search_maximum_distance=loop_dist, log_path=log)
+    for i in range(n_scans):
+        m.Process(ranges[i], odom[i], 0.1 * i)
+        for at, node in schedule:
+            if at == i:
+                m.RemoveNode(node)
+    alive = m.alive()
+    poses = m.poses()[alive]
+    m.set_log(None)
+    hip_log = _lines(log)
+    m.close()
+    assert sum(l.startswith("D ") for l in ref_log) == len(schedule) and sum(l.startswith("E ") for l in ref_log) >= len(schedule)
+    for k, (a, b) in enumerate(zip(ref_log, hip_log)):
+        assert a == b, f"solver-call logs diverge at line {k}:\n  reference: {a}\n  mapper   : {b}"
+    assert len(ref_log) == len(hip_log)
+    assert np.array_equal(ref["poses"][:, 0].astype(np.int32), alive)
+    assert np.array_equal(ref["poses"][:, 1:], poses), "final corrected poses differ"
+
+
+def test_lifelong_decay_bounds_the_graph(kartohip_lib):
+    """evaluateNodeDepreciation after every accepted scan (slam_toolbox_lifelong.cpp:149-178): on a circuit driven lap after
+    lap the nodes of earlier laps decay and leave, so the graph stays bounded while the mapper keeps closing loops."""
+    from slam_toolbox_amd.mapper import Mapper
+    n_scans = 700
+    ranges, odom = _queue(n_scans, "laps")
+    m = Mapper(synth.Laser())
+    m.SetLifelong(True)
+    for i in range(n_scans):
+        m.Process(ranges[i], odom[i], 0.1 * i)
+    st = m.stats()
+    alive = m.alive()
+    print(f"lifelong: {m.num_scans()} scans accepted, {len(alive)} alive, {st['nodes_removed']} removed, {st['loop_closures']} closures, "
+          f"lifelong step {st['lifelong_ms']:.0f} ms of {st['process_ms']:.0f} ms")
+    assert st["nodes_removed"] > 0 and st["loop_closures"] > 0
+    assert len(alive) + st["nodes_removed"] == m.num_scans()
+    assert 0 in alive and 1 in alive                      # the critical lynch points are never removed (:270-272)
+    m.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
-out=$GRAFT_REPO_ROOT/gpurun_out/r2d
+out=$GRAFT_REPO_ROOT/gpurun_out/r2e
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_mapper_gpu.py tests/test_comm_gpu.py tests/test_matcher_gpu.py tests/test_loops_gpu.py tests/test_spa_sharded_gpu.py -m gpu -q -rs -s > $out/pytest.log 2>&1
+timeout 900 python -m pytest tests/test_mapper_gpu.py tests/test_loops_gpu.py tests/test_lifelong_gpu.py -m gpu -q -rs -s > $out/pytest.log 2>&1
 echo "pytest rc=$?" >> $out/pytest.log
 grep -v "^Registering\|^Unregistering\|amdgpu.ids" $out/pytest.log | tail -40
