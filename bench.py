@@ -165,8 +165,26 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
         return None
     g = synth.make_pose_graph(10000, 30000, seed=12345)
     sol = HipSpaSolver(device=device)
+    collective = "none"
     if world > 1:
-        sol.enable_sharding(rank, world)
+        # the all-reduce of H || g runs INSIDE the library (ncclAllReduce of RCCL, kh_spa_set_comm); the 128-byte
+        # communicator id travels over the process group that already exists.  Should RCCL refuse (e.g. ranks sharing a
+        # device in a functional run), the C-ABI callback path through torch.distributed takes over.
+        import torch
+        import torch.distributed as dist
+        from slam_toolbox_amd import comm as khcomm
+        try:
+            uid = torch.zeros(khcomm.ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.from_numpy(khcomm.unique_id().copy())
+            uid = uid.to("cuda") if dist.get_backend() == "nccl" else uid
+            dist.broadcast(uid, src=0)
+            communicator = khcomm.Communicator(device, rank, world, uid.cpu().numpy())
+            sol.SetCommunicator(communicator)
+            collective = "in-library ncclAllReduce (RCCL)"
+        except Exception as exc:
+            sol.enable_sharding(rank, world)
+            collective = f"torch.distributed.all_reduce through the C-ABI callback ({type(exc).__name__})"
     # config[3] says "serialized pose graph": the graph goes through the library's own file format
     # (kh_spa_save / kh_spa_load, binary) before every solve, like loadSerializedPoseGraph rebuilds the plugin
     import tempfile
@@ -189,7 +207,7 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
     out = {key: float(np.median(times)) * 1e3, "solve_graph_load_ms": float(np.median(loads)) * 1e3,
            "solve_iterations": int(summ["iterations"]),
            "solve_final_cost": float(summ["final_cost"]), "solve_graph": "10000 nodes / 30000 edges",
-           "solve_parallelism": "1 GPU" if world == 1 else f"{world} GPUs: edge-block linearisation + all-reduce(H, g), replicated factorisation",
+           "solve_parallelism": "1 GPU" if world == 1 else f"{world} GPUs: edge-block linearisation + all-reduce(H, g) [{collective}], replicated factorisation",
            "solve_symbolic_ms": float(summ["symbolic_ms"]), "solve_nnz_factor": int(summ["nnz_factor"]),
            "solve_levels": int(summ["levels"])}
     if world == 1 and summ["factorizations"] > 0:
@@ -347,6 +365,72 @@ def loop_cpu_baseline(lb, n_sample=32):
         dt = time.time() - t0
     return {"value": len(work) / dt, "unit": "pairs/s", "cores": cores, "kind": "reference",
             "sample": f"{len(work)} of the batch's pairs, {T} concurrent (L, S) matcher pairs x {max(1, cores // T)} threads, {dt:.1f} s"}
+
+
+def strong_leg(device=0, rank=0, world=1, n_pairs=2048, distinct=256, batch=256):
+    """Strong scaling of the candidate matcher: a FIXED set of n_pairs loop-closure candidate
+    pairs (the config[2] batch, tiled) is dealt round-robin to the ranks, every rank coarse-matches its share on its GPU
+    (preset L MatchScan, doPenalize / doRefineMatch false), the 13 result doubles per pair are collected with one fixed-size
+    all-gather (RCCL with backend nccl) and TryCloseLoop's first-acceptance rule is applied to the gathered table.  Time =
+    max over ranks from the first match to the gathered table.  Every rank takes part; rank 0 reports (extra key)."""
+    from common import LASER, OFFLINE_PARAMS, PRESETS
+    from slam_toolbox_amd import shard, synth
+    from slam_toolbox_amd.scan_matcher import LocalizedRangeScan, MapperParams, ScanMatcher
+    import torch
+    lb = synth.loop_batch(distinct)
+    cache = {}
+
+    def scan_at(i):
+        if i not in cache:
+            cache[i] = LocalizedRangeScan(lb["ranges"][i], lb["truth"][i], LASER.min_angle, LASER.ang_res)
+        return cache[i]
+    queries = [LocalizedRangeScan(lb["ranges"][q], pose, LASER.min_angle, LASER.ang_res) for q, pose, _ in lb["pairs"]]
+    chains = [[scan_at(i) for i in chain] for _, _, chain in lb["pairs"]]
+    m = ScanMatcher.Create(MapperParams(**OFFLINE_PARAMS), *PRESETS["L"]["create"], device=device, max_batch=batch)
+    packs = {}
+
+    def match_fn(units):
+        key = tuple(u % distinct for u in units)
+        if key not in packs:
+            packs[key] = ScanMatcher.pack_batch([queries[u] for u in key], [chains[u] for u in key])
+        resp, means, covs, _ = m.MatchScanBatch(None, None, False, False, packed=packs[key])
+        return resp, means, covs
+    dev = "cuda" if world > 1 else "cpu"
+
+    def once():
+        return shard.match_candidates_sharded(match_fn, n_pairs, rank, world, batch=batch, device=dev)
+    once()                                                    # warm-up: allocations, marshalling
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t = time.perf_counter()
+        table = once()
+        times.append(shard.max_over_ranks(time.perf_counter() - t, device=dev))
+    m.close()
+    med = float(np.median(times))
+    return {"strong_scaling": {"pairs": n_pairs, "n_gpus": world, "ms": med * 1e3, "pairs_per_s": n_pairs / med,
+                               "first_accepted": int(shard.first_accepted(table, 0.35, 9.0)),
+                               "workload": f"{n_pairs} candidate pairs ({distinct} distinct, tiled) preset L coarse MatchScan, "
+                                           f"round-robin over {world} rank(s), one all-gather of {n_pairs} x 13 doubles"}}
+
+
+def replay_leg(device=0, n_scans=3000):
+    """BASELINE config[4]: lifelong-mode replay, end to end on one GPU -- scan queue -> mapper front end of the library
+    (sequential match, links, speculative loop closure, SPA solves, node decay) -> occupancy grid (extra keys).  The
+    default run replays a bounded prefix; profiles/r2_replay_50k_lifelong.json holds the 50 000-scan run of the same
+    command (tools/replay.py --scans 50000)."""
+    from slam_toolbox_amd import replay
+    out = replay.run(n_scans, lifelong=True, mode="sync", device=device)
+    st = out["stats"]
+    return {"replay_scans_per_s": out["scans_per_s"], "replay_workload": f"{n_scans}-scan lap circuit, lifelong mode, sync queue: "
+            f"{out['accepted']} accepted, {out['alive']} alive after node decay, {st['loop_closures']} loop closures, "
+            f"{st['matches']} matches", "replay_wall_s": out["wall_s"],
+            "replay_ms_split": {"match": st["match_ms"], "solver": st["solver_ms"], "pose_updates": st["update_ms"], "node_decay": st["lifelong_ms"]},
+            "replay_map_build_ms": out["map_build_ms"], "replay_map_iou_vs_truth_poses": out["map_iou_vs_truth_poses"],
+            "replay_pose_error_xy_rms_m": out["pose_error_xy_rms_m"],
+            "replay_50k": "profiles/r2_replay_50k_lifelong.json"}
 
 
 def enumeration_leg(device=0, n_scans=10000, n_queries=256):
@@ -574,6 +658,14 @@ def main():
                 solver_out = solver_leg(local_rank, rank, world, cpu=not args.no_cpu_baseline)
             except Exception as exc:      # the headline line must survive a failure of the extra leg
                 solver_out = {"solver_leg_error": repr(exc)[:200]}
+    strong_out = None
+    if not args.no_loop:
+        if world > 1:
+            dist.barrier()
+        try:
+            strong_out = strong_leg(local_rank, rank, world)
+        except Exception as exc:
+            strong_out = {"strong_leg_error": repr(exc)[:200]}
     if rank == 0:
         k3_ms = prof["score_ms"] / max(1, prof["score_launches"])
         # a step's batch is scored in sub-batches (pipelined with the host half): matches per k_score launch
@@ -625,10 +717,16 @@ def main():
             out["two_stream_ms_per_step"] = two_stream / args.steps * 1e3
         if solver_out:
             out.update(solver_out)
+        if strong_out:
+            out.update(strong_out)
         if world == 1 and not args.no_loop:
             out.update(loop_leg(local_rank, cpu=not args.no_cpu_baseline))
             out.update(enumeration_leg(local_rank))
             out.update(occupancy_leg(local_rank))
+            try:
+                out.update(replay_leg(local_rank))
+            except Exception as exc:
+                out["replay_leg_error"] = repr(exc)[:200]
         print(json.dumps(out), flush=True)
     for h in handles:
         h.close()

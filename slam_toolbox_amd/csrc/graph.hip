@@ -144,6 +144,7 @@ struct kh_graph
   int32_t device = 0;
   hipStream_t stream = nullptr;
   int32_t n = 0;
+  bool device_stale = false;   // the host copy is newer than the device arrays (uploaded by the next enumeration kernel)
   int32_t n_visit = 0;     // scans the candidate walks visit (kh_graph_set_scan_limit; = n unless scans were removed)
   double * d_xy = nullptr; size_t cap_xy = 0;
   int32_t * d_adj_ptr = nullptr; size_t cap_ptr = 0;
@@ -207,18 +208,9 @@ int kh_graph_set(kh_graph * g, int32_t n_scans, const double * ref_xy, const int
   for (size_t k = 0; k < n_adj; ++k) {
     if (adj_idx[k] < 0 || adj_idx[k] >= n_scans) {set_error("kh_graph_set: adjacency index out of range"); return KH_ERR_INVALID_ARG;}
   }
-  int rc = ensure(g->d_xy, g->cap_xy, std::max<size_t>(2 * n, 2)); if (rc) {return rc;}
-  rc = ensure(g->d_adj_ptr, g->cap_ptr, n + 1); if (rc) {return rc;}
-  rc = ensure(g->d_adj_idx, g->cap_idx, std::max<size_t>(n_adj, 1)); if (rc) {return rc;}
-  if (n) {
-    if (hipMemcpy(g->d_xy, ref_xy, 2 * n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(g->d_adj_ptr, adj_ptr, (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
-      (n_adj && hipMemcpy(g->d_adj_idx, adj_idx, n_adj * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess))
-    {
-      set_error("kh_graph_set: upload failed");
-      return KH_ERR_HIP;
-    }
-  }
+  // the neighbourhood walks (near chains, near linked) read the host copy; the device arrays are refreshed when an
+  // enumeration kernel next needs them (a mapper sets the graph several times per scan and enumerates once)
+  g->device_stale = true;
   g->n = n_scans; g->n_visit = n_scans;
   g->h_xy.assign(ref_xy, ref_xy + 2 * n);
   g->h_adj_ptr.assign(adj_ptr, adj_ptr + (n ? n + 1 : 0));
@@ -230,11 +222,8 @@ int kh_graph_set_positions(kh_graph * g, int32_t n_scans, const double * ref_xy)
 {
   if (!g || !ref_xy || n_scans != g->n) {return KH_ERR_INVALID_ARG;}
   if (hipSetDevice(g->device) != hipSuccess) {return KH_ERR_HIP;}
-  if (n_scans && hipMemcpy(g->d_xy, ref_xy, 2 * static_cast<size_t>(n_scans) * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-    set_error("kh_graph_set_positions: upload failed");
-    return KH_ERR_HIP;
-  }
   g->h_xy.assign(ref_xy, ref_xy + 2 * static_cast<size_t>(n_scans));
+  g->device_stale = true;
   return KH_OK;
 }
 
@@ -261,6 +250,21 @@ int kh_graph_find_loop_candidates_from(
     if (query_scans[i] < 0 || query_scans[i] >= g->n) {set_error("kh_graph_find_loop_candidates: unknown scan"); return KH_ERR_NOT_FOUND;}
   }
   if (hipSetDevice(g->device) != hipSuccess) {return KH_ERR_HIP;}
+  if (g->device_stale) {
+    const size_t ns = static_cast<size_t>(g->n), n_adj = g->h_adj_idx.size();
+    int urc = ensure(g->d_xy, g->cap_xy, std::max<size_t>(2 * ns, 2)); if (urc) {return urc;}
+    urc = ensure(g->d_adj_ptr, g->cap_ptr, ns + 1); if (urc) {return urc;}
+    urc = ensure(g->d_adj_idx, g->cap_idx, std::max<size_t>(n_adj, 1)); if (urc) {return urc;}
+    if (hipMemcpyAsync(g->d_xy, g->h_xy.data(), 2 * ns * sizeof(double), hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+      hipMemcpyAsync(g->d_adj_ptr, g->h_adj_ptr.data(), (ns + 1) * sizeof(int32_t), hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+      (n_adj && hipMemcpyAsync(g->d_adj_idx, g->h_adj_idx.data(), n_adj * sizeof(int32_t), hipMemcpyHostToDevice, g->stream) != hipSuccess) ||
+      hipStreamSynchronize(g->stream) != hipSuccess)
+    {
+      set_error("kh_graph: upload failed");
+      return KH_ERR_HIP;
+    }
+    g->device_stale = false;
+  }
   const size_t nq = static_cast<size_t>(n_queries), n = static_cast<size_t>(g->n);
   // a run needs at least one terminator, so a query has at most n / 2 + 1 chains; min_chain bounds it further
   const int32_t per_query = static_cast<int32_t>(std::min<size_t>(n / std::max(1, min_chain_size + 1) + 2, n / 2 + 1));

@@ -144,17 +144,32 @@ int kh_lifelong_scores(int32_t device, const kh_scan_box * reference, int32_t n,
     pts.insert(pts.end(), candidates[k].points_xy, candidates[k].points_xy + 2 * static_cast<size_t>(candidates[k].n_points));
   }
   const BoxDev ref = box(*reference);
-  BoxDev * d_boxes = nullptr; double * d_pts = nullptr; double * d_out = nullptr; int32_t * d_kept = nullptr;
+  // device scratch kept between calls (a mapper scores the neighbourhood of every accepted scan: four allocations and
+  // frees per call cost more than the two kernels); one set per calling thread and device
+  struct Scratch
+  {
+    int32_t device = -1;
+    BoxDev * boxes = nullptr; double * pts = nullptr; double * out = nullptr; int32_t * kept = nullptr;
+    size_t cap_boxes = 0, cap_pts = 0, cap_out = 0, cap_kept = 0;
+    void release() {(void)hipFree(boxes); (void)hipFree(pts); (void)hipFree(out); (void)hipFree(kept); *this = Scratch();}
+    ~Scratch() {}          // freed with the process: the HIP runtime may already be gone when thread-local destructors run
+  };
+  static thread_local Scratch scratch;
+  if (scratch.device != device) {if (scratch.device >= 0) {scratch.release();} scratch.device = device;}
   auto fail = [&](const char * what) {
     set_error(std::string("kh_lifelong_scores: ") + what);
-    (void)hipFree(d_boxes); (void)hipFree(d_pts); (void)hipFree(d_out); (void)hipFree(d_kept);
     return KH_ERR_HIP;
   };
   const size_t nn = static_cast<size_t>(n);
-  if (hipMalloc(reinterpret_cast<void **>(&d_boxes), nn * sizeof(BoxDev)) != hipSuccess ||
-    hipMalloc(reinterpret_cast<void **>(&d_pts), std::max<size_t>(pts.size(), 2) * 8) != hipSuccess ||
-    hipMalloc(reinterpret_cast<void **>(&d_out), 4 * nn * 8) != hipSuccess ||
-    hipMalloc(reinterpret_cast<void **>(&d_kept), (nn + 1) * 4) != hipSuccess) {return fail("allocation failed");}
+  auto grow = [&](auto *& p, size_t & cap, size_t need) {
+    if (need <= cap) {return true;}
+    if (p) {(void)hipFree(p); p = nullptr;}
+    cap = std::max(need, 2 * cap);
+    return hipMalloc(reinterpret_cast<void **>(&p), cap * sizeof(*p)) == hipSuccess;
+  };
+  if (!grow(scratch.boxes, scratch.cap_boxes, nn) || !grow(scratch.pts, scratch.cap_pts, std::max<size_t>(pts.size(), 2)) ||
+    !grow(scratch.out, scratch.cap_out, 4 * nn) || !grow(scratch.kept, scratch.cap_kept, nn + 1)) {scratch.release(); return fail("allocation failed");}
+  BoxDev * d_boxes = scratch.boxes; double * d_pts = scratch.pts; double * d_out = scratch.out; int32_t * d_kept = scratch.kept;
   if (hipMemcpy(d_boxes, boxes.data(), nn * sizeof(BoxDev), hipMemcpyHostToDevice) != hipSuccess ||
     (!pts.empty() && hipMemcpy(d_pts, pts.data(), pts.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ||
     hipMemset(d_kept + nn, 0, 4) != hipSuccess) {return fail("upload failed");}
@@ -173,7 +188,6 @@ int kh_lifelong_scores(int32_t device, const kh_scan_box * reference, int32_t n,
     if (scores) {scores[k] = out[3 * nn + k];}
     if (kept) {kept[k] = k_host[k];}
   }
-  (void)hipFree(d_boxes); (void)hipFree(d_pts); (void)hipFree(d_out); (void)hipFree(d_kept);
   return KH_OK;
 }
 

@@ -33,7 +33,7 @@ def _lines(path):
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libkarto_ref_slam.so not built (needs /root/reference)")
-@pytest.mark.parametrize("n_scans,loop_dist,kind", [(500, 3.0, "laps"), (230, 5.0, "sweep")])
+@pytest.mark.parametrize("n_scans,loop_dist,kind", [(500, 3.0, "laps"), (230, 5.0, "sweep"), (2000, 3.0, "laps")])
 def test_mapper_front_end_equals_the_reference_mapper(kartohip_lib, tmp_path, n_scans, loop_dist, kind):
     from slam_toolbox_amd.mapper import Mapper
     runner = os.path.join(ROOT, "tests", "ref_slam_runner.py")
