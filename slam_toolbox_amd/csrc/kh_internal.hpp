@@ -67,6 +67,10 @@ struct RasterJob
   int32_t * hvals;           // hcap: smallest job point index that falls into the cell (reset to INT32_MAX)
   uint8_t * hstate;          // hcap: 0 undecided, 1 active, 2 inactive
   int32_t * hnbr;            // hcap * kMaxFootprint: slot of the neighbouring cell's entry, -1 = none
+  // re-pitched copies of the grid for the scoring kernel (see CorrJob::grid2), kept in step with the grid tile by tile
+  uint8_t * grid2;           // nullptr = this slot has none
+  int32_t pitch2, copy_b;
+  int32_t * prev_work;       // [0] = number of tiles the PREVIOUS rasterisation touched, [4 ...] = their indices
 };
 constexpr int32_t kRasterTile = 64;
 
@@ -117,6 +121,16 @@ struct CorrJob
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
   unsigned long long * out;  // result block, see below
+  // Re-pitched copies (dual-copy layout).  A wave-level load of K3 reads four 64-byte row segments; in the grid's own
+  // pitch (a multiple of 8) a segment straddles a 128-byte cache line almost half of the time, and every straddle is one
+  // more L1 tag lookup (measured 6.3 per load, 4 rows x ~1.5 lines).  Copy A holds the same bytes at a pitch that is a
+  // multiple of 128, copy B the same again 64 bytes further along every row: for any window, one of the two has every
+  // row segment inside ONE line (4 lookups per load).  K2 picks the copy per beam and stores the offset in copy
+  // coordinates in a second set of lists; windows that wrap around the row end keep reading the grid itself.
+  const uint8_t * grid2;     // copy A; nullptr = none.  copy B = grid2 + copy_b
+  int32_t pitch2, copy_b;
+  int32_t * fast2;           // like `fast`, offsets into grid2
+  int32_t * tcounts2;        // like `tcounts`
   unsigned long long * load_counter;   // handle-wide tally of the row loads K3 will issue for the fast lists K2 builds (wave-level
                                        // dword-load instructions, 256 B each): the L1 side of the roofline; nullptr = not counted
 };
@@ -134,6 +148,8 @@ void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int3
 void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_cap, void * stream);
 void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
 void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream);
+void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles, void * stream);          // after launch_raster
+void launch_repitch_full(const RasterJob * d_job, int32_t rows, void * stream);                             // one job: whole grid
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
                   int32_t sx_variant, int32_t ry, void * stream);

@@ -130,6 +130,9 @@ struct Slot
   uint8_t * d_grid = nullptr;        // first grid byte (256-byte aligned); the allocation has kGridPad zero bytes either side
   uint8_t * d_grid_alloc = nullptr;
   uint32_t * d_blockmap = nullptr;   // bm_w x bm_h occupancy blocks of this grid (cleared and marked with it)
+  uint8_t * d_grid2 = nullptr;       // re-pitched copies A and B (CorrJob::grid2), allocated at the first search that profits
+  uint8_t * d_grid2_alloc = nullptr;
+  int32_t * d_prev_work = nullptr;   // tiles the previous rasterisation touched (what has to be zeroed in the copies)
   double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
   // correlate scratch
   int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
@@ -177,6 +180,8 @@ struct kh_matcher
   bool dense_score = false;        // kh_matcher_set_debug bit 2: do not skip beams whose window is empty
   int32_t bm_w = 0, bm_h = 0;
   int32_t rt_w = 0, rt_h = 0;      // rasteriser tiles over the grid
+  int32_t pitch2 = 0, copy_b = 0;  // dual-copy layout: row pitch (multiple of 128) and byte offset of copy B
+  bool dual_copy = true;           // kh_matcher_set_debug bit 4 switches the re-pitched copies off (measurements)
   bool lds_score = false;          // experimental LDS-staged scoring path (kh_matcher_set_debug bit 1)
   // profiling
   bool profiling = false;
@@ -353,6 +358,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   });
   const int32_t n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
   int32_t max_points = 0, max_cap = 0;
+  bool any_copies = false;
   ValidItem * items = reinterpret_cast<ValidItem *>(m->h_meta + items_at);
   size_t item = 0;
   for (size_t r = 0; r < n_jobs; ++r) {
@@ -393,6 +399,8 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
     j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
     j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * std::max<size_t>(np, 1);
+    j.grid2 = s.d_grid2; j.pitch2 = m->pitch2; j.copy_b = m->copy_b; j.prev_work = s.d_prev_work;
+    any_copies = any_copies || s.d_grid2 != nullptr;
     j.n_foot = n_foot;
     if (n_foot > 0) {
       // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon as the smear kernel
@@ -427,6 +435,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), m->stream);
   if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
   launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->stream);
+  if (any_copies) {launch_repitch(m->d_rjobs, static_cast<int32_t>(n_jobs), m->rt_w * m->rt_h, m->stream);}
   KH_HIP(hipGetLastError());
   if (timing) {
     std::fprintf(stderr, "[kh raster] host %.3f ms: %zu jobs, %zu (job, scan) items, %zu distinct scans, %.1f MB of points uploaded\n",
@@ -454,6 +463,36 @@ struct CorrReq
   // results
   double mean[3]; double cov[9]; double response; int status;
 };
+
+static inline double q_res_x(const CorrReq & q) {return q.res_x;}
+
+// Re-pitched copies of a slot's grid (CorrJob::grid2): allocated zeroed, filled from the grid as it stands, kept in step by
+// raster_batch from then on.
+static int allocate_copies(kh_matcher * m, Slot & s)
+{
+  const size_t rows = static_cast<size_t>(m->data_size / m->ws);
+  const size_t bytes = static_cast<size_t>(m->copy_b) * 2 + 2 * kGridPad;
+  KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_grid2_alloc), bytes));
+  KH_HIP(hipMemsetAsync(s.d_grid2_alloc, 0, bytes, m->stream));
+  s.d_grid2 = s.d_grid2_alloc + kGridPad;
+  const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
+  KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_prev_work), (nt + 4) * sizeof(int32_t)));
+  KH_HIP(hipMemsetAsync(s.d_prev_work, 0, (nt + 4) * sizeof(int32_t), m->stream));
+  // one-job descriptor for the full copy: only the fields k_repitch_full / k_repitch_keep read
+  RasterJob j;
+  std::memset(&j, 0, sizeof(j));
+  j.grid = s.d_grid; j.ws = m->ws; j.height = static_cast<int32_t>(rows);
+  j.grid2 = s.d_grid2; j.pitch2 = m->pitch2; j.copy_b = m->copy_b; j.prev_work = s.d_prev_work;
+  const size_t nt2 = nt;
+  j.n_work = s.d_rtiles + 2 * nt2; j.work = s.d_rtiles + 3 * nt2 + 4;
+  RasterJob * d_j = nullptr;
+  KH_HIP(hipMalloc(reinterpret_cast<void **>(&d_j), sizeof(RasterJob)));
+  KH_HIP(hipMemcpyAsync(d_j, &j, sizeof(RasterJob), hipMemcpyHostToDevice, m->stream));
+  launch_repitch_full(d_j, static_cast<int32_t>(rows), m->stream);
+  KH_HIP(hipStreamSynchronize(m->stream));       // `j` is on this stack, and the side streams may read the copies next
+  KH_HIP(hipFree(d_j));
+  return KH_OK;
+}
 
 static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na)
 {
@@ -634,8 +673,16 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       size_t lt = static_cast<size_t>((c.nx + 30) / 31) * ((c.ny + 4 * pick_ry(c.ny) - 1) / (4 * pick_ry(c.ny)));
       if (lt > 32) {lt = 1;}
       c.lt_alloc = static_cast<int32_t>(lt);
-      rc = ensure_device(s.d_fast, s.cap_fast, tp * kClasses * lt, m->stream); if (rc) {return rc;}
-      rc = ensure_device(s.d_tcounts, s.cap_tcounts, static_cast<size_t>(c.na) * kClasses * lt, m->stream); if (rc) {return rc;}
+      // (twice: the second half holds the lists into the re-pitched copies)
+      rc = ensure_device(s.d_fast, s.cap_fast, 2 * tp * kClasses * lt, m->stream); if (rc) {return rc;}
+      rc = ensure_device(s.d_tcounts, s.cap_tcounts, 2 * static_cast<size_t>(c.na) * kClasses * lt, m->stream); if (rc) {return rc;}
+      // dual-copy layout: worth its memory (2 x the grid) and upkeep for full-resolution searches with many angles whose
+      // window is one tile wide -- the config-2 CorrelateScan; decided from the request alone, allocated once per slot
+      const double work = static_cast<double>(c.nx) * c.ny * c.na * c.P;
+      const bool full_res = c.nx > 1 && std::fabs(q_res_x(reqs[i]) * m->scale - 1.0) < 1e-9 && c.nx <= kTileSpan;
+      if (m->dual_copy && !s.d_grid2 && full_res && work >= 1e8) {
+        rc = allocate_copies(m, s); if (rc) {return rc;}
+      }
     }
     {
       const size_t groups = (static_cast<size_t>(c.na) + kGroupAngles - 1) / kGroupAngles;
@@ -788,6 +835,15 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i;
     job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
     job->tile_best = s.d_tile_best;
+    // re-pitched copies: linear full-resolution lattice one tile wide (the copy is picked per beam for the tile at x0 = 0)
+    {
+      const bool use2 = s.d_grid2 != nullptr && m->dual_copy && linear && this_sx == 1 && job->tiles_x == 1;
+      const size_t lists = static_cast<size_t>(c.na) * kClasses * static_cast<size_t>(c.lt_alloc);
+      job->grid2 = use2 ? s.d_grid2 : nullptr;
+      job->pitch2 = m->pitch2; job->copy_b = m->copy_b;
+      job->fast2 = s.d_fast + lists * static_cast<size_t>(c.P);
+      job->tcounts2 = s.d_tcounts + lists;
+    }
     job->load_counter = m->profiling ? m->d_load_counter : nullptr;
   });
   bool all_lds = true;
@@ -1213,6 +1269,12 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_load_counter), 8)) != hipSuccess) {return fail(e, "hipMalloc counter");}
   if ((e = hipMemset(m->d_load_counter, 0, 8)) != hipSuccess) {return fail(e, "hipMemset counter");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
+  m->pitch2 = static_cast<int32_t>(align_up(static_cast<size_t>(m->ws), 128));
+  {
+    const size_t copy = align_up(static_cast<size_t>(m->pitch2) * (m->data_size / m->ws) + 256, 256);
+    if (2 * copy + 256 > (1ull << 31) - 4096) {m->dual_copy = false;}        // offsets into the copies are int32
+    m->copy_b = static_cast<int32_t>(std::min<size_t>(copy, (1ull << 30)));
+  }
   m->rt_w = (m->ws + kRasterTile - 1) / kRasterTile;
   m->rt_h = (m->data_size / m->ws + kRasterTile - 1) / kRasterTile;
   m->bm_w = (((m->ws >> kBlockShift) + 1) + 31) / 32 + 1;     // words per block row (+1 padding word)
@@ -1238,7 +1300,7 @@ void kh_matcher_destroy(kh_matcher * m)
   hipSetDevice(m->device);
   if (m->stream) {hipStreamSynchronize(m->stream);}
   for (auto & s : m->slots) {
-    hipFree(s.d_grid_alloc); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_tile_best); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_tcounts); hipFree(s.d_slow); hipFree(s.d_counts);
+    hipFree(s.d_grid_alloc); hipFree(s.d_grid2_alloc); hipFree(s.d_prev_work); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_tile_best); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_tcounts); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_ractive);
     hipFree(s.d_hkeys); hipFree(s.d_hvals); hipFree(s.d_hstate); hipFree(s.d_hnbr);
@@ -1284,6 +1346,7 @@ int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
   m->lds_score = (keep_response_volume & 2) != 0;
   m->dense_score = (keep_response_volume & 4) != 0;
   m->force_chunks = (keep_response_volume & 8) != 0;
+  m->dual_copy = (keep_response_volume & 16) == 0;
   return KH_OK;
 }
 

@@ -486,6 +486,77 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
   hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
 }
 
+// Re-pitched copies (CorrJob::grid2): the tiles the previous rasterisation touched are zeroed, the tiles this one touched
+// are copied from the grid, and this rasterisation's tile list becomes the "previous" one.  Traffic: 8 KB per touched tile.
+__device__ __forceinline__ void repitch_tile(const RasterJob & job, int t, bool zero)
+{
+  const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
+  const int ox = tx * kRasterTile, oy = ty * kRasterTile;
+  for (int i = threadIdx.x; i < kRasterTile * kRasterTile / 4; i += blockDim.x) {
+    const int row = i >> 4, wcol = i & 15;
+    const int y = oy + row, x = ox + 4 * wcol;
+    if (y >= job.height || x >= job.ws) {continue;}
+    const uint32_t v = zero ? 0u : reinterpret_cast<const uint32_t *>(job.grid)[((size_t)y * job.ws + x) >> 2];
+    const size_t at = (size_t)y * job.pitch2 + x;
+    *reinterpret_cast<uint32_t *>(job.grid2 + at) = v;
+    *reinterpret_cast<uint32_t *>(job.grid2 + job.copy_b + 64 + at) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_repitch(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  if (!job.grid2) {return;}
+  const int n_prev = job.prev_work[0], n_work = job.n_work[0];
+  for (int w = blockIdx.x; w < n_prev; w += gridDim.x) {repitch_tile(job, job.prev_work[4 + w], true);}
+  // a tile in both lists is zeroed and filled by different workgroups: order them through a second launch instead
+}
+__global__ __launch_bounds__(256) void k_repitch_fill(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  if (!job.grid2) {return;}
+  const int n_work = job.n_work[0];
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {repitch_tile(job, job.work[w], false);}
+}
+__global__ __launch_bounds__(256) void k_repitch_keep(const RasterJob * jobs)
+{
+  const RasterJob & job = jobs[blockIdx.x];
+  if (!job.grid2) {return;}
+  const int n_work = job.n_work[0];
+  for (int w = threadIdx.x; w < n_work; w += blockDim.x) {job.prev_work[4 + w] = job.work[w];}
+  if (threadIdx.x == 0) {job.prev_work[0] = n_work;}
+}
+
+void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles, void * stream)
+{
+  if (n_jobs <= 0) {return;}
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = std::min(max_tiles, 2048);
+  hipLaunchKernelGGL(k_repitch, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_repitch_fill, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_repitch_keep, dim3(n_jobs), dim3(256), 0, s, d_jobs);
+}
+
+// first use of the copies of a slot: the whole grid, row by row (the copies were zero-filled at allocation)
+__global__ __launch_bounds__(256) void k_repitch_full(const RasterJob * jobs, int rows)
+{
+  const RasterJob & job = jobs[0];
+  const int words = job.ws / 4;
+  for (int y = blockIdx.x; y < rows; y += gridDim.x) {
+    const uint32_t * src = reinterpret_cast<const uint32_t *>(job.grid + (size_t)y * job.ws);
+    uint32_t * a = reinterpret_cast<uint32_t *>(job.grid2 + (size_t)y * job.pitch2);
+    uint32_t * b = reinterpret_cast<uint32_t *>(job.grid2 + job.copy_b + 64 + (size_t)y * job.pitch2);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) {const uint32_t v = src[i]; a[i] = v; b[i] = v;}
+  }
+}
+
+void launch_repitch_full(const RasterJob * d_job, int32_t rows, void * stream)
+{
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_repitch_full, dim3(std::min(rows, 4096)), dim3(256), 0, s, d_job, (int)rows);
+  hipLaunchKernelGGL(k_repitch_keep, dim3(1), dim3(256), 0, s, d_job);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2: one workgroup per (angle, job).  Bit-exact table + compaction into the lists K3 walks.
 __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t stride)
@@ -495,6 +566,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   if (a >= job.na) {return;}
   __shared__ int32_t s_counts[kClasses + 1];
   __shared__ int32_t s_tcounts[kClasses * 32];
+  __shared__ int32_t s_tcounts2[kClasses * 32];
   __shared__ uint32_t s_bm[4096];
   __shared__ int4 s_tile_rect[32];       // per scoring tile: first / last cell (x, y) relative to the window start
   if (threadIdx.x < kClasses + 1) {s_counts[threadIdx.x] = 0;}
@@ -506,7 +578,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
     const int r0 = ty * ty_rows, r1 = min(job.ny, r0 + ty_rows) - 1;
     s_tile_rect[t] = make_int4(p0 * job.sx, r0 * job.sy_cells, p1 * job.sx, r1 * job.sy_cells);
   }
-  if (threadIdx.x < kClasses * 32) {s_tcounts[threadIdx.x] = 0;}
+  if (threadIdx.x < kClasses * 32) {s_tcounts[threadIdx.x] = 0; s_tcounts2[threadIdx.x] = 0;}
   const int lt = job.list_tiles;
   // small occupancy maps (coarse grids) are read from LDS: the per-tile tests make ~100 probes per beam
   const uint32_t * bmp = job.blockmap;
@@ -523,6 +595,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
   int32_t * table = job.table + (size_t)a * P;
   int32_t * fast = job.fast + (size_t)a * kClasses * lt * P;
+  int32_t * fast2 = job.grid2 ? job.fast2 + (size_t)a * kClasses * lt * P : nullptr;
   int32_t * slow = job.slow + (size_t)a * P;
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
     int32_t idx;
@@ -544,20 +617,25 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
       if ((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size) {continue;}  // off the grid for every pose
       if ((int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size) {
         uint32_t tmask = lt > 1 ? (0xffffffffu >> (32 - lt)) : 1u;
+        int32_t wx0 = 0, wy0 = 0;
+        bool in_row = false;                 // the window does not wrap around the row end
+        if (job.blockmap || job.grid2) {
+          // the window of this beam: x0 .. x0 + xs - 1 bytes of grid rows y0 .. y0 + ys - 1
+          const int32_t start = (int32_t)((int64_t)idx + bmin);
+          wy0 = (int32_t)((float)start * inv_ws);       // start / ws, fixed up below (start < 2^31, ws >= 8)
+          wx0 = start - wy0 * job.ws;
+          while (wx0 < 0) {wx0 += job.ws; --wy0;}
+          while (wx0 >= job.ws) {wx0 -= job.ws; ++wy0;}
+          in_row = wx0 + (job.nx - 1) * job.sx + 1 <= job.ws;
+        }
         if (job.blockmap) {
-          // the window of this beam: x0 .. x0 + xs - 1 bytes of grid rows y0 .. y0 + ys - 1.  If no stamp
-          // footprint overlaps any of its 32 x 32 blocks, every byte of it is 0 and the beam adds nothing
-          // to any pose of this angle: leave it out (bit-identical sums).  The same test per scoring tile
+          // If no stamp footprint overlaps any of the window's 32 x 32 blocks, every byte of it is 0 and the beam adds
+          // nothing to any pose of this angle: leave it out (bit-identical sums).  The same test per scoring tile
           // decides which tile lists the beam joins (large windows are rarely empty as a whole, their tiles
           // often are).  Windows that wrap around the row end (beams beyond the range threshold, Appendix
           // A.3) are kept everywhere.
-          const int32_t start = (int32_t)((int64_t)idx + bmin);
-          int32_t wy0 = (int32_t)((float)start * inv_ws);       // start / ws, fixed up below (start < 2^31, ws >= 8)
-          int32_t wx0 = start - wy0 * job.ws;
-          while (wx0 < 0) {wx0 += job.ws; --wy0;}
-          while (wx0 >= job.ws) {wx0 -= job.ws; ++wy0;}
           const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;
-          if (wx0 + xs <= job.ws) {
+          if (in_row) {
             auto any_block = [&](int x_lo, int y_lo, int x_hi, int y_hi) {
               const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
               const int by0 = y_lo >> kBlockShift, by1 = y_hi >> kBlockShift;
@@ -586,11 +664,23 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
         }
         // alignment class of the window start: K3 reads class-c windows with aligned dwords
         const int cls = (int)(((int64_t)idx + bmin) & (kClasses - 1));
+        // dual-copy layout: the aligned 64-byte segment K3 reads starts at wx0 - cls; the copy in which it does not
+        // straddle a 128-byte line (pitch2 is a multiple of 128, so every row of the window sits alike)
+        const bool dual = fast2 != nullptr && in_row;
+        int32_t idx2 = 0;
+        if (dual) {
+          const int32_t seg = wx0 - cls;
+          idx2 = wy0 * job.pitch2 + wx0 + ((seg & 127) > 64 ? job.copy_b + 64 : 0);
+        }
         while (tmask) {
           const int t = __builtin_ctz(tmask);
           tmask &= tmask - 1;
           const int li = cls * lt + t;
-          fast[(size_t)li * P + atomicAdd(&s_tcounts[li], 1)] = idx;
+          if (dual) {
+            fast2[(size_t)li * P + atomicAdd(&s_tcounts2[li], 1)] = idx2;
+          } else {
+            fast[(size_t)li * P + atomicAdd(&s_tcounts[li], 1)] = idx;
+          }
         }
         continue;
       }
@@ -599,11 +689,14 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   }
   __syncthreads();
   if (threadIdx.x < kClasses + 1) {job.counts[kCountsPerAngle * a + threadIdx.x] = s_counts[threadIdx.x];}
-  if ((int)threadIdx.x < kClasses * lt) {job.tcounts[(size_t)a * kClasses * lt + threadIdx.x] = s_tcounts[threadIdx.x];}
+  if ((int)threadIdx.x < kClasses * lt) {
+    job.tcounts[(size_t)a * kClasses * lt + threadIdx.x] = s_tcounts[threadIdx.x];
+    if (job.grid2) {job.tcounts2[(size_t)a * kClasses * lt + threadIdx.x] = s_tcounts2[threadIdx.x];}
+  }
   if (threadIdx.x == 0 && job.load_counter) {
     // every entry of a list costs K3 `ry` wave-level dword loads in each scoring tile that walks the list
     long long entries = 0;
-    for (int li = 0; li < kClasses * lt; ++li) {entries += s_tcounts[li];}
+    for (int li = 0; li < kClasses * lt; ++li) {entries += s_tcounts[li] + s_tcounts2[li];}
     const long long tiles_per_list = lt > 1 ? 1 : (long long)job.tiles_x * job.tiles_y;
     atomicAdd(job.load_counter, (unsigned long long)(entries * tiles_per_list * job.ry));
   }
@@ -705,33 +798,44 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
   // K2 keeps one list per (angle, class, scoring tile): the beams whose window has something in that tile
   const int lt = job.list_tiles;                 // tiles with lists of their own (1 = one list for all tiles)
   const size_t list_id = ((size_t)a * kClasses + cls) * lt + (lt > 1 ? tile : 0);
-  const int n_fast = live ? job.tcounts[list_id] : 0;
-  if (n_fast > 0) {
+  // SX == 2: poses sit on every other byte, the even or the odd ones depending on s
+  const uint32_t sel = (s & 1) ? 0x0c030c01u : 0x0c020c00u;
+  uint32_t lo[RY], hi[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {lo[r] = 0; hi[r] = 0;}
+  int since_flush = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      if (SX == 1) {
+        acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
+        acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
+      } else {
+        acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
+      }
+      lo[r] = 0; hi[r] = 0;
+    }
+    since_flush = 0;
+  };
+  // One list walk.  gbase = scalar part of the address (first byte of the lattice's window origin, moved back to the
+  // dword boundary; >= -3: the allocations have zero bytes in front), row_bytes = bytes per lattice row step.
+  // Offsets are fetched 64 at a time with one coalesced load and broadcast from the register with
+  // v_readlane, so the inner loop is: 1 SALU add for the window address, RY saddr-form aligned
+  // dword loads, 4 VALU per dword (2 at SX == 2).  Packed 16-bit partial sums are flushed every
+  // 512 beams (512 * 100 < 65536).
+  auto walk = [&](const gbyte * gbase, const gint * glist, const int n_list, const uint32_t row_bytes) {
+    if (n_list <= 0) {return;}
     // per-lane byte offset of row r inside the window; rows beyond ny are clamped (sums discarded)
     uint32_t voff[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       int yi = y0 + r * 4 + ly;
       yi = yi < job.ny ? yi : job.ny - 1;
-      voff[r] = (uint32_t)(4 * lx) + (uint32_t)yi * (uint32_t)job.sy_ws;
+      voff[r] = (uint32_t)(4 * lx) + (uint32_t)yi * row_bytes;
     }
-    // scalar part of the address: first grid byte of the lattice + tile origin, moved back to the
-    // dword boundary (>= -3: the allocation has kGridPad zero bytes in front)
-    const gbyte * gbase = as_global(job.grid) + ((int64_t)job.base0 + x0 * SX - s);
-    const gint * gfast = as_global(job.fast + list_id * P);
-    // SX == 2: poses sit on every other byte, the even or the odd ones depending on s
-    const uint32_t sel = (s & 1) ? 0x0c030c01u : 0x0c020c00u;
-    // Offsets are fetched 64 at a time with one coalesced load and broadcast from the register with
-    // v_readlane, so the inner loop is: 1 SALU add for the window address, RY saddr-form aligned
-    // dword loads, 4 VALU per dword (2 at SX == 2).  Packed 16-bit partial sums are flushed every
-    // 512 beams (512 * 100 < 65536).
-    uint32_t lo[RY], hi[RY];
-#pragma unroll
-    for (int r = 0; r < RY; ++r) {lo[r] = 0; hi[r] = 0;}
-    int since_flush = 0;
-    for (int jc = 0; jc < n_fast; jc += 64) {
-      const int cnt = min(64, n_fast - jc);
-      const int32_t mine = (lane < cnt) ? gfast[jc + lane] : 0;
+    for (int jc = 0; jc < n_list; jc += 64) {
+      const int cnt = min(64, n_list - jc);
+      const int32_t mine = (lane < cnt) ? glist[jc + lane] : 0;
       // UB beams per iteration: UB * RY loads are in flight before the first accumulate (the loop is
       // latency bound: ~1500 cycles per beam when every beam waits for its own loads)
       int k = 0;
@@ -770,20 +874,19 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
         }
       }
       since_flush += cnt;
-      if (since_flush + 64 > 512 || jc + 64 >= n_fast) {
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-          if (SX == 1) {
-            acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
-            acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
-          } else {
-            acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
-          }
-          lo[r] = 0; hi[r] = 0;
-        }
-        since_flush = 0;
-      }
+      if (since_flush + 64 > 512) {flush();}
     }
+  };
+  if (live) {
+    // the beams whose window lies inside a grid row read the re-pitched copy K2 chose for them (every row segment in one
+    // cache line), the few that wrap around the row end read the grid itself with its linear-index semantics
+    if (job.grid2) {
+      walk(as_global(job.grid2) + (x0 * SX - s), as_global(job.fast2 + list_id * P), job.tcounts2[list_id],
+        (uint32_t)job.pitch2 * (uint32_t)job.sy_cells);
+    }
+    walk(as_global(job.grid) + ((int64_t)job.base0 + x0 * SX - s), as_global(job.fast + list_id * P), job.tcounts[list_id],
+      (uint32_t)job.sy_ws);
+    flush();
   }
 
   // merge the four waves' partial sums: byte position j of the aligned tile row is pose (j - s) / SX

@@ -352,3 +352,34 @@ def test_ragged_batch_and_all_invalid_scan(kartohip_lib):
         _assert_same(c, covs[i], f"cov {i}")
     assert resp[2] == 0.0
     hmb.close()
+
+
+def test_dual_copy_layout_follows_the_grid(kartohip_lib):
+    """The re-pitched copies the full-resolution search reads (CorrJob::grid2) are built at the first search and then kept in
+    step with the grid tile by tile: a second, different scene rasterised into the same slot must score exactly like the
+    oracle again (stale tiles zeroed, new ones copied), and switching the copies off must not change a bit."""
+    import math
+    args = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+    om = make_oracle_matcher("C2", threads=8)
+    hm = make_hip_matcher("C2")
+    hm.set_debug(True)
+    results = []
+    for seed, start in ((7, 0), (8, 120), (9, 40)):
+        sc = Scenario(seed=seed, n_base=10, start=start)
+        oq, ob = sc.oracle_scans()
+        hq, hb = sc.hip_scans()
+        om.add_scans(oq, ob)
+        hm.AddScans(hq, hb)
+        r_o, mean_o, cov_o = om.correlate_scan(oq, sc.query_pose, *args, True, False)
+        r_h, mean_h, cov_h = hm.CorrelateScan(hq, sc.query_pose, *args, True, None, False)
+        vol = om.volume()
+        sums, resp = hm.volume()
+        assert np.array_equal(bits(vol[..., 0]), bits(resp)), f"scene {seed}: response volume differs"
+        _assert_same(r_o, r_h, "response"); _assert_same(mean_o, mean_h, "mean"); _assert_same(cov_o, cov_h, "covariance")
+        results.append((hq, sc.query_pose, sums.copy()))
+    hm.set_debug(True, no_dual_copy=True)
+    hq, pose, sums = results[-1]
+    hm.CorrelateScan(hq, pose, *args, True, None, False)
+    sums2, _ = hm.volume()
+    assert np.array_equal(sums, sums2)
+    hm.close()
