@@ -38,6 +38,7 @@ struct RasterJob
   const int32_t * scan_pt;   // n_scans: first point of base scan k in the arena
   const int32_t * scan_prefix;   // n_scans + 1: first job point of base scan k
   int32_t n_scans;
+  int32_t uniform_n;         // readings per base scan when all the job's scans have the same count (0 = ragged: bisect the prefix)
   double view_x, view_y;     // FindValidPoints' viewpoint = the query scan's sensor position (Mapper.cpp:572)
   uint8_t * active;          // n_points: 1 = the point is stamped.  Written by k_find_valid (FindValidPoints, Mapper.cpp:1113-1164),
                              // narrowed by the order-dependent "cell already occupied" rule (Mapper.cpp:1093-1096) when n_foot > 0

@@ -369,10 +369,11 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     s.off_y = pose[1] - (0.5 * (m->roi_h - 1) * res);
     int32_t * scan_pt = m->h_meta + meta_at[r];
     int32_t * scan_prefix = scan_pt + scans_of[r];
-    int32_t k = 0, run = 0;
+    int32_t k = 0, run = 0, uniform_n = -1;
     for (int32_t b = 0; b < reqs[r].n_base; ++b) {
       const kh_scan & sc = reqs[r].base[b];
       if (sc.points_xy == nullptr || sc.n <= 0) {continue;}
+      uniform_n = uniform_n < 0 ? sc.n : (uniform_n == sc.n ? uniform_n : 0);
       scan_pt[k] = arena_of.at(sc.points_xy);
       scan_prefix[k] = run;
       run += sc.n;
@@ -389,6 +390,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.grid = s.d_grid; j.arena = m->d_arena;
     j.scan_pt = m->d_meta + meta_at[r]; j.scan_prefix = m->d_meta + meta_at[r] + scans_of[r];
     j.n_scans = static_cast<int32_t>(scans_of[r]);
+    j.uniform_n = std::max(uniform_n, 0);
     j.view_x = pose[0]; j.view_y = pose[1];
     j.active = s.d_ractive; j.n_points = points_of[r];
     j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
@@ -679,8 +681,11 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       // dual-copy layout: worth its memory (2 x the grid) and upkeep for full-resolution searches with many angles whose
       // window is one tile wide -- the config-2 CorrelateScan; decided from the request alone, allocated once per slot
       const double work = static_cast<double>(c.nx) * c.ny * c.na * c.P;
-      const bool full_res = c.nx > 1 && std::fabs(q_res_x(reqs[i]) * m->scale - 1.0) < 1e-9 && c.nx <= kTileSpan;
-      if (m->dual_copy && !s.d_grid2 && full_res && work >= 1e8) {
+      // (the copy is picked per beam and scoring tile, so the lattice is one tile wide or has per-tile lists)
+      const double cells_per_step = q_res_x(reqs[i]) * m->scale;
+      const bool full_res = c.nx > 1 && std::fabs(cells_per_step - 1.0) < 1e-9 && c.nx <= kTileSpan;
+      const bool tiled_lists = lt > 1 && (std::fabs(cells_per_step - 1.0) < 1e-9 || std::fabs(cells_per_step - 2.0) < 1e-9);
+      if (m->dual_copy && !s.d_grid2 && (full_res || tiled_lists) && work >= 1e8) {
         rc = allocate_copies(m, s); if (rc) {return rc;}
       }
     }
@@ -837,7 +842,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->tile_best = s.d_tile_best;
     // re-pitched copies: linear full-resolution lattice one tile wide (the copy is picked per beam for the tile at x0 = 0)
     {
-      const bool use2 = s.d_grid2 != nullptr && m->dual_copy && linear && this_sx == 1 && job->tiles_x == 1;
+      const bool use2 = s.d_grid2 != nullptr && m->dual_copy && linear && (job->tiles_x == 1 || job->list_tiles > 1);
       const size_t lists = static_cast<size_t>(c.na) * kClasses * static_cast<size_t>(c.lt_alloc);
       job->grid2 = use2 ? s.d_grid2 : nullptr;
       job->pitch2 = m->pitch2; job->copy_b = m->copy_b;

@@ -169,6 +169,10 @@ void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream
 // job point p -> its world coordinates: base scan by bisection of the prefix (<= a few dozen scans), then the arena
 __device__ __forceinline__ double2 job_point(const RasterJob & job, int p)
 {
+  if (job.uniform_n > 0) {                      // the usual case: one laser, every scan has the same number of beams
+    const int k = p / job.uniform_n;
+    return reinterpret_cast<const double2 *>(job.arena)[job.scan_pt[k] + (p - k * job.uniform_n)];
+  }
   int lo = 0, hi = job.n_scans;                 // scan_prefix[lo] <= p < scan_prefix[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -312,48 +316,77 @@ void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_poi
   hipLaunchKernelGGL(k_active_set, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
 }
 
+// Adds 1 to counters[t] for every lane of the wave with t >= 0; the lanes that name the same counter share ONE atomic
+// (consecutive beams land in the same tile: without this a tile's counter takes hundreds of same-address atomics).
+// Returns the value the counter had before this lane's own increment.  Every lane of the wave must call it.
+__device__ __forceinline__ int wave_counter_add(int32_t * counters, int t)
+{
+  const int lane = threadIdx.x & 63;
+  int before = 0;
+  unsigned long long todo = __ballot(t >= 0);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const int t0 = __shfl(t, leader);
+    const unsigned long long same = __ballot(t == t0) & todo;
+    int base = 0;
+    if (lane == leader) {base = atomicAdd(&counters[t0], __builtin_popcountll(same));}
+    base = __shfl(base, leader);
+    if (t == t0) {before = base + __builtin_popcountll(same & ((1ull << lane) - 1ull));}
+    todo &= ~same;
+  }
+  return before;
+}
+
 __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.y];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= job.n_points) {return;}
-  int32_t * cell = job.cell_xy + 2 * (size_t)p;
-  cell[0] = -1; cell[1] = -1;
-  if (!job.active[p]) {return;}
-  int32_t gx, gy;
-  if (!roi_cell(job, job_point(job, p), gx, gy)) {return;}
-  if (job.n_foot > 0) {
-    // the order-dependent rule: only the first valid point of a cell can stamp, and only if k_active_set let it
-    const int32_t h = hash_find(job, (uint32_t)gy * (uint32_t)job.roi_w + (uint32_t)gx);
-    if (h < 0 || job.hvals[h] != p || job.hstate[h] != 1) {return;}
-  }
-  const int cx = gx + job.roi_x, cy = gy + job.roi_y;      // CorrelationGrid::GridIndex, Mapper.h:1122-1128
-  // the kernel's centre is 100 = its maximum: write it now and use the byte as the "cell already stamped" flag
-  const int32_t index = cx + cy * job.ws;
-  uint32_t * word = reinterpret_cast<uint32_t *>(job.grid) + (index >> 2);
-  const uint32_t bit = (uint32_t)kOccupied << (8 * (index & 3));
-  const uint32_t old = atomicOr(word, bit);
-  if (((old >> (8 * (index & 3))) & 0xffu) != 0) {return;}
-  cell[0] = cx; cell[1] = cy;
-  const int hk = job.kernel_size / 2;
-  {
-    const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
-    const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
-    for (int by = fy0; by <= fy1; ++by) {
-      for (int bx = fx0; bx <= fx1; ++bx) {
-        uint32_t * word = job.blockmap + (size_t)by * job.bm_w + (bx >> 5);
-        const uint32_t bit = 1u << (bx & 31);
-        if ((*word & bit) == 0) {atomicOr(word, bit);}
+  bool on = p < job.n_points;
+  int cx = -1, cy = -1;
+  if (on) {
+    int32_t * cell = job.cell_xy + 2 * (size_t)p;
+    cell[0] = -1; cell[1] = -1;
+    on = job.active[p] != 0;
+    int32_t gx = 0, gy = 0;
+    if (on) {on = roi_cell(job, job_point(job, p), gx, gy);}
+    if (on && job.n_foot > 0) {
+      // the order-dependent rule: only the first valid point of a cell can stamp, and only if k_active_set let it
+      const int32_t h = hash_find(job, (uint32_t)gy * (uint32_t)job.roi_w + (uint32_t)gx);
+      on = h >= 0 && job.hvals[h] == p && job.hstate[h] == 1;
+    }
+    if (on) {
+      cx = gx + job.roi_x; cy = gy + job.roi_y;              // CorrelationGrid::GridIndex, Mapper.h:1122-1128
+      // the kernel's centre is 100 = its maximum: write it now and use the byte as the "cell already stamped" flag
+      const int32_t index = cx + cy * job.ws;
+      uint32_t * word = reinterpret_cast<uint32_t *>(job.grid) + (index >> 2);
+      const uint32_t bit = (uint32_t)kOccupied << (8 * (index & 3));
+      const uint32_t old = atomicOr(word, bit);
+      on = ((old >> (8 * (index & 3))) & 0xffu) == 0;
+    }
+    if (on) {
+      cell[0] = cx; cell[1] = cy;
+      const int hk = job.kernel_size / 2;
+      const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
+      const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
+      for (int by = fy0; by <= fy1; ++by) {
+        for (int bx = fx0; bx <= fx1; ++bx) {
+          uint32_t * word = job.blockmap + (size_t)by * job.bm_w + (bx >> 5);
+          const uint32_t bit = 1u << (bx & 31);
+          if ((*word & bit) == 0) {atomicOr(word, bit);}
+        }
       }
     }
   }
-  const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
-  const int ty0 = (cy - hk) / kRasterTile, ty1 = (cy + hk) / kRasterTile;
-  for (int ty = ty0; ty <= ty1; ++ty) {
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      const int t = ty * job.tiles_w + tx;
-      if (atomicAdd(&job.tile_count[t], 1) == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}   // first point of the tile lists it
-    }
+  // incidence counts of the <= 2 x 2 tiles the footprint overlaps (k <= 41 < 64), wave-aggregated
+  const int hk = job.kernel_size / 2;
+  const int tx0 = on ? (cx - hk) / kRasterTile : 0, tx1 = on ? (cx + hk) / kRasterTile : 0;
+  const int ty0 = on ? (cy - hk) / kRasterTile : 0, ty1 = on ? (cy + hk) / kRasterTile : 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
+    const int t = (on && tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
+    const int before = wave_counter_add(job.tile_count, t);
+    if (t >= 0 && before == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}      // first point of the tile lists it
   }
 }
 
@@ -389,17 +422,18 @@ __global__ __launch_bounds__(256) void k_raster_fill(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.y];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= job.n_points) {return;}
-  const int cx = job.cell_xy[2 * (size_t)p], cy = job.cell_xy[2 * (size_t)p + 1];
-  if (cx < 0) {return;}
+  int cx = -1, cy = -1;
+  if (p < job.n_points) {cx = job.cell_xy[2 * (size_t)p]; cy = job.cell_xy[2 * (size_t)p + 1];}
+  const bool on = cx >= 0;
   const int hk = job.kernel_size / 2;
-  const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
-  const int ty0 = (cy - hk) / kRasterTile, ty1 = (cy + hk) / kRasterTile;
-  for (int ty = ty0; ty <= ty1; ++ty) {
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      const int t = ty * job.tiles_w + tx;
-      job.list[job.tile_start[t] + atomicAdd(&job.tile_cursor[t], 1)] = p;
-    }
+  const int tx0 = on ? (cx - hk) / kRasterTile : 0, tx1 = on ? (cx + hk) / kRasterTile : 0;
+  const int ty0 = on ? (cy - hk) / kRasterTile : 0, ty1 = on ? (cy + hk) / kRasterTile : 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
+    const int t = (on && tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
+    const int slot = wave_counter_add(job.tile_cursor, t);
+    if (t >= 0) {job.list[job.tile_start[t] + slot] = p;}
   }
 }
 
@@ -411,22 +445,25 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
 {
   const RasterJob & job = jobs[blockIdx.y];
   __shared__ uint32_t s_tile[kRasterTile * kRasterTile];
-  __shared__ uint8_t s_kernel[41 * 41 + 3];
+  __shared__ uint32_t s_cells[41 * 41];          // footprint cell c: value << 16 | row << 8 | column
   __shared__ int32_t s_px[256], s_py[256];
   const int k = job.kernel_size, hk = k / 2, kk = k * k;
   const int n_work = job.n_work[0];
   if ((int)blockIdx.x >= n_work) {return;}
-  for (int i = threadIdx.x; i < kk; i += blockDim.x) {s_kernel[i] = kernel[i];}
+  for (int i = threadIdx.x; i < kk; i += blockDim.x) {
+    const int row = i / k, col = i - row * k;
+    s_cells[i] = ((uint32_t)kernel[i] << 16) | ((uint32_t)row << 8) | (uint32_t)col;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int kWaves = 4;
-  // lanes over footprint cells.  kk >= 64: one point per wave pass, lane walks cells lane, lane + 64, ... with
-  // (row, col) advanced incrementally.  kk < 64: 64 / kk points per wave pass, one cell per lane.
+  // lanes over footprint cells.  kk >= 64: one point per wave pass, lane walks cells lane, lane + 64, ...
+  // kk < 64: 64 / kk points per wave pass, one cell per lane.  The inner loop was instruction bound (incremental
+  // row / column, byte load of the kernel value, two range tests: ~20 instructions per cell, 2.6 ms for the 224
+  // sequential-preset jobs of the loop-closure batch), hence the packed per-cell table.
   const int ppw = kk >= 64 ? 1 : 64 / kk;                 // points per wave pass
   const int sub = kk >= 64 ? 0 : lane / kk;               // which of them this lane works for
   const int c0 = kk >= 64 ? lane : lane - sub * kk;       // first cell of this lane
   const bool lane_on = kk >= 64 || sub < ppw;
-  const int row0 = c0 / k, col0 = c0 - row0 * k;
-  const int drow = 64 / k, dcol = 64 - drow * k;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int t = job.work[w];
     const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
@@ -446,15 +483,12 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
       for (int q = wave * ppw + sub; q < here; q += kWaves * ppw) {
         if (!lane_on) {break;}
         const int fx = s_px[q], fy = s_py[q];
-        int row = row0, col = col0;
+#pragma unroll 4
         for (int c = c0; c < kk; c += 64) {
-          const int x = fx + col, y = fy + row;
-          if ((unsigned)x < (unsigned)kRasterTile && (unsigned)y < (unsigned)kRasterTile) {
-            const uint32_t v = s_kernel[c];
-            if (v != 0) {atomicMax(&s_tile[y * kRasterTile + x], v);}
-          }
-          col += dcol; row += drow;
-          if (col >= k) {col -= k; ++row;}
+          const uint32_t e = s_cells[c];
+          const int x = fx + (int)(e & 0xffu), y = fy + (int)((e >> 8) & 0xffu);
+          // both inside [0, 64): for two's complement ints, (x | y) is in [0, 64) iff both are
+          if ((unsigned)(x | y) < (unsigned)kRasterTile && (e >> 16) != 0) {atomicMax(&s_tile[y * kRasterTile + x], e >> 16);}
         }
       }
     }
@@ -482,7 +516,8 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
   hipLaunchKernelGGL(k_raster_scan, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
   hipLaunchKernelGGL(k_raster_fill, per_point, dim3(256), 0, s, d_jobs);
   // non-empty tiles <= 4 per point and <= all tiles; a workgroup walks several when there are more
-  int blocks = std::min(std::min(max_tiles, 4 * max_points), 2048);
+  static const int tile_blocks = std::getenv("KH_TILE_BLOCKS") ? std::atoi(std::getenv("KH_TILE_BLOCKS")) : 2048;
+  int blocks = std::min(std::min(max_tiles, 4 * max_points), tile_blocks);
   hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
 }
 
@@ -667,16 +702,17 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
         // dual-copy layout: the aligned 64-byte segment K3 reads starts at wx0 - cls; the copy in which it does not
         // straddle a 128-byte line (pitch2 is a multiple of 128, so every row of the window sits alike)
         const bool dual = fast2 != nullptr && in_row;
-        int32_t idx2 = 0;
-        if (dual) {
-          const int32_t seg = wx0 - cls;
-          idx2 = wy0 * job.pitch2 + wx0 + ((seg & 127) > 64 ? job.copy_b + 64 : 0);
-        }
+        const int px = (job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan;
         while (tmask) {
           const int t = __builtin_ctz(tmask);
           tmask &= tmask - 1;
           const int li = cls * lt + t;
           if (dual) {
+            // the tile's 64-byte segments start at wx0 + x0 * sx, moved back to the dword boundary (K3's s); with one list
+            // for all tiles (lt == 1) the lattice is one tile wide (the host sees to it), i.e. x0 = 0
+            const int32_t xo = (lt > 1 ? (t % job.tiles_x) * px : 0) * job.sx;
+            const int32_t seg = (wx0 + xo) & ~3;
+            const int32_t idx2 = wy0 * job.pitch2 + wx0 + ((seg & 127) > 64 ? job.copy_b + 64 : 0);
             fast2[(size_t)li * P + atomicAdd(&s_tcounts2[li], 1)] = idx2;
           } else {
             fast[(size_t)li * P + atomicAdd(&s_tcounts[li], 1)] = idx;

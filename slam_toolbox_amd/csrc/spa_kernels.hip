@@ -718,17 +718,19 @@ __device__ __forceinline__ void load_diag_block(const double * F, int m, int jb,
   }
 }
 
-__global__ __launch_bounds__(256) void k_backward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs)
+// 1024 threads: the 16 columns of a block take their dot products at once (one wave each) instead of in four rounds --
+// the sweep is a chain of (dot, 16 x 16 back substitution) steps, each a memory latency long, so the rounds were the time
+__global__ __launch_bounds__(1024) void k_backward(SpaDev d, const int32_t * __restrict__ level_fronts, double * rhs)
 {
   const int k = level_fronts[blockIdx.x];
   const int m = d.front_m[k], ns = d.front_ns[k], nu = m - ns;
   const double * F = d.fronts + d.front_off[k];
   const int first = 3 * d.front_first[k];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
   extern __shared__ double sb[];
   const int32_t * rows = d.front_rows + d.front_rows_ptr[k];
-  for (int t = tid; t < ns; t += 256) {sb[t] = rhs[first + t];}
-  for (int q = tid; q < nu; q += 256) {sb[ns + q] = rhs[3 * rows[q / 3] + q % 3];}
+  for (int t = tid; t < ns; t += nthreads) {sb[t] = rhs[first + t];}
+  for (int q = tid; q < nu; q += nthreads) {sb[ns + q] = rhs[3 * rows[q / 3] + q % 3];}
   __syncthreads();
   const int nblk = (ns + NB - 1) / NB;
   for (int blk = nblk - 1; blk >= 0; --blk) {
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(256) void k_backward(SpaDev d, const int32_t * __re
     const int nb = min(NB, ns - jb);
     const int r0 = jb + nb;
     // w[t] = y[t] - sum_{i >= r0} L[i][t] x[i] : one wave per column, lanes over the rows
-    for (int c = wave; c < nb; c += 4) {
+    for (int c = wave; c < nb; c += nwaves) {
       const double * col = F + (int64_t)(jb + c) * m;
       double acc = 0.0;
       for (int i = r0 + lane; i < m; i += 64) {acc += col[i] * sb[i];}
@@ -758,13 +760,13 @@ __global__ __launch_bounds__(256) void k_backward(SpaDev d, const int32_t * __re
     }
     __syncthreads();
   }
-  for (int t = tid; t < ns; t += 256) {rhs[first + t] = sb[t];}
+  for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = sb[t];}
 }
 
 void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, void * stream)
 {
   if (n <= 0) {return;}
-  hipLaunchKernelGGL(k_backward, dim3(n), dim3(256), sizeof(double) * max_m, (hipStream_t)stream, d, level_fronts, rhs);
+  hipLaunchKernelGGL(k_backward, dim3(n), dim3(1024), sizeof(double) * max_m, (hipStream_t)stream, d, level_fronts, rhs);
 }
 
 }  // namespace kh
