@@ -130,6 +130,17 @@ KH_API int kh_matcher_correlate_batch(kh_matcher * m, int32_t n, const kh_scan *
                                       int32_t doing_fine_match, double * means, double * covs,
                                       double * responses, int32_t * status);
 
+/* ScanMatcher::ComputePositionalCovariance (Mapper.cpp:874-966): walks the search-space probabilities the last COARSE
+ * CorrelateScan of `slot` left behind (the reference keeps them in m_pSearchSpaceProbs) with the caller's geometry. */
+KH_API int kh_matcher_positional_covariance(kh_matcher * m, int32_t slot, const double best_pose[3], double best_response,
+                                            const double center[3], const double search_offset[2],
+                                            const double search_resolution[2], double angle_resolution, double cov[9]);
+/* ScanMatcher::ComputeAngularCovariance (Mapper.cpp:977-1025) for `query` against the grid in `slot`: only cov[8] is
+ * written.  (The reference reads the lookup table of its last CorrelateScan; here the scan is named.) */
+KH_API int kh_matcher_angular_covariance(kh_matcher * m, int32_t slot, const kh_scan * query, const double best_pose[3],
+                                         double best_response, const double center[3], double angle_offset,
+                                         double angle_resolution, double cov[9]);
+
 /* ---- introspection used by the parity tests and the bench (not needed by the adaptor) ---- */
 typedef struct kh_grid_info {
   int32_t width, height, width_step, data_size;      /* Grid<kt_int8u> incl. border (Karto.h:4636-4664) */

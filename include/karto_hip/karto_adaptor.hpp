@@ -14,6 +14,8 @@
 #ifndef KARTO_HIP__KARTO_ADAPTOR_HPP_
 #define KARTO_HIP__KARTO_ADAPTOR_HPP_
 
+#include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -43,6 +45,14 @@ inline kh_scan to_scan(karto::LocalizedRangeScan * pScan, std::vector<double> & 
   return s;
 }
 
+// HIP device the adaptors compute on when the caller names none: environment variable KARTO_HIP_DEVICE (one process
+// per GPU: the launcher exports it next to the rank), 0 otherwise
+inline int default_device()
+{
+  const char * e = std::getenv("KARTO_HIP_DEVICE");
+  return e ? std::atoi(e) : 0;
+}
+
 template<class T>
 inline T stored_parameter(karto::Mapper * pMapper, const char * name)
 {
@@ -59,8 +69,9 @@ public:
 
   static HipScanMatcher * Create(
     karto::Mapper * pMapper, kt_double searchSize, kt_double resolution,
-    kt_double smearDeviation, kt_double rangeThreshold, int device = 0)
+    kt_double smearDeviation, kt_double rangeThreshold, int device = -1)
   {
+    if (device < 0) {device = detail::default_device();}
     kh_matcher * h = nullptr;
     const int rc = kh_matcher_create(searchSize, resolution, smearDeviation, rangeThreshold, device, 1, &h);
     if (rc == KH_ERR_INVALID_ARG) {return NULL;}
@@ -68,6 +79,7 @@ public:
     HipScanMatcher * m = new HipScanMatcher();
     m->m_pHandle = h;
     m->m_pMapper = pMapper;
+    m->m_Resolution = resolution; m->m_SmearDeviation = smearDeviation;
     return m;
   }
 
@@ -77,6 +89,7 @@ public:
     karto::Matrix3 & rCovariance, kt_bool doPenalize = true, kt_bool doRefineMatch = true)
   {
     SyncParameters();
+    m_pLastScan = pScan;
     std::vector<std::vector<double>> store(1);
     std::vector<kh_scan> base;
     const kh_scan query = detail::to_scan(pScan, store[0]);
@@ -97,6 +110,7 @@ public:
     karto::Pose2 & rMean, karto::Matrix3 & rCovariance, kt_bool doingFineMatch)
   {
     SyncParameters();
+    m_pLastScan = pScan;
     std::vector<double> pts;
     const kh_scan query = detail::to_scan(pScan, pts);
     const double center[3] = {rSearchCenter.GetX(), rSearchCenter.GetY(), rSearchCenter.GetHeading()};
@@ -113,10 +127,65 @@ public:
     return response;
   }
 
+  // ScanMatcher::ComputePositionalCovariance (Mapper.h:1405-1412, Mapper.cpp:874-966): on the search-space probabilities
+  // the last coarse CorrelateScan left in the matcher, like the reference's m_pSearchSpaceProbs
+  void ComputePositionalCovariance(
+    const karto::Pose2 & rBestPose, kt_double bestResponse, const karto::Pose2 & rSearchCenter,
+    const karto::Vector2<kt_double> & rSearchSpaceOffset, const karto::Vector2<kt_double> & rSearchSpaceResolution,
+    kt_double searchAngleResolution, karto::Matrix3 & rCovariance)
+  {
+    const double best[3] = {rBestPose.GetX(), rBestPose.GetY(), rBestPose.GetHeading()};
+    const double center[3] = {rSearchCenter.GetX(), rSearchCenter.GetY(), rSearchCenter.GetHeading()};
+    const double off[2] = {rSearchSpaceOffset.GetX(), rSearchSpaceOffset.GetY()};
+    const double res[2] = {rSearchSpaceResolution.GetX(), rSearchSpaceResolution.GetY()};
+    double cov[9];
+    Check(kh_matcher_positional_covariance(m_pHandle, 0, best, bestResponse, center, off, res, searchAngleResolution, cov));
+    for (int r = 0; r < 3; ++r) {for (int c = 0; c < 3; ++c) {rCovariance(r, c) = cov[3 * r + c];}}
+  }
+
+  // ScanMatcher::ComputeAngularCovariance (Mapper.h:1421-1427, Mapper.cpp:977-1025) for the scan of the last
+  // MatchScan / CorrelateScan call (the reference reads the lookup table that call computed); writes rCovariance(2, 2)
+  void ComputeAngularCovariance(
+    const karto::Pose2 & rBestPose, kt_double bestResponse, const karto::Pose2 & rSearchCenter,
+    kt_double searchAngleOffset, kt_double searchAngleResolution, karto::Matrix3 & rCovariance)
+  {
+    if (!m_pLastScan) {throw std::runtime_error("karto_hip: ComputeAngularCovariance before any CorrelateScan");}
+    std::vector<double> pts;
+    const kh_scan query = detail::to_scan(m_pLastScan, pts);
+    const double best[3] = {rBestPose.GetX(), rBestPose.GetY(), rBestPose.GetHeading()};
+    const double center[3] = {rSearchCenter.GetX(), rSearchCenter.GetY(), rSearchCenter.GetHeading()};
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Check(kh_matcher_angular_covariance(m_pHandle, 0, &query, best, bestResponse, center, searchAngleOffset,
+      searchAngleResolution, cov));
+    rCovariance(2, 2) = cov[8];
+  }
+
+  // ScanMatcher::GetCorrelationGrid (Mapper.h:1433-1437, "for debugging"): a host-side karto::CorrelationGrid holding the
+  // bytes, the region of interest and the coordinate converter of the grid in HBM; refreshed on every call, owned here
+  karto::CorrelationGrid * GetCorrelationGrid()
+  {
+    kh_grid_info gi;
+    Check(kh_matcher_grid_info(m_pHandle, 0, &gi));
+    if (!m_pGridMirror) {
+      m_pGridMirror.reset(karto::CorrelationGrid::CreateGrid(gi.roi_w, gi.roi_h, m_Resolution, m_SmearDeviation));
+    }
+    Check(kh_matcher_read_grid(m_pHandle, 0, m_pGridMirror->GetDataPointer()));
+    m_pGridMirror->GetCoordinateConverter()->SetOffset(karto::Vector2<kt_double>(gi.offset_x, gi.offset_y));
+    return m_pGridMirror.get();
+  }
+
+  // karto::ScanMatcher::operator()(const kt_double &) is the row functor its own CorrelateScan hands to TBB
+  // (Mapper.cpp:641-694, 773); it works on private members of a search in progress and has no meaning outside one.
+  // Kept so that code naming it still compiles; the rows of a search are scored by the GPU inside CorrelateScan.
+  void operator()(const kt_double &) const
+  {
+    throw std::logic_error("karto_hip::HipScanMatcher: operator()(y) is internal to CorrelateScan");
+  }
+
   kh_matcher * GetHandle() const {return m_pHandle;}
 
 protected:
-  HipScanMatcher() : m_pHandle(nullptr), m_pMapper(nullptr) {}
+  HipScanMatcher() : m_pHandle(nullptr), m_pMapper(nullptr), m_pLastScan(nullptr), m_Resolution(0), m_SmearDeviation(0) {}
 
 private:
   void SyncParameters()
@@ -164,15 +233,28 @@ private:
 
   kh_matcher * m_pHandle;
   karto::Mapper * m_pMapper;
+  karto::LocalizedRangeScan * m_pLastScan;
+  kt_double m_Resolution, m_SmearDeviation;
+  std::unique_ptr<karto::CorrelationGrid> m_pGridMirror;
 };
 
 // ---------------------------------------------------------------------------------------------
 class HipSpaSolver : public karto::ScanSolver
 {
 public:
-  HipSpaSolver() : m_pHandle(nullptr)
+  // device < 0: environment variable KARTO_HIP_DEVICE, else 0 (pluginlib constructs plugins without arguments)
+  explicit HipSpaSolver(int device = -1) : m_pHandle(nullptr)
   {
-    if (kh_spa_create(0, &m_pHandle) != KH_OK) {throw std::runtime_error(std::string("karto_hip: ") + kh_last_error());}
+    if (device < 0) {device = detail::default_device();}
+    if (kh_spa_create(device, &m_pHandle) != KH_OK) {throw std::runtime_error(std::string("karto_hip: ") + kh_last_error());}
+  }
+
+  // Multi-GPU (one process per GPU, every process holds the same graph): the edge linearisation is sharded over the
+  // ranks of `comm` and H, g are summed with RCCL inside the library (kh_comm_create, karto_hip.h); NULL switches it off
+  void SetCommunicator(kh_comm * comm)
+  {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    kh_spa_set_comm(m_pHandle, comm);
   }
   virtual ~HipSpaSolver() {kh_spa_destroy(m_pHandle);}
 

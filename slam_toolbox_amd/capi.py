@@ -67,6 +67,7 @@ SYMBOLS = [
     "kh_matcher_create", "kh_matcher_destroy", "kh_matcher_set_params", "kh_matcher_match",
     "kh_matcher_match_batch", "kh_matcher_add_scans", "kh_matcher_correlate", "kh_matcher_correlate_batch",
     "kh_matcher_grid_info", "kh_matcher_read_grid", "kh_matcher_read_kernel", "kh_matcher_read_lookup",
+    "kh_matcher_positional_covariance", "kh_matcher_angular_covariance",
     "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile", "kh_matcher_score_loads",
     "kh_spa_options_default", "kh_spa_create", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
@@ -165,6 +166,8 @@ def lib():
     L.kh_matcher_add_scans.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), i32]
     L.kh_matcher_correlate.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, C.POINTER(dbl)]
     L.kh_matcher_correlate_batch.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, dptr, iptr]
+    L.kh_matcher_positional_covariance.argtypes = [vp, i32, dptr, dbl, dptr, dptr, dptr, dbl, dptr]
+    L.kh_matcher_angular_covariance.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dbl, dptr, dbl, dbl, dptr]
     L.kh_matcher_grid_info.argtypes = [vp, i32, C.POINTER(KhGridInfo)]
     L.kh_matcher_read_grid.argtypes = [vp, i32, bptr]
     L.kh_matcher_read_kernel.argtypes = [vp, bptr]

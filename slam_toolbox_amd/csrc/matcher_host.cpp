@@ -150,6 +150,9 @@ struct Slot
   // last correlate (for the introspection calls)
   CorrHost last;
   bool has_last = false;
+  bool volume_stale = false;         // the stored volume was overwritten by an off-lattice re-score (introspection reports it)
+  // what ComputePositionalCovariance reads: the search-space probabilities of the last COARSE search (Mapper.cpp:726-732, 781-799)
+  CorrHost last_coarse; std::vector<double> last_lattice; bool has_last_coarse = false;
 };
 
 }  // namespace kh
@@ -245,7 +248,10 @@ public:
   {
     if (n == 0) {return;}
     if (n == 1 || workers_.empty()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
-    std::lock_guard<std::mutex> serial(run_mu_);      // one parallel region at a time (handles may be on different threads)
+    // one parallel region at a time; a second handle arriving from another thread while the workers are taken does its
+    // loop itself instead of queueing behind the first (the regions are short: waiting would idle the caller's GPU stream)
+    std::unique_lock<std::mutex> serial(run_mu_, std::try_to_lock);
+    if (!serial.owns_lock()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
     {
       std::lock_guard<std::mutex> lk(mu_);
       fn_ = &fn; n_ = n; next_.store(0); pending_ = workers_.size(); ++generation_;
@@ -519,14 +525,15 @@ static int pick_ry(int32_t ny)
 }
 
 // Host half of ComputePositionalCovariance (Mapper.cpp:874-966) on the lattice maxima
+struct WalkGeometry {double center[3], off_x, off_y, res_x, res_y, ang_res;};
 static int positional_covariance(
-  const kh_matcher * m, const CorrHost & c, const std::vector<double> & lattice_max,
+  const kh_matcher * m, const CorrHost & c, const std::vector<double> & lattice_max, const WalkGeometry & w,
   const double best_pose[3], double best_response, double * cov)
 {
   std::fill(cov, cov + 9, 0.0);
   cov[0] = 1.0; cov[4] = 1.0; cov[8] = 1.0;       // SetToIdentity
   if (best_response < kTolerance) {
-    cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * (c.ang_res * c.ang_res);
+    cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * (w.ang_res * w.ang_res);
     return KH_OK;
   }
   // search-space-probs grid (Grid<kt_double>, side x side, Mapper.cpp:513-514, 726-732, 781-799)
@@ -545,16 +552,17 @@ static int positional_covariance(
     }
   }
   double aXX = 0, aXY = 0, aYY = 0, norm = 0;
-  const double dx = best_pose[0] - c.center[0], dy = best_pose[1] - c.center[1];
-  const uint32_t nX = static_cast<uint32_t>(round_half_away(c.off_x * 2.0 / c.res_x) + 1);
-  const double startX = -c.off_x;
-  const uint32_t nY = static_cast<uint32_t>(round_half_away(c.off_y * 2.0 / c.res_y) + 1);
-  const double startY = -c.off_y;
+  // the walk uses the CALLER's geometry on the grid the last coarse search left behind (Mapper.cpp:896-923)
+  const double dx = best_pose[0] - w.center[0], dy = best_pose[1] - w.center[1];
+  const uint32_t nX = static_cast<uint32_t>(round_half_away(w.off_x * 2.0 / w.res_x) + 1);
+  const double startX = -w.off_x;
+  const uint32_t nY = static_cast<uint32_t>(round_half_away(w.off_y * 2.0 / w.res_y) + 1);
+  const double startY = -w.off_y;
   for (uint32_t yi = 0; yi < nY; ++yi) {
-    const double y = startY + yi * c.res_y;
+    const double y = startY + yi * w.res_y;
     for (uint32_t xi = 0; xi < nX; ++xi) {
-      const double x = startX + xi * c.res_x;
-      const Cell g = world_to_grid(pscale, pox, poy, c.center[0] + x, c.center[1] + y);
+      const double x = startX + xi * w.res_x;
+      const Cell g = world_to_grid(pscale, pox, poy, w.center[0] + x, w.center[1] + y);
       if (!(g.x >= 0 && g.x < side) || !(g.y >= 0 && g.y < side)) {return KH_ERR_SEARCH;}
       const double response = probs[static_cast<size_t>(g.y) * side + g.x];
       if (response >= (best_response - 0.1)) {
@@ -567,8 +575,8 @@ static int positional_covariance(
   }
   if (norm > kTolerance) {
     double vXX = aXX / norm, vXY = aXY / norm, vYY = aYY / norm;
-    const double vTHTH = 4 * (c.ang_res * c.ang_res);
-    const double minXX = 0.1 * (c.res_x * c.res_x), minYY = 0.1 * (c.res_y * c.res_y);
+    const double vTHTH = 4 * (w.ang_res * w.ang_res);
+    const double minXX = 0.1 * (w.res_x * w.res_x), minYY = 0.1 * (w.res_y * w.res_y);
     vXX = vXX > minXX ? vXX : minXX;
     vYY = vYY > minYY ? vYY : minYY;
     const double mult = 1.0 / best_response;
@@ -577,6 +585,29 @@ static int positional_covariance(
   if (double_equal(cov[0], 0.0)) {cov[0] = kMaxVariance;}
   if (double_equal(cov[4], 0.0)) {cov[4] = kMaxVariance;}
   return KH_OK;
+}
+
+// the accumulation of ComputeAngularCovariance (Mapper.cpp:992-1024) over the raw responses of all angles at the best cell
+static double angular_variance(const std::vector<int32_t> & sums, double denom, double center_heading, double ang_off,
+  double ang_res, double best_angle, double best_response)
+{
+  const double startAngle = center_heading - ang_off;
+  double norm = 0.0, acc = 0.0;
+  for (size_t a = 0; a < sums.size(); ++a) {
+    const double angle = startAngle + static_cast<uint32_t>(a) * ang_res;
+    const double response = static_cast<double>(sums[a]) / denom;     // GetResponse: no penalty
+    if (response >= (best_response - 0.1)) {
+      norm += response;
+      acc += ((angle - best_angle) * (angle - best_angle) * response);
+    }
+  }
+  if (norm > kTolerance) {
+    if (acc < kTolerance) {acc = ang_res * ang_res;}
+    acc /= norm;
+  } else {
+    acc = 1000 * (ang_res * ang_res);
+  }
+  return acc;
 }
 
 static inline double host_response(const CorrHost & c, int32_t sum, int a, int yi, int xi)
@@ -965,6 +996,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     CorrReq & q = reqs[i];
     CorrHost & c = ctx[i];
     Slot & s = m->slots[c.slot];
+    s.volume_stale = false;
     const unsigned long long * out = B.h_out + out_words * i;
     double best;
     std::memcpy(&best, &out[0], 8);
@@ -1015,8 +1047,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     if (!c.fine) {
       std::vector<double> lattice(plane);
       std::memcpy(lattice.data(), out + kOutHeaderWords, plane * 8);
-      const int prc = positional_covariance(m, c, lattice, avg, best, q.cov);
+      WalkGeometry wg;
+      std::copy(c.center, c.center + 3, wg.center);
+      wg.off_x = c.off_x; wg.off_y = c.off_y; wg.res_x = c.res_x; wg.res_y = c.res_y; wg.ang_res = c.ang_res;
+      const int prc = positional_covariance(m, c, lattice, wg, avg, best, q.cov);
       if (prc != KH_OK) {q.status = prc; return KH_OK;}
+      s.last_coarse = c; s.last_lattice.swap(lattice); s.has_last_coarse = true;     // m_pSearchSpaceProbs of this matcher slot
     } else {
       // ComputeAngularCovariance, Mapper.cpp:977-1025
       const double bestAngle = normalize_angle_difference(avg[2], c.center[2]);
@@ -1037,7 +1073,11 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       } else if (fx >= 0) {
         KH_HIP(hipMemcpy2D(col.data(), 4, s.d_sums + static_cast<size_t>(fy) * c.nx + fx, plane * 4, 4, c.na, hipMemcpyDeviceToHost));
       } else {
-        // off-lattice best pose: score the single cell through the generic (per-pose checked) path
+        // off-lattice best pose: score the single cell through the generic (per-pose checked) path.  Finalisation may
+        // run on pool threads: one of them at a time talks to the stream
+        static std::mutex rescore_mutex;
+        std::lock_guard<std::mutex> rescore_lock(rescore_mutex);
+        s.volume_stale = true;
         CorrJob * job = reinterpret_cast<CorrJob *>(B.h_stage + stride * i);
         CorrJob one = *job;
         one.nx = 1; one.ny = 1; one.linear = 0; one.sx = 1; one.sy_ws = m->ws; one.base0 = gridIndex;
@@ -1051,25 +1091,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
         launch_score(B.d_stage + stride * i, stride, 1, 1, one.na, 1, 1, m->stream);
         KH_HIP(hipStreamSynchronize(m->stream));
         KH_HIP(hipMemcpy(col.data(), s.d_sums, sizeof(int32_t) * c.na, hipMemcpyDeviceToHost));
-        // NOTE: the slot's stored volume now holds this 1x1 search (introspection only)
+        // (the slot's stored volume now holds this 1 x 1 search: kh_matcher_read_volume reports KH_ERR_NOT_FOUND)
       }
-      const double startAngle = c.center[2] - c.ang_off;
-      double norm = 0.0, acc = 0.0;
-      for (int32_t a = 0; a < c.na; ++a) {
-        const double angle = startAngle + static_cast<uint32_t>(a) * c.ang_res;
-        const double response = static_cast<double>(col[a]) / c.denom;     // GetResponse: no penalty
-        if (response >= (best - 0.1)) {
-          norm += response;
-          acc += ((angle - bestAngle) * (angle - bestAngle) * response);
-        }
-      }
-      if (norm > kTolerance) {
-        if (acc < kTolerance) {acc = c.ang_res * c.ang_res;}
-        acc /= norm;
-      } else {
-        acc = 1000 * (c.ang_res * c.ang_res);
-      }
-      q.cov[8] = acc;
+      q.cov[8] = angular_variance(col, c.denom, c.center[2], c.ang_off, c.ang_res, bestAngle, best);
     }
     q.mean[0] = avg[0]; q.mean[1] = avg[1]; q.mean[2] = avg[2];
     q.response = best > 1.0 ? 1.0 : best;
@@ -1594,6 +1618,7 @@ int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, int32_t *
   if (!m || slot < 0 || slot >= m->max_batch || !nx || !ny || !na) {return KH_ERR_INVALID_ARG;}
   Slot & s = m->slots[slot];
   if (!s.has_last) {return KH_ERR_NOT_FOUND;}
+  if (s.volume_stale) {set_error("the last search re-scored an off-lattice best pose: its volume was not kept"); return KH_ERR_NOT_FOUND;}
   const CorrHost & c = s.last;
   *nx = c.nx; *ny = c.ny; *na = c.na;
   if (!out_sums && !out_responses) {return KH_OK;}
@@ -1615,6 +1640,51 @@ int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, int32_t *
       for (size_t p = 0; p < plane; ++p) {out_responses[p * c.na + a] = tmp[static_cast<size_t>(a) * plane + p];}
     }
   }
+  return KH_OK;
+}
+
+// ScanMatcher::ComputePositionalCovariance (Mapper.cpp:874-966) on the search-space probabilities the last COARSE
+// CorrelateScan of `slot` left behind
+int kh_matcher_positional_covariance(kh_matcher * m, int32_t slot, const double best_pose[3], double best_response,
+  const double center[3], const double search_offset[2], const double search_resolution[2], double angle_resolution,
+  double cov[9])
+{
+  if (!m || slot < 0 || slot >= m->max_batch || !best_pose || !center || !search_offset || !search_resolution || !cov) {return KH_ERR_INVALID_ARG;}
+  if (!(search_resolution[0] > 0.0) || !(search_resolution[1] > 0.0)) {return KH_ERR_INVALID_ARG;}
+  Slot & s = m->slots[slot];
+  if (!s.has_last_coarse) {set_error("no coarse search has run in this slot"); return KH_ERR_NOT_FOUND;}
+  WalkGeometry wg;
+  std::copy(center, center + 3, wg.center);
+  wg.off_x = search_offset[0]; wg.off_y = search_offset[1]; wg.res_x = search_resolution[0]; wg.res_y = search_resolution[1];
+  wg.ang_res = angle_resolution;
+  return positional_covariance(m, s.last_coarse, s.last_lattice, wg, best_pose, best_response, cov);
+}
+
+// ScanMatcher::ComputeAngularCovariance (Mapper.cpp:977-1025): GetResponse of every search angle at the best pose's cell
+// (one 1 x 1 search on the GPU against the grid currently in `slot`), then the reference's accumulation.  Only cov[8]
+// (theta-theta) is written.
+int kh_matcher_angular_covariance(kh_matcher * m, int32_t slot, const kh_scan * query, const double best_pose[3],
+  double best_response, const double center[3], double angle_offset, double angle_resolution, double cov[9])
+{
+  if (!m || slot < 0 || slot >= m->max_batch || check_scan(query) != KH_OK || query->n == 0 || !best_pose || !center || !cov ||
+    angle_resolution == 0.0) {return KH_ERR_INVALID_ARG;}
+  KH_HIP(hipSetDevice(m->device));
+  std::vector<CorrReq> reqs(1);
+  CorrReq & q = reqs[0];
+  q.slot = slot; q.scan = query;
+  q.center[0] = best_pose[0]; q.center[1] = best_pose[1]; q.center[2] = center[2];
+  q.off_x = 0.0; q.off_y = 0.0; q.res_x = m->grid_resolution(); q.res_y = m->grid_resolution();
+  q.ang_off = angle_offset; q.ang_res = angle_resolution; q.penalize = false; q.fine = true;
+  std::fill(q.cov, q.cov + 9, 0.0);
+  q.response = 0; q.status = KH_OK;
+  int rc = correlate_batch(m, reqs);
+  if (rc) {return rc;}
+  Slot & s = m->slots[slot];
+  const int32_t na = s.last.na;
+  std::vector<int32_t> col(static_cast<size_t>(na));
+  KH_HIP(hipMemcpy(col.data(), s.d_sums, sizeof(int32_t) * na, hipMemcpyDeviceToHost));
+  const double bestAngle = normalize_angle_difference(best_pose[2], center[2]);
+  cov[8] = angular_variance(col, s.last.denom, center[2], angle_offset, angle_resolution, bestAngle, best_response);
   return KH_OK;
 }
 

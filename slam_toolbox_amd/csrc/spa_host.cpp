@@ -113,7 +113,7 @@ struct kh_spa
   DevBuf<int32_t> d_edge_a, d_edge_b, d_free_of_node, d_node_of_free, d_slot_contrib_ptr, d_slot_contrib,
     d_bsr_row_ptr, d_bsr_col, d_bsr_diag, d_node_contrib_ptr, d_node_contrib, d_front_m, d_front_ns,
     d_front_first, d_rows_ptr, d_rows, d_child_ptr, d_child_list, d_relpos_ptr, d_relpos, d_slot_ld,
-    d_elim_of_free, d_free_of_elim, d_level_fronts, d_fail;
+    d_elim_of_free, d_free_of_elim, d_level_fronts, d_fail, d_sync;
   DevBuf<int64_t> d_front_off, d_slot_dest;
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
@@ -595,6 +595,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_scale.ensure(3 * nf); r2 |= s->d_diag.ensure(3 * nf); r2 |= s->d_rhs.ensure(3 * nf);
     r2 |= s->d_step.ensure(3 * nf); r2 |= s->d_delta.ensure(3 * nf);
     r2 |= s->d_fail.ensure(4);
+    r2 |= s->d_sync.ensure(4 * static_cast<size_t>(sym.n_fronts) + 4);
     r2 |= s->d_upd.ensure(static_cast<size_t>(3) * sym.rows_ptr[sym.n_fronts] + 16);
     if (r2) {return KH_ERR_HIP;}
     // the uploads above read pageable host vectors of this block: they must have landed before the block ends
@@ -692,7 +693,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_front_ns.release(); s->d_front_first.release(); s->d_rows_ptr.release(); s->d_rows.release();
   s->d_child_ptr.release(); s->d_child_list.release(); s->d_relpos_ptr.release(); s->d_relpos.release();
   s->d_slot_ld.release(); s->d_elim_of_free.release(); s->d_free_of_elim.release(); s->d_level_fronts.release();
-  s->d_fail.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
+  s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
   s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release();
@@ -1274,8 +1275,15 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     // factorisation and forward solve are one kernel per level (the forward step of a panel runs while its
     // L11 / L21 are still in LDS), so the right-hand side has to be in place first
     spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, st);
+    KS_HIP(hipMemsetAsync(s->d_sync.p, 0, sizeof(int32_t) * 4 * static_cast<size_t>(sym.n_fronts), st));
+    static const int ea_limit = std::getenv("KH_SPA_EXTEND_ADD") ? std::atoi(std::getenv("KH_SPA_EXTEND_ADD")) : 128;
     for (int l = 0; l < n_levels; ++l) {
-      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
+      const int32_t n_level = s->level_offsets[l + 1] - s->level_offsets[l];
+      // narrow levels: the extend-add runs chip-wide in its own launch instead of on each front's single CU
+      const bool split = l > 0 && n_level <= ea_limit;
+      if (split) {spa_launch_extend_add(dev, s->d_level_fronts.p + s->level_offsets[l], n_level, s->level_max_m[l], st);}
+      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], n_level, s->level_max_m[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p,
+        s->d_sync.p + 4 * s->level_offsets[l], split ? 1 : 0, st);
       dbg("factor+forward", l);
     }
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][1], st));}

@@ -517,14 +517,126 @@ __device__ __forceinline__ void trailing_update(double * F, const double * Xs, i
   }
 }
 
+// Extend-add of a whole level, chip-wide: workgroup (front, block of 16 destination columns).  Inside k_factor the sums
+// of a 456-row front's two children took one CU 65 us per level -- a quarter of the level on the narrow upper levels,
+// where most of the chip idles.  A child's struct rows map to INCREASING positions in the parent (both are in
+// elimination order), so the child columns that land in this workgroup's destination block are one contiguous range;
+// every entry of the block is summed by this workgroup alone, children in turn: no atomics, the same order every run.
+__global__ __launch_bounds__(256) void k_extend_add(SpaDev d, const int32_t * __restrict__ level_fronts)
+{
+  const int k = level_fronts[blockIdx.x];
+  const int m = d.front_m[k];
+  const int c_lo = 16 * (int)blockIdx.y, c_hi = min(m, c_lo + 16);
+  if (c_lo >= m) {return;}
+  double * F = d.fronts + d.front_off[k];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int32_t s_rp[2048];            // the child's struct rows' block positions in this front (m <= 8000 -> < 2667 blocks)
+  // the children's descriptors first, all at once: fetched one child after the other they are a chain of six dependent
+  // memory latencies per child, which was most of this kernel's 30 us
+  constexpr int kBatch = 8;
+  const int ci0 = d.child_ptr[k], ci1 = d.child_ptr[k + 1];
+  for (int cb = ci0; cb < ci1; cb += kBatch) {
+  int cid[kBatch], cm[kBatch], cns[kBatch], crp[kBatch];
+  long long coff[kBatch];
+#pragma unroll
+  for (int q = 0; q < kBatch; ++q) {cid[q] = cb + q < ci1 ? d.child_list[cb + q] : -1;}
+#pragma unroll
+  for (int q = 0; q < kBatch; ++q) {
+    const int c = cid[q] < 0 ? 0 : cid[q];
+    cm[q] = d.front_m[c]; cns[q] = d.front_ns[c]; coff[q] = d.front_off[c]; crp[q] = d.relpos_ptr[c];
+  }
+#pragma unroll
+  for (int q = 0; q < kBatch; ++q) {
+    if (cid[q] < 0) {continue;}
+    const int mc = cm[q], nsc = cns[q], nuc = mc - nsc;
+    const double * Uc = d.fronts + coff[q] + nsc + (int64_t)nsc * mc;
+    const int32_t * rp = d.relpos + crp[q];
+    const int nblk = nuc / 3;
+    const bool staged = nblk <= 2048;       // staged in LDS: the two bisections below are chains of dependent reads
+    if (staged) {for (int i = threadIdx.x; i < nblk; i += blockDim.x) {s_rp[i] = rp[i];}}
+    __syncthreads();
+    auto pos = [&](int a) {return 3 * (staged ? s_rp[a / 3] : rp[a / 3]) + a % 3;};
+    // first child column with pos >= c_lo, first with pos >= c_hi
+    int lo = 0, hi = nuc;
+    while (lo < hi) {const int mid = (lo + hi) >> 1; if (pos(mid) < c_lo) {lo = mid + 1;} else {hi = mid;}}
+    const int b_lo = lo;
+    hi = nuc;
+    while (lo < hi) {const int mid = (lo + hi) >> 1; if (pos(mid) < c_hi) {lo = mid + 1;} else {hi = mid;}}
+    const int b_hi = lo;
+    for (int b = b_lo + wave; b < b_hi; b += 4) {
+      double * dst = F + (int64_t)pos(b) * m;
+      const double * src = Uc + (int64_t)b * mc;
+      for (int a0 = b; a0 < nuc; a0 += 256) {
+        // four rows per lane in flight
+        double u[4], f[4];
+        int pa[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int a = a0 + lane + 64 * q;
+          pa[q] = a < nuc ? pos(a) : -1;
+          u[q] = a < nuc ? src[a] : 0.0;
+          f[q] = a < nuc ? dst[pa[q]] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {if (pa[q] >= 0) {dst[pa[q]] = f[q] + u[q];}}
+      }
+    }
+    __syncthreads();       // the next child may add into the same entries (and restages s_rp)
+  }
+  }
+}
+
+void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream)
+{
+  if (n <= 0) {return;}
+  hipLaunchKernelGGL(k_extend_add, dim3(n, (max_m + 15) / 16), dim3(256), 0, (hipStream_t)stream, d, level_fronts);
+}
+
+// ---- workgroup-level hand-offs between the workgroups that share one front (agent scope: the L1 of a CU is never
+// refreshed by another CU's stores, MI355X_MICROARCH.md "inter-workgroup visibility") ----
+// publish: everything this workgroup has stored becomes visible, then the word moves
+__device__ __forceinline__ void wg_publish_add(int * word, int value)
+{
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// wait until *word >= value, then make the publishers' stores visible to every thread of this workgroup.  The spin is
+// bounded: a hand-off that never comes (it cannot, all workgroups of a launch are resident) must not hang the device.
+__device__ __forceinline__ bool wg_wait_ge(int * word, int value)
+{
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 26); ++spin) {
+      if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value) {ok = 1; break;}
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+// G workgroups per front (G = 1 on the wide levels).  Workgroup 0 of a front is its LEADER and runs the factorisation
+// as before; on the narrow upper levels, where a handful of large fronts would leave most of the chip idle, G - 1 helper
+// workgroups take destination-column slices of the extend-add and tile slices of every K = 32 trailing update (the bulk
+// of the flops), reading the solved panel from the front itself.  Hand-offs: sync[4 * slot + 0] extend-add arrivals,
+// + 1 panel pairs published by the leader, + 2 helper completions (zeroed by the host before every factorisation).
 __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag, long long * tbuf,
-              double * rhs, double * upd, int lds_rows)
+              double * rhs, double * upd, int lds_rows, int G, int * sync, int matrix_added)
 {
   // KH_SPA_TIMING=1: stage timestamps (100 MHz wall clock) of the level's largest front, printed by the host
   int tcount = 0;
 #define TSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[1 + tcount++] = wall_clock64();} } while (0)
   TSTAMP();
-  const int k = level_fronts[blockIdx.x];
+  const int slot = (int)blockIdx.x / G, g = (int)blockIdx.x - slot * G;
+  int * sy = sync + 4 * slot;
+  const int k = level_fronts[slot];
   const int m = d.front_m[k], ns = d.front_ns[k];
   double * F = d.fronts + d.front_off[k];
   const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -555,12 +667,13 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     const int32_t * rp = d.relpos + d.relpos_ptr[c];
     for (int a = tid; a < nuc; a += nthreads) {pos[a] = 3 * rp[a / 3] + a % 3;}
     __syncthreads();
-    {
+    if (g == 0) {
       const double * uc = upd + 3 * (int64_t)d.front_rows_ptr[c];      // the child's forward-solve contribution
       for (int a = tid; a < nuc; a += nthreads) {sb[pos[a]] += uc[a];}
     }
     constexpr int CB = 8;
-    for (int b0 = wave * CB; b0 < nuc; b0 += nwaves * CB) {
+    // matrix_added: k_extend_add has already summed the children's update matrices into the front, chip-wide
+    for (int b0 = wave * CB; b0 < nuc && !matrix_added; b0 += nwaves * CB) {
       for (int a0 = b0; a0 < nuc; a0 += 64) {
         const int a = a0 + lane;
         double u[CB], f[CB];
@@ -570,7 +683,9 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
 #pragma unroll
         for (int q = 0; q < CB; ++q) {
           const int b = b0 + q;
-          on[q] = a < nuc && b < nuc && a >= b;
+          // with several workgroups on the front, a DESTINATION column (block of 16) has one owner: whatever the child,
+          // all additions into an entry come from the same workgroup, children in turn
+          on[q] = a < nuc && b < nuc && a >= b && (G == 1 || ((pos[b] >> 4) % G) == g);
           dst[q] = F + pa + (int64_t)(on[q] ? pos[b] : 0) * m;
           u[q] = on[q] ? Uc[a + (int64_t)b * mc] : 0.0;
           f[q] = on[q] ? *dst[q] : 0.0;
@@ -583,7 +698,40 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
   }
 
   TSTAMP();
+  if (G > 1) {
+    wg_publish_add(&sy[0], 1);
+    if (g > 0) {
+      // helper: the same walk over the panels as the leader's below, taking part in the K = 32 updates only
+      int pairs = 0;
+      for (int jb = 0; jb < ns; ) {
+        const int nb_a = min(NB, ns - jb);
+        const int rb = jb + nb_a;
+        const int nrows = m - rb;
+        const int nrows_pad = (nrows + 15) & ~15;
+        if (jb + 2 * NB > ns) {jb += NB; continue;}
+        ++pairs;
+        if (!wg_wait_ge(&sy[1], pairs)) {if (tid == 0) {atomicExch(fail_flag, 1);} return;}
+        if (use_lds) {
+          // the solved panel pair into this workgroup's LDS (rows relative to rb; the second panel has no rows 0..15),
+          // coalesced along the rows, then the same LDS-operand MFMA path as the leader's
+          for (int t = tid; t < nrows_pad * 2 * NB; t += nthreads) {
+            const int c = t / nrows_pad, row = t - c * nrows_pad;
+            Xs[row * XS + c] = (row < nrows && (c < NB || row >= NB)) ? F[(rb + row) + (int64_t)(jb + c) * m] : 0.0;
+          }
+          __syncthreads();
+          trailing_update<true, 32>(F, Xs, m, rb, jb, nb_a, NB, nrows, nrows_pad, false, false, lane, g * nwaves + wave, G * nwaves);
+        } else {
+          trailing_update<false, 32>(F, nullptr, m, rb, jb, nb_a, NB, nrows, nrows_pad, false, false, lane, g * nwaves + wave, G * nwaves);
+        }
+        wg_publish_add(&sy[2], 1);
+        jb += 2 * NB;
+      }
+      return;
+    }
+    if (!wg_wait_ge(&sy[0], G)) {if (tid == 0) {atomicExch(fail_flag, 1);} return;}
+  }
   // 2. blocked right-looking partial Cholesky of the first ns columns
+  int pairs_published = 0;
   if (tid == 0) {s_fail = 0;}
   __syncthreads();
   // Panels are taken in pairs with a delayed update: after panel A only the next 16 columns of the trailing
@@ -657,10 +805,14 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
     __syncthreads();
     const int nb_b = NB;
     panel(jb + NB, nb_b, rb, Xs + NB);
+    if (G > 1) {wg_publish_add(&sy[1], 1); ++pairs_published;}      // both panels are in the front: the helpers may start
     if (use_lds) {
-      trailing_update<true, 32>(F, Xs, m, rb, jb, nb_a, nb_b, nrows, nrows_pad, false, false, lane, wave, nwaves);
+      trailing_update<true, 32>(F, Xs, m, rb, jb, nb_a, nb_b, nrows, nrows_pad, false, false, lane, wave, G * nwaves);
     } else {
-      trailing_update<false, 32>(F, Xs, m, rb, jb, nb_a, nb_b, nrows, nrows_pad, false, false, lane, wave, nwaves);
+      trailing_update<false, 32>(F, Xs, m, rb, jb, nb_a, nb_b, nrows, nrows_pad, false, false, lane, wave, G * nwaves);
+    }
+    if (G > 1) {
+      if (!wg_wait_ge(&sy[2], (G - 1) * pairs_published)) {if (tid == 0) {atomicExch(fail_flag, 1);} return;}
     }
     __syncthreads();
     TSTAMP();
@@ -677,9 +829,18 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
 }
 
 void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag,
-                             double * rhs, double * upd, void * stream)
+                             double * rhs, double * upd, int32_t * sync, int32_t matrix_added, void * stream)
 {
   if (n <= 0) {return;}
+  // workgroups per front: all of a launch's workgroups have to be resident at once (they wait for each other), and a
+  // workgroup of this kernel takes a CU (1024 threads, up to 150 KB of LDS) -> at most 224 of the 256; small fronts gain
+  // nothing.  KH_SPA_GROUP=1 switches the sharing off.
+  // Measured (10k / 30k graph, stage timers): with G = 5..8 the K = 32 update of a 456-row front drops from 44 to 25 us,
+  // but the leader's own panel chain (2 x diagonal block + 2 x row solve + thin update, ~33 us per pair) gets 8 us slower
+  // with the helpers polling beside it, and the level times do not move: opt-in (KH_SPA_GROUP=8), off by default.
+  static const int group_cap = std::getenv("KH_SPA_GROUP") ? std::atoi(std::getenv("KH_SPA_GROUP")) : 1;
+  int G = 1;
+  if (max_m >= 160 && n <= 112) {G = std::max(1, std::min(group_cap, 224 / n));}
   const int threads = max_m <= 96 ? 256 : (max_m <= 192 ? 512 : 1024);
   const int lds_rows = ((max_m < kMaxLdsRows ? max_m : kMaxLdsRows) + 15) & ~15;
   // panel + the front's right-hand side behind it; fronts beyond the LDS panel keep only the rhs (+ the
@@ -695,7 +856,8 @@ void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
   if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 64 * sizeof(long long), hipHostMallocDefault);}
-  hipLaunchKernelGGL(k_factor, dim3(n), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, timing ? tbuf : nullptr, rhs, upd, lds_rows);
+  hipLaunchKernelGGL(k_factor, dim3(n * G), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, timing ? tbuf : nullptr, rhs, upd,
+                     lds_rows, G, sync, (int)matrix_added);
   if (timing) {
     (void)hipStreamSynchronize((hipStream_t)stream);
     std::fprintf(stderr, "[k_factor] n=%d max_m=%d front0 m=%lld ns=%lld stamps(x10ns):", n, max_m, tbuf[63] >> 32, tbuf[63] & 0xffffffff);

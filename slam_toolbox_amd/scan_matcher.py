@@ -194,6 +194,24 @@ class ScanMatcher:
                    "kh_matcher_correlate_batch")
         return resp, means.reshape(n, 3), covs.reshape(n, 3, 3), status
 
+    def ComputePositionalCovariance(self, bestPose, bestResponse, searchCenter, searchSpaceOffset, searchSpaceResolution,
+                                    searchAngleResolution, slot=0):
+        """ScanMatcher::ComputePositionalCovariance (Mapper.cpp:874-966) on the probabilities of the last coarse search"""
+        cov = np.zeros(9)
+        capi.check(capi.lib().kh_matcher_positional_covariance(self._h, slot, _d(bestPose), float(bestResponse), _d(searchCenter),
+                                                               _d(searchSpaceOffset), _d(searchSpaceResolution),
+                                                               float(searchAngleResolution), cov), "kh_matcher_positional_covariance")
+        return cov.reshape(3, 3)
+
+    def ComputeAngularCovariance(self, scan, bestPose, bestResponse, searchCenter, searchAngleOffset, searchAngleResolution, slot=0):
+        """ScanMatcher::ComputeAngularCovariance (Mapper.cpp:977-1025): returns the theta-theta variance"""
+        cov = np.zeros(9)
+        cs = scan.c()
+        capi.check(capi.lib().kh_matcher_angular_covariance(self._h, slot, C.byref(cs), _d(bestPose), float(bestResponse),
+                                                            _d(searchCenter), float(searchAngleOffset), float(searchAngleResolution),
+                                                            cov), "kh_matcher_angular_covariance")
+        return cov[8]
+
     # ---- introspection (parity tests / bench) ----
     def grid_info(self, slot=0):
         g = capi.KhGridInfo()

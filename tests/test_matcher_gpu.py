@@ -383,3 +383,27 @@ def test_dual_copy_layout_follows_the_grid(kartohip_lib):
     sums2, _ = hm.volume()
     assert np.array_equal(sums, sums2)
     hm.close()
+
+
+@pytest.mark.parametrize("preset", ["K", "S"])
+def test_covariance_members_reproduce_the_search(kartohip_lib, preset):
+    """ComputePositionalCovariance / ComputeAngularCovariance as separate calls (the two public members of
+    karto::ScanMatcher nobody calls from outside, Mapper.h:1405-1427) give what CorrelateScan computed with them inside,
+    which the tests above pin to the oracle: position block from the coarse search, theta-theta from the fine one."""
+    sc = Scenario(seed=5, n_base=8, start=60, perturb=(-0.04, 0.06, -0.03))
+    hq, hb = sc.hip_scans()
+    hm = make_hip_matcher(preset)
+    hm.AddScans(hq, hb)
+    res = 1.0 / hm.grid_info()["scale"]
+    p = PRESETS[preset]["params"]
+    side = PRESETS[preset]["create"][0]
+    off = 0.5 * round(side / res) * res
+    coarse = ((off, off), (2 * res, 2 * res), p["coarse_search_angle_offset"], p["coarse_angle_resolution"])
+    r, mean, cov = hm.CorrelateScan(hq, sc.query_pose, *coarse, True, None, False)
+    again = hm.ComputePositionalCovariance(mean, r, sc.query_pose, coarse[0], coarse[1], coarse[3])
+    _assert_same(cov, again, "positional covariance")
+    fine = ((res, res), (res, res), 0.5 * p["coarse_angle_resolution"], p["fine_search_angle_offset"])
+    r2, mean2, cov2 = hm.CorrelateScan(hq, mean, *fine, True, cov, True)
+    tt = hm.ComputeAngularCovariance(hq, mean2, r2, mean, fine[2], fine[3])
+    _assert_same(cov2[2, 2], tt, "angular covariance")
+    hm.close()
