@@ -145,7 +145,7 @@ constexpr size_t kOutHeaderWords = 2 + kTieCap / 2;
 
 // one (job, base scan) pair of a batch: k_find_valid walks one scan per lane
 struct ValidItem {int32_t job, scan;};
-void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, void * stream);
+void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream);
 void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_cap, void * stream);
 void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
 void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream);

@@ -363,7 +363,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     std::memcpy(m->h_arena + 2 * copies[i].dst, copies[i].src, sizeof(double) * 2 * static_cast<size_t>(copies[i].n));
   });
   const int32_t n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
-  int32_t max_points = 0, max_cap = 0;
+  int32_t max_points = 0, max_cap = 0, max_scan_n = 1;
   bool any_copies = false;
   ValidItem * items = reinterpret_cast<ValidItem *>(m->h_meta + items_at);
   size_t item = 0;
@@ -380,6 +380,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
       const kh_scan & sc = reqs[r].base[b];
       if (sc.points_xy == nullptr || sc.n <= 0) {continue;}
       uniform_n = uniform_n < 0 ? sc.n : (uniform_n == sc.n ? uniform_n : 0);
+      max_scan_n = std::max(max_scan_n, sc.n);
       scan_pt[k] = arena_of.at(sc.points_xy);
       scan_prefix[k] = run;
       run += sc.n;
@@ -440,7 +441,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[2], m->stream));}
   // 3. Grid::Clear (Karto.h:4612-4615), FindValidPoints, stamps
   launch_raster_clear(m->d_rjobs, static_cast<int32_t>(n_jobs), m->stream);
-  launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), m->stream);
+  launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), max_scan_n, m->stream);
   if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
   launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->stream);
   if (any_copies) {launch_repitch(m->d_rjobs, static_cast<int32_t>(n_jobs), m->rt_w * m->rt_h, m->stream);}

@@ -47,7 +47,7 @@ __device__ __forceinline__ int32_t d_to_int(double v)
 // passes, and the tail after the last trigger never is, so pass 2 walks back and hands every reading the verdict of the
 // first trigger behind it.
 constexpr int kCodeWords = 128;      // 2-bit codes of up to 2048 readings per lane live in LDS between the two passes
-__global__ __launch_bounds__(64) void k_find_valid(const RasterJob * jobs, const ValidItem * items, int n_items)
+__global__ __launch_bounds__(64) void k_find_valid_lane(const RasterJob * jobs, const ValidItem * items, int n_items)
 {
   __shared__ uint32_t s_codes[kCodeWords][64];           // [word][lane]: conflict-free
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,10 +117,96 @@ __global__ __launch_bounds__(64) void k_find_valid(const RasterJob * jobs, const
   }
 }
 
-void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, void * stream)
+// The same state machine with one WAVE per (job, base scan) pair: the readings sit in LDS, and "the next reading more
+// than 0.1 m from the reference point" -- the only thing the machine waits for between two triggers -- is found for 64
+// readings at a time (per-lane distance test, ballot, count trailing zeros).  The chain is then one step per TRIGGER
+// (a few hundred per scan) instead of one per reading, and a step costs an LDS read, ten FP64 operations and a ballot:
+// ~30 us per scan against 275 us for the lane-per-scan walk -- which is what a single MatchScan (10 running scans: ten
+// busy lanes on the whole chip) used to spend in this kernel.  The operations on the values are the reference's, in its
+// order; only the search between triggers is parallel.
+__device__ __forceinline__ double wave_bcast(double v, int lane)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__global__ __launch_bounds__(256) void k_find_valid(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n)
+{
+  extern __shared__ double2 s_pts_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= n_items) {return;}                             // wave-uniform; no block-wide barrier below
+  double2 * s_pts = s_pts_all + (size_t)wave * max_n;
+  const RasterJob & job = jobs[items[t].job];
+  const int k = items[t].scan;
+  const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
+  const double2 * pts = reinterpret_cast<const double2 *>(job.arena) + job.scan_pt[k];
+  uint8_t * out = job.active + job.scan_prefix[k];
+  for (int i = lane; i < n; i += 64) {s_pts[i] = pts[i];}
+  __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's LDS writes have landed (only it reads them)
+  __builtin_amdgcn_wave_barrier();
+  const double vx = job.view_x, vy = job.view_y;
+  const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
+  // the reference point starts at the first reading without a NaN coordinate (Mapper.cpp:1127-1136); nothing can trigger
+  // before it (the distances to NaN readings are NaN) nor at it (distance zero)
+  int pos = n;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < n && !isnan(s_pts[min(i, n - 1)].x) && !isnan(s_pts[min(i, n - 1)].y);
+    const unsigned long long mask = __ballot(ok);
+    if (mask) {pos = base + __builtin_ctzll(mask); break;}
+  }
+  int trailing = 0;
+  if (pos < n) {
+    double fx = s_pts[pos].x, fy = s_pts[pos].y;
+    ++pos;
+    while (pos < n) {
+      // first reading at or after pos that lies more than 0.1 m from (fx, fy)
+      int j = -1;
+      for (int base = pos & ~63; base < n; base += 64) {
+        const int i = base + lane;
+        const double2 c = s_pts[min(i, n - 1)];
+        const double dx = fx - c.x, dy = fy - c.y;
+        const bool hit = i >= pos && i < n && (dx * dx + dy * dy > min_square_distance);
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {j = base + __builtin_ctzll(mask); break;}
+      }
+      if (j < 0) {break;}
+      const double cx = s_pts[j].x, cy = s_pts[j].y;
+      const double a = vy - fy;
+      const double b = fx - vx;
+      const double cc = fy * vx - fx * vy;
+      const double ss = cx * a + cy * b + cc;
+      fx = cx; fy = cy;
+      // the run [trailing, j) is emitted iff the trigger lies on the viewpoint's side; either way it ends here
+      const uint8_t keep = ss < 0.0 ? 0 : 1;
+      for (int i = trailing + lane; i < j; i += 64) {out[i] = keep;}
+      trailing = j;
+      pos = j + 1;
+    }
+  }
+  for (int i = trailing + lane; i < n; i += 64) {out[i] = 0;}        // the tail after the last trigger is never emitted
+}
+
+void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream)
 {
   if (n_items <= 0) {return;}
-  hipLaunchKernelGGL(k_find_valid, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_jobs, d_items, (int)n_items);
+  // one lane per scan when the batch holds thousands of scans (measured: 6400 scans take 0.29 ms lane-per-scan -- every
+  // lane busy, one memory latency per reading -- against 0.6 ms wave-per-scan; ten scans take 275 us against ~100 us), or
+  // when 4 scans x 16 B per reading would not fit the LDS
+  if (max_n > 2048 || n_items > 4096) {
+    hipLaunchKernelGGL(k_find_valid_lane, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_jobs, d_items, (int)n_items);
+    return;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2048 * 16);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_find_valid, dim3((n_items + 3) / 4), dim3(256), (size_t)4 * max_n * sizeof(double2), (hipStream_t)stream, d_jobs,
+                     d_items, (int)n_items, (int)max_n);
 }
 
 // ---------------------------------------------------------------------------------------------
