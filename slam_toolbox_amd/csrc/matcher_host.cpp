@@ -359,9 +359,6 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   rc = ensure_device(m->d_meta, m->cap_dmeta, std::max<size_t>(meta_words, 1), m->stream); if (rc) {return rc;}
   // the pinned mirrors are reused by every call: the previous call's uploads must have left them
   KH_HIP(hipStreamSynchronize(m->stream));
-  HostPool::instance().run(copies.size(), [&](size_t i) {
-    std::memcpy(m->h_arena + 2 * copies[i].dst, copies[i].src, sizeof(double) * 2 * static_cast<size_t>(copies[i].n));
-  });
   const int32_t n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
   int32_t max_points = 0, max_cap = 0, max_scan_n = 1;
   bool any_copies = false;
@@ -430,17 +427,21 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
       }
     }
   }
-  // 2. upload: arena, scan lists + work items, jobs
-  if (arena_points) {
-    KH_HIP(hipMemcpyAsync(m->d_arena, m->h_arena, sizeof(double) * 2 * arena_points, hipMemcpyHostToDevice, m->stream));
-  }
+  // 2. upload the jobs and scan lists; Grid::Clear (Karto.h:4612-4615) -- up to 16.8 MB per job -- needs nothing else and
+  // runs while the pool gathers the distinct scans' points into the pinned arena
   if (meta_words) {
     KH_HIP(hipMemcpyAsync(m->d_meta, m->h_meta, sizeof(int32_t) * meta_words, hipMemcpyHostToDevice, m->stream));
   }
   KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * n_jobs, hipMemcpyHostToDevice, m->stream));
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[2], m->stream));}
-  // 3. Grid::Clear (Karto.h:4612-4615), FindValidPoints, stamps
   launch_raster_clear(m->d_rjobs, static_cast<int32_t>(n_jobs), m->stream);
+  HostPool::instance().run(copies.size(), [&](size_t i) {
+    std::memcpy(m->h_arena + 2 * copies[i].dst, copies[i].src, sizeof(double) * 2 * static_cast<size_t>(copies[i].n));
+  });
+  if (arena_points) {
+    KH_HIP(hipMemcpyAsync(m->d_arena, m->h_arena, sizeof(double) * 2 * arena_points, hipMemcpyHostToDevice, m->stream));
+  }
+  // 3. FindValidPoints, stamps
   launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), max_scan_n, m->stream);
   if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
   launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->stream);

@@ -119,8 +119,8 @@ struct kh_spa
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
   int32_t n_slots = 0;
-  std::vector<int32_t> level_offsets, level_max_m;
-  DevBuf<double> d_upd;
+  std::vector<int32_t> level_offsets, level_max_m, level_max_ns;
+  DevBuf<double> d_upd, d_fsb;
   // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
   int32_t shard_rank = 0, shard_world = 1;
   kh_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
@@ -559,13 +559,13 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     // level lists, concatenated
     std::vector<int32_t> level_fronts;
     s->level_offsets.assign(1, 0);
-    s->level_max_m.clear();
+    s->level_max_m.clear(); s->level_max_ns.clear();
     for (auto & lv : sym.levels) {
       level_fronts.insert(level_fronts.end(), lv.begin(), lv.end());
       s->level_offsets.push_back(static_cast<int32_t>(level_fronts.size()));
-      int32_t mm = 0;
-      for (int32_t k : lv) {mm = std::max(mm, sym.front_m[k]);}
-      s->level_max_m.push_back(mm);
+      int32_t mm = 0, mns = 0;
+      for (int32_t k : lv) {mm = std::max(mm, sym.front_m[k]); mns = std::max(mns, sym.front_ns[k]);}
+      s->level_max_m.push_back(mm); s->level_max_ns.push_back(mns);
     }
     // uploads
     hipStream_t st = s->stream;
@@ -597,6 +597,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_fail.ensure(4);
     r2 |= s->d_sync.ensure(4 * static_cast<size_t>(sym.n_fronts) + 4);
     r2 |= s->d_upd.ensure(static_cast<size_t>(3) * sym.rows_ptr[sym.n_fronts] + 16);
+    r2 |= s->d_fsb.ensure(static_cast<size_t>(3) * (static_cast<size_t>(nf) + sym.rows_ptr[sym.n_fronts]) + 16);
     if (r2) {return KH_ERR_HIP;}
     // the uploads above read pageable host vectors of this block: they must have landed before the block ends
     KS_HIP(hipStreamSynchronize(st));
@@ -696,7 +697,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
-  s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release();
+  s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release();
   for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   for (auto & row : s->ev_lin) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
@@ -1282,8 +1283,8 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       // narrow levels: the extend-add runs chip-wide in its own launch instead of on each front's single CU
       const bool split = l > 0 && n_level <= ea_limit;
       if (split) {spa_launch_extend_add(dev, s->d_level_fronts.p + s->level_offsets[l], n_level, s->level_max_m[l], st);}
-      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], n_level, s->level_max_m[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p,
-        s->d_sync.p + 4 * s->level_offsets[l], split ? 1 : 0, st);
+      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p,
+        s->d_rhs.p, s->d_upd.p, s->d_fsb.p, s->d_sync.p + 4 * s->level_offsets[l], split ? 1 : 0, st);
       dbg("factor+forward", l);
     }
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][1], st));}

@@ -64,8 +64,10 @@ void spa_launch_assemble(const SpaDev & d, const double * scale, const double * 
 // max_m = largest front dimension of the level (sizes the LDS panel / vector)
 // also does the forward solve of the level: rhs (elimination order) in, y out; upd as for the backward level
 // sync: 4 ints per front of the level (zeroed before every factorisation): hand-offs between the workgroups sharing a front
-void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t * fail_flag,
-                             double * rhs, double * upd, int32_t * sync, int32_t matrix_added, void * stream);
+// max_ns = most pivot columns of a front of the level; fsb: 3 * (free nodes + front_rows_ptr[n_fronts]) doubles, where the
+// right-hand-side slice of a front waits between the launches of the split form
+void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
+                             double * rhs, double * upd, double * fsb, int32_t * sync, int32_t matrix_added, void * stream);
 // the children's update matrices of every front of the level summed into the fronts, one workgroup per (front, 16
 // destination columns); follow with spa_launch_factor_level(..., matrix_added = 1, ...)
 void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream);
