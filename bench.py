@@ -173,18 +173,40 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
         import torch
         import torch.distributed as dist
         from slam_toolbox_amd import comm as khcomm
+        on_gpu = dist.get_backend() == "nccl"
+        uid = torch.zeros(khcomm.ID_BYTES, dtype=torch.uint8)
+        why = ""
         try:
-            uid = torch.zeros(khcomm.ID_BYTES, dtype=torch.uint8)
             if rank == 0:
                 uid = torch.from_numpy(khcomm.unique_id().copy())
-            uid = uid.to("cuda") if dist.get_backend() == "nccl" else uid
-            dist.broadcast(uid, src=0)
-            communicator = khcomm.Communicator(device, rank, world, uid.cpu().numpy())
-            sol.SetCommunicator(communicator)
-            collective = "in-library ncclAllReduce (RCCL)"
         except Exception as exc:
+            why = type(exc).__name__
+        uid = uid.to("cuda") if on_gpu else uid
+        dist.broadcast(uid, src=0)
+        # ncclCommInitRank is collective: it runs on a helper thread with a deadline, and the ranks then AGREE (min over
+        # ranks) on whether everybody has a communicator -- one rank falling back alone would leave the others waiting
+        # inside an all-reduce for ever
+        box = {}
+
+        def init():
+            try:
+                box["comm"] = khcomm.Communicator(device, rank, world, uid.cpu().numpy())
+            except Exception as exc:
+                box["why"] = type(exc).__name__
+        import threading
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        ok = torch.tensor([1 if "comm" in box else 0], dtype=torch.int32)
+        ok = ok.to("cuda") if on_gpu else ok
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            sol.SetCommunicator(box["comm"])
+            collective = "in-library ncclAllReduce (RCCL)"
+        else:
+            why = box.get("why", why or ("timeout" if th.is_alive() else "refused on another rank"))
             sol.enable_sharding(rank, world)
-            collective = f"torch.distributed.all_reduce through the C-ABI callback ({type(exc).__name__})"
+            collective = f"torch.distributed.all_reduce through the C-ABI callback (in-library communicator: {why})"
     # config[3] says "serialized pose graph": the graph goes through the library's own file format
     # (kh_spa_save / kh_spa_load, binary) before every solve, like loadSerializedPoseGraph rebuilds the plugin
     import tempfile
@@ -523,6 +545,11 @@ def occupancy_leg(device=0, n_scans=1000):
 
 
 def main():
+    # ONE JSON line on stdout: everything else a library prints there (RCCL's version banner at communicator creation,
+    # gloo's connection notes, karto's "Registering sensor") is pointed at stderr for the whole run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -741,7 +768,8 @@ def main():
                 out.update(replay_leg(local_rank))
             except Exception as exc:
                 out["replay_leg_error"] = repr(exc)[:200]
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     for h in handles:
         h.close()
     if world > 1:
