@@ -30,6 +30,7 @@ static void make_scan(kh_scan * out, double * ranges, double * points, double x,
   const double min_angle = -3.14159265358979323846 / 2.0, ang_res = 3.14159265358979323846 / (N_BEAMS - 1);
   for (int i = 0; i < N_BEAMS; ++i) {ranges[i] = room_range(x, y, th + min_angle + i * ang_res);}
   out->n = N_BEAMS; out->ranges = ranges; out->points_xy = points;
+  out->device_points_xy = NULL;                  /* not kept resident on the device: uploaded with the call */
   out->sensor_pose[0] = px; out->sensor_pose[1] = py; out->sensor_pose[2] = pth;
   kh_scan_points(ranges, N_BEAMS, out->sensor_pose, min_angle, ang_res, points);   /* LocalizedRangeScan::Update */
 }

@@ -56,6 +56,12 @@ typedef struct kh_scan {
   const double * ranges;
   const double * points_xy;
   double sensor_pose[3];
+  /* optional (NULL = not resident): the same 2 * n doubles as points_xy in DEVICE memory of the matcher's device
+   * (kh_device_malloc / kh_device_upload).  A scan used as a BASE scan (AddScans / MatchScan) is then read where it
+   * lies instead of being uploaded with every call -- the scan store of a mapper belongs in HBM (173 MB
+   * for 10 k scans); the caller re-uploads when the scan's pose changes (LocalizedRangeScan::Update).  points_xy must
+   * still be valid: the query side and the host half read it. */
+  const double * device_points_xy;
 } kh_scan;
 
 /* helper restating LocalizedRangeScan::Update for callers without karto objects

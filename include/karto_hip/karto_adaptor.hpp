@@ -42,6 +42,7 @@ inline kh_scan to_scan(karto::LocalizedRangeScan * pScan, std::vector<double> & 
   s.points_xy = points.data();
   const karto::Pose2 pose = pScan->GetSensorPose();
   s.sensor_pose[0] = pose.GetX(); s.sensor_pose[1] = pose.GetY(); s.sensor_pose[2] = pose.GetHeading();
+  s.device_points_xy = nullptr;            // karto keeps its scans on the host: uploaded per call
   return s;
 }
 

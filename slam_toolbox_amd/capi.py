@@ -22,7 +22,7 @@ bptr = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 class KhScan(C.Structure):
     _fields_ = [("n", C.c_int32), ("ranges", C.POINTER(C.c_double)), ("points_xy", C.POINTER(C.c_double)),
-                ("sensor_pose", C.c_double * 3)]
+                ("sensor_pose", C.c_double * 3), ("device_points_xy", C.c_void_p)]
 
 
 class KhMatchParams(C.Structure):

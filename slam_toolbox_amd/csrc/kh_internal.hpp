@@ -34,8 +34,8 @@ constexpr uint32_t kHashEmpty = 0xffffffffu;
 struct RasterJob
 {
   uint8_t * grid;            // data_size + kGridPad bytes
-  const double * arena;      // x0, y0, x1, y1, ... of every distinct base scan of the batch
-  const int32_t * scan_pt;   // n_scans: first point of base scan k in the arena
+  const double * const * scan_ptr;   // n_scans: the readings (x0, y0, x1, y1, ...) of base scan k -- in the batch's upload arena, or
+                                     // wherever the caller keeps the scan resident on the device (kh_scan::device_points_xy)
   const int32_t * scan_prefix;   // n_scans + 1: first job point of base scan k
   int32_t n_scans;
   int32_t uniform_n;         // readings per base scan when all the job's scans have the same count (0 = ragged: bisect the prefix)

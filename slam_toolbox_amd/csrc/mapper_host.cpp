@@ -118,7 +118,15 @@ struct MScan
   double barycenter[2] = {0.0, 0.0};
   double bbox[4] = {0.0, 0.0, 0.0, 0.0};   // min x, min y, max x, max y of the sensor position and the filtered readings
   int32_t n_filtered = 0;
+  // the unfiltered readings once more, in HBM: as a base scan of a match the scan is read where it lies (kh_scan::
+  // device_points_xy).  Uploaded on first use and again after the pose has moved (update_scan marks it stale).
+  double * d_points = nullptr;
+  bool d_stale = true;
   Pose sensor_pose() const {Pose p = corrected; p.h = normalize_angle(corrected.h); return p;}
+  MScan() = default;
+  MScan(const MScan &) = delete;
+  MScan & operator=(const MScan &) = delete;
+  ~MScan() {if (d_points) {kh_device_free(d_points);}}
 };
 
 struct Laser {int32_t n = 0; double min_angle = 0, ang_res = 0, min_range = 0, max_range = 0, range_threshold = 0;};
@@ -128,6 +136,7 @@ void update_scan(MScan & s, const Laser & L)
 {
   const Pose sp = s.sensor_pose();
   s.points.resize(2 * static_cast<size_t>(L.n));
+  s.d_stale = true;
   s.filtered.clear();
   double sum_x = 0.0, sum_y = 0.0;
   int32_t n_filtered = 0;
@@ -196,6 +205,23 @@ kh_scan as_kh_scan(const MScan & s)
   k.points_xy = s.points.data();
   const Pose sp = s.sensor_pose();
   k.sensor_pose[0] = sp.x; k.sensor_pose[1] = sp.y; k.sensor_pose[2] = sp.h;
+  k.device_points_xy = nullptr;
+  return k;
+}
+
+// the scan as a BASE scan of a match: its readings resident on the mapper's device
+kh_scan as_base_scan(kh_mapper * m, MScan & s)
+{
+  kh_scan k = as_kh_scan(s);
+  const int64_t bytes = static_cast<int64_t>(sizeof(double)) * static_cast<int64_t>(s.points.size());
+  if (bytes > 0) {
+    if (!s.d_points) {
+      void * p = nullptr;
+      if (kh_device_malloc(m->device, bytes, &p) == KH_OK) {s.d_points = static_cast<double *>(p); s.d_stale = true;}
+    }
+    if (s.d_points && s.d_stale && kh_device_upload(s.d_points, s.points.data(), bytes) == KH_OK) {s.d_stale = false;}
+    if (s.d_points && !s.d_stale) {k.device_points_xy = s.d_points;}      // any failure: the call uploads the scan itself
+  }
   return k;
 }
 
@@ -341,7 +367,7 @@ int match_chains(kh_mapper * m, kh_matcher * matcher, const std::vector<kh_scan>
     std::vector<kh_scan> base;
     std::vector<int32_t> begin(nb + 1, 0);
     for (size_t i = 0; i < nb; ++i) {
-      for (int32_t c : chains[at + i]) {base.push_back(as_kh_scan(*m->scans[c]));}
+      for (int32_t c : chains[at + i]) {base.push_back(as_base_scan(m, *m->scans[c]));}
       begin[i + 1] = static_cast<int32_t>(base.size());
     }
     std::vector<double> means(3 * nb), covs(9 * nb), resp(nb);
@@ -638,7 +664,7 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
   if (m->p.use_scan_matching && last) {
     const kh_scan q = as_kh_scan(*scan);
     std::vector<kh_scan> base;
-    for (int32_t r : m->running) {base.push_back(as_kh_scan(*m->scans[r]));}
+    for (int32_t r : m->running) {base.push_back(as_base_scan(m, *m->scans[r]));}
     double mean[3], response = 0.0;
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = kh_matcher_match(m->seq, &q, base.data(), static_cast<int32_t>(base.size()), 1, 1, mean, cov, &response);

@@ -338,6 +338,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
       const kh_scan & sc = reqs[r].base[b];
       if (sc.points_xy == nullptr || sc.n <= 0) {continue;}      // NULL scan: skipped (Mapper.cpp:1039-1041)
       ++scans_of[r]; pts += sc.n;
+      if (sc.device_points_xy) {continue;}                        // resident on the device: nothing to upload
       auto it = arena_of.find(sc.points_xy);
       if (it == arena_of.end()) {
         arena_of.emplace(sc.points_xy, static_cast<int32_t>(arena_points));
@@ -348,7 +349,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     if (pts > (1 << 30) || arena_points > (1u << 30)) {set_error("too many base scan points in one batch"); return KH_ERR_INVALID_ARG;}
     points_of[r] = static_cast<int32_t>(pts);
     meta_at[r] = meta_words;
-    meta_words += 2 * scans_of[r] + 1;
+    meta_words += 3 * scans_of[r] + 1 + ((scans_of[r] + 1) & 1);      // 64-bit scan pointers, then the prefix (kept 8-byte aligned)
     n_items += scans_of[r];
   }
   const size_t items_at = meta_words;
@@ -370,15 +371,15 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     // MatchScan steps 1-4, Mapper.cpp:543-569
     s.off_x = pose[0] - (0.5 * (m->roi_w - 1) * res);
     s.off_y = pose[1] - (0.5 * (m->roi_h - 1) * res);
-    int32_t * scan_pt = m->h_meta + meta_at[r];
-    int32_t * scan_prefix = scan_pt + scans_of[r];
+    const double ** scan_ptr = reinterpret_cast<const double **>(m->h_meta + meta_at[r]);
+    int32_t * scan_prefix = m->h_meta + meta_at[r] + 2 * scans_of[r];
     int32_t k = 0, run = 0, uniform_n = -1;
     for (int32_t b = 0; b < reqs[r].n_base; ++b) {
       const kh_scan & sc = reqs[r].base[b];
       if (sc.points_xy == nullptr || sc.n <= 0) {continue;}
       uniform_n = uniform_n < 0 ? sc.n : (uniform_n == sc.n ? uniform_n : 0);
       max_scan_n = std::max(max_scan_n, sc.n);
-      scan_pt[k] = arena_of.at(sc.points_xy);
+      scan_ptr[k] = sc.device_points_xy ? sc.device_points_xy : m->d_arena + 2 * static_cast<size_t>(arena_of.at(sc.points_xy));
       scan_prefix[k] = run;
       run += sc.n;
       items[item].job = static_cast<int32_t>(r); items[item].scan = k; ++item;
@@ -391,8 +392,8 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     rc = ensure_device(s.d_rlists, s.cap_rlists, std::max<size_t>(np, 1) * 6, m->stream); if (rc) {return rc;}
     RasterJob & j = m->h_rjobs[r];
     std::memset(&j, 0, sizeof(j));
-    j.grid = s.d_grid; j.arena = m->d_arena;
-    j.scan_pt = m->d_meta + meta_at[r]; j.scan_prefix = m->d_meta + meta_at[r] + scans_of[r];
+    j.grid = s.d_grid;
+    j.scan_ptr = reinterpret_cast<const double * const *>(m->d_meta + meta_at[r]); j.scan_prefix = m->d_meta + meta_at[r] + 2 * scans_of[r];
     j.n_scans = static_cast<int32_t>(scans_of[r]);
     j.uniform_n = std::max(uniform_n, 0);
     j.view_x = pose[0]; j.view_y = pose[1];
@@ -519,11 +520,17 @@ static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na)
   return L;
 }
 
+// rows per lane of the scoring kernel (a tile is 4 * ry lattice rows): the variant that loads the fewest rows for ny --
+// 81 rows are 3 tiles of 28 (ry 7: 21 row loads per beam and column of tiles) rather than 3 tiles of 32 (ry 8: 24)
 static int pick_ry(int32_t ny)
 {
-  if (ny > 16) {return 8;}
-  if (ny > 4) {return 4;}
-  return 1;
+  if (ny <= 4) {return 1;}
+  int best = 8, best_cost = 1 << 30;
+  for (int ry : {8, 7, 4}) {
+    const int cost = ((ny + 4 * ry - 1) / (4 * ry)) * ry;
+    if (cost < best_cost) {best = ry; best_cost = cost;}
+  }
+  return best;
 }
 
 // Host half of ComputePositionalCovariance (Mapper.cpp:874-966) on the lattice maxima
@@ -1465,6 +1472,15 @@ int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, c
 {
   if (!m || n < 0 || n > m->max_batch || !queries || !base_begin || !means || !covs || !responses) {return KH_ERR_INVALID_ARG;}
   KH_HIP(hipSetDevice(m->device));
+  static const bool batch_timing = std::getenv("KH_MATCH_TIMING") != nullptr;
+  const auto t_batch = std::chrono::steady_clock::now();
+  struct Report {
+    bool on; std::chrono::steady_clock::time_point t0; int32_t n;
+    ~Report() {
+      if (on) {std::fprintf(stderr, "[kh match_batch] %d matches, %.3f ms inside the call\n", n,
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());}
+    }
+  } report{batch_timing, t_batch, n};
   const kh_match_params & mp = m->params;
   std::vector<int> st(n, KH_OK);
   std::vector<int32_t> active;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void k_find_valid_lane(const RasterJob * jobs, 
   const RasterJob & job = jobs[items[t].job];
   const int k = items[t].scan;
   const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
-  const double2 * pts = reinterpret_cast<const double2 *>(job.arena) + job.scan_pt[k];
+  const double2 * pts = reinterpret_cast<const double2 *>(job.scan_ptr[k]);
   uint8_t * out = job.active + job.scan_prefix[k];
   const bool in_lds = n <= 16 * kCodeWords;              // longer scans keep their codes in `out` (global) instead
   const double vx = job.view_x, vy = job.view_y;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_find_valid(const RasterJob * jobs, cons
   const RasterJob & job = jobs[items[t].job];
   const int k = items[t].scan;
   const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
-  const double2 * pts = reinterpret_cast<const double2 *>(job.arena) + job.scan_pt[k];
+  const double2 * pts = reinterpret_cast<const double2 *>(job.scan_ptr[k]);
   uint8_t * out = job.active + job.scan_prefix[k];
   for (int i = lane; i < n; i += 64) {s_pts[i] = pts[i];}
   __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's LDS writes have landed (only it reads them)
@@ -257,14 +257,14 @@ __device__ __forceinline__ double2 job_point(const RasterJob & job, int p)
 {
   if (job.uniform_n > 0) {                      // the usual case: one laser, every scan has the same number of beams
     const int k = p / job.uniform_n;
-    return reinterpret_cast<const double2 *>(job.arena)[job.scan_pt[k] + (p - k * job.uniform_n)];
+    return reinterpret_cast<const double2 *>(job.scan_ptr[k])[p - k * job.uniform_n];
   }
   int lo = 0, hi = job.n_scans;                 // scan_prefix[lo] <= p < scan_prefix[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (job.scan_prefix[mid] <= p) {lo = mid;} else {hi = mid;}
   }
-  return reinterpret_cast<const double2 *>(job.arena)[job.scan_pt[lo] + (p - job.scan_prefix[lo])];
+  return reinterpret_cast<const double2 *>(job.scan_ptr[lo])[p - job.scan_prefix[lo]];
 }
 // CoordinateConverter::WorldToGrid (Karto.h:4421-4436) + the ROI test of AddScan (Mapper.cpp:1083-1088)
 __device__ __forceinline__ bool roi_cell(const RasterJob & job, double2 w, int32_t & gx, int32_t & gy)
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
   constexpr int PX = (SX == 1) ? kTileSpan : (kTileSpan + 1) / 2;   // poses per tile row
   constexpr int TY = 4 * RY;            // lattice rows per tile
   constexpr int NB = (SX == 1) ? 4 : 2; // byte positions per lane per row
-  constexpr int UB = (RY >= 8) ? KH_UB8 : 8;   // beams per inner iteration
+  constexpr int UB = (RY >= 7) ? KH_UB8 : 8;   // beams per inner iteration
   const int tx = tile % job.tiles_x, ty = tile / job.tiles_x;
   const int x0 = tx * PX, y0 = ty * TY;
   const int lane = threadIdx.x & 63;
@@ -1095,9 +1095,9 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
   static const int lds_pad = std::getenv("KH_K3_LDS_PAD") ? std::atoi(std::getenv("KH_K3_LDS_PAD")) : 0;
 #define KH_SCORE(SXV, RYV) hipLaunchKernelGGL((k_score<SXV, RYV, AW>), grid, dim3(256 * AW), lds_pad, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
   if (sx_variant == 2) {
-    if (ry == 8) {KH_SCORE(2, 8);} else if (ry == 4) {KH_SCORE(2, 4);} else {KH_SCORE(2, 1);}
+    if (ry == 8) {KH_SCORE(2, 8);} else if (ry == 7) {KH_SCORE(2, 7);} else if (ry == 4) {KH_SCORE(2, 4);} else {KH_SCORE(2, 1);}
   } else {
-    if (ry == 8) {KH_SCORE(1, 8);} else if (ry == 4) {KH_SCORE(1, 4);} else {KH_SCORE(1, 1);}
+    if (ry == 8) {KH_SCORE(1, 8);} else if (ry == 7) {KH_SCORE(1, 7);} else if (ry == 4) {KH_SCORE(1, 4);} else {KH_SCORE(1, 1);}
   }
 #undef KH_SCORE
 }

@@ -121,6 +121,7 @@ struct kh_spa
   int32_t n_slots = 0;
   std::vector<int32_t> level_offsets, level_max_m, level_max_ns;
   DevBuf<double> d_upd, d_fsb;
+  DevBuf<double> d_Hg_alt, d_best;          // normal equations at the candidate point (speculative); minimum-cost iterate
   // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
   int32_t shard_rank = 0, shard_world = 1;
   kh_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
@@ -591,6 +592,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_edge_lin.ensure(scratch); r2 |= s->d_edge_cost.ensure(std::max(E, 1));
     // H and g share one buffer so that a sharded run sums them across ranks with ONE all-reduce
     r2 |= s->d_Hg.ensure(static_cast<size_t>(n_slots) * 9 + static_cast<size_t>(nf) * 3 + 8);
+    r2 |= s->d_Hg_alt.ensure(static_cast<size_t>(n_slots) * 9 + static_cast<size_t>(nf) * 3 + 8);
     r2 |= s->d_fronts.ensure(static_cast<size_t>(sym.fronts_size) + 16);
     r2 |= s->d_scale.ensure(3 * nf); r2 |= s->d_diag.ensure(3 * nf); r2 |= s->d_rhs.ensure(3 * nf);
     r2 |= s->d_step.ensure(3 * nf); r2 |= s->d_delta.ensure(3 * nf);
@@ -616,7 +618,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   for (int32_t i = 0; i < N; ++i) {std::copy(s->nodes[i].pose, s->nodes[i].pose + 3, x.begin() + 3 * i);}
   int r3 = 0;
   r3 |= s->d_edge_z.upload(z, s->stream); r3 |= s->d_edge_u.upload(u, s->stream);
-  r3 |= s->d_x.upload(x, s->stream); r3 |= s->d_cand.ensure(x.size()); r3 |= s->d_scal.ensure(32);
+  r3 |= s->d_x.upload(x, s->stream); r3 |= s->d_cand.ensure(x.size()); r3 |= s->d_best.ensure(x.size()); r3 |= s->d_scal.ensure(32);
   if (r3) {return KH_ERR_HIP;}
   KS_HIP(hipStreamSynchronize(s->stream));   // the staging vectors above go out of scope
   if (std::getenv("KH_SPA_DEBUG")) {
@@ -697,7 +699,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
-  s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release();
+  s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release(); s->d_Hg_alt.release(); s->d_best.release();
   for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   for (auto & row : s->ev_lin) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
@@ -1198,22 +1200,28 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   const int32_t e_hi = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * (s->shard_rank + 1) / s->shard_world);
   const int64_t hg_count = static_cast<int64_t>(s->n_slots) * 9 + static_cast<int64_t>(dev.n_free) * 3;
   int n_lin = 0, n_timed = 0;
-  auto linearize = [&](const double * at) -> int {
+  auto linearize = [&](const SpaDev & into, const double * at, double * cost_slot) -> int {
     const bool timed = n_lin < 2 * kh_spa::kMaxTimed + 2;
     if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
-    spa_launch_linearize(dev, at, scal + 0, e_lo, e_hi, st);
+    spa_launch_linearize(into, at, cost_slot, e_lo, e_hi, st);
     if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
     if (s->comm) {
       // H || g of this rank's edge block -> sums over all ranks, on the solver's stream (RCCL over xGMI)
-      const int arc = kh_comm_allreduce_sum_f64(s->comm, dev.H, hg_count, st);
+      const int arc = kh_comm_allreduce_sum_f64(s->comm, into.H, hg_count, st);
       if (arc) {return arc;}
     } else if (s->shard_world > 1) {
       if (!s->allreduce) {set_error("kh_spa: sharding enabled without a communicator or an all-reduce callback"); return KH_ERR_INVALID_ARG;}
-      if (s->allreduce(s->allreduce_user, dev.H, hg_count, st) != 0) {set_error("kh_spa: all-reduce callback failed"); return KH_ERR_SOLVER;}
+      if (s->allreduce(s->allreduce_user, into.H, hg_count, st) != 0) {set_error("kh_spa: all-reduce callback failed"); return KH_ERR_SOLVER;}
     }
     return KH_OK;
   };
-  rc = linearize(x); if (rc) {return finish(rc);}
+  // The normal equations at the CANDIDATE point are built speculatively, into a second H || g, in the same batch of
+  // launches that evaluates the candidate's cost: a step is nearly always accepted, and the iteration then needs one
+  // read-back of scalars instead of two (each was a stream drain plus ~90 us before the next launch reached the GPU).
+  // A rejected step simply leaves the second buffer unused.
+  SpaDev alt = dev;
+  alt.H = s->d_Hg_alt.p; alt.g = s->d_Hg_alt.p + static_cast<size_t>(s->n_slots) * 9;
+  rc = linearize(dev, x, scal + 0); if (rc) {return finish(rc);}
   if (opt.jacobi_scaling) {
     spa_launch_jacobi_scale(dev, s->d_scale.p, st);
   } else {
@@ -1231,6 +1239,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   std::vector<double> best_x(static_cast<size_t>(dev.n_nodes) * 3);
   for (int32_t i = 0; i < dev.n_nodes; ++i) {std::copy(s->nodes[i].pose, s->nodes[i].pose + 3, best_x.begin() + 3 * i);}
   bool best_is_current = true;     // device x holds the minimum-cost iterate
+  bool best_on_device = false;     // ... otherwise d_best does (best_x on the host until the first accepted step)
   // TrustRegionStepEvaluator
   const int max_nonmono = opt.use_nonmonotonic_steps ? opt.max_consecutive_nonmonotonic_steps : 0;
   double ev_min = x_cost, ev_cur = x_cost, ev_ref = x_cost, ev_cand = x_cost, ev_acc_ref = 0.0, ev_acc_cand = 0.0;
@@ -1295,8 +1304,14 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     spa_launch_finish_step(dev, s->d_scale.p, s->d_rhs.p, s->d_step.p, s->d_delta.p, st);
     spa_launch_model(dev, s->d_scale.p, s->d_step.p, scal + 3, st);
     spa_launch_plus(dev, x, s->d_delta.p, cand, scal + 6, st);
-    spa_launch_cost(dev, cand, scal + 8, st);
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
+    static const bool speculate = !(std::getenv("KH_SPA_SPECULATE") && std::atoi(std::getenv("KH_SPA_SPECULATE")) == 0);
+    if (speculate) {
+      rc = linearize(alt, cand, scal + 8); if (rc) {return finish(rc);}      // cost of the candidate + its H, g
+      spa_launch_grad_norms(alt, cand, scal + 9, st);
+    } else {
+      spa_launch_cost(dev, cand, scal + 8, st);
+    }
     KS_HIP(hipGetLastError());
     rc = fetch(); if (rc) {return finish(rc);}
     solve_ms += ms_since(t1);
@@ -1331,19 +1346,22 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     }
     if (quality > opt.min_relative_decrease) {
       // HandleSuccessfulStep
-      if (best_is_current) {   // keep a copy of the best iterate before x moves on
-        KS_HIP(hipMemcpyAsync(best_x.data(), x, best_x.size() * 8, hipMemcpyDeviceToHost, st));
-        KS_HIP(hipStreamSynchronize(st));
+      if (best_is_current) {   // keep a copy of the best iterate before x moves on (device to device, no drain)
+        KS_HIP(hipMemcpyAsync(s->d_best.p, x, best_x.size() * 8, hipMemcpyDeviceToDevice, st));
+        best_on_device = true;
         best_is_current = false;
       }
       std::swap(x, cand);
       x_norm = cand_norm;
-      auto t2 = now();
-      rc = linearize(x); if (rc) {return finish(rc);}
-      spa_launch_grad_norms(dev, x, scal + 1, st);
-      rc = fetch(); if (rc) {return finish(rc);}
-      lin_ms += ms_since(t2);
-      x_cost = s->h_scal[0]; gmax = s->h_scal[1];
+      if (speculate) {
+        std::swap(dev.H, alt.H); std::swap(dev.g, alt.g);          // the speculative linearisation is the current one now
+        x_cost = s->h_scal[8]; gmax = s->h_scal[9];
+      } else {
+        rc = linearize(dev, x, scal + 0); if (rc) {return finish(rc);}
+        spa_launch_grad_norms(dev, x, scal + 1, st);
+        rc = fetch(); if (rc) {return finish(rc);}
+        x_cost = s->h_scal[0]; gmax = s->h_scal[1];
+      }
       step_successful = true;
       ++sum.successful_steps;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * quality - 1.0, 3));
@@ -1390,8 +1408,8 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     set_error("CeresSolver: Ceres could not find a usable solution to optimize.");
     return finish(KH_ERR_SOLVER);          // ceres_solver.cpp:249-254: state and corrections unchanged
   }
-  if (best_is_current) {
-    KS_HIP(hipMemcpyAsync(best_x.data(), x, best_x.size() * 8, hipMemcpyDeviceToHost, st));
+  if (best_is_current || best_on_device) {
+    KS_HIP(hipMemcpyAsync(best_x.data(), best_is_current ? x : s->d_best.p, best_x.size() * 8, hipMemcpyDeviceToHost, st));
     KS_HIP(hipStreamSynchronize(st));
   }
   for (int32_t i = 0; i < dev.n_nodes; ++i) {std::copy(best_x.begin() + 3 * i, best_x.begin() + 3 * i + 3, s->nodes[i].pose);}

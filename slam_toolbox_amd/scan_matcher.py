@@ -62,11 +62,24 @@ class LocalizedRangeScan:
         self.angular_resolution = float(angular_resolution)
         self.SetSensorPose(sensor_pose)
 
+    _resident = None
+
     def SetSensorPose(self, pose):
         self.sensor_pose = _d(pose).copy()
         self.points = np.zeros((self.ranges.shape[0], 2))
         capi.check(capi.lib().kh_scan_points(self.ranges, self.ranges.shape[0], self.sensor_pose, self.min_angle,
                                              self.angular_resolution, self.points), "kh_scan_points")
+        if self._resident is not None:
+            self._resident.upload(self.points)           # the device copy follows Update() (Karto.h:5644-5704)
+
+    def MakeResident(self, device=0):
+        """Keeps the point readings in HBM as well (kh_scan.device_points_xy): as a BASE scan of AddScans / MatchScan the
+        scan is then read where it lies instead of being uploaded with every call."""
+        from .comm import DeviceBuffer
+        if self._resident is None and self.points.size > 0:
+            self._resident = DeviceBuffer(self.points.size, device)
+            self._resident.upload(self.points)
+        return self
 
     def GetSensorPose(self):
         return self.sensor_pose.copy()
@@ -81,6 +94,7 @@ class LocalizedRangeScan:
         s.points_xy = self.points.ctypes.data_as(C.POINTER(C.c_double))
         for i in range(3):
             s.sensor_pose[i] = self.sensor_pose[i]
+        s.device_points_xy = self._resident.ptr if self._resident is not None else None
         return s
 
 

@@ -71,8 +71,12 @@ def _loop_batch_scans():
     cache_h, cache_o = {}, {}
 
     def h_scan(i):
+        # every other base scan lives in HBM (kh_scan.device_points_xy), the rest is uploaded by the call: both routes, mixed
+        # inside one chain, in the batch bench.py::loop_leg issues
         if i not in cache_h:
             cache_h[i] = LocalizedRangeScan(lb["ranges"][i], lb["truth"][i], LASER.min_angle, LASER.ang_res)
+            if i % 2 == 0:
+                cache_h[i].MakeResident()
         return cache_h[i]
 
     def o_scan(i):

@@ -407,3 +407,29 @@ def test_covariance_members_reproduce_the_search(kartohip_lib, preset):
     tt = hm.ComputeAngularCovariance(hq, mean2, r2, mean, fine[2], fine[3])
     _assert_same(cov2[2, 2], tt, "angular covariance")
     hm.close()
+
+
+def test_resident_base_scans_equal_uploaded_ones(kartohip_lib):
+    """kh_scan.device_points_xy: a base scan kept in HBM is read where it lies -- same grid, same match as when the call
+    uploads it; a pose change re-uploads (SetSensorPose), a chain may mix both kinds"""
+    def flat(res):
+        r, mean, cov = res
+        return np.concatenate([[r], np.asarray(mean).reshape(3), np.asarray(cov).reshape(9)])
+    sc = Scenario(seed=21, n_base=12, start=40)
+    q, base = sc.hip_scans()
+    hm = make_hip_matcher("S")
+    want = flat(hm.MatchScan(q, base, True, True))
+    grid = hm.GetCorrelationGrid().copy()
+    for k, b in enumerate(base):
+        if k % 3 != 1:
+            b.MakeResident()
+    got = flat(hm.MatchScan(q, base, True, True))
+    assert np.array_equal(hm.GetCorrelationGrid(), grid)
+    assert np.array_equal(bits(got), bits(want))
+    # move one resident scan: the device copy must follow
+    base[0].SetSensorPose(base[0].GetSensorPose() + np.array([0.07, -0.04, 0.01]))
+    got2 = flat(hm.MatchScan(q, base, True, True))
+    fresh = [type(b)(b.ranges, b.GetSensorPose(), b.min_angle, b.angular_resolution) for b in base]
+    want2 = flat(hm.MatchScan(q, fresh, True, True))
+    assert np.array_equal(bits(got2), bits(want2)) and not np.array_equal(bits(got2), bits(want))
+    hm.close()
