@@ -190,23 +190,140 @@ __global__ __launch_bounds__(256) void k_find_valid(const RasterJob * jobs, cons
   for (int i = trailing + lane; i < n; i += 64) {out[i] = 0;}        // the tail after the last trigger is never emitted
 }
 
+// FindValidPoints, data parallel inside one scan (wave per scan).  The state machine hops from trigger to trigger -- a
+// trigger is the first reading more than 0.1 m from the current anchor, and it becomes the next anchor -- so its path is a
+// walk along next(i) = "first reading after i more than 0.1 m from reading i", which every lane can evaluate for its own
+// readings.  Which readings the walk visits (reachability from the first valid reading) comes from pointer doubling in
+// LDS: 11 rounds for <= 2048 readings instead of one dependent hop per trigger (several hundred per scan when the beams
+// are long: 156 us for the 20 running scans of a sequential match with the hop-by-hop kernel k_find_valid).  The
+// side-of-line sign of every visited trigger and the fate of every run follow in parallel: reading i is emitted iff the
+// first trigger after it lies on the viewpoint's side (Mapper.cpp:1145-1160); the tail after the last trigger never is.
+// Same comparisons, same operand order as the sequential form: bit-identical flags.
+__global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n, int waves)
+{
+  extern __shared__ double2 s_fv[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * waves + wave;
+  if (wave >= waves || t >= n_items) {return;}            // wave-uniform; no block-wide barrier below
+  const int stride_i = max_n + 64;                        // ints per pointer array
+  // per wave: points, three pointer arrays, reach + keep bytes
+  const size_t per_wave = (size_t)max_n * sizeof(double2) + 3 * (size_t)stride_i * sizeof(int32_t) + 2 * (size_t)stride_i;
+  uint8_t * base_w = reinterpret_cast<uint8_t *>(s_fv) + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
+  double2 * P = reinterpret_cast<double2 *>(base_w);
+  int32_t * nxt0 = reinterpret_cast<int32_t *>(base_w + (size_t)max_n * sizeof(double2));
+  int32_t * nxa = nxt0 + stride_i;
+  int32_t * nxb = nxa + stride_i;
+  uint8_t * reach = reinterpret_cast<uint8_t *>(nxb + stride_i);
+  uint8_t * keep = reach + stride_i;
+  const RasterJob & job = jobs[items[t].job];
+  const int k = items[t].scan;
+  const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
+  const double2 * pts = reinterpret_cast<const double2 *>(job.scan_ptr[k]);
+  uint8_t * out = job.active + job.scan_prefix[k];
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this wave's LDS traffic has landed (only it uses the region)
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int i = lane; i < n; i += 64) {P[i] = pts[i]; reach[i] = 0; keep[i] = 0;}
+  if (lane == 0) {reach[n] = 0;}
+  lds_sync();
+  const double vx = job.view_x, vy = job.view_y;
+  const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
+  // the first reading without a NaN coordinate is the first anchor (Mapper.cpp:1127-1136)
+  int pos0 = n;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < n && !isnan(P[min(i, n - 1)].x) && !isnan(P[min(i, n - 1)].y);
+    const unsigned long long mask = __ballot(ok);
+    if (mask) {pos0 = base + __builtin_ctzll(mask); break;}
+  }
+  if (pos0 >= n) {
+    for (int i = lane; i < n; i += 64) {out[i] = 0;}
+    return;
+  }
+  // next(i): the trigger that follows if reading i is the anchor (n = none)
+  for (int i = lane; i < n; i += 64) {
+    const double fx = P[i].x, fy = P[i].y;
+    int j = (isnan(fx) || isnan(fy)) ? n : i + 1;         // a NaN reading is never an anchor (nothing is "farther" than NaN)
+    for (; j < n; ++j) {
+      const double dx = fx - P[j].x, dy = fy - P[j].y;
+      if (dx * dx + dy * dy > min_square_distance) {break;}
+    }
+    nxt0[i] = j;
+  }
+  if (lane == 0) {nxt0[n] = n; reach[pos0] = 1;}
+  lds_sync();
+  // reachability from pos0 by pointer doubling
+  const int32_t * cur = nxt0;
+  int32_t * nxt_w = nxa;
+  for (int span = 1; span < n; span <<= 1) {
+    for (int i = lane; i <= n; i += 64) {
+      const int j = cur[min(i, n)];
+      if (i < n && reach[i] && j < n) {reach[j] = 1;}
+      nxt_w[i] = j < n ? cur[j] : n;
+    }
+    lds_sync();
+    cur = nxt_w;
+    nxt_w = (nxt_w == nxa) ? nxb : nxa;
+  }
+  // every visited trigger: which side of the line viewpoint -> anchor it lies on (its anchor is the visited reading whose
+  // next() it is)
+  for (int i = lane; i < n; i += 64) {
+    const int j = nxt0[i];
+    if (reach[i] && j < n) {
+      const double fx = P[i].x, fy = P[i].y, cx = P[j].x, cy = P[j].y;
+      const double a = vy - fy;
+      const double b = fx - vx;
+      const double cc = fy * vx - fx * vy;
+      const double ss = cx * a + cy * b + cc;
+      keep[j] = ss < 0.0 ? 0 : 1;
+    }
+  }
+  lds_sync();
+  // reading i belongs to the run that ends at the first trigger after it
+  int later = -1;                                          // first trigger in the chunks behind the current one
+  for (int base = (n - 1) & ~63; base >= 0; base -= 64) {
+    const int i = base + lane;
+    const bool trig = i < n && i != pos0 && reach[min(i, n - 1)];
+    const unsigned long long mask = __ballot(trig);
+    const unsigned long long above = lane < 63 ? (mask >> (lane + 1)) : 0ull;
+    const int j = above ? i + 1 + __builtin_ctzll(above) : later;
+    if (i < n) {out[i] = j >= 0 ? keep[j] : 0;}
+    if (mask) {later = base + __builtin_ctzll(mask);}
+  }
+}
+
 void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream)
 {
   if (n_items <= 0) {return;}
   // one lane per scan when the batch holds thousands of scans (measured: 6400 scans take 0.29 ms lane-per-scan -- every
-  // lane busy, one memory latency per reading -- against 0.6 ms wave-per-scan; ten scans take 275 us against ~100 us), or
-  // when 4 scans x 16 B per reading would not fit the LDS
+  // lane busy, one memory latency per reading -- against 0.6 ms for a wave hopping from trigger to trigger), or when a
+  // scan's working set would not fit the LDS
+  static const int form = std::getenv("KH_FIND_VALID") ? std::atoi(std::getenv("KH_FIND_VALID")) : 0;   // 1: hop-by-hop wave kernel
   if (max_n > 2048 || n_items > 4096) {
     hipLaunchKernelGGL(k_find_valid_lane, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_jobs, d_items, (int)n_items);
     return;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2048 * 16);
-    attr_set = true;
+  if (form == 1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2048 * 16);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_find_valid, dim3((n_items + 3) / 4), dim3(256), (size_t)4 * max_n * sizeof(double2), (hipStream_t)stream, d_jobs,
+                       d_items, (int)n_items, (int)max_n);
+    return;
   }
-  hipLaunchKernelGGL(k_find_valid, dim3((n_items + 3) / 4), dim3(256), (size_t)4 * max_n * sizeof(double2), (hipStream_t)stream, d_jobs,
-                     d_items, (int)n_items, (int)max_n);
+  const size_t stride_i = (size_t)max_n + 64;
+  const size_t per_wave = (((size_t)max_n * sizeof(double2) + 3 * stride_i * sizeof(int32_t) + 2 * stride_i) + 15) & ~(size_t)15;
+  const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)150 * 1024) / per_wave));
+  static bool attr2_set = false;
+  if (!attr2_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid_par), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr2_set = true;
+  }
+  hipLaunchKernelGGL(k_find_valid_par, dim3((n_items + waves - 1) / waves), dim3(256), per_wave * waves, (hipStream_t)stream, d_jobs, d_items,
+                     (int)n_items, (int)max_n, waves);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -366,21 +483,21 @@ __global__ __launch_bounds__(1024) void k_active_set(const RasterJob * jobs)
     int left = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const int h = cand[i];
-      if (__hip_atomic_load(&job.hstate[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {continue;}
+      if (job.hstate[h] != 0) {continue;}
       const int4 nb4 = *reinterpret_cast<const int4 *>(job.hnbr + (size_t)h * kMaxFootprint);
       const int32_t nb[kMaxFootprint] = {nb4.x, nb4.y, nb4.z, nb4.w};
       bool blocked = false, waiting = false;
 #pragma unroll
       for (int f = 0; f < kMaxFootprint; ++f) {
         if (nb[f] < 0) {continue;}
-        const uint8_t st = __hip_atomic_load(&job.hstate[nb[f]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint8_t st = job.hstate[nb[f]];
         blocked = blocked || st == 1;
         waiting = waiting || st == 0;
       }
       if (blocked) {
-        __hip_atomic_store(&job.hstate[h], (uint8_t)2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        job.hstate[h] = 2;
       } else if (!waiting) {
-        __hip_atomic_store(&job.hstate[h], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        job.hstate[h] = 1;
       } else {
         ++left;
       }
