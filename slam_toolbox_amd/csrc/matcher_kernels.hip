@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_find_valid(const RasterJob * jobs, cons
   for (int i = trailing + lane; i < n; i += 64) {out[i] = 0;}        // the tail after the last trigger is never emitted
 }
 
-// FindValidPoints, data parallel inside one scan (wave per scan).  The state machine hops from trigger to trigger -- a
+// FindValidPoints, data parallel inside one scan (workgroup per scan).  The state machine hops from trigger to trigger -- a
 // trigger is the first reading more than 0.1 m from the current anchor, and it becomes the next anchor -- so its path is a
 // walk along next(i) = "first reading after i more than 0.1 m from reading i", which every lane can evaluate for its own
 // readings.  Which readings the walk visits (reachability from the first valid reading) comes from pointer doubling in
@@ -199,50 +199,43 @@ __global__ __launch_bounds__(256) void k_find_valid(const RasterJob * jobs, cons
 // side-of-line sign of every visited trigger and the fate of every run follow in parallel: reading i is emitted iff the
 // first trigger after it lies on the viewpoint's side (Mapper.cpp:1145-1160); the tail after the last trigger never is.
 // Same comparisons, same operand order as the sequential form: bit-identical flags.
-__global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n, int waves)
+__global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n)
 {
+  // one workgroup per scan: a lane owns every 256th reading, so the divergent forward scans of next() cost a lane four or
+  // five readings' worth of its slowest neighbour instead of seventeen (one wave per scan: 56 us for 20 scans)
   extern __shared__ double2 s_fv[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x * waves + wave;
-  if (wave >= waves || t >= n_items) {return;}            // wave-uniform; no block-wide barrier below
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int t = blockIdx.x;
   const int stride_i = max_n + 64;                        // ints per pointer array
-  // per wave: points, three pointer arrays, reach + keep bytes
-  const size_t per_wave = (size_t)max_n * sizeof(double2) + 3 * (size_t)stride_i * sizeof(int32_t) + 2 * (size_t)stride_i;
-  uint8_t * base_w = reinterpret_cast<uint8_t *>(s_fv) + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
-  double2 * P = reinterpret_cast<double2 *>(base_w);
-  int32_t * nxt0 = reinterpret_cast<int32_t *>(base_w + (size_t)max_n * sizeof(double2));
+  double2 * P = s_fv;
+  int32_t * nxt0 = reinterpret_cast<int32_t *>(P + max_n);
   int32_t * nxa = nxt0 + stride_i;
   int32_t * nxb = nxa + stride_i;
   uint8_t * reach = reinterpret_cast<uint8_t *>(nxb + stride_i);
   uint8_t * keep = reach + stride_i;
+  __shared__ int s_pos0;
+  __shared__ unsigned long long s_mask[40];               // triggers of every chunk of 64 readings (max_n <= 2048 -> 32 chunks)
+  __shared__ int s_later[40];                             // first trigger in the chunks behind chunk c, -1 = none
   const RasterJob & job = jobs[items[t].job];
   const int k = items[t].scan;
   const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
   const double2 * pts = reinterpret_cast<const double2 *>(job.scan_ptr[k]);
   uint8_t * out = job.active + job.scan_prefix[k];
-  auto lds_sync = [&]() {
-    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this wave's LDS traffic has landed (only it uses the region)
-    __builtin_amdgcn_wave_barrier();
-  };
-  for (int i = lane; i < n; i += 64) {P[i] = pts[i]; reach[i] = 0; keep[i] = 0;}
-  if (lane == 0) {reach[n] = 0;}
-  lds_sync();
+  if (tid == 0) {s_pos0 = n;}
+  for (int i = tid; i < n; i += nthreads) {P[i] = pts[i]; reach[i] = 0; keep[i] = 0;}
+  __syncthreads();
   const double vx = job.view_x, vy = job.view_y;
   const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
   // the first reading without a NaN coordinate is the first anchor (Mapper.cpp:1127-1136)
-  int pos0 = n;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const bool ok = i < n && !isnan(P[min(i, n - 1)].x) && !isnan(P[min(i, n - 1)].y);
-    const unsigned long long mask = __ballot(ok);
-    if (mask) {pos0 = base + __builtin_ctzll(mask); break;}
-  }
-  if (pos0 >= n) {
-    for (int i = lane; i < n; i += 64) {out[i] = 0;}
-    return;
+  {
+    int mine = n;
+    for (int i = tid; i < n; i += nthreads) {
+      if (!isnan(P[i].x) && !isnan(P[i].y)) {mine = i; break;}
+    }
+    if (mine < n) {atomicMin(&s_pos0, mine);}
   }
   // next(i): the trigger that follows if reading i is the anchor (n = none)
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += nthreads) {
     const double fx = P[i].x, fy = P[i].y;
     int j = (isnan(fx) || isnan(fy)) ? n : i + 1;         // a NaN reading is never an anchor (nothing is "farther" than NaN)
     for (; j < n; ++j) {
@@ -251,24 +244,31 @@ __global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, 
     }
     nxt0[i] = j;
   }
-  if (lane == 0) {nxt0[n] = n; reach[pos0] = 1;}
-  lds_sync();
+  if (tid == 0) {nxt0[n] = n; reach[n] = 0;}
+  __syncthreads();
+  const int pos0 = s_pos0;
+  if (pos0 >= n) {
+    for (int i = tid; i < n; i += nthreads) {out[i] = 0;}
+    return;
+  }
+  if (tid == 0) {reach[pos0] = 1;}
+  __syncthreads();
   // reachability from pos0 by pointer doubling
   const int32_t * cur = nxt0;
   int32_t * nxt_w = nxa;
   for (int span = 1; span < n; span <<= 1) {
-    for (int i = lane; i <= n; i += 64) {
-      const int j = cur[min(i, n)];
+    for (int i = tid; i <= n; i += nthreads) {
+      const int j = cur[i];
       if (i < n && reach[i] && j < n) {reach[j] = 1;}
       nxt_w[i] = j < n ? cur[j] : n;
     }
-    lds_sync();
+    __syncthreads();
     cur = nxt_w;
     nxt_w = (nxt_w == nxa) ? nxb : nxa;
   }
   // every visited trigger: which side of the line viewpoint -> anchor it lies on (its anchor is the visited reading whose
   // next() it is)
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += nthreads) {
     const int j = nxt0[i];
     if (reach[i] && j < n) {
       const double fx = P[i].x, fy = P[i].y, cx = P[j].x, cy = P[j].y;
@@ -279,17 +279,28 @@ __global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, 
       keep[j] = ss < 0.0 ? 0 : 1;
     }
   }
-  lds_sync();
   // reading i belongs to the run that ends at the first trigger after it
-  int later = -1;                                          // first trigger in the chunks behind the current one
-  for (int base = (n - 1) & ~63; base >= 0; base -= 64) {
+  const int n_chunks = (n + 63) >> 6;
+  for (int base = 64 * (tid >> 6); base < n; base += nthreads) {     // wave w takes chunks w, w + 4, ...
     const int i = base + lane;
     const bool trig = i < n && i != pos0 && reach[min(i, n - 1)];
     const unsigned long long mask = __ballot(trig);
-    const unsigned long long above = lane < 63 ? (mask >> (lane + 1)) : 0ull;
-    const int j = above ? i + 1 + __builtin_ctzll(above) : later;
-    if (i < n) {out[i] = j >= 0 ? keep[j] : 0;}
-    if (mask) {later = base + __builtin_ctzll(mask);}
+    if (lane == 0) {s_mask[base >> 6] = mask;}
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int later = -1;
+    for (int c = n_chunks - 1; c >= 0; --c) {
+      s_later[c] = later;
+      if (s_mask[c]) {later = 64 * c + __builtin_ctzll(s_mask[c]);}
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nthreads) {
+    const int c = i >> 6, l = i & 63;
+    const unsigned long long above = l < 63 ? (s_mask[c] >> (l + 1)) : 0ull;
+    const int j = above ? i + 1 + __builtin_ctzll(above) : s_later[c];
+    out[i] = j >= 0 ? keep[j] : 0;
   }
 }
 
@@ -315,15 +326,13 @@ void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int3
     return;
   }
   const size_t stride_i = (size_t)max_n + 64;
-  const size_t per_wave = (((size_t)max_n * sizeof(double2) + 3 * stride_i * sizeof(int32_t) + 2 * stride_i) + 15) & ~(size_t)15;
-  const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)150 * 1024) / per_wave));
+  const size_t lds = (size_t)max_n * sizeof(double2) + 3 * stride_i * sizeof(int32_t) + 2 * stride_i;
   static bool attr2_set = false;
   if (!attr2_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid_par), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid_par), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr2_set = true;
   }
-  hipLaunchKernelGGL(k_find_valid_par, dim3((n_items + waves - 1) / waves), dim3(256), per_wave * waves, (hipStream_t)stream, d_jobs, d_items,
-                     (int)n_items, (int)max_n, waves);
+  hipLaunchKernelGGL(k_find_valid_par, dim3(n_items), dim3(256), lds, (hipStream_t)stream, d_jobs, d_items, (int)n_items, (int)max_n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,41 +481,60 @@ __global__ __launch_bounds__(256) void k_cell_links(const RasterJob * jobs)
 // sequential answer whatever the sweep order (measured: 7-20 sweeps on the loop-closure chains).  One workgroup per job.
 __global__ __launch_bounds__(1024) void k_active_set(const RasterJob * jobs)
 {
+  // One workgroup per job; plain loads and stores (the job's state bytes are this workgroup's alone: the CU's L1 is
+  // coherent for its own waves across a barrier).  Every sweep decides what it can and writes the cells it could not decide
+  // to the other half of the candidate buffer (`list` holds 4 * n_points ints, the candidates at most n_points): dependency
+  // chains run along walls in scan order, most cells are decided in the first sweeps, and the later sweeps -- a dozen of
+  // them -- touch only what is left instead of the whole list.
   const RasterJob & job = jobs[blockIdx.x];
   if (job.n_foot <= 0) {return;}
   __shared__ int32_t s_left;
-  const int32_t * cand = job.list;
-  const int n = job.n_work[1];
-  for (int sweep = 0; sweep < 1 << 20; ++sweep) {
+  int32_t * src = job.list;
+  int32_t * dst = job.list + (job.n_points > 0 ? job.n_points : 1);
+  int n = job.n_work[1];
+  for (int sweep = 0; sweep < 1 << 20 && n > 0; ++sweep) {
     if (threadIdx.x == 0) {s_left = 0;}
     __syncthreads();
-    int left = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const int h = cand[i];
-      if (job.hstate[h] != 0) {continue;}
-      const int4 nb4 = *reinterpret_cast<const int4 *>(job.hnbr + (size_t)h * kMaxFootprint);
-      const int32_t nb[kMaxFootprint] = {nb4.x, nb4.y, nb4.z, nb4.w};
-      bool blocked = false, waiting = false;
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+      const int i = i0 + threadIdx.x;
+      bool undecided = false;
+      int h = 0;
+      if (i < n) {
+        h = src[i];
+        if (job.hstate[h] == 0) {
+          const int4 nb4 = *reinterpret_cast<const int4 *>(job.hnbr + (size_t)h * kMaxFootprint);
+          const int32_t nb[kMaxFootprint] = {nb4.x, nb4.y, nb4.z, nb4.w};
+          bool blocked = false, waiting = false;
 #pragma unroll
-      for (int f = 0; f < kMaxFootprint; ++f) {
-        if (nb[f] < 0) {continue;}
-        const uint8_t st = job.hstate[nb[f]];
-        blocked = blocked || st == 1;
-        waiting = waiting || st == 0;
+          for (int f = 0; f < kMaxFootprint; ++f) {
+            if (nb[f] < 0) {continue;}
+            const uint8_t st = job.hstate[nb[f]];
+            blocked = blocked || st == 1;
+            waiting = waiting || st == 0;
+          }
+          if (blocked) {
+            job.hstate[h] = 2;
+          } else if (!waiting) {
+            job.hstate[h] = 1;
+          } else {
+            undecided = true;
+          }
+        }
       }
-      if (blocked) {
-        job.hstate[h] = 2;
-      } else if (!waiting) {
-        job.hstate[h] = 1;
-      } else {
-        ++left;
+      // survivors -> dst, one LDS atomic per wave
+      const unsigned long long mask = __ballot(undecided);
+      if (mask) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == __builtin_ctzll(mask)) {base = atomicAdd(&s_left, __builtin_popcountll(mask));}
+        base = __shfl(base, __builtin_ctzll(mask));
+        if (undecided) {dst[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = h;}
       }
     }
-    if (left) {atomicAdd(&s_left, left);}
     __syncthreads();
-    const int total = s_left;
+    n = s_left;
     __syncthreads();
-    if (total == 0) {break;}
+    int32_t * t = src; src = dst; dst = t;
   }
 }
 
