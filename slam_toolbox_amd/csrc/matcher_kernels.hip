@@ -695,6 +695,22 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
   const int sub = kk >= 64 ? 0 : lane / kk;               // which of them this lane works for
   const int c0 = kk >= 64 ? lane : lane - sub * kk;       // first cell of this lane
   const bool lane_on = kk >= 64 || sub < ppw;
+  // kk >= 64: a lane's footprint cells (lane, lane + 64, ...: at most 27 of 41 x 41) are the same for every point, so their
+  // column, their offset inside a 64-wide tile and their value live in registers: per cell and point 2 adds, 2 compares and
+  // the LDS max are left (the packed table in LDS cost a read and four unpacking operations more; this loop is where the
+  // rasteriser's time goes: 1681 cells for each of ~10 000 distinct points of a sequential-preset job)
+  constexpr int kCellsPerLane = (41 * 41 + 63) / 64;
+  int ex[kCellsPerLane], ed[kCellsPerLane];
+  uint32_t ev[kCellsPerLane];
+  __syncthreads();                                         // s_cells is complete
+#pragma unroll
+  for (int u = 0; u < kCellsPerLane; ++u) {
+    const int c = lane + 64 * u;
+    const uint32_t e = c < kk ? s_cells[c] : 0u;           // beyond the footprint: value 0 at the corner cell, a no-op max
+    ex[u] = (int)(e & 0xffu);
+    ed[u] = (int)((e >> 8) & 0xffu) * kRasterTile + ex[u];
+    ev[u] = e >> 16;
+  }
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int t = job.work[w];
     const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
@@ -711,15 +727,30 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
         s_py[threadIdx.x] = job.cell_xy[2 * (size_t)p + 1] - hk - oy;
       }
       __syncthreads();
-      for (int q = wave * ppw + sub; q < here; q += kWaves * ppw) {
-        if (!lane_on) {break;}
-        const int fx = s_px[q], fy = s_py[q];
-#pragma unroll 4
-        for (int c = c0; c < kk; c += 64) {
-          const uint32_t e = s_cells[c];
-          const int x = fx + (int)(e & 0xffu), y = fy + (int)((e >> 8) & 0xffu);
-          // both inside [0, 64): for two's complement ints, (x | y) is in [0, 64) iff both are
-          if ((unsigned)(x | y) < (unsigned)kRasterTile && (e >> 16) != 0) {atomicMax(&s_tile[y * kRasterTile + x], e >> 16);}
+      if (kk >= 64) {
+        const int nc = (kk + 63) >> 6;                      // cells per lane actually in the footprint (wave-uniform bound)
+        for (int q = wave; q < here; q += kWaves) {
+          const int fx = s_px[q];
+          const int fb = s_py[q] * kRasterTile + fx;
+#pragma unroll
+          for (int u = 0; u < kCellsPerLane; ++u) {
+            if (u < nc) {
+              const int x = fx + ex[u], idx = fb + ed[u];
+              // column inside the tile and (given that) row inside the tile <=> index inside the tile
+              if ((unsigned)x < (unsigned)kRasterTile && (unsigned)idx < (unsigned)(kRasterTile * kRasterTile)) {atomicMax(&s_tile[idx], ev[u]);}
+            }
+          }
+        }
+      } else {
+        for (int q = wave * ppw + sub; q < here; q += kWaves * ppw) {
+          if (!lane_on) {break;}
+          const int fx = s_px[q], fy = s_py[q];
+          for (int c = c0; c < kk; c += 64) {
+            const uint32_t e = s_cells[c];
+            const int x = fx + (int)(e & 0xffu), y = fy + (int)((e >> 8) & 0xffu);
+            // both inside [0, 64): for two's complement ints, (x | y) is in [0, 64) iff both are
+            if ((unsigned)(x | y) < (unsigned)kRasterTile && (e >> 16) != 0) {atomicMax(&s_tile[y * kRasterTile + x], e >> 16);}
+          }
         }
       }
     }
