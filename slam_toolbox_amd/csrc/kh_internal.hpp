@@ -58,6 +58,7 @@ struct RasterJob
   int32_t * work;            // tiles_w * tiles_h   non-empty tiles
   int32_t * n_work;          // 1                   (written by the scan)
   int32_t * cell_xy;         // 2 * n_points        grid cell of every kept point, x < 0 = dropped
+  int32_t * rank;            // 4 * n_points        position of the point in the list of each of the <= 4 tiles its footprint overlaps
   int32_t * list;            // 4 * n_points        point indices, tile after tile
   // order-dependent rule (only when the smear kernel holds 100 off-centre): per-job open-addressing table over the ROI
   // cells the valid points fall into

@@ -146,7 +146,7 @@ struct Slot
   size_t cap_hkeys = 0, cap_hvals = 0, cap_hstate = 0, cap_hnbr = 0;
   double * d_tile_best = nullptr; size_t cap_tile_best = 0;
   int32_t * d_rtiles = nullptr;      // tile_count | tile_cursor | n_work(+pad) | tile_start | work   (first three zeroed per raster)
-  int32_t * d_rlists = nullptr; size_t cap_rlists = 0;   // cell_xy (2 np) | list (4 np)
+  int32_t * d_rlists = nullptr; size_t cap_rlists = 0;   // cell_xy (2 np) | list (4 np) | rank (4 np)
   // last correlate (for the introspection calls)
   CorrHost last;
   bool has_last = false;
@@ -389,7 +389,8 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     const size_t np = static_cast<size_t>(points_of[r]);
     max_points = std::max(max_points, points_of[r]);
     rc = ensure_device(s.d_ractive, s.cap_ractive, std::max<size_t>(np, 1), m->stream); if (rc) {return rc;}
-    rc = ensure_device(s.d_rlists, s.cap_rlists, std::max<size_t>(np, 1) * 6, m->stream); if (rc) {return rc;}
+    const size_t npad = (std::max<size_t>(np, 1) + 3) & ~static_cast<size_t>(3);      // the rank quadruples are read as int4
+    rc = ensure_device(s.d_rlists, s.cap_rlists, npad * 10, m->stream); if (rc) {return rc;}
     RasterJob & j = m->h_rjobs[r];
     std::memset(&j, 0, sizeof(j));
     j.grid = s.d_grid;
@@ -405,7 +406,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.tiles_w = m->rt_w; j.tiles_h = m->rt_h; j.height = m->data_size / m->ws;
     j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
     j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
-    j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * std::max<size_t>(np, 1);
+    j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * npad; j.rank = s.d_rlists + 6 * npad;
     j.grid2 = s.d_grid2; j.pitch2 = m->pitch2; j.copy_b = m->copy_b; j.prev_work = s.d_prev_work;
     any_copies = any_copies || s.d_grid2 != nullptr;
     j.n_foot = n_foot;

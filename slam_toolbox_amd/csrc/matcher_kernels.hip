@@ -587,12 +587,16 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
     }
     if (on) {
       cx = gx + job.roi_x; cy = gy + job.roi_y;              // CorrelationGrid::GridIndex, Mapper.h:1122-1128
-      // the kernel's centre is 100 = its maximum: write it now and use the byte as the "cell already stamped" flag
-      const int32_t index = cx + cy * job.ws;
-      uint32_t * word = reinterpret_cast<uint32_t *>(job.grid) + (index >> 2);
-      const uint32_t bit = (uint32_t)kOccupied << (8 * (index & 3));
-      const uint32_t old = atomicOr(word, bit);
-      on = ((old >> (8 * (index & 3))) & 0xffu) == 0;
+      if (job.n_foot <= 0) {
+        // the kernel's centre is 100 = its maximum: write it now and use the byte as the "cell already stamped" flag
+        // (with the cell table of the order-dependent rule the first point of a cell is known already -- hvals -- and
+        // the tile kernel writes the centre with the rest of the footprint: no read-modify-write of a cold grid line)
+        const int32_t index = cx + cy * job.ws;
+        uint32_t * word = reinterpret_cast<uint32_t *>(job.grid) + (index >> 2);
+        const uint32_t bit = (uint32_t)kOccupied << (8 * (index & 3));
+        const uint32_t old = atomicOr(word, bit);
+        on = ((old >> (8 * (index & 3))) & 0xffu) == 0;
+      }
     }
     if (on) {
       cell[0] = cx; cell[1] = cy;
@@ -608,16 +612,57 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
       }
     }
   }
-  // incidence counts of the <= 2 x 2 tiles the footprint overlaps (k <= 41 < 64), wave-aggregated
+  // Incidence counts of the <= 2 x 2 tiles the footprint overlaps (k <= 41 < 64) and the point's rank in each tile's list.
+  // The workgroup's 256 consecutive readings fall into a few dozen tiles: they are counted in an LDS table first (keys by
+  // linear probing in 256 slots, a crowded table sends the incidence to the global counter), then every occupied slot takes ONE global atomic -- all slots
+  // at once -- and a point's rank is its tile's base plus its rank inside the workgroup.  (A wave-by-wave aggregation
+  // took a chain of returning global atomics per wave, here and again in k_raster_fill: half of a single match's
+  // rasterisation time.)
+  constexpr int kSlots = 256;                                                   // one per thread: a single init / flush step
+  __shared__ int32_t s_key[kSlots], s_cnt[kSlots], s_base[kSlots];
+  s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0;
+  __syncthreads();
   const int hk = job.kernel_size / 2;
   const int tx0 = on ? (cx - hk) / kRasterTile : 0, tx1 = on ? (cx + hk) / kRasterTile : 0;
   const int ty0 = on ? (cy - hk) / kRasterTile : 0, ty1 = on ? (cy + hk) / kRasterTile : 0;
+  int slot_of[4], local[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
     const int t = (on && tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
-    const int before = wave_counter_add(job.tile_count, t);
-    if (t >= 0 && before == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}      // first point of the tile lists it
+    slot_of[q] = -1; local[q] = 0;
+    if (t >= 0) {
+      int sl = (int)(((uint32_t)t * 2654435761u) >> 24);                      // 8 bits
+      int tries = 0;
+      for (; tries < 24; ++tries) {
+        const int seen = atomicCAS(&s_key[sl], -1, t);
+        if (seen == -1 || seen == t) {break;}
+        sl = (sl + 1) & (kSlots - 1);
+      }
+      if (tries < 24) {
+        slot_of[q] = sl;
+        local[q] = atomicAdd(&s_cnt[sl], 1);
+      } else {
+        // table crowded (hundreds of distinct tiles under one workgroup's readings): this incidence goes to the counter itself
+        slot_of[q] = -2;
+        local[q] = atomicAdd(&job.tile_count[t], 1);
+        if (local[q] == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int t = s_key[threadIdx.x];
+    if (t >= 0) {
+      const int before = atomicAdd(&job.tile_count[t], s_cnt[threadIdx.x]);
+      s_base[threadIdx.x] = before;
+      if (before == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}                // the tile's first points list it
+    }
+  }
+  __syncthreads();
+  if (p < job.n_points) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {job.rank[4 * (size_t)p + q] = slot_of[q] >= 0 ? s_base[slot_of[q]] + local[q] : (slot_of[q] == -2 ? local[q] : -1);}
   }
 }
 
@@ -659,12 +704,15 @@ __global__ __launch_bounds__(256) void k_raster_fill(const RasterJob * jobs)
   const int hk = job.kernel_size / 2;
   const int tx0 = on ? (cx - hk) / kRasterTile : 0, tx1 = on ? (cx + hk) / kRasterTile : 0;
   const int ty0 = on ? (cy - hk) / kRasterTile : 0, ty1 = on ? (cy + hk) / kRasterTile : 0;
+  // the ranks k_raster_bin handed out are the positions: no counters, no atomics here
+  int4 r4 = make_int4(-1, -1, -1, -1);
+  if (on) {r4 = *reinterpret_cast<const int4 *>(job.rank + 4 * (size_t)p);}
+  const int rk[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
     const int t = (on && tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
-    const int slot = wave_counter_add(job.tile_cursor, t);
-    if (t >= 0) {job.list[job.tile_start[t] + slot] = p;}
+    if (t >= 0) {job.list[job.tile_start[t] + rk[q]] = p;}
   }
 }
 
