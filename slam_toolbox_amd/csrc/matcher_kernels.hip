@@ -307,11 +307,12 @@ __global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, 
 void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream)
 {
   if (n_items <= 0) {return;}
-  // one lane per scan when the batch holds thousands of scans (measured: 6400 scans take 0.29 ms lane-per-scan -- every
-  // lane busy, one memory latency per reading -- against 0.6 ms for a wave hopping from trigger to trigger), or when a
-  // scan's working set would not fit the LDS
+  // one lane per scan only when a scan's working set would not fit the LDS (> 2048 readings): 6400 scans of the
+  // loop-closure batch take 0.29 ms lane-per-scan (every lane busy, one memory latency per reading), 0.6 ms with a wave
+  // hopping from trigger to trigger, ~0.13 ms with the data-parallel workgroup per scan
   static const int form = std::getenv("KH_FIND_VALID") ? std::atoi(std::getenv("KH_FIND_VALID")) : 0;   // 1: hop-by-hop wave kernel
-  if (max_n > 2048 || n_items > 4096) {
+  static const int lane_from = std::getenv("KH_FIND_VALID_LANE_FROM") ? std::atoi(std::getenv("KH_FIND_VALID_LANE_FROM")) : (1 << 30);
+  if (max_n > 2048 || n_items > lane_from) {
     hipLaunchKernelGGL(k_find_valid_lane, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_jobs, d_items, (int)n_items);
     return;
   }
