@@ -750,12 +750,15 @@ def main():
                          "unit": "GB/s", "frac": l1_gbs / L1_PEAK_GBS,
                          "wave_loads_per_launch": loads_per_launch, "avg_launch_ms": k3_ms, "matches_per_launch": per_launch,
                          "l1_tag_lookup_frac": tag_frac,
+                         "l1_tag_plus_data_frac": (tag_frac + l1_gbs / L1_PEAK_GBS) if tag_frac is not None else None,
                          "traffic": traffic, "traffic_source": "recorded: " + os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 PMC passes of this "
                                                                "command; (2*FETCH_SIZE + WRITE_SIZE)*1024, scaled to this run's matches per launch)",
                          "hbm_frac": (traffic / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "algorithmic_gbs": alg_gbs, "algorithmic_ratio": alg_gbs / HBM_PEAK_GBS,
-                         "note": "bound = the resource nearest its limit; none is saturated (see DESIGN.md section 4): L1 data path "
-                                 "`frac`, L1 tag lookups `l1_tag_lookup_frac`, HBM `hbm_frac` (L2 hit %.1f %%, L1 hit %.1f %% recorded).  "
+                         "note": "bound = the vector L1 (TCP): it looks up tags and returns data serially for these loads, so its busy "
+                                 "fraction is the SUM of the data-path fraction `frac` and the tag-lookup fraction `l1_tag_lookup_frac` = "
+                                 "`l1_tag_plus_data_frac` ~ 1.0: the kernel runs at the L1's speed of light for the loads it issues "
+                                 "(DESIGN.md section 4); HBM `hbm_frac` (L2 hit %.1f %%, L1 hit %.1f %% recorded).  "
                                  "algorithmic_ratio = the reference's own access stream (5 B per lookup, every lookup) over the launch "
                                  "time against 8 TB/s: it exceeds 1 because the kernel reads cache-resident windows, 4 lookups per "
                                  "dword, and skips windows that hold only zeros -- it is not a fraction of a hardware limit"

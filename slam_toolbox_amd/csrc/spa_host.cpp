@@ -46,8 +46,11 @@ void set_error(const std::string & s);
     }                                                                                        \
   } while (0)
 
-struct Node {int32_t id; double pose[3];};
-struct Constraint {int32_t a, b; double z[3]; double u[9]; double omega[6];};   // omega: upper triangle of the information
+// `dead`: removed, waiting for settle() (RemoveNode / RemoveConstraint are O(1) / O(degree); a lifelong mapper removes a
+// node every other scan, and erasing from the middle of 60 000 constraints + re-keying the maps each time cost ~1 ms per
+// removed node)
+struct Node {int32_t id; double pose[3]; uint8_t dead = 0;};
+struct Constraint {int32_t a, b; double z[3]; double u[9]; double omega[6]; uint8_t dead = 0;};   // omega: upper triangle of the information
 
 struct Symbolic
 {
@@ -98,6 +101,7 @@ struct kh_spa
   std::unordered_map<int32_t, int32_t> index_of; // id -> position in nodes
   std::vector<Constraint> cons;
   std::multimap<std::pair<int32_t, int32_t>, int32_t> con_of;   // (a, b) -> position in cons
+  int32_t n_dead = 0;                            // tombstones in nodes + cons (settle() compacts, order preserved)
   int32_t first_id = 0; bool has_first = false; bool was_constant_set = false;
   std::vector<int32_t> corr_ids; std::vector<double> corr_poses;
   bool topology_dirty = true;
@@ -132,6 +136,33 @@ struct kh_spa
   hipEvent_t ev_lin[2 * kMaxTimed + 2][2] = {};
   double last_symbolic_ms = 0.0;
 };
+
+// drops the tombstones; positions in `nodes` / `cons` and both maps are final again afterwards.  Every entry point that
+// hands out positions, counts or the arrays themselves settles first.
+static void settle(kh_spa * s)
+{
+  if (!s || s->n_dead == 0) {return;}
+  s->cons.erase(std::remove_if(s->cons.begin(), s->cons.end(), [](const Constraint & c) {return c.dead != 0;}), s->cons.end());
+  s->nodes.erase(std::remove_if(s->nodes.begin(), s->nodes.end(), [](const Node & n) {return n.dead != 0;}), s->nodes.end());
+  s->con_of.clear();
+  for (size_t k = 0; k < s->cons.size(); ++k) {s->con_of.insert({{s->cons[k].a, s->cons[k].b}, static_cast<int32_t>(k)});}
+  s->index_of.clear();
+  for (size_t k = 0; k < s->nodes.size(); ++k) {s->index_of[s->nodes[k].id] = static_cast<int32_t>(k);}
+  s->n_dead = 0;
+}
+
+static void bury_constraint(kh_spa * s, int32_t k)
+{
+  Constraint & c = s->cons[k];
+  if (c.dead) {return;}
+  auto range = s->con_of.equal_range({c.a, c.b});
+  for (auto it = range.first; it != range.second; ++it) {
+    if (it->second == k) {s->con_of.erase(it); break;}
+  }
+  c.dead = 1;
+  ++s->n_dead;
+  s->topology_dirty = true;
+}
 
 namespace kh
 {
@@ -734,7 +765,7 @@ int kh_spa_set_comm(kh_spa * s, kh_comm * comm)
 int kh_spa_reset(kh_spa * s)     // ceres_solver.cpp:279-314
 {
   if (!s) {return KH_ERR_INVALID_ARG;}
-  s->nodes.clear(); s->index_of.clear(); s->cons.clear(); s->con_of.clear();
+  s->nodes.clear(); s->index_of.clear(); s->cons.clear(); s->con_of.clear(); s->n_dead = 0;
   s->corr_ids.clear(); s->corr_poses.clear();
   s->has_first = false; s->was_constant_set = false; s->topology_dirty = true; s->fixed_index = -1;
   return KH_OK;
@@ -795,6 +826,7 @@ int kh_spa_add_constraint_information(kh_spa * s, int32_t id_a, int32_t id_b, co
 
 int kh_spa_get_constraint(kh_spa * s, int32_t index, int32_t * id_a, int32_t * id_b, double z[3], double info_upper[6])
 {
+  settle(s);
   if (!s || index < 0) {return KH_ERR_INVALID_ARG;}
   if (index >= static_cast<int32_t>(s->cons.size())) {return KH_ERR_NOT_FOUND;}
   const Constraint & c = s->cons[index];
@@ -807,6 +839,7 @@ int kh_spa_get_constraint(kh_spa * s, int32_t index, int32_t * id_a, int32_t * i
 
 int kh_spa_get_nodes(kh_spa * s, int32_t * ids, double * poses)
 {
+  settle(s);
   if (!s) {return KH_ERR_INVALID_ARG;}
   for (size_t k = 0; k < s->nodes.size(); ++k) {
     if (ids) {ids[k] = s->nodes[k].id;}
@@ -817,6 +850,7 @@ int kh_spa_get_nodes(kh_spa * s, int32_t * ids, double * poses)
 
 int kh_spa_get_node_at(kh_spa * s, int32_t index, int32_t * id, double pose[3])
 {
+  settle(s);
   if (!s || index < 0) {return KH_ERR_INVALID_ARG;}
   if (index >= static_cast<int32_t>(s->nodes.size())) {return KH_ERR_NOT_FOUND;}
   if (id) {*id = s->nodes[index].id;}
@@ -963,6 +997,7 @@ int parse_binary(const std::string & data, GraphFile & g)
 
 int kh_spa_save(kh_spa * s, const char * path, int32_t format)
 {
+  settle(s);
   if (!s || !path || (format != KH_GRAPH_TEXT && format != KH_GRAPH_BINARY)) {return KH_ERR_INVALID_ARG;}
   FILE * f = std::fopen(path, format == KH_GRAPH_BINARY ? "wb" : "w");
   if (!f) {set_error("kh_spa_save: cannot open the file for writing"); return KH_ERR_IO;}
@@ -1028,34 +1063,21 @@ int kh_spa_load(kh_spa * s, const char * path)
   return KH_OK;
 }
 
-static void erase_constraints(kh_spa * s, const std::vector<int32_t> & doomed)
-{
-  if (doomed.empty()) {return;}
-  std::vector<uint8_t> kill(s->cons.size(), 0);
-  for (int32_t k : doomed) {kill[k] = 1;}
-  std::vector<Constraint> keep;
-  for (size_t k = 0; k < s->cons.size(); ++k) {if (!kill[k]) {keep.push_back(s->cons[k]);}}
-  s->cons.swap(keep);
-  s->con_of.clear();
-  for (size_t k = 0; k < s->cons.size(); ++k) {s->con_of.insert({{s->cons[k].a, s->cons[k].b}, static_cast<int32_t>(k)});}
-  s->topology_dirty = true;
-}
-
 int kh_spa_remove_node(kh_spa * s, int32_t id)     // ceres_solver.cpp:395-427 (RemoveParameterBlock drops its residuals)
 {
   if (!s) {return KH_ERR_INVALID_ARG;}
   auto it = s->index_of.find(id);
   if (it == s->index_of.end()) {set_error("RemoveNode: Failed to find node matching id"); return KH_ERR_NOT_FOUND;}
-  std::vector<int32_t> doomed;
-  for (size_t k = 0; k < s->cons.size(); ++k) {if (s->cons[k].a == id || s->cons[k].b == id) {doomed.push_back(static_cast<int32_t>(k));}}
-  erase_constraints(s, doomed);
-  s->nodes.erase(s->nodes.begin() + it->second);
+  for (size_t k = 0; k < s->cons.size(); ++k) {
+    if (!s->cons[k].dead && (s->cons[k].a == id || s->cons[k].b == id)) {bury_constraint(s, static_cast<int32_t>(k));}
+  }
+  s->nodes[it->second].dead = 1;
+  ++s->n_dead;
   // ceres_solver.cpp:395-427 erases the node and its parameter blocks; first_node_ keeps pointing at the erased entry
   // there (never dereferenced again once the blocks were set constant).  Here the gauge simply ends with the node: no
   // later node takes it over, and the pose-graph files stop naming it.
   if (s->has_first && id == s->first_id) {s->has_first = false;}
-  s->index_of.clear();
-  for (size_t k = 0; k < s->nodes.size(); ++k) {s->index_of[s->nodes[k].id] = static_cast<int32_t>(k);}
+  s->index_of.erase(it);
   s->topology_dirty = true;
   return KH_OK;
 }
@@ -1066,7 +1088,7 @@ int kh_spa_remove_constraint(kh_spa * s, int32_t id_a, int32_t id_b)    // ceres
   auto it = s->con_of.find({id_a, id_b});
   if (it == s->con_of.end()) {it = s->con_of.find({id_b, id_a});}
   if (it == s->con_of.end()) {set_error("RemoveConstraint: Failed to find residual block"); return KH_ERR_NOT_FOUND;}
-  erase_constraints(s, {it->second});
+  bury_constraint(s, it->second);
   return KH_OK;
 }
 
@@ -1091,8 +1113,8 @@ int kh_spa_get_node(kh_spa * s, int32_t id, double pose[3])
   return KH_OK;
 }
 
-int32_t kh_spa_num_nodes(kh_spa * s) {return s ? static_cast<int32_t>(s->nodes.size()) : 0;}
-int32_t kh_spa_num_constraints(kh_spa * s) {return s ? static_cast<int32_t>(s->cons.size()) : 0;}
+int32_t kh_spa_num_nodes(kh_spa * s) {settle(s); return s ? static_cast<int32_t>(s->nodes.size()) : 0;}
+int32_t kh_spa_num_constraints(kh_spa * s) {settle(s); return s ? static_cast<int32_t>(s->cons.size()) : 0;}
 
 int kh_spa_get_corrections(kh_spa * s, int32_t * n, int32_t * ids, double * poses)
 {
@@ -1142,6 +1164,7 @@ int kh_link_info(const double pose1[3], const double pose2[3], const double cov[
 // CeresSolver::Compute, ceres_solver.cpp:214-269
 int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
 {
+  settle(s);
   if (!s) {return KH_ERR_INVALID_ARG;}
   kh_spa_summary sum;
   std::memset(&sum, 0, sizeof(sum));

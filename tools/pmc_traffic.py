@@ -6,7 +6,7 @@ cache hit rates from the TCP / TCC passes.
 Units and gfx950 correction (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are reported in
 KiB; on gfx950 FETCH_SIZE counts 128-byte read requests at 64 bytes, so the read side is doubled:
     hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024        per launch (mean over the launches of the run)
-Usage: python tools/pmc_traffic.py gpurun_out/r1f k_score profiles/r1_k_score_pmc.json"""
+Usage: python tools/pmc_traffic.py gpurun_out/r1f k_score profiles/r1_k_score_pmc.json [matches per launch, default 64]"""
 import collections
 import csv
 import glob
@@ -17,7 +17,7 @@ import sys
 
 def main():
     root, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    res = {"kernel": kernel, "source": root}
+    res = {"kernel": kernel, "source": root, "matches_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 64}
     for f in sorted(glob.glob(os.path.join(root, "pmc_*", "p_counter_collection.csv"))):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
