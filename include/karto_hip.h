@@ -355,6 +355,13 @@ KH_API double kh_graph_last_kernel_ms(kh_graph * g);
  * fallen behind the largest scan id (Mapper.cpp:1974-1976, 1751-1756): only the first n_visit scans of the list are
  * visited as chain members (all of them still count for the breadth-first "linked" test).  kh_graph_set resets it to n. */
 KH_API int kh_graph_set_scan_limit(kh_graph * g, int32_t n_visit);
+/* Incremental edits of the store (what MapperGraph::AddVertex / AddEdge and a scan's SetSensorPose do to the reference's
+ * graph): a mapper that appends a scan and links it a few times per processed scan does not rebuild the store with
+ * kh_graph_set every time.  Positions are list positions as in kh_graph_set; an edge goes to the END of both
+ * adjacency lists (Vertex::GetAdjacentVertices order).  Removing a scan renumbers the list: rebuild with kh_graph_set. */
+KH_API int kh_graph_append_scan(kh_graph * g, const double ref_xy[2]);
+KH_API int kh_graph_add_edge(kh_graph * g, int32_t scan_a, int32_t scan_b);
+KH_API int kh_graph_set_position(kh_graph * g, int32_t scan, const double ref_xy[2]);
 /* MapperGraph::FindNearLinkedVertices (Mapper.cpp:1808-1819): the vertices a breadth-first traversal from the scan
  * reaches through vertices within max_distance of it, in visiting order (the scan itself first).  *n_found is the total. */
 KH_API int kh_graph_find_near_linked(kh_graph * g, int32_t query_scan, double max_distance, int32_t * scans, int32_t cap,

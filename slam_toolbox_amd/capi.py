@@ -86,7 +86,7 @@ SYMBOLS = [
     "kh_mapper_params_default", "kh_mapper_create", "kh_mapper_destroy", "kh_mapper_process", "kh_mapper_num_scans",
     "kh_mapper_num_edges", "kh_mapper_get_poses", "kh_mapper_get_scan", "kh_mapper_get_stats", "kh_mapper_solver",
     "kh_mapper_set_log", "kh_mapper_remove_node", "kh_mapper_set_lifelong", "kh_mapper_num_alive", "kh_mapper_get_alive",
-    "kh_graph_set_scan_limit", "kh_graph_find_near_linked",
+    "kh_graph_set_scan_limit", "kh_graph_find_near_linked", "kh_graph_append_scan", "kh_graph_add_edge", "kh_graph_set_position",
 ]
 
 
@@ -253,6 +253,9 @@ def lib():
         L.kh_mapper_num_alive.argtypes = [vp]
         L.kh_mapper_get_alive.argtypes = [vp, iptr]
         L.kh_graph_set_scan_limit.argtypes = [vp, i32]
+        L.kh_graph_append_scan.argtypes = [vp, dptr]
+        L.kh_graph_add_edge.argtypes = [vp, i32, i32]
+        L.kh_graph_set_position.argtypes = [vp, i32, dptr]
         L.kh_graph_find_near_linked.argtypes = [vp, i32, dbl, iptr, i32, C.POINTER(i32)]
     if hasattr(L, "kh_lifelong_scores"):
         L.kh_decay_params_default.argtypes = [C.POINTER(KhDecayParams)]

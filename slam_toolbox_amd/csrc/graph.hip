@@ -218,6 +218,39 @@ int kh_graph_set(kh_graph * g, int32_t n_scans, const double * ref_xy, const int
   return KH_OK;
 }
 
+int kh_graph_append_scan(kh_graph * g, const double ref_xy[2])
+{
+  if (!g || !ref_xy) {return KH_ERR_INVALID_ARG;}
+  if (g->h_adj_ptr.empty()) {g->h_adj_ptr.push_back(0);}
+  g->h_xy.push_back(ref_xy[0]); g->h_xy.push_back(ref_xy[1]);
+  g->h_adj_ptr.push_back(g->h_adj_ptr.back());
+  if (g->n_visit == g->n) {++g->n_visit;}
+  ++g->n;
+  g->device_stale = true;
+  return KH_OK;
+}
+
+int kh_graph_add_edge(kh_graph * g, int32_t scan_a, int32_t scan_b)
+{
+  if (!g || scan_a < 0 || scan_b < 0 || scan_a >= g->n || scan_b >= g->n || scan_a == scan_b) {return KH_ERR_INVALID_ARG;}
+  auto append = [&](int32_t at, int32_t what) {
+    g->h_adj_idx.insert(g->h_adj_idx.begin() + g->h_adj_ptr[static_cast<size_t>(at) + 1], what);
+    for (size_t k = static_cast<size_t>(at) + 1; k < g->h_adj_ptr.size(); ++k) {++g->h_adj_ptr[k];}
+  };
+  append(scan_a, scan_b);
+  append(scan_b, scan_a);
+  g->device_stale = true;
+  return KH_OK;
+}
+
+int kh_graph_set_position(kh_graph * g, int32_t scan, const double ref_xy[2])
+{
+  if (!g || !ref_xy || scan < 0 || scan >= g->n) {return KH_ERR_INVALID_ARG;}
+  g->h_xy[2 * static_cast<size_t>(scan)] = ref_xy[0]; g->h_xy[2 * static_cast<size_t>(scan) + 1] = ref_xy[1];
+  g->device_stale = true;
+  return KH_OK;
+}
+
 int kh_graph_set_positions(kh_graph * g, int32_t n_scans, const double * ref_xy)
 {
   if (!g || !ref_xy || n_scans != g->n) {return KH_ERR_INVALID_ARG;}

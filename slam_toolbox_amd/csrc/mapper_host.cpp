@@ -27,6 +27,8 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/karto_hip.h"
@@ -265,7 +267,13 @@ void set_sensor_pose(kh_mapper * m, MScan & s, const double pose[3])
   // GetCorrectedAt: sPose - worldSensorOffset with a zero offset: position unchanged, NormalizeAngle(heading - 0)
   s.corrected.x = pose[0]; s.corrected.y = pose[1]; s.corrected.h = normalize_angle(pose[2]);
   update_scan(s, m->laser);
-  m->graph_dirty = true;
+  if (!m->graph_dirty && s.id >= 0 && s.id < static_cast<int32_t>(m->compact_of.size()) && m->compact_of[s.id] >= 0) {
+    double xy[2];
+    reference_xy(m, s, xy);
+    if (kh_graph_set_position(m->graph, m->compact_of[s.id], xy) != KH_OK) {m->graph_dirty = true;}
+  } else {
+    m->graph_dirty = true;
+  }
 }
 
 // MapperGraph::LinkScans (Mapper.cpp:1620-1639) incl. AddEdge's "edge already exists" test (:1585-1618)
@@ -276,7 +284,8 @@ int link_scans(kh_mapper * m, int32_t from, int32_t to, const double mean[3], co
   m->adj[from].push_back(to);
   m->adj[to].push_back(from);
   ++m->n_edges;
-  m->graph_dirty = true;
+  // the store follows edit by edit while nothing was removed or re-posed since it was built (sync_graph rebuilds otherwise)
+  if (!m->graph_dirty && kh_graph_add_edge(m->graph, m->compact_of[from], m->compact_of[to]) != KH_OK) {m->graph_dirty = true;}
   // LinkInfo(pFromScan->GetCorrectedPose(), pToScan->GetCorrectedAt(rMean), rCovariance)
   const MScan & f = *m->scans[from];
   const double pose1[3] = {f.corrected.x, f.corrected.y, f.corrected.h};
@@ -340,13 +349,32 @@ int correct_poses(kh_mapper * m)
   }
   // SetCorrectedPoseAndUpdate of every scan: N x P cos / sin in libm (the reference does the same, serially)
   const auto t1 = std::chrono::steady_clock::now();
-  host_parallel_for(static_cast<size_t>(n), [&](size_t k) {
+  auto one = [&](size_t k) {
     const int32_t id = ids[k];
     if (id < 0 || id >= static_cast<int32_t>(m->scans.size()) || !m->scans[id]) {return;}
     MScan & s = *m->scans[id];
     s.corrected.x = poses[3 * k]; s.corrected.y = poses[3 * k + 1]; s.corrected.h = poses[3 * k + 2];
     update_scan(s, m->laser);
-  });
+  };
+  // thousands of scans x 1081 sin / cos: wider than the matcher's worker pool (32 threads suit its sub-millisecond
+  // bursts; this is milliseconds of uniform work -- 64 threads halved it on the 50 000-scan replay)
+  const unsigned wide = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+  if (n >= 4096 && wide > 32) {
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const size_t b = next.fetch_add(64);
+        if (b >= static_cast<size_t>(n)) {return;}
+        for (size_t k = b; k < std::min(static_cast<size_t>(n), b + 64); ++k) {one(k);}
+      }
+    };
+    std::vector<std::thread> team;
+    for (unsigned t = 1; t < wide; ++t) {team.emplace_back(worker);}
+    worker();
+    for (auto & t : team) {t.join();}
+  } else {
+    host_parallel_for(static_cast<size_t>(n), one);
+  }
   m->stats.update_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
   m->graph_dirty = true;
   if (m->log) {std::fprintf(m->log, "K\n");}
@@ -678,7 +706,17 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
   scan->id = id;
   m->scans.push_back(std::move(scan));
   m->adj.emplace_back(); m->out_edges.emplace_back();
-  m->graph_dirty = true;
+  if (!m->graph_dirty) {
+    double xy[2];
+    reference_xy(m, *m->scans[id], xy);
+    m->compact_of.push_back(static_cast<int32_t>(m->alive.size()));
+    m->alive.push_back(id);
+    if (kh_graph_append_scan(m->graph, xy) != KH_OK) {m->graph_dirty = true;}
+    // the scan map's size in id space bounds the candidate walks (see sync_graph)
+    const int32_t n_alive = static_cast<int32_t>(m->alive.size());
+    const int32_t n_visit = static_cast<int32_t>(std::lower_bound(m->alive.begin(), m->alive.end(), n_alive) - m->alive.begin());
+    if (!m->graph_dirty && kh_graph_set_scan_limit(m->graph, n_visit) != KH_OK) {m->graph_dirty = true;}
+  }
   MScan & s = *m->scans[id];
   if (m->p.use_scan_matching) {
     // AddVertex (:1418-1432): the solver node carries the corrected pose
