@@ -1285,7 +1285,9 @@ void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int
     const int slots8 = 8 * ((n + 7) / 8);
     const int G = std::min(split_cap, 224 / slots8);
     const int threads2 = max_m <= 96 ? 256 : 512;
-    if (G >= 4 && max_m >= 270 && !timing) {
+    static const int split_min_g = std::getenv("KH_SPA_SPLIT_MIN_G") ? std::atoi(std::getenv("KH_SPA_SPLIT_MIN_G")) : 4;
+    static const int split_min_m = std::getenv("KH_SPA_SPLIT_MIN_M") ? std::atoi(std::getenv("KH_SPA_SPLIT_MIN_M")) : 270;
+    if (G >= split_min_g && max_m >= split_min_m && !timing) {
       const int steps = (max_ns + 2 * NB - 1) / (2 * NB);
       for (int p = 0; p < steps; ++p) {
         hipLaunchKernelGGL(k_factor2, dim3(n), dim3(threads2), lds2, (hipStream_t)stream, d, level_fronts, fail_flag, (long long *)nullptr, rhs, upd, fsb,
