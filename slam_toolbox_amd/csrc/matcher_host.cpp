@@ -1162,8 +1162,18 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   // waited for), so later main-stream work needs no edge back
   KH_HIP(hipEventRecord(m->batch[0].kdone, m->stream));
   for (auto & b : m->batch) {KH_HIP(hipStreamWaitEvent(b.side, m->batch[0].kdone, 0));}
+  // a shorter first and last chunk: the pipeline fills on the first (its preparation, upload and K2 are exposed) and drains
+  // on the last (its K4, download and finalisation are); 32 measured 71.5 k config-2 matches/s against 69.6 k with
+  // uniform chunks of 64 and 68.7 k with 16.  KH_CHUNK_EDGE=64 restores the uniform split.
+  static const size_t edge = std::getenv("KH_CHUNK_EDGE") ? static_cast<size_t>(std::max(8, std::min(64, std::atoi(std::getenv("KH_CHUNK_EDGE"))))) : 32;
   std::vector<size_t> bounds;
-  for (size_t at = 0; at < n; at += kChunk) {bounds.push_back(at);}
+  if (edge < kChunk && n >= 2 * edge + kChunk) {
+    bounds.push_back(0);
+    for (size_t at = edge; at + edge < n; at += kChunk) {bounds.push_back(at);}
+    if (n - bounds.back() > kChunk) {bounds.push_back(n - edge);}
+  } else {
+    for (size_t at = 0; at < n; at += kChunk) {bounds.push_back(at);}
+  }
   bounds.push_back(n);
   const size_t chunks = bounds.size() - 1;
   auto begin_of = [&](size_t c) {return bounds[c];};

@@ -17,7 +17,7 @@ import sys
 
 def main():
     root, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    res = {"kernel": kernel, "source": root, "matches_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 64}
+    res = {"kernel": kernel, "source": root, "matches_per_launch": float(sys.argv[4]) if len(sys.argv) > 4 else 64.0}
     for f in sorted(glob.glob(os.path.join(root, "pmc_*", "p_counter_collection.csv"))):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
