@@ -128,7 +128,7 @@ struct MScan
   MScan() = default;
   MScan(const MScan &) = delete;
   MScan & operator=(const MScan &) = delete;
-  ~MScan() {if (d_points) {kh_device_free(d_points);}}
+  // d_points is a slot of the mapper's device slabs (take_slot / remove_node / kh_mapper_destroy), not owned here
 };
 
 struct Laser {int32_t n = 0; double min_angle = 0, ang_res = 0, min_range = 0, max_range = 0, range_threshold = 0;};
@@ -192,6 +192,9 @@ struct kh_mapper
   bool graph_dirty = true;
   FILE * log = nullptr;
   kh_mapper_stats stats;
+  // device copies of the scans' readings: slots of 2 * laser.n doubles carved from slabs of 256 (one hipMalloc per 256
+  // scans instead of one per scan), recycled when a node is removed
+  std::vector<double *> d_slabs, d_free_slots;
 };
 
 namespace kh
@@ -216,10 +219,17 @@ kh_scan as_base_scan(kh_mapper * m, MScan & s)
 {
   kh_scan k = as_kh_scan(s);
   const int64_t bytes = static_cast<int64_t>(sizeof(double)) * static_cast<int64_t>(s.points.size());
-  if (bytes > 0) {
+  if (bytes > 0 && s.points.size() == 2 * static_cast<size_t>(m->laser.n)) {
     if (!s.d_points) {
-      void * p = nullptr;
-      if (kh_device_malloc(m->device, bytes, &p) == KH_OK) {s.d_points = static_cast<double *>(p); s.d_stale = true;}
+      if (m->d_free_slots.empty()) {
+        constexpr int kSlabScans = 256;
+        void * p = nullptr;
+        if (kh_device_malloc(m->device, bytes * kSlabScans, &p) == KH_OK) {
+          m->d_slabs.push_back(static_cast<double *>(p));
+          for (int k = kSlabScans - 1; k >= 0; --k) {m->d_free_slots.push_back(static_cast<double *>(p) + static_cast<size_t>(k) * s.points.size());}
+        }
+      }
+      if (!m->d_free_slots.empty()) {s.d_points = m->d_free_slots.back(); m->d_free_slots.pop_back(); s.d_stale = true;}
     }
     if (s.d_points && s.d_stale && kh_device_upload(s.d_points, s.points.data(), bytes) == KH_OK) {s.d_stale = false;}
     if (s.d_points && !s.d_stale) {k.device_points_xy = s.d_points;}      // any failure: the call uploads the scan itself
@@ -526,6 +536,7 @@ int remove_node(kh_mapper * m, int32_t id)
   const int rc = kh_spa_remove_node(m->solver, id);
   if (rc != KH_OK && rc != KH_ERR_NOT_FOUND) {return rc;}
   m->adj[id].clear(); m->out_edges[id].clear();
+  if (m->scans[id]->d_points) {m->d_free_slots.push_back(m->scans[id]->d_points);}
   m->scans[id].reset();
   m->graph_dirty = true;
   m->stats.nodes_removed += 1;
@@ -640,6 +651,7 @@ void kh_mapper_destroy(kh_mapper * m)
   if (m->log) {std::fclose(m->log);}
   kh_matcher_destroy(m->seq); kh_matcher_destroy(m->loop);
   kh_spa_destroy(m->solver); kh_graph_destroy(m->graph);
+  for (double * slab : m->d_slabs) {kh_device_free(slab);}
   delete m;
 }
 
