@@ -53,6 +53,10 @@ def test_large_graph_against_the_oracle(kartohip_lib, max_distance, min_chain):
         assert got[k] == ref, (q, got[k][:3], ref[:3])
         n_chains += len(ref)
     assert n_chains > 0
+    # one query at a time is answered from the host copy of the store (a mapper's per-scan question): same chains as the
+    # kernel gave for the batch
+    for k in range(0, len(queries), 7):
+        assert s.FindPossibleLoopClosures(queries[k:k + 1], max_distance, min_chain)[0] == got[k]
     # moved scans, same topology
     xy2 = xy + 0.05 * np.sin(np.arange(xy.size).reshape(xy.shape))
     s.SetPositions(xy2)
