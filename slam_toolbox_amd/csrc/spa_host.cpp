@@ -100,7 +100,17 @@ struct kh_spa
   std::vector<Node> nodes;                       // insertion order
   std::unordered_map<int32_t, int32_t> index_of; // id -> position in nodes
   std::vector<Constraint> cons;
-  std::multimap<std::pair<int32_t, int32_t>, int32_t> con_of;   // (a, b) -> position in cons
+  std::unordered_multimap<uint64_t, int32_t> con_of;             // edge_key(a, b) -> position in cons (hashed: settle() re-keys
+                                                                 // tens of thousands of constraints before a Compute)
+  static uint64_t edge_key(int32_t a, int32_t b) {return (static_cast<uint64_t>(static_cast<uint32_t>(a)) << 32) | static_cast<uint32_t>(b);}
+  // the constraint between a and b (in that order) that was added first, -1 = none
+  int32_t first_constraint(int32_t a, int32_t b) const
+  {
+    int32_t best = -1;
+    auto range = con_of.equal_range(edge_key(a, b));
+    for (auto it = range.first; it != range.second; ++it) {if (best < 0 || it->second < best) {best = it->second;}}
+    return best;
+  }
   int32_t n_dead = 0;                            // tombstones in nodes + cons (settle() compacts, order preserved)
   int32_t first_id = 0; bool has_first = false; bool was_constant_set = false;
   std::vector<int32_t> corr_ids; std::vector<double> corr_poses;
@@ -145,7 +155,8 @@ static void settle(kh_spa * s)
   s->cons.erase(std::remove_if(s->cons.begin(), s->cons.end(), [](const Constraint & c) {return c.dead != 0;}), s->cons.end());
   s->nodes.erase(std::remove_if(s->nodes.begin(), s->nodes.end(), [](const Node & n) {return n.dead != 0;}), s->nodes.end());
   s->con_of.clear();
-  for (size_t k = 0; k < s->cons.size(); ++k) {s->con_of.insert({{s->cons[k].a, s->cons[k].b}, static_cast<int32_t>(k)});}
+  s->con_of.reserve(s->cons.size());
+  for (size_t k = 0; k < s->cons.size(); ++k) {s->con_of.insert({kh_spa::edge_key(s->cons[k].a, s->cons[k].b), static_cast<int32_t>(k)});}
   s->index_of.clear();
   for (size_t k = 0; k < s->nodes.size(); ++k) {s->index_of[s->nodes[k].id] = static_cast<int32_t>(k);}
   s->n_dead = 0;
@@ -155,7 +166,7 @@ static void bury_constraint(kh_spa * s, int32_t k)
 {
   Constraint & c = s->cons[k];
   if (c.dead) {return;}
-  auto range = s->con_of.equal_range({c.a, c.b});
+  auto range = s->con_of.equal_range(kh_spa::edge_key(c.a, c.b));
   for (auto it = range.first; it != range.second; ++it) {
     if (it->second == k) {s->con_of.erase(it); break;}
   }
@@ -334,18 +345,15 @@ static void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeL
   out.push_back(S);
 }
 
+// adjacency of the free nodes in CSR form: neighbours of i = adj_idx[adj_ptr[i] .. adj_ptr[i + 1]), ascending
 static int build_symbolic(
-  Symbolic & sym, int32_t n_free, const std::vector<std::vector<int32_t>> & adj,
-  const std::vector<double> & px, const std::vector<double> & py)
+  Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx)
 {
   sym = Symbolic();
   sym.n_free = n_free;
   NdContext ctx;
-  (void)px; (void)py;
-  ctx.adj_ptr.assign(n_free + 1, 0);
-  for (int32_t i = 0; i < n_free; ++i) {ctx.adj_ptr[i + 1] = ctx.adj_ptr[i] + static_cast<int32_t>(adj[i].size());}
-  ctx.adj_idx.resize(ctx.adj_ptr[n_free]);
-  for (int32_t i = 0; i < n_free; ++i) {std::copy(adj[i].begin(), adj[i].end(), ctx.adj_idx.begin() + ctx.adj_ptr[i]);}
+  ctx.adj_ptr = adj_ptr;
+  ctx.adj_idx = adj_idx;
   ctx.tag.assign(n_free, 0);
   ctx.dist.assign(n_free, 0);
   std::vector<int32_t> all(n_free);
@@ -376,8 +384,9 @@ static int build_symbolic(
     const int32_t end = sym.sn_first[k + 1];
     std::vector<int32_t> & r = rows[k];
     for (int32_t e = sym.sn_first[k]; e < end; ++e) {
-      for (int32_t w : adj[sym.free_of_elim[e]]) {
-        const int32_t ew = sym.elim_of_free[w];
+      const int32_t v = sym.free_of_elim[e];
+      for (int32_t q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) {
+        const int32_t ew = sym.elim_of_free[adj_idx[q]];
         if (ew >= end && stamp[ew] != k) {stamp[ew] = k; r.push_back(ew);}
       }
     }
@@ -459,9 +468,24 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   // gauge: first inserted node is constant once it has parameter blocks (ceres_solver.cpp:228-241)
   std::vector<uint8_t> used(N, 0);
   std::vector<int32_t> ea(E), eb(E);
-  for (int32_t e = 0; e < E; ++e) {
-    ea[e] = s->index_of.at(s->cons[e].a); eb[e] = s->index_of.at(s->cons[e].b);
-    used[ea[e]] = 1; used[eb[e]] = 1;
+  {
+    // node ids are scan ids: small and dense, so the 2 E lookups go through a table (a hash lookup each was 2 ms of every
+    // Compute on a 57 000-edge graph); sparse or negative ids keep the map
+    int32_t lo = 0, hi = -1;
+    for (const Node & nd : s->nodes) {lo = std::min(lo, nd.id); hi = std::max(hi, nd.id);}
+    std::vector<int32_t> pos_of_id;
+    if (lo >= 0 && hi >= 0 && static_cast<int64_t>(hi) < 8ll * N + 4096) {
+      pos_of_id.assign(static_cast<size_t>(hi) + 1, -1);
+      for (int32_t i = 0; i < N; ++i) {pos_of_id[s->nodes[i].id] = i;}
+    }
+    for (int32_t e = 0; e < E; ++e) {
+      if (!pos_of_id.empty()) {
+        ea[e] = pos_of_id[s->cons[e].a]; eb[e] = pos_of_id[s->cons[e].b];
+      } else {
+        ea[e] = s->index_of.at(s->cons[e].a); eb[e] = s->index_of.at(s->cons[e].b);
+      }
+      used[ea[e]] = 1; used[eb[e]] = 1;
+    }
   }
   if (!s->was_constant_set && s->has_first) {
     auto it = s->index_of.find(s->first_id);
@@ -499,14 +523,16 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
       if (fa >= 0 && fb >= 0 && fa != fb) {nbr[fill[fa]++] = fb; nbr[fill[fb]++] = fa;}
     }
-    std::vector<std::vector<int32_t>> adj(nf);
+    std::vector<int32_t> adj_ptr(nf + 1, 0), adj_idx;              // sorted, duplicate-free neighbour lists, compact
+    adj_idx.reserve(deg[nf]);
     std::vector<int32_t> row_ptr(nf + 1, 0), col, diag(nf), slot_row;
     col.reserve(deg[nf] + nf); slot_row.reserve(deg[nf] + nf);
     for (int32_t i = 0; i < nf; ++i) {
       int32_t * b = nbr.data() + deg[i], * e2 = nbr.data() + deg[i + 1];
       std::sort(b, e2);
       e2 = std::unique(b, e2);
-      adj[i].assign(b, e2);
+      adj_idx.insert(adj_idx.end(), b, e2);
+      adj_ptr[i + 1] = static_cast<int32_t>(adj_idx.size());
       bool placed = false;
       for (int32_t * q = b; q < e2; ++q) {
         if (!placed && *q > i) {diag[i] = static_cast<int32_t>(col.size()); col.push_back(i); slot_row.push_back(i); placed = true;}
@@ -546,10 +572,8 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       if (fb >= 0) {ncl[nfill[fb]++] = e * 2 + 1;}
     }
     // ordering + fronts
-    std::vector<double> px(nf), py(nf);
-    for (int32_t i = 0; i < nf; ++i) {px[i] = s->nodes[s->node_of_free[i]].pose[0]; py[i] = s->nodes[s->node_of_free[i]].pose[1];}
     const auto t_sym0 = std::chrono::steady_clock::now();
-    int rc = build_symbolic(s->sym, nf, adj, px, py);
+    int rc = build_symbolic(s->sym, nf, adj_ptr, adj_idx);
     if (rc) {return rc;}
     if (std::getenv("KH_SPA_DEBUG")) {
       std::fprintf(stderr, "[kh_spa] host: pattern %.2f ms, symbolic %.2f ms\n",
@@ -804,7 +828,7 @@ static int add_constraint_information(kh_spa * s, int32_t id_a, int32_t id_b, co
     set_error("CeresSolver: constraint information matrix is not positive definite");
     return KH_ERR_INVALID_ARG;
   }
-  s->con_of.insert({{id_a, id_b}, static_cast<int32_t>(s->cons.size())});
+  s->con_of.insert({kh_spa::edge_key(id_a, id_b), static_cast<int32_t>(s->cons.size())});
   s->cons.push_back(c);
   s->topology_dirty = true;
   return KH_OK;
@@ -1085,10 +1109,10 @@ int kh_spa_remove_node(kh_spa * s, int32_t id)     // ceres_solver.cpp:395-427 (
 int kh_spa_remove_constraint(kh_spa * s, int32_t id_a, int32_t id_b)    // ceres_solver.cpp:430-448
 {
   if (!s) {return KH_ERR_INVALID_ARG;}
-  auto it = s->con_of.find({id_a, id_b});
-  if (it == s->con_of.end()) {it = s->con_of.find({id_b, id_a});}
-  if (it == s->con_of.end()) {set_error("RemoveConstraint: Failed to find residual block"); return KH_ERR_NOT_FOUND;}
-  bury_constraint(s, it->second);
+  int32_t k = s->first_constraint(id_a, id_b);
+  if (k < 0) {k = s->first_constraint(id_b, id_a);}
+  if (k < 0) {set_error("RemoveConstraint: Failed to find residual block"); return KH_ERR_NOT_FOUND;}
+  bury_constraint(s, k);
   return KH_OK;
 }
 
