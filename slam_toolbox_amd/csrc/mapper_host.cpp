@@ -277,7 +277,8 @@ void set_sensor_pose(kh_mapper * m, MScan & s, const double pose[3])
   // GetCorrectedAt: sPose - worldSensorOffset with a zero offset: position unchanged, NormalizeAngle(heading - 0)
   s.corrected.x = pose[0]; s.corrected.y = pose[1]; s.corrected.h = normalize_angle(pose[2]);
   update_scan(s, m->laser);
-  if (!m->graph_dirty && s.id >= 0 && s.id < static_cast<int32_t>(m->compact_of.size()) && m->compact_of[s.id] >= 0) {
+  if (s.id < 0) {return;}               // not in the graph yet (the match of a new scan): AddScan appends it where it stands
+  if (!m->graph_dirty && s.id < static_cast<int32_t>(m->compact_of.size()) && m->compact_of[s.id] >= 0) {
     double xy[2];
     reference_xy(m, s, xy);
     if (kh_graph_set_position(m->graph, m->compact_of[s.id], xy) != KH_OK) {m->graph_dirty = true;}
