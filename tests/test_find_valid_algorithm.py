@@ -116,3 +116,38 @@ def test_pointer_doubling_equals_the_sequential_state_machine(oracle_lib, case):
     got = points[flags.astype(bool)]
     assert got.shape == want.shape
     assert np.array_equal(got.view(np.uint64), np.asarray(want).view(np.uint64))
+
+
+def _range_cases():
+    rng = np.random.default_rng(9)
+    n = LASER.n_beams
+    base = 4.0 + 2.0 * np.sin(np.linspace(0, 9, n)) + rng.normal(0, 0.01, n)
+    r0 = base.copy()
+    r0[rng.uniform(size=n) < 0.03] = np.nan
+    r0[rng.uniform(size=n) < 0.03] = np.inf
+    r1 = np.where(np.arange(n) % 9 < 4, 1.5, 12.0) + rng.normal(0, 0.05, n)
+    r2 = np.full(n, 0.7) + rng.normal(0, 0.002, n)
+    r2[:60] = np.nan
+    r2[400:640] = np.inf
+    return [r0, r1, r2]
+
+
+@pytest.mark.parametrize("case", range(3))
+def test_pointer_doubling_against_the_reference_itself(case):
+    """the same flags from the reference's own ScanMatcher::FindValidPoints (oracle/_ref, dev container only) on scans the
+    reference builds from ranges and pose"""
+    from common import OFFLINE_PARAMS, PRESETS
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    ref.init_laser(LASER)
+    pose = np.array([2.0, 1.0, -0.4])
+    rs = ref.RefScan(_range_cases()[case], pose)
+    points = rs.points()
+    assert points.shape[0] == LASER.n_beams
+    view = pose[:2] + np.array([0.3, -0.2])
+    rm = ref.RefMatcher(*PRESETS["S"]["create"], OFFLINE_PARAMS)
+    want = rm.find_valid_points(rs, view)
+    got = points[flags_by_pointer_doubling(points, view).astype(bool)]
+    assert got.shape == want.shape and got.shape[0] > 0
+    assert np.array_equal(got.view(np.uint64), np.ascontiguousarray(want).view(np.uint64))
