@@ -307,6 +307,7 @@ KH_API int kh_comm_create(int32_t device, int32_t rank, int32_t world, const uin
 KH_API void kh_comm_destroy(kh_comm * c);
 KH_API int32_t kh_comm_rank(const kh_comm * c);
 KH_API int32_t kh_comm_world(const kh_comm * c);
+KH_API int32_t kh_comm_device(const kh_comm * c);     /* the device the communicator was created on; -1 for NULL */
 /* in-place sum of `count` doubles at device_buf across the ranks, enqueued on hip_stream (a hipStream_t) */
 KH_API int kh_comm_allreduce_sum_f64(kh_comm * c, double * device_buf, int64_t count, void * hip_stream);
 /* every rank contributes count_per_rank doubles; device_recv (world * count_per_rank) holds them in rank order.  What the

@@ -79,7 +79,7 @@ SYMBOLS = [
     "kh_occupancy_compute_dimensions", "kh_occupancy_create", "kh_occupancy_destroy", "kh_occupancy_clear",
     "kh_occupancy_add_scans", "kh_occupancy_update", "kh_occupancy_read", "kh_occupancy_info",
     "kh_decay_params_default", "kh_lifelong_scores",
-    "kh_spa_set_comm", "kh_comm_unique_id", "kh_comm_create", "kh_comm_destroy", "kh_comm_rank", "kh_comm_world",
+    "kh_spa_set_comm", "kh_comm_unique_id", "kh_comm_create", "kh_comm_destroy", "kh_comm_rank", "kh_comm_world", "kh_comm_device",
     "kh_comm_allreduce_sum_f64", "kh_comm_allgather_f64",
     "kh_device_malloc", "kh_device_free", "kh_device_upload", "kh_device_download",
     "kh_graph_find_loop_candidates_from",
@@ -211,6 +211,7 @@ def lib():
         L.kh_comm_destroy.restype = None
         L.kh_comm_rank.argtypes = [vp]
         L.kh_comm_world.argtypes = [vp]
+        L.kh_comm_device.argtypes = [vp]
         L.kh_comm_allreduce_sum_f64.argtypes = [vp, vp, C.c_int64, vp]
         L.kh_comm_allgather_f64.argtypes = [vp, vp, vp, C.c_int64, vp]
         L.kh_spa_set_comm.argtypes = [vp, vp]

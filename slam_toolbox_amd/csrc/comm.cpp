@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -44,12 +45,24 @@ RcclApi & rccl()
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
+    // KH_RCCL_LIBRARY names the one library to bind (a site-specific build; the tests name a missing file to walk the
+    // not-found path)
+    const char * forced = std::getenv("KH_RCCL_LIBRARY");
     const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char * n : names) {
-      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-      if (api.handle) {break;}
+    if (forced && forced[0]) {
+      api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char * n : names) {
+        api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) {break;}
+      }
     }
-    if (!api.handle) {api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return;}
+    if (!api.handle) {
+      // dlerror() hands the message out ONCE and clears it: a second call returns NULL
+      const char * e = dlerror();
+      api.why = std::string("librccl not found: ") + (e ? e : "?");
+      return;
+    }
     auto sym = [&](const char * name) {
       void * p = dlsym(api.handle, name);
       if (!p && api.why.empty()) {api.why = std::string("librccl lacks ") + name;}
@@ -126,6 +139,7 @@ void kh_comm_destroy(kh_comm * c)
 
 int32_t kh_comm_rank(const kh_comm * c) {return c ? c->rank : -1;}
 int32_t kh_comm_world(const kh_comm * c) {return c ? c->world : 0;}
+int32_t kh_comm_device(const kh_comm * c) {return c ? c->device : -1;}
 
 int kh_comm_allreduce_sum_f64(kh_comm * c, double * device_buf, int64_t count, void * hip_stream)
 {
@@ -175,8 +189,18 @@ int kh_device_upload(void * device_dst, const void * host_src, int64_t bytes)
 int kh_device_download(void * host_dst, const void * device_src, int64_t bytes)
 {
   if (!host_dst || !device_src || bytes < 0) {return KH_ERR_INVALID_ARG;}
-  if (hipDeviceSynchronize() != hipSuccess ||
-    hipMemcpy(host_dst, device_src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost) != hipSuccess) {kh::set_error("hipMemcpy D2H failed"); return KH_ERR_HIP;}
+  // "waits for all queued work" is a promise about the device the buffer lives on, not the caller's current one
+  hipPointerAttribute_t attr;
+  int prev = -1;
+  if (hipPointerGetAttributes(&attr, device_src) == hipSuccess && hipGetDevice(&prev) == hipSuccess && attr.device != prev) {
+    if (hipSetDevice(attr.device) != hipSuccess) {kh::set_error("hipSetDevice failed"); return KH_ERR_HIP;}
+  } else {
+    prev = -1;
+  }
+  const bool ok = hipDeviceSynchronize() == hipSuccess &&
+    hipMemcpy(host_dst, device_src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost) == hipSuccess;
+  if (prev >= 0) {(void)hipSetDevice(prev);}
+  if (!ok) {kh::set_error("hipMemcpy D2H failed"); return KH_ERR_HIP;}
   return KH_OK;
 }
 

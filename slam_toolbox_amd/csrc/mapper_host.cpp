@@ -186,6 +186,9 @@ struct kh_mapper
   kh_decay_params decay;
   std::vector<int32_t> running;
   int32_t last = -1;
+  // set when Process() fails after its scan was committed to the scan list, the graph store and the solver: the
+  // `id - 1 = previous scan` bookkeeping no longer matches, so every later Process() refuses instead of mis-linking
+  bool failed = false;
   std::vector<std::vector<int32_t>> adj;                 // Vertex::GetAdjacentVertices order (Mapper.h:338-361)
   std::vector<std::vector<int32_t>> out_edges;           // targets of the edges whose SOURCE is the vertex (AddEdge's duplicate test)
   int64_t n_edges = 0;
@@ -675,6 +678,10 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
 {
   if (!m || !ranges || !odometric_pose || !accepted) {return KH_ERR_INVALID_ARG;}
   *accepted = 0;
+  if (m->failed) {
+    kh::set_error("kh_mapper_process: an earlier call failed after its scan had entered the graph; the handle is unusable");
+    return KH_ERR_SOLVER;
+  }
   const auto t_begin = std::chrono::steady_clock::now();
   std::unique_ptr<MScan> scan(new MScan());
   scan->ranges.assign(ranges, ranges + m->laser.n);
@@ -719,6 +726,8 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
   scan->id = id;
   m->scans.push_back(std::move(scan));
   m->adj.emplace_back(); m->out_edges.emplace_back();
+  // from here on the scan is part of the mapper: an error return leaves the handle marked failed
+  struct CommitGuard {kh_mapper * m; bool armed; ~CommitGuard() {if (armed) {m->failed = true;}}} guard{m, true};
   if (!m->graph_dirty) {
     double xy[2];
     reference_xy(m, *m->scans[id], xy);
@@ -809,6 +818,7 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     const int rc = kh::lifelong_step(m, id);
     if (rc) {return rc;}
   }
+  guard.armed = false;
   *accepted = 1;
   if (corrected_pose) {corrected_pose[0] = s.corrected.x; corrected_pose[1] = s.corrected.y; corrected_pose[2] = s.corrected.h;}
   if (covariance) {std::copy(cov, cov + 9, covariance);}
@@ -843,6 +853,13 @@ int kh_mapper_get_scan(const kh_mapper * m, int32_t index, kh_scan * scan, kh_sc
 int kh_mapper_remove_node(kh_mapper * m, int32_t scan_id)
 {
   if (!m) {return KH_ERR_INVALID_ARG;}
+  // The next Process() reads the last scan and every scan of the running window; the reference (GetLastScan /
+  // GetRunningScans hold raw pointers, Mapper.cpp:2688, 2716) would be left with dangling ones, and its only caller --
+  // the lifelong policy, which skips the newest scan_buffer_size scans -- never asks for this.  Refused here.
+  if (scan_id == m->last || std::find(m->running.begin(), m->running.end(), scan_id) != m->running.end()) {
+    kh::set_error("RemoveNode: the scan is the last scan or in the running-scan window");
+    return KH_ERR_INVALID_ARG;
+  }
   return kh::remove_node(m, scan_id);
 }
 

@@ -111,7 +111,9 @@ struct kh_spa
     for (auto it = range.first; it != range.second; ++it) {if (best < 0 || it->second < best) {best = it->second;}}
     return best;
   }
+  std::unordered_map<int32_t, std::vector<int32_t>> incident;   // node id -> positions in cons of its constraints (dead ones included until settle())
   int32_t n_dead = 0;                            // tombstones in nodes + cons (settle() compacts, order preserved)
+  int32_t n_dead_nodes = 0;                      // ... of which nodes
   int32_t first_id = 0; bool has_first = false; bool was_constant_set = false;
   std::vector<int32_t> corr_ids; std::vector<double> corr_poses;
   bool topology_dirty = true;
@@ -156,10 +158,16 @@ static void settle(kh_spa * s)
   s->nodes.erase(std::remove_if(s->nodes.begin(), s->nodes.end(), [](const Node & n) {return n.dead != 0;}), s->nodes.end());
   s->con_of.clear();
   s->con_of.reserve(s->cons.size());
-  for (size_t k = 0; k < s->cons.size(); ++k) {s->con_of.insert({kh_spa::edge_key(s->cons[k].a, s->cons[k].b), static_cast<int32_t>(k)});}
+  s->incident.clear();
+  for (size_t k = 0; k < s->cons.size(); ++k) {
+    s->con_of.insert({kh_spa::edge_key(s->cons[k].a, s->cons[k].b), static_cast<int32_t>(k)});
+    s->incident[s->cons[k].a].push_back(static_cast<int32_t>(k));
+    s->incident[s->cons[k].b].push_back(static_cast<int32_t>(k));
+  }
   s->index_of.clear();
   for (size_t k = 0; k < s->nodes.size(); ++k) {s->index_of[s->nodes[k].id] = static_cast<int32_t>(k);}
   s->n_dead = 0;
+  s->n_dead_nodes = 0;
 }
 
 static void bury_constraint(kh_spa * s, int32_t k)
@@ -780,6 +788,10 @@ int kh_spa_set_sharding(kh_spa * s, int32_t rank, int32_t world, kh_allreduce_fn
 int kh_spa_set_comm(kh_spa * s, kh_comm * comm)
 {
   if (!s) {return KH_ERR_INVALID_ARG;}
+  if (comm && kh_comm_device(comm) != s->device) {
+    set_error("kh_spa_set_comm: the communicator lives on another device than the solver");
+    return KH_ERR_INVALID_ARG;
+  }
   s->comm = comm; s->allreduce = nullptr; s->allreduce_user = nullptr;
   s->shard_rank = comm ? kh_comm_rank(comm) : 0;
   s->shard_world = comm ? kh_comm_world(comm) : 1;
@@ -789,7 +801,7 @@ int kh_spa_set_comm(kh_spa * s, kh_comm * comm)
 int kh_spa_reset(kh_spa * s)     // ceres_solver.cpp:279-314
 {
   if (!s) {return KH_ERR_INVALID_ARG;}
-  s->nodes.clear(); s->index_of.clear(); s->cons.clear(); s->con_of.clear(); s->n_dead = 0;
+  s->nodes.clear(); s->index_of.clear(); s->cons.clear(); s->con_of.clear(); s->incident.clear(); s->n_dead = 0; s->n_dead_nodes = 0;
   s->corr_ids.clear(); s->corr_poses.clear();
   s->has_first = false; s->was_constant_set = false; s->topology_dirty = true; s->fixed_index = -1;
   return KH_OK;
@@ -809,7 +821,9 @@ int kh_spa_add_node(kh_spa * s, int32_t id, const double pose[3])    // ceres_so
   Node n; n.id = id; std::copy(pose, pose + 3, n.pose);
   s->index_of[id] = static_cast<int32_t>(s->nodes.size());
   s->nodes.push_back(n);
-  if (s->nodes.size() == 1) {s->first_id = id; s->has_first = true;}
+  // the reference sets first_node_ whenever nodes_->size() == 1 after the insert (ceres_solver.cpp:331-334); tombstoned
+  // nodes are already gone from its map, so they do not count here either
+  if (static_cast<int32_t>(s->nodes.size()) - s->n_dead_nodes == 1) {s->first_id = id; s->has_first = true;}
   s->topology_dirty = true;
   return KH_OK;
 }
@@ -829,6 +843,8 @@ static int add_constraint_information(kh_spa * s, int32_t id_a, int32_t id_b, co
     return KH_ERR_INVALID_ARG;
   }
   s->con_of.insert({kh_spa::edge_key(id_a, id_b), static_cast<int32_t>(s->cons.size())});
+  s->incident[id_a].push_back(static_cast<int32_t>(s->cons.size()));
+  s->incident[id_b].push_back(static_cast<int32_t>(s->cons.size()));
   s->cons.push_back(c);
   s->topology_dirty = true;
   return KH_OK;
@@ -1092,11 +1108,14 @@ int kh_spa_remove_node(kh_spa * s, int32_t id)     // ceres_solver.cpp:395-427 (
   if (!s) {return KH_ERR_INVALID_ARG;}
   auto it = s->index_of.find(id);
   if (it == s->index_of.end()) {set_error("RemoveNode: Failed to find node matching id"); return KH_ERR_NOT_FOUND;}
-  for (size_t k = 0; k < s->cons.size(); ++k) {
-    if (!s->cons[k].dead && (s->cons[k].a == id || s->cons[k].b == id)) {bury_constraint(s, static_cast<int32_t>(k));}
+  auto inc = s->incident.find(id);                     // O(degree): the node's own constraint list
+  if (inc != s->incident.end()) {
+    for (int32_t k : inc->second) {bury_constraint(s, k);}
+    s->incident.erase(inc);
   }
   s->nodes[it->second].dead = 1;
   ++s->n_dead;
+  ++s->n_dead_nodes;
   // ceres_solver.cpp:395-427 erases the node and its parameter blocks; first_node_ keeps pointing at the erased entry
   // there (never dereferenced again once the blocks were set constant).  Here the gauge simply ends with the node: no
   // later node takes it over, and the pose-graph files stop naming it.

@@ -45,3 +45,25 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "karto_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(kartohip_lib):
+    """A box without librccl: kh_comm_unique_id reports KH_ERR_NO_DEVICE with the loader's message (the message used to
+    be fetched with two dlerror() calls, the second of which returns NULL -> std::string(NULL))."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from slam_toolbox_amd import capi\n"
+        "L = capi.lib()\n"
+        "buf = np.zeros(128, dtype=np.uint8)\n"
+        "rc = L.kh_comm_unique_id(buf)\n"
+        "assert rc == capi.KH_ERR_NO_DEVICE, rc\n"
+        "assert b'librccl not found' in L.kh_last_error(), L.kh_last_error()\n"
+        "rc = L.kh_comm_unique_id(buf)\n"
+        "assert rc == capi.KH_ERR_NO_DEVICE, rc\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, KH_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
