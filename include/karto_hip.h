@@ -232,9 +232,15 @@ typedef struct kh_spa_summary {
   double backward_gpu_ms;       /* backward sweeps + step evaluation */
   double linearize_gpu_ms;      /* edge linearisation + gathers of H and g (every evaluation point) */
   double symbolic_ms;           /* host: pattern + ordering + symbolic factorisation + uploads (0 when the topology was cached) */
+  double worst_linear_residual; /* KH_SPA_CHECK=1 only (else 0): max over the iterations of |(Hs + D/radius) step + gs| / |gs|,
+                                   evaluated from the block-sparse matrix, independent of the factorisation */
 } kh_spa_summary;
 
 KH_API int kh_spa_create(int32_t device, kh_spa ** out);
+/* Test / measurement switches, 0 = none.  Bit 0: every LM iteration also evaluates the residual of its linear solve from
+ * the block-sparse matrix (kh_spa_summary.worst_linear_residual).  Bits 4-7: numeric factorisation kernels -- 0 default
+ * (3), 3 level pipeline potrf/trsm/syrk, 2 panel-pair kernels, 1 their first form; all give the same factor. */
+KH_API int kh_spa_set_debug(kh_spa * s, int32_t flags);
 /* Multi-GPU (one process per GPU, every rank holds the same graph): rank r linearises the edge block
  * [E*r/world, E*(r+1)/world) into PARTIAL normal equations, and `allreduce` -- supplied by the host
  * framework, e.g. RCCL through torch.distributed -- must sum `count` doubles at `device_buf` (H followed

@@ -58,7 +58,8 @@ class KhSpaSummary(C.Structure):
                 ("linearize_ms", C.c_double), ("solve_ms", C.c_double), ("total_ms", C.c_double),
                 ("nnz_factor", C.c_int64), ("factor_flops", C.c_int64), ("factorizations", C.c_int32),
                 ("levels", C.c_int32), ("factor_gpu_ms", C.c_double), ("backward_gpu_ms", C.c_double),
-                ("linearize_gpu_ms", C.c_double), ("symbolic_ms", C.c_double)]
+                ("linearize_gpu_ms", C.c_double), ("symbolic_ms", C.c_double),
+                ("worst_linear_residual", C.c_double)]
 
 
 # every symbol include/karto_hip.h declares (tests check that the built library exports all of them)
@@ -69,7 +70,7 @@ SYMBOLS = [
     "kh_matcher_grid_info", "kh_matcher_read_grid", "kh_matcher_read_kernel", "kh_matcher_read_lookup",
     "kh_matcher_positional_covariance", "kh_matcher_angular_covariance",
     "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile", "kh_matcher_score_loads",
-    "kh_spa_options_default", "kh_spa_create", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
+    "kh_spa_options_default", "kh_spa_create", "kh_spa_set_debug", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
     "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
@@ -183,6 +184,7 @@ def lib():
         L.kh_spa_create.argtypes = [i32, C.POINTER(vp)]
         L.kh_spa_destroy.argtypes = [vp]
         L.kh_spa_destroy.restype = None
+        L.kh_spa_set_debug.argtypes = [vp, i32]
         L.kh_spa_set_options.argtypes = [vp, C.POINTER(KhSpaOptions)]
         L.kh_spa_reset.argtypes = [vp]
         L.kh_spa_clear.argtypes = [vp]

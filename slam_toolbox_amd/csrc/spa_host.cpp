@@ -32,6 +32,7 @@
 
 #include "../../include/karto_hip.h"
 #include "spa_internal.hpp"
+#include "spa_symbolic.hpp"
 
 namespace kh
 {
@@ -51,20 +52,6 @@ void set_error(const std::string & s);
 // removed node)
 struct Node {int32_t id; double pose[3]; uint8_t dead = 0;};
 struct Constraint {int32_t a, b; double z[3]; double u[9]; double omega[6]; uint8_t dead = 0;};   // omega: upper triangle of the information
-
-struct Symbolic
-{
-  int32_t n_free = 0, n_fronts = 0;
-  std::vector<int32_t> elim_of_free, free_of_elim, sn_first, sn_of_elim;
-  std::vector<int32_t> rows_ptr, rows, parent, level;
-  std::vector<int64_t> front_off;
-  std::vector<int32_t> front_m, front_ns, front_first;
-  std::vector<int32_t> child_ptr, child_list, relpos_ptr, relpos;
-  std::vector<std::vector<int32_t>> levels;
-  int64_t fronts_size = 0;
-  int64_t nnz_factor = 0;
-  int64_t factor_flops = 0;      // sum over the fronts of sum_{j < ns} (m - j)^2
-};
 
 template <class T>
 struct DevBuf
@@ -130,7 +117,9 @@ struct kh_spa
     d_bsr_row_ptr, d_bsr_col, d_bsr_diag, d_node_contrib_ptr, d_node_contrib, d_front_m, d_front_ns,
     d_front_first, d_rows_ptr, d_rows, d_child_ptr, d_child_list, d_relpos_ptr, d_relpos, d_slot_ld,
     d_elim_of_free, d_free_of_elim, d_level_fronts, d_fail, d_sync;
-  DevBuf<int64_t> d_front_off, d_slot_dest;
+  DevBuf<int64_t> d_front_off, d_slot_dest, d_winv_off;
+  DevBuf<double> d_winv;                       // L11^-T of every front (level pipeline, round 3)
+  DevBuf<FrontDesc> d_desc;
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
@@ -147,6 +136,7 @@ struct kh_spa
   hipEvent_t ev_phase[kMaxTimed][4] = {};     // factor begin, factor end = backward begin, backward end, (spare)
   hipEvent_t ev_lin[2 * kMaxTimed + 2][2] = {};
   double last_symbolic_ms = 0.0;
+  int32_t debug_flags = 0;                     // kh_spa_set_debug
 };
 
 // drops the tombstones; positions in `nodes` / `cons` and both maps are final again afterwards.  Every entry point that
@@ -236,233 +226,6 @@ static double karto_normalize_angle(double angle)   // Math.h:181-202
     if (angle > two_pi) {angle -= static_cast<uint32_t>(angle / two_pi) * two_pi;} else {angle -= two_pi;}
   }
   return angle;
-}
-
-// ---- symbolic analysis -------------------------------------------------------------------------
-// Nested dissection on the graph itself (George's level-structure bisection): BFS from a
-// pseudo-peripheral node, the middle level (trimmed to the vertices that really touch the far side) is
-// the separator.  Purely topological, so it does not depend on how far the current pose estimates have
-// drifted.  Leaves and separators become the supernodes of the multifrontal factorisation.
-struct NdContext
-{
-  // adjacency in CSR form (contiguous: the three BFS passes per subset are the cost of the ordering)
-  std::vector<int32_t> adj_ptr, adj_idx;
-  std::vector<int32_t> tag;           // subset membership stamp
-  std::vector<int32_t> dist;          // BFS level
-  std::atomic<int32_t> stamp{0};      // sibling subsets are dissected concurrently on disjoint vertices
-  int32_t leaf = 12;
-  int32_t parallel_depth = 3;         // recursion levels whose two halves run on separate threads
-};
-using SupernodeList = std::vector<std::vector<int32_t>>;
-
-// BFS inside the subset stamped `st`; returns the visit order (levels in ctx.dist)
-static void nd_bfs(NdContext & ctx, int32_t start, int32_t st, std::vector<int32_t> & order)
-{
-  order.clear();
-  order.push_back(start);
-  ctx.dist[start] = 0;
-  ctx.tag[start] = -st;               // visited marker
-  for (size_t h = 0; h < order.size(); ++h) {
-    const int32_t v = order[h];
-    const int32_t dv = ctx.dist[v] + 1;
-    for (int32_t k = ctx.adj_ptr[v]; k < ctx.adj_ptr[v + 1]; ++k) {
-      const int32_t w = ctx.adj_idx[k];
-      if (ctx.tag[w] == st) {ctx.tag[w] = -st; ctx.dist[w] = dv; order.push_back(w);}
-    }
-  }
-  for (int32_t v : order) {ctx.tag[v] = st;}
-}
-
-// appends the supernodes of `nodes` to `out` in elimination order (A's, B's, then the separator)
-static void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & out, int depth)
-{
-  if (nodes.empty()) {return;}
-  if (static_cast<int32_t>(nodes.size()) <= ctx.leaf) {
-    std::sort(nodes.begin(), nodes.end());
-    out.push_back(nodes);
-    return;
-  }
-  const int32_t st = ++ctx.stamp;
-  for (int32_t v : nodes) {ctx.tag[v] = st;}
-  std::vector<int32_t> order;
-  order.reserve(nodes.size());
-  nd_bfs(ctx, nodes[0], st, order);
-  auto both = [&](std::vector<int32_t> & A, std::vector<int32_t> & B) {
-    if (depth < ctx.parallel_depth && A.size() > 256 && B.size() > 256) {
-      SupernodeList out_b;
-      std::thread tb([&] {nd_recurse(ctx, B, out_b, depth + 1);});
-      nd_recurse(ctx, A, out, depth + 1);
-      tb.join();
-      for (auto & sn : out_b) {out.push_back(std::move(sn));}
-    } else {
-      nd_recurse(ctx, A, out, depth + 1);
-      nd_recurse(ctx, B, out, depth + 1);
-    }
-  };
-  if (order.size() < nodes.size()) {
-    // disconnected subset: split off this component, recurse on both parts (independent subtrees)
-    std::vector<int32_t> comp = order, rest;
-    for (int32_t v : comp) {ctx.tag[v] = 0;}
-    for (int32_t v : nodes) {if (ctx.tag[v] == st) {rest.push_back(v);}}
-    both(comp, rest);
-    return;
-  }
-  // pseudo-peripheral start: restart the BFS from the farthest vertex
-  {
-    const int32_t far = order.back();
-    nd_bfs(ctx, far, st, order);
-  }
-  const int32_t depth_bfs = ctx.dist[order.back()];
-  if (depth_bfs < 2) {                // clique-like: no level can separate anything
-    std::sort(nodes.begin(), nodes.end());
-    out.push_back(nodes);
-    return;
-  }
-  std::vector<int32_t> level_count(depth_bfs + 1, 0);
-  for (int32_t v : order) {level_count[ctx.dist[v]]++;}
-  // separator level: the smallest level among those that leave 25%..75% of the vertices on the near
-  // side; if the level structure is too coarse for that, the level closest to the median
-  const double total = static_cast<double>(order.size());
-  int32_t best = -1, fallback = 1; double best_count = 1e300, fallback_dist = 1e300; int32_t below = 0;
-  for (int32_t l = 1; l < depth_bfs; ++l) {
-    below += level_count[l - 1];
-    const double mid = (below + 0.5 * level_count[l]) / total;
-    if (std::fabs(mid - 0.5) < fallback_dist) {fallback_dist = std::fabs(mid - 0.5); fallback = l;}
-    if (mid >= 0.25 && mid <= 0.75 && level_count[l] < best_count) {best_count = level_count[l]; best = l;}
-  }
-  if (best < 0) {best = fallback;}
-  std::vector<int32_t> A, B, S;
-  for (int32_t v : order) {
-    const int32_t d = ctx.dist[v];
-    if (d < best) {A.push_back(v);} else if (d > best) {B.push_back(v);} else {
-      bool touches_far = false;
-      for (int32_t k = ctx.adj_ptr[v]; k < ctx.adj_ptr[v + 1]; ++k) {
-        const int32_t w = ctx.adj_idx[k];
-        if (ctx.tag[w] == st && ctx.dist[w] == best + 1) {touches_far = true; break;}
-      }
-      if (touches_far) {S.push_back(v);} else {A.push_back(v);}
-    }
-  }
-  if (S.empty() || A.empty() || B.empty()) {
-    std::sort(nodes.begin(), nodes.end());
-    out.push_back(nodes);
-    return;
-  }
-  both(A, B);
-  std::sort(S.begin(), S.end());
-  out.push_back(S);
-}
-
-// adjacency of the free nodes in CSR form: neighbours of i = adj_idx[adj_ptr[i] .. adj_ptr[i + 1]), ascending
-static int build_symbolic(
-  Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx)
-{
-  sym = Symbolic();
-  sym.n_free = n_free;
-  NdContext ctx;
-  ctx.adj_ptr = adj_ptr;
-  ctx.adj_idx = adj_idx;
-  ctx.tag.assign(n_free, 0);
-  ctx.dist.assign(n_free, 0);
-  std::vector<int32_t> all(n_free);
-  for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
-  SupernodeList supernodes;
-  nd_recurse(ctx, all, supernodes, 0);
-  const int32_t K = static_cast<int32_t>(supernodes.size());
-  sym.n_fronts = K;
-  sym.elim_of_free.assign(n_free, -1);
-  sym.free_of_elim.assign(n_free, -1);
-  sym.sn_first.assign(K + 1, 0);
-  sym.sn_of_elim.assign(n_free, -1);
-  int32_t pos = 0;
-  for (int32_t k = 0; k < K; ++k) {
-    sym.sn_first[k] = pos;
-    for (int32_t v : supernodes[k]) {
-      sym.elim_of_free[v] = pos; sym.free_of_elim[pos] = v; sym.sn_of_elim[pos] = k; ++pos;
-    }
-  }
-  sym.sn_first[K] = pos;
-  if (pos != n_free) {set_error("nested dissection lost nodes"); return KH_ERR_SOLVER;}
-
-  // struct rows, parents, children
-  std::vector<std::vector<int32_t>> rows(K), children(K);
-  std::vector<int32_t> stamp(n_free, -1);
-  sym.parent.assign(K, -1);
-  for (int32_t k = 0; k < K; ++k) {
-    const int32_t end = sym.sn_first[k + 1];
-    std::vector<int32_t> & r = rows[k];
-    for (int32_t e = sym.sn_first[k]; e < end; ++e) {
-      const int32_t v = sym.free_of_elim[e];
-      for (int32_t q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) {
-        const int32_t ew = sym.elim_of_free[adj_idx[q]];
-        if (ew >= end && stamp[ew] != k) {stamp[ew] = k; r.push_back(ew);}
-      }
-    }
-    for (int32_t c : children[k]) {
-      for (int32_t ew : rows[c]) {
-        if (ew >= end && stamp[ew] != k) {stamp[ew] = k; r.push_back(ew);}
-      }
-    }
-    std::sort(r.begin(), r.end());
-    if (!r.empty()) {
-      sym.parent[k] = sym.sn_of_elim[r[0]];
-      children[sym.parent[k]].push_back(k);
-    }
-  }
-  sym.rows_ptr.assign(K + 1, 0);
-  sym.child_ptr.assign(K + 1, 0);
-  sym.relpos_ptr.assign(K + 1, 0);
-  sym.level.assign(K, 0);
-  sym.front_off.assign(K, 0); sym.front_m.assign(K, 0); sym.front_ns.assign(K, 0); sym.front_first.assign(K, 0);
-  int64_t off = 0;
-  int32_t max_level = 0;
-  for (int32_t k = 0; k < K; ++k) {
-    sym.rows_ptr[k + 1] = sym.rows_ptr[k] + static_cast<int32_t>(rows[k].size());
-    sym.child_ptr[k + 1] = sym.child_ptr[k] + static_cast<int32_t>(children[k].size());
-    sym.relpos_ptr[k + 1] = sym.relpos_ptr[k] + static_cast<int32_t>(rows[k].size());
-    const int32_t ncols = sym.sn_first[k + 1] - sym.sn_first[k];
-    sym.front_ns[k] = 3 * ncols;
-    sym.front_m[k] = 3 * (ncols + static_cast<int32_t>(rows[k].size()));
-    sym.front_first[k] = sym.sn_first[k];
-    sym.front_off[k] = off;
-    off += static_cast<int64_t>(sym.front_m[k]) * sym.front_m[k];
-    sym.nnz_factor += static_cast<int64_t>(sym.front_ns[k]) * (sym.front_ns[k] + 1) / 2 +
-      static_cast<int64_t>(sym.front_ns[k]) * (sym.front_m[k] - sym.front_ns[k]);
-    for (int32_t j = 0; j < sym.front_ns[k]; ++j) {
-      sym.factor_flops += static_cast<int64_t>(sym.front_m[k] - j) * (sym.front_m[k] - j);
-    }
-    for (int32_t c : children[k]) {sym.level[k] = std::max(sym.level[k], sym.level[c] + 1);}
-    max_level = std::max(max_level, sym.level[k]);
-    if (sym.front_m[k] > 8000) {set_error("front too large for the triangular-solve kernels (m > 8000)"); return KH_ERR_SOLVER;}
-  }
-  sym.fronts_size = off;
-  sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);
-  for (int32_t k = 0; k < K; ++k) {
-    sym.rows.insert(sym.rows.end(), rows[k].begin(), rows[k].end());
-    sym.child_list.insert(sym.child_list.end(), children[k].begin(), children[k].end());
-    const int32_t p = sym.parent[k];
-    if (p < 0) {continue;}
-    const int32_t pcols = sym.sn_first[p + 1] - sym.sn_first[p];
-    for (size_t q = 0; q < rows[k].size(); ++q) {
-      const int32_t r = rows[k][q];
-      int32_t at;
-      if (r < sym.sn_first[p + 1]) {
-        at = r - sym.sn_first[p];
-      } else {
-        auto it = std::lower_bound(rows[p].begin(), rows[p].end(), r);
-        if (it == rows[p].end() || *it != r) {set_error("symbolic: child row missing in parent front"); return KH_ERR_SOLVER;}
-        at = pcols + static_cast<int32_t>(it - rows[p].begin());
-      }
-      sym.relpos[sym.relpos_ptr[k] + q] = at;
-    }
-  }
-  sym.levels.assign(max_level + 1, {});
-  for (int32_t k = 0; k < K; ++k) {sym.levels[sym.level[k]].push_back(k);}
-  // largest fronts first: they are the critical path of their level, so they should be dispatched first
-  for (auto & lv : sym.levels) {
-    std::stable_sort(lv.begin(), lv.end(), [&](int32_t a, int32_t b) {return sym.front_m[a] > sym.front_m[b];});
-  }
-  return KH_OK;
 }
 
 // ---- problem setup on the device -----------------------------------------------------------------
@@ -581,7 +344,11 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     }
     // ordering + fronts
     const auto t_sym0 = std::chrono::steady_clock::now();
-    int rc = build_symbolic(s->sym, nf, adj_ptr, adj_idx);
+    SymbolicOptions sopt;
+    if (const char * e = std::getenv("KH_SPA_LEAF")) {sopt.leaf_nodes = std::max(1, std::atoi(e));}
+    if (const char * e = std::getenv("KH_SPA_PMAX")) {sopt.max_pivot_nodes = std::min(42, std::max(1, std::atoi(e)));}
+    if (const char * e = std::getenv("KH_SPA_CANDS")) {sopt.separator_candidates = std::max(1, std::atoi(e));}
+    int rc = build_symbolic(s->sym, nf, adj_ptr, adj_idx, sopt);
     if (rc) {return rc;}
     if (std::getenv("KH_SPA_DEBUG")) {
       std::fprintf(stderr, "[kh_spa] host: pattern %.2f ms, symbolic %.2f ms\n",
@@ -606,11 +373,11 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       const int32_t ei = sym.elim_of_free[slot_row[k]], ej = sym.elim_of_free[col[k]];
       if (ei < ej) {continue;}
       const int32_t f = sym.sn_of_elim[ej];
-      const int32_t ncols = sym.sn_first[f + 1] - sym.sn_first[f];
-      const int32_t colpos = ej - sym.sn_first[f];
+      const int32_t ncols = sym.front_ns[f] / 3;
+      const int32_t colpos = ej - sym.front_first[f];
       int32_t rowpos;
-      if (ei < sym.sn_first[f + 1]) {
-        rowpos = ei - sym.sn_first[f];
+      if (ei < sym.front_first[f] + ncols) {
+        rowpos = ei - sym.front_first[f];
       } else {
         const auto b = sym.rows.begin() + sym.rows_ptr[f], e2 = sym.rows.begin() + sym.rows_ptr[f + 1];
         auto it = std::lower_bound(b, e2, ei);
@@ -649,6 +416,17 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_slot_dest.upload(slot_dest, st); r2 |= s->d_slot_ld.upload(slot_ld, st);
     r2 |= s->d_elim_of_free.upload(sym.elim_of_free, st); r2 |= s->d_free_of_elim.upload(sym.free_of_elim, st);
     r2 |= s->d_level_fronts.upload(level_fronts, st);
+    r2 |= s->d_winv_off.upload(sym.winv_off, st);
+    std::vector<FrontDesc> desc(sym.n_fronts);
+    for (int32_t k = 0; k < sym.n_fronts; ++k) {
+      FrontDesc & fd = desc[k];
+      std::memset(&fd, 0, sizeof(fd));
+      fd.off = sym.front_off[k]; fd.woff = sym.winv_off[k]; fd.m = sym.front_m[k]; fd.ns = sym.front_ns[k]; fd.first = sym.front_first[k];
+      fd.rows_ptr = sym.rows_ptr[k]; fd.child_ptr = sym.child_ptr[k]; fd.child_end = sym.child_ptr[k + 1];
+      fd.relpos_ptr = sym.relpos_ptr[k]; fd.parent = sym.parent[k];
+    }
+    r2 |= s->d_desc.upload(desc, st);
+    r2 |= s->d_winv.ensure(static_cast<size_t>(sym.winv_size) + 16);
     if (r2) {return KH_ERR_HIP;}
     s->n_slots = n_slots;
     const size_t scratch = std::max<size_t>(static_cast<size_t>(21) * E, static_cast<size_t>(9) * nf + 16);
@@ -704,6 +482,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   dev.slot_dest = s->d_slot_dest.p; dev.slot_ld = s->d_slot_ld.p;
   dev.elim_of_free = s->d_elim_of_free.p; dev.free_of_elim = s->d_free_of_elim.p;
   dev.fronts = s->d_fronts.p; dev.fronts_size = sym.fronts_size;
+  dev.winv = s->d_winv.p; dev.winv_off = s->d_winv_off.p; dev.desc = s->d_desc.p;
   has_work = true;
   return KH_OK;
 }
@@ -759,7 +538,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_front_ns.release(); s->d_front_first.release(); s->d_rows_ptr.release(); s->d_rows.release();
   s->d_child_ptr.release(); s->d_child_list.release(); s->d_relpos_ptr.release(); s->d_relpos.release();
   s->d_slot_ld.release(); s->d_elim_of_free.release(); s->d_free_of_elim.release(); s->d_level_fronts.release();
-  s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_edge_z.release(); s->d_edge_u.release();
+  s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_winv_off.release(); s->d_winv.release(); s->d_desc.release(); s->d_edge_z.release(); s->d_edge_u.release();
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
   s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release(); s->d_Hg_alt.release(); s->d_best.release();
@@ -795,6 +574,13 @@ int kh_spa_set_comm(kh_spa * s, kh_comm * comm)
   s->comm = comm; s->allreduce = nullptr; s->allreduce_user = nullptr;
   s->shard_rank = comm ? kh_comm_rank(comm) : 0;
   s->shard_world = comm ? kh_comm_world(comm) : 1;
+  return KH_OK;
+}
+
+int kh_spa_set_debug(kh_spa * s, int32_t flags)
+{
+  if (!s) {return KH_ERR_INVALID_ARG;}
+  s->debug_flags = flags;
   return KH_OK;
 }
 
@@ -1353,21 +1139,41 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, st);
     KS_HIP(hipMemsetAsync(s->d_sync.p, 0, sizeof(int32_t) * 4 * static_cast<size_t>(sym.n_fronts), st));
     static const int ea_limit = std::getenv("KH_SPA_EXTEND_ADD") ? std::atoi(std::getenv("KH_SPA_EXTEND_ADD")) : 128;
+    // KH_SPA_FACTOR: 3 (default) the level pipeline potrf -> trsm -> syrk, 2 the panel-pair kernels of round 2, 1 their first form
+    static const int factor_env = std::getenv("KH_SPA_FACTOR") ? std::atoi(std::getenv("KH_SPA_FACTOR")) : 3;
+    const int factor_mode = ((s->debug_flags >> 4) & 15) ? ((s->debug_flags >> 4) & 15) : factor_env;
+    const bool pipeline = factor_mode >= 3 && spa_level_pipeline_fits(sym.max_m, sym.max_ns);
     for (int l = 0; l < n_levels; ++l) {
       const int32_t n_level = s->level_offsets[l + 1] - s->level_offsets[l];
+      const int32_t * lf = s->d_level_fronts.p + s->level_offsets[l];
+      if (pipeline) {
+        if (l > 0) {spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st);}
+        spa_launch_factor3_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
+        dbg("potrf+trsm+syrk", l);
+        continue;
+      }
       // narrow levels: the extend-add runs chip-wide in its own launch instead of on each front's single CU
       const bool split = l > 0 && n_level <= ea_limit;
-      if (split) {spa_launch_extend_add(dev, s->d_level_fronts.p + s->level_offsets[l], n_level, s->level_max_m[l], st);}
-      spa_launch_factor_level(dev, s->d_level_fronts.p + s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p,
+      if (split) {spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st);}
+      spa_launch_factor_level(dev, lf, n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p,
         s->d_rhs.p, s->d_upd.p, s->d_fsb.p, s->d_sync.p + 4 * s->level_offsets[l], split ? 1 : 0, st);
       dbg("factor+forward", l);
     }
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][1], st));}
     for (int l = n_levels - 1; l >= 0; --l) {
-      spa_launch_backward_level(dev, s->d_level_fronts.p + s->level_offsets[l], s->level_offsets[l + 1] - s->level_offsets[l], s->level_max_m[l], s->d_rhs.p, st);
+      const int32_t n_level = s->level_offsets[l + 1] - s->level_offsets[l];
+      const int32_t * lf = s->d_level_fronts.p + s->level_offsets[l];
+      if (pipeline) {
+        spa_launch_backward3_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_rhs.p, st);
+      } else {
+        spa_launch_backward_level(dev, lf, n_level, s->level_max_m[l], s->d_rhs.p, st);
+      }
       dbg("backward", l);
     }
     spa_launch_finish_step(dev, s->d_scale.p, s->d_rhs.p, s->d_step.p, s->d_delta.p, st);
+    static const bool lin_check_env = std::getenv("KH_SPA_CHECK") != nullptr;
+    const bool lin_check = lin_check_env || (s->debug_flags & 1);
+    if (lin_check) {spa_launch_lin_check(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, s->d_step.p, scal + 12, st);}
     spa_launch_model(dev, s->d_scale.p, s->d_step.p, scal + 3, st);
     spa_launch_plus(dev, x, s->d_delta.p, cand, scal + 6, st);
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
@@ -1381,6 +1187,11 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     KS_HIP(hipGetLastError());
     rc = fetch(); if (rc) {return finish(rc);}
     solve_ms += ms_since(t1);
+    if (lin_check) {
+      std::fprintf(stderr, "[kh_spa] iteration %d: relative residual of the linear solve %.3e (fail flag %d)\n", iteration,
+        std::sqrt(s->h_scal[12] / std::max(s->h_scal[13], 1e-300)), s->h_fail[0]);
+      sum.worst_linear_residual = std::max(sum.worst_linear_residual, std::sqrt(s->h_scal[12] / std::max(s->h_scal[13], 1e-300)));
+    }
     reuse_diagonal = true;
     const double step_dot_g = s->h_scal[3], step_H_step = s->h_scal[4], nonfinite = s->h_scal[5];
     const double step_norm = std::sqrt(s->h_scal[6]);

@@ -6,6 +6,22 @@
 namespace kh
 {
 
+// Everything a workgroup of the level pipeline needs to know about its front, in one 64-byte record (fronts are numbered
+// level by level, so a level's records are contiguous)
+struct alignas(16) FrontDesc
+{
+  int64_t off;             // offset (doubles) of the front in `fronts`
+  int64_t woff;            // offset (doubles) of its L11^-T block in `winv`
+  int32_t m, ns;           // scalar dimension, scalar pivot columns
+  int32_t first;           // first elimination position (node units)
+  int32_t rows_ptr;        // struct rows in front_rows; also 3 * rows_ptr = its slot in upd
+  int32_t child_ptr, child_end;      // children in child_list
+  int32_t relpos_ptr;      // positions of its struct rows inside the parent front (node units) in relpos
+  int32_t parent;
+  int32_t pad[4];
+};
+static_assert(sizeof(FrontDesc) == 64, "FrontDesc is one 64-byte record");
+
 // Device view of one linear-algebra problem instance.  All pointers are device pointers.
 struct SpaDev
 {
@@ -53,6 +69,10 @@ struct SpaDev
   const int32_t * free_of_elim;
   double * fronts;
   int64_t fronts_size;
+  // round 3: L11^-T of every front (nsp x nsp, nsp = ns rounded up to 16; row q holds (L11^-T)[q][:], zeros left of the diagonal)
+  double * winv;
+  const int64_t * winv_off;
+  const FrontDesc * desc;
 };
 
 // [e_lo, e_hi): edge block linearised by this rank (0, n_edges on a single GPU)
@@ -73,11 +93,22 @@ void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int
 void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream);
 // upd: per-front forward-solve contributions to the ancestors, 3 * front_rows_ptr[n_fronts] doubles
 void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, void * stream);
+// round-3 level pipeline (potrf -> trsm -> syrk, see spa_kernels.hip): the children's update matrices must already be summed
+// into the fronts (spa_launch_extend_add); also does the forward solve of the level like spa_launch_factor_level
+// (the level = fronts first_front .. first_front + n - 1)
+void spa_launch_factor3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
+                              double * rhs, double * upd, void * stream);
+void spa_launch_backward3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, void * stream);
+// whether the largest front of a problem fits the LDS budgets of the level pipeline (otherwise: panel-pair kernels)
+bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns);
 // rhs (elimination order) <- scale * g ; and back: step = -y (free order), delta = step * scale
 void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, void * stream);
 void spa_launch_finish_step(const SpaDev & d, const double * scale, const double * rhs, double * step, double * delta, void * stream);
 // out[0] = step.gs, out[1] = step^T Hs step, out[2] = any non-finite in step
 void spa_launch_model(const SpaDev & d, const double * scale, const double * step, double * out3, void * stream);
+// debugging aid (KH_SPA_CHECK): out[0] = |(Hs + D / radius) step + gs|^2, out[1] = |gs|^2 from the BSR matrix
+void spa_launch_lin_check(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, const double * step, double * out2,
+                          void * stream);
 // cand = Plus(x, delta); out[0] = |x - cand|^2 over free params, out[1] = |cand|^2 over free params
 void spa_launch_plus(const SpaDev & d, const double * x, const double * delta, double * cand, double * out2, void * stream);
 // projected-gradient norms: out[0] = max |x - Plus(x, -g)|, out[1] = |x_free|^2

@@ -290,6 +290,41 @@ __global__ void k_plus(SpaDev d, const double * x, const double * delta, double 
   }
   cand[3 * n] = px; cand[3 * n + 1] = py; cand[3 * n + 2] = pt;
 }
+// KH_SPA_CHECK=1 (debugging aid): the linear system of this iteration, (Hs + D / radius) step + gs = 0 in the scaled
+// variables, evaluated with the BSR matrix -- independent of the fronts.  out[0] = |residual|^2, out[1] = |gs|^2.
+__global__ __launch_bounds__(1024) void k_lin_check(SpaDev d, const double * scale, const double * diagonal, double inv_radius,
+                                                     const double * step, double * out2)
+{
+  __shared__ double s0[1024];
+  __shared__ double s1[1024];
+  double a0 = 0.0, a1 = 0.0;
+  const int n3 = d.n_free * 3;
+  for (int t = threadIdx.x; t < n3; t += 1024) {
+    const int i = t / 3, r = t - i * 3;
+    double acc = 0.0;
+    for (int k = d.bsr_row_ptr[i]; k < d.bsr_row_ptr[i + 1]; ++k) {
+      const int j = d.bsr_col[k];
+      const double * blk = d.H + (size_t)k * 9 + r * 3;
+      acc += blk[0] * scale[3 * j] * step[3 * j] + blk[1] * scale[3 * j + 1] * step[3 * j + 1] + blk[2] * scale[3 * j + 2] * step[3 * j + 2];
+    }
+    const double gs = scale[t] * d.g[t];
+    const double res = scale[t] * acc + diagonal[t] * inv_radius * step[t] + gs;
+    a0 += res * res; a1 += gs * gs;
+  }
+  s0[threadIdx.x] = a0; s1[threadIdx.x] = a1;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {s0[threadIdx.x] += s0[threadIdx.x + w]; s1[threadIdx.x] += s1[threadIdx.x + w];}
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {out2[0] = s0[0]; out2[1] = s1[0];}
+}
+void spa_launch_lin_check(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, const double * step, double * out2,
+                          void * stream)
+{
+  hipLaunchKernelGGL(k_lin_check, dim3(1), dim3(1024), 0, (hipStream_t)stream, d, scale, diagonal, inv_radius, step, out2);
+}
+
 void spa_launch_plus(const SpaDev & d, const double * x, const double * delta, double * cand, double * out2, void * stream)
 {
   hipStream_t s = (hipStream_t)stream;
@@ -522,8 +557,9 @@ __device__ __forceinline__ void trailing_update(double * F, const double * Xs, i
 // where most of the chip idles.  A child's struct rows map to INCREASING positions in the parent (both are in
 // elimination order), so the child columns that land in this workgroup's destination block are one contiguous range;
 // every entry of the block is summed by this workgroup alone, children in turn: no atomics, the same order every run.
-__global__ __launch_bounds__(256) void k_extend_add(SpaDev d, const int32_t * __restrict__ level_fronts)
+__global__ __launch_bounds__(1024) void k_extend_add(SpaDev d, const int32_t * __restrict__ level_fronts)
 {
+  const int nw = (int)blockDim.x >> 6;
   const int k = level_fronts[blockIdx.x];
   const int m = d.front_m[k];
   const int c_lo = 16 * (int)blockIdx.y, c_hi = min(m, c_lo + 16);
@@ -563,7 +599,7 @@ __global__ __launch_bounds__(256) void k_extend_add(SpaDev d, const int32_t * __
     hi = nuc;
     while (lo < hi) {const int mid = (lo + hi) >> 1; if (pos(mid) < c_hi) {lo = mid + 1;} else {hi = mid;}}
     const int b_hi = lo;
-    for (int b = b_lo + wave; b < b_hi; b += 4) {
+    for (int b = b_lo + wave; b < b_hi; b += nw) {
       double * dst = F + (int64_t)pos(b) * m;
       const double * src = Uc + (int64_t)b * mc;
       for (int a0 = b; a0 < nuc; a0 += 256) {
@@ -589,7 +625,11 @@ __global__ __launch_bounds__(256) void k_extend_add(SpaDev d, const int32_t * __
 void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream)
 {
   if (n <= 0) {return;}
-  hipLaunchKernelGGL(k_extend_add, dim3(n, (max_m + 15) / 16), dim3(256), 0, (hipStream_t)stream, d, level_fronts);
+  // one wave per destination column of the block of 16 (with four waves a workgroup walked its columns four at a time, each
+  // walk a round trip to memory); wide levels keep the small workgroups
+  static const int ea_threads = std::getenv("KH_SPA_EA_THREADS") ? std::atoi(std::getenv("KH_SPA_EA_THREADS")) : 0;
+  const int threads = ea_threads ? ea_threads : ((int64_t)n * ((max_m + 15) / 16) > 512 ? 256 : 1024);
+  hipLaunchKernelGGL(k_extend_add, dim3(n, (max_m + 15) / 16), dim3(threads), 0, (hipStream_t)stream, d, level_fronts);
 }
 
 // ---- workgroup-level hand-offs between the workgroups that share one front (agent scope: the L1 of a CU is never
@@ -1390,6 +1430,625 @@ void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, i
 {
   if (n <= 0) {return;}
   hipLaunchKernelGGL(k_backward, dim3(n), dim3(1024), sizeof(double) * max_m, (hipStream_t)stream, d, level_fronts, rhs);
+}
+
+
+// =============================================================================================
+// K6, round 3: the level pipeline  potrf -> trsm -> syrk  (one launch each per level of the assembly tree).
+//
+// The panel-pair kernels above keep a front on ONE compute unit from its first pivot to its last: the pivot chain, the
+// row solves and the K = 32 updates of all its panel pairs run back to back, and on the upper levels of the tree -- a
+// handful of fronts with 100+ pivots and 300-400 rows each -- 250 of the 256 CUs idle while those few grind through 6-7
+// pairs (rocprof, round 2: 34 k_factor2 + 24 k_update2 launches = 1.8 ms per factorisation at 0.5 TFLOP/s).  The only
+// inherently serial part of a front is the Cholesky of its ns x ns pivot block; everything else is matrix products:
+//   potrf  one workgroup per front: F11 = L11 L11^T inside LDS (ns <= 128: the symbolic analysis splits larger
+//          supernodes into chains), and in the SAME sweep W = L11^-T: the identity rides along as extra rows of the panel
+//          (x L11^T = e_i, solved block column by block column like every other row), stored in the unused upper triangle
+//          of the LDS matrix.  The 16 x 16 inverse of a diagonal block comes out of its pivot chain the same way (the rows
+//          of the identity reuse the chain's own broadcasts), so every row solve of the panel is a 16 x 16 x 16 MFMA
+//          product instead of a substitution.  y1 = L11^-1 b1 (forward solve) is one product with W^T.
+//   trsm   L21 = F21 W, a plain GEMM over row slabs of every front of the level (chip-wide), fused with the forward-solve
+//          contribution  b2 -= L21 y1.
+//   syrk   F22 -= L21 L21^T over 32 x 32 / 64 x 64 tiles of every front of the level (chip-wide).
+// With W the backward solve of a level is two matrix-vector products (k_backward3) instead of a chain of 16 x 16
+// substitutions, each a memory latency long.  Fronts are numbered level by level, so a workgroup finds its front at
+// first_front + blockIdx.x and everything it needs to know about it in ONE 64-byte descriptor: on this problem size a
+// dependent global load is about a microsecond, and a chain of four index look-ups was a third of a small kernel's time.
+constexpr int kPotrfMaxNs = 128;
+constexpr int XDS = NB + 2;                // row stride of the 16 x 16 inverse of a diagonal block in LDS
+
+// 16 x 16 Cholesky in the registers of lanes 0..15 (lane = row) with the identity riding along: xr = row `lane` of the
+// identity on entry, row `lane` of L^-T on return (x L^T = e, right-looking: the L[c][j] a pivot broadcasts for the
+// trailing update of the block are exactly the factors the rows of the identity need).
+__device__ __forceinline__ bool diag_chain_inv(double (&row)[NB], double (&xr)[NB], int lane, double & rdiag)
+{
+  bool bad = false;
+  rdiag = 1.0;
+  const int l16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double djj = row_bcast(row[j], j);
+    if (!(djj > 0.0)) {bad = true; djj = 1.0;}
+    double r = __builtin_amdgcn_rsq(djj);
+    const double h = 0.5 * djj;
+    r = r * (1.5 - h * r * r);
+    r = r * (1.5 - h * r * r);
+    row[j] = (l16 == j) ? djj * r : row[j] * r;
+    if (l16 == j) {rdiag = r;}
+    xr[j] *= r;
+#pragma unroll
+    for (int c = j + 1; c < NB; ++c) {
+      const double lcj = row_bcast(row[j], c);          // L[c][j]
+      row[c] -= row[j] * lcj;
+      xr[c] -= xr[j] * lcj;
+    }
+  }
+  return bad;
+}
+
+// Diagonal block `blk` of the LDS matrix (row stride LD): L over its lower part, the strictly upper part of L^-T over its
+// strictly upper part, all of L^-T to xd (16 x XDS), the reciprocal pivots (= diagonal of L^-T) to rdv
+__device__ __forceinline__ bool potrf_diag(double * blk, int LD, int lane, double * xd, double * rdv)
+{
+  double row[NB], xr[NB];
+  const int l16 = lane & 15;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    row[c] = (lane < NB && c <= lane) ? blk[lane * LD + c] : ((lane >= NB && c == l16) ? 1.0 : 0.0);
+    xr[c] = c == l16 ? 1.0 : 0.0;
+  }
+  double rdiag;
+  const bool bad = diag_chain_inv(row, xr, lane, rdiag);
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      blk[lane * LD + c] = (c <= lane) ? row[c] : xr[c];
+      xd[lane * XDS + c] = xr[c];
+    }
+    rdv[lane] = rdiag;
+  }
+  return bad && lane < NB;
+}
+
+// row "solve" of one 16-row tile: T <- T Dinv^T  (Dinv^T = L_jj^-T in xd), in place, one wave
+__device__ __forceinline__ void potrf_rowsolve_tile(double * tile, int LD, const double * xd, int lane)
+{
+  const int lr = lane & 15, lk = lane >> 4;
+  const double * tb = tile + lr * LD + 4 * lk;         // b: T[lr][k]
+  const double * xa = xd + 4 * lk * XDS + lr;          // a: (L^-T)[k][lr]
+  double b[4], a[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {b[kk] = tb[kk]; a[kk] = xa[kk * XDS];}
+  v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);}
+  double * cp = tile + lr * LD + lk;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
+}
+
+// one 16 x 16 tile of the in-LDS update  C[rowI0.., colJ0..] -= B A^T  with A = rows colJ0.. of the matrix at columns
+// c0..c0+15 and B = 16 rows at `bsrc` (row stride bstride), K = 16
+__device__ __forceinline__ void potrf_tile(double * A, int LD, int rowI0, int colJ0, int c0, const double * bsrc, int bstride, int lane,
+                                           bool lower_only)
+{
+  const int lr = lane & 15, lk = lane >> 4;
+  double * cp = A + (rowI0 + lr) * LD + colJ0 + lk;
+  v4d acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {acc[r] = cp[4 * r];}
+  const double * xa = A + (colJ0 + lr) * LD + c0 + 4 * lk;
+  const double * xb = bsrc + lr * bstride + 4 * lk;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb[kk], acc, 0, 0, 0);}
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (!lower_only || lk + 4 * r <= lr) {cp[4 * r] = acc[r];}
+  }
+}
+
+#define PSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[1 + tcount++] = wall_clock64();} } while (0)
+
+__global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
+                                               long long * tbuf)
+{
+  int tcount = 0;
+  PSTAMP();
+  const FrontDesc fd = d.desc[first_front + blockIdx.x];
+  const int m = fd.m, ns = fd.ns;
+  const int nsp = (ns + NB - 1) & ~(NB - 1), nt = nsp >> 4, LD = nsp + 2;
+  double * F = d.fronts + fd.off;
+  double * W = d.winv + fd.woff;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  extern __shared__ double smem[];
+  double * A = smem;                                               // [nsp][LD]: lower = F11 -> L11, strictly upper = L11^-T
+  double * rd = smem + (size_t)lds_nsp * (lds_nsp + 2);            // [lds_nsp] reciprocal diagonal of L11 = diagonal of L11^-T
+  double * yv = rd + lds_nsp;                                      // [lds_nsp] y1
+  double * Xd = yv + lds_nsp;                                      // [2][16][XDS] L_jj^-T of the current / next panel
+  double * sb = Xd + 2 * NB * XDS;                                 // [m] the front's slice of the right-hand side
+  __shared__ int s_fail;
+  if (tid == 0) {s_fail = 0;}
+  // children's descriptors, all at once (fetched one after the other they are a chain of memory latencies per child)
+  constexpr int CB = 4;
+  FrontDesc cd[CB];
+  const int nchild = fd.child_end - fd.child_ptr;
+  const int self = first_front + (int)blockIdx.x;
+  auto load_children = [&](int cb) {
+    int cid[CB];
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {cid[q] = cb + q < nchild ? d.child_list[fd.child_ptr + cb + q] : self;}
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {cd[q] = d.desc[cid[q]];}
+  };
+  load_children(0);
+  // right-hand side: the pivots' entries + (below) the children's forward-solve contributions
+  const int first = 3 * fd.first;
+  for (int t = tid; t < m; t += nthreads) {sb[t] = t < ns ? rhs[first + t] : 0.0;}
+  // pivot block -> LDS, 16 x 16 tile by tile (256 threads = one entry per thread and tile): zeros in the tiles above the
+  // diagonal (the identity's off-diagonal part); the tiles of the lower triangle from the front, twelve loads in flight per
+  // thread (an entry that is not wanted reads F[0] instead, selected afterwards), with the identity on the padding
+  {
+    const int ti = tid & 15, tj = tid >> 4;
+    for (int I = 0; I < nt; ++I) {
+      for (int J = I + 1; J < nt; ++J) {A[(NB * I + ti) * LD + NB * J + tj] = 0.0;}
+    }
+    constexpr int LU = 12;
+    const int ntiles = nt * (nt + 1) / 2;
+    for (int t0 = 0; t0 < ntiles; t0 += LU) {
+      double v[LU];
+      int ii[LU], jj[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int t = min(t0 + u, ntiles - 1);
+        int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        I -= (I * (I + 1) / 2 > t) ? 1 : 0;
+        I += ((I + 1) * (I + 2) / 2 <= t) ? 1 : 0;
+        const int J = t - I * (I + 1) / 2;
+        ii[u] = NB * I + ti; jj[u] = NB * J + tj;
+        const bool want = ii[u] < ns && jj[u] <= ii[u];
+        v[u] = *(want ? F + ii[u] + (int64_t)jj[u] * m : F);
+      }
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        if (t0 + u < ntiles) {
+          const bool want = ii[u] < ns && jj[u] <= ii[u];
+          A[ii[u] * LD + jj[u]] = want ? v[u] : ((ii[u] == jj[u]) ? 1.0 : 0.0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  PSTAMP();
+  for (int cb = 0; cb < nchild; cb += CB) {
+    if (cb > 0) {load_children(cb);}
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      if (cb + q >= nchild) {break;}
+      const int nuc = cd[q].m - cd[q].ns;
+      const int32_t * rp = d.relpos + cd[q].relpos_ptr;
+      const double * uc = upd + 3 * (int64_t)cd[q].rows_ptr;
+      for (int a = tid; a < nuc; a += nthreads) {sb[3 * rp[a / 3] + a % 3] += uc[a];}
+      __syncthreads();
+    }
+  }
+  PSTAMP();
+  for (int jb = 0; jb < nt; ++jb) {
+    const int c0 = jb * NB;
+    double * xd = Xd + (jb & 1) * NB * XDS;
+    // Trailing update of panel jb - 1 inside LDS.  Tiles: (I, J) with I >= J >= jb of the pivot block, and (I, J) with
+    // I < jb <= J of the identity rows.  Wave 0 takes the diagonal tile of THIS panel first and factors it right away
+    // (look-ahead): the pivot chain runs beside the other waves' tiles.
+    if (jb > 0) {
+      const int p0 = c0 - NB;                         // first column of the previous panel
+      const double * xp = Xd + ((jb - 1) & 1) * NB * XDS;
+      const int nreg = (nt - jb) * (nt - jb + 1) / 2, napp = jb * (nt - jb);
+      auto do_tile = [&](int t) {
+        if (t < nreg) {
+          int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+          I -= (I * (I + 1) / 2 > t) ? 1 : 0;
+          I += ((I + 1) * (I + 2) / 2 <= t) ? 1 : 0;
+          const int J = t - I * (I + 1) / 2;
+          const int bi = jb + I, bj = jb + J;
+          potrf_tile(A, LD, NB * bi, NB * bj, p0, A + NB * bi * LD + p0, LD, lane, bi == bj);
+        } else {
+          const int q = t - nreg;
+          const int ie = q / (nt - jb), bj = jb + (q - ie * (nt - jb));
+          const bool cur = ie == jb - 1;
+          potrf_tile(A, LD, NB * ie, NB * bj, p0, cur ? xp : A + NB * ie * LD + p0, cur ? XDS : LD, lane, false);
+        }
+      };
+      if (wave == 0) {
+        do_tile(0);                          // t = 0 is (jb, jb)
+      } else {
+        for (int t = wave; t < nreg + napp; t += nwaves - 1) {do_tile(t);}
+      }
+    }
+    if (wave == 0) {
+      if (potrf_diag(A + c0 * LD + c0, LD, lane, xd, rd + c0)) {s_fail = 1;}
+    }
+    __syncthreads();                     // L_jj^-T of this panel is in xd, the updates of the previous panel are done
+    PSTAMP();
+    // row solves, one 16-row tile per wave: rows below the block (L21 part of F11) and the rows of the identity that
+    // started in earlier panels (tiles above the block, in the upper triangle); the block's own rows ARE xd
+    for (int t = wave; t < nt - 1; t += nwaves) {
+      const int bi = t < jb ? t : t + 1;
+      potrf_rowsolve_tile(A + NB * bi * LD + c0, LD, xd, lane);
+    }
+    __syncthreads();
+    PSTAMP();
+  }
+  // y1 = L11^-1 b1 = W^T b1: two threads per entry, each with half of the sum
+  {
+    const int j = tid >> 1, half = tid & 1;
+    double acc = 0.0;
+    if (j < ns) {
+      const int q0 = half ? (j + 1) >> 1 : 0, q1 = half ? j : (j + 1) >> 1;
+#pragma unroll 8
+      for (int q = q0; q < q1; ++q) {acc += A[q * LD + j] * sb[q];}
+      if (half) {acc += rd[j] * sb[j];}
+    }
+    acc += __shfl_xor(acc, 1);
+    if (j < ns && !half) {yv[j] = acc;}
+  }
+  // W to its own block (column-major Linv = row-major L^-T, zeros left of the diagonal).  L11 itself is not needed again:
+  // the row solves of the front (trsm) and both triangular solves use W.
+#pragma unroll 4
+  for (int idx = tid; idx < nsp * nsp; idx += nthreads) {
+    const int q = idx / nsp, j = idx - q * nsp;            // W[j + q * nsp] = (L^-T)[q][j]
+    W[idx] = j > q ? A[q * LD + j] : (j == q ? rd[q] : 0.0);
+  }
+  __syncthreads();
+  for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = yv[t];}
+  {
+    double * uk = upd + 3 * (int64_t)fd.rows_ptr;
+    for (int q = tid; q < m - ns; q += nthreads) {uk[q] = sb[ns + q];}
+  }
+  PSTAMP();
+  if (tbuf && blockIdx.x == 0 && threadIdx.x == 0) {tbuf[0] = tcount; tbuf[63] = ((long long)m << 32) | ns;}
+  if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
+}
+
+// rows [row0, row0 + R) x columns [0, nsp) of the panel columns of a front -> LDS rows of stride LD (zeros outside
+// nr rows / ns columns), sixteen loads in flight per thread
+template <int R>
+__device__ __forceinline__ void stage_rows(double * S, int LD, const double * Fcol0, int m, int nr, int ns, int nsp, int tid, int nthreads)
+{
+  constexpr int LU = 16;
+  for (int base = 0; base < R * nsp; base += LU * nthreads) {
+    double v[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int idx = base + u * nthreads + tid;
+      const int c = idx / R, i = idx - c * R;
+      const bool want = idx < R * nsp && i < nr && c < ns;
+      v[u] = *(want ? Fcol0 + i + (int64_t)c * m : Fcol0);
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int idx = base + u * nthreads + tid;
+      const int c = idx / R, i = idx - c * R;
+      if (idx < R * nsp) {S[i * LD + c] = (i < nr && c < ns) ? v[u] : 0.0;}
+    }
+  }
+}
+
+// L21 = F21 W for a slab of R rows of one front (grid: front x slab), then upd -= L21 y1.  A wave owns column blocks
+// of 16: the W entries of a block -- up to 128 k x 16 columns, 32 loads per lane -- are all requested before the first
+// MFMA (a loop over k blocks with its loads inside is a chain of L2 latencies), and serve the R / 16 row tiles of the slab.
+template <int R>
+__global__ __launch_bounds__(256) void k_trsm(SpaDev d, int first_front, const double * __restrict__ rhs, double * upd, int lds_nsp)
+{
+  const FrontDesc fd = d.desc[first_front + blockIdx.x];
+  const int m = fd.m, ns = fd.ns, nu = m - ns;
+  const int r0 = R * (int)blockIdx.y;
+  if (r0 >= nu) {return;}
+  const int nr = min(R, nu - r0);
+  const int nsp = (ns + NB - 1) & ~(NB - 1), nt = nsp >> 4, LD = nsp + 2;
+  double * F = d.fronts + fd.off;
+  const double * W = d.winv + fd.woff;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  extern __shared__ double smem[];
+  double * S = smem;                                         // [R][LD] the slab of F21
+  double * yv = smem + (size_t)R * (lds_nsp + 2);            // [lds_nsp] y1
+  double * red = yv + lds_nsp;                               // [4][R] per-wave partial sums of L21 y1
+  const int first = 3 * fd.first;
+  constexpr int RT = R / NB;
+  constexpr int NTMAX = kPotrfMaxNs / NB;
+  double * uk = upd + 3 * (int64_t)fd.rows_ptr;
+  const double uold = tid < nr ? uk[r0 + tid] : 0.0;
+  for (int j = tid; j < nsp; j += nthreads) {yv[j] = j < ns ? rhs[first + j] : 0.0;}
+  for (int j = tid; j < 4 * R; j += nthreads) {red[j] = 0.0;}
+  stage_rows<R>(S, LD, F + ns + r0, m, nr, ns, nsp, tid, nthreads);
+  __syncthreads();
+  double part[RT];
+#pragma unroll
+  for (int it = 0; it < RT; ++it) {part[it] = 0.0;}
+  for (int q = wave; q < nt; q += nwaves) {
+    const int J = (q & 1) ? nt - 1 - (q >> 1) : (q >> 1);      // long and short K ranges alternate
+    const double * wcol = W + (NB * J + lr);                   // (L^-T)[k][16 J + lr] = W[(16 J + lr) + k * nsp]
+    double a[NTMAX][4];
+#pragma unroll
+    for (int K = 0; K < NTMAX; ++K) {
+      const int Kc = K <= J ? K : 0;                           // always a valid address: no load under a branch
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {a[K][kk] = wcol[(int64_t)(NB * Kc + 4 * lk + kk) * nsp];}
+    }
+    v4d acc[RT];
+#pragma unroll
+    for (int it = 0; it < RT; ++it) {acc[it] = v4d{0.0, 0.0, 0.0, 0.0};}
+#pragma unroll
+    for (int K = 0; K < NTMAX; ++K) {
+      if (K <= J) {                                            // wave-uniform
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+          for (int it = 0; it < RT; ++it) {
+            acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[K][kk], S[(NB * it + lr) * LD + NB * K + 4 * lk + kk], acc[it], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // lane (lr, lk) holds L21[16 it + lr][16 J + lk + 4 r]
+#pragma unroll
+    for (int it = 0; it < RT; ++it) {
+      const int row = NB * it + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = NB * J + lk + 4 * r;
+        if (row < nr && col < ns) {F[(ns + r0 + row) + (int64_t)col * m] = acc[it][r];}
+        part[it] += acc[it][r] * yv[col];                      // yv is zero on the padding columns
+      }
+    }
+  }
+  // forward solve: upd[row] -= sum_j L21[row][j] y1[j]; the four lane groups and the waves add up in a fixed order
+#pragma unroll
+  for (int it = 0; it < RT; ++it) {
+    double p = part[it];
+    p += __shfl_xor(p, 16);
+    p += __shfl_xor(p, 32);
+    if (lk == 0) {red[wave * R + NB * it + lr] = p;}
+  }
+  __syncthreads();
+  if (tid < nr) {uk[r0 + tid] = uold - ((red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid]));}
+}
+
+// F22 -= L21 L21^T, one TS x TS tile of the lower triangle per workgroup (grid: front x tile).  TS = 64: eight waves,
+// each with a pair of 16 x 16 sub-tiles that share the row operand (two independent accumulators: the matrix pipe sees
+// back-to-back MFMAs while the next operands arrive from LDS); TS = 32: four waves, one sub-tile each.
+template <int TS>
+__global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int lds_nsp)
+{
+  const FrontDesc fd = d.desc[first_front + blockIdx.x];
+  const int m = fd.m, ns = fd.ns, nu = m - ns;
+  const int ntm = (nu + TS - 1) / TS;
+  const int t = blockIdx.y;
+  if (t >= ntm * (ntm + 1) / 2) {return;}
+  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  I -= (I * (I + 1) / 2 > t) ? 1 : 0;
+  I += ((I + 1) * (I + 2) / 2 <= t) ? 1 : 0;
+  const int J = t - I * (I + 1) / 2;
+  const int nsp = (ns + NB - 1) & ~(NB - 1), LD = nsp + 2;
+  double * F = d.fronts + fd.off;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  extern __shared__ double smem[];
+  double * XA = smem;                                               // rows of tile row I: [TS][LD]
+  double * XB = (I == J) ? XA : smem + (size_t)TS * (lds_nsp + 2);  // rows of tile column J
+  constexpr int UT = TS / 32;                  // sub-tiles per wave (side by side)
+  constexpr int PW = (TS / NB) / UT;           // waves per sub-tile row
+  const int si = wave / PW, sj0 = UT * (wave - si * PW);
+  // accumulators first: their loads fly while the panel rows are staged
+  v4d acc[UT];
+  bool live[UT];
+  const int row = TS * I + NB * si + lr;
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const int sj = sj0 + u;
+    live[u] = !(I == J && sj > si);
+    const int col0 = TS * J + NB * sj + lk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = col0 + 4 * r;
+      const bool ok = live[u] && row < nu && col <= row;
+      const double v = *(ok ? F + (ns + row) + (int64_t)(ns + col) * m : F);
+      acc[u][r] = ok ? v : 0.0;
+    }
+  }
+  stage_rows<TS>(XA, LD, F + ns + TS * I, m, min(TS, nu - TS * I), ns, nsp, tid, nthreads);
+  if (I != J) {stage_rows<TS>(XB, LD, F + ns + TS * J, m, min(TS, nu - TS * J), ns, nsp, tid, nthreads);}
+  __syncthreads();
+  if (live[0]) {
+    const double * xb = XA + (NB * si + lr) * LD + 4 * lk;
+    const double * xa0 = XB + (NB * sj0 + lr) * LD + 4 * lk;
+    if (UT == 2 && live[UT - 1]) {
+      const double * xa1 = xa0 + NB * LD;
+      for (int K = 0; K < nsp; K += NB) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double b = xb[K + kk];
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa0[K + kk], b, acc[0], 0, 0, 0);
+          acc[UT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa1[K + kk], b, acc[UT - 1], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int K = 0; K < nsp; K += NB) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa0[K + kk], xb[K + kk], acc[0], 0, 0, 0);}
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const int col0 = TS * J + NB * (sj0 + u) + lk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = col0 + 4 * r;
+      if (live[u] && row < nu && col <= row) {F[(ns + row) + (int64_t)(ns + col) * m] = acc[u][r];}
+    }
+  }
+}
+
+// Backward solve of a level with W = L11^-T:  x1 = W (y1 - L21^T x2), two sets of independent dot products.  A wave takes
+// sixteen columns; the entries of L21 and W it needs are requested right after the descriptor, together with y1 and the
+// gather of x2 (kept in registers for fronts of up to 64 * NI struct rows: one round of memory latency instead of four).
+__global__ __launch_bounds__(512) void k_backward3(SpaDev d, int first_front, double * rhs)
+{
+  const FrontDesc fd = d.desc[first_front + blockIdx.x];
+  const int m = fd.m, ns = fd.ns, nu = m - ns;
+  const int nsp = (ns + NB - 1) & ~(NB - 1);
+  const double * F = d.fronts + fd.off;
+  const double * W = d.winv + fd.woff;
+  const int first = 3 * fd.first;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+  extern __shared__ double sb[];                 // [m] : w (pivots) | x2 (struct rows), then [nsp] x1
+  double * xo = sb + m;
+  const int32_t * rows = d.front_rows + fd.rows_ptr;
+  constexpr int CW = 16;                         // columns per wave per pass (8 waves x 16 = every column of a front)
+  constexpr int NI = 5;                          // 64-row chunks of L21 held in registers
+  const int cb0 = CW * wave;
+  const bool fast = nu <= 64 * NI && ns <= CW * nwaves;
+  double l21[NI][CW];
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = min(lane + 64 * it, max(nu - 1, 0));
+#pragma unroll
+      for (int q = 0; q < CW; ++q) {
+        const int c = min(cb0 + q, ns - 1);
+        l21[it][q] = nu > 0 ? F[(ns + i) + (int64_t)c * m] : 0.0;
+      }
+    }
+  }
+  for (int t = tid; t < ns; t += nthreads) {sb[t] = rhs[first + t];}
+  for (int q = tid; q < nu; q += nthreads) {sb[ns + q] = rhs[3 * rows[q / 3] + q % 3];}
+  __syncthreads();
+  // w[c] = y1[c] - L21[:, c] . x2
+  for (int cbase = cb0; cbase < ns; cbase += CW * nwaves) {
+    double acc[CW];
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {acc[q] = 0.0;}
+    if (fast) {
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int i = lane + 64 * it;
+        const double x = i < nu ? sb[ns + i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {acc[q] += l21[it][q] * x;}
+      }
+    } else {
+      for (int i = lane; i < nu; i += 64) {
+        const double x = sb[ns + i];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+          const int c = min(cbase + q, ns - 1);
+          acc[q] += F[(ns + i) + (int64_t)c * m] * x;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) {acc[q] += __shfl_xor(acc[q], s);}
+      if (lane == 0 && cbase + q < ns) {sb[cbase + q] -= acc[q];}
+    }
+  }
+  __syncthreads();
+  // x1[c] = sum_{j >= c} (L^-T)[c][j] w[j],  (L^-T)[c][j] = W[j + c * nsp]  (zeros left of the diagonal)
+  for (int cbase = cb0; cbase < ns; cbase += CW * nwaves) {
+    double acc[CW];
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {acc[q] = 0.0;}
+    {
+      for (int j = cbase + lane; j < ns; j += 64) {
+        const double wj = sb[j];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+          const int c = min(cbase + q, ns - 1);
+          acc[q] += W[j + (int64_t)c * nsp] * wj;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CW; ++q) {
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) {acc[q] += __shfl_xor(acc[q], s);}
+      if (lane == 0 && cbase + q < ns) {xo[cbase + q] = acc[q];}
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = xo[t];}
+}
+
+static size_t potrf_lds_bytes(int nsp, int max_m)
+{
+  return sizeof(double) * ((size_t)nsp * (nsp + 2) + 2 * (size_t)nsp + 2 * NB * XDS + (size_t)max_m + 8);
+}
+
+bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns)
+{
+  const int nsp = (max_ns + NB - 1) & ~(NB - 1);
+  return max_ns <= kPotrfMaxNs && potrf_lds_bytes(nsp, max_m) <= 160 * 1024 - 256 && sizeof(double) * ((size_t)max_m + nsp + 8) <= 64 * 1024;
+}
+
+void spa_launch_factor3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
+                              double * rhs, double * upd, void * stream)
+{
+  if (n <= 0) {return;}
+  hipStream_t s = (hipStream_t)stream;
+  const int nsp = (max_ns + NB - 1) & ~(NB - 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int big = 160 * 1024 - 256;       // static LDS (a flag word) counts against the same 160 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsm<32>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsm<64>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_syrk<32>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_syrk<64>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  static long long * tbuf = nullptr;
+  static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
+  if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 64 * sizeof(long long), hipHostMallocDefault);}
+  hipLaunchKernelGGL(k_potrf, dim3(n), dim3(256), potrf_lds_bytes(nsp, max_m), s, d, first_front, fail_flag, rhs, upd, nsp,
+                     timing ? tbuf : (long long *)nullptr);
+  if (timing) {
+    (void)hipStreamSynchronize(s);
+    std::fprintf(stderr, "[k_potrf] n=%d front0 m=%lld ns=%lld stamps(x10ns):", n, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
+    for (int i = 1; i < (int)tbuf[0]; ++i) {std::fprintf(stderr, " %lld", tbuf[1 + i] - tbuf[i]);}
+    std::fprintf(stderr, "\n");
+  }
+  const int max_nu = max_m - 3;       // a front has at least one pivot node; an upper bound is enough for the grid
+  if (max_nu <= 0) {return;}
+  // slabs / tiles: small enough that a narrow level still spreads over the chip, large enough that a wide one does not
+  // drown in workgroups
+  static const int force_r = std::getenv("KH_SPA_TRSM_R") ? std::atoi(std::getenv("KH_SPA_TRSM_R")) : 0;
+  static const int force_ts = std::getenv("KH_SPA_SYRK_TS") ? std::atoi(std::getenv("KH_SPA_SYRK_TS")) : 0;
+  const int slabs32 = (max_nu + 31) / 32;
+  const bool r64 = force_r ? force_r == 64 : (int64_t)n * slabs32 >= 1024;
+  if (r64) {
+    hipLaunchKernelGGL(k_trsm<64>, dim3(n, (max_nu + 63) / 64), dim3(256), sizeof(double) * ((size_t)64 * (nsp + 2) + nsp + 4 * 64 + 8), s, d, first_front, rhs, upd, nsp);
+  } else {
+    hipLaunchKernelGGL(k_trsm<32>, dim3(n, slabs32), dim3(256), sizeof(double) * ((size_t)32 * (nsp + 2) + nsp + 4 * 32 + 8), s, d, first_front, rhs, upd, nsp);
+  }
+  const int nt32 = (max_nu + 31) / 32, nt64 = (max_nu + 63) / 64;
+  const bool t64 = force_ts ? force_ts == 64 : (int64_t)n * (nt32 * (nt32 + 1) / 2) >= 2048;
+  if (t64) {
+    hipLaunchKernelGGL(k_syrk<64>, dim3(n, nt64 * (nt64 + 1) / 2), dim3(512), sizeof(double) * ((size_t)2 * 64 * (nsp + 2) + 8), s, d, first_front, nsp);
+  } else {
+    hipLaunchKernelGGL(k_syrk<32>, dim3(n, nt32 * (nt32 + 1) / 2), dim3(256), sizeof(double) * ((size_t)2 * 32 * (nsp + 2) + 8), s, d, first_front, nsp);
+  }
+}
+
+void spa_launch_backward3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, void * stream)
+{
+  if (n <= 0) {return;}
+  const int nsp = (max_ns + NB - 1) & ~(NB - 1);
+  hipLaunchKernelGGL(k_backward3, dim3(n), dim3(max_ns <= 64 ? 256 : 512), sizeof(double) * ((size_t)max_m + nsp + 8), (hipStream_t)stream, d, first_front, rhs);
 }
 
 }  // namespace kh

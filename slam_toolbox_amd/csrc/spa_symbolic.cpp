@@ -1,0 +1,362 @@
+// Symbolic analysis of the pose-graph SPA solver: nested dissection, supernodes, assembly tree (see spa_symbolic.hpp).
+//
+// Ordering = nested dissection on the graph itself.  A subset is cut at a level of the breadth-first level structure
+// rooted at a pseudo-peripheral vertex (George): every edge of the subset joins equal or adjacent levels, so the edges
+// between level l - 1 and level l are an edge separator, and a MINIMUM VERTEX COVER of that bipartite edge set (Koenig:
+// from a maximum matching) is a vertex separator -- never larger than either boundary, on a pose graph typically 30-40 %
+// smaller than the whole level the first version of this solver removed.  The pose graph of a mapper that drives the same
+// aisles lap after lap is a thick chain (every cut has about the same width), so the separator size enters the
+// factorisation with its third power at every level of the tree.  Purely topological: independent of how far the pose
+// estimates have drifted.  Leaves and separators become the supernodes (= fronts) of the multifrontal factorisation.
+#include "spa_symbolic.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <thread>
+
+#include "../../include/karto_hip.h"
+
+namespace kh
+{
+void set_error(const std::string & s);
+
+namespace
+{
+
+struct NdContext
+{
+  const std::vector<int32_t> * adj_ptr = nullptr;
+  const std::vector<int32_t> * adj_idx = nullptr;
+  std::vector<int32_t> tag;           // subset membership stamp
+  std::vector<int32_t> dist;          // BFS level
+  std::vector<int32_t> loc;           // scratch: local index of a vertex inside the bipartite cut graph
+  std::atomic<int32_t> stamp{0};      // sibling subsets are dissected concurrently on disjoint vertices
+  SymbolicOptions opt;
+};
+using SupernodeList = std::vector<std::vector<int32_t>>;
+
+// BFS inside the subset stamped `st`; returns the visit order (sorted by level; levels in ctx.dist)
+void nd_bfs(NdContext & ctx, int32_t start, int32_t st, std::vector<int32_t> & order)
+{
+  const std::vector<int32_t> & ap = *ctx.adj_ptr, & ai = *ctx.adj_idx;
+  order.clear();
+  order.push_back(start);
+  ctx.dist[start] = 0;
+  ctx.tag[start] = -st;               // visited marker
+  for (size_t h = 0; h < order.size(); ++h) {
+    const int32_t v = order[h];
+    const int32_t dv = ctx.dist[v] + 1;
+    for (int32_t k = ap[v]; k < ap[v + 1]; ++k) {
+      const int32_t w = ai[k];
+      if (ctx.tag[w] == st) {ctx.tag[w] = -st; ctx.dist[w] = dv; order.push_back(w);}
+    }
+  }
+  for (int32_t v : order) {ctx.tag[v] = st;}
+}
+
+// Minimum vertex cover of the edges between level l - 1 (left) and level l (right) of the level structure in `order`
+// (level q = order[lstart[q] .. lstart[q + 1])).  Kuhn's augmenting paths (the sides hold tens of vertices), then Koenig's
+// construction: with Z = the vertices reachable from the unmatched left vertices by alternating paths, the cover is
+// (left \ Z) + (right & Z).
+void cut_vertex_cover(NdContext & ctx, const std::vector<int32_t> & order, const std::vector<int32_t> & lstart, int32_t l, int32_t st,
+  std::vector<int32_t> & cover)
+{
+  const std::vector<int32_t> & ap = *ctx.adj_ptr, & ai = *ctx.adj_idx;
+  cover.clear();
+  std::vector<int32_t> left, right;                 // vertex ids
+  std::vector<int32_t> eptr(1, 0), eidx;            // left local -> right locals
+  for (int32_t q = lstart[l]; q < lstart[l + 1]; ++q) {ctx.loc[order[q]] = -1;}
+  for (int32_t q = lstart[l - 1]; q < lstart[l]; ++q) {
+    const int32_t v = order[q];
+    const size_t before = eidx.size();
+    for (int32_t k = ap[v]; k < ap[v + 1]; ++k) {
+      const int32_t w = ai[k];
+      if (ctx.tag[w] != st || ctx.dist[w] != l) {continue;}
+      if (ctx.loc[w] < 0) {ctx.loc[w] = static_cast<int32_t>(right.size()); right.push_back(w);}
+      eidx.push_back(ctx.loc[w]);
+    }
+    if (eidx.size() > before) {left.push_back(v); eptr.push_back(static_cast<int32_t>(eidx.size()));}
+  }
+  const int32_t nl = static_cast<int32_t>(left.size()), nr = static_cast<int32_t>(right.size());
+  std::vector<int32_t> match_l(nl, -1), match_r(nr, -1), seen(nr, -1);
+  // iterative augmenting-path search from left vertex `root`
+  std::vector<int32_t> stack_v, stack_e;
+  for (int32_t root = 0; root < nl; ++root) {
+    stack_v.assign(1, root); stack_e.assign(1, eptr[root]);
+    bool found = false;
+    while (!stack_v.empty() && !found) {
+      const int32_t u = stack_v.back();
+      int32_t & e = stack_e.back();
+      if (e >= eptr[u + 1]) {stack_v.pop_back(); stack_e.pop_back(); continue;}
+      const int32_t r = eidx[e++];
+      if (seen[r] == root) {continue;}
+      seen[r] = root;
+      if (match_r[r] < 0) {
+        // flip the path: the stack holds the left vertices, each one's last taken edge is stack_e - 1
+        int32_t rr = r;
+        for (int32_t d = static_cast<int32_t>(stack_v.size()) - 1; d >= 0; --d) {
+          const int32_t lu = stack_v[d];
+          const int32_t prev = match_l[lu];
+          match_l[lu] = rr; match_r[rr] = lu;
+          rr = prev;
+        }
+        found = true;
+      } else {
+        stack_v.push_back(match_r[r]); stack_e.push_back(eptr[match_r[r]]);
+      }
+    }
+  }
+  std::vector<uint8_t> zl(nl, 0), zr(nr, 0);
+  std::vector<int32_t> work;
+  for (int32_t u = 0; u < nl; ++u) {if (match_l[u] < 0) {zl[u] = 1; work.push_back(u);}}
+  while (!work.empty()) {
+    const int32_t u = work.back(); work.pop_back();
+    for (int32_t e = eptr[u]; e < eptr[u + 1]; ++e) {
+      const int32_t r = eidx[e];
+      if (zr[r]) {continue;}
+      zr[r] = 1;
+      const int32_t u2 = match_r[r];
+      if (u2 >= 0 && !zl[u2]) {zl[u2] = 1; work.push_back(u2);}
+    }
+  }
+  for (int32_t u = 0; u < nl; ++u) {if (!zl[u]) {cover.push_back(left[u]);}}
+  for (int32_t r = 0; r < nr; ++r) {if (zr[r]) {cover.push_back(right[r]);}}
+}
+
+// appends the supernodes of `nodes` to `out` in elimination order (A's, B's, then the separator)
+void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & out, int depth)
+{
+  if (nodes.empty()) {return;}
+  if (static_cast<int32_t>(nodes.size()) <= ctx.opt.leaf_nodes) {
+    std::sort(nodes.begin(), nodes.end());
+    out.push_back(nodes);
+    return;
+  }
+  const int32_t st = ++ctx.stamp;
+  for (int32_t v : nodes) {ctx.tag[v] = st;}
+  std::vector<int32_t> order;
+  order.reserve(nodes.size());
+  nd_bfs(ctx, nodes[0], st, order);
+  auto both = [&](std::vector<int32_t> & A, std::vector<int32_t> & B) {
+    if (depth < ctx.opt.parallel_depth && A.size() > 256 && B.size() > 256) {
+      SupernodeList out_b;
+      std::thread tb([&] {nd_recurse(ctx, B, out_b, depth + 1);});
+      nd_recurse(ctx, A, out, depth + 1);
+      tb.join();
+      for (auto & sn : out_b) {out.push_back(std::move(sn));}
+    } else {
+      nd_recurse(ctx, A, out, depth + 1);
+      nd_recurse(ctx, B, out, depth + 1);
+    }
+  };
+  if (order.size() < nodes.size()) {
+    // disconnected subset: split off this component, recurse on both parts (independent subtrees)
+    std::vector<int32_t> comp = order, rest;
+    for (int32_t v : comp) {ctx.tag[v] = 0;}
+    for (int32_t v : nodes) {if (ctx.tag[v] == st) {rest.push_back(v);}}
+    both(comp, rest);
+    return;
+  }
+  // pseudo-peripheral start: restart the BFS from the farthest vertex
+  {
+    const int32_t far = order.back();
+    nd_bfs(ctx, far, st, order);
+  }
+  const int32_t depth_bfs = ctx.dist[order.back()];
+  auto as_leaf = [&]() {
+    std::sort(nodes.begin(), nodes.end());
+    out.push_back(nodes);
+  };
+  if (depth_bfs < 2) {as_leaf(); return;}      // clique-like: no level can separate anything
+  std::vector<int32_t> lstart(depth_bfs + 2, 0);
+  for (int32_t v : order) {lstart[ctx.dist[v] + 1]++;}
+  for (int32_t l = 0; l <= depth_bfs; ++l) {lstart[l + 1] += lstart[l];}
+  // candidate cuts "between level l - 1 and level l": those that leave balance_lo .. balance_hi of the vertices on the near
+  // side, cheapest boundary estimate first; if the level structure is too coarse for that, the cut closest to the median
+  const double total = static_cast<double>(order.size());
+  struct Cand {int32_t est, l;};
+  std::vector<Cand> cands;
+  int32_t fallback = 1; double fallback_dist = 1e300;
+  for (int32_t l = 1; l <= depth_bfs; ++l) {
+    const double frac = lstart[l] / total;         // vertices at distance < l
+    const int32_t below = lstart[l] - lstart[l - 1], at = lstart[l + 1] - lstart[l];
+    if (std::fabs(frac - 0.5) < fallback_dist) {fallback_dist = std::fabs(frac - 0.5); fallback = l;}
+    if (frac >= ctx.opt.balance_lo && frac <= ctx.opt.balance_hi) {cands.push_back({std::min(below, at), l});}
+  }
+  if (cands.empty()) {cands.push_back({0, fallback});}
+  std::stable_sort(cands.begin(), cands.end(), [](const Cand & a, const Cand & b) {return a.est < b.est;});
+  if (static_cast<int32_t>(cands.size()) > ctx.opt.separator_candidates) {cands.resize(ctx.opt.separator_candidates);}
+  std::vector<int32_t> best_cover, cover;
+  int32_t best_l = -1;
+  for (const Cand & c : cands) {
+    if (best_l >= 0 && c.est >= static_cast<int32_t>(best_cover.size())) {
+      // the cover of a cut is at most its smaller boundary, but equal to it only in the worst case: a boundary that is
+      // already no smaller than the best cover cannot win by much, and the candidates are sorted by that estimate
+      if (c.est > static_cast<int32_t>(best_cover.size()) + static_cast<int32_t>(best_cover.size()) / 2) {break;}
+    }
+    cut_vertex_cover(ctx, order, lstart, c.l, st, cover);
+    if (cover.empty()) {continue;}
+    if (best_l < 0 || cover.size() < best_cover.size()) {best_cover.swap(cover); best_l = c.l;}
+  }
+  if (best_l < 0) {as_leaf(); return;}
+  for (int32_t v : best_cover) {ctx.tag[v] = 0;}              // out of the subset
+  std::vector<int32_t> A, B;
+  for (int32_t v : order) {
+    if (ctx.tag[v] != st) {continue;}
+    if (ctx.dist[v] < best_l) {A.push_back(v);} else {B.push_back(v);}
+  }
+  if (A.empty() || B.empty()) {as_leaf(); return;}
+  both(A, B);
+  std::sort(best_cover.begin(), best_cover.end());
+  out.push_back(best_cover);
+}
+
+}  // namespace
+
+int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
+  const SymbolicOptions & opt)
+{
+  sym = Symbolic();
+  sym.n_free = n_free;
+  NdContext ctx;
+  ctx.adj_ptr = &adj_ptr;
+  ctx.adj_idx = &adj_idx;
+  ctx.opt = opt;
+  ctx.tag.assign(n_free, 0);
+  ctx.dist.assign(n_free, 0);
+  ctx.loc.assign(n_free, -1);
+  std::vector<int32_t> all(n_free);
+  for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
+  SupernodeList dissected;
+  nd_recurse(ctx, all, dissected, 0);
+  // a front's pivot block is factored inside one workgroup's LDS: larger supernodes become a chain of fronts (each part
+  // the only child of the next; same columns, same fill)
+  SupernodeList supernodes;
+  supernodes.reserve(dissected.size());
+  const int32_t cap = std::max(1, opt.max_pivot_nodes);
+  for (auto & sn : dissected) {
+    const int32_t n = static_cast<int32_t>(sn.size());
+    if (n <= cap) {supernodes.push_back(std::move(sn)); continue;}
+    const int32_t parts = (n + cap - 1) / cap, step = (n + parts - 1) / parts;
+    for (int32_t b = 0; b < n; b += step) {supernodes.emplace_back(sn.begin() + b, sn.begin() + std::min(n, b + step));}
+  }
+  const int32_t K = static_cast<int32_t>(supernodes.size());
+  sym.n_fronts = K;
+  sym.elim_of_free.assign(n_free, -1);
+  sym.free_of_elim.assign(n_free, -1);
+  sym.sn_of_elim.assign(n_free, -1);
+  // `o` = index of a supernode in elimination order, `k` = its front id: fronts are numbered level by level (largest first
+  // inside a level), so that a level is a contiguous id range and its descriptors are contiguous in memory
+  std::vector<int32_t> first_o(K + 1, 0);
+  int32_t pos = 0;
+  for (int32_t o = 0; o < K; ++o) {
+    first_o[o] = pos;
+    for (int32_t v : supernodes[o]) {
+      if (v < 0 || v >= n_free || sym.elim_of_free[v] >= 0) {set_error("nested dissection produced an invalid ordering"); return KH_ERR_SOLVER;}
+      sym.elim_of_free[v] = pos; sym.free_of_elim[pos] = v; sym.sn_of_elim[pos] = o; ++pos;     // o for now, k below
+    }
+  }
+  first_o[K] = pos;
+  if (pos != n_free) {set_error("nested dissection lost nodes"); return KH_ERR_SOLVER;}
+
+  // struct rows, parents, children (in elimination order: children before parents)
+  std::vector<std::vector<int32_t>> rows(K), children(K);
+  std::vector<int32_t> stamp(n_free, -1), parent_o(K, -1), level_o(K, 0), m_o(K, 0);
+  int32_t max_level = 0;
+  for (int32_t o = 0; o < K; ++o) {
+    const int32_t end = first_o[o + 1];
+    std::vector<int32_t> & r = rows[o];
+    for (int32_t e = first_o[o]; e < end; ++e) {
+      const int32_t v = sym.free_of_elim[e];
+      for (int32_t q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) {
+        const int32_t ew = sym.elim_of_free[adj_idx[q]];
+        if (ew >= end && stamp[ew] != o) {stamp[ew] = o; r.push_back(ew);}
+      }
+    }
+    for (int32_t c : children[o]) {
+      for (int32_t ew : rows[c]) {
+        if (ew >= end && stamp[ew] != o) {stamp[ew] = o; r.push_back(ew);}
+      }
+      level_o[o] = std::max(level_o[o], level_o[c] + 1);
+    }
+    std::sort(r.begin(), r.end());
+    if (!r.empty()) {
+      parent_o[o] = sym.sn_of_elim[r[0]];
+      children[parent_o[o]].push_back(o);
+    }
+    m_o[o] = 3 * (end - first_o[o] + static_cast<int32_t>(r.size()));
+    max_level = std::max(max_level, level_o[o]);
+    if (m_o[o] > 8000) {set_error("front too large for the triangular-solve kernels (m > 8000)"); return KH_ERR_SOLVER;}
+  }
+  std::vector<int32_t> o_of_k(K), k_of_o(K);
+  for (int32_t o = 0; o < K; ++o) {o_of_k[o] = o;}
+  std::stable_sort(o_of_k.begin(), o_of_k.end(), [&](int32_t a, int32_t b) {
+    if (level_o[a] != level_o[b]) {return level_o[a] < level_o[b];}
+    return m_o[a] > m_o[b];                  // largest fronts first: they are the critical path of their level
+  });
+  for (int32_t k = 0; k < K; ++k) {k_of_o[o_of_k[k]] = k;}
+  for (int32_t e = 0; e < n_free; ++e) {sym.sn_of_elim[e] = k_of_o[sym.sn_of_elim[e]];}
+
+  sym.parent.assign(K, -1);
+  sym.rows_ptr.assign(K + 1, 0);
+  sym.child_ptr.assign(K + 1, 0);
+  sym.relpos_ptr.assign(K + 1, 0);
+  sym.level.assign(K, 0);
+  sym.front_off.assign(K, 0); sym.front_m.assign(K, 0); sym.front_ns.assign(K, 0); sym.front_first.assign(K, 0);
+  sym.winv_off.assign(K, 0);
+  sym.levels.assign(max_level + 1, {});
+  int64_t off = 0, woff = 0;
+  for (int32_t k = 0; k < K; ++k) {
+    const int32_t o = o_of_k[k];
+    sym.rows_ptr[k + 1] = sym.rows_ptr[k] + static_cast<int32_t>(rows[o].size());
+    sym.child_ptr[k + 1] = sym.child_ptr[k] + static_cast<int32_t>(children[o].size());
+    sym.relpos_ptr[k + 1] = sym.relpos_ptr[k] + static_cast<int32_t>(rows[o].size());
+    sym.parent[k] = parent_o[o] < 0 ? -1 : k_of_o[parent_o[o]];
+    sym.level[k] = level_o[o];
+    sym.levels[level_o[o]].push_back(k);
+    const int32_t ncols = first_o[o + 1] - first_o[o];
+    sym.front_ns[k] = 3 * ncols;
+    sym.front_m[k] = m_o[o];
+    sym.front_first[k] = first_o[o];
+    sym.front_off[k] = off;
+    off += static_cast<int64_t>(sym.front_m[k]) * sym.front_m[k];
+    const int64_t nsp = (sym.front_ns[k] + 15) & ~15;
+    sym.winv_off[k] = woff;
+    woff += nsp * nsp;
+    sym.max_m = std::max(sym.max_m, sym.front_m[k]); sym.max_ns = std::max(sym.max_ns, sym.front_ns[k]);
+    sym.nnz_factor += static_cast<int64_t>(sym.front_ns[k]) * (sym.front_ns[k] + 1) / 2 +
+      static_cast<int64_t>(sym.front_ns[k]) * (sym.front_m[k] - sym.front_ns[k]);
+    for (int32_t j = 0; j < sym.front_ns[k]; ++j) {
+      sym.factor_flops += static_cast<int64_t>(sym.front_m[k] - j) * (sym.front_m[k] - j);
+    }
+  }
+  sym.fronts_size = off;
+  sym.winv_size = woff;
+  sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);
+  for (int32_t k = 0; k < K; ++k) {
+    const int32_t o = o_of_k[k];
+    sym.rows.insert(sym.rows.end(), rows[o].begin(), rows[o].end());
+    for (int32_t c : children[o]) {sym.child_list.push_back(k_of_o[c]);}
+    const int32_t po = parent_o[o];
+    if (po < 0) {continue;}
+    const int32_t pfirst = first_o[po], pend = first_o[po + 1], pcols = pend - pfirst;
+    for (size_t q = 0; q < rows[o].size(); ++q) {
+      const int32_t r = rows[o][q];
+      int32_t at;
+      if (r < pend) {
+        at = r - pfirst;
+      } else {
+        auto it = std::lower_bound(rows[po].begin(), rows[po].end(), r);
+        if (it == rows[po].end() || *it != r) {set_error("symbolic: child row missing in parent front"); return KH_ERR_SOLVER;}
+        at = pcols + static_cast<int32_t>(it - rows[po].begin());
+      }
+      sym.relpos[sym.relpos_ptr[k] + q] = at;
+    }
+  }
+  return KH_OK;
+}
+
+}  // namespace kh

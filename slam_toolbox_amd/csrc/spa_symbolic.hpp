@@ -1,0 +1,49 @@
+// Symbolic analysis of the pose-graph normal matrix (hot path B): fill-reducing ordering, supernodes (= fronts of the
+// multifrontal factorisation), their row structures, the assembly tree and its level schedule.  Host-only code: no HIP.
+//
+// Reference: solvers/ceres_solver.cpp:214-269 hands the problem to Ceres' SPARSE_NORMAL_CHOLESKY, whose ordering and
+// symbolic factorisation happen inside SuiteSparse/CHOLMOD -- a third-party dependency that is not in the reference tree.
+// This is the equivalent stage of the MI355X solver.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace kh
+{
+
+struct Symbolic
+{
+  int32_t n_free = 0, n_fronts = 0;
+  // fronts are numbered level by level: level l = the contiguous id range levels[l].front() .. levels[l].back()
+  std::vector<int32_t> elim_of_free, free_of_elim, sn_of_elim;      // sn_of_elim: elimination position -> front id
+  std::vector<int32_t> rows_ptr, rows, parent, level;
+  std::vector<int64_t> front_off;
+  std::vector<int32_t> front_m, front_ns, front_first;
+  std::vector<int32_t> child_ptr, child_list, relpos_ptr, relpos;
+  std::vector<std::vector<int32_t>> levels;
+  int64_t fronts_size = 0;
+  int64_t nnz_factor = 0;
+  int64_t factor_flops = 0;      // sum over the fronts of sum_{j < ns} (m - j)^2
+  // inverse of the pivot block's Cholesky factor, one nsp x nsp block per front (nsp = ns rounded up to 16)
+  std::vector<int64_t> winv_off;
+  int64_t winv_size = 0;
+  int32_t max_m = 0, max_ns = 0;
+};
+
+struct SymbolicOptions
+{
+  int32_t leaf_nodes = 12;          // subsets of at most this many nodes are not dissected further
+  int32_t max_pivot_nodes = 42;     // supernodes with more pivots are split into a chain of fronts (42 nodes = 126 columns:
+                                    // the pivot block of a front is factored inside one workgroup's LDS, 128 x 130 doubles)
+  int32_t separator_candidates = 4; // BFS levels tried as the cut of a subset (each one refined to a minimum vertex cover)
+  int32_t parallel_depth = 3;       // recursion levels whose two halves run on separate threads
+  double balance_lo = 0.35;         // a cut must leave at least this fraction of the subset on the near side ...
+  double balance_hi = 0.65;         // ... and at most this
+};
+
+// adjacency of the free nodes in CSR form: neighbours of i = adj_idx[adj_ptr[i] .. adj_ptr[i + 1]), ascending, no
+// self loops.  Returns 0 or a KH_ERR_* code (message through kh::set_error).
+int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
+  const SymbolicOptions & opt);
+
+}  // namespace kh

@@ -214,3 +214,39 @@ def test_robust_loss_matches_oracle(kartohip_lib, loss):
     ref_sq, _ = spa.solve(g["init"], g["edges"], z, g["cov"])
     assert _diff(ref_sq, ref_x) > 1e-3
     sol.close()
+
+
+def _solve(g, **kw):
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    sol = HipSpaSolver()
+    sol.set_debug(**kw)
+    sol.load(g["init"], g["edges"], g["z"], g["cov"])
+    summ = sol.Compute()
+    x = sol.poses()
+    sol.close()
+    return summ, x
+
+
+@pytest.mark.parametrize("n_clique,n_chain", [(2, 0), (4, 3), (6, 9), (11, 0), (12, 2), (17, 30), (22, 1), (23, 5), (33, 7), (43, 2), (44, 40), (70, 40),
+                                              (86, 1), (127, 3), (150, 3)])
+def test_linear_solves_of_dense_fronts(kartohip_lib, n_clique, n_chain):
+    """Every tail shape of the pivot block (3 * (n_clique - 1) pivots: 3 ... 447; above 126 the supernode is a chain of
+    fronts) through the level pipeline: the residual of EVERY linear solve of the run, evaluated from the block-sparse
+    matrix, and the same poses as the panel-pair kernels."""
+    g = _clique_graph(n_clique, n_chain, seed=100 + n_clique)
+    s3, x3 = _solve(g, check_linear_solves=True, factor_kernels=3)
+    s2, x2 = _solve(g, check_linear_solves=True, factor_kernels=2)
+    assert s3["usable"] == 1 and s3["iterations"] == s2["iterations"], (s3, s2)
+    assert 0.0 < s3["worst_linear_residual"] < 1e-9, s3
+    assert 0.0 < s2["worst_linear_residual"] < 1e-9, s2
+    assert _diff(x3, x2) < 1e-9
+
+
+@pytest.mark.parametrize("n,e,seed", [(40, 60, 3), (300, 700, 5), (2000, 5000, 9), (3000, 9000, 4)])
+def test_linear_solves_of_pose_graphs(kartohip_lib, n, e, seed):
+    g = synth.make_pose_graph(n, e, seed=seed)
+    s3, x3 = _solve(g, check_linear_solves=True, factor_kernels=3)
+    s2, x2 = _solve(g, check_linear_solves=True, factor_kernels=2)
+    assert s3["usable"] == 1 and s3["iterations"] == s2["iterations"], (s3, s2)
+    assert 0.0 < s3["worst_linear_residual"] < 1e-9, s3
+    assert _diff(x3, x2) < 1e-8
