@@ -125,7 +125,7 @@ struct kh_spa
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
   int32_t n_slots = 0;
   std::vector<int32_t> level_offsets, level_max_m, level_max_ns;
-  DevBuf<double> d_upd, d_fsb;
+  DevBuf<double> d_upd, d_fsb, d_partial;
   DevBuf<double> d_Hg_alt, d_best;          // normal equations at the candidate point (speculative); minimum-cost iterate
   // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
   int32_t shard_rank = 0, shard_world = 1;
@@ -440,6 +440,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_fail.ensure(4);
     r2 |= s->d_sync.ensure(4 * static_cast<size_t>(sym.n_fronts) + 4);
     r2 |= s->d_upd.ensure(static_cast<size_t>(3) * sym.rows_ptr[sym.n_fronts] + 16);
+    r2 |= s->d_partial.ensure(static_cast<size_t>(5) * ((nf + 255) / 256) + (E + 255) / 256 + static_cast<size_t>(2) * ((3 * nf + 255) / 256) + 32);
     r2 |= s->d_fsb.ensure(static_cast<size_t>(3) * (static_cast<size_t>(nf) + sym.rows_ptr[sym.n_fronts]) + 16);
     if (r2) {return KH_ERR_HIP;}
     // the uploads above read pageable host vectors of this block: they must have landed before the block ends
@@ -541,7 +542,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_winv_off.release(); s->d_winv.release(); s->d_desc.release(); s->d_edge_z.release(); s->d_edge_u.release();
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
-  s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release(); s->d_Hg_alt.release(); s->d_best.release();
+  s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release(); s->d_partial.release(); s->d_Hg_alt.release(); s->d_best.release();
   for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   for (auto & row : s->ev_lin) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
@@ -1026,6 +1027,8 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   hipStream_t st = s->stream;
   double * x = s->d_x.p; double * cand = s->d_cand.p;
   double * scal = s->d_scal.p;
+  // the fused step kernel writes the candidate of the free nodes only: the gauge node and unused nodes carry their pose
+  KS_HIP(hipMemcpyAsync(cand, x, sizeof(double) * 3 * static_cast<size_t>(dev.n_nodes), hipMemcpyDeviceToDevice, s->stream));
   const int n_levels = static_cast<int>(sym.levels.size());
   sum.nnz_factor = sym.nnz_factor;
 
@@ -1170,19 +1173,30 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       }
       dbg("backward", l);
     }
-    spa_launch_finish_step(dev, s->d_scale.p, s->d_rhs.p, s->d_step.p, s->d_delta.p, st);
+    static const bool speculate = !(std::getenv("KH_SPA_SPECULATE") && std::atoi(std::getenv("KH_SPA_SPECULATE")) == 0);
     static const bool lin_check_env = std::getenv("KH_SPA_CHECK") != nullptr;
     const bool lin_check = lin_check_env || (s->debug_flags & 1);
-    if (lin_check) {spa_launch_lin_check(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, s->d_step.p, scal + 12, st);}
-    spa_launch_model(dev, s->d_scale.p, s->d_step.p, scal + 3, st);
-    spa_launch_plus(dev, x, s->d_delta.p, cand, scal + 6, st);
-    if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
-    static const bool speculate = !(std::getenv("KH_SPA_SPECULATE") && std::atoi(std::getenv("KH_SPA_SPECULATE")) == 0);
-    if (speculate) {
-      rc = linearize(alt, cand, scal + 8); if (rc) {return finish(rc);}      // cost of the candidate + its H, g
-      spa_launch_grad_norms(alt, cand, scal + 9, st);
+    const bool fused_step = speculate && s->shard_world == 1 && !s->comm && !(std::getenv("KH_SPA_FUSED_STEP") && std::atoi(std::getenv("KH_SPA_FUSED_STEP")) == 0);
+    if (fused_step) {
+      // the candidate's cost AND its normal equations (speculative: a step is nearly always accepted) ride in the same batch
+      const bool timed_lin = n_lin < 2 * kh_spa::kMaxTimed + 2;
+      if (timed_lin) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
+      spa_launch_step_and_linearize(dev, alt, s->d_scale.p, s->d_rhs.p, x, s->d_step.p, s->d_delta.p, cand, s->d_partial.p, scal, st);
+      if (timed_lin) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
+      if (lin_check) {spa_launch_lin_check(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, s->d_step.p, scal + 12, st);}
+      if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
     } else {
-      spa_launch_cost(dev, cand, scal + 8, st);
+      spa_launch_finish_step(dev, s->d_scale.p, s->d_rhs.p, s->d_step.p, s->d_delta.p, st);
+      if (lin_check) {spa_launch_lin_check(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, s->d_step.p, scal + 12, st);}
+      spa_launch_model(dev, s->d_scale.p, s->d_step.p, scal + 3, st);
+      spa_launch_plus(dev, x, s->d_delta.p, cand, scal + 6, st);
+      if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
+      if (speculate) {
+        rc = linearize(alt, cand, scal + 8); if (rc) {return finish(rc);}      // cost of the candidate + its H, g
+        spa_launch_grad_norms(alt, cand, scal + 9, st);
+      } else {
+        spa_launch_cost(dev, cand, scal + 8, st);
+      }
     }
     KS_HIP(hipGetLastError());
     rc = fetch(); if (rc) {return finish(rc);}

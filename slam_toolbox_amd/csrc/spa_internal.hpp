@@ -106,6 +106,11 @@ void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, v
 void spa_launch_finish_step(const SpaDev & d, const double * scale, const double * rhs, double * step, double * delta, void * stream);
 // out[0] = step.gs, out[1] = step^T Hs step, out[2] = any non-finite in step
 void spa_launch_model(const SpaDev & d, const double * scale, const double * step, double * out3, void * stream);
+// single GPU: step = -y, delta, cand = Plus(x, delta), the model-cost terms and step norms from `cur` (scal[3..7]); cost,
+// normal equations and gradient norms of the candidate into `alt` (scal[8..10]).  partial: spa_step_partials_size doubles.
+int64_t spa_step_partials_size(const SpaDev & d);
+void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const double * scale, const double * rhs, const double * x, double * step,
+                                   double * delta, double * cand, double * partial, double * scal, void * stream);
 // debugging aid (KH_SPA_CHECK): out[0] = |(Hs + D / radius) step + gs|^2, out[1] = |gs|^2 from the BSR matrix
 void spa_launch_lin_check(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, const double * step, double * out2,
                           void * stream);

@@ -365,6 +365,148 @@ void spa_launch_grad_norms(const SpaDev & d, const double * x, double * out2, vo
 }
 
 // ---------------------------------------------------------------------------------------------
+// The step evaluation of an LM iteration in five launches (single GPU): fourteen small launches -- six of them one-workgroup
+// sums over 30 000 values, 8-10 us each -- were 0.15 ms of every iteration.  Every kernel leaves per-workgroup partial
+// sums (tree reduction in LDS, fixed order: bit-reproducible), and one last workgroup adds the partials up.
+//   k_step_fused   step = -y, delta = step * scale, cand = Plus(x, delta), model-cost terms, step norms  (thread = free node)
+//   k_edge_lin<true, true>  candidate cost + linearisation, cost partials
+//   k_gather_H, k_gather_g<true>  normal equations at the candidate, gradient-norm partials
+//   k_reduce_partials
+template <int N>
+__device__ __forceinline__ void block_reduce_store(double (&v)[N], int max_mask, double * out)      // bit q of max_mask: entry q is a maximum
+{
+  __shared__ double red[N][256];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {red[q][threadIdx.x] = v[q];}
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const double a = red[q][threadIdx.x], b = red[q][threadIdx.x + w];
+        red[q][threadIdx.x] = ((max_mask >> q) & 1) ? fmax(a, b) : a + b;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < N) {out[threadIdx.x] = red[threadIdx.x][0];}
+}
+
+__global__ __launch_bounds__(256) void k_step_fused(SpaDev d, const double * __restrict__ scale, const double * __restrict__ rhs,
+                                                    const double * __restrict__ x, double * step, double * delta, double * cand, double * partial)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double p[5] = {0.0, 0.0, 0.0, 0.0, 0.0};        // step.gs, step^T Hs step, non-finite marker, |x - cand|^2, |cand|^2
+  if (i < d.n_free) {
+    const int e = d.elim_of_free[i];
+    double st[3], acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {st[c] = -rhs[3 * e + c];}                 // levenberg_marquardt_strategy.cc: step *= -1
+    for (int k = d.bsr_row_ptr[i]; k < d.bsr_row_ptr[i + 1]; ++k) {
+      const int j = d.bsr_col[k];
+      const int ej = d.elim_of_free[j];
+      const double * blk = d.H + (size_t)k * 9;
+      double sj[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {sj[c] = scale[3 * j + c] * -rhs[3 * ej + c];}
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {acc[r] += blk[3 * r] * sj[0] + blk[3 * r + 1] * sj[1] + blk[3 * r + 2] * sj[2];}
+    }
+    double dl[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double sc = scale[3 * i + r];
+      step[3 * i + r] = st[r];
+      dl[r] = st[r] * sc;                                                  // trust_region_minimizer.cc: delta = step .* jacobian_scaling
+      delta[3 * i + r] = dl[r];
+      p[0] += st[r] * sc * d.g[3 * i + r];
+      p[1] += st[r] * (acc[r] * sc);
+      p[2] += (st[r] - st[r] == 0.0) ? 0.0 : 1.0;
+    }
+    const int n = d.node_of_free[i];
+    const double px = x[3 * n], py = x[3 * n + 1], pt = x[3 * n + 2];
+    const double nx = px + dl[0], ny = py + dl[1];
+    const double nt = d_normalize_angle(pt + dl[2]);                       // AngleLocalParameterization, ceres_utils.h:38-55
+    const double ex = px - nx, ey = py - ny, et = pt - nt;
+    p[3] = ex * ex + ey * ey + et * et;
+    p[4] = nx * nx + ny * ny + nt * nt;
+    cand[3 * n] = nx; cand[3 * n + 1] = ny; cand[3 * n + 2] = nt;
+  }
+  block_reduce_store<5>(p, 0, partial + 5 * blockIdx.x);
+}
+
+// gradient at the candidate + the projected-gradient norms (k_gather_g and k_grad_norms in one)
+__global__ __launch_bounds__(256) void k_gather_g_norms(SpaDev d, const double * __restrict__ x, double * partial)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  double p[2] = {0.0, 0.0};                       // max |x - Plus(x, -g)|, |x_free|^2
+  if (t < d.n_free * 3) {
+    const int i = t / 3, comp = t - i * 3;
+    double acc = 0.0;
+    for (int k = d.node_contrib_ptr[i]; k < d.node_contrib_ptr[i + 1]; ++k) {
+      const int code = d.node_contrib[k];
+      const int e = code >> 1, role = code & 1;
+      const double * lin = d.edge_lin + 21 * (size_t)e;
+      const double * J = lin + (role ? 12 : 3);
+      acc += J[comp] * lin[0] + J[3 + comp] * lin[1] + J[6 + comp] * lin[2];
+    }
+    d.g[t] = acc;
+    const double v = x[3 * d.node_of_free[i] + comp];
+    const double moved = comp == 2 ? d_normalize_angle(v - acc) : v - acc;
+    p[0] = fabs(v - moved);
+    p[1] = v * v;
+  }
+  block_reduce_store<2>(p, 1, partial + 2 * blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_edge_cost_partials(SpaDev d, double * partial)
+{
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  double p[1] = {e < d.n_edges ? d.edge_cost[e] : 0.0};
+  block_reduce_store<1>(p, 0, partial + blockIdx.x);
+}
+
+// out[3..7] <- step partials, out[8] <- 0.5 * cost partials, out[9], out[10] <- gradient norm partials
+__global__ __launch_bounds__(256) void k_reduce_partials(const double * ps, int ns, const double * pe, int ne, const double * pg, int ng, double * out)
+{
+  double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < ns; b += 256) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {v[q] += ps[5 * b + q];}
+  }
+  for (int b = threadIdx.x; b < ne; b += 256) {v[5] += pe[b];}
+  for (int b = threadIdx.x; b < ng; b += 256) {v[6] = fmax(v[6], pg[2 * b]); v[7] += pg[2 * b + 1];}
+  __shared__ double res[8];
+  block_reduce_store<8>(v, 1 << 6, res);
+  __syncthreads();
+  if (threadIdx.x < 5) {out[3 + threadIdx.x] = res[threadIdx.x];}
+  if (threadIdx.x == 5) {out[8] = 0.5 * res[5];}
+  if (threadIdx.x == 6) {out[9] = res[6];}
+  if (threadIdx.x == 7) {out[10] = res[7];}
+}
+
+int64_t spa_step_partials_size(const SpaDev & d)
+{
+  return 5 * (int64_t)((d.n_free + 255) / 256) + (d.n_edges + 255) / 256 + 2 * (int64_t)((3 * d.n_free + 255) / 256) + 16;
+}
+
+void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const double * scale, const double * rhs, const double * x, double * step,
+                                   double * delta, double * cand, double * partial, double * scal, void * stream)
+{
+  hipStream_t s = (hipStream_t)stream;
+  const int nbs = (cur.n_free + 255) / 256, nbe = (cur.n_edges + 255) / 256, nbg = (3 * cur.n_free + 255) / 256;
+  double * ps = partial, * pe = ps + 5 * (size_t)nbs, * pg = pe + nbe;
+  hipLaunchKernelGGL(k_step_fused, dim3(nbs), dim3(256), 0, s, cur, scale, rhs, x, step, delta, cand, ps);
+  if (alt.n_edges > 0) {
+    hipLaunchKernelGGL(k_edge_lin<true>, dim3(nbe), dim3(256), 0, s, alt, cand, 0, alt.n_edges);
+    hipLaunchKernelGGL(k_edge_cost_partials, dim3(nbe), dim3(256), 0, s, alt, pe);
+    hipLaunchKernelGGL(k_gather_H, dim3((alt.n_slots * 9 + 255) / 256), dim3(256), 0, s, alt);
+  }
+  hipLaunchKernelGGL(k_gather_g_norms, dim3(nbg), dim3(256), 0, s, alt, cand, pg);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, ps, nbs, pe, alt.n_edges > 0 ? nbe : 0, pg, nbg, scal);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K6b: multifrontal partial Cholesky, one workgroup per front.
 //
 // Blocked right-looking factorisation of the front's first ns columns, panel width NB = 16:
@@ -1547,7 +1689,7 @@ __device__ __forceinline__ void potrf_tile(double * A, int LD, int rowI0, int co
   }
 }
 
-#define PSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[1 + tcount++] = wall_clock64();} } while (0)
+#define PSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[64 + tcount] = clock64(); tbuf[1 + tcount++] = wall_clock64();} } while (0)
 
 __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
                                                long long * tbuf)
@@ -1892,10 +2034,11 @@ __global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int 
   }
 }
 
-// Backward solve of a level with W = L11^-T:  x1 = W (y1 - L21^T x2), two sets of independent dot products.  A wave takes
-// sixteen columns; the entries of L21 and W it needs are requested right after the descriptor, together with y1 and the
-// gather of x2 (kept in registers for fronts of up to 64 * NI struct rows: one round of memory latency instead of four).
-__global__ __launch_bounds__(512) void k_backward3(SpaDev d, int first_front, double * rhs)
+// Backward solve of a level with W = L11^-T:  x1 = W (y1 - L21^T x2), two sets of independent dot products, one wave per
+// pair of columns.  (A variant that requested every entry of L21 and W a wave needs right after the descriptor -- 80 loads
+// per lane, fully unrolled -- was SLOWER, 306 us per sweep against 177: these kernels run once per level, and a long
+// straight-line body is paid for in instruction fetch.)
+__global__ __launch_bounds__(1024) void k_backward3(SpaDev d, int first_front, double * rhs)
 {
   const FrontDesc fd = d.desc[first_front + blockIdx.x];
   const int m = fd.m, ns = fd.ns, nu = m - ns;
@@ -1907,77 +2050,37 @@ __global__ __launch_bounds__(512) void k_backward3(SpaDev d, int first_front, do
   extern __shared__ double sb[];                 // [m] : w (pivots) | x2 (struct rows), then [nsp] x1
   double * xo = sb + m;
   const int32_t * rows = d.front_rows + fd.rows_ptr;
-  constexpr int CW = 16;                         // columns per wave per pass (8 waves x 16 = every column of a front)
-  constexpr int NI = 5;                          // 64-row chunks of L21 held in registers
-  const int cb0 = CW * wave;
-  const bool fast = nu <= 64 * NI && ns <= CW * nwaves;
-  double l21[NI][CW];
-  if (fast) {
-#pragma unroll
-    for (int it = 0; it < NI; ++it) {
-      const int i = min(lane + 64 * it, max(nu - 1, 0));
-#pragma unroll
-      for (int q = 0; q < CW; ++q) {
-        const int c = min(cb0 + q, ns - 1);
-        l21[it][q] = nu > 0 ? F[(ns + i) + (int64_t)c * m] : 0.0;
-      }
-    }
-  }
   for (int t = tid; t < ns; t += nthreads) {sb[t] = rhs[first + t];}
   for (int q = tid; q < nu; q += nthreads) {sb[ns + q] = rhs[3 * rows[q / 3] + q % 3];}
   __syncthreads();
   // w[c] = y1[c] - L21[:, c] . x2
-  for (int cbase = cb0; cbase < ns; cbase += CW * nwaves) {
-    double acc[CW];
-#pragma unroll
-    for (int q = 0; q < CW; ++q) {acc[q] = 0.0;}
-    if (fast) {
-#pragma unroll
-      for (int it = 0; it < NI; ++it) {
-        const int i = lane + 64 * it;
-        const double x = i < nu ? sb[ns + i] : 0.0;
-#pragma unroll
-        for (int q = 0; q < CW; ++q) {acc[q] += l21[it][q] * x;}
-      }
-    } else {
-      for (int i = lane; i < nu; i += 64) {
-        const double x = sb[ns + i];
-#pragma unroll
-        for (int q = 0; q < CW; ++q) {
-          const int c = min(cbase + q, ns - 1);
-          acc[q] += F[(ns + i) + (int64_t)c * m] * x;
-        }
-      }
+  for (int c = 2 * wave; c < ns; c += 2 * nwaves) {
+    const double * col0 = F + ns + (int64_t)c * m;
+    const double * col1 = col0 + (c + 1 < ns ? m : 0);
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = lane; i < nu; i += 64) {
+      const double x = sb[ns + i];
+      a0 += col0[i] * x;
+      a1 += col1[i] * x;
     }
 #pragma unroll
-    for (int q = 0; q < CW; ++q) {
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) {acc[q] += __shfl_xor(acc[q], s);}
-      if (lane == 0 && cbase + q < ns) {sb[cbase + q] -= acc[q];}
-    }
+    for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
+    if (lane == 0) {sb[c] -= a0; if (c + 1 < ns) {sb[c + 1] -= a1;}}
   }
   __syncthreads();
   // x1[c] = sum_{j >= c} (L^-T)[c][j] w[j],  (L^-T)[c][j] = W[j + c * nsp]  (zeros left of the diagonal)
-  for (int cbase = cb0; cbase < ns; cbase += CW * nwaves) {
-    double acc[CW];
-#pragma unroll
-    for (int q = 0; q < CW; ++q) {acc[q] = 0.0;}
-    {
-      for (int j = cbase + lane; j < ns; j += 64) {
-        const double wj = sb[j];
-#pragma unroll
-        for (int q = 0; q < CW; ++q) {
-          const int c = min(cbase + q, ns - 1);
-          acc[q] += W[j + (int64_t)c * nsp] * wj;
-        }
-      }
+  for (int c = 2 * wave; c < ns; c += 2 * nwaves) {
+    const double * w0 = W + (int64_t)c * nsp;
+    const double * w1 = w0 + (c + 1 < ns ? nsp : 0);
+    double a0 = 0.0, a1 = 0.0;
+    for (int j = c + lane; j < ns; j += 64) {
+      const double wj = sb[j];
+      a0 += w0[j] * wj;
+      a1 += w1[j] * wj;
     }
 #pragma unroll
-    for (int q = 0; q < CW; ++q) {
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) {acc[q] += __shfl_xor(acc[q], s);}
-      if (lane == 0 && cbase + q < ns) {xo[cbase + q] = acc[q];}
-    }
+    for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
+    if (lane == 0) {xo[c] = a0; if (c + 1 < ns) {xo[c + 1] = a1;}}
   }
   __syncthreads();
   for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = xo[t];}
@@ -2013,13 +2116,17 @@ void spa_launch_factor3_level(const SpaDev & d, int32_t first_front, int32_t n, 
   }
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
-  if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 64 * sizeof(long long), hipHostMallocDefault);}
+  if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 128 * sizeof(long long), hipHostMallocDefault);}
   hipLaunchKernelGGL(k_potrf, dim3(n), dim3(256), potrf_lds_bytes(nsp, max_m), s, d, first_front, fail_flag, rhs, upd, nsp,
                      timing ? tbuf : (long long *)nullptr);
   if (timing) {
     (void)hipStreamSynchronize(s);
     std::fprintf(stderr, "[k_potrf] n=%d front0 m=%lld ns=%lld stamps(x10ns):", n, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
     for (int i = 1; i < (int)tbuf[0]; ++i) {std::fprintf(stderr, " %lld", tbuf[1 + i] - tbuf[i]);}
+    const int last = (int)tbuf[0] - 1;
+    if (last > 0) {
+      std::fprintf(stderr, "  | shader clock %.0f MHz", (double)(tbuf[64 + last] - tbuf[64]) / (double)(tbuf[1 + last] - tbuf[1]) * 100.0);
+    }
     std::fprintf(stderr, "\n");
   }
   const int max_nu = max_m - 3;       // a front has at least one pivot node; an upper bound is enough for the grid
@@ -2048,7 +2155,7 @@ void spa_launch_backward3_level(const SpaDev & d, int32_t first_front, int32_t n
 {
   if (n <= 0) {return;}
   const int nsp = (max_ns + NB - 1) & ~(NB - 1);
-  hipLaunchKernelGGL(k_backward3, dim3(n), dim3(max_ns <= 64 ? 256 : 512), sizeof(double) * ((size_t)max_m + nsp + 8), (hipStream_t)stream, d, first_front, rhs);
+  hipLaunchKernelGGL(k_backward3, dim3(n), dim3(max_ns <= 48 ? 256 : 1024), sizeof(double) * ((size_t)max_m + nsp + 8), (hipStream_t)stream, d, first_front, rhs);
 }
 
 }  // namespace kh

@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -231,7 +233,9 @@ int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & 
   std::vector<int32_t> all(n_free);
   for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
   SupernodeList dissected;
+  const auto t_nd0 = std::chrono::steady_clock::now();
   nd_recurse(ctx, all, dissected, 0);
+  const auto t_nd1 = std::chrono::steady_clock::now();
   // a front's pivot block is factored inside one workgroup's LDS: larger supernodes become a chain of fronts (each part
   // the only child of the next; same columns, same fill)
   SupernodeList supernodes;
@@ -335,6 +339,11 @@ int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & 
   }
   sym.fronts_size = off;
   sym.winv_size = woff;
+  if (std::getenv("KH_SPA_DEBUG")) {
+    std::fprintf(stderr, "[kh_spa] symbolic: nested dissection %.2f ms, structure %.2f ms\n",
+      std::chrono::duration<double, std::milli>(t_nd1 - t_nd0).count(),
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nd1).count());
+  }
   sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);
   for (int32_t k = 0; k < K; ++k) {
     const int32_t o = o_of_k[k];

@@ -36,7 +36,7 @@ struct SymbolicOptions
   int32_t max_pivot_nodes = 42;     // supernodes with more pivots are split into a chain of fronts (42 nodes = 126 columns:
                                     // the pivot block of a front is factored inside one workgroup's LDS, 128 x 130 doubles)
   int32_t separator_candidates = 4; // BFS levels tried as the cut of a subset (each one refined to a minimum vertex cover)
-  int32_t parallel_depth = 3;       // recursion levels whose two halves run on separate threads
+  int32_t parallel_depth = 4;       // recursion levels whose two halves run on separate threads
   double balance_lo = 0.35;         // a cut must leave at least this fraction of the subset on the near side ...
   double balance_hi = 0.65;         // ... and at most this
 };
