@@ -463,6 +463,57 @@ def strong_leg(device=0, rank=0, world=1, n_pairs=2048, distinct=256, batch=256)
                                            f"round-robin over {world} rank(s), one all-gather of {n_pairs} x 13 doubles"}}
 
 
+def group_leg(devices, n_pairs=2048, distinct=256, batch=256):
+    """The same fixed set of candidate pairs as strong_leg through the IN-PROCESS multi-device batch of the library
+    (kh_matcher_group_match_batch: one member per entry of `devices`, candidate i on member i % members, a host thread per
+    member, results in candidate order; no collective).  This is the path kh_mapper's TryCloseLoop uses
+    (kh_mapper_create_on_devices).  Rank 0 only; the graph's scans are resident on every member's device."""
+    from common import LASER, OFFLINE_PARAMS, PRESETS
+    from slam_toolbox_amd import shard, synth
+    from slam_toolbox_amd.comm import DeviceBuffer
+    from slam_toolbox_amd.scan_matcher import LocalizedRangeScan, MapperParams, ScanMatcherGroup
+    lb = synth.loop_batch(distinct)
+    scans, copies = {}, {}
+
+    def scan_at(i):
+        if i not in scans:
+            scans[i] = LocalizedRangeScan(lb["ranges"][i], lb["truth"][i], LASER.min_angle, LASER.ang_res)
+        return scans[i]
+
+    def copy_on(i, dev):
+        if (i, dev) not in copies:
+            buf = DeviceBuffer(scans[i].points.size, dev)
+            buf.upload(scans[i].points)
+            copies[(i, dev)] = buf
+        return copies[(i, dev)].ptr
+    queries = [LocalizedRangeScan(lb["ranges"][q], pose, LASER.min_angle, LASER.ang_res) for q, pose, _ in lb["pairs"]]
+    g = ScanMatcherGroup(MapperParams(**OFFLINE_PARAMS), *PRESETS["L"]["create"], devices=devices, max_batch_per_member=batch)
+    nm = len(devices)
+    units = [u % distinct for u in range(n_pairs)]
+    q_list = [queries[u] for u in units]
+    b_list = [[scan_at(i) for i in lb["pairs"][u][2]] for u in units]
+    rows = []
+    for k, u in enumerate(units):
+        for i in lb["pairs"][u][2]:
+            row = [0] * nm
+            row[k % nm] = copy_on(i, devices[k % nm])          # only the member that reads the scan needs the copy
+            rows.append(row)
+    packed = g.pack_batch(q_list, b_list, np.asarray(rows, dtype=np.uint64))
+    g.MatchScanBatch(None, None, False, False, packed=packed)      # warm-up: allocations
+    times = []
+    for _ in range(3):
+        t = time.perf_counter()
+        resp, means, covs, st = g.MatchScanBatch(None, None, False, False, packed=packed)
+        times.append(time.perf_counter() - t)
+    g.close()
+    table = np.concatenate([resp[:, None], means, covs.reshape(-1, 9)], axis=1)
+    med = float(np.median(times))
+    return {"pairs": n_pairs, "members": nm, "devices": list(map(int, devices)), "ms": med * 1e3, "pairs_per_s": n_pairs / med,
+            "first_accepted": int(shard.first_accepted(table, 0.35, 9.0)),
+            "workload": f"{n_pairs} candidate pairs ({distinct} distinct, tiled) preset L coarse MatchScan through "
+                        f"kh_matcher_group_match_batch, one process, {nm} member(s), no collective"}
+
+
 def replay_leg(device=0, n_scans=3000):
     """BASELINE config[4]: lifelong-mode replay, end to end on one GPU -- scan queue -> mapper front end of the library
     (sequential match, links, speculative loop closure, SPA solves, node decay) -> occupancy grid (extra keys).  The
@@ -718,6 +769,19 @@ def main():
             strong_out = strong_leg(local_rank, rank, world)
         except Exception as exc:
             strong_out = {"strong_leg_error": repr(exc)[:200]}
+        # the in-process form (what the mapper front end uses): rank 0 drives one member per GPU of the run from ONE
+        # process, the other ranks wait; at N = 1 also two members sharing the GPU (the N > 1 code path on one device)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            try:
+                strong_out["strong_scaling_in_process"] = group_leg(list(range(world)))
+                if world == 1:
+                    strong_out["strong_scaling_in_process_two_members_one_gpu"] = group_leg([0, 0])
+            except Exception as exc:
+                strong_out["group_leg_error"] = repr(exc)[:200]
+        if world > 1:
+            dist.barrier()
     if rank == 0:
         k3_ms = prof["score_ms"] / max(1, prof["score_launches"])
         # a step's batch is scored in sub-batches (pipelined with the host half): matches per k_score launch

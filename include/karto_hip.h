@@ -113,6 +113,29 @@ KH_API int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * que
                                   double * means /* 3n */, double * covs /* 9n */,
                                   double * responses /* n */, int32_t * status /* n */);
 
+/* ---- the same batch over several devices of ONE process (loop-closure candidate batches shard
+ * across the GPUs of a node; replaces nothing in the reference, which walks the candidates one at a time,
+ * Mapper.cpp:1500-1561).  One matcher per entry of `devices` (the same device may be listed more than once: independent
+ * members sharing a GPU), each driven by its own host thread; candidate i goes to member i % n_members, every member
+ * works through its share in chunks of at most max_batch_per_member, and the results come back in candidate order -- what
+ * TryCloseLoop's first-acceptance rule needs.  No collective: the matches are independent.
+ * base_device_points: NULL, or n_members pointers per base scan, entry [t * n_members + k] = the copy of base[t]'s
+ * points_xy in the memory of member k's device (NULL = not resident there: the member uploads the scan itself);
+ * kh_scan.device_points_xy is only honoured by a one-member group without such a table. */
+typedef struct kh_matcher_group kh_matcher_group;
+KH_API int kh_matcher_group_create(double search_size, double resolution, double smear_deviation, double range_threshold,
+                                   const int32_t * devices, int32_t n_devices, int32_t max_batch_per_member,
+                                   kh_matcher_group ** out);
+KH_API void kh_matcher_group_destroy(kh_matcher_group * g);
+KH_API int kh_matcher_group_set_params(kh_matcher_group * g, const kh_match_params * p);
+KH_API int32_t kh_matcher_group_size(const kh_matcher_group * g);
+KH_API kh_matcher * kh_matcher_group_member(kh_matcher_group * g, int32_t index);     /* owned by the group */
+KH_API int32_t kh_matcher_group_device(const kh_matcher_group * g, int32_t index);
+KH_API int kh_matcher_group_match_batch(kh_matcher_group * g, int32_t n, const kh_scan * queries, const kh_scan * base,
+                                        const int32_t * base_begin, const double * const * base_device_points,
+                                        int32_t do_penalize, int32_t do_refine, double * means /* 3n */,
+                                        double * covs /* 9n */, double * responses /* n */, int32_t * status /* n */);
+
 /* MatchScan steps 1-4 + AddScans only (Mapper.cpp:543-574): centre the grid of batch slot
  * `slot` on the query's sensor pose and rasterise the base scans into it. */
 KH_API int kh_matcher_add_scans(kh_matcher * m, int32_t slot, const kh_scan * query,
@@ -239,7 +262,8 @@ typedef struct kh_spa_summary {
 KH_API int kh_spa_create(int32_t device, kh_spa ** out);
 /* Test / measurement switches, 0 = none.  Bit 0: every LM iteration also evaluates the residual of its linear solve from
  * the block-sparse matrix (kh_spa_summary.worst_linear_residual).  Bits 4-7: numeric factorisation kernels -- 0 default
- * (3), 3 level pipeline potrf/trsm/syrk, 2 panel-pair kernels, 1 their first form; all give the same factor. */
+ * (3), 3 level pipeline potrf/trsm/syrk, 2 panel-pair kernels, 1 their first form; all give the same factor.  Bit 8: the
+ * level pipeline reads the children's update matrices in place instead of running the extend-add launches. */
 KH_API int kh_spa_set_debug(kh_spa * s, int32_t flags);
 /* Multi-GPU (one process per GPU, every rank holds the same graph): rank r linearises the edge block
  * [E*r/world, E*(r+1)/world) into PARTIAL normal equations, and `allreduce` -- supplied by the host
@@ -478,6 +502,11 @@ KH_API void kh_mapper_params_default(kh_mapper_params * p);
 /* max_candidates = capacity of one matcher batch (near chains / loop candidates beyond it go in further batches) */
 KH_API int kh_mapper_create(const kh_mapper_params * params, const kh_laser * laser, int32_t device, int32_t max_candidates,
                             kh_mapper ** out);
+/* The same mapper with its candidate batches (loop closure, near chains) dealt over one matcher pair per entry of `devices`
+ * (kh_matcher_group); devices[0] also carries the sequential matches, the solver and the graph store.  The run is
+ * identical to the one-device mapper's: the matches are independent and are consumed in candidate order. */
+KH_API int kh_mapper_create_on_devices(const kh_mapper_params * params, const kh_laser * laser, const int32_t * devices,
+                                       int32_t n_devices, int32_t max_candidates, kh_mapper ** out);
 KH_API void kh_mapper_destroy(kh_mapper * m);
 /* Mapper::Process for one scan: `ranges` = laser->n_beams readings, the odometric pose of the robot, the time stamp.
  * *accepted = 0 when the scan is dropped by HasMovedEnough (Mapper.cpp:3110-3142).  corrected_pose / covariance may be NULL. */

@@ -70,6 +70,8 @@ SYMBOLS = [
     "kh_matcher_grid_info", "kh_matcher_read_grid", "kh_matcher_read_kernel", "kh_matcher_read_lookup",
     "kh_matcher_positional_covariance", "kh_matcher_angular_covariance",
     "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile", "kh_matcher_score_loads",
+    "kh_matcher_group_create", "kh_matcher_group_destroy", "kh_matcher_group_set_params", "kh_matcher_group_size", "kh_matcher_group_member",
+    "kh_matcher_group_device", "kh_matcher_group_match_batch",
     "kh_spa_options_default", "kh_spa_create", "kh_spa_set_debug", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
@@ -84,7 +86,7 @@ SYMBOLS = [
     "kh_comm_allreduce_sum_f64", "kh_comm_allgather_f64",
     "kh_device_malloc", "kh_device_free", "kh_device_upload", "kh_device_download",
     "kh_graph_find_loop_candidates_from",
-    "kh_mapper_params_default", "kh_mapper_create", "kh_mapper_destroy", "kh_mapper_process", "kh_mapper_num_scans",
+    "kh_mapper_params_default", "kh_mapper_create", "kh_mapper_create_on_devices", "kh_mapper_destroy", "kh_mapper_process", "kh_mapper_num_scans",
     "kh_mapper_num_edges", "kh_mapper_get_poses", "kh_mapper_get_scan", "kh_mapper_get_stats", "kh_mapper_solver",
     "kh_mapper_set_log", "kh_mapper_remove_node", "kh_mapper_set_lifelong", "kh_mapper_num_alive", "kh_mapper_get_alive",
     "kh_graph_set_scan_limit", "kh_graph_find_near_linked", "kh_graph_append_scan", "kh_graph_add_edge", "kh_graph_set_position",
@@ -164,6 +166,16 @@ def lib():
     L.kh_matcher_set_params.argtypes = [vp, C.POINTER(KhMatchParams)]
     L.kh_matcher_match.argtypes = [vp, C.POINTER(KhScan), C.POINTER(KhScan), i32, i32, i32, dptr, dptr, C.POINTER(dbl)]
     L.kh_matcher_match_batch.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), iptr, i32, i32, dptr, dptr, dptr, iptr]
+    if hasattr(L, "kh_matcher_group_create"):
+        L.kh_matcher_group_create.argtypes = [dbl, dbl, dbl, dbl, iptr, i32, i32, C.POINTER(vp)]
+        L.kh_matcher_group_destroy.argtypes = [vp]
+        L.kh_matcher_group_destroy.restype = None
+        L.kh_matcher_group_set_params.argtypes = [vp, C.POINTER(KhMatchParams)]
+        L.kh_matcher_group_size.argtypes = [vp]
+        L.kh_matcher_group_member.argtypes = [vp, i32]
+        L.kh_matcher_group_member.restype = vp
+        L.kh_matcher_group_device.argtypes = [vp, i32]
+        L.kh_matcher_group_match_batch.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), iptr, vp, i32, i32, dptr, dptr, dptr, iptr]
     L.kh_matcher_add_scans.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), i32]
     L.kh_matcher_correlate.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, C.POINTER(dbl)]
     L.kh_matcher_correlate_batch.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, dptr, iptr]
@@ -239,6 +251,7 @@ def lib():
         L.kh_mapper_params_default.argtypes = [C.POINTER(KhMapperParams)]
         L.kh_mapper_params_default.restype = None
         L.kh_mapper_create.argtypes = [C.POINTER(KhMapperParams), C.POINTER(KhLaser), i32, i32, C.POINTER(vp)]
+        L.kh_mapper_create_on_devices.argtypes = [C.POINTER(KhMapperParams), C.POINTER(KhLaser), iptr, i32, i32, C.POINTER(vp)]
         L.kh_mapper_destroy.argtypes = [vp]
         L.kh_mapper_destroy.restype = None
         L.kh_mapper_process.argtypes = [vp, dptr, dptr, dbl, C.POINTER(i32), dptr, dptr]

@@ -122,8 +122,9 @@ struct MScan
   int32_t n_filtered = 0;
   // the unfiltered readings once more, in HBM: as a base scan of a match the scan is read where it lies (kh_scan::
   // device_points_xy).  Uploaded on first use and again after the pose has moved (update_scan marks it stale).
-  double * d_points = nullptr;
-  bool d_stale = true;
+  static constexpr int kMaxDeviceSlots = 16;
+  double * d_points[kMaxDeviceSlots] = {};       // one copy per distinct device of the mapper (slot 0 = the mapper's own device)
+  uint16_t d_fresh = 0;                          // bit k: the copy in slot k holds the current points
   Pose sensor_pose() const {Pose p = corrected; p.h = normalize_angle(corrected.h); return p;}
   MScan() = default;
   MScan(const MScan &) = delete;
@@ -138,7 +139,7 @@ void update_scan(MScan & s, const Laser & L)
 {
   const Pose sp = s.sensor_pose();
   s.points.resize(2 * static_cast<size_t>(L.n));
-  s.d_stale = true;
+  s.d_fresh = 0;
   s.filtered.clear();
   double sum_x = 0.0, sum_y = 0.0;
   int32_t n_filtered = 0;
@@ -175,8 +176,15 @@ struct kh_mapper
   kh_mapper_params p;
   Laser laser;
   int32_t device = 0, max_candidates = 64;
-  kh_matcher * seq = nullptr;
-  kh_matcher * loop = nullptr;
+  kh_matcher * seq = nullptr;                            // = member 0 of seq_group
+  kh_matcher * loop = nullptr;                           // = member 0 of loop_group
+  // candidate batches (loop closure, near chains) are dealt over the members of these groups: one member per entry of the
+  // device list the mapper was created on (kh_mapper_create_on_devices), each with its own scan copies
+  kh_matcher_group * seq_group = nullptr;
+  kh_matcher_group * loop_group = nullptr;
+  std::vector<int32_t> member_device;                    // device of member k
+  std::vector<int32_t> member_slot;                      // scan-copy slot of member k (members on one device share a slot)
+  int32_t n_slots = 1;
   kh_spa * solver = nullptr;
   kh_graph * graph = nullptr;
   std::vector<std::unique_ptr<MScan>> scans;             // processed scans, index = state id = unique id; null once removed
@@ -197,7 +205,8 @@ struct kh_mapper
   kh_mapper_stats stats;
   // device copies of the scans' readings: slots of 2 * laser.n doubles carved from slabs of 256 (one hipMalloc per 256
   // scans instead of one per scan), recycled when a node is removed
-  std::vector<double *> d_slabs, d_free_slots;
+  std::vector<double *> d_slabs[MScan::kMaxDeviceSlots], d_free_slots[MScan::kMaxDeviceSlots];
+  std::vector<int32_t> slot_device;                      // device of scan-copy slot q
 };
 
 namespace kh
@@ -217,26 +226,37 @@ kh_scan as_kh_scan(const MScan & s)
   return k;
 }
 
-// the scan as a BASE scan of a match: its readings resident on the mapper's device
+// the scan's readings resident in scan-copy slot `slot` (= on that slot's device): the device address, or NULL when the
+// copy could not be made (the match call then uploads the scan itself)
+const double * resident_points(kh_mapper * m, MScan & s, int slot)
+{
+  const int64_t bytes = static_cast<int64_t>(sizeof(double)) * static_cast<int64_t>(s.points.size());
+  if (bytes <= 0 || s.points.size() != 2 * static_cast<size_t>(m->laser.n)) {return nullptr;}
+  if (!s.d_points[slot]) {
+    if (m->d_free_slots[slot].empty()) {
+      constexpr int kSlabScans = 256;
+      void * p = nullptr;
+      if (kh_device_malloc(m->slot_device[slot], bytes * kSlabScans, &p) == KH_OK) {
+        m->d_slabs[slot].push_back(static_cast<double *>(p));
+        for (int k = kSlabScans - 1; k >= 0; --k) {m->d_free_slots[slot].push_back(static_cast<double *>(p) + static_cast<size_t>(k) * s.points.size());}
+      }
+    }
+    if (!m->d_free_slots[slot].empty()) {
+      s.d_points[slot] = m->d_free_slots[slot].back(); m->d_free_slots[slot].pop_back();
+      s.d_fresh &= static_cast<uint16_t>(~(1u << slot));
+    }
+  }
+  if (s.d_points[slot] && !(s.d_fresh & (1u << slot)) && kh_device_upload(s.d_points[slot], s.points.data(), bytes) == KH_OK) {
+    s.d_fresh |= static_cast<uint16_t>(1u << slot);
+  }
+  return (s.d_points[slot] && (s.d_fresh & (1u << slot))) ? s.d_points[slot] : nullptr;
+}
+
+// the scan as a BASE scan of a match on the mapper's own device: its readings resident there
 kh_scan as_base_scan(kh_mapper * m, MScan & s)
 {
   kh_scan k = as_kh_scan(s);
-  const int64_t bytes = static_cast<int64_t>(sizeof(double)) * static_cast<int64_t>(s.points.size());
-  if (bytes > 0 && s.points.size() == 2 * static_cast<size_t>(m->laser.n)) {
-    if (!s.d_points) {
-      if (m->d_free_slots.empty()) {
-        constexpr int kSlabScans = 256;
-        void * p = nullptr;
-        if (kh_device_malloc(m->device, bytes * kSlabScans, &p) == KH_OK) {
-          m->d_slabs.push_back(static_cast<double *>(p));
-          for (int k = kSlabScans - 1; k >= 0; --k) {m->d_free_slots.push_back(static_cast<double *>(p) + static_cast<size_t>(k) * s.points.size());}
-        }
-      }
-      if (!m->d_free_slots.empty()) {s.d_points = m->d_free_slots.back(); m->d_free_slots.pop_back(); s.d_stale = true;}
-    }
-    if (s.d_points && s.d_stale && kh_device_upload(s.d_points, s.points.data(), bytes) == KH_OK) {s.d_stale = false;}
-    if (s.d_points && !s.d_stale) {k.device_points_xy = s.d_points;}      // any failure: the call uploads the scan itself
-  }
+  k.device_points_xy = resident_points(m, s, 0);
   return k;
 }
 
@@ -397,35 +417,42 @@ int correct_poses(kh_mapper * m)
 
 struct MatchOut {double response; double mean[3]; double cov[9];};
 
-// n independent MatchScan calls (query i against chain i) on `matcher`, in batches of the matcher's capacity
-int match_chains(kh_mapper * m, kh_matcher * matcher, const std::vector<kh_scan> & queries, const std::vector<std::vector<int32_t>> & chains,
+// n independent MatchScan calls (query i against chain i) on the members of `group` (candidate i on member i % members,
+// each member on the scan copies of its own device), results in candidate order
+int match_chains(kh_mapper * m, kh_matcher_group * group, const std::vector<kh_scan> & queries, const std::vector<std::vector<int32_t>> & chains,
   bool penalize, bool refine, std::vector<MatchOut> & out)
 {
   const size_t n = chains.size();
   out.assign(n, MatchOut());
-  const size_t cap = static_cast<size_t>(m->max_candidates);
-  for (size_t at = 0; at < n; at += cap) {
-    const size_t nb = std::min(cap, n - at);
-    std::vector<kh_scan> base;
-    std::vector<int32_t> begin(nb + 1, 0);
-    for (size_t i = 0; i < nb; ++i) {
-      for (int32_t c : chains[at + i]) {base.push_back(as_base_scan(m, *m->scans[c]));}
-      begin[i + 1] = static_cast<int32_t>(base.size());
+  if (n == 0) {return KH_OK;}
+  const int32_t nm = kh_matcher_group_size(group);
+  std::vector<kh_scan> base;
+  std::vector<int32_t> begin(n + 1, 0);
+  std::vector<const double *> table;
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t member = static_cast<int32_t>(i % static_cast<size_t>(nm));
+    for (int32_t c : chains[i]) {
+      MScan & s = *m->scans[c];
+      base.push_back(as_kh_scan(s));
+      const size_t row = table.size();
+      table.resize(row + static_cast<size_t>(nm), nullptr);
+      table[row + member] = resident_points(m, s, m->member_slot[member]);       // only the member that will read it
     }
-    std::vector<double> means(3 * nb), covs(9 * nb), resp(nb);
-    std::vector<int32_t> status(nb, 0);
-    const auto t0 = std::chrono::steady_clock::now();
-    const int rc = kh_matcher_match_batch(matcher, static_cast<int32_t>(nb), queries.data() + at, base.data(), begin.data(),
-        penalize ? 1 : 0, refine ? 1 : 0, means.data(), covs.data(), resp.data(), status.data());
-    m->stats.match_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    m->stats.matches += static_cast<int64_t>(nb);
-    if (rc) {return rc;}
-    for (size_t i = 0; i < nb; ++i) {
-      if (status[i] != KH_OK) {return status[i];}             // the reference throws (Mapper.cpp:786-796, 828)
-      out[at + i].response = resp[i];
-      std::copy(means.begin() + 3 * i, means.begin() + 3 * i + 3, out[at + i].mean);
-      std::copy(covs.begin() + 9 * i, covs.begin() + 9 * i + 9, out[at + i].cov);
-    }
+    begin[i + 1] = static_cast<int32_t>(base.size());
+  }
+  std::vector<double> means(3 * n), covs(9 * n), resp(n);
+  std::vector<int32_t> status(n, 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = kh_matcher_group_match_batch(group, static_cast<int32_t>(n), queries.data(), base.data(), begin.data(), table.data(),
+      penalize ? 1 : 0, refine ? 1 : 0, means.data(), covs.data(), resp.data(), status.data());
+  m->stats.match_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  m->stats.matches += static_cast<int64_t>(n);
+  if (rc) {return rc;}
+  for (size_t i = 0; i < n; ++i) {
+    if (status[i] != KH_OK) {return status[i];}             // the reference throws (Mapper.cpp:786-796, 828)
+    out[i].response = resp[i];
+    std::copy(means.begin() + 3 * i, means.begin() + 3 * i + 3, out[i].mean);
+    std::copy(covs.begin() + 9 * i, covs.begin() + 9 * i + 9, out[i].cov);
   }
   return KH_OK;
 }
@@ -468,7 +495,7 @@ int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
     MScan & scan = *m->scans[scan_id];
     // coarse: m_pLoopScanMatcher->MatchScan(pScan, candidateChain, bestPose, covariance, false, false), all chains at once
     std::vector<MatchOut> coarse;
-    rc = match_chains(m, m->loop, std::vector<kh_scan>(chains.size(), as_kh_scan(scan)), chains, false, false, coarse);
+    rc = match_chains(m, m->loop_group, std::vector<kh_scan>(chains.size(), as_kh_scan(scan)), chains, false, false, coarse);
     if (rc) {return rc;}
     std::vector<int32_t> passing;
     for (int32_t c = 0; c < n_chains; ++c) {
@@ -492,7 +519,7 @@ int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
       tmp.push_back(std::move(t));
     }
     std::vector<MatchOut> fine;
-    rc = match_chains(m, m->seq, fine_queries, fine_chains, false, true, fine);
+    rc = match_chains(m, m->seq_group, fine_queries, fine_chains, false, true, fine);
     if (rc) {return rc;}
     // consume in the reference's order up to the first accepted closure
     int32_t accepted = -1;
@@ -540,7 +567,9 @@ int remove_node(kh_mapper * m, int32_t id)
   const int rc = kh_spa_remove_node(m->solver, id);
   if (rc != KH_OK && rc != KH_ERR_NOT_FOUND) {return rc;}
   m->adj[id].clear(); m->out_edges[id].clear();
-  if (m->scans[id]->d_points) {m->d_free_slots.push_back(m->scans[id]->d_points);}
+  for (int q = 0; q < m->n_slots; ++q) {
+    if (m->scans[id]->d_points[q]) {m->d_free_slots[q].push_back(m->scans[id]->d_points[q]);}
+  }
   m->scans[id].reset();
   m->graph_dirty = true;
   m->stats.nodes_removed += 1;
@@ -624,38 +653,65 @@ void kh_mapper_params_default(kh_mapper_params * p)
   p->match.angle_variance_penalty = 1.0 * 1.0; p->match.minimum_angle_penalty = 0.9;
 }
 
-int kh_mapper_create(const kh_mapper_params * params, const kh_laser * laser, int32_t device, int32_t max_candidates, kh_mapper ** out)
+int kh_mapper_create_on_devices(const kh_mapper_params * params, const kh_laser * laser, const int32_t * devices, int32_t n_devices,
+  int32_t max_candidates, kh_mapper ** out)
 {
-  if (!out || !params || !laser || laser->n_beams <= 0 || max_candidates < 1) {return KH_ERR_INVALID_ARG;}
+  if (!out || !params || !laser || laser->n_beams <= 0 || max_candidates < 1 || !devices || n_devices < 1) {return KH_ERR_INVALID_ARG;}
   *out = nullptr;
   std::unique_ptr<kh_mapper> m(new kh_mapper());
-  m->p = *params; m->device = device; m->max_candidates = max_candidates;
+  m->p = *params; m->device = devices[0]; m->max_candidates = max_candidates;
   m->laser.n = laser->n_beams; m->laser.min_angle = laser->minimum_angle; m->laser.ang_res = laser->angular_resolution;
   m->laser.min_range = laser->minimum_range; m->laser.max_range = laser->maximum_range; m->laser.range_threshold = laser->range_threshold;
   std::memset(&m->stats, 0, sizeof(m->stats));
   auto fail = [&](int rc) {kh_mapper_destroy(m.release()); return rc;};
-  // Mapper::Initialize (Mapper.cpp:2606-2631): the sequential matcher; MapperGraph's constructor: the loop matcher (:1397-1400)
-  int rc = kh_matcher_create(params->correlation_search_space_dimension, params->correlation_search_space_resolution,
-      params->correlation_search_space_smear_deviation, laser->range_threshold, device, max_candidates, &m->seq);
+  // scan copies: one slot per DISTINCT device (members that share a device share the copies)
+  for (int32_t k = 0; k < n_devices; ++k) {
+    int32_t slot = -1;
+    for (size_t q = 0; q < m->slot_device.size(); ++q) {if (m->slot_device[q] == devices[k]) {slot = static_cast<int32_t>(q);}}
+    if (slot < 0) {
+      if (static_cast<int>(m->slot_device.size()) >= MScan::kMaxDeviceSlots) {
+        kh::set_error("kh_mapper_create_on_devices: more than 16 distinct devices");
+        return fail(KH_ERR_INVALID_ARG);
+      }
+      slot = static_cast<int32_t>(m->slot_device.size());
+      m->slot_device.push_back(devices[k]);
+    }
+    m->member_device.push_back(devices[k]);
+    m->member_slot.push_back(slot);
+  }
+  m->n_slots = static_cast<int32_t>(m->slot_device.size());
+  // Mapper::Initialize (Mapper.cpp:2606-2631): the sequential matcher; MapperGraph's constructor: the loop matcher (:1397-1400);
+  // here one of each per member, member 0 = the reference's two matchers
+  int rc = kh_matcher_group_create(params->correlation_search_space_dimension, params->correlation_search_space_resolution,
+      params->correlation_search_space_smear_deviation, laser->range_threshold, devices, n_devices, max_candidates, &m->seq_group);
   if (rc) {return fail(rc);}
-  rc = kh_matcher_create(params->loop_search_space_dimension, params->loop_search_space_resolution,
-      params->loop_search_space_smear_deviation, laser->range_threshold, device, max_candidates, &m->loop);
+  rc = kh_matcher_group_create(params->loop_search_space_dimension, params->loop_search_space_resolution,
+      params->loop_search_space_smear_deviation, laser->range_threshold, devices, n_devices, max_candidates, &m->loop_group);
   if (rc) {return fail(rc);}
-  rc = kh_matcher_set_params(m->seq, &params->match); if (rc) {return fail(rc);}
-  rc = kh_matcher_set_params(m->loop, &params->match); if (rc) {return fail(rc);}
-  rc = kh_spa_create(device, &m->solver); if (rc) {return fail(rc);}
-  rc = kh_graph_create(device, &m->graph); if (rc) {return fail(rc);}
+  rc = kh_matcher_group_set_params(m->seq_group, &params->match); if (rc) {return fail(rc);}
+  rc = kh_matcher_group_set_params(m->loop_group, &params->match); if (rc) {return fail(rc);}
+  m->seq = kh_matcher_group_member(m->seq_group, 0);
+  m->loop = kh_matcher_group_member(m->loop_group, 0);
+  rc = kh_spa_create(m->device, &m->solver); if (rc) {return fail(rc);}
+  rc = kh_graph_create(m->device, &m->graph); if (rc) {return fail(rc);}
   *out = m.release();
   return KH_OK;
+}
+
+int kh_mapper_create(const kh_mapper_params * params, const kh_laser * laser, int32_t device, int32_t max_candidates, kh_mapper ** out)
+{
+  return kh_mapper_create_on_devices(params, laser, &device, 1, max_candidates, out);
 }
 
 void kh_mapper_destroy(kh_mapper * m)
 {
   if (!m) {return;}
   if (m->log) {std::fclose(m->log);}
-  kh_matcher_destroy(m->seq); kh_matcher_destroy(m->loop);
+  kh_matcher_group_destroy(m->seq_group); kh_matcher_group_destroy(m->loop_group);
   kh_spa_destroy(m->solver); kh_graph_destroy(m->graph);
-  for (double * slab : m->d_slabs) {kh_device_free(slab);}
+  for (auto & slabs : m->d_slabs) {
+    for (double * slab : slabs) {kh_device_free(slab);}
+  }
   delete m;
 }
 
@@ -776,7 +832,7 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
         chains.push_back(run_of(m, flat[2 * c], flat[2 * c + 1]));
       }
       std::vector<MatchOut> res;
-      rc = match_chains(m, m->seq, std::vector<kh_scan>(chains.size(), as_kh_scan(s)), chains, false, true, res);
+      rc = match_chains(m, m->seq_group, std::vector<kh_scan>(chains.size(), as_kh_scan(s)), chains, false, true, res);
       if (rc) {return rc;}
       for (size_t c = 0; c < chains.size(); ++c) {
         if (res[c].response > m->p.link_match_minimum_response_fine - kTolerance) {

@@ -1,0 +1,141 @@
+// In-process multi-device candidate sharding: one scan matcher per device of a list, a
+// batch of independent (query, base chain) matches dealt round robin to the members, every member driven by its own host
+// thread, results written back in candidate order.
+//
+// Reference behaviour this has to preserve: MapperGraph::TryCloseLoop (lib/karto_sdk/src/Mapper.cpp:1500-1561) walks the
+// candidate chains in order and accepts the FIRST that passes -- so the caller needs every result in candidate order, and
+// the matches themselves are independent (each owns its correlation grid), which is why they shard without a collective:
+// one 8-GPU node is one process's worth of devices.  The same device may be listed more than once (two members on one
+// GPU): that is how a 1-GPU box exercises the N > 1 path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/karto_hip.h"
+
+namespace kh
+{
+void set_error(const std::string & s);
+}
+
+struct kh_matcher_group
+{
+  std::vector<kh_matcher *> members;
+  std::vector<int32_t> devices;
+  int32_t max_batch = 0;
+};
+
+extern "C" {
+
+int kh_matcher_group_create(double search_size, double resolution, double smear_deviation, double range_threshold,
+  const int32_t * devices, int32_t n_devices, int32_t max_batch_per_member, kh_matcher_group ** out)
+{
+  if (!out || !devices || n_devices < 1 || max_batch_per_member < 1) {return KH_ERR_INVALID_ARG;}
+  *out = nullptr;
+  kh_matcher_group * g = new kh_matcher_group();
+  g->max_batch = max_batch_per_member;
+  for (int32_t k = 0; k < n_devices; ++k) {
+    kh_matcher * m = nullptr;
+    const int rc = kh_matcher_create(search_size, resolution, smear_deviation, range_threshold, devices[k], max_batch_per_member, &m);
+    if (rc) {kh_matcher_group_destroy(g); return rc;}
+    g->members.push_back(m);
+    g->devices.push_back(devices[k]);
+  }
+  *out = g;
+  return KH_OK;
+}
+
+void kh_matcher_group_destroy(kh_matcher_group * g)
+{
+  if (!g) {return;}
+  for (kh_matcher * m : g->members) {kh_matcher_destroy(m);}
+  delete g;
+}
+
+int kh_matcher_group_set_params(kh_matcher_group * g, const kh_match_params * p)
+{
+  if (!g || !p) {return KH_ERR_INVALID_ARG;}
+  for (kh_matcher * m : g->members) {
+    const int rc = kh_matcher_set_params(m, p);
+    if (rc) {return rc;}
+  }
+  return KH_OK;
+}
+
+int32_t kh_matcher_group_size(const kh_matcher_group * g) {return g ? static_cast<int32_t>(g->members.size()) : 0;}
+
+kh_matcher * kh_matcher_group_member(kh_matcher_group * g, int32_t index)
+{
+  return (g && index >= 0 && index < static_cast<int32_t>(g->members.size())) ? g->members[index] : nullptr;
+}
+
+int32_t kh_matcher_group_device(const kh_matcher_group * g, int32_t index)
+{
+  return (g && index >= 0 && index < static_cast<int32_t>(g->devices.size())) ? g->devices[index] : -1;
+}
+
+int kh_matcher_group_match_batch(kh_matcher_group * g, int32_t n, const kh_scan * queries, const kh_scan * base, const int32_t * base_begin,
+  const double * const * base_device_points, int32_t do_penalize, int32_t do_refine, double * means, double * covs, double * responses,
+  int32_t * status)
+{
+  if (!g || n < 0 || !queries || !base_begin || !means || !covs || !responses) {return KH_ERR_INVALID_ARG;}
+  const int32_t nm = static_cast<int32_t>(g->members.size());
+  struct Share
+  {
+    std::vector<int32_t> pairs;                  // candidate indices of this member, ascending
+    int rc = KH_OK;
+    std::string error;
+  };
+  std::vector<Share> shares(nm);
+  for (int32_t i = 0; i < n; ++i) {shares[i % nm].pairs.push_back(i);}
+  auto run = [&](int32_t k) {
+    Share & sh = shares[k];
+    const int32_t cap = g->max_batch;
+    for (size_t at = 0; at < sh.pairs.size() && sh.rc == KH_OK; at += static_cast<size_t>(cap)) {
+      const int32_t nb = static_cast<int32_t>(std::min<size_t>(cap, sh.pairs.size() - at));
+      std::vector<kh_scan> q(nb), b;
+      std::vector<int32_t> begin(nb + 1, 0);
+      for (int32_t j = 0; j < nb; ++j) {
+        const int32_t i = sh.pairs[at + j];
+        q[j] = queries[i];
+        for (int32_t t = base_begin[i]; t < base_begin[i + 1]; ++t) {
+          kh_scan s = base[t];
+          // a device copy is only good on the device it lives on: the caller's table names the copy of (scan, member)
+          s.device_points_xy = base_device_points ? base_device_points[static_cast<size_t>(t) * nm + k] : (nm == 1 ? base[t].device_points_xy : nullptr);
+          b.push_back(s);
+        }
+        begin[j + 1] = static_cast<int32_t>(b.size());
+      }
+      std::vector<double> mean(3 * static_cast<size_t>(nb)), cov(9 * static_cast<size_t>(nb)), resp(nb);
+      std::vector<int32_t> st(nb, KH_OK);
+      sh.rc = kh_matcher_match_batch(g->members[k], nb, q.data(), b.empty() ? nullptr : b.data(), begin.data(), do_penalize, do_refine,
+          mean.data(), cov.data(), resp.data(), st.data());
+      if (sh.rc) {sh.error = kh_last_error(); break;}          // the message is thread local: carried to the caller below
+      for (int32_t j = 0; j < nb; ++j) {
+        const int32_t i = sh.pairs[at + j];
+        std::copy(mean.begin() + 3 * j, mean.begin() + 3 * j + 3, means + 3 * static_cast<size_t>(i));
+        std::copy(cov.begin() + 9 * j, cov.begin() + 9 * j + 9, covs + 9 * static_cast<size_t>(i));
+        responses[i] = resp[j];
+        if (status) {status[i] = st[j];}
+      }
+    }
+  };
+  // member 0 works on the calling thread; members without work get no thread
+  std::vector<std::thread> threads;
+  for (int32_t k = 1; k < nm; ++k) {
+    if (!shares[k].pairs.empty()) {threads.emplace_back(run, k);}
+  }
+  if (!shares[0].pairs.empty()) {run(0);}
+  for (std::thread & t : threads) {t.join();}
+  for (int32_t k = 0; k < nm; ++k) {
+    if (shares[k].rc) {kh::set_error(shares[k].error); return shares[k].rc;}
+  }
+  return KH_OK;
+}
+
+}  // extern "C"

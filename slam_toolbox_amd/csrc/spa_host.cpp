@@ -120,6 +120,7 @@ struct kh_spa
   DevBuf<int64_t> d_front_off, d_slot_dest, d_winv_off;
   DevBuf<double> d_winv;                       // L11^-T of every front (level pipeline, round 3)
   DevBuf<FrontDesc> d_desc;
+  DevBuf<int32_t> d_cinv;
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
@@ -423,8 +424,13 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       std::memset(&fd, 0, sizeof(fd));
       fd.off = sym.front_off[k]; fd.woff = sym.winv_off[k]; fd.m = sym.front_m[k]; fd.ns = sym.front_ns[k]; fd.first = sym.front_first[k];
       fd.rows_ptr = sym.rows_ptr[k]; fd.child_ptr = sym.child_ptr[k]; fd.child_end = sym.child_ptr[k + 1];
-      fd.relpos_ptr = sym.relpos_ptr[k]; fd.parent = sym.parent[k];
+      fd.relpos_ptr = sym.relpos_ptr[k]; fd.parent = sym.parent[k]; fd.cinv_ptr = sym.cinv_ptr[k];
+      for (int32_t q = 0; q < 3 && fd.child_ptr + q < fd.child_end; ++q) {
+        const int32_t c = sym.child_list[fd.child_ptr + q];
+        fd.ch[q].off = sym.front_off[c]; fd.ch[q].m = sym.front_m[c]; fd.ch[q].ns = sym.front_ns[c]; fd.ch[q].rows_ptr = sym.rows_ptr[c];
+      }
     }
+    r2 |= s->d_cinv.upload(sym.cinv, st);
     r2 |= s->d_desc.upload(desc, st);
     r2 |= s->d_winv.ensure(static_cast<size_t>(sym.winv_size) + 16);
     if (r2) {return KH_ERR_HIP;}
@@ -483,7 +489,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   dev.slot_dest = s->d_slot_dest.p; dev.slot_ld = s->d_slot_ld.p;
   dev.elim_of_free = s->d_elim_of_free.p; dev.free_of_elim = s->d_free_of_elim.p;
   dev.fronts = s->d_fronts.p; dev.fronts_size = sym.fronts_size;
-  dev.winv = s->d_winv.p; dev.winv_off = s->d_winv_off.p; dev.desc = s->d_desc.p;
+  dev.winv = s->d_winv.p; dev.winv_off = s->d_winv_off.p; dev.desc = s->d_desc.p; dev.cinv = s->d_cinv.p;
   has_work = true;
   return KH_OK;
 }
@@ -539,7 +545,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_front_ns.release(); s->d_front_first.release(); s->d_rows_ptr.release(); s->d_rows.release();
   s->d_child_ptr.release(); s->d_child_list.release(); s->d_relpos_ptr.release(); s->d_relpos.release();
   s->d_slot_ld.release(); s->d_elim_of_free.release(); s->d_free_of_elim.release(); s->d_level_fronts.release();
-  s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_winv_off.release(); s->d_winv.release(); s->d_desc.release(); s->d_edge_z.release(); s->d_edge_u.release();
+  s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_winv_off.release(); s->d_winv.release(); s->d_desc.release(); s->d_cinv.release(); s->d_edge_z.release(); s->d_edge_u.release();
   s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
   s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release(); s->d_partial.release(); s->d_Hg_alt.release(); s->d_best.release();
@@ -1055,11 +1061,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   const int32_t e_hi = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * (s->shard_rank + 1) / s->shard_world);
   const int64_t hg_count = static_cast<int64_t>(s->n_slots) * 9 + static_cast<int64_t>(dev.n_free) * 3;
   int n_lin = 0, n_timed = 0;
-  auto linearize = [&](const SpaDev & into, const double * at, double * cost_slot) -> int {
-    const bool timed = n_lin < 2 * kh_spa::kMaxTimed + 2;
-    if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
-    spa_launch_linearize(into, at, cost_slot, e_lo, e_hi, st);
-    if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
+  auto allreduce_Hg = [&](const SpaDev & into) -> int {
     if (s->comm) {
       // H || g of this rank's edge block -> sums over all ranks, on the solver's stream (RCCL over xGMI)
       const int arc = kh_comm_allreduce_sum_f64(s->comm, into.H, hg_count, st);
@@ -1069,6 +1071,13 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       if (s->allreduce(s->allreduce_user, into.H, hg_count, st) != 0) {set_error("kh_spa: all-reduce callback failed"); return KH_ERR_SOLVER;}
     }
     return KH_OK;
+  };
+  auto linearize = [&](const SpaDev & into, const double * at, double * cost_slot) -> int {
+    const bool timed = n_lin < 2 * kh_spa::kMaxTimed + 2;
+    if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
+    spa_launch_linearize(into, at, cost_slot, e_lo, e_hi, st);
+    if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
+    return allreduce_Hg(into);
   };
   // The normal equations at the CANDIDATE point are built speculatively, into a second H || g, in the same batch of
   // launches that evaluates the candidate's cost: a step is nearly always accepted, and the iteration then needs one
@@ -1150,7 +1159,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       const int32_t n_level = s->level_offsets[l + 1] - s->level_offsets[l];
       const int32_t * lf = s->d_level_fronts.p + s->level_offsets[l];
       if (pipeline) {
-        if (l > 0) {spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st);}
+        if (l > 0 && !dev.gather) {spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st);}
         spa_launch_factor3_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
         dbg("potrf+trsm+syrk", l);
         continue;
@@ -1176,13 +1185,16 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     static const bool speculate = !(std::getenv("KH_SPA_SPECULATE") && std::atoi(std::getenv("KH_SPA_SPECULATE")) == 0);
     static const bool lin_check_env = std::getenv("KH_SPA_CHECK") != nullptr;
     const bool lin_check = lin_check_env || (s->debug_flags & 1);
-    const bool fused_step = speculate && s->shard_world == 1 && !s->comm && !(std::getenv("KH_SPA_FUSED_STEP") && std::atoi(std::getenv("KH_SPA_FUSED_STEP")) == 0);
+    const bool fused_step = speculate && !(std::getenv("KH_SPA_FUSED_STEP") && std::atoi(std::getenv("KH_SPA_FUSED_STEP")) == 0);
     if (fused_step) {
       // the candidate's cost AND its normal equations (speculative: a step is nearly always accepted) ride in the same batch
       const bool timed_lin = n_lin < 2 * kh_spa::kMaxTimed + 2;
       if (timed_lin) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
-      spa_launch_step_and_linearize(dev, alt, s->d_scale.p, s->d_rhs.p, x, s->d_step.p, s->d_delta.p, cand, s->d_partial.p, scal, st);
+      spa_launch_step_and_linearize(dev, alt, s->d_scale.p, s->d_rhs.p, x, s->d_step.p, s->d_delta.p, cand, s->d_partial.p, e_lo, e_hi, st);
       if (timed_lin) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
+      // a communicator (or a sharding callback) sums this rank's H || g with the others', also with one rank (identity)
+      rc = allreduce_Hg(alt); if (rc) {return finish(rc);}
+      spa_launch_step_scalars(alt, cand, s->d_partial.p, e_lo > 0 || e_hi < dev.n_edges, scal, st);
       if (lin_check) {spa_launch_lin_check(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, s->d_step.p, scal + 12, st);}
       if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
     } else {

@@ -6,8 +6,16 @@
 namespace kh
 {
 
-// Everything a workgroup of the level pipeline needs to know about its front, in one 64-byte record (fronts are numbered
-// level by level, so a level's records are contiguous)
+// Everything a workgroup of the level pipeline needs to know about its front, in one 128-byte record (fronts are numbered
+// level by level, so a level's records are contiguous), including where its first three children's update matrices are: a
+// front READS its children's contributions when it loads its own entries (no extend-add pass over the parent).
+struct ChildInfo
+{
+  int64_t off;             // offset (doubles) of the child front in `fronts`
+  int32_t m, ns;           // its dimension and pivot count: the update matrix is the trailing (m - ns)^2 block
+  int32_t rows_ptr;        // 3 * rows_ptr = the child's slot in upd (forward-solve contributions)
+  int32_t pad;
+};
 struct alignas(16) FrontDesc
 {
   int64_t off;             // offset (doubles) of the front in `fronts`
@@ -18,9 +26,11 @@ struct alignas(16) FrontDesc
   int32_t child_ptr, child_end;      // children in child_list
   int32_t relpos_ptr;      // positions of its struct rows inside the parent front (node units) in relpos
   int32_t parent;
-  int32_t pad[4];
+  int32_t cinv_ptr;        // gather maps in cinv: child number s -> cinv[cinv_ptr + s * (m / 3) + position] = child row or -1
+  int32_t pad0;
+  ChildInfo ch[3];
 };
-static_assert(sizeof(FrontDesc) == 64, "FrontDesc is one 64-byte record");
+static_assert(sizeof(FrontDesc) == 128, "FrontDesc is one 128-byte record");
 
 // Device view of one linear-algebra problem instance.  All pointers are device pointers.
 struct SpaDev
@@ -73,6 +83,8 @@ struct SpaDev
   double * winv;
   const int64_t * winv_off;
   const FrontDesc * desc;
+  const int32_t * cinv;
+  int32_t gather;          // 1: fronts read their children's update matrices in place; 0: spa_launch_extend_add has summed them in
 };
 
 // [e_lo, e_hi): edge block linearised by this rank (0, n_edges on a single GPU)
@@ -106,11 +118,14 @@ void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, v
 void spa_launch_finish_step(const SpaDev & d, const double * scale, const double * rhs, double * step, double * delta, void * stream);
 // out[0] = step.gs, out[1] = step^T Hs step, out[2] = any non-finite in step
 void spa_launch_model(const SpaDev & d, const double * scale, const double * step, double * out3, void * stream);
-// single GPU: step = -y, delta, cand = Plus(x, delta), the model-cost terms and step norms from `cur` (scal[3..7]); cost,
-// normal equations and gradient norms of the candidate into `alt` (scal[8..10]).  partial: spa_step_partials_size doubles.
+// step = -y, delta, cand = Plus(x, delta), the model-cost terms and step norms from `cur`; cost and normal equations of
+// the candidate (this rank's edge block [e_lo, e_hi)) into `alt`.  A sharded caller sums alt.H || alt.g over the ranks, then
+// spa_launch_step_scalars leaves scal[3..7] (step), scal[8] (cost), scal[9..10] (gradient norms).
+// partial: spa_step_partials_size doubles.
 int64_t spa_step_partials_size(const SpaDev & d);
 void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const double * scale, const double * rhs, const double * x, double * step,
-                                   double * delta, double * cand, double * partial, double * scal, void * stream);
+                                   double * delta, double * cand, double * partial, int e_lo, int e_hi, void * stream);
+void spa_launch_step_scalars(const SpaDev & alt, const double * cand, double * partial, bool sharded, double * scal, void * stream);
 // debugging aid (KH_SPA_CHECK): out[0] = |(Hs + D / radius) step + gs|^2, out[1] = |gs|^2 from the BSR matrix
 void spa_launch_lin_check(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, const double * step, double * out2,
                           void * stream);

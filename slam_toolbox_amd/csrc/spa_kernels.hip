@@ -490,19 +490,54 @@ int64_t spa_step_partials_size(const SpaDev & d)
   return 5 * (int64_t)((d.n_free + 255) / 256) + (d.n_edges + 255) / 256 + 2 * (int64_t)((3 * d.n_free + 255) / 256) + 16;
 }
 
+// projected-gradient norm partials on their own (sharded runs: g is only complete after the all-reduce); the same
+// arithmetic and the same partial layout as k_gather_g_norms
+__global__ __launch_bounds__(256) void k_grad_norm_partials(SpaDev d, const double * __restrict__ x, double * partial)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  double p[2] = {0.0, 0.0};
+  if (t < d.n_free * 3) {
+    const int i = t / 3, comp = t - i * 3;
+    const double acc = d.g[t];
+    const double v = x[3 * d.node_of_free[i] + comp];
+    const double moved = comp == 2 ? d_normalize_angle(v - acc) : v - acc;
+    p[0] = fabs(v - moved);
+    p[1] = v * v;
+  }
+  block_reduce_store<2>(p, 1, partial + 2 * blockIdx.x);
+}
+
+// first half: everything up to H and g of this rank's edge block [e_lo, e_hi); a sharded caller sums H || g over the ranks
+// before the second half
 void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const double * scale, const double * rhs, const double * x, double * step,
-                                   double * delta, double * cand, double * partial, double * scal, void * stream)
+                                   double * delta, double * cand, double * partial, int e_lo, int e_hi, void * stream)
 {
   hipStream_t s = (hipStream_t)stream;
   const int nbs = (cur.n_free + 255) / 256, nbe = (cur.n_edges + 255) / 256, nbg = (3 * cur.n_free + 255) / 256;
   double * ps = partial, * pe = ps + 5 * (size_t)nbs, * pg = pe + nbe;
+  const bool sharded = e_lo > 0 || e_hi < alt.n_edges;
   hipLaunchKernelGGL(k_step_fused, dim3(nbs), dim3(256), 0, s, cur, scale, rhs, x, step, delta, cand, ps);
   if (alt.n_edges > 0) {
-    hipLaunchKernelGGL(k_edge_lin<true>, dim3(nbe), dim3(256), 0, s, alt, cand, 0, alt.n_edges);
+    // sharded: the cost is still evaluated over all edges on every rank (E threads, microseconds)
+    if (sharded) {hipLaunchKernelGGL(k_edge_lin<false>, dim3(nbe), dim3(256), 0, s, alt, cand, 0, alt.n_edges);}
+    hipLaunchKernelGGL(k_edge_lin<true>, dim3(nbe), dim3(256), 0, s, alt, cand, e_lo, e_hi);
     hipLaunchKernelGGL(k_edge_cost_partials, dim3(nbe), dim3(256), 0, s, alt, pe);
     hipLaunchKernelGGL(k_gather_H, dim3((alt.n_slots * 9 + 255) / 256), dim3(256), 0, s, alt);
   }
-  hipLaunchKernelGGL(k_gather_g_norms, dim3(nbg), dim3(256), 0, s, alt, cand, pg);
+  if (sharded) {
+    hipLaunchKernelGGL(k_gather_g, dim3(nbg), dim3(256), 0, s, alt);
+  } else {
+    hipLaunchKernelGGL(k_gather_g_norms, dim3(nbg), dim3(256), 0, s, alt, cand, pg);
+  }
+}
+
+// second half: scal[3..10] from the partial sums (sharded: the gradient norms from the summed g first)
+void spa_launch_step_scalars(const SpaDev & alt, const double * cand, double * partial, bool sharded, double * scal, void * stream)
+{
+  hipStream_t s = (hipStream_t)stream;
+  const int nbs = (alt.n_free + 255) / 256, nbe = (alt.n_edges + 255) / 256, nbg = (3 * alt.n_free + 255) / 256;
+  double * ps = partial, * pe = ps + 5 * (size_t)nbs, * pg = pe + nbe;
+  if (sharded) {hipLaunchKernelGGL(k_grad_norm_partials, dim3(nbg), dim3(256), 0, s, alt, cand, pg);}
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, ps, nbs, pe, alt.n_edges > 0 ? nbe : 0, pg, nbg, scal);
 }
 
@@ -1669,28 +1704,87 @@ __device__ __forceinline__ void potrf_rowsolve_tile(double * tile, int LD, const
   for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
 }
 
-// one 16 x 16 tile of the in-LDS update  C[rowI0.., colJ0..] -= B A^T  with A = rows colJ0.. of the matrix at columns
-// c0..c0+15 and B = 16 rows at `bsrc` (row stride bstride), K = 16
-__device__ __forceinline__ void potrf_tile(double * A, int LD, int rowI0, int colJ0, int c0, const double * bsrc, int bstride, int lane,
-                                           bool lower_only)
+#define PSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[64 + tcount] = clock64(); tbuf[1 + tcount++] = wall_clock64();} } while (0)
+
+// ---- children's update matrices, read in place (no extend-add pass) ----
+// child number s of a front: the first three sit in the front's own descriptor, further ones (rare: a separator above
+// several disconnected pieces) come from the child list
+__device__ __forceinline__ ChildInfo child_info(const SpaDev & d, const FrontDesc & fd, int s)
+{
+  if (s == 0) {return fd.ch[0];}
+  if (s == 1) {return fd.ch[1];}
+  if (s == 2) {return fd.ch[2];}
+  const FrontDesc & c = d.desc[d.child_list[fd.child_ptr + s]];
+  ChildInfo ci;
+  ci.off = c.off; ci.m = c.m; ci.ns = c.ns; ci.rows_ptr = c.rows_ptr; ci.pad = 0;
+  return ci;
+}
+
+// entry (i, j), i >= j (scalar positions in the parent front), of one child's update matrix, 0 where the child has none
+__device__ __forceinline__ double gather_entry(const double * __restrict__ fronts, const ChildInfo & c, const int32_t * __restrict__ inv, int i, int j)
+{
+  const int in = i / 3, jn = j / 3;
+  const int a = inv[in], b = inv[jn];
+  const bool ok = a >= 0 && b >= 0;
+  const int64_t at = ok ? (int64_t)(c.ns + 3 * a + (i - 3 * in)) + (int64_t)(c.ns + 3 * b + (j - 3 * jn)) * c.m : 0;
+  const double v = fronts[c.off + at];
+  return ok ? v : 0.0;
+}
+
+// Initial value of the 16 x 16 tile (rows row0.., columns col0..) of the pivot block in MFMA accumulator layout: the
+// front's own (assembled) entries plus the children's update matrices; identity on the padding; entries above the
+// diagonal are not meaningful
+__device__ __forceinline__ v4d pivot_tile_init(const SpaDev & d, const FrontDesc & fd, const double * __restrict__ F, int nchild, int row0, int col0, int lane)
 {
   const int lr = lane & 15, lk = lane >> 4;
-  double * cp = A + (rowI0 + lr) * LD + colJ0 + lk;
-  v4d acc;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {acc[r] = cp[4 * r];}
-  const double * xa = A + (colJ0 + lr) * LD + c0 + 4 * lk;
-  const double * xb = bsrc + lr * bstride + 4 * lk;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb[kk], acc, 0, 0, 0);}
+  const int row = row0 + lr, m = fd.m, ns = fd.ns, mp = m / 3;
+  v4d v;
+  bool want[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (!lower_only || lk + 4 * r <= lr) {cp[4 * r] = acc[r];}
+    const int col = col0 + lk + 4 * r;
+    want[r] = row < ns && col <= row;
+    v[r] = *(want[r] ? F + row + (int64_t)col * m : F);
+  }
+  for (int s = 0; s < nchild; ++s) {
+    const ChildInfo c = child_info(d, fd, s);
+    const int32_t * inv = d.cinv + fd.cinv_ptr + s * mp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = col0 + lk + 4 * r;
+      const double g = gather_entry(d.fronts, c, inv, want[r] ? row : 0, want[r] ? col : 0);
+      v[r] += want[r] ? g : 0.0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int col = col0 + lk + 4 * r;
+    v[r] = want[r] ? v[r] : ((row == col) ? 1.0 : 0.0);
+  }
+  return v;
+}
+
+// acc -= B A^T over the column blocks [p_lo, p_hi) of the LDS matrix X (row stride LD):  A = rows arow0.., B = rows brow0..
+__device__ __forceinline__ void ll_accumulate(v4d & acc, const double * X, int LD, int arow0, int brow0, int p_lo, int p_hi, int lane)
+{
+  const int lr = lane & 15, lk = lane >> 4;
+  const double * xa = X + (arow0 + lr) * LD + 4 * lk;
+  const double * xb = X + (brow0 + lr) * LD + 4 * lk;
+  for (int p = p_lo; p < p_hi; ++p) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[NB * p + kk], xb[NB * p + kk], acc, 0, 0, 0);}
   }
 }
 
-#define PSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[64 + tcount] = clock64(); tbuf[1 + tcount++] = wall_clock64();} } while (0)
-
+// Pivot block of every front of a level, LEFT-LOOKING, 256 threads (= 4 waves) per front.  Step jb (16 columns):
+//   U  the tiles of column block jb get their final values: initial value (regular tiles: the front's entries + the
+//      children's, read straight into MFMA accumulators one step ahead; identity rows: zero) minus the products with every
+//      earlier column block.  Wave 0 takes the diagonal tile and runs its pivot chain (with L_jj^-T riding along) while waves
+//      1-3 do the rest, write block jb - 1 of W = L11^-T to memory and give the identity rows of block jb - 1 their first
+//      term (the one that needs L_(jb-1)(jb-1)^-T, which only lives for one step).
+//   R  row solves: every tile of the column times L_jj^-T (MFMA).
+// LDS holds only SOLVED tiles: L11 in the lower triangle, L11^-T strictly above it.  Nothing is staged in a prologue and
+// nothing but the last block of W is left for the epilogue.
 __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
                                                long long * tbuf)
 {
@@ -1699,126 +1793,144 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
   const FrontDesc fd = d.desc[first_front + blockIdx.x];
   const int m = fd.m, ns = fd.ns;
   const int nsp = (ns + NB - 1) & ~(NB - 1), nt = nsp >> 4, LD = nsp + 2;
-  double * F = d.fronts + fd.off;
+  const double * F = d.fronts + fd.off;
   double * W = d.winv + fd.woff;
   const int tid = threadIdx.x, nthreads = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   extern __shared__ double smem[];
-  double * A = smem;                                               // [nsp][LD]: lower = F11 -> L11, strictly upper = L11^-T
+  double * X = smem;                                               // [nsp][LD]: lower = L11, strictly upper = L11^-T
   double * rd = smem + (size_t)lds_nsp * (lds_nsp + 2);            // [lds_nsp] reciprocal diagonal of L11 = diagonal of L11^-T
   double * yv = rd + lds_nsp;                                      // [lds_nsp] y1
-  double * Xd = yv + lds_nsp;                                      // [2][16][XDS] L_jj^-T of the current / next panel
+  double * Xd = yv + lds_nsp;                                      // [2][16][XDS] L_jj^-T of the current / previous panel
   double * sb = Xd + 2 * NB * XDS;                                 // [m] the front's slice of the right-hand side
   __shared__ int s_fail;
   if (tid == 0) {s_fail = 0;}
-  // children's descriptors, all at once (fetched one after the other they are a chain of memory latencies per child)
-  constexpr int CB = 4;
-  FrontDesc cd[CB];
   const int nchild = fd.child_end - fd.child_ptr;
-  const int self = first_front + (int)blockIdx.x;
-  auto load_children = [&](int cb) {
-    int cid[CB];
+  const int nkids = d.gather ? nchild : 0;            // children whose update matrices are read in place
+  const int mp = m / 3;
+  // first column block's tiles: wave 0 the diagonal tile, waves 1..3 the tiles below it (round robin, up to three each)
+  constexpr int SL = 3;
+  v4d cur[SL];
+  auto prefetch = [&](int jb) {
+    if (jb >= nt) {return;}
+    if (wave == 0) {
+      cur[0] = pivot_tile_init(d, fd, F, nkids, NB * jb, NB * jb, lane);
+    } else {
 #pragma unroll
-    for (int q = 0; q < CB; ++q) {cid[q] = cb + q < nchild ? d.child_list[fd.child_ptr + cb + q] : self;}
-#pragma unroll
-    for (int q = 0; q < CB; ++q) {cd[q] = d.desc[cid[q]];}
+      for (int q = 0; q < SL; ++q) {
+        const int I = jb + 1 + (wave - 1) + 3 * q;
+        if (I < nt) {cur[q] = pivot_tile_init(d, fd, F, nkids, NB * I, NB * jb, lane);}
+      }
+    }
   };
-  load_children(0);
-  // right-hand side: the pivots' entries + (below) the children's forward-solve contributions
+  prefetch(0);
+  // right-hand side: the pivots' entries + the children's forward-solve contributions (gathered through the same maps)
   const int first = 3 * fd.first;
-  for (int t = tid; t < m; t += nthreads) {sb[t] = t < ns ? rhs[first + t] : 0.0;}
-  // pivot block -> LDS, 16 x 16 tile by tile (256 threads = one entry per thread and tile): zeros in the tiles above the
-  // diagonal (the identity's off-diagonal part); the tiles of the lower triangle from the front, twelve loads in flight per
-  // thread (an entry that is not wanted reads F[0] instead, selected afterwards), with the identity on the padding
-  {
-    const int ti = tid & 15, tj = tid >> 4;
-    for (int I = 0; I < nt; ++I) {
-      for (int J = I + 1; J < nt; ++J) {A[(NB * I + ti) * LD + NB * J + tj] = 0.0;}
+  for (int t = tid; t < m; t += nthreads) {
+    double v = t < ns ? rhs[first + t] : 0.0;
+    const int tn = t / 3;
+    for (int s = 0; s < nchild; ++s) {
+      const ChildInfo c = child_info(d, fd, s);
+      const int a = d.cinv[fd.cinv_ptr + s * mp + tn];
+      const double u = upd[3 * (int64_t)c.rows_ptr + (a >= 0 ? 3 * a + (t - 3 * tn) : 0)];
+      v += a >= 0 ? u : 0.0;
     }
-    constexpr int LU = 12;
-    const int ntiles = nt * (nt + 1) / 2;
-    for (int t0 = 0; t0 < ntiles; t0 += LU) {
-      double v[LU];
-      int ii[LU], jj[LU];
-#pragma unroll
-      for (int u = 0; u < LU; ++u) {
-        const int t = min(t0 + u, ntiles - 1);
-        int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        I -= (I * (I + 1) / 2 > t) ? 1 : 0;
-        I += ((I + 1) * (I + 2) / 2 <= t) ? 1 : 0;
-        const int J = t - I * (I + 1) / 2;
-        ii[u] = NB * I + ti; jj[u] = NB * J + tj;
-        const bool want = ii[u] < ns && jj[u] <= ii[u];
-        v[u] = *(want ? F + ii[u] + (int64_t)jj[u] * m : F);
-      }
-#pragma unroll
-      for (int u = 0; u < LU; ++u) {
-        if (t0 + u < ntiles) {
-          const bool want = ii[u] < ns && jj[u] <= ii[u];
-          A[ii[u] * LD + jj[u]] = want ? v[u] : ((ii[u] == jj[u]) ? 1.0 : 0.0);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  PSTAMP();
-  for (int cb = 0; cb < nchild; cb += CB) {
-    if (cb > 0) {load_children(cb);}
-#pragma unroll
-    for (int q = 0; q < CB; ++q) {
-      if (cb + q >= nchild) {break;}
-      const int nuc = cd[q].m - cd[q].ns;
-      const int32_t * rp = d.relpos + cd[q].relpos_ptr;
-      const double * uc = upd + 3 * (int64_t)cd[q].rows_ptr;
-      for (int a = tid; a < nuc; a += nthreads) {sb[3 * rp[a / 3] + a % 3] += uc[a];}
-      __syncthreads();
-    }
+    sb[t] = v;
   }
   PSTAMP();
   for (int jb = 0; jb < nt; ++jb) {
     const int c0 = jb * NB;
     double * xd = Xd + (jb & 1) * NB * XDS;
-    // Trailing update of panel jb - 1 inside LDS.  Tiles: (I, J) with I >= J >= jb of the pivot block, and (I, J) with
-    // I < jb <= J of the identity rows.  Wave 0 takes the diagonal tile of THIS panel first and factors it right away
-    // (look-ahead): the pivot chain runs beside the other waves' tiles.
-    if (jb > 0) {
-      const int p0 = c0 - NB;                         // first column of the previous panel
-      const double * xp = Xd + ((jb - 1) & 1) * NB * XDS;
-      const int nreg = (nt - jb) * (nt - jb + 1) / 2, napp = jb * (nt - jb);
-      auto do_tile = [&](int t) {
-        if (t < nreg) {
-          int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-          I -= (I * (I + 1) / 2 > t) ? 1 : 0;
-          I += ((I + 1) * (I + 2) / 2 <= t) ? 1 : 0;
-          const int J = t - I * (I + 1) / 2;
-          const int bi = jb + I, bj = jb + J;
-          potrf_tile(A, LD, NB * bi, NB * bj, p0, A + NB * bi * LD + p0, LD, lane, bi == bj);
+    const double * xp = Xd + ((jb + 1) & 1) * NB * XDS;            // L^-T of the previous diagonal block
+    if (wave == 0) {
+      v4d acc = cur[0];
+      prefetch(jb + 1);
+      ll_accumulate(acc, X, LD, c0, c0, 0, jb, lane);
+      double * cp = X + (c0 + lr) * LD + c0 + lk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {if (lk + 4 * r <= lr) {cp[4 * r] = acc[r];}}
+      if (potrf_diag(X + c0 * LD + c0, LD, lane, xd, rd + c0)) {s_fail = 1;}
+    } else {
+      v4d mine[SL];
+#pragma unroll
+      for (int q = 0; q < SL; ++q) {mine[q] = cur[q];}
+      prefetch(jb + 1);
+      // regular tiles (I, jb), I > jb
+#pragma unroll
+      for (int q = 0; q < SL; ++q) {
+        const int I = jb + 1 + (wave - 1) + 3 * q;
+        if (I >= nt) {break;}
+        v4d acc = mine[q];
+        ll_accumulate(acc, X, LD, c0, NB * I, 0, jb, lane);
+        double * cp = X + (NB * I + lr) * LD + c0 + lk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
+      }
+      // identity rows (I, jb), I < jb: their value so far (block I's own term, written one step after block I) minus the
+      // products with the column blocks I + 1 .. jb - 1; block jb - 1 starts here, with its own term
+      for (int I = wave - 1; I < jb; I += 3) {
+        double * cp = X + (NB * I + lr) * LD + c0 + lk;
+        v4d acc;
+        if (I == jb - 1) {
+          acc = v4d{0.0, 0.0, 0.0, 0.0};
+          const double * xa = X + (c0 + lr) * LD + NB * I + 4 * lk;
+          const double * xb = xp + lr * XDS + 4 * lk;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb[kk], acc, 0, 0, 0);}
         } else {
-          const int q = t - nreg;
-          const int ie = q / (nt - jb), bj = jb + (q - ie * (nt - jb));
-          const bool cur = ie == jb - 1;
-          potrf_tile(A, LD, NB * ie, NB * bj, p0, cur ? xp : A + NB * ie * LD + p0, cur ? XDS : LD, lane, false);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {acc[r] = cp[4 * r];}
+          ll_accumulate(acc, X, LD, c0, NB * I, I + 1, jb, lane);
         }
-      };
-      if (wave == 0) {
-        do_tile(0);                          // t = 0 is (jb, jb)
-      } else {
-        for (int t = wave; t < nreg + napp; t += nwaves - 1) {do_tile(t);}
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
+      }
+      if (jb > 0) {
+        const int I = jb - 1;
+        // block I's own term for the later column blocks J > jb:  E[I][J] = -L_II^-T L[J][I]^T
+        for (int J = jb + 1 + (wave - 1); J < nt; J += 3) {
+          v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+          const double * xa = X + (NB * J + lr) * LD + NB * I + 4 * lk;
+          const double * xb = xp + lr * XDS + 4 * lk;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb[kk], acc, 0, 0, 0);}
+          double * cp = X + (NB * I + lr) * LD + NB * J + lk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
+        }
+        // column block I of W is final: tiles (q <= I, I); W[(16 I + j) + (16 q + i) * nsp] = (L^-T)[16 q + i][16 I + j]
+        for (int q = wave - 1; q <= I; q += 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int idx = lane + 64 * e, i = idx >> 4, j = idx & 15;
+            W[(NB * I + j) + (int64_t)(NB * q + i) * nsp] = q == I ? xp[i * XDS + j] : X[(NB * q + i) * LD + NB * I + j];
+          }
+        }
       }
     }
-    if (wave == 0) {
-      if (potrf_diag(A + c0 * LD + c0, LD, lane, xd, rd + c0)) {s_fail = 1;}
-    }
-    __syncthreads();                     // L_jj^-T of this panel is in xd, the updates of the previous panel are done
+    __syncthreads();                     // the tiles of column block jb and L_jj^-T are in place
     PSTAMP();
-    // row solves, one 16-row tile per wave: rows below the block (L21 part of F11) and the rows of the identity that
-    // started in earlier panels (tiles above the block, in the upper triangle); the block's own rows ARE xd
-    for (int t = wave; t < nt - 1; t += nwaves) {
+    // row solves, one 16-row tile per wave: rows below the block (L11 part) and the identity rows above it; the block's
+    // own identity rows ARE xd
+    for (int t = wave; t < nt - 1; t += 4) {
       const int bi = t < jb ? t : t + 1;
-      potrf_rowsolve_tile(A + NB * bi * LD + c0, LD, xd, lane);
+      potrf_rowsolve_tile(X + NB * bi * LD + c0, LD, xd, lane);
     }
     __syncthreads();
     PSTAMP();
+  }
+  // last column block of W
+  {
+    const int I = nt - 1;
+    const double * xl = Xd + (I & 1) * NB * XDS;
+    for (int q = wave; q <= I; q += 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = lane + 64 * e, i = idx >> 4, j = idx & 15;
+        W[(NB * I + j) + (int64_t)(NB * q + i) * nsp] = q == I ? xl[i * XDS + j] : X[(NB * q + i) * LD + NB * I + j];
+      }
+    }
   }
   // y1 = L11^-1 b1 = W^T b1: two threads per entry, each with half of the sum
   {
@@ -1827,18 +1939,11 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
     if (j < ns) {
       const int q0 = half ? (j + 1) >> 1 : 0, q1 = half ? j : (j + 1) >> 1;
 #pragma unroll 8
-      for (int q = q0; q < q1; ++q) {acc += A[q * LD + j] * sb[q];}
+      for (int q = q0; q < q1; ++q) {acc += X[q * LD + j] * sb[q];}
       if (half) {acc += rd[j] * sb[j];}
     }
     acc += __shfl_xor(acc, 1);
     if (j < ns && !half) {yv[j] = acc;}
-  }
-  // W to its own block (column-major Linv = row-major L^-T, zeros left of the diagonal).  L11 itself is not needed again:
-  // the row solves of the front (trsm) and both triangular solves use W.
-#pragma unroll 4
-  for (int idx = tid; idx < nsp * nsp; idx += nthreads) {
-    const int q = idx / nsp, j = idx - q * nsp;            // W[j + q * nsp] = (L^-T)[q][j]
-    W[idx] = j > q ? A[q * LD + j] : (j == q ? rd[q] : 0.0);
   }
   __syncthreads();
   for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = yv[t];}
@@ -1851,12 +1956,16 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
   if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
 }
 
-// rows [row0, row0 + R) x columns [0, nsp) of the panel columns of a front -> LDS rows of stride LD (zeros outside
-// nr rows / ns columns), sixteen loads in flight per thread
+// rows [prow0, prow0 + R) x columns [0, nsp) of the panel columns of a front -> LDS rows of stride LD (zeros outside
+// nr rows / ns columns), sixteen loads in flight per thread; with kids, the children's update matrices are added (the
+// same thread handles the same entry in every pass: no barrier in between)
 template <int R>
-__device__ __forceinline__ void stage_rows(double * S, int LD, const double * Fcol0, int m, int nr, int ns, int nsp, int tid, int nthreads)
+__device__ __forceinline__ void stage_rows(double * S, int LD, const SpaDev & d, const FrontDesc & fd, int prow0, int nr, int ns, int nsp, int nkids,
+                                           int tid, int nthreads)
 {
   constexpr int LU = 16;
+  const int m = fd.m, mp = m / 3;
+  const double * Fcol0 = d.fronts + fd.off + prow0;
   for (int base = 0; base < R * nsp; base += LU * nthreads) {
     double v[LU];
 #pragma unroll
@@ -1865,6 +1974,18 @@ __device__ __forceinline__ void stage_rows(double * S, int LD, const double * Fc
       const int c = idx / R, i = idx - c * R;
       const bool want = idx < R * nsp && i < nr && c < ns;
       v[u] = *(want ? Fcol0 + i + (int64_t)c * m : Fcol0);
+    }
+    for (int s = 0; s < nkids; ++s) {
+      const ChildInfo ci = child_info(d, fd, s);
+      const int32_t * inv = d.cinv + fd.cinv_ptr + s * mp;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int idx = base + u * nthreads + tid;
+        const int c = idx / R, i = idx - c * R;
+        const bool want = idx < R * nsp && i < nr && c < ns;
+        const double g = gather_entry(d.fronts, ci, inv, want ? prow0 + i : 0, want ? c : 0);
+        v[u] += want ? g : 0.0;
+      }
     }
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
@@ -1903,7 +2024,7 @@ __global__ __launch_bounds__(256) void k_trsm(SpaDev d, int first_front, const d
   const double uold = tid < nr ? uk[r0 + tid] : 0.0;
   for (int j = tid; j < nsp; j += nthreads) {yv[j] = j < ns ? rhs[first + j] : 0.0;}
   for (int j = tid; j < 4 * R; j += nthreads) {red[j] = 0.0;}
-  stage_rows<R>(S, LD, F + ns + r0, m, nr, ns, nsp, tid, nthreads);
+  stage_rows<R>(S, LD, d, fd, ns + r0, nr, ns, nsp, d.gather ? fd.child_end - fd.child_ptr : 0, tid, nthreads);
   __syncthreads();
   double part[RT];
 #pragma unroll
@@ -2000,8 +2121,27 @@ __global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int 
       acc[u][r] = ok ? v : 0.0;
     }
   }
-  stage_rows<TS>(XA, LD, F + ns + TS * I, m, min(TS, nu - TS * I), ns, nsp, tid, nthreads);
-  if (I != J) {stage_rows<TS>(XB, LD, F + ns + TS * J, m, min(TS, nu - TS * J), ns, nsp, tid, nthreads);}
+  {
+    // the children's update matrices join here (the front's own F22 holds only its assembled entries)
+    const int nkids = d.gather ? fd.child_end - fd.child_ptr : 0, mp = m / 3;
+    for (int s = 0; s < nkids; ++s) {
+      const ChildInfo ci = child_info(d, fd, s);
+      const int32_t * inv = d.cinv + fd.cinv_ptr + s * mp;
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int col0 = TS * J + NB * (sj0 + u) + lk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = col0 + 4 * r;
+          const bool ok = live[u] && row < nu && col <= row;
+          const double g = gather_entry(d.fronts, ci, inv, ok ? ns + row : 0, ok ? ns + col : 0);
+          acc[u][r] += ok ? g : 0.0;
+        }
+      }
+    }
+  }
+  stage_rows<TS>(XA, LD, d, fd, ns + TS * I, min(TS, nu - TS * I), ns, nsp, 0, tid, nthreads);      // L21 is final: no children
+  if (I != J) {stage_rows<TS>(XB, LD, d, fd, ns + TS * J, min(TS, nu - TS * J), ns, nsp, 0, tid, nthreads);}
   __syncthreads();
   if (live[0]) {
     const double * xb = XA + (NB * si + lr) * LD + 4 * lk;

@@ -365,6 +365,20 @@ int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & 
       sym.relpos[sym.relpos_ptr[k] + q] = at;
     }
   }
+  // gather maps: the inverse of relpos, per (front, child)
+  sym.cinv_ptr.assign(K + 1, 0);
+  for (int32_t k = 0; k < K; ++k) {
+    sym.cinv_ptr[k + 1] = sym.cinv_ptr[k] + (sym.child_ptr[k + 1] - sym.child_ptr[k]) * (sym.front_m[k] / 3);
+  }
+  sym.cinv.assign(sym.cinv_ptr[K], -1);
+  for (int32_t k = 0; k < K; ++k) {
+    const int32_t mp = sym.front_m[k] / 3;
+    for (int32_t ci = sym.child_ptr[k]; ci < sym.child_ptr[k + 1]; ++ci) {
+      const int32_t c = sym.child_list[ci];
+      int32_t * inv = sym.cinv.data() + sym.cinv_ptr[k] + (ci - sym.child_ptr[k]) * mp;
+      for (int32_t q = sym.relpos_ptr[c]; q < sym.relpos_ptr[c + 1]; ++q) {inv[sym.relpos[q]] = q - sym.relpos_ptr[c];}
+    }
+  }
   return KH_OK;
 }
 

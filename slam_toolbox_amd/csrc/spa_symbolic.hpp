@@ -24,6 +24,10 @@ struct Symbolic
   int64_t fronts_size = 0;
   int64_t nnz_factor = 0;
   int64_t factor_flops = 0;      // sum over the fronts of sum_{j < ns} (m - j)^2
+  // gather maps of the level pipeline (a front reads its children's update matrices instead of having them added into it):
+  // for child number s of front k, cinv[cinv_ptr[k] + s * (front_m[k] / 3) + i] = index of the child's struct row that sits
+  // at position i (node units) of front k, or -1
+  std::vector<int32_t> cinv_ptr, cinv;
   // inverse of the pivot block's Cholesky factor, one nsp x nsp block per front (nsp = ns rounded up to 16)
   std::vector<int64_t> winv_off;
   int64_t winv_size = 0;

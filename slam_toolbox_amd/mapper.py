@@ -16,9 +16,11 @@ from . import capi
 
 
 class Mapper:
-    def __init__(self, laser, device: int = 0, max_candidates: int = 32, log_path: str = None, **params):
+    def __init__(self, laser, device: int = 0, max_candidates: int = 32, log_path: str = None, devices=None, **params):
         """laser: anything with n_beams, min_angle, ang_res, min_range, max_range, range_threshold (synth.Laser);
-        params: fields of kh_mapper_params to override (AS STORED by karto::Mapper: variances squared)."""
+        params: fields of kh_mapper_params to override (AS STORED by karto::Mapper: variances squared);
+        devices: device list of kh_mapper_create_on_devices (candidate batches dealt over one matcher pair per entry; the
+        same device may be listed more than once), default [device]."""
         p = capi.KhMapperParams()
         capi.lib().kh_mapper_params_default(C.byref(p))
         match_fields = {k for k, _ in capi.KhMatchParams._fields_}
@@ -31,7 +33,9 @@ class Mapper:
                 raise KeyError(k)
         L = capi.KhLaser(laser.n_beams, laser.min_angle, laser.ang_res, laser.min_range, laser.max_range, laser.range_threshold)
         self._h = C.c_void_p()
-        capi.check(capi.lib().kh_mapper_create(C.byref(p), C.byref(L), device, max_candidates, C.byref(self._h)), "kh_mapper_create")
+        devs = np.asarray([device] if devices is None else list(devices), dtype=np.int32)
+        capi.check(capi.lib().kh_mapper_create_on_devices(C.byref(p), C.byref(L), devs, len(devs), max_candidates, C.byref(self._h)),
+                   "kh_mapper_create_on_devices")
         self.n_beams = laser.n_beams
         if log_path:
             capi.check(capi.lib().kh_mapper_set_log(self._h, log_path.encode()), "kh_mapper_set_log")

@@ -22,10 +22,10 @@ class LapQueue:
     """n_scans scans of the lap circuit (synth.trajectory_laps).  The circuit is periodic, so the exact ray casting is done
     once per circuit position and every scan adds its own range noise, +inf and NaN beams on top."""
 
-    def __init__(self, n_scans: int, seed: int = 4, aisles=(0, 1)):
+    def __init__(self, n_scans: int, seed: int = 4, aisles=(0, 1), drift_xy: float = 0.02, drift_theta_deg: float = 0.5):
         self.laser = synth.Laser()
         self.world = synth.make_world(12345)
-        self.truth, self.odom = synth.trajectory_laps(n_scans, aisles=aisles)
+        self.truth, self.odom = synth.trajectory_laps(n_scans, aisles=aisles, drift_xy=drift_xy, drift_theta_deg=drift_theta_deg)
         self.rng = np.random.default_rng(seed)
         self._cast = {}
         self.n = n_scans

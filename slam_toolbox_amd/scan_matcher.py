@@ -297,3 +297,63 @@ class ScanMatcher:
             self.close()
         except Exception:
             pass
+
+
+class ScanMatcherGroup:
+    """kh_matcher_group: one ScanMatcher per entry of `devices` in ONE process; MatchScanBatch deals candidate i to member
+    i % len(devices) (a host thread per member) and returns the results in candidate order -- the in-process form of the
+    multi-GPU loop-closure batch (MapperGraph::TryCloseLoop's candidates, Mapper.cpp:1500-1561).  The same device may be
+    listed more than once."""
+
+    def __init__(self, mapper_params: MapperParams, searchSize, resolution, smearDeviation, rangeThreshold, devices,
+                 max_batch_per_member: int = 64):
+        self.devices = np.asarray(list(devices), dtype=np.int32)
+        h = C.c_void_p()
+        capi.check(capi.lib().kh_matcher_group_create(searchSize, resolution, smearDeviation, rangeThreshold, self.devices,
+                                                      len(self.devices), max_batch_per_member, C.byref(h)), "kh_matcher_group_create")
+        self._h = h
+        p = mapper_params.c()
+        capi.check(capi.lib().kh_matcher_group_set_params(self._h, C.byref(p)), "kh_matcher_group_set_params")
+
+    def __len__(self):
+        return int(capi.lib().kh_matcher_group_size(self._h))
+
+    def pack_batch(self, scans, base_lists, device_points=None):
+        """ctypes marshalling of a batch, reusable across calls (see ScanMatcher.pack_batch)"""
+        q_arr, b_arr, begin, n, keep = ScanMatcher.pack_batch(scans, base_lists)
+        table = None
+        if device_points is not None:
+            table = np.ascontiguousarray(device_points, dtype=np.uint64)
+            assert table.shape == (len(keep[1]), len(self))
+        return (q_arr, b_arr, begin, n, keep, table)
+
+    def MatchScanBatch(self, scans, base_lists, doPenalize=True, doRefineMatch=True, device_points=None, packed=None):
+        """device_points: None, or an (n_base_total, n_members) uint64 array of device addresses (0 = not resident)"""
+        if packed is not None:
+            q_arr, b_arr, begin, n, _keep, table = packed
+            means, covs, resp, status = np.zeros(3 * n), np.zeros(9 * n), np.zeros(n), np.zeros(n, dtype=np.int32)
+            capi.check(capi.lib().kh_matcher_group_match_batch(
+                self._h, n, q_arr, b_arr, begin, None if table is None else table.ctypes.data_as(C.c_void_p),
+                int(doPenalize), int(doRefineMatch), means, covs, resp, status), "kh_matcher_group_match_batch")
+            return resp, means.reshape(n, 3), covs.reshape(n, 3, 3), status
+        n = len(scans)
+        flat = [b for lst in base_lists for b in lst]
+        begin = np.zeros(n + 1, dtype=np.int32)
+        begin[1:] = np.cumsum([len(lst) for lst in base_lists])
+        means = np.zeros(3 * n)
+        covs = np.zeros(9 * n)
+        resp = np.zeros(n)
+        status = np.zeros(n, dtype=np.int32)
+        table = None
+        if device_points is not None:
+            table = np.ascontiguousarray(device_points, dtype=np.uint64)
+            assert table.shape == (len(flat), len(self))
+        capi.check(capi.lib().kh_matcher_group_match_batch(
+            self._h, n, _scan_array(scans), _scan_array(flat), begin, None if table is None else table.ctypes.data_as(C.c_void_p),
+            int(doPenalize), int(doRefineMatch), means, covs, resp, status), "kh_matcher_group_match_batch")
+        return resp, means.reshape(n, 3), covs.reshape(n, 3, 3), status
+
+    def close(self):
+        if self._h:
+            capi.lib().kh_matcher_group_destroy(self._h)
+            self._h = None

@@ -250,3 +250,7 @@ def test_linear_solves_of_pose_graphs(kartohip_lib, n, e, seed):
     assert s3["usable"] == 1 and s3["iterations"] == s2["iterations"], (s3, s2)
     assert 0.0 < s3["worst_linear_residual"] < 1e-9, s3
     assert _diff(x3, x2) < 1e-8
+    # the level pipeline with the children's update matrices read in place (no extend-add launches)
+    sg, xg = _solve(g, check_linear_solves=True, factor_kernels=3, gather_children=True)
+    assert sg["iterations"] == s3["iterations"] and 0.0 < sg["worst_linear_residual"] < 1e-9, sg
+    assert _diff(xg, x3) < 1e-9

@@ -29,7 +29,7 @@ def _probe(tmp_path, edges, n_nodes, args=()):
     while p < raw.size:
         n = int(raw[p]); arrays.append(raw[p + 1:p + 1 + n]); p += 1 + n
     names = ["free_of_elim", "front_first", "front_ns", "front_m", "level", "parent", "rows_ptr", "rows", "child_ptr", "child_list",
-             "relpos_ptr", "relpos"]
+             "relpos_ptr", "relpos", "cinv_ptr", "cinv"]
     assert len(arrays) == len(names)
     return dict(zip(names, arrays))
 
@@ -92,6 +92,15 @@ def _check(sym, edges, n_nodes):
         else:
             assert parent[k] == -1
     assert covered.all()
+    # gather maps = inverse of relpos per (front, child)
+    for k in range(K):
+        mp = m[k] // 3
+        kids_k = sym["child_list"][sym["child_ptr"][k]:sym["child_ptr"][k + 1]]
+        assert sym["cinv_ptr"][k + 1] - sym["cinv_ptr"][k] == len(kids_k) * mp
+        for s_, c in enumerate(kids_k):
+            inv = sym["cinv"][sym["cinv_ptr"][k] + s_ * mp:sym["cinv_ptr"][k] + (s_ + 1) * mp]
+            rel = sym["relpos"][sym["relpos_ptr"][c]:sym["relpos_ptr"][c + 1]]
+            assert np.array_equal(np.nonzero(inv >= 0)[0], rel) and np.array_equal(inv[rel], np.arange(len(rel)))
     assert padding <= 0.1 * max(1, total_rows), (padding, total_rows)
     assert np.all(np.diff(level) >= 0), "front ids are not level by level"
     for l in range(level.max() + 1):

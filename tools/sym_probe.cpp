@@ -61,7 +61,7 @@ int main(int argc, char ** argv)
   std::printf("sum of the levels' largest pivot counts: %d\n", sum_ns);
   if (const char * dump = std::getenv("SYM_PROBE_DUMP")) {
     // int32 arrays, each preceded by its length: free_of_elim, front_first, front_ns, front_m, level, parent, rows_ptr, rows,
-    // child_ptr, child_list, relpos_ptr, relpos
+    // child_ptr, child_list, relpos_ptr, relpos, cinv_ptr, cinv
     FILE * o = std::fopen(dump, "wb");
     auto put = [&](const std::vector<int32_t> & v) {
       const int32_t n32 = static_cast<int32_t>(v.size());
@@ -69,6 +69,7 @@ int main(int argc, char ** argv)
     };
     put(sym.free_of_elim); put(sym.front_first); put(sym.front_ns); put(sym.front_m); put(sym.level); put(sym.parent);
     put(sym.rows_ptr); put(sym.rows); put(sym.child_ptr); put(sym.child_list); put(sym.relpos_ptr); put(sym.relpos);
+    put(sym.cinv_ptr); put(sym.cinv);
     std::fclose(o);
   }
   return rc;
