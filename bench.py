@@ -248,15 +248,18 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
            "solve_levels": int(summ["levels"])}
     if world == 1 and summ["factorizations"] > 0:
         # K6: flops of the numeric factorisations / GPU time of the assemble + factor + forward sweeps (HIP events)
-        flops = float(summ["factor_flops"]) * summ["factorizations"]
+        # factor_flops counts multiply-adds (sum over the fronts of sum_j (m - j)^2): two floating-point operations each
+        flops = 2.0 * float(summ["factor_flops"]) * summ["factorizations"]
         tf = flops / (summ["factor_gpu_ms"] * 1e-3) / 1e12 if summ["factor_gpu_ms"] > 0 else 0.0
         n_lin = summ["successful_steps"]          # evaluation points linearised (the start + every accepted step)
         lin_bytes = 480.0 * 30000 * n_lin         # 144 B read + 336 B written per edge
         lin_gbs = lin_bytes / (summ["linearize_gpu_ms"] * 1e-3) / 1e9 if summ["linearize_gpu_ms"] > 0 else 0.0
         out["solve_rooflines"] = [
-            {"kernel": "K6 k_factor (multifrontal Cholesky + fused forward solve)", "bound": "latency (dependent levels); ceiling quoted = mfma f64",
+            {"kernel": "K6 level pipeline: k_potrf + k_trsm + k_syrk + k_extend_add (+ assemble), multifrontal Cholesky with the forward solve fused",
+             "bound": "latency (dependent levels: the pivot chains of k_potrf); ceiling quoted = mfma f64",
              "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-             "flops_per_factorization": float(summ["factor_flops"]), "factorizations": int(summ["factorizations"]),
+             "flops_per_factorization": 2.0 * float(summ["factor_flops"]), "multiply_adds_per_factorization": float(summ["factor_flops"]),
+             "factorizations": int(summ["factorizations"]),
              "gpu_ms": float(summ["factor_gpu_ms"]), "levels": int(summ["levels"]), "nnz_factor": int(summ["nnz_factor"]),
              "traffic": None},
             {"kernel": "K5 k_edge_lin + k_gather_H / _g (normal equations)", "bound": "hbm", "achieved": lin_gbs, "peak": HBM_PEAK_GBS,
@@ -463,6 +466,49 @@ def strong_leg(device=0, rank=0, world=1, n_pairs=2048, distinct=256, batch=256)
                                            f"round-robin over {world} rank(s), one all-gather of {n_pairs} x 13 doubles"}}
 
 
+def latency_leg(device=0):
+    """One call at a time -- what karto::ScanMatcher's interface gives slam_toolbox (include/karto_hip/karto_adaptor.hpp:
+    HipScanMatcher packs and uploads the base scans with every MatchScan) next to the same call with the base scans
+    resident in HBM (kh_scan.device_points_xy, what kh_mapper does).  Presets: S sequential (10 base scans), L loop (20),
+    C2 = BASELINE config[1]'s geometry as a full MatchScan (coarse 31 x 31 x 81 poses at 1 cm / 0.5 deg, then the fine
+    pass) and as the single CorrelateScan over 61 x 61 x 81 poses the headline batches up."""
+    import math
+    from common import Scenario, make_hip_matcher
+    out = {}
+    for preset, nbase in (("S", 10), ("L", 20), ("C2", 10)):
+        sc = Scenario(seed=11, n_base=nbase, start=20)
+        q, b = sc.hip_scans()
+        hm = make_hip_matcher(preset)
+        row = {}
+        for label in ("base_scans_uploaded_per_call", "base_scans_resident"):
+            if label == "base_scans_resident":
+                for scan in b:
+                    scan.MakeResident(device)
+            for _ in range(3):
+                hm.MatchScan(q, b, True, True)
+            n = 30
+            t = time.perf_counter()
+            for _ in range(n):
+                hm.MatchScan(q, b, True, True)
+            row[label + "_ms"] = (time.perf_counter() - t) / n * 1e3
+        if preset == "C2":
+            hm.AddScans(q, b, slot=0)
+            args = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+            for _ in range(3):
+                hm.CorrelateScan(q, sc.query_pose, *args, True)
+            n = 30
+            t = time.perf_counter()
+            for _ in range(n):
+                hm.CorrelateScan(q, sc.query_pose, *args, True)
+            row["single_correlate_scan_ms"] = (time.perf_counter() - t) / n * 1e3
+            row["single_correlate_scan_per_s"] = 1e3 / row["single_correlate_scan_ms"]
+        hm.close()
+        out[preset] = row
+    return {"single_call_latency": out,
+            "single_call_latency_note": "wall time per call from Python through the C ABI, MatchScan(doPenalize, doRefineMatch) = true; "
+                                        "C2.single_correlate_scan_ms = config[1] issued one CorrelateScan at a time"}
+
+
 def group_leg(devices, n_pairs=2048, distinct=256, batch=256):
     """The same fixed set of candidate pairs as strong_leg through the IN-PROCESS multi-device batch of the library
     (kh_matcher_group_match_batch: one member per entry of `devices`, candidate i on member i % members, a host thread per
@@ -514,21 +560,104 @@ def group_leg(devices, n_pairs=2048, distinct=256, batch=256):
                         f"kh_matcher_group_match_batch, one process, {nm} member(s), no collective"}
 
 
-def replay_leg(device=0, n_scans=3000):
+def replay_cpu_baseline(n_scans=1500):
+    """CPU baseline of config[4] AND the pin of the replay: the first n_scans of the replay queue, non-lifelong (the
+    reference's lifelong node is a ROS node and cannot be built here), through the REFERENCE karto::Mapper built from
+    /root/reference (oracle/_ref/libkarto_ref_slam.so: reference Mapper.cpp + reference CPU ScanMatcher on 64 host threads;
+    its solver plugin is this library's, attached through karto::ScanSolver -- Ceres is not available) and through the
+    library's mapper.  Reports the reference's rate, whether the two runs end with the same poses bit for bit, and the
+    intersection-over-union of the two occupancy maps."""
+    import ctypes as C
+    from slam_toolbox_amd import replay
+    from slam_toolbox_amd.mapper import Mapper
+    from slam_toolbox_amd.occupancy_grid import OccupancyGrid
+    from slam_toolbox_amd.scan_matcher import LocalizedRangeScan
+    path = os.path.join(ROOT, "oracle", "_ref", "libkarto_ref_slam.so")
+    if not os.path.exists(path):
+        return {"replay_cpu_baseline": None, "replay_cpu_baseline_note": "oracle/_ref/libkarto_ref_slam.so not built"}
+    q = replay.LapQueue(n_scans)
+    ranges = np.ascontiguousarray(np.stack([q.ranges(i) for i in range(n_scans)]))
+    odom = np.ascontiguousarray(q.odom)
+    L = q.laser
+    m = Mapper(L)
+    t0 = time.perf_counter()
+    ids = [i for i in range(n_scans) if m.Process(ranges[i], odom[i], 0.1 * i)[0]]
+    t_hip = time.perf_counter() - t0
+    poses = m.poses()
+    m.close()
+    lib = C.CDLL(path)
+    lib.ref_init_laser.restype = C.c_int
+    lib.ref_init_laser.argtypes = [C.c_double] * 6
+    lib.ref_slam_run.restype = C.c_int
+    lib.ref_slam_run.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_char_p, C.c_void_p, C.c_int]
+    nb = lib.ref_init_laser(L.min_angle, L.max_angle, L.ang_res, L.min_range, L.max_range, L.range_threshold)
+    threads = min(64, os.cpu_count() or 1)
+    lib.ref_set_threads(threads)
+    out = np.zeros((n_scans, 4))
+    t0 = time.perf_counter()
+    acc = lib.ref_slam_run(n_scans, nb, ranges.ctypes.data, odom.ctypes.data, 3.0, b"/tmp/kh_bench_ref_replay.log", out.ctypes.data, n_scans)
+    t_ref = time.perf_counter() - t0
+    ref = out[:max(acc, 0), 1:]
+    same = bool(acc == len(ids) and np.array_equal(ref, poses))
+    iou = None
+    if acc == len(ids) and acc > 0:
+        a_scans = [LocalizedRangeScan(ranges[i], p, L.min_angle, L.ang_res) for i, p in zip(ids, poses)]
+        b_scans = [LocalizedRangeScan(ranges[i], p, L.min_angle, L.ang_res) for i, p in zip(ids, ref)]
+        g = OccupancyGrid.CreateFromScans(a_scans + b_scans, 0.05, L, 0)
+        g.Clear(); g.AddScans(a_scans, L); g.Update()
+        ma = g.cells()[:, :g.width] == 100
+        g.Clear(); g.AddScans(b_scans, L); g.Update()
+        mb = g.cells()[:, :g.width] == 100
+        iou = float((ma & mb).sum()) / max(1, int((ma | mb).sum()))
+        t_scans = [LocalizedRangeScan(ranges[i], q.truth[i], L.min_angle, L.ang_res) for i in ids]
+        g.Clear(); g.AddScans(t_scans, L); g.Update()
+        mt = g.cells()[:, :g.width] == 100
+        iou_truth = float((ma & mt).sum()) / max(1, int((ma | mt).sum()))
+        g.close()
+    else:
+        iou_truth = None
+    truth = q.truth[np.asarray(ids)]
+    d = poses - truth
+    return {"replay_cpu_baseline": {"value": n_scans / t_ref, "unit": "scans/s", "cores": threads, "kind": "reference",
+                                    "sample": f"first {n_scans} scans of the replay queue, non-lifelong, reference karto::Mapper::Process with its "
+                                              f"CPU scan matcher ({t_ref:.1f} s); the library's mapper on the same scans: {t_hip:.2f} s"},
+            "replay_poses_identical_to_reference": same, "replay_map_iou_vs_reference": iou,
+            "replay_nonlifelong_map_iou_vs_truth_poses": iou_truth,
+            "replay_reference_scans": n_scans, "replay_reference_accepted": int(acc),
+            "replay_reference_pose_error_xy_rms_m": float(np.sqrt((d[:, :2] ** 2).sum(1).mean()))}
+
+
+def replay_leg(device=0, n_scans=3000, cpu=True):
     """BASELINE config[4]: lifelong-mode replay, end to end on one GPU -- scan queue -> mapper front end of the library
     (sequential match, links, speculative loop closure, SPA solves, node decay) -> occupancy grid (extra keys).  The
-    default run replays a bounded prefix; profiles/r2_replay_50k_lifelong.json holds the 50 000-scan run of the same
-    command (tools/replay.py --scans 50000)."""
+    default run replays a bounded prefix, once with every scan processed (sync) and once behind the asynchronous node's
+    depth-1 queue with scans arriving every 25 ms (src/slam_toolbox_async.cpp:34-57); tools/replay.py --scans 50000 is the
+    full-length run (profiles/)."""
     from slam_toolbox_amd import replay
     out = replay.run(n_scans, lifelong=True, mode="sync", device=device)
     st = out["stats"]
-    return {"replay_scans_per_s": out["scans_per_s"], "replay_workload": f"{n_scans}-scan lap circuit, lifelong mode, sync queue: "
-            f"{out['accepted']} accepted, {out['alive']} alive after node decay, {st['loop_closures']} loop closures, "
-            f"{st['matches']} matches", "replay_wall_s": out["wall_s"],
-            "replay_ms_split": {"match": st["match_ms"], "solver": st["solver_ms"], "pose_updates": st["update_ms"], "node_decay": st["lifelong_ms"]},
-            "replay_map_build_ms": out["map_build_ms"], "replay_map_iou_vs_truth_poses": out["map_iou_vs_truth_poses"],
-            "replay_pose_error_xy_rms_m": out["pose_error_xy_rms_m"],
-            "replay_50k": "profiles/r2_replay_50k_lifelong.json"}
+    res = {"replay_scans_per_s": out["scans_per_s"], "replay_workload": f"{n_scans}-scan lap circuit (odometry noise 1 % / 0.2 deg per m), "
+           f"lifelong mode, sync queue: {out['accepted']} accepted, {out['alive']} alive after node decay, {st['loop_closures']} loop closures, "
+           f"{st['matches']} matches", "replay_wall_s": out["wall_s"],
+           "replay_ms_split": {"match": st["match_ms"], "solver": st["solver_ms"], "pose_updates": st["update_ms"], "node_decay": st["lifelong_ms"]},
+           "replay_map_build_ms": out["map_build_ms"], "replay_map_iou_vs_truth_poses": out["map_iou_vs_truth_poses"],
+           "replay_map_occupied_within_one_cell_of_truth_map": out["map_occupied_within_one_cell_of_truth_map"],
+           "replay_pose_error_xy_rms_m": out["pose_error_xy_rms_m"], "replay_pose_error_xy_max_m": out["pose_error_xy_max_m"],
+           "replay_graph_components": out["graph_components"],
+           "replay_lifelong_note": "the node-decay policy (slam_toolbox_lifelong.cpp:149-178, restated and pinned in tests/test_lifelong_policy_gpu.py) "
+                                   "removes vertices together with their edges and keeps nothing connected: on a circuit driven lap after lap the pose "
+                                   "graph falls apart into replay_graph_components pieces and the map drifts with it; the same queue WITHOUT node decay "
+                                   "(replay_nonlifelong_*, poses identical to the reference mapper's) is the accuracy reference"}
+    period, n_async = 0.025, 800                      # 40 Hz (UTM-30LX): 20 s of wall time when nothing is dropped
+    a = replay.run(n_async, lifelong=True, mode="async", period_s=period, device=device)
+    res["replay_async"] = {"period_s": period, "scans": n_async, "processed": a["processed"], "dropped": a["dropped"], "wall_s": a["wall_s"],
+                           "busy_s": a["busy_s"], "waited_for_arrivals_s": a["waited_for_arrivals_s"],
+                           "map_iou_vs_truth_poses": a["map_iou_vs_truth_poses"],
+                           "note": "scan k arrives at k * period_s; the mapper waits for arrivals when it is ahead and skips to the most "
+                                   "recent arrival when it is behind (depth-1 queue)"}
+    if cpu:
+        res.update(replay_cpu_baseline())
+    return res
 
 
 def enumeration_leg(device=0, n_scans=10000, n_queries=256):
@@ -843,7 +972,8 @@ def main():
             out.update(enumeration_leg(local_rank))
             out.update(occupancy_leg(local_rank))
             try:
-                out.update(replay_leg(local_rank))
+                out.update(replay_leg(local_rank, cpu=not args.no_cpu_baseline))
+                out.update(latency_leg(local_rank))
             except Exception as exc:
                 out["replay_leg_error"] = repr(exc)[:200]
         json_out.write(json.dumps(out) + "\n")

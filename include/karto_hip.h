@@ -522,6 +522,13 @@ KH_API int kh_mapper_get_stats(const kh_mapper * m, kh_mapper_stats * out);
  * LifelongSlamToolbox::removeFromSlamGraph does, slam_toolbox_lifelong.cpp:330-342): the scan's edges leave its
  * neighbours, the graph and the solver (RemoveConstraint), the node leaves the solver (RemoveNode) and the scan list. */
 KH_API int kh_mapper_remove_node(kh_mapper * m, int32_t scan_id);
+/* Vertex::GetAdjacentVertices of the scan's vertex, in the reference's order (Mapper.h:338-361): *n = their number,
+ * `adjacent` (may be NULL) receives at most `capacity` scan ids.  Vertex::SetScore (Mapper.h:326-329), what
+ * LifelongSlamToolbox::updateScoresSlamGraph does to a vertex that stays (slam_toolbox_lifelong.cpp:356-365).  Together
+ * with kh_mapper_get_scan and kh_mapper_remove_node a host can run its own node-decay policy -- and the tests replay the
+ * library's policy with an independent restatement. */
+KH_API int kh_mapper_get_adjacency(const kh_mapper * m, int32_t scan_id, int32_t * adjacent, int32_t capacity, int32_t * n);
+KH_API int kh_mapper_set_node_score(kh_mapper * m, int32_t scan_id, double score);
 /* LifelongSlamToolbox::evaluateNodeDepreciation after every accepted scan (slam_toolbox_lifelong.cpp:149-178):
  * FindNearLinkedVertices within half the diagonal of the scan's bounding box, kh_lifelong_scores over them, removal of the
  * ones scoring below params->removal_score, the new score stored on the others.  params = NULL switches it off. */

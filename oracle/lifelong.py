@@ -96,3 +96,45 @@ def compute_scores(reference, candidates, p=None):
         else:
             score[k] = objective_score(iou[k], area[k], reading[k], c.n_edges, c.score, num, p)
     return kept, iou, area, reading, score
+
+
+def evaluate_node_depreciation(reference_id, boxes, adjacency, reference_xy, p=None):
+    """LifelongSlamToolbox::evaluateNodeDepreciation (slam_toolbox_lifelong.cpp:149-178) for the scan just added, with
+    lifelong_search_use_tree false: radius = half the diagonal of the scan's bounding box (:158-160),
+    FindNearLinkedVertices = the breadth-first walk over the graph's edges that stops at vertices farther than the radius
+    from the scan (Mapper.cpp:1263-1333, oracle/loops.py), computeScores (:295-329: the IoU / edge-count filter ERASES
+    candidates in place, the survivors are scored with the surviving count), then in that order: score below
+    lifelong_node_removal_score -> removeFromSlamGraph, else updateScoresSlamGraph.
+
+    boxes: scan id -> ScanBox of every scan still in the map (n_edges = GetEdges().size(), score = Vertex::GetScore());
+    adjacency: scan id -> adjacent scan ids in GetAdjacentVertices order; reference_xy: scan id -> GetReferencePose() xy.
+    Returns the decisions in the reference's order: [("remove", id) | ("score", id, value)]."""
+    from collections import deque
+    p = p or DecayParams()
+    ref = boxes[reference_id]
+    w, h = ref.bbox_size
+    radius = np.sqrt(w * w + h * h) / 2.0
+    lim = radius * radius - 1e-06                              # NearScanVisitor::Visit, Mapper.cpp:1326-1327 (KT_TOLERANCE)
+    centre = reference_xy[reference_id]
+    near, seen, todo = [], {reference_id}, deque([reference_id])
+    while todo:
+        v = todo.popleft()
+        dx, dy = reference_xy[v][0] - centre[0], reference_xy[v][1] - centre[1]
+        if dx * dx + dy * dy <= lim:
+            near.append(v)
+            for u in adjacency[v]:
+                u = int(u)
+                if u not in seen:
+                    seen.add(u)
+                    todo.append(u)
+    cands = [boxes[v] for v in near]
+    kept, _, _, _, score = compute_scores(ref, cands, p)
+    out = []
+    for k, v in enumerate(near):
+        if not kept[k]:
+            continue
+        if score[k] < p.removal_score:
+            out.append(("remove", v))
+        else:
+            out.append(("score", v, float(score[k])))
+    return out

@@ -88,7 +88,7 @@ SYMBOLS = [
     "kh_graph_find_loop_candidates_from",
     "kh_mapper_params_default", "kh_mapper_create", "kh_mapper_create_on_devices", "kh_mapper_destroy", "kh_mapper_process", "kh_mapper_num_scans",
     "kh_mapper_num_edges", "kh_mapper_get_poses", "kh_mapper_get_scan", "kh_mapper_get_stats", "kh_mapper_solver",
-    "kh_mapper_set_log", "kh_mapper_remove_node", "kh_mapper_set_lifelong", "kh_mapper_num_alive", "kh_mapper_get_alive",
+    "kh_mapper_set_log", "kh_mapper_remove_node", "kh_mapper_get_adjacency", "kh_mapper_set_node_score", "kh_mapper_set_lifelong", "kh_mapper_num_alive", "kh_mapper_get_alive",
     "kh_graph_set_scan_limit", "kh_graph_find_near_linked", "kh_graph_append_scan", "kh_graph_add_edge", "kh_graph_set_position",
 ]
 
@@ -251,6 +251,8 @@ def lib():
         L.kh_mapper_params_default.argtypes = [C.POINTER(KhMapperParams)]
         L.kh_mapper_params_default.restype = None
         L.kh_mapper_create.argtypes = [C.POINTER(KhMapperParams), C.POINTER(KhLaser), i32, i32, C.POINTER(vp)]
+        L.kh_mapper_get_adjacency.argtypes = [vp, i32, iptr, i32, C.POINTER(i32)]
+        L.kh_mapper_set_node_score.argtypes = [vp, i32, dbl]
         L.kh_mapper_create_on_devices.argtypes = [C.POINTER(KhMapperParams), C.POINTER(KhLaser), iptr, i32, i32, C.POINTER(vp)]
         L.kh_mapper_destroy.argtypes = [vp]
         L.kh_mapper_destroy.restype = None

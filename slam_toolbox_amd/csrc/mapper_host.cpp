@@ -906,6 +906,22 @@ int kh_mapper_get_scan(const kh_mapper * m, int32_t index, kh_scan * scan, kh_sc
   return KH_OK;
 }
 
+int kh_mapper_get_adjacency(const kh_mapper * m, int32_t scan_id, int32_t * adjacent, int32_t capacity, int32_t * n)
+{
+  if (!m || !n || scan_id < 0 || scan_id >= static_cast<int32_t>(m->scans.size()) || !m->scans[scan_id]) {return KH_ERR_NOT_FOUND;}
+  const std::vector<int32_t> & a = m->adj[scan_id];
+  *n = static_cast<int32_t>(a.size());
+  if (adjacent) {std::copy(a.begin(), a.begin() + std::min<size_t>(a.size(), static_cast<size_t>(std::max(capacity, 0))), adjacent);}
+  return KH_OK;
+}
+
+int kh_mapper_set_node_score(kh_mapper * m, int32_t scan_id, double score)
+{
+  if (!m || scan_id < 0 || scan_id >= static_cast<int32_t>(m->scans.size()) || !m->scans[scan_id]) {return KH_ERR_NOT_FOUND;}
+  m->scans[scan_id]->score = score;
+  return KH_OK;
+}
+
 int kh_mapper_remove_node(kh_mapper * m, int32_t scan_id)
 {
   if (!m) {return KH_ERR_INVALID_ARG;}

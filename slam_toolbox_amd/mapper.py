@@ -67,6 +67,20 @@ class Mapper:
         capi.check(capi.lib().kh_mapper_get_scan(self._h, index, C.byref(s), C.byref(b)), "kh_mapper_get_scan")
         return s, b
 
+    def adjacency(self, scan_id: int) -> np.ndarray:
+        """Vertex::GetAdjacentVertices of the scan's vertex, in the reference's order"""
+        n = C.c_int32(0)
+        out = np.zeros(64, dtype=np.int32)
+        capi.check(capi.lib().kh_mapper_get_adjacency(self._h, int(scan_id), out, out.size, C.byref(n)), "kh_mapper_get_adjacency")
+        if n.value > out.size:
+            out = np.zeros(n.value, dtype=np.int32)
+            capi.check(capi.lib().kh_mapper_get_adjacency(self._h, int(scan_id), out, out.size, C.byref(n)), "kh_mapper_get_adjacency")
+        return out[:n.value]
+
+    def SetNodeScore(self, scan_id: int, score: float):
+        """Vertex::SetScore (LifelongSlamToolbox::updateScoresSlamGraph)"""
+        capi.check(capi.lib().kh_mapper_set_node_score(self._h, int(scan_id), float(score)), "kh_mapper_set_node_score")
+
     def RemoveNode(self, scan_id: int):
         """Mapper::RemoveNodeFromGraph + MapperSensorManager::RemoveScan (what lifelong mode does to a decayed node)"""
         capi.check(capi.lib().kh_mapper_remove_node(self._h, int(scan_id)), "kh_mapper_remove_node")

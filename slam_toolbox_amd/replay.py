@@ -22,7 +22,11 @@ class LapQueue:
     """n_scans scans of the lap circuit (synth.trajectory_laps).  The circuit is periodic, so the exact ray casting is done
     once per circuit position and every scan adds its own range noise, +inf and NaN beams on top."""
 
-    def __init__(self, n_scans: int, seed: int = 4, aisles=(0, 1), drift_xy: float = 0.02, drift_theta_deg: float = 0.5):
+    # Odometry noise per 0.5 m step: 5 mm in x and y (1 %) and 0.1 deg (0.2 deg/m) -- ordinary wheel odometry.  The round-2
+    # queue used 2 cm and 0.5 deg per step (4 %, 1 deg/m): with that the REFERENCE mapper itself ends 0.24 m rms / 1.2 m max
+    # from the ground truth after 1500 scans (tools/replay_vs_reference.py: reference and library poses identical bit for
+    # bit), so the map's agreement with the truth said nothing about this library.  With this noise both end at 2.3 cm rms.
+    def __init__(self, n_scans: int, seed: int = 4, aisles=(0, 1), drift_xy: float = 0.005, drift_theta_deg: float = 0.1):
         self.laser = synth.Laser()
         self.world = synth.make_world(12345)
         self.truth, self.odom = synth.trajectory_laps(n_scans, aisles=aisles, drift_xy=drift_xy, drift_theta_deg=drift_theta_deg)
@@ -44,28 +48,35 @@ class LapQueue:
 
 
 def run(n_scans: int, lifelong: bool = True, mode: str = "sync", period_s: float = 0.025, device: int = 0,
-        max_candidates: int = 32, map_resolution: float = 0.05, progress=None, **mapper_params):
+        max_candidates: int = 32, map_resolution: float = 0.05, progress=None, devices=None, queue=None, **mapper_params):
     """Replays the queue; returns a dict with the throughput, the mapper's own statistics and the map agreement."""
     from .mapper import Mapper
     from .occupancy_grid import OccupancyGrid
     from .scan_matcher import LocalizedRangeScan
-    q = LapQueue(n_scans)
-    m = Mapper(q.laser, device=device, max_candidates=max_candidates, **mapper_params)
+    q = queue or LapQueue(n_scans)
+    m = Mapper(q.laser, device=device, max_candidates=max_candidates, devices=devices, **mapper_params)
     if lifelong:
         m.SetLifelong(True)
     # the queue is made up front so that the timed region holds the mapper, not the ray casting
     all_ranges = [q.ranges(i) for i in range(n_scans)]
     t0 = time.perf_counter()
     processed = dropped = accepted = 0
+    waited_s = 0.0
     queue_index = []                       # scan id -> position in the queue
     i = 0
     while i < n_scans:
         if mode == "async":
-            # the scan the depth-1 queue holds now: the most recent one that has arrived
-            latest = min(n_scans - 1, int((time.perf_counter() - t0) / period_s))
+            # scan k ARRIVES at k * period_s.  The depth-1 queue holds the most recent arrival: a mapper that is behind
+            # skips to it (the ones in between are dropped), a mapper that is ahead waits for the next scan to arrive --
+            # with a mapper faster than the sensor nothing is dropped and the run lasts n_scans * period_s
+            now = time.perf_counter() - t0
+            latest = min(n_scans - 1, int(now / period_s))
             if latest > i:
                 dropped += latest - i
                 i = latest
+            elif now < i * period_s:
+                time.sleep(i * period_s - now)
+                waited_s += i * period_s - now
         ok, _, _ = m.Process(all_ranges[i], q.odom[i], 0.1 * i)
         processed += 1
         if ok:
@@ -79,6 +90,21 @@ def run(n_scans: int, lifelong: bool = True, mode: str = "sync", period_s: float
     wall = time.perf_counter() - t0
     st = m.stats()
     alive = m.alive()
+    # connected components of the pose graph that is left (node decay removes vertices with their edges: nothing in
+    # LifelongSlamToolbox::evaluateNodeDepreciation keeps the graph connected)
+    comp_of = {}
+    for root in alive.tolist():
+        if root in comp_of:
+            continue
+        comp_of[root] = root
+        todo = [root]
+        while todo:
+            v = todo.pop()
+            for u in m.adjacency(v).tolist():
+                if u not in comp_of:
+                    comp_of[u] = root
+                    todo.append(u)
+    comp_sizes = sorted(np.unique(list(comp_of.values()), return_counts=True)[1].tolist(), reverse=True) if comp_of else []
     poses = m.poses()[alive]
     truth = q.truth[[queue_index[k] for k in alive]]
     # final map: OccupancyGrid::CreateFromScans over the scans still in the graph at their corrected poses, against the map
@@ -129,6 +155,8 @@ def run(n_scans: int, lifelong: bool = True, mode: str = "sync", period_s: float
     near_aligned = float((occ_c & dilate(occ_b)).sum()) / max(1, int(occ_c.sum()))
     out = {"scans": n_scans, "processed": processed, "dropped": dropped, "accepted": accepted, "alive": int(len(alive)),
            "wall_s": wall, "scans_per_s": processed / wall, "mode": mode, "lifelong": lifelong,
+           "graph_components": len(comp_sizes), "graph_largest_components": comp_sizes[:5],
+           "period_s": period_s if mode == "async" else None, "waited_for_arrivals_s": waited_s, "busy_s": wall - waited_s,
            "map_build_ms": map_ms, "map_cells": [int(ref_grid.width), int(ref_grid.height)],
            "map_occupied": int(occ_a.sum()), "map_free": int((cells == 255).sum()),
            "map_iou_vs_truth_poses": iou, "map_occupied_within_one_cell_of_truth_map": near,
@@ -140,6 +168,8 @@ def run(n_scans: int, lifelong: bool = True, mode: str = "sync", period_s: float
                        "pose_error_xy_rms_m": float(np.sqrt((da[:, :2] ** 2).sum(1).mean())),
                        "pose_error_heading_max_rad": float(np.abs(da[:, 2]).max())},
            "stats": st}
+    out["poses"] = poses
+    out["alive_queue_index"] = [queue_index[k] for k in alive]
     ref_grid.close()
     m.close()
     return out

@@ -1,0 +1,101 @@
+"""GPU: the node-decay POLICY of lifelong mode -- which vertices are candidates, in which order they are scored, removal
+while iterating, score write-back (LifelongSlamToolbox::evaluateNodeDepreciation, src/experimental/slam_toolbox_lifelong.cpp:
+149-178, 294-329) -- replayed over an 800-scan queue twice: once by the library (kh_mapper_set_lifelong: the policy runs
+inside kh_mapper_process), once by oracle/lifelong.py::evaluate_node_depreciation driving a NON-lifelong mapper through its
+public entry points (state out: kh_mapper_get_scan / kh_mapper_get_adjacency; decisions in: kh_mapper_remove_node /
+kh_mapper_set_node_score).  The two runs must remove the same nodes at the same scans in the same order, end with the same
+graph, and log the same solver calls line by line.  (The score arithmetic itself is pinned with the reference's own five
+known answers in tests/test_lifelong_oracle.py / test_lifelong_gpu.py; the reference node needs rclcpp and cannot be built here.)"""
+import numpy as np
+import pytest
+
+from common import bits
+from slam_toolbox_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _queue(n_scans):
+    world = synth.make_world(12345)
+    truth, odom = synth.trajectory_laps(n_scans)
+    rng = np.random.default_rng(4)
+    ranges = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], rng) for i in range(n_scans)]))
+    return ranges, np.ascontiguousarray(odom)
+
+
+def _log_lines(path):
+    return [" ".join(l.split()[:2]) if l.startswith("X ") else l.rstrip("\n") for l in open(path) if not l.startswith("Z ")]
+
+
+def test_lifelong_policy_equals_the_oracle_control_flow(kartohip_lib, tmp_path):
+    from oracle import lifelong
+    from slam_toolbox_amd.mapper import Mapper
+    n_scans = 800
+    ranges, odom = _queue(n_scans)
+    # run A: the library's own policy
+    log_a = str(tmp_path / "a.log")
+    a = Mapper(synth.Laser(), log_path=log_a)
+    a.SetLifelong(True)
+    removed_a = []
+    for i in range(n_scans):
+        before = set(a.alive().tolist())
+        ok, _, _ = a.Process(ranges[i], odom[i], 0.1 * i)
+        gone = before - set(a.alive().tolist())
+        removed_a.append(sorted(gone))
+    # run B: the oracle's restatement of the control flow on a mapper that does not decay by itself
+    log_b = str(tmp_path / "b.log")
+    b = Mapper(synth.Laser(), log_path=log_b)
+    p = lifelong.DecayParams()
+    removed_b, decisions = [], 0
+
+    class Boxes(dict):
+        def __missing__(self, sid):
+            _, box = b.scan(sid)
+            pts = np.ctypeslib.as_array(box.points_xy, shape=(max(box.n_points, 1), 2))[:box.n_points].copy() if box.n_points else np.zeros((0, 2))
+            self[sid] = lifelong.ScanBox((box.barycenter[0], box.barycenter[1]), (box.bbox_size[0], box.bbox_size[1]), pts,
+                                         box.unique_id, box.n_edges, box.score)
+            return self[sid]
+
+    class Adjacency(dict):
+        def __missing__(self, sid):
+            self[sid] = b.adjacency(sid)
+            return self[sid]
+
+    class RefXY(dict):
+        def __init__(self, boxes):
+            super().__init__()
+            self.boxes = boxes
+
+        def __missing__(self, sid):
+            self[sid] = self.boxes[sid].barycenter          # GetReferencePose(use_scan_barycenter = true)
+            return self[sid]
+
+    for i in range(n_scans):
+        ok, _, _ = b.Process(ranges[i], odom[i], 0.1 * i)
+        gone = []
+        if ok:
+            sid = b.num_scans() - 1
+            boxes = Boxes()
+            todo = lifelong.evaluate_node_depreciation(sid, boxes, Adjacency(), RefXY(boxes), p)
+            decisions += len(todo)
+            for d in todo:
+                if d[0] == "remove":
+                    b.RemoveNode(d[1])
+                    gone.append(d[1])
+                else:
+                    b.SetNodeScore(d[1], d[2])
+        removed_b.append(sorted(gone))
+    n_removed = sum(len(g) for g in removed_a)
+    print(f"lifelong policy: {a.num_scans()} scans accepted, {n_removed} removed by the library, {sum(len(g) for g in removed_b)} by the oracle "
+          f"policy, {decisions} scored candidates")
+    assert n_removed >= 20, "the queue does not exercise the decay"
+    first = next((i for i in range(n_scans) if removed_a[i] != removed_b[i]), None)
+    assert first is None, f"removals differ first at queue scan {first}: library {removed_a[first]} oracle {removed_b[first]}"
+    assert np.array_equal(a.alive(), b.alive())
+    assert np.array_equal(bits(a.poses()[a.alive()]), bits(b.poses()[b.alive()]))
+    a.set_log(None); b.set_log(None)
+    la, lb = _log_lines(log_a), _log_lines(log_b)
+    for k, (x, y) in enumerate(zip(la, lb)):
+        assert x == y, f"solver-call logs diverge at line {k}:\n  library policy: {x}\n  oracle policy : {y}"
+    assert len(la) == len(lb)
+    a.close(); b.close()

@@ -15,4 +15,5 @@ ap.add_argument("--period", type=float, default=0.025)
 ap.add_argument("--progress", type=int, default=0)
 a = ap.parse_args()
 out = replay.run(a.scans, lifelong=not a.no_lifelong, mode=a.mode, period_s=a.period, progress=a.progress or None)
+out.pop("poses", None); out.pop("alive_queue_index", None)
 print(json.dumps(out))
