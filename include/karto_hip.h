@@ -257,6 +257,9 @@ typedef struct kh_spa_summary {
   double symbolic_ms;           /* host: pattern + ordering + symbolic factorisation + uploads (0 when the topology was cached) */
   double worst_linear_residual; /* KH_SPA_CHECK=1 only (else 0): max over the iterations of |(Hs + D/radius) step + gs| / |gs|,
                                    evaluated from the block-sparse matrix, independent of the factorisation */
+  int32_t analysis;             /* symbolic analysis of this Compute(): 0 none (topology unchanged), 1 full nested dissection,
+                                   2 incremental (supernodes of the last dissection reused, new nodes as leading leaves) */
+  int32_t analysis_pad;
 } kh_spa_summary;
 
 KH_API int kh_spa_create(int32_t device, kh_spa ** out);

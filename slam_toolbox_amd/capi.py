@@ -59,7 +59,7 @@ class KhSpaSummary(C.Structure):
                 ("nnz_factor", C.c_int64), ("factor_flops", C.c_int64), ("factorizations", C.c_int32),
                 ("levels", C.c_int32), ("factor_gpu_ms", C.c_double), ("backward_gpu_ms", C.c_double),
                 ("linearize_gpu_ms", C.c_double), ("symbolic_ms", C.c_double),
-                ("worst_linear_residual", C.c_double)]
+                ("worst_linear_residual", C.c_double), ("analysis", C.c_int32), ("analysis_pad", C.c_int32)]
 
 
 # every symbol include/karto_hip.h declares (tests check that the built library exports all of them)

@@ -112,6 +112,10 @@ struct kh_spa
   // is reset and re-added unchanged -- loadSerializedPoseGraph followed by Compute -- keeps its ordering, symbolic
   // factorisation and device index maps
   std::vector<int32_t> cached_ea, cached_eb; int32_t cached_n = -1, cached_fixed = -2;
+  // supernodes of the last nested dissection by NODE ID (incremental re-analysis), the factorisation cost and size it had
+  std::vector<std::vector<int32_t>> cached_sn_ids;
+  int64_t cached_full_flops = 0; int32_t cached_full_nf = 0; int32_t reuse_count = 0;
+  int32_t last_analysis_incremental = 0;
   // device buffers
   DevBuf<int32_t> d_edge_a, d_edge_b, d_free_of_node, d_node_of_free, d_slot_contrib_ptr, d_slot_contrib,
     d_bsr_row_ptr, d_bsr_col, d_bsr_diag, d_node_contrib_ptr, d_node_contrib, d_front_m, d_front_ns,
@@ -314,6 +318,64 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       row_ptr[i + 1] = static_cast<int32_t>(col.size());
     }
     const int32_t n_slots = static_cast<int32_t>(col.size());
+    // Ordering + fronts on a thread of their own, beside the contribution lists below (both only read the adjacency).
+    // INCREMENTAL re-analysis: a loop closure adds a few dozen nodes and edges to a graph that was dissected milliseconds
+    // ago (and lifelong mode removes a few).  The supernodes of the last dissection, kept by node id, are reused -- the
+    // nodes that have left drop out, the new ones become leading leaf supernodes (eliminated first: no extra levels; their
+    // old neighbours become mutually adjacent, which the structure pass accounts for like any fill) -- and only the structure
+    // is rebuilt.  A full dissection again when the new nodes pass a quarter of the graph, when the fill has grown by half,
+    // or after kMaxReuse re-analyses.  kh_spa_reset() forgets the supernodes (a reloaded graph is analysed from scratch).
+    const auto t_sym0 = std::chrono::steady_clock::now();
+    SymbolicOptions sopt;
+    if (const char * e = std::getenv("KH_SPA_LEAF")) {sopt.leaf_nodes = std::max(1, std::atoi(e));}
+    if (const char * e = std::getenv("KH_SPA_PMAX")) {sopt.max_pivot_nodes = std::min(42, std::max(1, std::atoi(e)));}
+    if (const char * e = std::getenv("KH_SPA_CANDS")) {sopt.separator_candidates = std::max(1, std::atoi(e));}
+    static const bool incremental_on = !(std::getenv("KH_SPA_INCREMENTAL") && std::atoi(std::getenv("KH_SPA_INCREMENTAL")) == 0);
+    int sym_rc = KH_OK;
+    bool sym_incremental = false;
+    std::string sym_error;
+    std::thread sym_thread([&]() {
+      constexpr int kMaxReuse = 24;
+      std::vector<std::vector<int32_t>> sn;
+      if (incremental_on && !s->cached_sn_ids.empty() && s->reuse_count < kMaxReuse) {
+        // node id -> free index of this problem
+        std::unordered_map<int32_t, int32_t> free_of_id;
+        free_of_id.reserve(static_cast<size_t>(nf) * 2);
+        for (int32_t f = 0; f < nf; ++f) {free_of_id[s->nodes[s->node_of_free[f]].id] = f;}
+        std::vector<uint8_t> placed(nf, 0);
+        int32_t kept = 0;
+        for (const auto & ids : s->cached_sn_ids) {
+          std::vector<int32_t> g;
+          for (int32_t id : ids) {
+            auto it = free_of_id.find(id);
+            if (it != free_of_id.end()) {g.push_back(it->second); placed[it->second] = 1; ++kept;}
+          }
+          if (!g.empty()) {std::sort(g.begin(), g.end()); sn.push_back(std::move(g));}
+        }
+        if (nf - kept <= std::max(64, nf / 4)) {
+          std::vector<int32_t> fresh;
+          for (int32_t f = 0; f < nf; ++f) {if (!placed[f]) {fresh.push_back(f);}}
+          if (!fresh.empty()) {sn.insert(sn.begin(), std::move(fresh));}          // build_structure splits it into a chain when long
+          sym_rc = build_structure(s->sym, nf, adj_ptr, adj_idx, sopt, sn);
+          if (sym_rc == KH_OK && s->sym.factor_flops <= s->cached_full_flops * 3 / 2 * std::max<int64_t>(1, (nf + s->cached_full_nf - 1) / std::max(1, s->cached_full_nf))) {
+            sym_incremental = true;
+            return;
+          }
+        }
+      }
+      std::vector<std::vector<int32_t>> dissected;
+      sym_rc = nested_dissection(nf, adj_ptr, adj_idx, sopt, dissected);
+      if (sym_rc == KH_OK) {
+        s->cached_sn_ids.assign(dissected.size(), {});
+        for (size_t k = 0; k < dissected.size(); ++k) {
+          for (int32_t f : dissected[k]) {s->cached_sn_ids[k].push_back(s->nodes[s->node_of_free[f]].id);}
+        }
+        sym_rc = build_structure(s->sym, nf, adj_ptr, adj_idx, sopt, dissected);
+        s->cached_full_flops = s->sym.factor_flops; s->cached_full_nf = nf; s->reuse_count = 0;
+      }
+      if (sym_rc != KH_OK) {sym_error = kh_last_error();}
+    });
+    struct Joiner {std::thread & t; ~Joiner() {if (t.joinable()) {t.join();}}} sym_joiner{sym_thread};
     auto slot_of = [&](int32_t i, int32_t j) {
       const auto b = col.begin() + row_ptr[i], e2 = col.begin() + row_ptr[i + 1];
       return static_cast<int32_t>(std::lower_bound(b, e2, j) - col.begin());
@@ -343,17 +405,16 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       if (fa >= 0) {ncl[nfill[fa]++] = e * 2 + 0;}
       if (fb >= 0) {ncl[nfill[fb]++] = e * 2 + 1;}
     }
-    // ordering + fronts
-    const auto t_sym0 = std::chrono::steady_clock::now();
-    SymbolicOptions sopt;
-    if (const char * e = std::getenv("KH_SPA_LEAF")) {sopt.leaf_nodes = std::max(1, std::atoi(e));}
-    if (const char * e = std::getenv("KH_SPA_PMAX")) {sopt.max_pivot_nodes = std::min(42, std::max(1, std::atoi(e)));}
-    if (const char * e = std::getenv("KH_SPA_CANDS")) {sopt.separator_candidates = std::max(1, std::atoi(e));}
-    int rc = build_symbolic(s->sym, nf, adj_ptr, adj_idx, sopt);
-    if (rc) {return rc;}
+    const auto t_lists = std::chrono::steady_clock::now();
+    sym_thread.join();
+    if (sym_rc) {set_error(sym_error); return sym_rc;}
+    if (sym_incremental) {++s->reuse_count;}
+    s->last_analysis_incremental = sym_incremental ? 1 : 0;
+    int rc = KH_OK;
     if (std::getenv("KH_SPA_DEBUG")) {
-      std::fprintf(stderr, "[kh_spa] host: pattern %.2f ms, symbolic %.2f ms\n",
+      std::fprintf(stderr, "[kh_spa] host: adjacency %.2f ms, lists %.2f ms beside the %s analysis (%.2f ms)\n",
         std::chrono::duration<double, std::milli>(t_sym0 - t_prep0).count(),
+        std::chrono::duration<double, std::milli>(t_lists - t_sym0).count(), sym_incremental ? "incremental" : "full",
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sym0).count());
     }
     if (std::getenv("KH_SPA_DEBUG")) {
@@ -597,6 +658,7 @@ int kh_spa_reset(kh_spa * s)     // ceres_solver.cpp:279-314
   s->nodes.clear(); s->index_of.clear(); s->cons.clear(); s->con_of.clear(); s->incident.clear(); s->n_dead = 0; s->n_dead_nodes = 0;
   s->corr_ids.clear(); s->corr_poses.clear();
   s->has_first = false; s->was_constant_set = false; s->topology_dirty = true; s->fixed_index = -1;
+  s->cached_sn_ids.clear(); s->reuse_count = 0;        // a rebuilt graph is dissected from scratch
   return KH_OK;
 }
 
@@ -1295,6 +1357,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   sum.linearize_ms = lin_ms; sum.solve_ms = solve_ms;
   sum.factor_flops = sym.factor_flops; sum.factorizations = iteration; sum.levels = n_levels;
   sum.symbolic_ms = s->last_symbolic_ms;
+  sum.analysis = s->last_symbolic_ms > 0.0 ? (s->last_analysis_incremental ? 2 : 1) : 0;
   {
     // every recorded event has completed: each iteration ended with a stream synchronisation
     float ms = 0.0f;

@@ -128,8 +128,10 @@ void cut_vertex_cover(NdContext & ctx, const std::vector<int32_t> & order, const
   for (int32_t r = 0; r < nr; ++r) {if (zr[r]) {cover.push_back(right[r]);}}
 }
 
-// appends the supernodes of `nodes` to `out` in elimination order (A's, B's, then the separator)
-void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & out, int depth)
+// appends the supernodes of `nodes` to `out` in elimination order (A's, B's, then the separator).  `hint`: a vertex of the
+// subset known to lie at one of its ends (the root or the farthest vertex of the parent's level structure, whichever side
+// the subset came from), or -1: with a hint ONE breadth-first search gives connectivity and the level structure.
+void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & out, int depth, int32_t hint = -1)
 {
   if (nodes.empty()) {return;}
   if (static_cast<int32_t>(nodes.size()) <= ctx.opt.leaf_nodes) {
@@ -141,17 +143,18 @@ void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & o
   for (int32_t v : nodes) {ctx.tag[v] = st;}
   std::vector<int32_t> order;
   order.reserve(nodes.size());
-  nd_bfs(ctx, nodes[0], st, order);
-  auto both = [&](std::vector<int32_t> & A, std::vector<int32_t> & B) {
+  const bool hinted = hint >= 0 && ctx.tag[hint] == st;
+  nd_bfs(ctx, hinted ? hint : nodes[0], st, order);
+  auto both = [&](std::vector<int32_t> & A, std::vector<int32_t> & B, int32_t hint_a, int32_t hint_b) {
     if (depth < ctx.opt.parallel_depth && A.size() > 256 && B.size() > 256) {
       SupernodeList out_b;
-      std::thread tb([&] {nd_recurse(ctx, B, out_b, depth + 1);});
-      nd_recurse(ctx, A, out, depth + 1);
+      std::thread tb([&] {nd_recurse(ctx, B, out_b, depth + 1, hint_b);});
+      nd_recurse(ctx, A, out, depth + 1, hint_a);
       tb.join();
       for (auto & sn : out_b) {out.push_back(std::move(sn));}
     } else {
-      nd_recurse(ctx, A, out, depth + 1);
-      nd_recurse(ctx, B, out, depth + 1);
+      nd_recurse(ctx, A, out, depth + 1, hint_a);
+      nd_recurse(ctx, B, out, depth + 1, hint_b);
     }
   };
   if (order.size() < nodes.size()) {
@@ -159,11 +162,11 @@ void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & o
     std::vector<int32_t> comp = order, rest;
     for (int32_t v : comp) {ctx.tag[v] = 0;}
     for (int32_t v : nodes) {if (ctx.tag[v] == st) {rest.push_back(v);}}
-    both(comp, rest);
+    both(comp, rest, -1, -1);
     return;
   }
-  // pseudo-peripheral start: restart the BFS from the farthest vertex
-  {
+  // pseudo-peripheral start: restart the BFS from the farthest vertex (a hinted start already is such a vertex)
+  if (!hinted) {
     const int32_t far = order.back();
     nd_bfs(ctx, far, st, order);
   }
@@ -211,18 +214,16 @@ void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & o
     if (ctx.dist[v] < best_l) {A.push_back(v);} else {B.push_back(v);}
   }
   if (A.empty() || B.empty()) {as_leaf(); return;}
-  both(A, B);
+  both(A, B, order.front(), order.back());      // the near side holds the root of this level structure, the far side its last vertex
   std::sort(best_cover.begin(), best_cover.end());
   out.push_back(best_cover);
 }
 
 }  // namespace
 
-int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
-  const SymbolicOptions & opt)
+int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
+  const SymbolicOptions & opt, std::vector<std::vector<int32_t>> & supernodes)
 {
-  sym = Symbolic();
-  sym.n_free = n_free;
   NdContext ctx;
   ctx.adj_ptr = &adj_ptr;
   ctx.adj_idx = &adj_idx;
@@ -232,9 +233,30 @@ int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & 
   ctx.loc.assign(n_free, -1);
   std::vector<int32_t> all(n_free);
   for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
+  supernodes.clear();
+  nd_recurse(ctx, all, supernodes, 0);
+  return KH_OK;
+}
+
+int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
+  const SymbolicOptions & opt)
+{
   SupernodeList dissected;
   const auto t_nd0 = std::chrono::steady_clock::now();
-  nd_recurse(ctx, all, dissected, 0);
+  int rc = nested_dissection(n_free, adj_ptr, adj_idx, opt, dissected);
+  if (rc) {return rc;}
+  if (std::getenv("KH_SPA_DEBUG")) {
+    std::fprintf(stderr, "[kh_spa] symbolic: nested dissection %.2f ms\n",
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nd0).count());
+  }
+  return build_structure(sym, n_free, adj_ptr, adj_idx, opt, dissected);
+}
+
+int build_structure(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
+  const SymbolicOptions & opt, std::vector<std::vector<int32_t>> & dissected)
+{
+  sym = Symbolic();
+  sym.n_free = n_free;
   const auto t_nd1 = std::chrono::steady_clock::now();
   // a front's pivot block is factored inside one workgroup's LDS: larger supernodes become a chain of fronts (each part
   // the only child of the next; same columns, same fill)
@@ -340,8 +362,7 @@ int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & 
   sym.fronts_size = off;
   sym.winv_size = woff;
   if (std::getenv("KH_SPA_DEBUG")) {
-    std::fprintf(stderr, "[kh_spa] symbolic: nested dissection %.2f ms, structure %.2f ms\n",
-      std::chrono::duration<double, std::milli>(t_nd1 - t_nd0).count(),
+    std::fprintf(stderr, "[kh_spa] symbolic: structure %.2f ms\n",
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nd1).count());
   }
   sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);

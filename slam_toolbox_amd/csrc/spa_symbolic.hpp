@@ -39,7 +39,7 @@ struct SymbolicOptions
   int32_t leaf_nodes = 12;          // subsets of at most this many nodes are not dissected further
   int32_t max_pivot_nodes = 42;     // supernodes with more pivots are split into a chain of fronts (42 nodes = 126 columns:
                                     // the pivot block of a front is factored inside one workgroup's LDS, 128 x 130 doubles)
-  int32_t separator_candidates = 4; // BFS levels tried as the cut of a subset (each one refined to a minimum vertex cover)
+  int32_t separator_candidates = 2; // BFS levels tried as the cut of a subset (each one refined to a minimum vertex cover)
   int32_t parallel_depth = 4;       // recursion levels whose two halves run on separate threads
   double balance_lo = 0.35;         // a cut must leave at least this fraction of the subset on the near side ...
   double balance_hi = 0.65;         // ... and at most this
@@ -49,5 +49,13 @@ struct SymbolicOptions
 // self loops.  Returns 0 or a KH_ERR_* code (message through kh::set_error).
 int build_symbolic(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
   const SymbolicOptions & opt);
+// The two halves of build_symbolic.  nested_dissection: the supernodes in elimination order (before the chain split).
+// build_structure: everything else, for ANY partition of the free nodes into supernodes in a valid elimination order --
+// e.g. the supernodes of an earlier analysis with the nodes that have left removed and the new nodes as leading leaves
+// (the solver's incremental re-analysis after a loop closure); `supernodes` is consumed.
+int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
+  const SymbolicOptions & opt, std::vector<std::vector<int32_t>> & supernodes);
+int build_structure(Symbolic & sym, int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
+  const SymbolicOptions & opt, std::vector<std::vector<int32_t>> & supernodes);
 
 }  // namespace kh

@@ -185,4 +185,12 @@ def test_config3_spa_10k_nodes_30k_edges(kartohip_lib):
     dt = _diff(sol.poses(), ref_t)
     assert dt < 1e-5, dt
     print(f"config[3] tight: {summ['iterations']} iterations, max |pose - oracle| {dt:.2e}")
+    # The exposure of the 1e-4 bar to Ceres' trajectory (the oracle is unpinned at the Ceres boundary):
+    # with the plugin's function_tolerance 1e-3 the solve stops after 9 iterations, and that iterate is NOT near the optimum --
+    # it sits decimetres away, so agreeing with Ceres to 1e-4 means reproducing its trajectory (same steps, same stopping
+    # iteration), not just its minimiser
+    early_vs_optimum_xy = float(np.abs((ref_x - ref_t)[:, :2]).max())
+    early_vs_optimum_h = float(np.abs((ref_x - ref_t)[:, 2]).max())
+    print(f"config[3] exposure: max |early-stopped iterate - tight optimum| = {early_vs_optimum_xy:.3f} m, {early_vs_optimum_h:.4f} rad")
+    assert 0.1 < early_vs_optimum_xy < 2.0 and early_vs_optimum_h > 1e-3
     sol.close()

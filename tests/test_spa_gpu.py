@@ -254,3 +254,52 @@ def test_linear_solves_of_pose_graphs(kartohip_lib, n, e, seed):
     sg, xg = _solve(g, check_linear_solves=True, factor_kernels=3, gather_children=True)
     assert sg["iterations"] == s3["iterations"] and 0.0 < sg["worst_linear_residual"] < 1e-9, sg
     assert _diff(xg, x3) < 1e-9
+
+
+def test_incremental_reanalysis_after_a_loop_closure(kartohip_lib):
+    """A solved graph grows by a stretch of new scans and a few loop-closure links, and loses a node: the next Compute()
+    reuses the supernodes of the last nested dissection (new nodes as leading leaves, summary.analysis == 2) and must return
+    what a solver that sees the final graph for the first time returns -- same iterations, same poses to rounding."""
+    from oracle import spa
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    g = synth.make_pose_graph(1500, 4000, seed=21)
+    n0, extra = 1470, 30                                   # the last 30 nodes arrive after the first solve
+    e = g["edges"]
+    first = (e[:, 0] < n0) & (e[:, 1] < n0)
+    a = HipSpaSolver()
+    a.set_debug(check_linear_solves=True)
+    for i in range(n0):
+        a.AddNode(i, g["init"][i])
+    for k in np.flatnonzero(first):
+        a.AddConstraint(int(e[k, 0]), int(e[k, 1]), g["z"][k], g["cov"][k].reshape(3, 3))
+    s1 = a.Compute()
+    assert s1["analysis"] == 1 and s1["usable"] == 1
+    x1 = np.array([p for _, p in a.GetCorrections()])
+    for i in range(n0, n0 + extra):
+        a.AddNode(i, g["init"][i])
+    for k in np.flatnonzero(~first):
+        a.AddConstraint(int(e[k, 0]), int(e[k, 1]), g["z"][k], g["cov"][k].reshape(3, 3))
+    a.RemoveNode(700)
+    s2 = a.Compute()
+    assert s2["analysis"] == 2, s2
+    assert 0.0 < s2["worst_linear_residual"] < 1e-9
+    # the same final graph, same starting point, analysed from scratch
+    b = HipSpaSolver()
+    start = np.vstack([x1, g["init"][n0:n0 + extra]])
+    keep = [i for i in range(n0 + extra) if i != 700]
+    for i in keep:
+        b.AddNode(i, start[i])
+    for k in range(e.shape[0]):
+        if 700 not in (int(e[k, 0]), int(e[k, 1])):
+            b.AddConstraint(int(e[k, 0]), int(e[k, 1]), g["z"][k], g["cov"][k].reshape(3, 3))
+    s3 = b.Compute()
+    assert s3["analysis"] == 1 and s3["iterations"] == s2["iterations"]
+    ids_a = [i for i, _ in a.GetCorrections()]
+    assert ids_a == keep
+    pa = np.array([p for _, p in a.GetCorrections()])
+    pb = np.array([p for _, p in b.GetCorrections()])
+    assert _diff(pa, pb) < 1e-8
+    # unchanged topology: no analysis at all
+    s4 = a.Compute()
+    assert s4["analysis"] == 0
+    a.close(); b.close()
