@@ -294,6 +294,15 @@ void ref_link_info(const double * pose1, const double * pose2, const double * co
   fill_cov(li.GetCovariance(), cov_out);
 }
 // Matrix3::Inverse (Karto.h:2533-2577)
+// Transform(pose1, pose2).TransformPose(src), Karto.h:2946-3024 (what Mapper::Process does to a new scan's odometric pose,
+// Mapper.cpp:2699-2703)
+void ref_transform_pose(const double * pose1, const double * pose2, const double * src, double * out)
+{
+  Transform t(Pose2(pose1[0], pose1[1], pose1[2]), Pose2(pose2[0], pose2[1], pose2[2]));
+  const Pose2 r = t.TransformPose(Pose2(src[0], src[1], src[2]));
+  out[0] = r.GetX(); out[1] = r.GetY(); out[2] = r.GetHeading();
+}
+
 void ref_matrix3_inverse(const double * a, double * out)
 {
   Matrix3 c;

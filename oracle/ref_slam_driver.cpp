@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <map>
@@ -245,7 +246,17 @@ static int run_queue(
       s->SetCorrectedPose(p);
       s->SetTime(0.1 * i);
       Matrix3 cov;
-      if (mapper.Process(s, &cov)) {kept.push_back(s);} else {delete s;}
+      if (mapper.Process(s, &cov)) {
+        kept.push_back(s);
+        // KH_LOG_FINAL_POSES (debugging aid, both sides): the scan's pose when Process() returns -- after the weighted mean
+        // of AddEdges and any loop closure, which no solver call shows
+        if (std::getenv("KH_LOG_FINAL_POSES")) {
+          const Pose2 f = s->GetCorrectedPose();
+          std::fprintf(log, "F %d %.17g %.17g %.17g\n", s->GetUniqueId(), f.GetX(), f.GetY(), f.GetHeading());
+        }
+      } else {
+        delete s;
+      }
       for (int r2 = 0; r2 < n_remove; ++r2) {
         if (remove_at[r2] != i) {continue;}
         LocalizedRangeScan * victim = mapper.m_pMapperSensorManager->GetScan(remove_id[r2]);

@@ -562,8 +562,10 @@ int kh_weighted_mean(int32_t n, const double * means, const double * covariances
   for (int32_t k = 0; k < n; ++k) {
     const double * p = means + 3 * static_cast<size_t>(k);
     const double * inv = &inverses[9 * static_cast<size_t>(k)];
-    theta_x += std::cos(p[2]);
-    theta_y += std::sin(p[2]);
+    double sin_h, cos_h;
+    ::sincos(p[2], &sin_h, &cos_h);          // one sincos like the reference's GCC build (see ref_sincos in matcher_host.cpp)
+    theta_x += cos_h;
+    theta_y += sin_h;
     double w[9];                                                     // inverseOfSumOfInverses * inverse, Karto.h:2634-2647
     for (int r = 0; r < 3; ++r) {
       for (int c = 0; c < 3; ++c) {

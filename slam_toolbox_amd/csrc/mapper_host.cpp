@@ -40,6 +40,11 @@ void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
 
 namespace
 {
+// cos and sin of ONE angle, the way the reference's Release build computes them: GCC (-O1 and up) merges a cos(a) / sin(a)
+// pair into one sincos(a) call, and glibc's sincos is NOT bit-identical to its cos and sin everywhere (a = 0.11462314399891493:
+// cos(a) = 0.9934379567501339, sincos(a) gives 0.993437956750134).  Every place where the reference takes both of the same
+// angle goes through here, so that the library does not depend on whether ITS compiler merges the pair (clang does not).
+static inline void ref_sincos(double a, double * s, double * c) {::sincos(a, s, c);}
 constexpr double kTolerance = 1e-06;                  // KT_TOLERANCE, Math.h:41
 constexpr double kPi = 3.14159265358979323846;        // Math.h:31
 constexpr double k2Pi = 6.28318530717958647692;       // Math.h:32
@@ -64,7 +69,9 @@ struct Mat3
   void identity() {std::memset(m, 0, sizeof(m)); m[0][0] = m[1][1] = m[2][2] = 1.0;}
   void from_axis_angle(double x, double y, double z, double radians)      // Karto.h:2482-2511
   {
-    const double cosRadians = std::cos(radians), sinRadians = std::sin(radians), oneMinusCos = 1.0 - cosRadians;
+    double cosRadians, sinRadians;
+    ref_sincos(radians, &sinRadians, &cosRadians);
+    const double oneMinusCos = 1.0 - cosRadians;
     const double xx = x * x, yy = y * y, zz = z * z;
     const double xyMCos = x * y * oneMinusCos, xzMCos = x * z * oneMinusCos, yzMCos = y * z * oneMinusCos;
     const double xSin = x * sinRadians, ySin = y * sinRadians, zSin = z * sinRadians;
@@ -147,8 +154,10 @@ void update_scan(MScan & s, const Laser & L)
   for (int32_t i = 0; i < L.n; ++i) {
     const double r = s.ranges[i];
     const double angle = sp.h + L.min_angle + static_cast<uint32_t>(i) * L.ang_res;
-    const double px = sp.x + (r * std::cos(angle));
-    const double py = sp.y + (r * std::sin(angle));
+    double sin_a, cos_a;
+    ref_sincos(angle, &sin_a, &cos_a);
+    const double px = sp.x + (r * cos_a);
+    const double py = sp.y + (r * sin_a);
     s.points[2 * i] = px; s.points[2 * i + 1] = py;
     if (r >= L.min_range && r <= L.range_threshold) {          // math::InRange
       sum_x += px; sum_y += py; ++n_filtered;
@@ -775,6 +784,19 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     m->stats.match_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     m->stats.matches += 1;
     if (rc) {return rc;}
+    // KH_MAPPER_DUMP_MATCH=<scan id>:<path> (debugging aid): the inputs and the result of this sequential match as raw doubles
+    // (n_base, n_beams, query pose, query ranges, per base scan: pose, ranges; mean, covariance, response)
+    static const char * dump_spec = std::getenv("KH_MAPPER_DUMP_MATCH");
+    if (dump_spec && std::atoi(dump_spec) == static_cast<int>(m->scans.size()) && std::strchr(dump_spec, ':')) {
+      if (FILE * f = std::fopen(std::strchr(dump_spec, ':') + 1, "wb")) {
+        const double hdr[2] = {static_cast<double>(base.size()), static_cast<double>(q.n)};
+        std::fwrite(hdr, 8, 2, f);
+        std::fwrite(q.sensor_pose, 8, 3, f); std::fwrite(q.ranges, 8, static_cast<size_t>(q.n), f);
+        for (const kh_scan & b : base) {std::fwrite(b.sensor_pose, 8, 3, f); std::fwrite(b.ranges, 8, static_cast<size_t>(b.n), f);}
+        std::fwrite(mean, 8, 3, f); std::fwrite(cov, 8, 9, f); std::fwrite(&response, 8, 1, f);
+        std::fclose(f);
+      }
+    }
     set_sensor_pose(m, *scan, mean);
   }
   // AddScan: state id = unique id = position in the list (:2727)
@@ -875,6 +897,9 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     if (rc) {return rc;}
   }
   guard.armed = false;
+  if (m->log && std::getenv("KH_LOG_FINAL_POSES")) {     // debugging aid, see oracle/ref_slam_driver.cpp
+    std::fprintf(m->log, "F %d %.17g %.17g %.17g\n", id, s.corrected.x, s.corrected.y, s.corrected.h);
+  }
   *accepted = 1;
   if (corrected_pose) {corrected_pose[0] = s.corrected.x; corrected_pose[1] = s.corrected.y; corrected_pose[2] = s.corrected.h;}
   if (covariance) {std::copy(cov, cov + 9, covariance);}

@@ -44,6 +44,11 @@ void set_error(const std::string & s) {g_last_error = s;}
   } while (0)
 
 // ---- exact scalar helpers (Math.h) ----------------------------------------------------------
+// cos and sin of ONE angle, the way the reference's Release build computes them: GCC (-O1 and up) merges a cos(a) / sin(a)
+// pair into one sincos(a) call, and glibc's sincos is NOT bit-identical to its cos and sin everywhere (a = 0.11462314399891493:
+// cos(a) = 0.9934379567501339, sincos(a) gives 0.993437956750134).  Every place where the reference takes both of the same
+// angle goes through here, so that the library does not depend on whether ITS compiler merges the pair (clang does not).
+static inline void ref_sincos(double a, double * s, double * c) {::sincos(a, s, c);}
 constexpr double kTolerance = 1e-06;                 // Math.h:41
 constexpr double kPi = 3.14159265358979323846;       // Math.h:31
 constexpr double k2Pi = 6.28318530717958647692;      // Math.h:32
@@ -798,8 +803,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     for (int32_t a = 0; a < c.na; ++a) {
       const double angle = startAngle + static_cast<uint32_t>(a) * c.ang_res;
       c.angles[a] = angle;
-      cos_sin[2 * a] = std::cos(angle);          // Karto.h:6857-6858
-      cos_sin[2 * a + 1] = std::sin(angle);
+      ref_sincos(angle, &cos_sin[2 * a + 1], &cos_sin[2 * a]);          // Karto.h:6857-6858
       const double squaredAngleDistance = (angle - c.center[2]) * (angle - c.center[2]);
       double anglePenalty = 1.0 - (kAngleGain * squaredAngleDistance / mp.angle_variance_penalty);
       anglePenalty = anglePenalty > mp.minimum_angle_penalty ? anglePenalty : mp.minimum_angle_penalty;
@@ -827,7 +831,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
         r00 = 1; r01 = 0; r02 = 0; r10 = 0; r11 = 1; r12 = 0;
       } else {
         const double radians = 0.0 - th;
-        const double cosR = std::cos(radians), sinR = std::sin(radians), omc = 1.0 - cosR;
+        double cosR, sinR;
+        ref_sincos(radians, &sinR, &cosR);
+        const double omc = 1.0 - cosR;
         r00 = 0.0 * omc + cosR;
         r01 = 0.0 * 0.0 * omc - 1.0 * sinR;
         r02 = 0.0 * 1.0 * omc + 0.0 * sinR;
@@ -1047,8 +1053,10 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       ax += c.center[0] + c.x_poses[xi];
       ay += c.center[1] + c.y_poses[yi];
       const double heading = normalize_angle(c.angles[a]);
-      thetaX += std::cos(heading);
-      thetaY += std::sin(heading);
+      double sin_h, cos_h;
+      ref_sincos(heading, &sin_h, &cos_h);
+      thetaX += cos_h;
+      thetaY += sin_h;
     }
     const int32_t count = static_cast<int32_t>(ties.size());
     ax /= count; ay /= count; thetaX /= count; thetaY /= count;
@@ -1215,8 +1223,10 @@ int kh_scan_points(const double * ranges, int32_t n, const double sensor_pose[3]
   if (!ranges || !out || n < 0) {return KH_ERR_INVALID_ARG;}
   for (int32_t i = 0; i < n; ++i) {          // Karto.h:5663-5682
     const double angle = sensor_pose[2] + min_angle + static_cast<uint32_t>(i) * angular_resolution;
-    out[2 * i] = sensor_pose[0] + (ranges[i] * std::cos(angle));
-    out[2 * i + 1] = sensor_pose[1] + (ranges[i] * std::sin(angle));
+    double sin_a, cos_a;
+    ref_sincos(angle, &sin_a, &cos_a);
+    out[2 * i] = sensor_pose[0] + (ranges[i] * cos_a);
+    out[2 * i + 1] = sensor_pose[1] + (ranges[i] * sin_a);
   }
   return KH_OK;
 }

@@ -63,6 +63,10 @@ struct DevBuf
     if (p) {KS_HIP(hipFree(p)); p = nullptr;}
     cap = std::max(n, cap + cap / 2);
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T)));
+    // KH_SPA_POISON=1 (debugging aid): new buffers start as NaN / -1 patterns, so that a kernel that reads what nobody
+    // wrote shows up as a failed solve instead of as a last-bit difference between two processes
+    static const bool poison = std::getenv("KH_SPA_POISON") != nullptr;
+    if (poison) {KS_HIP(hipMemset(p, 0xFF, cap * sizeof(T))); KS_HIP(hipDeviceSynchronize());}
     return KH_OK;
   }
   int upload(const std::vector<T> & v, hipStream_t s)
@@ -83,6 +87,8 @@ struct kh_spa
 {
   int32_t device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;               // the part of a level's extend-add that k_potrf does not read
+  hipEvent_t ev_level[2] = {};
   kh_spa_options opt;
   std::vector<Node> nodes;                       // insertion order
   std::unordered_map<int32_t, int32_t> index_of; // id -> position in nodes
@@ -587,6 +593,8 @@ int kh_spa_create(int32_t device, kh_spa ** out)
   kh_spa_options_default(&s->opt);
   KS_HIP(hipSetDevice(device));
   KS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  KS_HIP(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+  for (auto & e : s->ev_level) {KS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));}
   KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_scal), sizeof(double) * 32, hipHostMallocDefault));
   KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_fail), sizeof(int32_t) * 4, hipHostMallocDefault));
   for (auto & row : s->ev_phase) {for (auto & e : row) {KS_HIP(hipEventCreate(&e));}}
@@ -614,6 +622,8 @@ void kh_spa_destroy(kh_spa * s)
   for (auto & row : s->ev_lin) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
   if (s->h_fail) {(void)hipHostFree(s->h_fail);}
+  if (s->stream2) {(void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2);}
+  for (auto & e : s->ev_level) {if (e) {(void)hipEventDestroy(e);}}
   if (s->stream) {(void)hipStreamDestroy(s->stream);}
   delete s;
 }
@@ -1030,7 +1040,7 @@ int kh_link_info(const double pose1[3], const double pose2[3], const double cov[
   const double x1 = pose1[0], y1 = pose1[1], t1 = pose1[2];
   double c = 1.0, sn = 0.0, tx = 0.0, ty = 0.0, tth = 0.0;
   if (!(x1 == 0.0 && y1 == 0.0 && t1 == 0.0)) {
-    c = std::cos(0.0 - t1); sn = std::sin(0.0 - t1);
+    ::sincos(0.0 - t1, &sn, &c);             // one sincos like the reference's GCC build (see ref_sincos in matcher_host.cpp)
     if (x1 != 0.0 || y1 != 0.0) {
       tx = 0.0 - (c * x1 + (0.0 - sn) * y1 + 0.0 * t1);
       ty = 0.0 - (sn * x1 + c * y1 + 0.0 * t1);
@@ -1041,7 +1051,8 @@ int kh_link_info(const double pose1[3], const double pose2[3], const double cov[
   diff[1] = ty + (sn * pose2[0] + c * pose2[1] + 0.0 * pose2[2]);
   diff[2] = karto_normalize_angle(pose2[2] + tth);
   // covariance rotated into the frame of pose1: R(-t1) * cov * R(-t1)^T (Matrix3 triple-loop products)
-  const double cr = std::cos(-t1), sr = std::sin(-t1);
+  double cr, sr;
+  ::sincos(-t1, &sr, &cr);
   const double omc = 1.0 - cr;      // Matrix3::FromAxisAngle(0, 0, 1, -t1), Karto.h:2482-2511
   const double R[9] = {0.0 * omc + cr, 0.0 - sr, 0.0, 0.0 + sr, 0.0 * omc + cr, 0.0, 0.0, 0.0, 1.0 * omc + cr};
   double tmp[9], Rt[9];
@@ -1221,8 +1232,26 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       const int32_t n_level = s->level_offsets[l + 1] - s->level_offsets[l];
       const int32_t * lf = s->d_level_fronts.p + s->level_offsets[l];
       if (pipeline) {
-        if (l > 0 && !dev.gather) {spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st);}
-        spa_launch_factor3_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
+        // The children's update matrices go into the pivot blocks first (all k_potrf reads); the rest of the extend-add
+        // runs on a second stream BESIDE the pivot chains and is waited for before the row solves.
+        // (measured on the 10k / 30k graph: 14.7 ms per solve with the split against 13.2 without -- two event records and two
+        // stream waits per level on the critical stream cost more than the overlap wins; off unless KH_SPA_EA_OVERLAP=1)
+        static const bool overlap_ea = std::getenv("KH_SPA_EA_OVERLAP") && std::atoi(std::getenv("KH_SPA_EA_OVERLAP")) != 0;
+        const bool split_ea = l > 0 && !dev.gather && overlap_ea && s->stream2 && !dbg_sync;
+        if (l > 0 && !dev.gather) {
+          if (split_ea) {
+            KS_HIP(hipEventRecord(s->ev_level[0], st));                    // the level below is complete
+            KS_HIP(hipStreamWaitEvent(s->stream2, s->ev_level[0], 0));
+            spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], s->stream2, 2, s->level_max_ns[l]);
+            KS_HIP(hipEventRecord(s->ev_level[1], s->stream2));
+            spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st, 1, s->level_max_ns[l]);
+          } else {
+            spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st);
+          }
+        }
+        spa_launch_potrf_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
+        if (split_ea) {KS_HIP(hipStreamWaitEvent(st, s->ev_level[1], 0));}
+        spa_launch_update_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_rhs.p, s->d_upd.p, st);
         dbg("potrf+trsm+syrk", l);
         continue;
       }

@@ -102,14 +102,17 @@ void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int
                              double * rhs, double * upd, double * fsb, int32_t * sync, int32_t matrix_added, void * stream);
 // the children's update matrices of every front of the level summed into the fronts, one workgroup per (front, 16
 // destination columns); follow with spa_launch_factor_level(..., matrix_added = 1, ...)
-void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream);
+// part 0: everything; 1: only the pivot blocks (max_ns = most pivot columns of a front of the level); 2: everything else
+void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream, int32_t part = 0,
+                           int32_t max_ns = 0);
 // upd: per-front forward-solve contributions to the ancestors, 3 * front_rows_ptr[n_fronts] doubles
 void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, double * rhs, void * stream);
 // round-3 level pipeline (potrf -> trsm -> syrk, see spa_kernels.hip): the children's update matrices must already be summed
 // into the fronts (spa_launch_extend_add); also does the forward solve of the level like spa_launch_factor_level
 // (the level = fronts first_front .. first_front + n - 1)
-void spa_launch_factor3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
-                              double * rhs, double * upd, void * stream);
+void spa_launch_potrf_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
+                            double * rhs, double * upd, void * stream);
+void spa_launch_update_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, double * upd, void * stream);
 void spa_launch_backward3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, void * stream);
 // whether the largest front of a problem fits the LDS budgets of the level pipeline (otherwise: panel-pair kernels)
 bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns);

@@ -734,11 +734,15 @@ __device__ __forceinline__ void trailing_update(double * F, const double * Xs, i
 // where most of the chip idles.  A child's struct rows map to INCREASING positions in the parent (both are in
 // elimination order), so the child columns that land in this workgroup's destination block are one contiguous range;
 // every entry of the block is summed by this workgroup alone, children in turn: no atomics, the same order every run.
-__global__ __launch_bounds__(1024) void k_extend_add(SpaDev d, const int32_t * __restrict__ level_fronts)
+// part: 0 everything; 1 only the front's PIVOT BLOCK (destination rows and columns < ns: what k_potrf reads); 2 everything
+// else (it runs on a second stream beside k_potrf of the same level).
+__global__ __launch_bounds__(1024) void k_extend_add(SpaDev d, const int32_t * __restrict__ level_fronts, int part)
 {
   const int nw = (int)blockDim.x >> 6;
   const int k = level_fronts[blockIdx.x];
   const int m = d.front_m[k];
+  const int nsp_front = d.front_ns[k];
+  if (part == 1 && 16 * (int)blockIdx.y >= nsp_front) {return;}
   const int c_lo = 16 * (int)blockIdx.y, c_hi = min(m, c_lo + 16);
   if (c_lo >= m) {return;}
   double * F = d.fronts + d.front_off[k];
@@ -776,19 +780,29 @@ __global__ __launch_bounds__(1024) void k_extend_add(SpaDev d, const int32_t * _
     hi = nuc;
     while (lo < hi) {const int mid = (lo + hi) >> 1; if (pos(mid) < c_hi) {lo = mid + 1;} else {hi = mid;}}
     const int b_hi = lo;
+    // first child row that lands below the front's pivot block
+    int a_piv = nuc;
+    if (part != 0) {
+      int l2 = 0, h2 = nuc;
+      while (l2 < h2) {const int mid = (l2 + h2) >> 1; if (pos(mid) < nsp_front) {l2 = mid + 1;} else {h2 = mid;}}
+      a_piv = l2;
+    }
     for (int b = b_lo + wave; b < b_hi; b += nw) {
       double * dst = F + (int64_t)pos(b) * m;
       const double * src = Uc + (int64_t)b * mc;
-      for (int a0 = b; a0 < nuc; a0 += 256) {
+      const bool pivot_col = b < a_piv;
+      const int a_begin = part == 2 && pivot_col ? max(b, a_piv) : b;
+      const int a_end = part == 1 ? (pivot_col ? a_piv : 0) : nuc;
+      for (int a0 = a_begin; a0 < a_end; a0 += 256) {
         // four rows per lane in flight
         double u[4], f[4];
         int pa[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int a = a0 + lane + 64 * q;
-          pa[q] = a < nuc ? pos(a) : -1;
-          u[q] = a < nuc ? src[a] : 0.0;
-          f[q] = a < nuc ? dst[pa[q]] : 0.0;
+          pa[q] = a < a_end ? pos(a) : -1;
+          u[q] = a < a_end ? src[a] : 0.0;
+          f[q] = a < a_end ? dst[pa[q]] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {if (pa[q] >= 0) {dst[pa[q]] = f[q] + u[q];}}
@@ -799,14 +813,15 @@ __global__ __launch_bounds__(1024) void k_extend_add(SpaDev d, const int32_t * _
   }
 }
 
-void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream)
+void spa_launch_extend_add(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, void * stream, int32_t part, int32_t max_ns)
 {
   if (n <= 0) {return;}
+  if (part == 1) {max_m = std::min(max_m, max_ns);}      // only the column blocks of the pivot block have work
   // one wave per destination column of the block of 16 (with four waves a workgroup walked its columns four at a time, each
   // walk a round trip to memory); wide levels keep the small workgroups
   static const int ea_threads = std::getenv("KH_SPA_EA_THREADS") ? std::atoi(std::getenv("KH_SPA_EA_THREADS")) : 0;
   const int threads = ea_threads ? ea_threads : ((int64_t)n * ((max_m + 15) / 16) > 512 ? 256 : 1024);
-  hipLaunchKernelGGL(k_extend_add, dim3(n, (max_m + 15) / 16), dim3(threads), 0, (hipStream_t)stream, d, level_fronts);
+  hipLaunchKernelGGL(k_extend_add, dim3(n, (max_m + 15) / 16), dim3(threads), 0, (hipStream_t)stream, d, level_fronts, (int)part);
 }
 
 // ---- workgroup-level hand-offs between the workgroups that share one front (agent scope: the L1 of a CU is never
@@ -2216,8 +2231,8 @@ __global__ __launch_bounds__(1024) void k_backward3(SpaDev d, int first_front, d
     for (int j = c + lane; j < ns; j += 64) {
       const double wj = sb[j];
       a0 += w0[j] * wj;
-      a1 += w1[j] * wj;
-    }
+      a1 += j > c ? w1[j] * wj : 0.0;       // row c + 1 starts at column c + 1: left of it W holds nothing (not even zeros when
+    }                                        // c + 1 opens a new block of 16)
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
     if (lane == 0) {xo[c] = a0; if (c + 1 < ns) {xo[c + 1] = a1;}}
@@ -2237,12 +2252,8 @@ bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns)
   return max_ns <= kPotrfMaxNs && potrf_lds_bytes(nsp, max_m) <= 160 * 1024 - 256 && sizeof(double) * ((size_t)max_m + nsp + 8) <= 64 * 1024;
 }
 
-void spa_launch_factor3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
-                              double * rhs, double * upd, void * stream)
+static void pipeline_attributes()
 {
-  if (n <= 0) {return;}
-  hipStream_t s = (hipStream_t)stream;
-  const int nsp = (max_ns + NB - 1) & ~(NB - 1);
   static bool attr_set = false;
   if (!attr_set) {
     const int big = 160 * 1024 - 256;       // static LDS (a flag word) counts against the same 160 KB
@@ -2254,6 +2265,15 @@ void spa_launch_factor3_level(const SpaDev & d, int32_t first_front, int32_t n, 
     (void)hipGetLastError();
     attr_set = true;
   }
+}
+
+void spa_launch_potrf_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
+                            double * rhs, double * upd, void * stream)
+{
+  if (n <= 0) {return;}
+  hipStream_t s = (hipStream_t)stream;
+  const int nsp = (max_ns + NB - 1) & ~(NB - 1);
+  pipeline_attributes();
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
   if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 128 * sizeof(long long), hipHostMallocDefault);}
@@ -2269,6 +2289,14 @@ void spa_launch_factor3_level(const SpaDev & d, int32_t first_front, int32_t n, 
     }
     std::fprintf(stderr, "\n");
   }
+}
+
+void spa_launch_update_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, double * upd, void * stream)
+{
+  if (n <= 0) {return;}
+  hipStream_t s = (hipStream_t)stream;
+  const int nsp = (max_ns + NB - 1) & ~(NB - 1);
+  pipeline_attributes();
   const int max_nu = max_m - 3;       // a front has at least one pivot node; an upper bound is enough for the grid
   if (max_nu <= 0) {return;}
   // slabs / tiles: small enough that a narrow level still spreads over the chip, large enough that a wide one does not

@@ -67,3 +67,25 @@ def test_missing_rccl_is_an_error_code_not_a_crash(kartohip_lib):
     env = dict(os.environ, KH_RCCL_LIBRARY="/nonexistent/librccl.so.1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_paired_cos_sin_follow_the_reference_build(kartohip_lib):
+    """The reference's Release build (GCC) turns every cos(a) / sin(a) pair of one angle into one sincos(a) call, and
+    glibc's sincos differs from its cos in the last bit for some angles (found by the 2000-scan drop-in run: a 1-ulp
+    difference in Transform::TransformPose, Karto.h:2946-3024, grew into a diverging solver log).  kh_scan_points restates
+    LocalizedRangeScan::Update (Karto.h:5644-5704), one of those pairs: it must return sincos' values."""
+    import ctypes
+    import numpy as np
+    a = 0.11462314399891493
+    libm = ctypes.CDLL("libm.so.6")
+    libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    libm.cos.restype = ctypes.c_double
+    libm.cos.argtypes = [ctypes.c_double]
+    s, c = ctypes.c_double(), ctypes.c_double()
+    libm.sincos(a, ctypes.byref(s), ctypes.byref(c))
+    if c.value == libm.cos(a):
+        pytest.skip("this libm's sincos agrees with cos for the probe angle")
+    out = np.zeros(2)
+    rc = kartohip_lib.kh_scan_points(np.ones(1), 1, np.array([0.0, 0.0, a]), 0.0, 0.01, out)
+    assert rc == capi.KH_OK
+    assert out[0] == c.value and out[1] == s.value
