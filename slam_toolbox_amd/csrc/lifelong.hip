@@ -47,21 +47,12 @@ __device__ __forceinline__ double d_iou(const BoxDev & a, const BoxDev & b)
   return i / uni;
 }
 
-__global__ __launch_bounds__(256) void k_decay_filter(BoxDev ref, const BoxDev * cands, int32_t n, double iou_thresh,
-  double * iou_out, int32_t * kept, int32_t * n_kept)
-{
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) {return;}
-  const double iou = d_iou(ref, cands[k]);
-  iou_out[k] = iou;
-  const int keep = !(iou < iou_thresh || cands[k].edges < 2);
-  kept[k] = keep;
-  if (keep) {atomicAdd(n_kept, 1);}
-}
-
-__global__ __launch_bounds__(256) void k_decay_score(BoxDev ref, const BoxDev * cands, int32_t n, const double * points,
-  kh_decay_params p, const double * iou_in, const int32_t * kept, const int32_t * n_kept, double * area_out,
-  double * reading_out, double * score_out)
+// one wave per candidate: the filter of computeScores (IoU below lifelong_minimum_score or fewer than 2 edges -> dropped), the
+// reading count, the metrics and the objective.  (computeScore hands the number of surviving candidates to
+// computeObjectiveScore, which computes candidate_scale_factor from it and never uses it, :231-240: nothing here needs the
+// count, so the filter does not have to be a kernel of its own.)
+__global__ __launch_bounds__(256) void k_decay(BoxDev ref, const BoxDev * cands, int32_t n, const double * points, kh_decay_params p,
+  double * iou_out, double * area_out, double * reading_out, double * score_out, int32_t * kept)
 {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= n) {return;}
@@ -77,16 +68,18 @@ __global__ __launch_bounds__(256) void k_decay_score(BoxDev ref, const BoxDev * 
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) {inner += __shfl_xor(inner, s);}
   if (lane != 0) {return;}
+  const double iou = d_iou(ref, c);
+  const int keep = !(iou < p.iou_thresh || c.edges < 2);
   const double area = d_intersect(ref, c) / (c.h * c.w);
   const double reading = (double)inner / (double)c.n_pts;
+  iou_out[wave] = iou; kept[wave] = keep;
   area_out[wave] = area; reading_out[wave] = reading;
   double score = 0.0;
-  if (kept[wave]) {
+  if (keep) {
     const bool lynch = c.id == 0 || c.id == 1;
     if (ref.id - c.id < p.scan_buffer_size || lynch) {
       score = c.score;
     } else {
-      const double iou = iou_in[wave];
       if (iou > p.iou_match && c.edges < 3) {
         score = -1.0;
       } else {
@@ -95,7 +88,6 @@ __global__ __launch_bounds__(256) void k_decay_score(BoxDev ref, const BoxDev * 
         csf = csf < 0.0 ? 0.0 : csf;                                                            // std::max(0., ...)
         csf = csf < 1.0 ? csf : 1.0;                                                            // std::min(1.0, ...)
         csf = overlap < csf ? overlap : csf;                                                    // std::min(csf, overlap)
-        (void)n_kept;                                    // candidate_scale_factor is computed but unused (:231-240)
         score = c.score * (1.0 + csf) - overlap - p.nearby_penalty;
         if (score > 1.0) {score = 1.0;}
       }
@@ -129,29 +121,23 @@ int kh_lifelong_scores(int32_t device, const kh_scan_box * reference, int32_t n,
   }
   if (n == 0) {return KH_OK;}
   if (hipSetDevice(device) != hipSuccess) {return KH_ERR_HIP;}
-  std::vector<BoxDev> boxes(n);
-  std::vector<double> pts;
-  auto box = [](const kh_scan_box & s) {
-    BoxDev b; b.bx = s.barycenter[0]; b.by = s.barycenter[1]; b.w = s.bbox_size[0]; b.h = s.bbox_size[1];
-    b.id = s.unique_id; b.edges = s.n_edges; b.score = s.score; b.pt_begin = 0; b.n_pts = 0; b.pad = 0;
-    return b;
-  };
-  for (int32_t k = 0; k < n; ++k) {
-    if (candidates[k].n_points < 0 || (candidates[k].n_points > 0 && !candidates[k].points_xy)) {return KH_ERR_INVALID_ARG;}
-    boxes[k] = box(candidates[k]);
-    boxes[k].pt_begin = static_cast<int64_t>(pts.size() / 2);
-    boxes[k].n_pts = candidates[k].n_points;
-    pts.insert(pts.end(), candidates[k].points_xy, candidates[k].points_xy + 2 * static_cast<size_t>(candidates[k].n_points));
-  }
-  const BoxDev ref = box(*reference);
-  // device scratch kept between calls (a mapper scores the neighbourhood of every accepted scan: four allocations and
-  // frees per call cost more than the two kernels); one set per calling thread and device
+  // One call per accepted scan of a lifelong mapper, a dozen candidates each: the call is all latency.  Inputs are packed
+  // straight into ONE pinned block (boxes, then the points), one asynchronous copy in, one kernel, one copy out, one wait
+  // (the first version: three blocking copies in, a memset, two kernels, two blocking copies out = 110 us per call,
+  // 3.7 s of the 50 000-scan replay).  Scratch is kept per calling thread and device.
   struct Scratch
   {
     int32_t device = -1;
-    BoxDev * boxes = nullptr; double * pts = nullptr; double * out = nullptr; int32_t * kept = nullptr;
-    size_t cap_boxes = 0, cap_pts = 0, cap_out = 0, cap_kept = 0;
-    void release() {(void)hipFree(boxes); (void)hipFree(pts); (void)hipFree(out); (void)hipFree(kept); *this = Scratch();}
+    hipStream_t stream = nullptr;
+    char * h_in = nullptr; char * d_in = nullptr; char * h_out = nullptr; char * d_out = nullptr;
+    size_t cap_in = 0, cap_out = 0;
+    void release()
+    {
+      if (h_in) {(void)hipHostFree(h_in);} if (h_out) {(void)hipHostFree(h_out);}
+      if (d_in) {(void)hipFree(d_in);} if (d_out) {(void)hipFree(d_out);}
+      if (stream) {(void)hipStreamDestroy(stream);}
+      *this = Scratch();
+    }
     ~Scratch() {}          // freed with the process: the HIP runtime may already be gone when thread-local destructors run
   };
   static thread_local Scratch scratch;
@@ -161,26 +147,55 @@ int kh_lifelong_scores(int32_t device, const kh_scan_box * reference, int32_t n,
     return KH_ERR_HIP;
   };
   const size_t nn = static_cast<size_t>(n);
-  auto grow = [&](auto *& p, size_t & cap, size_t need) {
-    if (need <= cap) {return true;}
-    if (p) {(void)hipFree(p); p = nullptr;}
-    cap = std::max(need, 2 * cap);
-    return hipMalloc(reinterpret_cast<void **>(&p), cap * sizeof(*p)) == hipSuccess;
+  size_t n_pts = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    if (candidates[k].n_points < 0 || (candidates[k].n_points > 0 && !candidates[k].points_xy)) {return KH_ERR_INVALID_ARG;}
+    n_pts += static_cast<size_t>(candidates[k].n_points);
+  }
+  const size_t in_bytes = nn * sizeof(BoxDev) + std::max<size_t>(n_pts, 1) * 16;
+  const size_t out_bytes = nn * (4 * sizeof(double) + sizeof(int32_t));
+  if (!scratch.stream && hipStreamCreateWithFlags(&scratch.stream, hipStreamNonBlocking) != hipSuccess) {return fail("stream creation failed");}
+  if (in_bytes > scratch.cap_in) {
+    if (scratch.h_in) {(void)hipHostFree(scratch.h_in); scratch.h_in = nullptr;}
+    if (scratch.d_in) {(void)hipFree(scratch.d_in); scratch.d_in = nullptr;}
+    scratch.cap_in = std::max(in_bytes, 2 * scratch.cap_in);
+    if (hipHostMalloc(reinterpret_cast<void **>(&scratch.h_in), scratch.cap_in, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&scratch.d_in), scratch.cap_in) != hipSuccess) {scratch.release(); return fail("allocation failed");}
+  }
+  if (out_bytes > scratch.cap_out) {
+    if (scratch.h_out) {(void)hipHostFree(scratch.h_out); scratch.h_out = nullptr;}
+    if (scratch.d_out) {(void)hipFree(scratch.d_out); scratch.d_out = nullptr;}
+    scratch.cap_out = std::max(out_bytes, 2 * scratch.cap_out);
+    if (hipHostMalloc(reinterpret_cast<void **>(&scratch.h_out), scratch.cap_out, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&scratch.d_out), scratch.cap_out) != hipSuccess) {scratch.release(); return fail("allocation failed");}
+  }
+  auto box = [](const kh_scan_box & s) {
+    BoxDev b; b.bx = s.barycenter[0]; b.by = s.barycenter[1]; b.w = s.bbox_size[0]; b.h = s.bbox_size[1];
+    b.id = s.unique_id; b.edges = s.n_edges; b.score = s.score; b.pt_begin = 0; b.n_pts = 0; b.pad = 0;
+    return b;
   };
-  if (!grow(scratch.boxes, scratch.cap_boxes, nn) || !grow(scratch.pts, scratch.cap_pts, std::max<size_t>(pts.size(), 2)) ||
-    !grow(scratch.out, scratch.cap_out, 4 * nn) || !grow(scratch.kept, scratch.cap_kept, nn + 1)) {scratch.release(); return fail("allocation failed");}
-  BoxDev * d_boxes = scratch.boxes; double * d_pts = scratch.pts; double * d_out = scratch.out; int32_t * d_kept = scratch.kept;
-  if (hipMemcpy(d_boxes, boxes.data(), nn * sizeof(BoxDev), hipMemcpyHostToDevice) != hipSuccess ||
-    (!pts.empty() && hipMemcpy(d_pts, pts.data(), pts.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ||
-    hipMemset(d_kept + nn, 0, 4) != hipSuccess) {return fail("upload failed");}
-  double * d_iou = d_out, * d_area = d_out + nn, * d_read = d_out + 2 * nn, * d_score = d_out + 3 * nn;
-  hipLaunchKernelGGL(k_decay_filter, dim3((n + 255) / 256), dim3(256), 0, nullptr, ref, d_boxes, n, params->iou_thresh, d_iou, d_kept, d_kept + nn);
-  hipLaunchKernelGGL(k_decay_score, dim3((n + 3) / 4), dim3(256), 0, nullptr, ref, d_boxes, n, d_pts, *params, d_iou, d_kept,
-    d_kept + nn, d_area, d_read, d_score);
-  std::vector<double> out(4 * nn);
-  std::vector<int32_t> k_host(nn);
-  if (hipMemcpy(out.data(), d_out, out.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-    hipMemcpy(k_host.data(), d_kept, nn * 4, hipMemcpyDeviceToHost) != hipSuccess) {return fail("download failed");}
+  BoxDev * h_boxes = reinterpret_cast<BoxDev *>(scratch.h_in);
+  double * h_pts = reinterpret_cast<double *>(scratch.h_in + nn * sizeof(BoxDev));
+  size_t at = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    h_boxes[k] = box(candidates[k]);
+    h_boxes[k].pt_begin = static_cast<int64_t>(at);
+    h_boxes[k].n_pts = candidates[k].n_points;
+    std::copy(candidates[k].points_xy, candidates[k].points_xy + 2 * static_cast<size_t>(candidates[k].n_points), h_pts + 2 * at);
+    at += static_cast<size_t>(candidates[k].n_points);
+  }
+  const BoxDev ref = box(*reference);
+  hipStream_t st = scratch.stream;
+  if (hipMemcpyAsync(scratch.d_in, scratch.h_in, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {return fail("upload failed");}
+  const BoxDev * d_boxes = reinterpret_cast<const BoxDev *>(scratch.d_in);
+  const double * d_pts = reinterpret_cast<const double *>(scratch.d_in + nn * sizeof(BoxDev));
+  double * d_iou = reinterpret_cast<double *>(scratch.d_out), * d_area = d_iou + nn, * d_read = d_iou + 2 * nn, * d_score = d_iou + 3 * nn;
+  int32_t * d_kept = reinterpret_cast<int32_t *>(d_iou + 4 * nn);
+  hipLaunchKernelGGL(k_decay, dim3((n + 3) / 4), dim3(256), 0, st, ref, d_boxes, n, d_pts, *params, d_iou, d_area, d_read, d_score, d_kept);
+  if (hipMemcpyAsync(scratch.h_out, scratch.d_out, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+    hipStreamSynchronize(st) != hipSuccess) {return fail("kernel or download failed");}
+  const double * out = reinterpret_cast<const double *>(scratch.h_out);
+  const int32_t * k_host = reinterpret_cast<const int32_t *>(out + 4 * nn);
   for (size_t k = 0; k < nn; ++k) {
     if (iou) {iou[k] = out[k];}
     if (area_overlap) {area_overlap[k] = out[nn + k];}

@@ -37,6 +37,7 @@ namespace kh
 {
 void set_error(const std::string & s);
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
+void host_parallel_for_wide(size_t n, const std::function<void(size_t)> & fn);
 
 namespace
 {
@@ -399,22 +400,14 @@ int correct_poses(kh_mapper * m)
     s.corrected.x = poses[3 * k]; s.corrected.y = poses[3 * k + 1]; s.corrected.h = poses[3 * k + 2];
     update_scan(s, m->laser);
   };
-  // thousands of scans x 1081 sin / cos: wider than the matcher's worker pool (32 threads suit its sub-millisecond
-  // bursts; this is milliseconds of uniform work -- 64 threads halved it on the 50 000-scan replay)
-  const unsigned wide = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
-  if (n >= 4096 && wide > 32) {
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-      for (;;) {
-        const size_t b = next.fetch_add(64);
-        if (b >= static_cast<size_t>(n)) {return;}
-        for (size_t k = b; k < std::min(static_cast<size_t>(n), b + 64); ++k) {one(k);}
-      }
-    };
-    std::vector<std::thread> team;
-    for (unsigned t = 1; t < wide; ++t) {team.emplace_back(worker);}
-    worker();
-    for (auto & t : team) {t.join();}
+  // thousands of scans x 1081 sincos: wider than the matcher's worker pool (32 threads suit its sub-millisecond bursts;
+  // this is milliseconds of uniform work -- N x 1081 libm calls that have to stay on the host for bit-exactness,
+  // Karto.h:5488-5493, 5644-5704 -- so it goes to the wide pool in chunks of 32 scans)
+  if (n >= 2048) {
+    const size_t chunks = (static_cast<size_t>(n) + 31) / 32;
+    host_parallel_for_wide(chunks, [&](size_t c) {
+      for (size_t k = 32 * c; k < std::min(static_cast<size_t>(n), 32 * c + 32); ++k) {one(k);}
+    });
   } else {
     host_parallel_for(static_cast<size_t>(n), one);
   }

@@ -247,7 +247,12 @@ static int ensure_pinned(T *& p, size_t & cap, size_t need, hipStream_t stream)
 class HostPool
 {
 public:
-  static HostPool & instance() {static HostPool p; return p;}
+  static HostPool & instance() {static HostPool p(0); return p;}
+  // the mapper's pose re-projections: milliseconds of uniform work over thousands of scans, kept alive between calls (a team
+  // spawned per call cost a millisecond per loop closure).  64 threads: the work writes 35 KB per scan (points, filtered
+  // points) and is bound by the host's memory bandwidth well before the box runs out of cores -- 192 threads took 7.9 s of
+  // the 50 000-scan replay where 64 take 4
+  static HostPool & wide() {static HostPool p(1); return p;}
   // runs fn(i) for i in [0, n); returns when all are done
   void run(size_t n, const std::function<void(size_t)> & fn)
   {
@@ -274,10 +279,10 @@ public:
     for (auto & t : workers_) {t.join();}
   }
 private:
-  HostPool()
+  explicit HostPool(int wide_pool)
   {
-    unsigned want = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char * e = std::getenv("KH_HOST_THREADS")) {want = static_cast<unsigned>(std::max(1, std::atoi(e)));}
+    unsigned want = std::min(wide_pool ? 64u : 32u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char * e = std::getenv(wide_pool ? "KH_MAPPER_UPDATE_THREADS" : "KH_HOST_THREADS")) {want = static_cast<unsigned>(std::max(1, std::atoi(e)));}
     for (unsigned t = 1; t < want; ++t) {workers_.emplace_back([this] {loop();});}
   }
   void work()
@@ -316,6 +321,7 @@ private:
 };
 
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn) {HostPool::instance().run(n, fn);}
+void host_parallel_for_wide(size_t n, const std::function<void(size_t)> & fn) {HostPool::wide().run(n, fn);}
 
 // ---- rasterisation of n jobs (slots[i] <- base scans of job i) ------------------------------
 struct RasterReq {int32_t slot; const kh_scan * query; const kh_scan * base; int32_t n_base;};
