@@ -33,8 +33,14 @@ ALG_BYTES_C2 = C2["nx"] * C2["ny"] * C2["na"] * P_BEAMS * 5 + C2["nx"] * C2["ny"
 HBM_PEAK_GBS = 8000.0
 # L1 (TCP) data path: 64 B per clock per CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md: chip parameters, L1 32 KiB/CU)
 L1_PEAK_GBS = 64.0 * 256 * 2.4
+# measured on the box (tools/tcp_ceiling.hip, profiles/r3_tcp_ceiling.txt): a loop of k_score-shaped loads (four 64-byte row
+# segments per wave-level dword load) over an L1-resident window returns 37.6 TB/s = 4.2 clocks per load, whether the
+# segments touch 4 or 8 lines; the same loop over a window that misses the L1 and hits the L2 needs 8.0 (4 lines) to 10.7
+# (8 lines) clocks per load, i.e. about 1 clock more per missing line
+L1_MEASURED_CEILING_GBS = 37600.0
+L1_HIT_CLOCKS_PER_LOAD, L1_MISS_CLOCKS_PER_LINE = 4.2, 0.95
 FP64_PEAK_TFLOPS = 78.6            # MI355X FP64 vector = matrix peak (spec); v_mfma_f64_16x16x4_f64
-PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r2_k_score_pmc.json", "r1_k_score_pmc.json"))
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r3_k_score_pmc.json", "r2_k_score_pmc.json", "r1_k_score_pmc.json"))
                  if os.path.exists(p)), os.path.join(ROOT, "profiles", "r1_k_score_pmc.json"))
 
 
@@ -923,6 +929,10 @@ def main():
         rec = pmc_recorded()
         traffic = pmc_traffic(per_launch)
         rec_scale = per_launch / float(rec.get("matches_per_launch", per_launch)) if rec else 1.0
+        clocks_per_load = k3_ms * 1e-3 * 2.4e9 * 256 / max(1.0, loads_per_launch)
+        model_clocks = None
+        if rec.get("TCP_TCC_READ_REQ_sum") and rec.get("SQ_INSTS_VMEM_RD"):
+            model_clocks = L1_HIT_CLOCKS_PER_LOAD + L1_MISS_CLOCKS_PER_LINE * rec["TCP_TCC_READ_REQ_sum"] / rec["SQ_INSTS_VMEM_RD"]
         tag_frac = None
         if rec.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
             # one tag lookup per clock per CU: recorded TCP accesses per launch against 256 CUs x 2.4 GHz x this run's launch time
@@ -943,14 +953,18 @@ def main():
                          "unit": "GB/s", "frac": l1_gbs / L1_PEAK_GBS,
                          "wave_loads_per_launch": loads_per_launch, "avg_launch_ms": k3_ms, "matches_per_launch": per_launch,
                          "l1_tag_lookup_frac": tag_frac,
-                         "l1_tag_plus_data_frac": (tag_frac + l1_gbs / L1_PEAK_GBS) if tag_frac is not None else None,
+                         "l1_measured_ceiling_gbs": L1_MEASURED_CEILING_GBS, "frac_of_measured_ceiling": l1_gbs / L1_MEASURED_CEILING_GBS,
+                         "clocks_per_load": clocks_per_load, "clocks_per_load_model": model_clocks,
                          "traffic": traffic, "traffic_source": "recorded: " + os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 PMC passes of this "
                                                                "command; (2*FETCH_SIZE + WRITE_SIZE)*1024, scaled to this run's matches per launch)",
                          "hbm_frac": (traffic / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "algorithmic_gbs": alg_gbs, "algorithmic_ratio": alg_gbs / HBM_PEAK_GBS,
-                         "note": "bound = the vector L1 (TCP): it looks up tags and returns data serially for these loads, so its busy "
-                                 "fraction is the SUM of the data-path fraction `frac` and the tag-lookup fraction `l1_tag_lookup_frac` = "
-                                 "`l1_tag_plus_data_frac` ~ 1.0: the kernel runs at the L1's speed of light for the loads it issues "
+                         "note": "bound = the vector L1 (TCP).  `frac` = live L1->register byte rate over the data-path peak (64 B/clk/CU); "
+                                 "`frac_of_measured_ceiling` = the same over what a loop of the same load shape reaches on an L1-resident "
+                                 "window (profiles/r3_tcp_ceiling.txt: 37.6 TB/s, 4.2 clocks per load for 4..8 lines per load -- tag look-ups "
+                                 "and data return overlap, which retires round 2's serial tags+data model and its 'speed of light' reading).  "
+                                 "`clocks_per_load_model` = 4.2 + 0.95 x (L2 read requests per load, recorded PMC) from the same probe's "
+                                 "L1-miss/L2-hit rows; the kernel needs `clocks_per_load`: the rest is not bandwidth of either cache "
                                  "(DESIGN.md section 4); HBM `hbm_frac` (L2 hit %.1f %%, L1 hit %.1f %% recorded).  "
                                  "algorithmic_ratio = the reference's own access stream (5 B per lookup, every lookup) over the launch "
                                  "time against 8 TB/s: it exceeds 1 because the kernel reads cache-resident windows, 4 lookups per "

@@ -72,6 +72,8 @@ struct RasterJob
   // re-pitched copies of the grid for the scoring kernel (see CorrJob::grid2), kept in step with the grid tile by tile
   uint8_t * grid2;           // nullptr = this slot has none
   int32_t pitch2, copy_b;
+  int32_t copy_kind;         // 1 = copies A / B of the grid itself; 2 = column-decimated copies (CorrJob::dec): pitch2 = their row
+                             // pitch, copy_b = bytes of one of the four (even A | odd A | even B | odd B)
   int32_t * prev_work;       // [0] = number of tiles the PREVIOUS rasterisation touched, [4 ...] = their indices
 };
 constexpr int32_t kRasterTile = 64;
@@ -133,6 +135,19 @@ struct CorrJob
   int32_t pitch2, copy_b;
   int32_t * fast2;           // like `fast`, offsets into grid2
   int32_t * tcounts2;        // like `tcounts`
+  // Column-decimated copies (dec != 0, lattices with sx == 2: the coarse search of MatchScan steps two cells).  Scored from
+  // the grid itself, half of every loaded dword belongs to no pose.  Copy E holds the even columns of every row, copy O the
+  // odd ones, each at a pitch that is a multiple of 128: a window that starts in column wx0 reads copy (wx0 & 1) from column
+  // wx0 >> 1 on, one byte per pose -- the sx == 2 search becomes an sx == 1 search (61 poses per tile row instead of 31) on
+  // the copy, and K3 runs its SX = 1 instance.  Both exist twice, the second 64 bytes further along (as above).  The 64
+  // bytes behind the ws / 2 columns of row y repeat the start of row y + 1: a window that runs over the row end reads on in
+  // the next row like the linear grid index does (Appendix A.3), so every fast beam is served by the copies.
+  int32_t dec;
+  int32_t pad;               // zero bytes in front of and behind the grid (and, row for row, its copies) that windows may read: a
+                             // pose whose index falls off the array adds nothing in the reference (Mapper.cpp:1192-1197) and a
+                             // zero here -- beams whose window leaves the array by less than this stay on the fast lists
+  int32_t dbg_skip;          // timing experiments only (KH_K3_SKIP): bit 0 = no slow path, bit 1 = no probs atomics, bit 2 = no walk
+  int32_t tile_px;           // poses per row of a scoring tile: 61, or 31 for sx == 2 read from the grid itself
   unsigned long long * load_counter;   // handle-wide tally of the row loads K3 will issue for the fast lists K2 builds (wave-level
                                        // dword-load instructions, 256 B each): the L1 side of the roofline; nullptr = not counted
 };

@@ -137,6 +137,7 @@ struct Slot
   uint32_t * d_blockmap = nullptr;   // bm_w x bm_h occupancy blocks of this grid (cleared and marked with it)
   uint8_t * d_grid2 = nullptr;       // re-pitched copies A and B (CorrJob::grid2), allocated at the first search that profits
   uint8_t * d_grid2_alloc = nullptr;
+  int32_t copy_kind = 0;             // 0 none, 1 copies A / B of the grid, 2 column-decimated copies (RasterJob::copy_kind)
   int32_t * d_prev_work = nullptr;   // tiles the previous rasterisation touched (what has to be zeroed in the copies)
   double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
   // correlate scratch
@@ -189,6 +190,9 @@ struct kh_matcher
   int32_t bm_w = 0, bm_h = 0;
   int32_t rt_w = 0, rt_h = 0;      // rasteriser tiles over the grid
   int32_t pitch2 = 0, copy_b = 0;  // dual-copy layout: row pitch (multiple of 128) and byte offset of copy B
+  int32_t pad_rows = 0;            // zero rows in front of and behind every slot's grid and copies (CorrJob::pad)
+  size_t grid_pad = 0;             // the same in bytes of the grid's own pitch, rounded up to 256, plus kGridPad
+  int32_t pitch_d = 0, copy_q = 0; // column-decimated copies: row pitch and bytes of one of the four; copy_q 0 = too large for int32 offsets
   bool dual_copy = true;           // kh_matcher_set_debug bit 4 switches the re-pitched copies off (measurements)
   bool lds_score = false;          // experimental LDS-staged scoring path (kh_matcher_set_debug bit 1)
   // profiling
@@ -418,7 +422,8 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
     j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
     j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * npad; j.rank = s.d_rlists + 6 * npad;
-    j.grid2 = s.d_grid2; j.pitch2 = m->pitch2; j.copy_b = m->copy_b; j.prev_work = s.d_prev_work;
+    j.grid2 = s.d_grid2; j.copy_kind = s.copy_kind; j.prev_work = s.d_prev_work;
+    j.pitch2 = s.copy_kind == 2 ? m->pitch_d : m->pitch2; j.copy_b = s.copy_kind == 2 ? m->copy_q : m->copy_b;
     any_copies = any_copies || s.d_grid2 != nullptr;
     j.n_foot = n_foot;
     if (n_foot > 0) {
@@ -491,13 +496,14 @@ static inline double q_res_x(const CorrReq & q) {return q.res_x;}
 
 // Re-pitched copies of a slot's grid (CorrJob::grid2): allocated zeroed, filled from the grid as it stands, kept in step by
 // raster_batch from then on.
-static int allocate_copies(kh_matcher * m, Slot & s)
+static int allocate_copies(kh_matcher * m, Slot & s, int32_t kind)
 {
   const size_t rows = static_cast<size_t>(m->data_size / m->ws);
-  const size_t bytes = static_cast<size_t>(m->copy_b) * 2 + 2 * kGridPad;
+  const size_t bytes = (kind == 2 ? static_cast<size_t>(m->copy_q) * 4 + 64 : static_cast<size_t>(m->copy_b) * 2 + 64) + 2 * kGridPad;
+  s.copy_kind = kind;
   KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_grid2_alloc), bytes));
   KH_HIP(hipMemsetAsync(s.d_grid2_alloc, 0, bytes, m->stream));
-  s.d_grid2 = s.d_grid2_alloc + kGridPad;
+  s.d_grid2 = s.d_grid2_alloc + kGridPad + static_cast<size_t>(m->pad_rows) * (kind == 2 ? m->pitch_d : m->pitch2);
   const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
   KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_prev_work), (nt + 4) * sizeof(int32_t)));
   KH_HIP(hipMemsetAsync(s.d_prev_work, 0, (nt + 4) * sizeof(int32_t), m->stream));
@@ -505,7 +511,8 @@ static int allocate_copies(kh_matcher * m, Slot & s)
   RasterJob j;
   std::memset(&j, 0, sizeof(j));
   j.grid = s.d_grid; j.ws = m->ws; j.height = static_cast<int32_t>(rows);
-  j.grid2 = s.d_grid2; j.pitch2 = m->pitch2; j.copy_b = m->copy_b; j.prev_work = s.d_prev_work;
+  j.grid2 = s.d_grid2; j.copy_kind = kind; j.prev_work = s.d_prev_work;
+  j.pitch2 = kind == 2 ? m->pitch_d : m->pitch2; j.copy_b = kind == 2 ? m->copy_q : m->copy_b;
   const size_t nt2 = nt;
   j.n_work = s.d_rtiles + 2 * nt2; j.work = s.d_rtiles + 3 * nt2 + 4;
   RasterJob * d_j = nullptr;
@@ -738,7 +745,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       const bool full_res = c.nx > 1 && std::fabs(cells_per_step - 1.0) < 1e-9 && c.nx <= kTileSpan;
       const bool tiled_lists = lt > 1 && (std::fabs(cells_per_step - 1.0) < 1e-9 || std::fabs(cells_per_step - 2.0) < 1e-9);
       if (m->dual_copy && !s.d_grid2 && (full_res || tiled_lists) && work >= 1e8) {
-        rc = allocate_copies(m, s); if (rc) {return rc;}
+        // a search that steps two cells (MatchScan's coarse pass) gets the column-decimated copies
+        const bool two_cells = std::fabs(cells_per_step - 2.0) < 1e-9 && m->copy_q > 0 && (m->ws % 8) == 0;
+        rc = allocate_copies(m, s, two_cells ? 2 : 1); if (rc) {return rc;}
       }
     }
     {
@@ -862,11 +871,18 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->linear = linear ? 1 : 0; job->sx = sx; job->sy_ws = sy_ws; job->base0 = c.bx[0] + c.by[0];
     const int this_sx = (linear && sx == 2) ? 2 : 1;
     const int this_ry = pick_ry(c.ny);
-    const int px = score_tile_poses(this_sx);
-    job->tiles_x = (c.nx + px - 1) / px;
     job->tiles_y = (c.ny + 4 * this_ry - 1) / (4 * this_ry);
-    job->ry = this_ry;
-    job_sx[i] = this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
+    // column-decimated copies of the slot: the two-cell search is scored as a one-cell search on them (CorrJob::dec), as long
+    // as the copy can be picked per beam and tile (one tile column, or lists per tile)
+    bool dec = s.copy_kind == 2 && m->dual_copy && this_sx == 2 && sy_ws % m->ws == 0;
+    if (dec) {
+      const int32_t tiles = ((c.nx + kTileSpan - 1) / kTileSpan) * job->tiles_y;
+      dec = c.nx <= kTileSpan || (tiles >= 4 && tiles <= c.lt_alloc);
+    }
+    const int px = dec ? kTileSpan : score_tile_poses(this_sx);
+    job->tiles_x = (c.nx + px - 1) / px;
+    job->ry = this_ry; job->tile_px = px; job->dec = dec ? 1 : 0;
+    job_sx[i] = dec ? 1 : this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
     // LDS-staged scoring: linear lattice whose window fits 64 bytes x 64 rows
     const bool lds_ok = lds_enabled && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
       sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && (c.ny - 1) * sx + 1 <= kLdsRows;
@@ -895,15 +911,24 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->tile_best = s.d_tile_best;
     // re-pitched copies: linear full-resolution lattice one tile wide (the copy is picked per beam for the tile at x0 = 0)
     {
-      const bool use2 = s.d_grid2 != nullptr && m->dual_copy && linear && (job->tiles_x == 1 || job->list_tiles > 1);
+      const bool use2 = dec || (s.copy_kind == 1 && m->dual_copy && linear && (job->tiles_x == 1 || job->list_tiles > 1));
       const size_t lists = static_cast<size_t>(c.na) * kClasses * static_cast<size_t>(c.lt_alloc);
       job->grid2 = use2 ? s.d_grid2 : nullptr;
-      job->pitch2 = m->pitch2; job->copy_b = m->copy_b;
+      job->pitch2 = dec ? m->pitch_d : m->pitch2; job->copy_b = dec ? m->copy_q : m->copy_b;
       job->fast2 = s.d_fast + lists * static_cast<size_t>(c.P);
       job->tcounts2 = s.d_tcounts + lists;
     }
+    job->pad = std::max(0, m->pad_rows * m->ws - 512);
     job->load_counter = m->profiling ? m->d_load_counter : nullptr;
+    static const int dbg_skip = std::getenv("KH_K3_SKIP") ? std::atoi(std::getenv("KH_K3_SKIP")) : 0;
+    job->dbg_skip = dbg_skip;
   });
+  if (timing) {
+    const CorrJob * j0 = reinterpret_cast<const CorrJob *>(B.h_stage);
+    std::fprintf(stderr, "[kh corr] job 0: %d x %d x %d poses, sx %d, tiles %d x %d of %d x %d poses, lists per tile %d, copies %d (slot kind %d), "
+      "dec %d, ws %d\n", j0->nx, j0->ny, j0->na, j0->sx, j0->tiles_x, j0->tiles_y, j0->tile_px, 4 * j0->ry, j0->list_tiles,
+      j0->grid2 ? 1 : 0, m->slots[ctx[0].slot].copy_kind, j0->dec, m->ws);
+  }
   bool all_lds = true;
   for (size_t i = 0; i < n; ++i) {
     if (sx_variant < 0) {sx_variant = job_sx[i]; ry = job_ry[i];}
@@ -948,7 +973,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     for (size_t i = 0; i < n; ++i) {
       const CorrJob * job = reinterpret_cast<const CorrJob *>(B.h_stage + stride * i);
       launch_score(B.d_stage + stride * i, stride, 1, job->tiles_x * job->tiles_y, job->na,
-        (job->linear && job->sx == 2) ? 2 : 1, job->ry, m->stream);
+        (job->linear && job->sx == 2 && !job->dec) ? 2 : 1, job->ry, m->stream);
     }
   }
   if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], m->stream));}
@@ -1334,11 +1359,19 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_load_counter), 8)) != hipSuccess) {return fail(e, "hipMalloc counter");}
   if ((e = hipMemset(m->d_load_counter, 0, 8)) != hipSuccess) {return fail(e, "hipMemset counter");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
+  // zero rows either side: as many as the search space is high, so that any search window that touches the array is inside
+  m->pad_rows = m->roi_h + 8;
+  m->grid_pad = align_up(static_cast<size_t>(m->pad_rows) * m->ws, 256) + kGridPad;
   m->pitch2 = static_cast<int32_t>(align_up(static_cast<size_t>(m->ws), 128));
   {
-    const size_t copy = align_up(static_cast<size_t>(m->pitch2) * (m->data_size / m->ws) + 256, 256);
+    const size_t copy = align_up(static_cast<size_t>(m->pitch2) * (m->data_size / m->ws + 2 * m->pad_rows) + 256, 256);
     if (2 * copy + 256 > (1ull << 31) - 4096) {m->dual_copy = false;}        // offsets into the copies are int32
     m->copy_b = static_cast<int32_t>(std::min<size_t>(copy, (1ull << 30)));
+  }
+  {
+    m->pitch_d = static_cast<int32_t>(align_up(static_cast<size_t>(m->ws) / 2 + 64, 128));
+    const size_t quarter = align_up(static_cast<size_t>(m->pitch_d) * (m->data_size / m->ws + 2 * m->pad_rows) + 256, 256);
+    m->copy_q = 4 * quarter + 4096 < (1ull << 31) ? static_cast<int32_t>(quarter) : 0;
   }
   m->rt_w = (m->ws + kRasterTile - 1) / kRasterTile;
   m->rt_h = (m->data_size / m->ws + kRasterTile - 1) / kRasterTile;
@@ -1346,9 +1379,9 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   m->bm_h = (m->data_size / m->ws >> kBlockShift) + 2;
   m->slots.resize(max_batch);
   for (auto & s : m->slots) {
-    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid_alloc), static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
-    if ((e = hipMemset(s.d_grid_alloc, 0, static_cast<size_t>(m->data_size) + 2 * kGridPad)) != hipSuccess) {return fail(e, "hipMemset grid");}
-    s.d_grid = s.d_grid_alloc + kGridPad;
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid_alloc), static_cast<size_t>(m->data_size) + 2 * m->grid_pad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
+    if ((e = hipMemset(s.d_grid_alloc, 0, static_cast<size_t>(m->data_size) + 2 * m->grid_pad)) != hipSuccess) {return fail(e, "hipMemset grid");}
+    s.d_grid = s.d_grid_alloc + m->grid_pad;
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_blockmap), static_cast<size_t>(m->bm_w) * m->bm_h * 4)) != hipSuccess) {return fail(e, "hipMalloc block map");}
     if ((e = hipMemset(s.d_blockmap, 0, static_cast<size_t>(m->bm_w) * m->bm_h * 4)) != hipSuccess) {return fail(e, "hipMemset block map");}
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_rtiles), (4 * static_cast<size_t>(m->rt_w) * m->rt_h + 8) * sizeof(int32_t))) != hipSuccess) {return fail(e, "hipMalloc raster tiles");}

@@ -834,10 +834,36 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
 
 // Re-pitched copies (CorrJob::grid2): the tiles the previous rasterisation touched are zeroed, the tiles this one touched
 // are copied from the grid, and this rasterisation's tile list becomes the "previous" one.  Traffic: 8 KB per touched tile.
+// column-decimated copies (RasterJob::copy_kind 2): cells x .. x + 7 (x a multiple of 8) of grid row y, as two dwords
+__device__ __forceinline__ void dec_store(const RasterJob & job, int y, int x, uint32_t d0, uint32_t d1)
+{
+  const uint32_t even = __builtin_amdgcn_perm(d1, d0, 0x06040200u), odd = __builtin_amdgcn_perm(d1, d0, 0x07050301u);
+  const size_t cb = (size_t)job.copy_b;
+  auto put = [&](size_t at) {
+    *reinterpret_cast<uint32_t *>(job.grid2 + at) = even;
+    *reinterpret_cast<uint32_t *>(job.grid2 + cb + at) = odd;
+    *reinterpret_cast<uint32_t *>(job.grid2 + 2 * cb + 64 + at) = even;
+    *reinterpret_cast<uint32_t *>(job.grid2 + 3 * cb + 64 + at) = odd;
+  };
+  put((size_t)y * job.pitch2 + (x >> 1));
+  // the first 64 columns of a row are repeated behind the row above
+  // (row -1 is part of the zero rows in front of the copy: a window that starts there runs on into row 0)
+  if (x < 128) {put((size_t)((int64_t)(y - 1) * job.pitch2 + (job.ws >> 1) + (x >> 1)));}
+}
 __device__ __forceinline__ void repitch_tile(const RasterJob & job, int t, bool zero)
 {
   const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
   const int ox = tx * kRasterTile, oy = ty * kRasterTile;
+  if (job.copy_kind == 2) {
+    for (int i = threadIdx.x; i < kRasterTile * kRasterTile / 8; i += blockDim.x) {
+      const int row = i >> 3, c8 = i & 7;
+      const int y = oy + row, x = ox + 8 * c8;
+      if (y >= job.height || x >= job.ws) {continue;}
+      const uint2 v = zero ? make_uint2(0u, 0u) : *reinterpret_cast<const uint2 *>(job.grid + (size_t)y * job.ws + x);
+      dec_store(job, y, x, v.x, v.y);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < kRasterTile * kRasterTile / 4; i += blockDim.x) {
     const int row = i >> 4, wcol = i & 15;
     const int y = oy + row, x = ox + 4 * wcol;
@@ -888,6 +914,15 @@ __global__ __launch_bounds__(256) void k_repitch_full(const RasterJob * jobs, in
 {
   const RasterJob & job = jobs[0];
   const int words = job.ws / 4;
+  if (job.copy_kind == 2) {
+    for (int y = blockIdx.x; y < rows; y += gridDim.x) {
+      for (int i = threadIdx.x; i < job.ws / 8; i += blockDim.x) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(job.grid + (size_t)y * job.ws + 8 * i);
+        dec_store(job, y, 8 * i, v.x, v.y);
+      }
+    }
+    return;
+  }
   for (int y = blockIdx.x; y < rows; y += gridDim.x) {
     const uint32_t * src = reinterpret_cast<const uint32_t *>(job.grid + (size_t)y * job.ws);
     uint32_t * a = reinterpret_cast<uint32_t *>(job.grid2 + (size_t)y * job.pitch2);
@@ -918,7 +953,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   if (threadIdx.x < kClasses + 1) {s_counts[threadIdx.x] = 0;}
   if ((int)threadIdx.x < job.list_tiles && job.list_tiles > 1) {
     const int t = threadIdx.x;
-    const int px = (job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan, ty_rows = 4 * job.ry;
+    const int px = job.tile_px, ty_rows = 4 * job.ry;
     const int tx = t % job.tiles_x, ty = t / job.tiles_x;
     const int p0 = tx * px, p1 = min(job.nx, p0 + px) - 1;         // poses of the tile
     const int r0 = ty * ty_rows, r1 = min(job.ny, r0 + ty_rows) - 1;
@@ -961,7 +996,7 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
     if (idx == kInvalidScan) {continue;}   // Mapper.cpp:1194
     if (job.linear) {
       if ((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size) {continue;}  // off the grid for every pose
-      if ((int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size) {
+      if ((int64_t)idx + bmin >= -(int64_t)job.pad && (int64_t)idx + bmax < (int64_t)job.data_size + job.pad) {
         uint32_t tmask = lt > 1 ? (0xffffffffu >> (32 - lt)) : 1u;
         int32_t wx0 = 0, wy0 = 0;
         bool in_row = false;                 // the window does not wrap around the row end
@@ -984,7 +1019,8 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
           if (in_row) {
             auto any_block = [&](int x_lo, int y_lo, int x_hi, int y_hi) {
               const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
-              const int by0 = y_lo >> kBlockShift, by1 = y_hi >> kBlockShift;
+              // rows above and below the array hold nothing
+              const int by0 = max(y_lo, 0) >> kBlockShift, by1 = min(y_hi >> kBlockShift, job.bm_h - 1);
               // bits bx0 .. bx1 of every block row: two adjacent words cover them (the rows carry a padding
               // word).  No early exit: the probes are independent loads.
               const int wi = bx0 >> 5, sh = bx0 & 31, nb = bx1 - bx0 + 1;
@@ -1009,16 +1045,27 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
           }
         }
         // alignment class of the window start: K3 reads class-c windows with aligned dwords
-        const int cls = (int)(((int64_t)idx + bmin) & (kClasses - 1));
+        const int cls = job.dec ? ((wx0 >> 1) & (kClasses - 1)) : (int)(((int64_t)idx + bmin) & (kClasses - 1));
         // dual-copy layout: the aligned 64-byte segment K3 reads starts at wx0 - cls; the copy in which it does not
         // straddle a 128-byte line (pitch2 is a multiple of 128, so every row of the window sits alike)
-        const bool dual = fast2 != nullptr && in_row;
-        const int px = (job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan;
+        const bool dual = fast2 != nullptr && (in_row || job.dec);
+        const int px = job.tile_px;
         while (tmask) {
           const int t = __builtin_ctz(tmask);
           tmask &= tmask - 1;
           const int li = cls * lt + t;
-          if (dual) {
+          if (dual && job.dec) {
+            // column-decimated copies: the tile's segments start in column k = (wx0 >> 1) + x0 of copy (wx0 & 1); behind the
+            // row end they continue at the start of the next row (columns < 64 of it are repeated behind this row, so only a
+            // tile that STARTS behind the row end moves down a row)
+            const int32_t half = job.ws >> 1;
+            const int32_t xo = lt > 1 ? (t % job.tiles_x) * px : 0;
+            int32_t k0 = wx0 >> 1, row = wy0;
+            if (k0 + xo >= half) {k0 -= half; ++row;}
+            const int32_t seg = (k0 + xo) & ~3;
+            const int32_t idx2 = row * job.pitch2 + k0 + ((wx0 & 1) ? job.copy_b : 0) + ((seg & 127) > 64 ? 2 * job.copy_b + 64 : 0);
+            fast2[(size_t)li * P + atomicAdd(&s_tcounts2[li], 1)] = idx2;
+          } else if (dual) {
             // the tile's 64-byte segments start at wx0 + x0 * sx, moved back to the dword boundary (K3's s); with one list
             // for all tiles (lt == 1) the lattice is one tile wide (the host sees to it), i.e. x0 = 0
             const int32_t xo = (lt > 1 ? (t % job.tiles_x) * px : 0) * job.sx;
@@ -1130,7 +1177,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
   __syncthreads();
 
   const int P = job.n_points;
-  const int n_slow = live ? job.counts[kCountsPerAngle * a + kClasses] : 0;
+  const int n_slow = (live && !(job.dbg_skip & 1)) ? job.counts[kCountsPerAngle * a + kClasses] : 0;
 
   int32_t acc[RY][NB];
 #pragma unroll
@@ -1224,7 +1271,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
       if (since_flush + 64 > 512) {flush();}
     }
   };
-  if (live) {
+  if (live && !(job.dbg_skip & 4)) {
     // the beams whose window lies inside a grid row read the re-pitched copy K2 chose for them (every row segment in one
     // cache line), the few that wrap around the row end read the grid itself with its linear-index semantics
     if (job.grid2) {
@@ -1278,7 +1325,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
     const double response = pose_response(job, sum, a, yi, xi);
     if (job.write_resp) {job.resp[o] = response;}
     best = response > best ? response : best;
-    if (job.coarse && response > 0.0) {
+    if (job.coarse && response > 0.0 && !(job.dbg_skip & 2)) {
       atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
     }
   }
@@ -1351,7 +1398,7 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
   if (job.tile_best) {
     // only the scoring tiles whose own best response ties with the global one can hold a tie
     const int tiles = job.tiles_x * job.tiles_y;
-    const int px = (job.linear && job.sx == 2) ? (kTileSpan + 1) / 2 : kTileSpan, ty_rows = 4 * job.ry;
+    const int px = job.tile_px, ty_rows = 4 * job.ry;
     for (int pi = blockIdx.x; pi < job.na * tiles; pi += gridDim.x) {
       const double delta = job.tile_best[pi] - best;
       if (!(delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06)) {continue;}
@@ -1797,7 +1844,7 @@ __global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t
     const double response = pose_response(job, sum, a, yi, xi);
     if (job.write_resp) {job.resp[o] = response;}
     best = response > best ? response : best;
-    if (job.coarse && response > 0.0) {
+    if (job.coarse && response > 0.0 && !(job.dbg_skip & 2)) {
       atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
     }
   }
