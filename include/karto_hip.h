@@ -194,7 +194,9 @@ KH_API int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, in
  * do not leave out the beams whose whole search window lies in grid blocks no scan point was stamped into
  * (they add 0 to every pose, so the results are identical either way; for measurements); bit 3: send every batch
  * of >= 128 searches through the chunked pipeline, which otherwise only large searches take (tests); bit 4: score from the
- * grid itself instead of its re-pitched copies (same results; for measurements); all off by default */
+ * grid itself instead of its re-pitched copies (same results; for measurements); bit 5: take the byte sums of one-cell
+ * searches on the matrix cores (v_mfma_i32_16x16x32_i8) instead of the vector ALU (same results, same speed within 5 %:
+ * DESIGN.md section 4); all off by default */
 KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t flags);
 /* HIP stream all kernels of this handle are launched on (hipStream_t as void*), so the caller can
  * bracket launches with HIP events on the right stream */

@@ -143,6 +143,7 @@ struct CorrJob
   // bytes behind the ws / 2 columns of row y repeat the start of row y + 1: a window that runs over the row end reads on in
   // the next row like the linear grid index does (Appendix A.3), so every fast beam is served by the copies.
   int32_t dec;
+  int32_t pad_rows;          // zero rows in front of and behind the grid and each of its copies
   int32_t pad;               // zero bytes in front of and behind the grid (and, row for row, its copies) that windows may read: a
                              // pose whose index falls off the array adds nothing in the reference (Mapper.cpp:1192-1197) and a
                              // zero here -- beams whose window leaves the array by less than this stay on the fast lists
@@ -169,7 +170,7 @@ void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles,
 void launch_repitch_full(const RasterJob * d_job, int32_t rows, void * stream);                             // one job: whole grid
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
-                  int32_t sx_variant, int32_t ry, void * stream);
+                  int32_t sx_variant, int32_t ry, void * stream, bool mfma = false);
 // poses per tile row of the scoring kernel for a lattice step of sx cells
 inline int32_t score_tile_poses(int32_t sx) {return sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;}
 void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);

@@ -194,6 +194,7 @@ struct kh_matcher
   size_t grid_pad = 0;             // the same in bytes of the grid's own pitch, rounded up to 256, plus kGridPad
   int32_t pitch_d = 0, copy_q = 0; // column-decimated copies: row pitch and bytes of one of the four; copy_q 0 = too large for int32 offsets
   bool dual_copy = true;           // kh_matcher_set_debug bit 4 switches the re-pitched copies off (measurements)
+  bool mfma_score = std::getenv("KH_K3_MFMA") != nullptr;   // kh_matcher_set_debug bit 5: byte sums on the matrix cores (k_score<.., MF>)
   bool lds_score = false;          // experimental LDS-staged scoring path (kh_matcher_set_debug bit 1)
   // profiling
   bool profiling = false;
@@ -918,7 +919,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       job->fast2 = s.d_fast + lists * static_cast<size_t>(c.P);
       job->tcounts2 = s.d_tcounts + lists;
     }
-    job->pad = std::max(0, m->pad_rows * m->ws - 512);
+    job->pad = std::max(0, m->pad_rows * m->ws - 512); job->pad_rows = m->pad_rows;
     job->load_counter = m->profiling ? m->d_load_counter : nullptr;
     static const int dbg_skip = std::getenv("KH_K3_SKIP") ? std::atoi(std::getenv("KH_K3_SKIP")) : 0;
     job->dbg_skip = dbg_skip;
@@ -968,12 +969,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   if (use_lds) {
     launch_score_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, m->stream);
   } else if (uniform_kernel) {
-    launch_score(B.d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, m->stream);
+    launch_score(B.d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, m->stream, m->mfma_score);
   } else {
     for (size_t i = 0; i < n; ++i) {
       const CorrJob * job = reinterpret_cast<const CorrJob *>(B.h_stage + stride * i);
       launch_score(B.d_stage + stride * i, stride, 1, job->tiles_x * job->tiles_y, job->na,
-        (job->linear && job->sx == 2 && !job->dec) ? 2 : 1, job->ry, m->stream);
+        (job->linear && job->sx == 2 && !job->dec) ? 2 : 1, job->ry, m->stream, m->mfma_score);
     }
   }
   if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], m->stream));}
@@ -1443,6 +1444,7 @@ int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
   m->keep_responses = (keep_response_volume & 1) != 0;
   m->lds_score = (keep_response_volume & 2) != 0;
   m->dense_score = (keep_response_volume & 4) != 0;
+  if (keep_response_volume & 32) {m->mfma_score = true;}
   m->force_chunks = (keep_response_volume & 8) != 0;
   m->dual_copy = (keep_response_volume & 16) == 0;
   return KH_OK;

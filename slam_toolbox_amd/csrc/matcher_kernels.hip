@@ -1143,7 +1143,17 @@ __device__ __forceinline__ const gint * as_global(const int32_t * p) {return (co
 // A workgroup is AW adjacent angles x 4 alignment classes = 4*AW waves.  Adjacent angles read windows
 // that overlap by ~85 % and sweep the beam list at the same pace, so sharing a CU (one L1) turns
 // most of their L2->L1 line fills into L1 hits.
-template <int SX, int RY, int AW>
+//
+// MF (SX == 1 only): the byte sums are taken by the matrix cores instead of the vector ALU.  Unpacking and adding a loaded
+// dword costs the VALU 4 instructions = 16 SIMD clocks per 256 bytes, exactly what the L1 needs to deliver them: the
+// VALU instance of the kernel is co-limited by the two.  v_mfma_i32_16x16x32_i8 computes D[i][j] += sum_k A[i][k] B[k][j]
+// with B[8g .. 8g + 7][j] = the 8 bytes lane (j = lane & 15, g = lane >> 4) supplies: here the dwords of TWO beams loaded
+// by that lane.  With the constant selector A[i][k] = ((k & 3) == (i & 3) && (k >> 3) == (i >> 2)) row 4g + b of D is, column
+// by column, the sum of byte b of the two dwords of lane (j, g) -- and D[4g + b][j] is register b of lane (j, g): every lane
+// gets the four byte sums of its own loads as 32-bit integers, one MFMA (16 SIMD clocks, its own pipe) per 512 loaded bytes,
+// no unpacking and no 16-bit flushes.  (dwordx2 loads of two rows per lane would halve the load count, but the texture
+// addresser handles them at half the byte rate: tools/tcp_ceiling.hip, 16.2 clocks per 512 bytes.)
+template <int SX, int RY, int AW, bool MF>
 __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t stride, int n_jobs, int chunks,
                                                     int na_chunk, int tiles_max)
 {
@@ -1271,9 +1281,72 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
       if (since_flush + 64 > 512) {flush();}
     }
   };
+  // MF: 32-bit sums straight from the matrix cores; acc_mf[r][b] has the meaning of acc[r][b] (see the head of the kernel)
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i acc_mf[MF ? RY : 1];
+#pragma unroll
+  for (int t = 0; t < (MF ? RY : 1); ++t) {acc_mf[t] = v4i{0, 0, 0, 0};}
+  auto walk_mf = [&](const gbyte * gbase, const gint * glist, const int n_list, const uint32_t row_bytes) {
+    if (n_list <= 0) {return;}
+    // selector A[i][k], lane (i = lane & 15, group = lane >> 4) holds k = 8 * group .. 8 * group + 7
+    long sel;
+    {
+      const int i = lane & 15;
+      sel = ((lane >> 4) == (i >> 2)) ? (long)(0x0000000100000001ull << (8 * (i & 3))) : 0l;
+    }
+    uint32_t voff[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      int yi = y0 + r * 4 + ly;
+      yi = yi < job.ny ? yi : job.ny - 1;
+      voff[r] = (uint32_t)(4 * lx) + (uint32_t)yi * row_bytes;
+    }
+    for (int jc = 0; jc < n_list; jc += 64) {
+      const int cnt = min(64, n_list - jc);
+      const int32_t mine = (lane < cnt) ? glist[jc + lane] : 0;
+      int k = 0;
+      for (; k + UB <= cnt; k += UB) {
+        uint32_t w[UB][RY];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const gbyte * wb = gbase + __builtin_amdgcn_readlane(mine, k + u);
+#pragma unroll
+          for (int r = 0; r < RY; ++r) {w[u][r] = *reinterpret_cast<const gu32 *>(wb + voff[r]);}
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u += 2) {
+#pragma unroll
+          for (int r = 0; r < RY; ++r) {
+            const long pair = (long)(((unsigned long long)w[u + 1][r] << 32) | w[u][r]);
+            acc_mf[r] = __builtin_amdgcn_mfma_i32_16x16x32_i8(sel, pair, acc_mf[r], 0, 0, 0);
+          }
+        }
+      }
+      for (; k < cnt; k += 2) {
+        const bool two = k + 1 < cnt;
+        const gbyte * wb0 = gbase + __builtin_amdgcn_readlane(mine, k);
+        const gbyte * wb1 = two ? gbase + __builtin_amdgcn_readlane(mine, k + 1) : wb0;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+          const uint32_t w0 = *reinterpret_cast<const gu32 *>(wb0 + voff[r]);
+          const uint32_t w1 = two ? *reinterpret_cast<const gu32 *>(wb1 + voff[r]) : 0u;
+          const long pair = (long)(((unsigned long long)w1 << 32) | w0);
+          acc_mf[r] = __builtin_amdgcn_mfma_i32_16x16x32_i8(sel, pair, acc_mf[r], 0, 0, 0);
+        }
+      }
+    }
+  };
   if (live && !(job.dbg_skip & 4)) {
     // the beams whose window lies inside a grid row read the re-pitched copy K2 chose for them (every row segment in one
     // cache line), the few that wrap around the row end read the grid itself with its linear-index semantics
+    if (MF) {
+      if (job.grid2) {
+        walk_mf(as_global(job.grid2) + (x0 * SX - s), as_global(job.fast2 + list_id * P), job.tcounts2[list_id],
+          (uint32_t)job.pitch2 * (uint32_t)job.sy_cells);
+      }
+      walk_mf(as_global(job.grid) + ((int64_t)job.base0 + x0 * SX - s), as_global(job.fast + list_id * P), job.tcounts[list_id],
+        (uint32_t)job.sy_ws);
+    } else {
     if (job.grid2) {
       walk(as_global(job.grid2) + (x0 * SX - s), as_global(job.fast2 + list_id * P), job.tcounts2[list_id],
         (uint32_t)job.pitch2 * (uint32_t)job.sy_cells);
@@ -1281,9 +1354,18 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
     walk(as_global(job.grid) + ((int64_t)job.base0 + x0 * SX - s), as_global(job.fast + list_id * P), job.tcounts[list_id],
       (uint32_t)job.sy_ws);
     flush();
+    }
   }
 
   // merge the four waves' partial sums: byte position j of the aligned tile row is pose (j - s) / SX
+  // (MF: D[4 * group + b][column] of the MFMA is register b of lane (column, group) -- the lane that loaded the bytes)
+  if (MF) {
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {acc[r][b] = acc_mf[r][b];}
+    }
+  }
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
 #pragma unroll
@@ -1348,7 +1430,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
 }
 
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
-                  int32_t sx_variant, int32_t ry, void * stream)
+                  int32_t sx_variant, int32_t ry, void * stream, bool mfma)
 {
   if (n_jobs <= 0 || max_tiles <= 0 || max_na <= 0) {return;}
   // AW = 4 (four adjacent angles sharing a CU) was measured: L1 hit rate 31 -> 38 %, no gain in time
@@ -1365,11 +1447,15 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
   hipStream_t s = (hipStream_t)stream;
   // KH_K3_LDS_PAD=<bytes>: dynamic LDS nobody uses, to cap the workgroups per CU (occupancy experiment of DESIGN.md section 4)
   static const int lds_pad = std::getenv("KH_K3_LDS_PAD") ? std::atoi(std::getenv("KH_K3_LDS_PAD")) : 0;
-#define KH_SCORE(SXV, RYV) hipLaunchKernelGGL((k_score<SXV, RYV, AW>), grid, dim3(256 * AW), lds_pad, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
+  // mfma: the matrix-core instance of the one-cell kernel (bit-identical sums; measured within +-5 % of the vector-ALU one --
+  // 0.636 against 0.611 ms per 51 config-2 matches, 2.44 against 2.56 ms on the loop preset: the VALU is not what binds)
+#define KH_SCORE(SXV, RYV, MFV) hipLaunchKernelGGL((k_score<SXV, RYV, AW, MFV>), grid, dim3(256 * AW), lds_pad, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
   if (sx_variant == 2) {
-    if (ry == 8) {KH_SCORE(2, 8);} else if (ry == 7) {KH_SCORE(2, 7);} else if (ry == 4) {KH_SCORE(2, 4);} else {KH_SCORE(2, 1);}
+    if (ry == 8) {KH_SCORE(2, 8, false);} else if (ry == 7) {KH_SCORE(2, 7, false);} else if (ry == 4) {KH_SCORE(2, 4, false);} else {KH_SCORE(2, 1, false);}
+  } else if (!mfma) {
+    if (ry == 8) {KH_SCORE(1, 8, false);} else if (ry == 7) {KH_SCORE(1, 7, false);} else if (ry == 4) {KH_SCORE(1, 4, false);} else {KH_SCORE(1, 1, false);}
   } else {
-    if (ry == 8) {KH_SCORE(1, 8);} else if (ry == 7) {KH_SCORE(1, 7);} else if (ry == 4) {KH_SCORE(1, 4);} else {KH_SCORE(1, 1);}
+    if (ry == 8) {KH_SCORE(1, 8, true);} else if (ry == 7) {KH_SCORE(1, 7, true);} else if (ry == 4) {KH_SCORE(1, 4, true);} else {KH_SCORE(1, 1, true);}
   }
 #undef KH_SCORE
 }

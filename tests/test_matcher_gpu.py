@@ -382,7 +382,42 @@ def test_dual_copy_layout_follows_the_grid(kartohip_lib):
     hm.CorrelateScan(hq, pose, *args, True, None, False)
     sums2, _ = hm.volume()
     assert np.array_equal(sums, sums2)
+    # the matrix-core instance of the scoring kernel (kh_matcher_set_debug bit 5): the same integer sums
+    for no_copies in (False, True):
+        hm.set_debug(True, no_dual_copy=no_copies, mfma_score=True)
+        hm.CorrelateScan(hq, pose, *args, True, None, False)
+        sums3, _ = hm.volume()
+        assert np.array_equal(sums, sums3), f"MFMA scoring differs (copies off: {no_copies})"
     hm.close()
+
+
+def test_two_cell_search_from_the_column_decimated_copies(kartohip_lib):
+    """MatchScan's coarse pass of the loop preset steps two cells: the slot gets column-decimated copies (CorrJob::dec) and the
+    search is scored as a one-cell search on them -- windows that start in the zero rows in front of the grid, run over a
+    row end or leave the array included (readings up to 30 m on a grid with a 20 m border).  The sums must equal the
+    oracle's volume, with the copies, without them, and through the matrix-core instance of the kernel."""
+    import math
+    sc = Scenario(seed=21, n_base=12, start=300, perturb=(0.9, -1.3, 0.05))
+    oq, ob = sc.oracle_scans()
+    hq, hb = sc.hip_scans()
+    om = make_oracle_matcher("L", threads=8)
+    om.add_scans(oq, ob)
+    res = 1.0 / om.grid_info()["scale"]
+    side = PRESETS["L"]["create"][0]
+    off = 0.5 * round(side / res) * res
+    p = PRESETS["L"]["params"]
+    args = ((off, off), (2 * res, 2 * res), p["coarse_search_angle_offset"], p["coarse_angle_resolution"])
+    r_o, mean_o, cov_o = om.correlate_scan(oq, sc.query_pose, *args, False, False)
+    vol = om.volume()
+    for kw in (dict(), dict(no_dual_copy=True), dict(mfma_score=True)):
+        hm = make_hip_matcher("L")
+        hm.set_debug(True, **kw)
+        hm.AddScans(hq, hb)
+        r_h, mean_h, cov_h = hm.CorrelateScan(hq, sc.query_pose, *args, False, None, False)
+        sums, resp = hm.volume()
+        assert np.array_equal(bits(vol[..., 0]), bits(resp)), f"response volume differs ({kw})"
+        _assert_same(r_o, r_h, "response"); _assert_same(mean_o, mean_h, "mean"); _assert_same(cov_o, cov_h, "covariance")
+        hm.close()
 
 
 @pytest.mark.parametrize("preset", ["K", "S"])

@@ -33,6 +33,35 @@ __global__ __launch_bounds__(512) void k_probe(const unsigned * __restrict__ buf
   if (s == 0x12345678u) {out[0] = s;}          // never true: keeps the loads alive
 }
 
+// the same for dwordx2 loads: lane = (row lane >> 3 of 8, 8-byte chunk lane & 7): EIGHT 64-byte row segments per wave-level load
+// (512 bytes); `shift` = 4 moves every segment to a dword-but-not-qword-aligned start (the alignment classes of k_score)
+template <int UNROLL>
+__global__ __launch_bounds__(512) void k_probe2(const unsigned * __restrict__ buf, int shift_words, int iters, int halves, unsigned * out)
+{
+  constexpr int kPitch = 64;
+  const int lane = threadIdx.x & 63, g = lane >> 3, l = lane & 7;
+  unsigned long long acc[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {acc[u] = 0;}
+  // a wave covers 8 rows per load; 8 waves x 8 loads: the 32 rows of a half are visited twice per iteration
+  const unsigned * base = buf + (size_t)blockIdx.x * ((size_t)halves * 32 * kPitch) + (((threadIdx.x >> 6) & 3) * 8 + g) * kPitch + shift_words + 2 * l;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned * p = base + ((it & (halves - 1)) << 11);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      unsigned lo, hi;
+      const unsigned * q = p + ((u & 1) * 16);            // two column positions inside the 256-byte row
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(*(unsigned long long *)&acc[u]) : "v"(q) : "memory");
+      (void)lo; (void)hi;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  unsigned long long s = 0;
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {s += acc[u];}
+  if (s == 0x12345678ull) {out[0] = (unsigned)s;}
+}
+
 int main()
 {
   const int n_cu = 256, threads = 512;                          // one workgroup of 8 waves per CU
@@ -64,6 +93,26 @@ int main()
       const double wave_loads = (double)blocks * (threads / 64) * n_it * unroll;
       const double cyc = best * 1e-3 * 2.4e9 * n_cu / wave_loads;
       std::printf("%d  %d  %.3f  %.3e  %.2f  %.1f\n", halves * 8, tags, best, wave_loads, cyc, wave_loads * 256.0 / (best * 1e-3) / 1e12);
+    }
+  }
+  std::printf("# dwordx2 loads, 8 row segments of 64 B per wave-level load (512 B)\n# window_KB  start_mod_8  ms  wave_loads  cycles_per_wave_load_per_CU  TB/s_to_registers\n");
+  for (int h = 0; h < 2; ++h) {
+    for (int sh = 0; sh < 2; ++sh) {
+      const int halves = halves_of[h];
+      hipLaunchKernelGGL(k_probe2<8>, dim3(blocks), dim3(threads), 0, 0, d, sh, 200, halves, o);
+      hipDeviceSynchronize();
+      float best = 1e30f;
+      const int n_it = h == 0 ? iters : iters / 4;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_probe2<8>, dim3(blocks), dim3(threads), 0, 0, d, sh, n_it, halves, o);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) {best = ms;}
+      }
+      const double wave_loads = (double)blocks * (threads / 64) * n_it * unroll;
+      const double cyc = best * 1e-3 * 2.4e9 * n_cu / wave_loads;
+      std::printf("%d  %d  %.3f  %.3e  %.2f  %.1f\n", halves * 8, 4 * sh, best, wave_loads, cyc, wave_loads * 512.0 / (best * 1e-3) / 1e12);
     }
   }
   return 0;
