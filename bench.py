@@ -325,16 +325,17 @@ def loop_leg(device=0, n_pairs=256, batch=256, cpu=True, resident=True):
             packs[key] = ScanMatcher.pack_batch([queries[i] for i in ids], [chains[i] for i in ids])
         return packs[key]
 
-    def run():
+    from slam_toolbox_amd.scan_matcher import LoopClosureBatch
+
+    def run(pieces=4):
+        # MapperGraph::TryCloseLoop's two matches per chain (Mapper.cpp:1515-1549) through kh_loop_closure_batch: preset L coarse
+        # match -> gate -> preset S match of the temporary scan at the coarse pose, the batch cut into `pieces` so that the two
+        # matchers (two handles, two streams) overlap; pieces = 1 is the round-2 form, two batch calls back to back
         table = []
         for b in range(0, n_pairs, batch):
             ids = list(range(b, min(n_pairs, b + batch)))
-            resp, means, covs, st = mL.MatchScanBatch(None, None, False, False, packed=packed(ids))
-            gate = (resp > 0.35) & (covs[:, 0, 0] < 9.0) & (covs[:, 1, 1] < 9.0)
-            ok = [ids[k] for k in np.flatnonzero(gate)]
-            if ok:
-                mS.MatchScanBatch(None, None, False, True, packed=packed(ok))
-            table.append((len(ids), len(ok)))
+            o = LoopClosureBatch(mL, mS, None, None, LASER.min_angle, LASER.ang_res, 0.35, 9.0, pieces=pieces, packed=packed(ids))
+            table.append((len(ids), int(o["passed"].sum())))
         return table
     run()                                                     # warm-up: allocations
     times = []
@@ -342,16 +343,23 @@ def loop_leg(device=0, n_pairs=256, batch=256, cpu=True, resident=True):
         t = time.perf_counter()
         table = run()
         times.append(time.perf_counter() - t)
-    # one more pass with the library's event timers on: GPU time of the rasteriser (K1) and of the scoring kernel
+    serial = []
+    for _ in range(3):
+        t = time.perf_counter()
+        run(pieces=1)
+        serial.append(time.perf_counter() - t)
+    # one more pass with the library's event timers on: GPU time of the rasteriser (K1) and of the scoring kernel (the
+    # event pairs synchronise the host: unpipelined, so that the four figures do not contain each other's kernels)
     mL.profile(True); mS.profile(True)
-    run()
+    run(pieces=1)
     pL, pS = mL.profile(False), mS.profile(False)
     n_ok = sum(t[1] for t in table)
     mL.close(); mS.close()
     med = float(np.median(times))
-    out = {"loop_pairs_per_s": n_pairs / med, "loop_batch_ms": med * 1e3,
+    out = {"loop_pairs_per_s": n_pairs / med, "loop_batch_ms": med * 1e3, "loop_batch_ms_unpipelined": float(np.median(serial)) * 1e3,
            "loop_workload": f"{n_pairs} distinct pairs (chains 10-40 scans): preset L coarse MatchScan, "
-                            f"{n_ok} of them passing the gate -> preset S coarse+fine",
+                            f"{n_ok} of them passing the gate -> preset S coarse+fine match of the temporary scan at the coarse pose "
+                            f"(kh_loop_closure_batch, 4 pieces: the two matchers overlap)",
            "loop_gpu_ms": {"raster_L": pL["raster_ms"], "score_L": pL["score_ms"], "raster_S": pS["raster_ms"], "score_S": pS["score_ms"]}}
     # K1 roofline (HBM): SURVEY 8d B_rast = grid bytes (clear) + 16 B per point + 2 k^2 per new cell; reported against the
     # grid bytes + points, the part that is compulsory for any implementation that clears the grid

@@ -136,6 +136,20 @@ KH_API int kh_matcher_group_match_batch(kh_matcher_group * g, int32_t n, const k
                                         int32_t do_penalize, int32_t do_refine, double * means /* 3n */,
                                         double * covs /* 9n */, double * responses /* n */, int32_t * status /* n */);
 
+/* MapperGraph::TryCloseLoop's pair of matches (Mapper.cpp:1515-1549) for n candidate chains at once: the coarse match of
+ * queries[i] against base[base_begin[i] .. base_begin[i + 1]) on the loop matcher `coarse` (doPenalize false, doRefineMatch
+ * false), the gate (response > minimum_response_coarse, cov(0,0) and cov(1,1) < maximum_variance_coarse: passed[i]), and for
+ * the chains that pass the match of the temporary scan at the coarse pose (the same ranges, point readings recomputed with
+ * kh_scan_points for min_angle / angular_resolution) on the sequential matcher `fine` (doPenalize false, refined).  The
+ * batch is cut into `pieces` (4 suits 256 chains; 1 = the two batches one after the other) and the two matchers work on
+ * neighbouring pieces at the same time.  fine_* entries of chains that did not pass are left untouched.  Both matchers need
+ * max_batch >= ceil(n / pieces); their base scans' device_points_xy, if any, must live on BOTH matchers' device. */
+KH_API int kh_loop_closure_batch(kh_matcher * coarse, kh_matcher * fine, int32_t n, const kh_scan * queries, const kh_scan * base,
+                                 const int32_t * base_begin, double min_angle, double angular_resolution,
+                                 double minimum_response_coarse, double maximum_variance_coarse, int32_t pieces,
+                                 double * coarse_means, double * coarse_covs, double * coarse_responses, int32_t * passed,
+                                 double * fine_means, double * fine_covs, double * fine_responses);
+
 /* MatchScan steps 1-4 + AddScans only (Mapper.cpp:543-574): centre the grid of batch slot
  * `slot` on the query's sensor pose and rasterise the base scans into it. */
 KH_API int kh_matcher_add_scans(kh_matcher * m, int32_t slot, const kh_scan * query,

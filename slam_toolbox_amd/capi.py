@@ -71,7 +71,7 @@ SYMBOLS = [
     "kh_matcher_positional_covariance", "kh_matcher_angular_covariance",
     "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile", "kh_matcher_score_loads",
     "kh_matcher_group_create", "kh_matcher_group_destroy", "kh_matcher_group_set_params", "kh_matcher_group_size", "kh_matcher_group_member",
-    "kh_matcher_group_device", "kh_matcher_group_match_batch",
+    "kh_matcher_group_device", "kh_matcher_group_match_batch", "kh_loop_closure_batch",
     "kh_spa_options_default", "kh_spa_create", "kh_spa_set_debug", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
@@ -176,6 +176,8 @@ def lib():
         L.kh_matcher_group_member.restype = vp
         L.kh_matcher_group_device.argtypes = [vp, i32]
         L.kh_matcher_group_match_batch.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), iptr, vp, i32, i32, dptr, dptr, dptr, iptr]
+        L.kh_loop_closure_batch.argtypes = [vp, vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), iptr, dbl, dbl, dbl, dbl, i32,
+                                            dptr, dptr, dptr, iptr, dptr, dptr, dptr]
     L.kh_matcher_add_scans.argtypes = [vp, i32, C.POINTER(KhScan), C.POINTER(KhScan), i32]
     L.kh_matcher_correlate.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, C.POINTER(dbl)]
     L.kh_matcher_correlate_batch.argtypes = [vp, i32, C.POINTER(KhScan), dptr, dptr, dptr, dbl, dbl, i32, i32, dptr, dptr, dptr, iptr]

@@ -12,7 +12,10 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -21,6 +24,7 @@
 namespace kh
 {
 void set_error(const std::string & s);
+void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
 }
 
 struct kh_matcher_group
@@ -135,6 +139,94 @@ int kh_matcher_group_match_batch(kh_matcher_group * g, int32_t n, const kh_scan 
   for (int32_t k = 0; k < nm; ++k) {
     if (shares[k].rc) {kh::set_error(shares[k].error); return shares[k].rc;}
   }
+  return KH_OK;
+}
+
+// MapperGraph::TryCloseLoop's two matches for n candidate chains at once (Mapper.cpp:1515-1549): the coarse match on the loop
+// matcher, the gate, and for the chains that pass the fine match of a temporary scan placed at the coarse pose (tmpScan,
+// :1527-1534: same range readings, sensor pose = bestPose, point readings recomputed) on the sequential matcher.  The batch is
+// cut into `pieces`; while the coarse matcher works on piece k + 1 a second host thread runs the fine matches of piece k on
+// the fine matcher -- two handles, two streams, each used by one thread: the host halves of one stage (job tables, uploads,
+// downloads, covariances) disappear behind the kernels of the other.
+int kh_loop_closure_batch(kh_matcher * coarse, kh_matcher * fine, int32_t n, const kh_scan * queries, const kh_scan * base,
+  const int32_t * base_begin, double min_angle, double angular_resolution, double minimum_response_coarse, double maximum_variance_coarse,
+  int32_t pieces, double * coarse_means, double * coarse_covs, double * coarse_responses, int32_t * passed, double * fine_means,
+  double * fine_covs, double * fine_responses)
+{
+  if (!coarse || !fine || n < 0 || !queries || !base_begin || !coarse_means || !coarse_covs || !coarse_responses || !passed || !fine_means ||
+    !fine_covs || !fine_responses) {return KH_ERR_INVALID_ARG;}
+  if (n == 0) {return KH_OK;}
+  pieces = std::max(1, std::min(pieces, n));
+  std::vector<int32_t> bound(pieces + 1);
+  for (int32_t k = 0; k <= pieces; ++k) {bound[k] = static_cast<int32_t>(static_cast<int64_t>(n) * k / pieces);}
+  std::mutex mu;
+  std::condition_variable cv;
+  int32_t ready = 0;                 // pieces whose coarse results are in
+  bool abort = false;
+  int fine_rc = KH_OK;
+  std::string fine_error;
+  std::thread consumer([&] {
+    for (int32_t k = 0; k < pieces; ++k) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] {return ready > k || abort;});
+        if (abort) {return;}
+      }
+      std::vector<int32_t> ids;
+      for (int32_t i = bound[k]; i < bound[k + 1]; ++i) {
+        // Mapper.cpp:1519-1521
+        passed[i] = (coarse_responses[i] > minimum_response_coarse && coarse_covs[9 * i] < maximum_variance_coarse &&
+          coarse_covs[9 * i + 4] < maximum_variance_coarse) ? 1 : 0;
+        if (passed[i]) {ids.push_back(i);}
+      }
+      if (ids.empty()) {continue;}
+      const size_t m = ids.size();
+      std::vector<std::vector<double>> points(m);
+      std::vector<kh_scan> q(m), b;
+      std::vector<int32_t> begin(m + 1, 0);
+      for (size_t j = 0; j < m; ++j) {
+        const int32_t i = ids[j];
+        q[j] = queries[i];
+        std::copy(coarse_means + 3 * i, coarse_means + 3 * i + 3, q[j].sensor_pose);
+        points[j].resize(2 * static_cast<size_t>(q[j].n));
+        q[j].points_xy = points[j].data(); q[j].device_points_xy = nullptr;
+        for (int32_t t = base_begin[i]; t < base_begin[i + 1]; ++t) {b.push_back(base[t]);}
+        begin[j + 1] = static_cast<int32_t>(b.size());
+      }
+      // LocalizedRangeScan::Update of the temporary scans (one libm sincos per reading): on the worker pool
+      kh::host_parallel_for(m, [&](size_t j) {
+        kh_scan_points(q[j].ranges, q[j].n, q[j].sensor_pose, min_angle, angular_resolution, points[j].data());
+      });
+      std::vector<double> mean(3 * m), cov(9 * m), resp(m);
+      std::vector<int32_t> st(m, KH_OK);
+      int rc = kh_matcher_match_batch(fine, static_cast<int32_t>(m), q.data(), b.empty() ? nullptr : b.data(), begin.data(), 0, 1,
+          mean.data(), cov.data(), resp.data(), st.data());
+      for (size_t j = 0; j < m && rc == KH_OK; ++j) {rc = st[j];}
+      if (rc) {fine_rc = rc; fine_error = kh_last_error(); return;}
+      for (size_t j = 0; j < m; ++j) {
+        const int32_t i = ids[j];
+        std::copy(mean.begin() + 3 * j, mean.begin() + 3 * j + 3, fine_means + 3 * static_cast<size_t>(i));
+        std::copy(cov.begin() + 9 * j, cov.begin() + 9 * j + 9, fine_covs + 9 * static_cast<size_t>(i));
+        fine_responses[i] = resp[j];
+      }
+    }
+  });
+  int rc = KH_OK;
+  for (int32_t k = 0; k < pieces && rc == KH_OK; ++k) {
+    const int32_t i0 = bound[k], nk = bound[k + 1] - bound[k];
+    std::vector<int32_t> st(nk, KH_OK);
+    rc = kh_matcher_match_batch(coarse, nk, queries + i0, base, base_begin + i0, 0, 0, coarse_means + 3 * static_cast<size_t>(i0),
+        coarse_covs + 9 * static_cast<size_t>(i0), coarse_responses + i0, st.data());
+    for (int32_t j = 0; j < nk && rc == KH_OK; ++j) {rc = st[j];}
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (rc) {abort = true;} else {ready = k + 1;}
+    }
+    cv.notify_all();
+  }
+  consumer.join();
+  if (rc) {return rc;}
+  if (fine_rc) {kh::set_error(fine_error); return fine_rc;}
   return KH_OK;
 }
 

@@ -185,7 +185,7 @@ struct kh_matcher
   int32_t * h_meta = nullptr; int32_t * d_meta = nullptr; size_t cap_hmeta = 0, cap_dmeta = 0;
   RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
   bool keep_responses = false;
-  bool force_chunks = false;       // kh_matcher_set_debug bit 3: chunk every batch of >= 128 (tests)
+  bool force_chunks = std::getenv("KH_FORCE_CHUNKS") != nullptr;       // kh_matcher_set_debug bit 3: chunk every batch of >= 128 (tests)
   bool dense_score = false;        // kh_matcher_set_debug bit 2: do not skip beams whose window is empty
   int32_t bm_w = 0, bm_h = 0;
   int32_t rt_w = 0, rt_h = 0;      // rasteriser tiles over the grid
@@ -525,13 +525,14 @@ static int allocate_copies(kh_matcher * m, Slot & s, int32_t kind)
   return KH_OK;
 }
 
-static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na)
+// (the distance penalties -- nx * ny doubles, 52 KB of a loop-closure search's 70 -- are only staged for searches that penalise)
+static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na, bool penalize)
 {
   StageLayout L;
   size_t o = align_up(sizeof(CorrJob), 256);
   L.bx = o; o = align_up(o + sizeof(int32_t) * nx, 16);
   L.by = o; o = align_up(o + sizeof(int32_t) * ny, 16);
-  L.dist_pen = o; o = align_up(o + sizeof(double) * nx * ny, 16);
+  L.dist_pen = o; o = align_up(o + (penalize ? sizeof(double) * nx * ny : 0), 16);
   L.ang_pen = o; o = align_up(o + sizeof(double) * na, 16);
   L.cos_sin = o; o = align_up(o + sizeof(double) * 2 * na, 16);
   L.local = o; o = align_up(o + sizeof(double) * 2 * P, 16);
@@ -698,7 +699,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     for (int32_t k = 0; k < c.nx; ++k) {c.x_poses[k] = startX + static_cast<uint32_t>(k) * q.res_x;}
     for (int32_t k = 0; k < c.ny; ++k) {c.y_poses[k] = startY + static_cast<uint32_t>(k) * q.res_y;}
     c.denom = static_cast<double>(static_cast<uint32_t>(c.P) * 100u);     // Mapper.cpp:1204
-    lay[i] = stage_layout(c.P, c.nx, c.ny, c.na);
+    lay[i] = stage_layout(c.P, c.nx, c.ny, c.na, q.penalize);
     stride = std::max(stride, lay[i].total);
     out_words = std::max(out_words, kOutHeaderWords + static_cast<size_t>(c.nx) * c.ny);
     max_na = std::max(max_na, c.na);
@@ -812,7 +813,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     if (!linear) {sx = 1; sy_ws = m->ws;}
 
     // penalties, Mapper.cpp:671-685
-    c.dist_pen.assign(static_cast<size_t>(c.nx) * c.ny, 1.0);
+    if (q.penalize) {c.dist_pen.assign(static_cast<size_t>(c.nx) * c.ny, 1.0);} else {c.dist_pen.clear();}
     c.ang_pen.assign(c.na, 1.0);
     c.angles.resize(c.na);
     const double startAngle = c.center[2] - c.ang_off;
@@ -826,6 +827,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       c.ang_pen[a] = anglePenalty;
       ang_pen[a] = anglePenalty;
     }
+    if (q.penalize) {
     for (int32_t yi = 0; yi < c.ny; ++yi) {
       const double squareY = c.y_poses[yi] * c.y_poses[yi];
       for (int32_t xi = 0; xi < c.nx; ++xi) {
@@ -836,6 +838,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
         c.dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
         dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
       }
+    }
     }
 
     // scan points in the sensor frame: Transform(sensorPose).InverseTransformPose, Karto.h:6813-6824,
@@ -1445,7 +1448,7 @@ int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
   m->lds_score = (keep_response_volume & 2) != 0;
   m->dense_score = (keep_response_volume & 4) != 0;
   if (keep_response_volume & 32) {m->mfma_score = true;}
-  m->force_chunks = (keep_response_volume & 8) != 0;
+  m->force_chunks = (keep_response_volume & 8) != 0 || std::getenv("KH_FORCE_CHUNKS") != nullptr;
   m->dual_copy = (keep_response_volume & 16) == 0;
   return KH_OK;
 }

@@ -724,9 +724,18 @@ __global__ __launch_bounds__(256) void k_raster_fill(const RasterJob * jobs)
 __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, const uint8_t * __restrict__ kernel)
 {
   const RasterJob & job = jobs[blockIdx.y];
-  __shared__ uint32_t s_tile[kRasterTile * kRasterTile];
-  __shared__ uint32_t s_cells[41 * 41];          // footprint cell c: value << 16 | row << 8 | column
-  __shared__ int32_t s_px[256], s_py[256];
+  // one block so that the tile starts >= 40 tile rows into the workgroup's LDS: the stamping loop addresses footprint row r
+  // as (column base of row 0) + r * 256 in the instruction's offset field, and the base of a footprint that starts above
+  // the tile must not be a negative LDS address
+  struct Lds
+  {
+    uint32_t cells[41 * 41];                     // footprint cell c: value << 16 | row << 8 | column
+    int32_t px[256], py[256];
+    uint32_t pad[(40 * kRasterTile * 4 - 41 * 41 * 4 - 2048) / 4];
+    uint32_t tile[kRasterTile * kRasterTile];
+  };
+  __shared__ Lds lds;
+  uint32_t * s_tile = lds.tile; uint32_t * s_cells = lds.cells; int32_t * s_px = lds.px; int32_t * s_py = lds.py;
   const int k = job.kernel_size, hk = k / 2, kk = k * k;
   const int n_work = job.n_work[0];
   if ((int)blockIdx.x >= n_work) {return;}
@@ -744,22 +753,11 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
   const int sub = kk >= 64 ? 0 : lane / kk;               // which of them this lane works for
   const int c0 = kk >= 64 ? lane : lane - sub * kk;       // first cell of this lane
   const bool lane_on = kk >= 64 || sub < ppw;
-  // kk >= 64: a lane's footprint cells (lane, lane + 64, ...: at most 27 of 41 x 41) are the same for every point, so their
-  // column, their offset inside a 64-wide tile and their value live in registers: per cell and point 2 adds, 2 compares and
-  // the LDS max are left (the packed table in LDS cost a read and four unpacking operations more; this loop is where the
-  // rasteriser's time goes: 1681 cells for each of ~10 000 distinct points of a sequential-preset job)
-  constexpr int kCellsPerLane = (41 * 41 + 63) / 64;
-  int ex[kCellsPerLane], ed[kCellsPerLane];
-  uint32_t ev[kCellsPerLane];
+  // kk >= 64: lane l < k keeps column l of the smear kernel in registers, one value per footprint row
+  uint32_t colv[41];
   __syncthreads();                                         // s_cells is complete
 #pragma unroll
-  for (int u = 0; u < kCellsPerLane; ++u) {
-    const int c = lane + 64 * u;
-    const uint32_t e = c < kk ? s_cells[c] : 0u;           // beyond the footprint: value 0 at the corner cell, a no-op max
-    ex[u] = (int)(e & 0xffu);
-    ed[u] = (int)((e >> 8) & 0xffu) * kRasterTile + ex[u];
-    ev[u] = e >> 16;
-  }
+  for (int r = 0; r < 41; ++r) {colv[r] = (kk >= 64 && r < k && lane < k) ? (s_cells[r * k + lane] >> 16) : 0u;}
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int t = job.work[w];
     const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
@@ -777,16 +775,24 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
       }
       __syncthreads();
       if (kk >= 64) {
-        const int nc = (kk + 63) >> 6;                      // cells per lane actually in the footprint (wave-uniform bound)
+        // lane = footprint COLUMN, rows in a fully unrolled loop: whether a row of the footprint lies inside the tile is the
+        // same for the whole wave (scalar branch), whether the lane's column does is decided once per point (exec mask), and
+        // the row advances through the instruction's offset field -- per footprint row ONE ds_max and nothing else, the
+        // lanes on consecutive words of a tile row (no bank conflicts).  The round-2 mapping (lanes over the k * k cells
+        // in row-major order) spent six VALU instructions per ds_max on two range tests and lost half of the LDS cycles to
+        // conflicts where a lane group wrapped into the next footprint row (rocprofv3: SQ_LDS_BANK_CONFLICT 51 % of
+        // SQ_ACTIVE_INST_LDS, 325 M VALU against 55 M LDS instructions per launch).
         for (int q = wave; q < here; q += kWaves) {
-          const int fx = s_px[q];
-          const int fb = s_py[q] * kRasterTile + fx;
+          const int fx = __builtin_amdgcn_readfirstlane(s_px[q]), fy = __builtin_amdgcn_readfirstlane(s_py[q]);   // the wave's point
+          const int x = fx + lane;
+          const int r_lo = max(0, -fy), r_hi = min(k - 1, kRasterTile - 1 - fy);        // footprint rows inside the tile
+          if (r_hi < r_lo) {continue;}
+          const unsigned long long rows = ((2ull << r_hi) - 1ull) & ~((1ull << r_lo) - 1ull);    // one scalar bit test per row
+          if (lane < k && (unsigned)x < (unsigned)kRasterTile) {
+            uint32_t * col = &s_tile[fy * kRasterTile + x];
 #pragma unroll
-          for (int u = 0; u < kCellsPerLane; ++u) {
-            if (u < nc) {
-              const int x = fx + ex[u], idx = fb + ed[u];
-              // column inside the tile and (given that) row inside the tile <=> index inside the tile
-              if ((unsigned)x < (unsigned)kRasterTile && (unsigned)idx < (unsigned)(kRasterTile * kRasterTile)) {atomicMax(&s_tile[idx], ev[u]);}
+            for (int r = 0; r < 41; ++r) {
+              if ((rows >> r) & 1ull) {atomicMax(col + r * kRasterTile, colv[r]);}          // (a 0 at a corner: a no-op)
             }
           }
         }

@@ -299,6 +299,22 @@ class ScanMatcher:
             pass
 
 
+def LoopClosureBatch(coarse: "ScanMatcher", fine: "ScanMatcher", scans, base_lists, min_angle: float, angular_resolution: float,
+                     minimum_response_coarse: float, maximum_variance_coarse: float, pieces: int = 4, packed=None):
+    """MapperGraph::TryCloseLoop's coarse match, gate and fine match of the temporary scan at the coarse pose
+    (Mapper.cpp:1515-1549) for a batch of candidate chains: kh_loop_closure_batch.  Returns a dict of arrays; the fine_*
+    rows of chains that did not pass are NaN."""
+    q_arr, b_arr, begin, n, _keep = packed if packed is not None else ScanMatcher.pack_batch(scans, base_lists)
+    cm, cc, cr = np.zeros(3 * n), np.zeros(9 * n), np.zeros(n)
+    fm, fc, fr = np.full(3 * n, np.nan), np.full(9 * n, np.nan), np.full(n, np.nan)
+    passed = np.zeros(n, dtype=np.int32)
+    capi.check(capi.lib().kh_loop_closure_batch(coarse._h, fine._h, n, q_arr, b_arr, begin, min_angle, angular_resolution,
+                                                minimum_response_coarse, maximum_variance_coarse, pieces, cm, cc, cr, passed, fm, fc, fr),
+               "kh_loop_closure_batch")
+    return {"coarse_response": cr, "coarse_mean": cm.reshape(n, 3), "coarse_covariance": cc.reshape(n, 3, 3), "passed": passed.astype(bool),
+            "fine_response": fr, "fine_mean": fm.reshape(n, 3), "fine_covariance": fc.reshape(n, 3, 3)}
+
+
 class ScanMatcherGroup:
     """kh_matcher_group: one ScanMatcher per entry of `devices` in ONE process; MatchScanBatch deals candidate i to member
     i % len(devices) (a host thread per member) and returns the results in candidate order -- the in-process form of the

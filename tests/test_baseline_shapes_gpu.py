@@ -148,6 +148,55 @@ def test_config2_loop_batch_256_pairs(kartohip_lib):
     mS.close()
 
 
+def test_config2_loop_closure_batch_pipelined(kartohip_lib):
+    """kh_loop_closure_batch = TryCloseLoop's coarse match, gate and fine match of the temporary scan AT THE COARSE POSE
+    (Mapper.cpp:1515-1549), the two matchers working on neighbouring pieces of the batch at the same time.  The coarse
+    results must be the ones of the plain batch call, the gate the reference's, the fine results the oracle's (and the
+    reference's own on a subset) for a scan with the same ranges at the coarse pose -- whatever the number of pieces."""
+    from oracle import karto
+    from slam_toolbox_amd.scan_matcher import LoopClosureBatch, MapperParams, ScanMatcher
+    lb, hq, hb, oq, ob = _loop_batch_scans()
+    mp = MapperParams(**OFFLINE_PARAMS)
+    mL = ScanMatcher.Create(mp, *PRESETS["L"]["create"], max_batch=N_PAIRS)
+    mS = ScanMatcher.Create(mp, *PRESETS["S"]["create"], max_batch=N_PAIRS)
+    resp, means, covs, st = mL.MatchScanBatch(hq, hb, False, False)
+    out = {}
+    for pieces in (1, 4, 7):
+        out[pieces] = LoopClosureBatch(mL, mS, hq, hb, LASER.min_angle, LASER.ang_res, 0.35, 9.0, pieces=pieces)
+        o = out[pieces]
+        assert np.array_equal(bits(o["coarse_response"]), bits(resp)) and np.array_equal(bits(o["coarse_mean"]), bits(means)) and \
+            np.array_equal(bits(o["coarse_covariance"]), bits(covs)), f"coarse results differ from the plain batch ({pieces} pieces)"
+        assert [bool(p) for p in o["passed"]] == [_gate(resp[i], covs[i]) for i in range(N_PAIRS)]
+        for key in ("fine_response", "fine_mean", "fine_covariance"):
+            assert np.array_equal(bits(o[key]), bits(out[1][key])), f"{key} depends on the number of pieces"
+    o = out[4]
+    ok = [i for i in range(N_PAIRS) if o["passed"][i]]
+    assert 0 < len(ok) < N_PAIRS
+    assert np.isnan(o["fine_response"][[i for i in range(N_PAIRS) if not o["passed"][i]]]).all()
+    threads = min(64, os.cpu_count() or 1)
+    oS = make_oracle_matcher("S", threads=threads)
+    for i in ok[::4]:
+        q, pose, chain = lb["pairs"][i]
+        tmp = karto.Scan(lb["ranges"][q], means[i], LASER)               # tmpScan: same readings, sensor pose = bestPose
+        r, mean, cov = oS.match_scan(tmp, ob[i], False, True)
+        assert np.array_equal(bits(_row(r, mean, cov)), bits(_row(o["fine_response"][i], o["fine_mean"][i], o["fine_covariance"][i]))), \
+            f"pair {i}: fine match of the temporary scan differs from the oracle's"
+    from oracle import ref
+    if ref.available():
+        ref.init_laser(LASER)
+        ref.lib().ref_set_threads(threads)
+        rS = ref.RefMatcher(*PRESETS["S"]["create"], OFFLINE_PARAMS)
+        for i in ok[::16]:
+            q, pose, chain = lb["pairs"][i]
+            rq = ref.RefScan(lb["ranges"][q], means[i])
+            rb = [ref.RefScan(lb["ranges"][c], lb["truth"][c]) for c in chain]
+            r, mean, cov = rS.match_scan(rq, rb, False, True)
+            assert np.array_equal(bits(_row(r, mean, cov)), bits(_row(o["fine_response"][i], o["fine_mean"][i], o["fine_covariance"][i]))), \
+                f"pair {i}: fine match of the temporary scan differs from the reference's"
+    mL.close()
+    mS.close()
+
+
 # ------------------------------------------------------------------ config[3]: 10k nodes / 30k edges
 TIGHT = dict(max_num_iterations=200, function_tolerance=1e-15, gradient_tolerance=1e-14, parameter_tolerance=1e-14)
 
