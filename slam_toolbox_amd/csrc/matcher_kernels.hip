@@ -569,41 +569,72 @@ __device__ __forceinline__ int wave_counter_add(int32_t * counters, int t)
   return before;
 }
 
+// kBinPoints points per thread: the kernel is a chain of dependent memory round trips per point (active flag -> scan
+// pointer -> reading -> returning atomic on a cold grid line -> block map -> tile counter), so what a thread needs is several
+// points in flight, not more threads (one point per thread: 0.9 ms per 256-job batch at 0.6 TB/s of HBM traffic)
+constexpr int kBinPoints = 4;
 __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.y];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool on = p < job.n_points;
-  int cx = -1, cy = -1;
-  if (on) {
-    int32_t * cell = job.cell_xy + 2 * (size_t)p;
-    cell[0] = -1; cell[1] = -1;
-    on = job.active[p] != 0;
-    int32_t gx = 0, gy = 0;
-    if (on) {on = roi_cell(job, job_point(job, p), gx, gy);}
-    if (on && job.n_foot > 0) {
-      // the order-dependent rule: only the first valid point of a cell can stamp, and only if k_active_set let it
-      const int32_t h = hash_find(job, (uint32_t)gy * (uint32_t)job.roi_w + (uint32_t)gx);
-      on = h >= 0 && job.hvals[h] == p && job.hstate[h] == 1;
+  if ((int)blockIdx.x * 256 * kBinPoints >= job.n_points) {return;}
+  int pe[kBinPoints], cx[kBinPoints], cy[kBinPoints];
+  bool on[kBinPoints];
+  uint8_t act[kBinPoints];
+#pragma unroll
+  for (int e = 0; e < kBinPoints; ++e) {
+    pe[e] = ((int)blockIdx.x * kBinPoints + e) * 256 + (int)threadIdx.x;
+    on[e] = pe[e] < job.n_points;
+    act[e] = on[e] ? job.active[pe[e]] : (uint8_t)0;
+    cx[e] = -1; cy[e] = -1;
+  }
+  double2 pt[kBinPoints];
+#pragma unroll
+  for (int e = 0; e < kBinPoints; ++e) {
+    on[e] = on[e] && act[e] != 0;
+    pt[e] = on[e] ? job_point(job, pe[e]) : make_double2(0.0, 0.0);
+  }
+  int32_t gx[kBinPoints], gy[kBinPoints];
+#pragma unroll
+  for (int e = 0; e < kBinPoints; ++e) {
+    gx[e] = 0; gy[e] = 0;
+    if (on[e]) {on[e] = roi_cell(job, pt[e], gx[e], gy[e]);}
+  }
+  if (job.n_foot > 0) {
+    // the order-dependent rule: only the first valid point of a cell can stamp, and only if k_active_set let it
+#pragma unroll
+    for (int e = 0; e < kBinPoints; ++e) {
+      if (on[e]) {
+        const int32_t h = hash_find(job, (uint32_t)gy[e] * (uint32_t)job.roi_w + (uint32_t)gx[e]);
+        on[e] = h >= 0 && job.hvals[h] == pe[e] && job.hstate[h] == 1;
+      }
     }
-    if (on) {
-      cx = gx + job.roi_x; cy = gy + job.roi_y;              // CorrelationGrid::GridIndex, Mapper.h:1122-1128
+  }
+  uint32_t old[kBinPoints];
+#pragma unroll
+  for (int e = 0; e < kBinPoints; ++e) {
+    old[e] = 0;
+    if (on[e]) {
+      cx[e] = gx[e] + job.roi_x; cy[e] = gy[e] + job.roi_y;              // CorrelationGrid::GridIndex, Mapper.h:1122-1128
       if (job.n_foot <= 0) {
         // the kernel's centre is 100 = its maximum: write it now and use the byte as the "cell already stamped" flag
         // (with the cell table of the order-dependent rule the first point of a cell is known already -- hvals -- and
         // the tile kernel writes the centre with the rest of the footprint: no read-modify-write of a cold grid line)
-        const int32_t index = cx + cy * job.ws;
+        const int32_t index = cx[e] + cy[e] * job.ws;
         uint32_t * word = reinterpret_cast<uint32_t *>(job.grid) + (index >> 2);
         const uint32_t bit = (uint32_t)kOccupied << (8 * (index & 3));
-        const uint32_t old = atomicOr(word, bit);
-        on = ((old >> (8 * (index & 3))) & 0xffu) == 0;
+        old[e] = (atomicOr(word, bit) >> (8 * (index & 3))) & 0xffu;
       }
     }
-    if (on) {
-      cell[0] = cx; cell[1] = cy;
-      const int hk = job.kernel_size / 2;
-      const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
-      const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
+  }
+  const int hk = job.kernel_size / 2;
+#pragma unroll
+  for (int e = 0; e < kBinPoints; ++e) {
+    on[e] = on[e] && old[e] == 0;
+    int32_t * cell = job.cell_xy + 2 * (size_t)pe[e];
+    if (pe[e] < job.n_points) {cell[0] = on[e] ? cx[e] : -1; cell[1] = on[e] ? cy[e] : -1;}
+    if (on[e]) {
+      const int fx0 = (cx[e] - hk) >> kBlockShift, fx1 = (cx[e] + hk) >> kBlockShift;
+      const int fy0 = (cy[e] - hk) >> kBlockShift, fy1 = (cy[e] + hk) >> kBlockShift;
       for (int by = fy0; by <= fy1; ++by) {
         for (int bx = fx0; bx <= fx1; ++bx) {
           uint32_t * word = job.blockmap + (size_t)by * job.bm_w + (bx >> 5);
@@ -614,7 +645,7 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
     }
   }
   // Incidence counts of the <= 2 x 2 tiles the footprint overlaps (k <= 41 < 64) and the point's rank in each tile's list.
-  // The workgroup's 256 consecutive readings fall into a few dozen tiles: they are counted in an LDS table first (keys by
+  // The workgroup's consecutive readings fall into a few dozen tiles: they are counted in an LDS table first (keys by
   // linear probing in 256 slots, a crowded table sends the incidence to the global counter), then every occupied slot takes ONE global atomic -- all slots
   // at once -- and a point's rank is its tile's base plus its rank inside the workgroup.  (A wave-by-wave aggregation
   // took a chain of returning global atomics per wave, here and again in k_raster_fill: half of a single match's
@@ -623,31 +654,33 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
   __shared__ int32_t s_key[kSlots], s_cnt[kSlots], s_base[kSlots];
   s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int hk = job.kernel_size / 2;
-  const int tx0 = on ? (cx - hk) / kRasterTile : 0, tx1 = on ? (cx + hk) / kRasterTile : 0;
-  const int ty0 = on ? (cy - hk) / kRasterTile : 0, ty1 = on ? (cy + hk) / kRasterTile : 0;
-  int slot_of[4], local[4];
+  int slot_of[kBinPoints][4], local[kBinPoints][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
-    const int t = (on && tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
-    slot_of[q] = -1; local[q] = 0;
-    if (t >= 0) {
-      int sl = (int)(((uint32_t)t * 2654435761u) >> 24);                      // 8 bits
-      int tries = 0;
-      for (; tries < 24; ++tries) {
-        const int seen = atomicCAS(&s_key[sl], -1, t);
-        if (seen == -1 || seen == t) {break;}
-        sl = (sl + 1) & (kSlots - 1);
-      }
-      if (tries < 24) {
-        slot_of[q] = sl;
-        local[q] = atomicAdd(&s_cnt[sl], 1);
-      } else {
-        // table crowded (hundreds of distinct tiles under one workgroup's readings): this incidence goes to the counter itself
-        slot_of[q] = -2;
-        local[q] = atomicAdd(&job.tile_count[t], 1);
-        if (local[q] == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}
+  for (int e = 0; e < kBinPoints; ++e) {
+    const int tx0 = on[e] ? (cx[e] - hk) / kRasterTile : 0, tx1 = on[e] ? (cx[e] + hk) / kRasterTile : 0;
+    const int ty0 = on[e] ? (cy[e] - hk) / kRasterTile : 0, ty1 = on[e] ? (cy[e] + hk) / kRasterTile : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
+      const int t = (on[e] && tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
+      slot_of[e][q] = -1; local[e][q] = 0;
+      if (t >= 0) {
+        int sl = (int)(((uint32_t)t * 2654435761u) >> 24);                      // 8 bits
+        int tries = 0;
+        for (; tries < 24; ++tries) {
+          const int seen = atomicCAS(&s_key[sl], -1, t);
+          if (seen == -1 || seen == t) {break;}
+          sl = (sl + 1) & (kSlots - 1);
+        }
+        if (tries < 24) {
+          slot_of[e][q] = sl;
+          local[e][q] = atomicAdd(&s_cnt[sl], 1);
+        } else {
+          // table crowded (hundreds of distinct tiles under one workgroup's readings): this incidence goes to the counter itself
+          slot_of[e][q] = -2;
+          local[e][q] = atomicAdd(&job.tile_count[t], 1);
+          if (local[e][q] == 0) {job.work[atomicAdd(job.n_work, 1)] = t;}
+        }
       }
     }
   }
@@ -661,9 +694,14 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
     }
   }
   __syncthreads();
-  if (p < job.n_points) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {job.rank[4 * (size_t)p + q] = slot_of[q] >= 0 ? s_base[slot_of[q]] + local[q] : (slot_of[q] == -2 ? local[q] : -1);}
+  for (int e = 0; e < kBinPoints; ++e) {
+    if (pe[e] < job.n_points) {
+      int rk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {rk[q] = slot_of[e][q] >= 0 ? s_base[slot_of[e][q]] + local[e][q] : (slot_of[e][q] == -2 ? local[e][q] : -1);}
+      *reinterpret_cast<int4 *>(job.rank + 4 * (size_t)pe[e]) = make_int4(rk[0], rk[1], rk[2], rk[3]);
+    }
   }
 }
 
@@ -829,7 +867,7 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
   if (n_jobs <= 0 || max_points <= 0) {return;}
   hipStream_t s = (hipStream_t)stream;
   dim3 per_point((max_points + 255) / 256, n_jobs);
-  hipLaunchKernelGGL(k_raster_bin, per_point, dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_raster_bin, dim3((max_points + 256 * kBinPoints - 1) / (256 * kBinPoints), n_jobs), dim3(256), 0, s, d_jobs);
   hipLaunchKernelGGL(k_raster_scan, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
   hipLaunchKernelGGL(k_raster_fill, per_point, dim3(256), 0, s, d_jobs);
   // non-empty tiles <= 4 per point and <= all tiles; a workgroup walks several when there are more
