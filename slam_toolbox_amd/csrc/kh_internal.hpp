@@ -166,7 +166,7 @@ void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int3
 void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_cap, void * stream);
 void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
 void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream);
-void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles, void * stream);          // after launch_raster
+void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles, void * stream, bool any_copies);          // after launch_raster
 void launch_repitch_full(const RasterJob * d_job, int32_t rows, void * stream);                             // one job: whole grid
 void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,

@@ -464,7 +464,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), max_scan_n, m->stream);
   if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
   launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->stream);
-  if (any_copies) {launch_repitch(m->d_rjobs, static_cast<int32_t>(n_jobs), m->rt_w * m->rt_h, m->stream);}
+  launch_repitch(m->d_rjobs, static_cast<int32_t>(n_jobs), m->rt_w * m->rt_h, m->stream, any_copies);
   KH_HIP(hipGetLastError());
   if (timing) {
     std::fprintf(stderr, "[kh raster] host %.3f ms: %zu jobs, %zu (job, scan) items, %zu distinct scans, %.1f MB of points uploaded\n",
@@ -506,8 +506,6 @@ static int allocate_copies(kh_matcher * m, Slot & s, int32_t kind)
   KH_HIP(hipMemsetAsync(s.d_grid2_alloc, 0, bytes, m->stream));
   s.d_grid2 = s.d_grid2_alloc + kGridPad + static_cast<size_t>(m->pad_rows) * (kind == 2 ? m->pitch_d : m->pitch2);
   const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
-  KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_prev_work), (nt + 4) * sizeof(int32_t)));
-  KH_HIP(hipMemsetAsync(s.d_prev_work, 0, (nt + 4) * sizeof(int32_t), m->stream));
   // one-job descriptor for the full copy: only the fields k_repitch_full / k_repitch_keep read
   RasterJob j;
   std::memset(&j, 0, sizeof(j));
@@ -1389,6 +1387,10 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_blockmap), static_cast<size_t>(m->bm_w) * m->bm_h * 4)) != hipSuccess) {return fail(e, "hipMalloc block map");}
     if ((e = hipMemset(s.d_blockmap, 0, static_cast<size_t>(m->bm_w) * m->bm_h * 4)) != hipSuccess) {return fail(e, "hipMemset block map");}
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_rtiles), (4 * static_cast<size_t>(m->rt_w) * m->rt_h + 8) * sizeof(int32_t))) != hipSuccess) {return fail(e, "hipMalloc raster tiles");}
+    // tiles the slot's previous rasterisation wrote ([0] = how many): none yet, the grid is all zero
+    const size_t prev_bytes = (static_cast<size_t>(m->rt_w) * m->rt_h + 4) * sizeof(int32_t);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_prev_work), prev_bytes)) != hipSuccess) {return fail(e, "hipMalloc tile list");}
+    if ((e = hipMemset(s.d_prev_work, 0, prev_bytes)) != hipSuccess) {return fail(e, "hipMemset tile list");}
   }
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&m->h_rjobs), sizeof(RasterJob) * max_batch, hipHostMallocDefault)) != hipSuccess) {return fail(e, "hipHostMalloc");}
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_rjobs), sizeof(RasterJob) * max_batch)) != hipSuccess) {return fail(e, "hipMalloc");}

@@ -356,13 +356,29 @@ __global__ __launch_bounds__(256) void k_raster_clear(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.y];
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
-  // the grid base is 256-byte aligned and ws is a multiple of 8: whole uint2 words, then the tail
-  const size_t bytes = (size_t)job.ws * job.height;
-  uint4 * g16 = reinterpret_cast<uint4 *>(job.grid);
-  const size_t n16 = bytes / 16;
-  const uint4 zero = make_uint4(0, 0, 0, 0);
-  for (size_t i = tid; i < n16; i += nth) {g16[i] = zero;}
-  for (size_t i = n16 * 16 + tid; i < bytes; i += nth) {job.grid[i] = 0;}
+  // Only the tiles the previous rasterisation of this slot wrote can hold anything but 0 (k_raster_tile writes whole tiles,
+  // k_raster_bin's centre bytes lie in listed tiles, k_tiles_keep records the list): zeroing those is Grid::Clear.  A 4096 x
+  // 4093 grid of the sequential preset is 16.8 MB, the ~1000 tiles a chain of scans touches are 4 MB.
+  {
+    const int n_prev = job.prev_work[0];
+    for (int w = blockIdx.x; w < n_prev; w += gridDim.x) {
+      const int t = job.prev_work[4 + w];
+      const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
+      const int ox = tx * kRasterTile, oy = ty * kRasterTile;
+      // 64 rows x 64 bytes: 256 threads x 16 bytes (ws is a multiple of 8, the tile starts on a multiple of 64)
+      const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+      const int y = oy + row, x = ox + 16 * part;
+      if (y < job.height && x < job.ws) {
+        uint8_t * at = job.grid + (size_t)y * job.ws + x;
+        if (x + 16 <= job.ws) {
+          *reinterpret_cast<uint2 *>(at) = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2 *>(at + 8) = make_uint2(0u, 0u);
+        } else {
+          for (int i = 0; x + i < job.ws; i += 8) {*reinterpret_cast<uint2 *>(at + i) = make_uint2(0u, 0u);}
+        }
+      }
+    }
+  }
   const size_t bm = (size_t)job.bm_w * job.bm_h;
   for (size_t i = tid; i < bm; i += nth) {job.blockmap[i] = 0u;}
   // tile_count | tile_cursor | n_work (+3 pad) are contiguous
@@ -420,19 +436,48 @@ __device__ __forceinline__ int32_t hash_find(const RasterJob & job, uint32_t key
 // Order-dependent rule, step 1 (only when the kernel holds 100 off-centre): the FIRST valid point of every ROI cell.
 // Whatever happens to it, the cell is 100 once it has been visited (either it was 100 already, or the point sets it),
 // so every later point of the cell is skipped; only the firsts are candidates for stamping.
+constexpr int kCellPoints = 4;          // points per thread, loads and table probes of all of them in flight (see k_raster_bin)
 __global__ __launch_bounds__(256) void k_cell_first(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.y];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= job.n_points || job.n_foot <= 0 || !job.active[p]) {return;}
-  int32_t gx, gy;
-  if (!roi_cell(job, job_point(job, p), gx, gy)) {return;}
-  const uint32_t key = (uint32_t)gy * (uint32_t)job.roi_w + (uint32_t)gx;
-  uint32_t h = hash_slot(job, key);
-  for (;;) {
-    const uint32_t old = atomicCAS(&job.hkeys[h], kHashEmpty, key);
-    if (old == kHashEmpty || old == key) {atomicMin(&job.hvals[h], p); return;}
-    h = (h + 1) & (uint32_t)(job.hcap - 1);
+  if (job.n_foot <= 0 || (int)blockIdx.x * 256 * kCellPoints >= job.n_points) {return;}
+  int pe[kCellPoints];
+  bool on[kCellPoints];
+  uint8_t act[kCellPoints];
+#pragma unroll
+  for (int e = 0; e < kCellPoints; ++e) {
+    pe[e] = ((int)blockIdx.x * kCellPoints + e) * 256 + (int)threadIdx.x;
+    on[e] = pe[e] < job.n_points;
+    act[e] = on[e] ? job.active[pe[e]] : (uint8_t)0;
+  }
+  double2 pt[kCellPoints];
+#pragma unroll
+  for (int e = 0; e < kCellPoints; ++e) {
+    on[e] = on[e] && act[e] != 0;
+    pt[e] = on[e] ? job_point(job, pe[e]) : make_double2(0.0, 0.0);
+  }
+  uint32_t key[kCellPoints], h[kCellPoints];
+#pragma unroll
+  for (int e = 0; e < kCellPoints; ++e) {
+    int32_t gx = 0, gy = 0;
+    if (on[e]) {on[e] = roi_cell(job, pt[e], gx, gy);}
+    key[e] = (uint32_t)gy * (uint32_t)job.roi_w + (uint32_t)gx;
+    h[e] = hash_slot(job, key[e]);
+  }
+  // probe round by round: the compare-and-swaps of the points still looking for their slot are issued together
+  bool any = true;
+  while (any) {
+    uint32_t seen[kCellPoints];
+#pragma unroll
+    for (int e = 0; e < kCellPoints; ++e) {seen[e] = on[e] ? atomicCAS(&job.hkeys[h[e]], kHashEmpty, key[e]) : 0u;}
+    any = false;
+#pragma unroll
+    for (int e = 0; e < kCellPoints; ++e) {
+      if (on[e]) {
+        if (seen[e] == kHashEmpty || seen[e] == key[e]) {atomicMin(&job.hvals[h[e]], pe[e]); on[e] = false;}
+        else {h[e] = (h[e] + 1) & (uint32_t)(job.hcap - 1); any = true;}
+      }
+    }
   }
 }
 
@@ -448,19 +493,42 @@ __global__ __launch_bounds__(256) void k_cell_links(const RasterJob * jobs)
   if (mine_is_candidate) {
     const int32_t mine = job.hvals[h];
     const int32_t gy = (int32_t)(key / (uint32_t)job.roi_w), gx = (int32_t)(key - (uint32_t)gy * (uint32_t)job.roi_w);
+    // the <= 4 neighbour cells are looked up side by side: every probing round loads the keys of all lookups still running
     int32_t nbr[kMaxFootprint];
+    uint32_t want[kMaxFootprint], at[kMaxFootprint];
+    bool run[kMaxFootprint];
 #pragma unroll
     for (int f = 0; f < kMaxFootprint; ++f) {
-      int32_t ns = -1;
+      nbr[f] = -1; run[f] = false; want[f] = 0; at[f] = 0;
       if (f < job.n_foot) {
         const int32_t nx = gx + job.foot_dx[f], ny = gy + job.foot_dy[f];
         if (nx >= 0 && nx < job.roi_w && ny >= 0 && ny < job.roi_h) {
-          ns = hash_find(job, (uint32_t)ny * (uint32_t)job.roi_w + (uint32_t)nx);
-          if (ns >= 0 && job.hvals[ns] > mine) {ns = -1;}
+          want[f] = (uint32_t)ny * (uint32_t)job.roi_w + (uint32_t)nx;
+          at[f] = hash_slot(job, want[f]);
+          run[f] = true;
         }
       }
-      nbr[f] = ns;
     }
+    bool any = true;
+    while (any) {
+      uint32_t k[kMaxFootprint];
+#pragma unroll
+      for (int f = 0; f < kMaxFootprint; ++f) {k[f] = run[f] ? job.hkeys[at[f]] : kHashEmpty;}
+      any = false;
+#pragma unroll
+      for (int f = 0; f < kMaxFootprint; ++f) {
+        if (run[f]) {
+          if (k[f] == want[f]) {nbr[f] = (int32_t)at[f]; run[f] = false;}
+          else if (k[f] == kHashEmpty) {run[f] = false;}
+          else {at[f] = (at[f] + 1) & (uint32_t)(job.hcap - 1); any = true;}
+        }
+      }
+    }
+    int32_t nv[kMaxFootprint];
+#pragma unroll
+    for (int f = 0; f < kMaxFootprint; ++f) {nv[f] = nbr[f] >= 0 ? job.hvals[nbr[f]] : 0;}
+#pragma unroll
+    for (int f = 0; f < kMaxFootprint; ++f) {if (nbr[f] >= 0 && nv[f] > mine) {nbr[f] = -1;}}
     *reinterpret_cast<int4 *>(job.hnbr + (size_t)h * kMaxFootprint) = make_int4(nbr[0], nbr[1], nbr[2], nbr[3]);
     job.hstate[h] = 0;
   }
@@ -543,7 +611,7 @@ void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_poi
 {
   if (n_jobs <= 0 || max_points <= 0) {return;}
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_cell_first, dim3((max_points + 255) / 256, n_jobs), dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_cell_first, dim3((max_points + 256 * kCellPoints - 1) / (256 * kCellPoints), n_jobs), dim3(256), 0, s, d_jobs);
   hipLaunchKernelGGL(k_cell_links, dim3((max_cap + 255) / 256, n_jobs), dim3(256), 0, s, d_jobs);
   hipLaunchKernelGGL(k_active_set, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
 }
@@ -937,19 +1005,21 @@ __global__ __launch_bounds__(256) void k_repitch_fill(const RasterJob * jobs)
 __global__ __launch_bounds__(256) void k_repitch_keep(const RasterJob * jobs)
 {
   const RasterJob & job = jobs[blockIdx.x];
-  if (!job.grid2) {return;}
   const int n_work = job.n_work[0];
   for (int w = threadIdx.x; w < n_work; w += blockDim.x) {job.prev_work[4 + w] = job.work[w];}
   if (threadIdx.x == 0) {job.prev_work[0] = n_work;}
 }
 
-void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles, void * stream)
+void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles, void * stream, bool any_copies)
 {
   if (n_jobs <= 0) {return;}
   hipStream_t s = (hipStream_t)stream;
   const int blocks = std::min(max_tiles, 2048);
-  hipLaunchKernelGGL(k_repitch, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs);
-  hipLaunchKernelGGL(k_repitch_fill, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs);
+  if (any_copies) {
+    hipLaunchKernelGGL(k_repitch, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs);
+    hipLaunchKernelGGL(k_repitch_fill, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs);
+  }
+  // this rasterisation's tile list becomes the "previous" one: the next Grid::Clear of the slot zeroes exactly these tiles
   hipLaunchKernelGGL(k_repitch_keep, dim3(n_jobs), dim3(256), 0, s, d_jobs);
 }
 
