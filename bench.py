@@ -44,6 +44,26 @@ PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r3_k_s
                  if os.path.exists(p)), os.path.join(ROOT, "profiles", "r1_k_score_pmc.json"))
 
 
+def recorded_kernels(name):
+    """per-kernel records of a committed rocprofv3 summary (tools/pmc_summary.py): {} when the file is missing"""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def recorded_traffic(doc, kernels, units):
+    """HBM bytes per unit of work: sum over the named kernels (prefix match) of recorded bytes per launch x recorded launches,
+    divided by the units of work the recorded run did.  None when nothing was recorded."""
+    total, seen = 0.0, False
+    for k, d in doc.get("kernels", {}).items():
+        if any(k.startswith(n) for n in kernels) and "hbm_bytes_per_launch" in d and d.get("calls"):
+            total += d["hbm_bytes_per_launch"] * d["calls"]
+            seen = True
+    return total / units if seen and units else None
+
+
 def pmc_rates():
     """(L2 hit rate, L1 hit rate) of k_score from the same committed PMC passes, for the roofline note."""
     try:
@@ -260,6 +280,10 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
         n_lin = summ["successful_steps"]          # evaluation points linearised (the start + every accepted step)
         lin_bytes = 480.0 * 30000 * n_lin         # 144 B read + 336 B written per edge
         lin_gbs = lin_bytes / (summ["linearize_gpu_ms"] * 1e-3) / 1e9 if summ["linearize_gpu_ms"] > 0 else 0.0
+        spa_doc = recorded_kernels("r3_spa_pmc.json")
+        k6_traffic = recorded_traffic(spa_doc, ("k_potrf", "k_trsm", "k_syrk", "k_extend_add"), spa_doc.get("factorizations"))
+        k5_traffic = recorded_traffic(spa_doc, ("k_edge_lin", "k_gather_H", "k_gather_g"),
+                                      spa_doc.get("kernels", {}).get("k_gather_H", {}).get("calls"))
         out["solve_rooflines"] = [
             {"kernel": "K6 level pipeline: k_potrf + k_trsm + k_syrk + k_extend_add (+ assemble), multifrontal Cholesky with the forward solve fused",
              "bound": "latency (dependent levels: the pivot chains of k_potrf); ceiling quoted = mfma f64",
@@ -267,10 +291,12 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
              "flops_per_factorization": 2.0 * float(summ["factor_flops"]), "multiply_adds_per_factorization": float(summ["factor_flops"]),
              "factorizations": int(summ["factorizations"]),
              "gpu_ms": float(summ["factor_gpu_ms"]), "levels": int(summ["levels"]), "nnz_factor": int(summ["nnz_factor"]),
-             "traffic": None},
+             "traffic": k6_traffic, "traffic_source": "recorded: profiles/r3_spa_pmc.json (rocprofv3 PMC passes of tools/quick_spa.py, the same "
+                                                      "graph): HBM bytes of k_potrf + k_trsm + k_syrk + k_extend_add per numeric factorisation"},
             {"kernel": "K5 k_edge_lin + k_gather_H / _g (normal equations)", "bound": "hbm", "achieved": lin_gbs, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": lin_gbs / HBM_PEAK_GBS, "algorithmic_bytes": lin_bytes, "linearizations": int(n_lin),
-             "gpu_ms": float(summ["linearize_gpu_ms"]), "traffic": None,
+             "gpu_ms": float(summ["linearize_gpu_ms"]), "traffic": k5_traffic,
+             "traffic_source": "recorded: profiles/r3_spa_pmc.json: HBM bytes of k_edge_lin + k_gather_H + k_gather_g per linearisation",
              "note": "480 B per edge algorithmic (SURVEY 8d); 14.4 MB per linearisation is latency-, not bandwidth-sized"},
         ]
         out["solve_backward_gpu_ms"] = float(summ["backward_gpu_ms"])
@@ -369,9 +395,19 @@ def loop_leg(device=0, n_pairs=256, batch=256, cpu=True, resident=True):
     k1_ms = pL["raster_ms"] + pS["raster_ms"]
     if k1_ms > 0:
         gbs = k1_bytes / (k1_ms * 1e-3) / 1e9
-        out["loop_rooflines"] = [{"kernel": "K1 k_raster_* (clear + bin / scan / fill / tile), presets L and S", "bound": "hbm", "achieved": gbs,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": k1_bytes,
-                                  "gpu_ms": k1_ms, "traffic": None}]
+        K1 = ("k_raster_", "k_find_valid", "k_cell_", "k_active_set", "k_repitch")
+        doc = recorded_kernels("r3_loop_pmc.json")
+        batches = doc.get("kernels", {}).get("k_raster_scan", {}).get("calls", 0) / 2.0         # one launch per stage (L, S) of a batch
+        traffic = recorded_traffic(doc, K1, batches)
+        out["loop_rooflines"] = [{"kernel": "K1 k_find_valid + k_cell_* + k_active_set + k_raster_* + k_repitch*, presets L and S", "bound": "hbm",
+                                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": k1_bytes,
+                                  "gpu_ms": k1_ms, "traffic": traffic,
+                                  "traffic_gbs": (traffic / (k1_ms * 1e-3) / 1e9) if traffic else None,
+                                  "traffic_source": "recorded: profiles/r3_loop_pmc.json (rocprofv3 PMC passes of tools/loop_pieces.py, the same 256-pair "
+                                                    "batch; (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the K1 kernels, per batch)",
+                                  "note": "algorithmic_bytes still prices Grid::Clear at the whole grid (SURVEY 8d); the kernels zero only the tiles "
+                                          "the slot's previous rasterisation wrote, so the measured traffic is BELOW the algorithmic figure for the "
+                                          "clear and above it for the cell-table and tile-list passes"}]
     if resident:
         host = loop_leg(device, n_pairs, batch, cpu=False, resident=False)
         out["loop_batch_ms_host_scans"] = host["loop_batch_ms"]

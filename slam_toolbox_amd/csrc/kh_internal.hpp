@@ -124,7 +124,8 @@ struct CorrJob
   double * tile_best;        // [na][tiles_y * tiles_x] best response of every scoring tile (K3 -> K4); nullptr = K4 scans everything
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)
-  unsigned long long * out;  // result block, see below
+  unsigned long long * out;  // result block, see below (zeroed by K2: out_words words)
+  int32_t out_words;
   // Re-pitched copies (dual-copy layout).  A wave-level load of K3 reads four 64-byte row segments; in the grid's own
   // pitch (a multiple of 8) a segment straddles a 128-byte cache line almost half of the time, and every straddle is one
   // more L1 tag lookup (measured 6.3 per load, 4 rows x ~1.5 lines).  Copy A holds the same bytes at a pitch that is a
@@ -164,7 +165,8 @@ constexpr size_t kOutHeaderWords = 2 + kTieCap / 2;
 struct ValidItem {int32_t job, scan;};
 void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream);
 void launch_active_set(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_cap, void * stream);
-void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream);
+void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
+  void * stream);
 void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream);
 void launch_repitch(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_tiles, void * stream, bool any_copies);          // after launch_raster
 void launch_repitch_full(const RasterJob * d_job, int32_t rows, void * stream);                             // one job: whole grid

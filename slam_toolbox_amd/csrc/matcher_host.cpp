@@ -463,7 +463,7 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   // 3. FindValidPoints, stamps
   launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), max_scan_n, m->stream);
   if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
-  launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->stream);
+  launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->kernel_size, m->stream);
   launch_repitch(m->d_rjobs, static_cast<int32_t>(n_jobs), m->rt_w * m->rt_h, m->stream, any_copies);
   KH_HIP(hipGetLastError());
   if (timing) {
@@ -908,7 +908,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       const int32_t tiles = job->tiles_x * job->tiles_y;
       job->list_tiles = (tiles >= 4 && tiles <= c.lt_alloc) ? tiles : 1;
     }
-    job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i;
+    job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i; job->out_words = static_cast<int32_t>(out_words);
     job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
     job->tile_best = s.d_tile_best;
     // re-pitched copies: linear full-resolution lattice one tile wide (the copy is picked per beam for the tile at x0 = 0)
@@ -956,7 +956,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   // else of a chunk happens under the scoring of its neighbours
   hipStream_t cs = overlap ? B.side : m->stream;
   KH_HIP(hipMemcpyAsync(B.d_stage, B.h_stage, stride * n, hipMemcpyHostToDevice, cs));
-  KH_HIP(hipMemsetAsync(B.d_out, 0, out_words * 8 * n, cs));
+  // (the result blocks are zeroed by K2)
   if (use_lds) {
     launch_offsets_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, cs);
   } else {

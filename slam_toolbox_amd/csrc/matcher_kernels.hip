@@ -930,7 +930,83 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
   }
 }
 
-void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, void * stream)
+// The same for kernels of 8 x 8 to 41 x 41 cells with the TILE IN REGISTERS: wave w owns tile rows 16w .. 16w + 15, lane =
+// tile column, acc[j] = cell (16w + j, lane).  Every wave walks all points of the tile; for a point whose footprint starts
+// at (fx, fy) relative to the tile the value for tile row y and this lane's column is kernel[y - fy][lane - fx], read from
+// a byte table in LDS whose rows are padded with zeros left and right (no column test) and above and below (rows are taken
+// in groups of four under one scalar test): per tile row ONE ds_read_u8 and ONE v_max_u32, no atomics -- the LDS-atomic
+// form above is bound by ds_max_u32 at about 4 clocks per wave instruction.
+__global__ __launch_bounds__(256) void k_raster_tile_reg(const RasterJob * jobs, const uint8_t * __restrict__ kernel)
+{
+  const RasterJob & job = jobs[blockIdx.y];
+  constexpr int kPitch = 192;                  // 64 zeros | <= 41 values | zeros: index 64 + lane - fx is in [1, 167]
+  constexpr int kGuard = 15;                   // zero rows above and below
+  __shared__ int32_t s_px[256], s_py[256];
+  __shared__ uint8_t s_tab[(41 + 2 * kGuard) * kPitch];
+  const int k = job.kernel_size, hk = k / 2;
+  const int n_work = job.n_work[0];
+  if ((int)blockIdx.x >= n_work) {return;}
+  for (int i = threadIdx.x; i < (41 + 2 * kGuard) * kPitch / 4; i += blockDim.x) {reinterpret_cast<uint32_t *>(s_tab)[i] = 0u;}
+  __syncthreads();
+  for (int i = threadIdx.x; i < k * k; i += blockDim.x) {
+    const int row = i / k, col = i - row * k;
+    s_tab[(kGuard + row) * kPitch + 64 + col] = kernel[i];
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int band = 16 * wave;                  // first tile row of this wave
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int t = job.work[w];
+    const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
+    const int ox = tx * kRasterTile, oy = ty * kRasterTile;       // grid cell of the tile's corner
+    uint32_t acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {acc[j] = 0u;}
+    const int begin = job.tile_start[t], count = job.tile_count[t];
+    for (int chunk = 0; chunk < count; chunk += 256) {
+      const int here = min(256, count - chunk);
+      __syncthreads();                                            // table complete / previous chunk consumed
+      if ((int)threadIdx.x < here) {
+        const int p = job.list[begin + chunk + threadIdx.x];
+        s_px[threadIdx.x] = job.cell_xy[2 * (size_t)p] - hk - ox;          // footprint corner relative to the tile
+        s_py[threadIdx.x] = job.cell_xy[2 * (size_t)p + 1] - hk - oy;
+      }
+      __syncthreads();
+      for (int q0 = 0; q0 < here; q0 += 64) {
+        const int cnt = min(64, here - q0);
+        const int mx = s_px[q0 + lane], my = s_py[q0 + lane];      // (entries beyond `here` are stale: not read out below)
+        for (int q = 0; q < cnt; ++q) {
+          const int fx = __builtin_amdgcn_readlane(mx, q), fy = __builtin_amdgcn_readlane(my, q);
+          // footprint rows r = band + j - fy in [0, k) <=> j in [j_lo, j_hi]
+          const int j_lo = max(0, fy - band), j_hi = min(15, fy - band + k - 1);
+          if (j_hi < j_lo) {continue;}
+          const uint8_t * row0 = s_tab + (kGuard + band - fy) * kPitch + 64 - fx + lane;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (j_hi >= 4 * g && j_lo <= 4 * g + 3) {
+              uint32_t v[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {v[u] = row0[(4 * g + u) * kPitch];}
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {acc[4 * g + u] = max(acc[4 * g + u], v[u]);}
+            }
+          }
+        }
+      }
+    }
+    // write the band: 16 rows x 64 bytes, lane = column (clipped to the grid)
+    const int x = ox + lane;
+    if (x < job.ws) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int y = oy + band + j;
+        if (y < job.height) {job.grid[(size_t)y * job.ws + x] = (uint8_t)acc[j];}
+      }
+    }
+  }
+}
+
+void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
+  void * stream)
 {
   if (n_jobs <= 0 || max_points <= 0) {return;}
   hipStream_t s = (hipStream_t)stream;
@@ -941,7 +1017,13 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
   // non-empty tiles <= 4 per point and <= all tiles; a workgroup walks several when there are more
   static const int tile_blocks = std::getenv("KH_TILE_BLOCKS") ? std::atoi(std::getenv("KH_TILE_BLOCKS")) : 2048;
   int blocks = std::min(std::min(max_tiles, 4 * max_points), tile_blocks);
-  hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
+  // kernels of >= 8 x 8 cells: tile in registers; KH_RASTER_TILE_LDS=1 keeps the LDS-atomic form (measurements)
+  static const bool lds_form = std::getenv("KH_RASTER_TILE_LDS") != nullptr;
+  if (kernel_size >= 8 && !lds_form) {
+    hipLaunchKernelGGL(k_raster_tile_reg, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
+  } else {
+    hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
+  }
 }
 
 // Re-pitched copies (CorrJob::grid2): the tiles the previous rasterisation touched are zeroed, the tiles this one touched
@@ -1059,6 +1141,12 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
   const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.y * stride);
   const int a = blockIdx.x;
   if (a >= job.na) {return;}
+  // the job's result block starts from zero (best response, tie count, probs): every angle's workgroup clears its share
+  {
+    const int per = (job.out_words + job.na - 1) / job.na;
+    const int hi = min(job.out_words, (a + 1) * per);
+    for (int i = a * per + threadIdx.x; i < hi; i += blockDim.x) {job.out[i] = 0ull;}
+  }
   __shared__ int32_t s_counts[kClasses + 1];
   __shared__ int32_t s_tcounts[kClasses * 32];
   __shared__ int32_t s_tcounts2[kClasses * 32];
@@ -1696,6 +1784,13 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   const int group = blockIdx.x;
   const int a0 = group * kGroupAngles;
   if (a0 >= job.na) {return;}
+  {
+    // the job's result block starts from zero: every group's workgroup clears its share
+    const int groups = (job.na + kGroupAngles - 1) / kGroupAngles;
+    const int per = (job.out_words + groups - 1) / groups;
+    const int hi = min(job.out_words, (group + 1) * per);
+    for (int i = group * per + threadIdx.x; i < hi; i += blockDim.x) {job.out[i] = 0ull;}
+  }
   const int P = job.n_points;
   extern __shared__ int32_t s_xy[];              // [kGroupAngles][2][P]: gx, gy (gy = kNotFast: not a fast beam)
   __shared__ int32_t s_slow[kGroupAngles];
