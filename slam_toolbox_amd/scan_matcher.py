@@ -300,7 +300,7 @@ class ScanMatcher:
 
 
 def LoopClosureBatch(coarse: "ScanMatcher", fine: "ScanMatcher", scans, base_lists, min_angle: float, angular_resolution: float,
-                     minimum_response_coarse: float, maximum_variance_coarse: float, pieces: int = 4, packed=None):
+                     minimum_response_coarse: float, maximum_variance_coarse: float, pieces: int = 1, packed=None):
     """MapperGraph::TryCloseLoop's coarse match, gate and fine match of the temporary scan at the coarse pose
     (Mapper.cpp:1515-1549) for a batch of candidate chains: kh_loop_closure_batch.  Returns a dict of arrays; the fine_*
     rows of chains that did not pass are NaN."""
