@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkartohip.so")
+LIB_PATH = os.environ.get("KH_LIBRARY") or os.path.join(HERE, "libkartohip.so")     # KH_LIBRARY: another build of the same sources (measurements)
 
 KH_OK, KH_ERR_INVALID_ARG, KH_ERR_NO_DEVICE, KH_ERR_HIP, KH_ERR_SEARCH, KH_ERR_NOT_FOUND, KH_ERR_SOLVER, KH_ERR_IO = range(8)
 KH_GRAPH_TEXT, KH_GRAPH_BINARY = 0, 1

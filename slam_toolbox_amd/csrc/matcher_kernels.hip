@@ -1636,7 +1636,10 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
 {
   if (n_jobs <= 0 || max_tiles <= 0 || max_na <= 0) {return;}
   // AW = 4 (four adjacent angles sharing a CU) was measured: L1 hit rate 31 -> 38 %, no gain in time
-  constexpr int AW = 1;
+#ifndef KH_AW
+#define KH_AW 1
+#endif
+  constexpr int AW = KH_AW;
   const int groups = (max_na + AW - 1) / AW;      // angle groups per job
   // units of XCD-local work: whole jobs, or contiguous ranges of angle groups when jobs are scarce
   int chunks = 1;

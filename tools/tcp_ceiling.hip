@@ -62,6 +62,37 @@ __global__ __launch_bounds__(512) void k_probe2(const unsigned * __restrict__ bu
   if (s == 0x12345678ull) {out[0] = (unsigned)s;}
 }
 
+// mixed hits and misses: of the four 64-byte row segments of a wave-level dword load, `miss_groups` come from a window that is
+// evicted before its next use (L1 miss, L2 hit: 64 KB per workgroup, walked round robin) and the rest from a resident one
+template <int UNROLL>
+__global__ __launch_bounds__(512) void k_probe_mix(const unsigned * __restrict__ buf, int miss_groups, int iters, unsigned * out)
+{
+  constexpr int kPitch = 64;
+  const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+  const int wave = (threadIdx.x >> 6) & 7;
+  unsigned acc[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {acc[u] = 0;}
+  // per workgroup: 8 halves of 8 KB for the streaming part, then 8 KB resident (4 x 8 rows x 256 B)
+  const unsigned * wg = buf + (size_t)blockIdx.x * (9 * 32 * kPitch);
+  const unsigned * hot = wg + 8 * 32 * kPitch + (wave * 4 + g) * kPitch + l;
+  const unsigned * cold = wg + (wave * 4 + g) * kPitch + l;
+  const bool miss = g < miss_groups;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned * p = miss ? cold + ((it & 7) << 11) : hot;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      // the resident rows are re-read with a column shift inside the line (no new line), the streaming ones walk the half
+      const unsigned * q = miss ? p + ((u * 4 * kPitch) & 2047) : p + 16 * (u & 1);
+      acc[u] += *q;
+    }
+  }
+  unsigned s = 0;
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {s += acc[u];}
+  if (s == 0x12345678u) {out[0] = s;}
+}
+
 int main()
 {
   const int n_cu = 256, threads = 512;                          // one workgroup of 8 waves per CU
@@ -94,6 +125,23 @@ int main()
       const double cyc = best * 1e-3 * 2.4e9 * n_cu / wave_loads;
       std::printf("%d  %d  %.3f  %.3e  %.2f  %.1f\n", halves * 8, tags, best, wave_loads, cyc, wave_loads * 256.0 / (best * 1e-3) / 1e12);
     }
+  }
+  std::printf("# mixed: of the 4 row segments (lines) of a dword load, N miss the L1 and hit the L2\n# missing_lines  ms  wave_loads  cycles_per_wave_load_per_CU  TB/s_to_registers\n");
+  for (int m = 0; m <= 4; ++m) {
+    hipLaunchKernelGGL(k_probe_mix<8>, dim3(blocks), dim3(threads), 0, 0, d, m, 200, o);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    const int n_it = iters / 4;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k_probe_mix<8>, dim3(blocks), dim3(threads), 0, 0, d, m, n_it, o);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) {best = ms;}
+    }
+    const double wave_loads = (double)blocks * (threads / 64) * n_it * unroll;
+    const double cyc = best * 1e-3 * 2.4e9 * n_cu / wave_loads;
+    std::printf("%d  %.3f  %.3e  %.2f  %.1f\n", m, best, wave_loads, cyc, wave_loads * 256.0 / (best * 1e-3) / 1e12);
   }
   std::printf("# dwordx2 loads, 8 row segments of 64 B per wave-level load (512 B)\n# window_KB  start_mod_8  ms  wave_loads  cycles_per_wave_load_per_CU  TB/s_to_registers\n");
   for (int h = 0; h < 2; ++h) {
