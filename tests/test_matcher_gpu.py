@@ -5,7 +5,7 @@ IEEE operation order, the device half is exact integer + unfused FP64)."""
 import numpy as np
 import pytest
 
-from common import PRESETS, Scenario, bits, make_hip_matcher, make_oracle_matcher
+from common import C2_PARAMS, PRESETS, Scenario, bits, make_hip_matcher, make_oracle_matcher
 
 pytestmark = pytest.mark.gpu
 
@@ -160,6 +160,33 @@ def test_chunked_config2_batch_equals_single(kartohip_lib):
         queries.append(q)
         centers.append(scs[b % 4].query_pose)
     corr = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+    singles = [hm.CorrelateScan(queries[b], centers[b], *corr, True, None, False, slot=b) for b in range(4)]
+    resp, means, covs, status = hm.CorrelateScanBatch(None, np.asarray(centers), *corr, True, False,
+                                                      scan_array=(_scan_array(queries), n))
+    assert (status == 0).all()
+    for b in range(n):
+        r, m, c = singles[b % 4]
+        _assert_same(r, resp[b], "response")
+        _assert_same(m, means[b], "mean")
+        _assert_same(c, covs[b], "cov")
+    hm.close()
+
+
+def test_chunked_batch_of_searches_three_tiles_tall(kartohip_lib):
+    """130 one-cell searches of 81 x 81 poses (three scoring tiles of 28 rows) in one call -- the chunked pipeline with
+    a kernel instance and a tile count config 2 never uses -- against the same searches one at a time."""
+    import math
+    from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher, _scan_array
+    n = 130
+    scs = [Scenario(seed=90 + i, n_base=6, start=37 * i + 5, perturb=(0.02 * (i - 1), 0.03 * i, 0.01 * (i - 2))) for i in range(4)]
+    hm = ScanMatcher.Create(MapperParams(**C2_PARAMS), 0.4, 0.005, 0.03, 20.0, max_batch=n)
+    queries, centers = [], []
+    for b in range(n):
+        q, base = scs[b % 4].hip_scans()
+        hm.AddScans(q, base, slot=b)
+        queries.append(q)
+        centers.append(scs[b % 4].query_pose)
+    corr = ((0.2, 0.2), (0.005, 0.005), math.radians(10.0), math.radians(0.5))
     singles = [hm.CorrelateScan(queries[b], centers[b], *corr, True, None, False, slot=b) for b in range(4)]
     resp, means, covs, status = hm.CorrelateScanBatch(None, np.asarray(centers), *corr, True, False,
                                                       scan_array=(_scan_array(queries), n))
@@ -415,6 +442,37 @@ def test_two_cell_search_from_the_column_decimated_copies(kartohip_lib):
         hm.AddScans(hq, hb)
         r_h, mean_h, cov_h = hm.CorrelateScan(hq, sc.query_pose, *args, False, None, False)
         sums, resp = hm.volume()
+        assert np.array_equal(bits(vol[..., 0]), bits(resp)), f"response volume differs ({kw})"
+        _assert_same(r_o, r_h, "response"); _assert_same(mean_o, mean_h, "mean"); _assert_same(cov_o, cov_h, "covariance")
+        hm.close()
+
+
+@pytest.mark.parametrize("side_m, n_angles", [(0.4, 17), (0.64, 9)])
+def test_full_resolution_search_of_several_tiles(kartohip_lib, side_m, n_angles):
+    """One-cell searches taller than two scoring tiles: 81 x 81 poses (rows per lane 7: three tiles of 28 rows, one list for all
+    tiles, copies A / B) and 129 x 129 poses (3 x 5 tiles of 61 x 32 poses with a list per tile).  config 2 and the presets
+    never produce these shapes; the sums must still be the oracle's, with and without the copies."""
+    import math
+    from oracle import karto
+    from slam_toolbox_amd.scan_matcher import MapperParams, ScanMatcher
+    create = (side_m, 0.005, 0.03, 20.0)
+    sc = Scenario(seed=33, n_base=8, start=200, perturb=(0.02, -0.04, 0.01))
+    oq, ob = sc.oracle_scans()
+    hq, hb = sc.hip_scans()
+    om = karto.Matcher(*create, C2_PARAMS, threads=16)
+    om.add_scans(oq, ob)
+    off = 0.5 * round(side_m / 0.005) * 0.005
+    half = 0.5 * (n_angles - 1) * math.radians(0.5)
+    args = ((off, off), (0.005, 0.005), half, math.radians(0.5))
+    r_o, mean_o, cov_o = om.correlate_scan(oq, sc.query_pose, *args, True, False)
+    vol = om.volume()
+    for kw in (dict(), dict(no_dual_copy=True), dict(mfma_score=True)):
+        hm = ScanMatcher.Create(MapperParams(**C2_PARAMS), *create, max_batch=1)
+        hm.set_debug(True, **kw)
+        hm.AddScans(hq, hb)
+        r_h, mean_h, cov_h = hm.CorrelateScan(hq, sc.query_pose, *args, True, None, False)
+        sums, resp = hm.volume()
+        assert resp.shape == vol[..., 0].shape
         assert np.array_equal(bits(vol[..., 0]), bits(resp)), f"response volume differs ({kw})"
         _assert_same(r_o, r_h, "response"); _assert_same(mean_o, mean_h, "mean"); _assert_same(cov_o, cov_h, "covariance")
         hm.close()
