@@ -68,17 +68,23 @@ struct Mat3
 {
   double m[3][3];
   void identity() {std::memset(m, 0, sizeof(m)); m[0][0] = m[1][1] = m[2][2] = 1.0;}
-  void from_axis_angle(double x, double y, double z, double radians)      // Karto.h:2482-2511
+  // Rodrigues' rotation about a unit axis, in the operation order of Matrix3::FromAxisAngle (Karto.h:2482-2511) -- the solver log
+  // is compared with the reference's at 17 digits: diagonal a_i a_i (1 - c) + c; off-diagonal (a_i a_j)(1 - c) -+ a_k s, "+" where
+  // (i, j, k) is an odd permutation
+  void from_axis_angle(double ax, double ay, double az, double angle)
   {
-    double cosRadians, sinRadians;
-    ref_sincos(radians, &sinRadians, &cosRadians);
-    const double oneMinusCos = 1.0 - cosRadians;
-    const double xx = x * x, yy = y * y, zz = z * z;
-    const double xyMCos = x * y * oneMinusCos, xzMCos = x * z * oneMinusCos, yzMCos = y * z * oneMinusCos;
-    const double xSin = x * sinRadians, ySin = y * sinRadians, zSin = z * sinRadians;
-    m[0][0] = xx * oneMinusCos + cosRadians; m[0][1] = xyMCos - zSin; m[0][2] = xzMCos + ySin;
-    m[1][0] = xyMCos + zSin; m[1][1] = yy * oneMinusCos + cosRadians; m[1][2] = yzMCos - xSin;
-    m[2][0] = xzMCos - ySin; m[2][1] = yzMCos + xSin; m[2][2] = zz * oneMinusCos + cosRadians;
+    const double axis[3] = {ax, ay, az};
+    double s, c;
+    ref_sincos(angle, &s, &c);
+    const double versine = 1.0 - c;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        if (i == j) {m[i][i] = axis[i] * axis[i] * versine + c; continue;}
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const double symmetric = axis[lo] * axis[hi] * versine, skew = axis[3 - i - j] * s;
+        m[i][j] = ((j - i + 3) % 3 == 2) ? symmetric + skew : symmetric - skew;
+      }
+    }
   }
   Pose mul(const Pose & p) const                                          // Matrix3 * Pose2, Karto.h:2654-2666
   {
