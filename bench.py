@@ -557,7 +557,28 @@ def latency_leg(device=0):
             row["single_correlate_scan_per_s"] = 1e3 / row["single_correlate_scan_ms"]
         hm.close()
         out[preset] = row
-    return {"single_call_latency": out,
+    # config[1]'s geometry as FULL MatchScans in one batch (rasterise + coarse 31 x 31 x 81 + fine per pair): 64 pairs per call
+    from slam_toolbox_amd.scan_matcher import ScanMatcher
+    scs = [Scenario(seed=40 + i, n_base=10, start=31 * i + 7) for i in range(8)]
+    distinct = [sc.hip_scans() for sc in scs]
+    for _, base in distinct:
+        for scan in base:
+            scan.MakeResident(device)
+    pairs = [distinct[i % 8] for i in range(64)]
+    hm = make_hip_matcher("C2", max_batch=64)
+    pack = ScanMatcher.pack_batch([q for q, _ in pairs], [b for _, b in pairs])
+    for _ in range(2):
+        hm.MatchScanBatch(None, None, True, True, packed=pack)
+    ts = []
+    for _ in range(5):
+        t = time.perf_counter()
+        hm.MatchScanBatch(None, None, True, True, packed=pack)
+        ts.append(time.perf_counter() - t)
+    hm.close()
+    batch_ms = float(np.median(ts)) * 1e3
+    return {"single_call_latency": out, "config2_match_scan_batch_ms": batch_ms, "config2_match_scans_per_s": 64.0 / (batch_ms * 1e-3),
+            "config2_match_scan_workload": "64 (query, 10 base scans) pairs per kh_matcher_match_batch at config[1]'s geometry: AddScans + coarse "
+                                           "CorrelateScan 31 x 31 x 81 poses + fine pass (SURVEY 8d), base scans resident",
             "single_call_latency_note": "wall time per call from Python through the C ABI, MatchScan(doPenalize, doRefineMatch) = true; "
                                         "C2.single_correlate_scan_ms = config[1] issued one CorrelateScan at a time"}
 
