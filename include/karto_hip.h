@@ -499,6 +499,8 @@ typedef struct kh_mapper kh_mapper;
 typedef struct kh_laser {                       /* karto::LaserRangeFinder (Karto.h:4060-4330) */
   int32_t n_beams;
   double minimum_angle, angular_resolution, minimum_range, maximum_range, range_threshold;
+  double offset_x, offset_y, offset_heading;    /* LaserRangeFinder::GetOffsetPose: where the sensor sits on the robot (zeros = at
+                                                   its centre); sensor pose = GetSensorAt(corrected pose), Karto.h:5566-5588 */
 } kh_laser;
 typedef struct kh_mapper_params {               /* Mapper::InitializeParameters (Mapper.cpp:2086-2297) */
   int32_t use_scan_matching, use_scan_barycenter;

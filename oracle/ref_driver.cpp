@@ -64,6 +64,14 @@ int ref_init_laser(
   return static_cast<int>(g_lrf->GetNumberOfRangeReadings());
 }
 
+// LaserRangeFinder::SetOffsetPose: where the sensor sits on the robot (call after ref_init_laser)
+int ref_set_laser_offset(double x, double y, double heading)
+{
+  if (g_lrf == nullptr) {return -1;}
+  g_lrf->SetOffsetPose(Pose2(x, y, heading));
+  return 0;
+}
+
 void ref_set_threads(int n) {tbb::ref_thread_count() = n;}
 
 void * ref_mapper_create() {return new Mapper();}

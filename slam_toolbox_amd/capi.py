@@ -107,7 +107,8 @@ class KhDecayParams(C.Structure):
 
 class KhLaser(C.Structure):
     _fields_ = [("n_beams", C.c_int32), ("minimum_angle", C.c_double), ("angular_resolution", C.c_double),
-                ("minimum_range", C.c_double), ("maximum_range", C.c_double), ("range_threshold", C.c_double)]
+                ("minimum_range", C.c_double), ("maximum_range", C.c_double), ("range_threshold", C.c_double),
+                ("offset_x", C.c_double), ("offset_y", C.c_double), ("offset_heading", C.c_double)]
 
 
 class KhMapperParams(C.Structure):

@@ -17,7 +17,7 @@
 // then moves every pose, so what was computed for later chains is discarded and the enumeration resumes behind the
 // accepted chain with the new poses (closures are rare, the speculation almost always commits).
 //
-// Scope: one laser with zero mount offset, mapping mode (no localization buffer, no scan removal).
+// Scope: one laser (mounted anywhere on the robot: kh_laser::offset_*, Karto.h:5566-5586), mapping mode (no localization buffer).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -139,19 +139,45 @@ struct MScan
   static constexpr int kMaxDeviceSlots = 16;
   double * d_points[kMaxDeviceSlots] = {};       // one copy per distinct device of the mapper (slot 0 = the mapper's own device)
   uint16_t d_fresh = 0;                          // bit k: the copy in slot k holds the current points
-  Pose sensor_pose() const {Pose p = corrected; p.h = normalize_angle(corrected.h); return p;}
+  Pose sensor;                                   // GetSensorAt(corrected), refreshed by update_scan (every write of `corrected` is followed by one)
+  Pose sensor_pose() const {return sensor;}
   MScan() = default;
   MScan(const MScan &) = delete;
   MScan & operator=(const MScan &) = delete;
   // d_points is a slot of the mapper's device slabs (take_slot / remove_node / kh_mapper_destroy), not owned here
 };
 
-struct Laser {int32_t n = 0; double min_angle = 0, ang_res = 0, min_range = 0, max_range = 0, range_threshold = 0;};
+struct Laser
+{
+  int32_t n = 0;
+  double min_angle = 0, ang_res = 0, min_range = 0, max_range = 0, range_threshold = 0;
+  Pose offset;                                   // LaserRangeFinder::GetOffsetPose: the sensor in the robot's frame
+};
+
+// LocalizedRangeScan::GetSensorAt (Karto.h:5566-5569): Transform(robot pose).TransformPose(offset pose)
+Pose sensor_at(const Laser & L, const Pose & robot) {return transform_pose(Pose(), robot, L.offset);}
+
+// LocalizedRangeScan::GetCorrectedAt (Karto.h:5576-5588): the robot pose that puts the sensor at `sensor`
+Pose corrected_at(const Laser & L, const Pose & sensor)
+{
+  const double offset_length = std::sqrt(L.offset.x * L.offset.x + L.offset.y * L.offset.y);       // Vector2::Length
+  const double offset_heading = L.offset.h;
+  const double angle_offset = std::atan2(L.offset.y, L.offset.x);
+  const double heading = normalize_angle(sensor.h);
+  double sin_w, cos_w;
+  ref_sincos(heading + angle_offset - offset_heading, &sin_w, &cos_w);
+  Pose robot;                                      // Pose2::operator-: positions subtract, the heading difference is normalised
+  robot.x = sensor.x - offset_length * cos_w;
+  robot.y = sensor.y - offset_length * sin_w;
+  robot.h = normalize_angle(sensor.h - offset_heading);
+  return robot;
+}
 
 // LocalizedRangeScan::Update, Karto.h:5644-5704
 void update_scan(MScan & s, const Laser & L)
 {
-  const Pose sp = s.sensor_pose();
+  s.sensor = sensor_at(L, s.corrected);
+  const Pose sp = s.sensor;
   s.points.resize(2 * static_cast<size_t>(L.n));
   s.d_fresh = 0;
   s.filtered.clear();
@@ -313,8 +339,8 @@ int sync_graph(kh_mapper * m)
 // SetSensorPose (Karto.h:5552-5557): corrected = GetCorrectedAt(pose), then Update
 void set_sensor_pose(kh_mapper * m, MScan & s, const double pose[3])
 {
-  // GetCorrectedAt: sPose - worldSensorOffset with a zero offset: position unchanged, NormalizeAngle(heading - 0)
-  s.corrected.x = pose[0]; s.corrected.y = pose[1]; s.corrected.h = normalize_angle(pose[2]);
+  Pose sensor; sensor.x = pose[0]; sensor.y = pose[1]; sensor.h = pose[2];
+  s.corrected = corrected_at(m->laser, sensor);
   update_scan(s, m->laser);
   if (s.id < 0) {return;}               // not in the graph yet (the match of a new scan): AddScan appends it where it stands
   if (!m->graph_dirty && s.id < static_cast<int32_t>(m->compact_of.size()) && m->compact_of[s.id] >= 0) {
@@ -339,7 +365,9 @@ int link_scans(kh_mapper * m, int32_t from, int32_t to, const double mean[3], co
   // LinkInfo(pFromScan->GetCorrectedPose(), pToScan->GetCorrectedAt(rMean), rCovariance)
   const MScan & f = *m->scans[from];
   const double pose1[3] = {f.corrected.x, f.corrected.y, f.corrected.h};
-  const double pose2[3] = {mean[0], mean[1], normalize_angle(mean[2])};
+  Pose mean_sensor; mean_sensor.x = mean[0]; mean_sensor.y = mean[1]; mean_sensor.h = mean[2];
+  const Pose to_robot = corrected_at(m->laser, mean_sensor);
+  const double pose2[3] = {to_robot.x, to_robot.y, to_robot.h};
   double diff[3], cov_out[9];
   int rc = kh_link_info(pose1, pose2, cov, diff, cov_out);
   if (rc) {return rc;}
@@ -520,7 +548,8 @@ int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
     for (int32_t c : passing) {
       std::unique_ptr<MScan> t(new MScan());
       t->ranges = scan.ranges; t->corrected = scan.corrected;
-      t->corrected.x = coarse[c].mean[0]; t->corrected.y = coarse[c].mean[1]; t->corrected.h = normalize_angle(coarse[c].mean[2]);
+      Pose best; best.x = coarse[c].mean[0]; best.y = coarse[c].mean[1]; best.h = coarse[c].mean[2];
+      t->corrected = corrected_at(m->laser, best);                 // tmpScan.SetSensorPose(bestPose), Mapper.cpp:1533
       update_scan(*t, m->laser);
       fine_queries.push_back(as_kh_scan(*t));
       fine_chains.push_back(chains[c]);
@@ -670,6 +699,7 @@ int kh_mapper_create_on_devices(const kh_mapper_params * params, const kh_laser 
   m->p = *params; m->device = devices[0]; m->max_candidates = max_candidates;
   m->laser.n = laser->n_beams; m->laser.min_angle = laser->minimum_angle; m->laser.ang_res = laser->angular_resolution;
   m->laser.min_range = laser->minimum_range; m->laser.max_range = laser->maximum_range; m->laser.range_threshold = laser->range_threshold;
+  m->laser.offset.x = laser->offset_x; m->laser.offset.y = laser->offset_y; m->laser.offset.h = laser->offset_heading;
   std::memset(&m->stats, 0, sizeof(m->stats));
   auto fail = [&](int rc) {kh_mapper_destroy(m.release()); return rc;};
   // scan copies: one slot per DISTINCT device (members that share a device share the copies)
@@ -759,13 +789,14 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
   if (last) {
     bool moved = false;
     if (scan->time - last->time >= m->p.minimum_time_interval) {moved = true;}
+    // the scanner's pose for the two odometric poses (GetSensorAt, :3123-3124)
+    const Pose last_scanner = sensor_at(m->laser, last->odometric), scanner = sensor_at(m->laser, scan->odometric);
     if (!moved) {
-      // GetSensorAt(odometric pose) with a zero mount offset: the pose with its heading normalised
-      const double deltaHeading = normalize_angle(normalize_angle(scan->odometric.h) - normalize_angle(last->odometric.h));
+      const double deltaHeading = normalize_angle(scanner.h - last_scanner.h);
       if (std::fabs(deltaHeading) >= m->p.minimum_travel_heading) {moved = true;}
     }
     if (!moved) {
-      const double dx = last->odometric.x - scan->odometric.x, dy = last->odometric.y - scan->odometric.y;
+      const double dx = last_scanner.x - scanner.x, dy = last_scanner.y - scanner.y;
       if (dx * dx + dy * dy >= m->p.minimum_travel_distance * m->p.minimum_travel_distance - kTolerance) {moved = true;}
     }
     if (!moved) {return KH_OK;}

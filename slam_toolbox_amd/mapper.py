@@ -31,7 +31,9 @@ class Mapper:
                 setattr(p, k, v)
             else:
                 raise KeyError(k)
-        L = capi.KhLaser(laser.n_beams, laser.min_angle, laser.ang_res, laser.min_range, laser.max_range, laser.range_threshold)
+        off = tuple(getattr(laser, "offset", (0.0, 0.0, 0.0)))      # where the sensor sits on the robot (x, y, heading)
+        L = capi.KhLaser(laser.n_beams, laser.min_angle, laser.ang_res, laser.min_range, laser.max_range, laser.range_threshold,
+                         off[0], off[1], off[2])
         self._h = C.c_void_p()
         devs = np.asarray([device] if devices is None else list(devices), dtype=np.int32)
         capi.check(capi.lib().kh_mapper_create_on_devices(C.byref(p), C.byref(L), devs, len(devs), max_candidates, C.byref(self._h)),

@@ -31,6 +31,7 @@ class Laser:
     min_range: float = MIN_RANGE
     max_range: float = MAX_RANGE
     range_threshold: float = RANGE_THRESHOLD
+    offset: tuple = (0.0, 0.0, 0.0)        # LaserRangeFinder::GetOffsetPose: the sensor on the robot (x, y, heading)
 
 
 def _rect(x0, y0, x1, y1):

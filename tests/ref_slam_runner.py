@@ -1,6 +1,7 @@
 """Helper process of tests/test_dropin_mapper_gpu.py: runs the synthetic scan queue through the reference's own
 karto::Mapper in ONE of the oracle/_ref builds (each build carries its own copy of the karto singletons, so each
 run gets a process of its own).  usage: ref_slam_runner.py <lib.so> <n_scans> <loop_search_distance> <out_prefix> [sweep|laps]
+[removal schedule or ""] [laser mount offset "x,y,heading"]
 sweep = one boustrophedon pass through the aisles (4 m apart: needs a 5 m loop search distance to close anything);
 laps = the same two aisles driven lap after lap (closes loops with the shipped 3.0 m, offline.yaml:40)."""
 import ctypes as C
@@ -27,6 +28,9 @@ def main():
     laser = synth.Laser()
     n_beams = lib.ref_init_laser(laser.min_angle, laser.max_angle, laser.ang_res, laser.min_range, laser.max_range,
                                  laser.range_threshold)
+    if len(sys.argv) > 7 and sys.argv[7]:
+        lib.ref_set_laser_offset.argtypes = [C.c_double] * 3
+        assert lib.ref_set_laser_offset(*[float(v) for v in sys.argv[7].split(",")]) == 0
     lib.ref_set_threads(min(32, os.cpu_count() or 1))
     world = synth.make_world(12345)
     truth, odom = synth.trajectory_laps(n_scans) if kind == "laps" else synth.trajectory(n_scans)

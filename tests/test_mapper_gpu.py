@@ -67,6 +67,37 @@ def test_mapper_front_end_equals_the_reference_mapper(kartohip_lib, tmp_path, n_
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libkarto_ref_slam.so not built (needs /root/reference)")
+def test_laser_mounted_off_the_robot_centre(kartohip_lib, tmp_path):
+    """A laser that does not sit at the robot's centre (LaserRangeFinder::SetOffsetPose): sensor pose = GetSensorAt(corrected
+    pose), corrected pose = GetCorrectedAt(sensor pose) (Karto.h:5566-5588) in HasMovedEnough, the matches, the links, the
+    temporary scan of TryCloseLoop and CorrectPoses.  Same queue through the reference Mapper with the same mount: the solver
+    logs and the final poses must be identical."""
+    from slam_toolbox_amd.mapper import Mapper
+    n_scans, loop_dist, kind, mount = 500, 3.0, "laps", (0.22, -0.08, 0.15)
+    runner = os.path.join(ROOT, "tests", "ref_slam_runner.py")
+    prefix = str(tmp_path / "ref")
+    subprocess.run([sys.executable, runner, LIB, str(n_scans), str(loop_dist), prefix, kind, "", ",".join(repr(v) for v in mount)],
+                   check=True, timeout=900)
+    ref = np.load(prefix + ".npz")
+    ref_log = _lines(prefix + ".log")
+    ranges, odom = _queue(n_scans, kind)
+    log = str(tmp_path / "hip.log")
+    m = Mapper(synth.Laser(offset=mount), loop_search_maximum_distance=loop_dist, log_path=log)
+    accepted = sum(int(m.Process(ranges[i], odom[i], 0.1 * i)[0]) for i in range(n_scans))
+    poses = m.poses()
+    st = m.stats()
+    m.set_log(None)
+    hip_log = _lines(log)
+    m.close()
+    print(f"mounted at {mount}: accepted {accepted} (reference {int(ref['accepted'])}), {st['loop_closures']} closures")
+    assert accepted == int(ref["accepted"])
+    for k, (a, b) in enumerate(zip(ref_log, hip_log)):
+        assert a == b, f"solver-call logs diverge at line {k}:\n  reference: {a}\n  mapper   : {b}"
+    assert len(ref_log) == len(hip_log)
+    assert np.array_equal(ref["poses"][:, 1:], poses), "final corrected poses differ"
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libkarto_ref_slam.so not built (needs /root/reference)")
 def test_node_removal_equals_the_reference_graph_edits(kartohip_lib, tmp_path):
     """Lifelong mode's graph edits without its policy: the same nodes are removed at the same points of the queue from the
     reference Mapper (Mapper::RemoveNodeFromGraph + MapperSensorManager::RemoveScan, the way
