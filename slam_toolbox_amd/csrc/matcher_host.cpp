@@ -1361,8 +1361,9 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_load_counter), 8)) != hipSuccess) {return fail(e, "hipMalloc counter");}
   if ((e = hipMemset(m->d_load_counter, 0, 8)) != hipSuccess) {return fail(e, "hipMemset counter");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
-  // zero rows either side: as many as the search space is high, so that any search window that touches the array is inside
-  m->pad_rows = m->roi_h + 8;
+  // zero rows either side: as many as the SEARCH SPACE is high (m->side cells: 61 / 161 / 51 for the C2 / L / S presets -- not the
+  // grid's region of interest, which also spans the range threshold), so that any search window that touches the array is inside
+  m->pad_rows = m->side + 8;
   m->grid_pad = align_up(static_cast<size_t>(m->pad_rows) * m->ws, 256) + kGridPad;
   m->pitch2 = static_cast<int32_t>(align_up(static_cast<size_t>(m->ws), 128));
   {
