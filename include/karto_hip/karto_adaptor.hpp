@@ -14,6 +14,8 @@
 #ifndef KARTO_HIP__KARTO_ADAPTOR_HPP_
 #define KARTO_HIP__KARTO_ADAPTOR_HPP_
 
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -66,7 +68,25 @@ inline T stored_parameter(karto::Mapper * pMapper, const char * name)
 class HipScanMatcher
 {
 public:
-  virtual ~HipScanMatcher() {kh_matcher_destroy(m_pHandle);}
+  virtual ~HipScanMatcher()
+  {
+    for (auto & kv : m_Resident) {kh_device_free(kv.second.device_points);}
+    kh_matcher_destroy(m_pHandle);
+  }
+
+  // Base scans stay resident on the device between calls (default on): a processed scan serves as a base scan of dozens of
+  // consecutive matches (the running-scan window slides by one per scan), so its 17 KB of point readings are uploaded when it
+  // first appears and again only after its pose has moved (CorrectPoses), instead of with every MatchScan.  The copies are
+  // keyed by the scan's unique id and checked against its sensor pose and reading count; at most `capacity` scans are kept
+  // (least recently used go first).  0 switches the cache off (every call uploads what it reads, like the round-2 adaptor).
+  void SetResidentScanCapacity(size_t capacity)
+  {
+    m_ResidentCapacity = capacity;
+    if (capacity == 0) {
+      for (auto & kv : m_Resident) {kh_device_free(kv.second.device_points);}
+      m_Resident.clear();
+    }
+  }
 
   static HipScanMatcher * Create(
     karto::Mapper * pMapper, kt_double searchSize, kt_double resolution,
@@ -79,6 +99,7 @@ public:
     if (rc != KH_OK) {throw std::runtime_error(std::string("karto_hip: ") + kh_last_error());}
     HipScanMatcher * m = new HipScanMatcher();
     m->m_pHandle = h;
+    m->m_Device = device;
     m->m_pMapper = pMapper;
     m->m_Resolution = resolution; m->m_SmearDeviation = smearDeviation;
     return m;
@@ -95,6 +116,7 @@ public:
     std::vector<kh_scan> base;
     const kh_scan query = detail::to_scan(pScan, store[0]);
     Collect(rBaseScans, base, store);
+    MakeResident(rBaseScans, base);
     double mean[3], cov[9], response = 0.0;
     const int rc = kh_matcher_match(
       m_pHandle, &query, base.data(), static_cast<int32_t>(base.size()), doPenalize, doRefineMatch, mean, cov, &response);
@@ -226,6 +248,71 @@ private:
       base.push_back(detail::to_scan(kv.second, store.back()));
     }
   }
+  // device copies of the base scans' readings (kh_scan::device_points_xy), see SetResidentScanCapacity
+  struct ResidentScan
+  {
+    double pose[3] = {0, 0, 0};
+    int32_t n = 0;
+    void * device_points = nullptr;
+    uint64_t used = 0;
+  };
+  void MakeResident(karto::LocalizedRangeScan * pScan, kh_scan & s)
+  {
+    if (m_ResidentCapacity == 0 || pScan == NULL || s.n <= 0 || pScan->GetUniqueId() < 0) {return;}
+    ResidentScan & r = m_Resident[pScan->GetUniqueId()];
+    const int64_t bytes = static_cast<int64_t>(sizeof(double)) * 2 * s.n;
+    const bool same = r.device_points != nullptr && r.n == s.n && r.pose[0] == s.sensor_pose[0] && r.pose[1] == s.sensor_pose[1] &&
+      r.pose[2] == s.sensor_pose[2];
+    if (!same) {
+      if (r.device_points != nullptr && r.n != s.n) {kh_device_free(r.device_points); r.device_points = nullptr;}
+      if (r.device_points == nullptr && kh_device_malloc(m_Device, bytes, &r.device_points) != KH_OK) {
+        m_Resident.erase(pScan->GetUniqueId());
+        return;                                      // no room: this call uploads the scan itself
+      }
+      if (kh_device_upload(r.device_points, s.points_xy, bytes) != KH_OK) {
+        kh_device_free(r.device_points);
+        m_Resident.erase(pScan->GetUniqueId());
+        return;
+      }
+      r.n = s.n;
+      r.pose[0] = s.sensor_pose[0]; r.pose[1] = s.sensor_pose[1]; r.pose[2] = s.sensor_pose[2];
+    }
+    r.used = ++m_ResidentClock;
+    s.device_points_xy = static_cast<const double *>(r.device_points);
+  }
+  void MakeResident(const karto::LocalizedRangeScanVector & rScans, std::vector<kh_scan> & base)
+  {
+    size_t k = 0;
+    for (karto::LocalizedRangeScan * p : rScans) {
+      if (p == NULL) {continue;}
+      MakeResident(p, base[k++]);
+    }
+    Trim();
+  }
+  void MakeResident(const karto::LocalizedRangeScanMap & rScans, std::vector<kh_scan> & base)
+  {
+    size_t k = 0;
+    for (const auto & kv : rScans) {
+      if (kv.second == NULL) {continue;}
+      MakeResident(kv.second, base[k++]);
+    }
+    Trim();
+  }
+  void Trim()
+  {
+    if (m_Resident.size() <= m_ResidentCapacity) {return;}
+    // drop the least recently used half (never what this call just touched: those carry the newest stamps)
+    std::vector<std::pair<uint64_t, int32_t>> order;
+    order.reserve(m_Resident.size());
+    for (const auto & kv : m_Resident) {order.emplace_back(kv.second.used, kv.first);}
+    std::sort(order.begin(), order.end());
+    for (size_t i = 0; i < order.size() / 2; ++i) {
+      auto it = m_Resident.find(order[i].second);
+      kh_device_free(it->second.device_points);
+      m_Resident.erase(it);
+    }
+  }
+
   static void Check(int rc)
   {
     if (rc == KH_ERR_SEARCH) {throw std::runtime_error("Mapper FATAL ERROR - Unable to find best position");}
@@ -233,6 +320,10 @@ private:
   }
 
   kh_matcher * m_pHandle;
+  int m_Device = 0;
+  std::unordered_map<int32_t, ResidentScan> m_Resident;
+  size_t m_ResidentCapacity = 4096;                  // 4096 scans x 17 KB = 70 MB
+  uint64_t m_ResidentClock = 0;
   karto::Mapper * m_pMapper;
   karto::LocalizedRangeScan * m_pLastScan;
   kt_double m_Resolution, m_SmearDeviation;
