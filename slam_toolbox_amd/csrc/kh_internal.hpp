@@ -148,7 +148,6 @@ struct CorrJob
   int32_t pad;               // zero bytes in front of and behind the grid (and, row for row, its copies) that windows may read: a
                              // pose whose index falls off the array adds nothing in the reference (Mapper.cpp:1192-1197) and a
                              // zero here -- beams whose window leaves the array by less than this stay on the fast lists
-  int32_t dbg_skip;          // timing experiments only (KH_K3_SKIP): bit 0 = no slow path, bit 1 = no probs atomics, bit 2 = no walk
   int32_t tile_px;           // poses per row of a scoring tile: 61, or 31 for sx == 2 read from the grid itself
   unsigned long long * load_counter;   // handle-wide tally of the row loads K3 will issue for the fast lists K2 builds (wave-level
                                        // dword-load instructions, 256 B each): the L1 side of the roofline; nullptr = not counted

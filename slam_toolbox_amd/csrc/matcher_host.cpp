@@ -922,8 +922,6 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     }
     job->pad = std::max(0, m->pad_rows * m->ws - 512); job->pad_rows = m->pad_rows;
     job->load_counter = m->profiling ? m->d_load_counter : nullptr;
-    static const int dbg_skip = std::getenv("KH_K3_SKIP") ? std::atoi(std::getenv("KH_K3_SKIP")) : 0;
-    job->dbg_skip = dbg_skip;
   });
   if (timing) {
     const CorrJob * j0 = reinterpret_cast<const CorrJob *>(B.h_stage);

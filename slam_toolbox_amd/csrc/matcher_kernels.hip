@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
   __syncthreads();
 
   const int P = job.n_points;
-  const int n_slow = (live && !(job.dbg_skip & 1)) ? job.counts[kCountsPerAngle * a + kClasses] : 0;
+  const int n_slow = live ? job.counts[kCountsPerAngle * a + kClasses] : 0;
 
   int32_t acc[RY][NB];
 #pragma unroll
@@ -1538,7 +1538,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
       }
     }
   };
-  if (live && !(job.dbg_skip & 4)) {
+  if (live) {
     // the beams whose window lies inside a grid row read the re-pitched copy K2 chose for them (every row segment in one
     // cache line), the few that wrap around the row end read the grid itself with its linear-index semantics
     if (MF) {
@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
     const double response = pose_response(job, sum, a, yi, xi);
     if (job.write_resp) {job.resp[o] = response;}
     best = response > best ? response : best;
-    if (job.coarse && response > 0.0 && !(job.dbg_skip & 2)) {
+    if (job.coarse && response > 0.0) {
       atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
     }
   }
@@ -2142,7 +2142,7 @@ __global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t
     const double response = pose_response(job, sum, a, yi, xi);
     if (job.write_resp) {job.resp[o] = response;}
     best = response > best ? response : best;
-    if (job.coarse && response > 0.0 && !(job.dbg_skip & 2)) {
+    if (job.coarse && response > 0.0) {
       atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
     }
   }
