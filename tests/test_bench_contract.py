@@ -47,7 +47,7 @@ def test_line_has_the_contract_keys():
 def test_kernel_time_agrees_with_the_rocprof_summary():
     d = _line()
     with open(os.path.join(PROF, f"{ROUND}_bench_kernel_stats.csv")) as f:
-        rows = [r for r in csv.DictReader(f) if "k_score<1, 8, 1>" in r["Name"]]
+        rows = [r for r in csv.DictReader(f) if "k_score<1, 8, 1" in r["Name"]]
     assert len(rows) == 1
     avg_ms = float(rows[0]["AverageNs"]) * 1e-6
     assert abs(avg_ms - d["roofline"]["avg_launch_ms"]) / avg_ms < 0.05
@@ -57,3 +57,36 @@ def test_kernel_time_agrees_with_the_rocprof_summary():
     # traffic = PMC HBM bytes per launch, scaled to the matches one launch of the run scored
     want = p["hbm_bytes_per_launch"] / p["matches_per_launch"] * d["roofline"]["matches_per_launch"]
     assert abs(d["roofline"]["traffic"] - want) / want < 0.02
+
+
+def _recorded(name):
+    with open(os.path.join(PROF, name)) as f:
+        return json.load(f)
+
+
+def _traffic(doc, prefixes, units):
+    total = sum(d["hbm_bytes_per_launch"] * d["calls"] for k, d in doc["kernels"].items()
+                if any(k.startswith(p) for p in prefixes) and "hbm_bytes_per_launch" in d and d.get("calls"))
+    return total / units
+
+
+def test_loop_and_solver_rooflines_carry_the_recorded_traffic():
+    """`loop_rooflines` / `solve_rooflines` of the committed line: `traffic` = HBM bytes from the committed PMC summaries
+    (tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate passes, (2 * FETCH + WRITE) * 1024), per loop batch and per
+    numeric factorisation; the summaries are re-collected after the line, so a few per cent of run-to-run spread are allowed."""
+    if ROUND in ("r1", "r2"):
+        return
+    d = _line()
+    loop = _recorded(f"{ROUND}_loop_pmc.json")
+    batches = loop["kernels"]["k_raster_scan"]["calls"] / 2.0
+    want = _traffic(loop, ("k_raster_", "k_find_valid", "k_cell_", "k_active_set", "k_repitch"), batches)
+    got = d["loop_rooflines"][0]["traffic"]
+    assert got is not None and abs(got - want) / want < 0.03
+    assert 0.0 < d["loop_rooflines"][0]["frac"] <= 1.0
+    spa = _recorded(f"{ROUND}_spa_pmc.json")
+    want = _traffic(spa, ("k_potrf", "k_trsm", "k_syrk", "k_extend_add"), spa["factorizations"])
+    k6 = d["solve_rooflines"][0]
+    assert k6["traffic"] is not None and abs(k6["traffic"] - want) / want < 0.05
+    assert 0.0 < k6["frac"] <= 1.0 and k6["unit"] == "TFLOP/s"
+    # flops = 2 x multiply-adds of the symbolic analysis, per factorisation
+    assert abs(k6["flops_per_factorization"] - 2.0 * k6["multiply_adds_per_factorization"]) < 1.0
