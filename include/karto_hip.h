@@ -203,14 +203,15 @@ KH_API int kh_matcher_read_lookup(kh_matcher * m, int32_t slot, int32_t * n_angl
 KH_API int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, int32_t * ny,
                                   int32_t * na, int32_t * out_sums, double * out_responses);
 /* bit 0: keep the penalised response volume of every CorrelateScan on the device so that
- * kh_matcher_read_volume can return it (parity tests); bit 1: score through the experimental
- * LDS-staged kernel where the search shape allows it (same results, currently slower); bit 2: dense scoring --
+ * kh_matcher_read_volume can return it (parity tests); bit 1: score EVERY search the LDS-staged kernels can take through
+ * them (by default only the large ones: windows of at most 61 bytes x 64 rows with >= 1e8 lookups per search, where they
+ * were measured faster); bit 6: none (the windowed kernel scores everything); bit 2: dense scoring --
  * do not leave out the beams whose whole search window lies in grid blocks no scan point was stamped into
  * (they add 0 to every pose, so the results are identical either way; for measurements); bit 3: send every batch
  * of >= 128 searches through the chunked pipeline, which otherwise only large searches take (tests); bit 4: score from the
- * grid itself instead of its re-pitched copies (same results; for measurements); bit 5: take the byte sums of one-cell
- * searches on the matrix cores (v_mfma_i32_16x16x32_i8) instead of the vector ALU (same results, same speed within 5 %:
- * DESIGN.md section 4); all off by default */
+ * grid itself instead of its re-pitched copies (same results; for measurements); bit 5: the windowed kernel takes the byte
+ * sums of one-cell searches on the matrix cores (v_mfma_i32_16x16x32_i8) instead of the vector ALU (same results, same speed
+ * within 5 %: DESIGN.md section 4).  Results are identical under every combination. */
 KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t flags);
 /* HIP stream all kernels of this handle are launched on (hipStream_t as void*), so the caller can
  * bracket launches with HIP events on the right stream */

@@ -16,14 +16,14 @@ constexpr int32_t kTileSpan = 61;             // bytes of it that hold poses wha
 constexpr int32_t kClasses = 4;               // alignment classes of a beam offset: (base0 + offset) & 3
 constexpr int32_t kBlockShift = 5;             // occupancy block map: one byte per 32 x 32 grid cells ("a stamp touched this block")
 constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per class, [4] = slow beams
-// LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; beams are taken in slots
-// of kSlotBeams consecutive beams, each slot split into sub-chunks whose window union fits the LDS budget
+// LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; the beams are cut into chunks of
+// consecutive beams whose windows' union fits one LDS region (built by kLdsRanges waves, a quarter of the beams each)
 constexpr int32_t kGroupAngles = 2;
-constexpr int32_t kSlotBeams = 32;
-constexpr int32_t kChunkWords = 8;            // int32 words per sub-chunk descriptor
-constexpr int32_t kLdsPitch = 256;            // bytes per staged grid row: one LDS-DMA wave instruction = 4 rows
-constexpr int32_t kLdsRows = 240;             // rows of one staged region
-constexpr int32_t kLdsRegionBytes = kLdsRows * kLdsPitch;   // 60 KB, double buffered
+constexpr int32_t kLdsRanges = 4;
+constexpr int32_t kChunkWords = 8;            // int32 words per chunk descriptor
+constexpr int32_t kLdsPitch = 192;            // bytes per staged grid row (64 mod 128: conflict-free ds_read_b32 of two rows)
+constexpr int32_t kLdsRows = 196;             // rows of one staged region
+constexpr int32_t kLdsRegionBytes = 37 * 1024;   // >= kLdsRows * kLdsPitch, a multiple of the 1 KB an LDS-DMA instruction fills; double buffered
 
 // One rasterisation job (ScanMatcher::AddScans, Mapper.cpp:1032-1105) -- device visible.
 // The base scans' UNFILTERED point readings live once per distinct scan in the batch's arena; a job names its scans
@@ -116,8 +116,8 @@ struct CorrJob
   int32_t lds_path;
   int32_t sy_cells;          // grid rows per lattice step in y (sy_ws / ws)
   int32_t * rel;             // na*P: byte offset of the beam's window start inside its sub-chunk's LDS region, or -1
-  int32_t * chunks;          // [groups][slots][kSlotBeams][kChunkWords]: sub-chunk descriptors
-  int32_t * chunk_counts;    // [groups][slots]: sub-chunks of the slot
+  int32_t * chunks;          // [groups][kLdsRanges][ceil(P / kLdsRanges)][kChunkWords]: chunk descriptors
+  int32_t * chunk_counts;    // [groups][kLdsRanges]: chunks of the beam range
   // empty-window skipping: a beam whose whole window lies in blocks no stamp touched adds 0 to every pose
   const uint32_t * blockmap; // see RasterJob; nullptr = do not skip
   int32_t bm_w, bm_h;

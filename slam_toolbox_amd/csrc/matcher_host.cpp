@@ -195,7 +195,8 @@ struct kh_matcher
   int32_t pitch_d = 0, copy_q = 0; // column-decimated copies: row pitch and bytes of one of the four; copy_q 0 = too large for int32 offsets
   bool dual_copy = true;           // kh_matcher_set_debug bit 4 switches the re-pitched copies off (measurements)
   bool mfma_score = std::getenv("KH_K3_MFMA") != nullptr;   // kh_matcher_set_debug bit 5: byte sums on the matrix cores (k_score<.., MF>)
-  bool lds_score = false;          // experimental LDS-staged scoring path (kh_matcher_set_debug bit 1)
+  bool lds_score = false;          // kh_matcher_set_debug bit 1: LDS-staged scoring path for every search it can take (default: the large ones)
+  bool windowed_score = false;     // kh_matcher_set_debug bit 6: never (the windowed kernel k_score scores everything)
   // profiling
   bool profiling = false;
   double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0, score_jobs = 0;
@@ -751,10 +752,11 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
       }
     }
     {
+      // chunk descriptors of the LDS-staged path: at most one per beam, kept per (angle pair, beam range)
       const size_t groups = (static_cast<size_t>(c.na) + kGroupAngles - 1) / kGroupAngles;
-      const size_t slots = (static_cast<size_t>(c.P) + kSlotBeams - 1) / kSlotBeams;
-      rc = ensure_device(s.d_chunks, s.cap_chunks, groups * slots * kSlotBeams * kChunkWords, m->stream); if (rc) {return rc;}
-      rc = ensure_device(s.d_chunk_counts, s.cap_chunk_counts, groups * slots, m->stream); if (rc) {return rc;}
+      const size_t range_len = (static_cast<size_t>(c.P) + kLdsRanges - 1) / kLdsRanges;
+      rc = ensure_device(s.d_chunks, s.cap_chunks, groups * kLdsRanges * range_len * kChunkWords, m->stream); if (rc) {return rc;}
+      rc = ensure_device(s.d_chunk_counts, s.cap_chunk_counts, groups * kLdsRanges, m->stream); if (rc) {return rc;}
     }
     const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
     rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
@@ -765,9 +767,13 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
 
   }
   std::vector<int32_t> job_sx(n, 1), job_ry(n, 1), job_tiles(n, 1), job_lds(n, 0);
-  // measured slower than the windowed kernel (VALU bound: 7 ops per dword + staging): opt-in
-  static const bool lds_env = std::getenv("KH_LDS_SCORE") != nullptr;
-  const bool lds_enabled = lds_env || m->lds_score;
+  // LDS-staged scoring (k_offsets_lds / k_score_lds): by default for the searches it was measured faster on -- windows of at most
+  // 61 bytes x 64 rows with >= 1e8 lookups per search (the config-2 CorrelateScan: 0.47 against 0.60 ms per 51 matches); smaller
+  // searches keep the windowed kernel, whose fixed costs per launch are lower.  KH_LDS_SCORE=1 / kh_matcher_set_debug bit 1:
+  // every search the path can take; KH_LDS_SCORE=0 / bit 6: none.
+  static const int lds_env = std::getenv("KH_LDS_SCORE") ? std::atoi(std::getenv("KH_LDS_SCORE")) : -1;
+  const bool lds_never = lds_env == 0 || m->windowed_score;
+  const bool lds_always = !lds_never && (lds_env > 0 || m->lds_score);
   HostPool::instance().run(n, [&](size_t i) {
     CorrReq & q = reqs[i];
     CorrHost & c = ctx[i];
@@ -886,8 +892,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->ry = this_ry; job->tile_px = px; job->dec = dec ? 1 : 0;
     job_sx[i] = dec ? 1 : this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
     // LDS-staged scoring: linear lattice whose window fits 64 bytes x 64 rows
-    const bool lds_ok = lds_enabled && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
-      sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && (c.ny - 1) * sx + 1 <= kLdsRows;
+    const bool lds_wanted = lds_always || (!lds_never && static_cast<double>(c.nx) * c.ny * c.na * c.P >= 1e8);
+    const bool lds_ok = lds_wanted && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
+      sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && 63 * sx + 1 <= kLdsRows;
     job_lds[i] = lds_ok ? 1 : 0;
     job->lds_path = job_lds[i]; job->sy_cells = sy_ws / m->ws;
     job->rel = s.d_fast; job->chunks = s.d_chunks; job->chunk_counts = s.d_chunk_counts;
@@ -940,10 +947,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   int32_t tile_pairs = 0;
   for (size_t i = 0; i < n; ++i) {
     CorrJob * job = reinterpret_cast<CorrJob *>(B.h_stage + stride * i);
-    if (use_lds) {job->tile_best = nullptr;}            // the LDS-staged kernel does not report tile bests
+    if (use_lds) {
+      // the LDS-staged kernel scores an angle's whole lattice in one workgroup: one scoring tile per angle for K4
+      job->tiles_x = 1; job->tiles_y = 1; job->ry = 16; job->tile_px = kTileSpan;
+    }
     tile_pairs = std::max(tile_pairs, job->na * job->tiles_x * job->tiles_y);
   }
-  if (use_lds) {tile_pairs = 0;}
   B.tile_pairs = tile_pairs;
 
   // ---- 2. upload, launch, download ----
@@ -960,25 +969,31 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   } else {
     launch_offsets(B.d_stage, stride, static_cast<int32_t>(n), max_na, cs);
   }
-  if (overlap) {
+  // The scoring kernel of a chunk goes on the chunk's own side stream as well (KH_K3_MAIN=1: on the handle's main stream, one
+  // scoring kernel after the other, as through round 3): the two staging sets then are two independent in-order queues, and the
+  // workgroups of chunk i + 1 fill the compute units the tail of chunk i leaves idle (2099 workgroups on 512 slots are 4.1
+  // rounds: a fifth of the kernel's time ran at a tenth of the occupancy).
+  static const bool k3_main = std::getenv("KH_K3_MAIN") != nullptr;
+  hipStream_t ks = (overlap && !k3_main) ? cs : m->stream;
+  if (overlap && ks != cs) {
     KH_HIP(hipEventRecord(B.up, cs));
-    KH_HIP(hipStreamWaitEvent(m->stream, B.up, 0));
+    KH_HIP(hipStreamWaitEvent(ks, B.up, 0));
   }
-  if (m->profiling) {KH_HIP(hipEventRecord(B.ev[0], m->stream));}
+  if (m->profiling) {KH_HIP(hipEventRecord(B.ev[0], ks));}
   if (use_lds) {
-    launch_score_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, m->stream);
+    launch_score_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, ks);
   } else if (uniform_kernel) {
-    launch_score(B.d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, m->stream, m->mfma_score);
+    launch_score(B.d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, ks, m->mfma_score);
   } else {
     for (size_t i = 0; i < n; ++i) {
       const CorrJob * job = reinterpret_cast<const CorrJob *>(B.h_stage + stride * i);
       launch_score(B.d_stage + stride * i, stride, 1, job->tiles_x * job->tiles_y, job->na,
-        (job->linear && job->sx == 2 && !job->dec) ? 2 : 1, job->ry, m->stream, m->mfma_score);
+        (job->linear && job->sx == 2 && !job->dec) ? 2 : 1, job->ry, ks, m->mfma_score);
     }
   }
-  if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], m->stream));}
-  if (overlap) {
-    KH_HIP(hipEventRecord(B.kdone, m->stream));
+  if (m->profiling) {KH_HIP(hipEventRecord(B.ev[1], ks));}
+  if (overlap && ks != cs) {
+    KH_HIP(hipEventRecord(B.kdone, ks));
     KH_HIP(hipStreamWaitEvent(cs, B.kdone, 0));
   }
   launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, B.tile_pairs, cs);
@@ -1012,23 +1027,23 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     const CorrHost & c0 = ctx[0];
     const Slot & s0 = m->slots[c0.slot];
     const size_t groups = (static_cast<size_t>(c0.na) + kGroupAngles - 1) / kGroupAngles;
-    const size_t slots = (static_cast<size_t>(c0.P) + kSlotBeams - 1) / kSlotBeams;
-    std::vector<int32_t> cc(groups * slots), dd(groups * slots * kSlotBeams * kChunkWords);
+    const size_t range_len = (static_cast<size_t>(c0.P) + kLdsRanges - 1) / kLdsRanges;
+    std::vector<int32_t> cc(groups * kLdsRanges), dd(groups * kLdsRanges * range_len * kChunkWords);
     KH_HIP(hipMemcpy(cc.data(), s0.d_chunk_counts, cc.size() * 4, hipMemcpyDeviceToHost));
     KH_HIP(hipMemcpy(dd.data(), s0.d_chunks, dd.size() * 4, hipMemcpyDeviceToHost));
-    long total = 0, bytes = 0, beams = 0, maxb = 0;
-    for (size_t g = 0; g < groups; ++g) {
-      for (size_t sl = 0; sl < slots; ++sl) {
-        for (int32_t k = 0; k < cc[g * slots + sl]; ++k) {
-          const int32_t * d = dd.data() + ((g * slots + sl) * kSlotBeams + k) * kChunkWords;
-          ++total; bytes += static_cast<long>(d[3]) * kLdsPitch; beams += d[1] - d[0];
-          maxb = std::max<long>(maxb, static_cast<long>(d[3]) * kLdsPitch);
-        }
+    long total = 0, bytes = 0, windows = 0, maxb = 0, small = 0;
+    for (size_t g = 0; g < groups * kLdsRanges; ++g) {
+      for (int32_t k = 0; k < cc[g]; ++k) {
+        const int32_t * d = dd.data() + (g * range_len + k) * kChunkWords;
+        ++total; bytes += static_cast<long>(d[3]) * kLdsPitch; windows += d[6];
+        maxb = std::max<long>(maxb, static_cast<long>(d[3]) * kLdsPitch);
+        if (d[6] < 16) {++small;}
       }
     }
-    std::fprintf(stderr, "[kh lds] job 0: %zu groups x %zu slots, %ld sub-chunks (%.1f per group), mean region %.1f KB, max %.1f KB, mean beams %.1f\n",
-      groups, slots, total, static_cast<double>(total) / groups, bytes / 1024.0 / std::max(1l, total), maxb / 1024.0,
-      static_cast<double>(beams) / std::max(1l, total));
+    std::fprintf(stderr, "[kh lds] job 0: %zu angle pairs, %ld chunks (%.1f per pair, %ld with < 16 windows), mean region %.1f KB, max %.1f KB, "
+      "%.1f windows per chunk, %.0f staged bytes per window\n",
+      groups, total, static_cast<double>(total) / groups, small, bytes / 1024.0 / std::max(1l, total), maxb / 1024.0,
+      static_cast<double>(windows) / std::max(1l, total), static_cast<double>(bytes) / std::max(1l, windows));
   }
   if (m->profiling) {
     float ms = 0;
@@ -1183,7 +1198,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   // on the worker pool, the scoring kernel ~13 us).  Chunks of 64 keep the scoring launches at full efficiency;
   // splitting a batch of 32 into halves was measured slower than not splitting (0.85 against 0.76 ms), so batches
   // below 2 * kChunk are not split.  KH_PIPELINE=0 switches the chunking off.
-  constexpr size_t kChunk = 64;
+  static const size_t kChunk = std::getenv("KH_CHUNK") ? static_cast<size_t>(std::max(8, std::atoi(std::getenv("KH_CHUNK")))) : 64;
   static const bool pipeline = !(std::getenv("KH_PIPELINE") && std::atoi(std::getenv("KH_PIPELINE")) == 0);
   // ... and only searches whose scoring kernel dwarfs the hand-overs between the streams: a chunk of 64 config-2
   // searches scores for 0.85 ms, a chunk of loop-closure coarse searches (half the lookups, a quarter of the loads)
@@ -1204,7 +1219,7 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   // a shorter first and last chunk: the pipeline fills on the first (its preparation, upload and K2 are exposed) and drains
   // on the last (its K4, download and finalisation are); 32 measured 71.5 k config-2 matches/s against 69.6 k with
   // uniform chunks of 64 and 68.7 k with 16.  KH_CHUNK_EDGE=64 restores the uniform split.
-  static const size_t edge = std::getenv("KH_CHUNK_EDGE") ? static_cast<size_t>(std::max(8, std::min(64, std::atoi(std::getenv("KH_CHUNK_EDGE"))))) : 32;
+  static const size_t edge = std::getenv("KH_CHUNK_EDGE") ? static_cast<size_t>(std::max(8, std::min(256, std::atoi(std::getenv("KH_CHUNK_EDGE"))))) : 32;
   std::vector<size_t> bounds;
   if (edge < kChunk && n >= 2 * edge + kChunk) {
     bounds.push_back(0);
@@ -1356,8 +1371,9 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
     if ((e = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
   }
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
-  if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_load_counter), 8)) != hipSuccess) {return fail(e, "hipMalloc counter");}
-  if ((e = hipMemset(m->d_load_counter, 0, 8)) != hipSuccess) {return fail(e, "hipMemset counter");}
+  // (word 0 = the tally; the words behind it are used by measurement builds of the kernels only)
+  if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_load_counter), 512)) != hipSuccess) {return fail(e, "hipMalloc counter");}
+  if ((e = hipMemset(m->d_load_counter, 0, 512)) != hipSuccess) {return fail(e, "hipMemset counter");}
   if ((e = hipMemcpy(m->d_kernel, m->kernel.data(), m->kernel.size(), hipMemcpyHostToDevice)) != hipSuccess) {return fail(e, "hipMemcpy kernel");}
   // zero rows either side: as many as the SEARCH SPACE is high (m->side cells: 61 / 161 / 51 for the C2 / L / S presets -- not the
   // grid's region of interest, which also spans the range threshold), so that any search window that touches the array is inside
@@ -1447,6 +1463,7 @@ int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
   if (!m) {return KH_ERR_INVALID_ARG;}
   m->keep_responses = (keep_response_volume & 1) != 0;
   m->lds_score = (keep_response_volume & 2) != 0;
+  m->windowed_score = (keep_response_volume & 64) != 0;
   m->dense_score = (keep_response_volume & 4) != 0;
   if (keep_response_volume & 32) {m->mfma_score = true;}
   m->force_chunks = (keep_response_volume & 8) != 0 || std::getenv("KH_FORCE_CHUNKS") != nullptr;
@@ -1796,7 +1813,23 @@ int kh_matcher_score_loads(kh_matcher * m, int64_t * wave_loads, int32_t reset)
   unsigned long long v = 0;
   KH_HIP(hipMemcpy(&v, m->d_load_counter, 8, hipMemcpyDeviceToHost));
   *wave_loads = static_cast<int64_t>(v);
-  if (reset) {KH_HIP(hipMemset(m->d_load_counter, 0, 8));}
+#ifdef KH_LDS_TIMING
+  {
+    // measurement build of k_score_lds: clocks per phase, summed over all waves since the last reset
+    unsigned long long w[32];
+    KH_HIP(hipMemcpy(w, m->d_load_counter, sizeof(w), hipMemcpyDeviceToHost));
+    {
+      const double nk = static_cast<double>(std::max<unsigned long long>(1, w[22]));
+      std::fprintf(stderr, "[kh lds timing] k_offsets_lds per wave (%llu waves): setup %.0f  beams %.0f  builder %.0f  end %.0f  total %.0f clocks\n",
+        w[22], w[17] / nk, w[18] / nk, w[19] / nk, w[20] / nk, w[21] / nk);
+    }
+    const double n = static_cast<double>(std::max<unsigned long long>(1, w[9]));
+    std::fprintf(stderr, "[kh lds timing] per wave (%llu waves, %.1f chunks each): setup %.0f  barrier %.0f  issue %.0f  score %.0f  tail %.0f  epilogue: zero %.0f  "
+      "merge %.0f  poses %.0f  rest %.0f  total %.0f clocks\n", w[9], w[8] / n, w[1] / n, w[2] / n, w[3] / n, w[4] / n, w[5] / n, w[10] / n, w[11] / n, w[12] / n,
+      w[6] / n, w[7] / n);
+  }
+#endif
+  if (reset) {KH_HIP(hipMemset(m->d_load_counter, 0, 512));}
   return KH_OK;
 }
 

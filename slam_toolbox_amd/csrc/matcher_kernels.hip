@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
   }
   __syncthreads();
 
-  // epilogue: sums, responses, best, probs
+  // epilogue: sums, responses, best
   double best = 0.0;
   const size_t plane = (size_t)job.nx * job.ny;
   for (int p = tid; p < TY * PX; p += 256) {
@@ -1609,9 +1609,6 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
     const double response = pose_response(job, sum, a, yi, xi);
     if (job.write_resp) {job.resp[o] = response;}
     best = response > best ? response : best;
-    if (job.coarse && response > 0.0) {
-      atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
-    }
   }
   // wave max -> workgroup (= tile of one angle) max -> one atomic per workgroup
 #pragma unroll
@@ -1674,6 +1671,31 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
   const size_t plane = (size_t)job.nx * job.ny;
   const double best = __longlong_as_double((long long)job.out[0]);
   uint32_t * tie_idx = reinterpret_cast<uint32_t *>(job.out + 2);
+  if (job.coarse) {
+    // search-space probabilities (Mapper.cpp:781-799): the best response over the angles of every cell, recomputed here from
+    // the stored sums with the same device function -- one plain store per cell instead of one atomic maximum per POSE in the
+    // scoring kernel's epilogue (301 401 of them per config-2 match, all on the same 30 KB)
+    const int na = job.na, nxp = job.nx;
+    const int32_t * const sums = job.sums;
+    unsigned long long * const probs = job.out + kOutHeaderWords;
+    for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < (int)plane; cell += gridDim.x * blockDim.x) {
+      const int yi = cell / nxp, xi = cell - yi * nxp;
+      double m = 0.0;
+      for (int a0 = 0; a0 < na; a0 += 8) {
+        int32_t v[8];                                    // eight independent loads in flight, then the eight responses
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {v[t] = a0 + t < na ? sums[(size_t)(a0 + t) * plane + cell] : 0;}
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (a0 + t < na) {
+            const double response = pose_response(job, v[t], a0 + t, yi, xi);
+            m = response > m ? response : m;
+          }
+        }
+      }
+      probs[cell] = (unsigned long long)__double_as_longlong(m);
+    }
+  }
   auto consider = [&](int a, int yi, int xi) {
     const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
     const double response = pose_response(job, job.sums[o], a, yi, xi);
@@ -1742,43 +1764,80 @@ void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t 
 
 // =============================================================================================
 // LDS-staged scoring path (windows of at most 61 bytes x 64 lattice rows: BASELINE config 2, the
-// sequential preset, every fine search).  Experimental, opt-in (kh_matcher_set_debug bit 1).
+// sequential preset, every fine search).
 //
-// The windowed kernel above is bound by L2->L1 line fills: the 32 KB L1 cannot keep the windows of the
-// resident waves, so almost every window row is re-fetched from L2 although neighbouring beams and
-// neighbouring angles read nearly the same bytes.  Here the reuse is explicit: a workgroup scores
-// kGroupAngles adjacent angles, takes the beams in scan order (= order along the scanned contour) in
-// sub-chunks whose windows' union -- a rectangle of at most 240 rows x 256 bytes of the grid -- is staged
-// in LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers), double buffered, and every
-// (angle, beam) window is then read from LDS.
+// The windowed kernel above is bound by the vector L1: every (angle, beam) window is 64 bytes x 64 rows = 4 KB of dword
+// loads, the 32 KB L1 cannot keep the windows of the resident waves, and 64 B / clk / CU is all the L1 delivers however
+// the lines are arranged.  But the windows of consecutive beams lie a few cells apart (median 3 - 7 cells at 5 mm), and
+// those of the same beam at adjacent angles likewise: the UNION of the windows of some dozen consecutive beams at two
+// adjacent angles is a rectangle of <= 192 bytes x <= 200 rows -- 300 - 1000 staged bytes per 4 KB window.  So:
 //
-//   K2' k_offsets_lds  one workgroup per (angle group, job): bit-exact lookup table (as K2); one WAVE per
-//                      slot of 32 beams (lane = beam) splits the slot by halving until the rectangle fits and
-//                      writes the LDS-relative window offsets, sorted by alignment class, per angle
-//   K3' k_score_lds    16 waves = 2 angles x 4 alignment classes x 2 row halves.  Per sub-chunk:
-//                      [barrier] issue the DMA of the next region, then score the current one: one aligned
-//                      ds_read_b32 (row offsets are immediates: the pitch is fixed) + 4 VALU per 4 lookups.
+//   K2' k_offsets_lds  one workgroup per (angle pair, job): bit-exact lookup table (as K2), empty-window test against the
+//                      occupancy block map (as K2), then four builder waves (lane = beam) cut their quarter of the beams
+//                      greedily into CHUNKS -- the longest run of consecutive beams whose windows' union fits one LDS
+//                      region (wave-level prefix min / max of the window corners) -- and write per chunk a descriptor
+//                      and, per angle, the LDS-relative window offsets sorted by alignment class.
+//   K3' k_score_lds    512 threads = 2 angles x 4 row quarters, two workgroups per CU.  Per chunk: [barrier] LDS-DMA of the
+//                      NEXT chunk's region into the other buffer (global_load_lds_dwordx4: no staging registers), then the
+//                      current one is scored from LDS: aligned ds_read_b32 (pitch 192 B: the two rows a 32-lane half reads sit
+//                      in disjoint banks), FOUR beams of one alignment class at a time, and the byte sums are taken by the
+//                      matrix cores: v_mfma_i32_16x16x64_i8 with a constant selector adds, per lane, byte b of the four
+//                      dwords it loaded into accumulator b -- one MFMA per 1 KB read, no unpacking, no VALU in the loop
+//                      besides the four window addresses.  The alignment class (window start & 3) only decides which of a
+//                      wave's four accumulator sets a beam adds to; the sets are merged with their shifts in the epilogue.
+//
+// LDS staging alone (round 1: ds_read_b32 + 4 VALU per dword) lost to the vector ALU, the matrix-core sums alone (round 3)
+// to the L1; together neither is on the critical path: what remains is the LDS read itself, 128 B / clk / CU for b32.
 // =============================================================================================
 namespace kh
 {
 
-struct ChunkDesc {int32_t beam_begin, beam_end, g0, rows, cnt[kGroupAngles], pad0, pad1;};
+#ifndef KH_LDS_EXP
+#define KH_LDS_EXP 0          // measurement builds only: 1 = no region DMA, 4 = no scoring, 5 = no chunk loop (results are then wrong)
+#endif
+struct ChunkDesc {int32_t beam_begin, beam_end, g0, rows, cnt[kGroupAngles], windows, pad1;};
 static_assert(sizeof(ChunkDesc) == kChunkWords * 4, "descriptor size");
 static_assert(kGroupAngles == 2, "the wave roles below assume two angles per workgroup");
+static_assert(kLdsPitch % 16 == 0 && kLdsPitch % 128 == 64, "rows of a 32-lane half must fall into disjoint banks");
+static_assert(kLdsRegionBytes % 1024 == 0 && kLdsRegionBytes >= kLdsRows * kLdsPitch, "one LDS-DMA instruction fills 1 KB");
 
 constexpr int kNotFast = INT32_MIN;
 
-__device__ __forceinline__ int wave_min(int v)
+// inclusive prefix minimum / maximum over the lanes of a wave, in registers: DPP row shifts inside the rows of 16 lanes, then the
+// two row broadcasts (lane 15 of a row into the next row; lane 31 into the upper half).  A lane without a source keeps the
+// operation's identity.  (Through __shfl_up every one of the 6 steps is an LDS round trip: the four scans of a builder step took
+// ~2500 clocks.)
+template <bool kMin>
+__device__ __forceinline__ int wave_prefix(int v)
 {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) {const int o = __shfl_xor(v, s); v = o < v ? o : v;}
+  constexpr int ident = kMin ? INT32_MAX : INT32_MIN;
+  auto op = [](int x, int y) {return kMin ? (y < x ? y : x) : (y > x ? y : x);};
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));      // row_shr:1
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));      // row_shr:2
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));      // row_shr:4
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));      // row_shr:8
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
   return v;
 }
-__device__ __forceinline__ int wave_max(int v)
+__device__ __forceinline__ int wave_prefix_min(int v, int) {return wave_prefix<true>(v);}
+__device__ __forceinline__ int wave_prefix_max(int v, int) {return wave_prefix<false>(v);}
+
+// Does any stamp footprint overlap the window [x_lo, x_hi] x [y_lo, y_hi] (grid cells)?  One bit per 32 x 32 block, rows padded
+// by a word; rows above and below the array hold nothing.  No early exit: the probes are independent loads.
+__device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w, int bm_h, int x_lo, int y_lo, int x_hi, int y_hi)
 {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) {const int o = __shfl_xor(v, s); v = o > v ? o : v;}
-  return v;
+  const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
+  const int by0 = max(y_lo, 0) >> kBlockShift, by1 = min(y_hi >> kBlockShift, bm_h - 1);
+  const int wi = bx0 >> 5, sh = bx0 & 31, nb = bx1 - bx0 + 1;
+  if (nb > 32) {return true;}
+  const unsigned long long span = (1ull << nb) - 1ull;
+  unsigned long long any = 0;
+  for (int by = by0; by <= by1; ++by) {
+    const uint32_t * row = bmp + (size_t)by * bm_w + wi;
+    any |= (((unsigned long long)row[1] << 32) | row[0]) >> sh;
+  }
+  return (any & span) != 0;
 }
 
 __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_t stride)
@@ -1787,6 +1846,13 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   const int group = blockIdx.x;
   const int a0 = group * kGroupAngles;
   if (a0 >= job.na) {return;}
+#ifdef KH_LDS_TIMING
+  unsigned long long tk_t = __builtin_readcyclecounter(), tk_a = 0, tk_b = 0, tk_c = 0, tk_d = 0;
+  const unsigned long long tk_start = tk_t;
+#define KH_TK(var) do {const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - tk_t; tk_t = now_;} while (0)
+#else
+#define KH_TK(var)
+#endif
   {
     // the job's result block starts from zero: every group's workgroup clears its share
     const int groups = (job.na + kGroupAngles - 1) / kGroupAngles;
@@ -1797,10 +1863,35 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   const int P = job.n_points;
   extern __shared__ int32_t s_xy[];              // [kGroupAngles][2][P]: gx, gy (gy = kNotFast: not a fast beam)
   __shared__ int32_t s_slow[kGroupAngles];
+  __shared__ uint32_t s_bm[4096];
   if (threadIdx.x < kGroupAngles) {s_slow[threadIdx.x] = 0;}
+  const uint32_t * bmp = job.blockmap;
+  if (bmp && job.bm_w * job.bm_h <= 4096) {
+    for (int i = threadIdx.x; i < job.bm_w * job.bm_h; i += blockDim.x) {s_bm[i] = job.blockmap[i];}
+    bmp = s_bm;
+  }
   __syncthreads();
+  KH_TK(tk_a);
   const int64_t bmin = job.base0;
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
+  const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;   // cells a window covers
+  const float inv_ws = 1.0f / (float)job.ws;
+  // this thread's beams: sensor-frame point and validity, read once for both angles and all in flight together (read between the
+  // stores of the loop below every beam paid a full memory latency)
+  constexpr int kBeamsPerThread = 8;                       // P <= 2048 on this path
+  double plx[kBeamsPerThread], ply[kBeamsPerThread];
+  bool pinv[kBeamsPerThread];
+#pragma unroll
+  for (int t = 0; t < kBeamsPerThread; ++t) {
+    const int i = threadIdx.x + 256 * t;
+    const bool in = i < P;
+    pinv[t] = in ? job.invalid[i] != 0 : true;
+    plx[t] = in ? job.local[2 * i] : 0.0;
+    ply[t] = in ? job.local[2 * i + 1] : 0.0;
+  }
+  const int ws = job.ws, bm_w = job.bm_w, bm_h = job.bm_h;
+  const int64_t data_size = job.data_size, pad = job.pad;
+  const double off_x = job.grid_off_x, off_y = job.grid_off_y, scale = job.scale;
   for (int q = 0; q < kGroupAngles; ++q) {
     const int a = a0 + q;
     int32_t * sgx = s_xy + (size_t)(2 * q) * P;
@@ -1812,27 +1903,48 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
     const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
     int32_t * table = job.table + (size_t)a * P;
     int32_t * slow = job.slow + (size_t)a * P;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+#pragma unroll
+    for (int t = 0; t < kBeamsPerThread; ++t) {
+      const int i = threadIdx.x + 256 * t;
+      if (i >= P) {break;}
       int32_t idx, gx = 0, gy = kNotFast;
-      if (job.invalid[i]) {
+      if (pinv[t]) {
         idx = kInvalidScan;
       } else {
-        const double lx = job.local[2 * i], ly = job.local[2 * i + 1];
+        const double lx = plx[t], ly = ply[t];
         // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
         const double ox = cosine * lx - sine * ly;
         const double oy = sine * lx + cosine * ly;
-        const double gxd = ((ox + job.grid_off_x) - job.grid_off_x) * job.scale;
-        const double gyd = ((oy + job.grid_off_y) - job.grid_off_y) * job.scale;
+        const double gxd = ((ox + off_x) - off_x) * scale;
+        const double gyd = ((oy + off_y) - off_y) * scale;
         gx = d_to_int(d_round(gxd));
         const int32_t gyi = d_to_int(d_round(gyd));
-        idx = (int32_t)((uint32_t)gx + (uint32_t)gyi * (uint32_t)job.ws);   // base Grid::GridIndex, no ROI
+        idx = (int32_t)((uint32_t)gx + (uint32_t)gyi * (uint32_t)ws);   // base Grid::GridIndex, no ROI
         if (idx != kInvalidScan) {
-          const bool off_grid = (int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= job.data_size;
-          const bool inside = (int64_t)idx + bmin >= 0 && (int64_t)idx + bmax < job.data_size;
+          const bool off_grid = (int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= data_size;
+          // (a pose whose index falls off the array adds nothing in the reference, Mapper.cpp:1192-1197, and a zero here: the
+          // allocation has job.pad zero bytes in front of and behind the grid)
+          const bool inside = (int64_t)idx + bmin >= -pad && (int64_t)idx + bmax < data_size + pad;
           // the rectangle arithmetic needs the linear index to be exactly gx + gy * ws
-          const bool exact = (int64_t)gx + (int64_t)gyi * job.ws == (int64_t)idx && gx > -(1 << 20) && gx < (1 << 20);
+          const bool exact = (int64_t)gx + (int64_t)gyi * ws == (int64_t)idx && gx > -(1 << 20) && gx < (1 << 20);
           if (!off_grid) {
-            if (inside && exact) {gy = gyi;} else {slow[atomicAdd(&s_slow[q], 1)] = idx;}
+            if (inside && exact) {
+              gy = gyi;
+              if (bmp) {
+                // a window none of whose 32 x 32 blocks was touched by a stamp adds 0 to every pose of this angle: leave the
+                // beam out (bit-identical sums).  Windows that wrap around the row end are kept (Appendix A.3).
+                const int32_t start = (int32_t)((int64_t)idx + bmin);
+                int32_t wy0 = (int32_t)((float)start * inv_ws);
+                int32_t wx0 = start - wy0 * ws;
+                while (wx0 < 0) {wx0 += ws; --wy0;}
+                while (wx0 >= ws) {wx0 -= ws; ++wy0;}
+                if (wx0 + xs <= ws && !window_has_blocks(bmp, bm_w, bm_h, wx0, wy0, wx0 + xs - 1, wy0 + ys - 1)) {
+                  gy = kNotFast;
+                }
+              }
+            } else {
+              slow[atomicAdd(&s_slow[q], 1)] = idx;
+            }
           }
         }
       }
@@ -1841,92 +1953,113 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
     }
   }
   __syncthreads();
-  // ---- one wave per slot, lane = beam: split into sub-chunks, write descriptors and class-sorted offsets ----
+  KH_TK(tk_b);
+  // ---- four builder waves, lane = beam: greedy chunks over this wave's quarter of the beams ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_slots = (P + kSlotBeams - 1) / kSlotBeams;
-  const int span_x = 68;                                   // bytes a wave may read past a window start (64 + dword slack)
-  const int span_rows = (job.ny - 1) * job.sy_cells + 1;   // grid rows a window covers
-  for (int slot = wave; slot < n_slots; slot += 4) {
-    const int b_lo = slot * kSlotBeams;
-    const int n_in = min(P - b_lo, kSlotBeams);
+  const int range_len = (P + kLdsRanges - 1) / kLdsRanges;
+  const int lo = wave * range_len, hi = min(P, lo + range_len);
+  // rows a wave of K3' reads past a window's first row (63 lattice rows), and rows that have to be staged
+  const int read_rows = 63 * job.sy_cells + 1;
+  const int span_rows = ys;
+  ChunkDesc * out = reinterpret_cast<ChunkDesc *>(job.chunks) + ((size_t)group * kLdsRanges + wave) * range_len;
+  const int32_t * sgx0 = s_xy, * sgy0 = s_xy + P, * sgx1 = s_xy + 2 * P, * sgy1 = s_xy + 3 * P;
+  int n_out = 0;
+  long long windows_total = 0;
+  int begin = lo;
+  while (begin < hi) {
+    const int i = begin + lane;
+    const bool inr = i < hi;
     int gx[kGroupAngles], gy[kGroupAngles];
+    gx[0] = inr ? sgx0[i] : 0; gy[0] = inr ? sgy0[i] : kNotFast;
+    gx[1] = inr ? sgx1[i] : 0; gy[1] = inr ? sgy1[i] : kNotFast;
+    int n = 0, x0 = 0, y0 = 0, rows = 0;
+    bool any_chunk = false;
+    for (;;) {
+      int xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
 #pragma unroll
-    for (int q = 0; q < kGroupAngles; ++q) {
-      const int32_t * sgx = s_xy + (size_t)(2 * q) * P;
-      gx[q] = lane < n_in ? sgx[b_lo + lane] : 0;
-      gy[q] = lane < n_in ? sgx[P + b_lo + lane] : kNotFast;
-    }
-    ChunkDesc * out = reinterpret_cast<ChunkDesc *>(job.chunks) + ((size_t)group * n_slots + slot) * kSlotBeams;
-    int n_out = 0;
-    int begin = 0;
-    while (begin < n_in) {
-      int end = n_in;
-      int x0 = 0, y0 = 0, rows = 0;
-      bool any = false, fits = false;
-      for (;;) {
-        const bool in = lane >= begin && lane < end;
-        int xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
-#pragma unroll
-        for (int q = 0; q < kGroupAngles; ++q) {
-          if (in && gy[q] != kNotFast) {
-            xmin = min(xmin, gx[q]); xmax = max(xmax, gx[q]); ymin = min(ymin, gy[q]); ymax = max(ymax, gy[q]);
-          }
-        }
-        xmin = wave_min(xmin); xmax = wave_max(xmax); ymin = wave_min(ymin); ymax = wave_max(ymax);
-        any = xmin != INT32_MAX;
-        if (!any) {break;}
-        const int al = (int)(((int64_t)job.base0 + xmin) & 15);          // ws % 16 == 0: the same for every row
-        x0 = xmin - al; y0 = ymin;
-        rows = (ymax - y0) + span_rows;
-        fits = (xmax - x0 + span_x <= kLdsPitch) && rows <= kLdsRows;
-        if (fits || end - begin == 1) {break;}
-        end = begin + (end - begin + 1) / 2;
-      }
-      if (any) {
-        const bool in = lane >= begin && lane < end;
-        ChunkDesc d;
-        d.beam_begin = b_lo + begin; d.beam_end = b_lo + end;
-        d.g0 = y0 * job.ws + x0; d.rows = rows; d.pad0 = 0; d.pad1 = 0;
-#pragma unroll
-        for (int q = 0; q < kGroupAngles; ++q) {
-          const int a = a0 + q;
-          d.cnt[q] = 0;
-          if (a >= job.na) {continue;}                           // wave-uniform
-          const bool mine = in && gy[q] != kNotFast;
-          const int rel = (gy[q] - y0) * kLdsPitch + (gx[q] - x0);
-          if (fits) {
-            // sort the sub-chunk's offsets of this angle by alignment class: four contiguous segments
-            const int cls = rel & 3;
-            int offset = 0, my_rank = 0, packed = 0;
-#pragma unroll
-            for (int c = 0; c < kClasses; ++c) {
-              const unsigned long long mask = __ballot(mine && cls == c);
-              const int cnt = __popcll(mask);
-              if (cls == c) {my_rank = offset + __popcll(mask & ((1ull << lane) - 1ull));}
-              offset += cnt;
-              packed |= cnt << (8 * c);
-            }
-            d.cnt[q] = packed;
-            if (mine) {job.rel[(size_t)a * P + b_lo + begin + my_rank] = rel;}
-          } else if (mine) {
-            // a single beam whose windows at the two angles are too far apart: exact per-pose path
-            (job.slow + (size_t)a * P)[atomicAdd(&s_slow[q], 1)] = gx[q] + gy[q] * job.ws;
-          }
-        }
-        if (fits) {
-          if (lane == 0) {out[n_out] = d;}
-          ++n_out;
+      for (int q = 0; q < kGroupAngles; ++q) {
+        if (gy[q] != kNotFast) {
+          xmin = min(xmin, gx[q]); xmax = max(xmax, gx[q]); ymin = min(ymin, gy[q]); ymax = max(ymax, gy[q]);
         }
       }
-      begin = end;
+      xmin = wave_prefix_min(xmin, lane); xmax = wave_prefix_max(xmax, lane);
+      ymin = wave_prefix_min(ymin, lane); ymax = wave_prefix_max(ymax, lane);
+      const bool any = xmin != INT32_MAX;
+      const int al = (int)(((int64_t)job.base0 + xmin) & 15);          // 16-byte alignment of the region's first row
+      const int px0 = xmin - al;
+      const bool fits = any && (xmax - px0 + kTileBytes <= kLdsPitch) && (ymax - ymin + read_rows <= kLdsRows);
+      const unsigned long long okm = __ballot(!any || fits);             // the union only grows: a run of leading ones
+      n = (okm == ~0ull) ? 64 : __ffsll((long long)~okm) - 1;
+      if (n > 0) {
+        // the chunk = lanes 0 .. n - 1; its rectangle is what lane n - 1 sees
+        x0 = __shfl(px0, n - 1); y0 = __shfl(ymin, n - 1);
+        rows = __shfl(ymax, n - 1) - y0 + span_rows;
+        any_chunk = __shfl((int)any, n - 1) != 0;
+        break;
+      }
+      // the two windows of the first beam are too far apart for one region: the second angle's goes the exact per-pose way
+      // (a window alone always fits; the first angle's follows only if it ever did not)
+      if (lane == 0) {
+        const int qd = gy[1] != kNotFast ? 1 : 0;
+        (job.slow + (size_t)(a0 + qd) * P)[atomicAdd(&s_slow[qd], 1)] = gx[qd] + gy[qd] * job.ws;
+        gy[qd] = kNotFast;
+      }
     }
-    if (lane == 0) {job.chunk_counts[(size_t)group * n_slots + slot] = n_out;}
+    n = min(n, hi - begin);
+    if (any_chunk) {
+      const bool in = lane < n;
+      ChunkDesc d;
+      d.beam_begin = begin; d.beam_end = begin + n;
+      d.g0 = y0 * job.ws + x0; d.rows = rows; d.pad1 = 0;
+      int windows = 0;
+#pragma unroll
+      for (int q = 0; q < kGroupAngles; ++q) {
+        const int a = a0 + q;
+        d.cnt[q] = 0;
+        if (a >= job.na) {continue;}                           // wave-uniform
+        const bool mine = in && gy[q] != kNotFast;
+        const int rel = (gy[q] - y0) * kLdsPitch + (gx[q] - x0);
+        // sort the chunk's offsets of this angle by alignment class: four contiguous segments
+        const int cls = rel & 3;
+        int offset = 0, my_rank = 0, packed = 0;
+#pragma unroll
+        for (int c = 0; c < kClasses; ++c) {
+          const unsigned long long mask = __ballot(mine && cls == c);
+          const int cnt = __popcll(mask);
+          if (cls == c) {my_rank = offset + __popcll(mask & ((1ull << lane) - 1ull));}
+          offset += cnt;
+          packed |= cnt << (8 * c);
+        }
+        d.cnt[q] = packed;
+        windows += offset;
+        if (mine) {job.rel[(size_t)a * P + begin + my_rank] = rel & ~3;}      // K3' reads aligned dwords; the class is the segment
+      }
+      d.windows = windows;
+      windows_total += windows;
+      if (lane == 0) {out[n_out] = d;}
+      ++n_out;
+    }
+    begin += n;
   }
+  if (lane == 0) {
+    job.chunk_counts[(size_t)group * kLdsRanges + wave] = n_out;
+    // every window costs K3' sixteen wave-level ds_read_b32 (256 B each): the numerator of the roofline
+    if (job.load_counter && windows_total) {atomicAdd(job.load_counter, (unsigned long long)(windows_total * 16));}
+  }
+  KH_TK(tk_c);
   __syncthreads();
   if (threadIdx.x < kGroupAngles && a0 + (int)threadIdx.x < job.na) {
     job.counts[kCountsPerAngle * (a0 + threadIdx.x) + kClasses] = s_slow[threadIdx.x];
   }
+#ifdef KH_LDS_TIMING
+  KH_TK(tk_d);
+  if (lane == 0 && job.load_counter && (blockIdx.x % 7) == 0) {
+    unsigned long long * c = job.load_counter + 16;
+    atomicAdd(c + 1, tk_a); atomicAdd(c + 2, tk_b); atomicAdd(c + 3, tk_c); atomicAdd(c + 4, tk_d); atomicAdd(c + 5, tk_t - tk_start); atomicAdd(c + 6, 1ull);
+  }
+#endif
 }
+#undef KH_TK
 
 void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream)
 {
@@ -1934,22 +2067,29 @@ void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, i
   const int groups = (max_na + kGroupAngles - 1) / kGroupAngles;
   // dynamic LDS: gx, gy of kGroupAngles angles; the host guarantees P <= 2048 on this path
   const size_t lds = sizeof(int32_t) * 2 * kGroupAngles * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_offsets_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(k_offsets_lds, dim3(groups, n_jobs), dim3(256), lds, (hipStream_t)stream, d_jobs, stride);
 }
 
-// K3'.  S = grid cells per lattice step (x and y).  16 waves: wave = q * 8 + cls * 2 + half:
-// angle q of the group, alignment class cls, rows 32 * half .. 32 * half + 31; lane = (lx = lane & 15:
-// one aligned dword of the 64-byte tile row, ly = lane >> 4); rows yi = 32 * half + 4 * k + ly, k < 8.
-constexpr int kMaxLdsDescs = 160;
+// K3'.  S = grid cells per lattice step (x and y).  2 * NW waves: wave = q * NW + share: angle q of the pair, lattice rows
+// 4 * RQ * share .. + 4 * RQ - 1 (RQ = 16 / NW); lane = (lx = lane & 15: one aligned dword of the 64-byte window row,
+// ly = lane >> 4); rows yi = 4 * RQ * share + 4 * r + ly, r < RQ.  acc[c][r] = the four byte sums of the lane's dword over the
+// class-c beams.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(1))) const void gvoid;
+typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int S>
-__global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
+template <int S, int NW>
+__global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
 {
-  constexpr int RY = 8;
-  constexpr int NB = (S == 1) ? 4 : 2;
+  constexpr int RQ = 16 / NW;                              // rows per lane (NW waves share the 64 rows of an angle's windows)
+  constexpr int kThreadsPerAngle = 64 * NW;
   constexpr int PX = (S == 1) ? kTileSpan : (kTileSpan + 1) / 2;
+  constexpr int kRowStep = 4 * S * kLdsPitch;              // bytes between two rows of a lane
   int job_index, group;
   if (xcd_map) {
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
@@ -1962,197 +2102,272 @@ __global__ __launch_bounds__(1024) void k_score_lds(const uint8_t * jobs, size_t
   if (job_index >= n_jobs) {return;}
   const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)job_index * stride);
   if (group * kGroupAngles >= job.na) {return;}
-  extern __shared__ uint32_t s_region[];                   // two regions of kLdsRegionBytes
-  __shared__ ChunkDesc s_desc[kMaxLdsDescs];
-  __shared__ int s_ndesc, s_first_slot;
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_region[];     // two regions of kLdsRegionBytes
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lx = lane & 15, ly = lane >> 4;
-  const int q = wave >> 3, cls = (wave >> 1) & 3, half = wave & 1;
+  const int q = wave / NW, quarter = wave % NW;          // ("quarter": this wave's share of the rows, 4 * RQ of them)
   const int a = group * kGroupAngles + q;
   const bool live = a < job.na;
   const int P = job.n_points;
-  const int n_slots = (P + kSlotBeams - 1) / kSlotBeams;
+  const int range_len = (P + kLdsRanges - 1) / kLdsRanges;
 
-  int32_t acc[RY][NB];
+  v4i acc[kClasses][RQ];
 #pragma unroll
-  for (int r = 0; r < RY; ++r) {
+  for (int c = 0; c < kClasses; ++c) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {acc[r][b] = 0;}
+    for (int r = 0; r < RQ; ++r) {acc[c][r] = v4i{0, 0, 0, 0};}
   }
-  uint32_t lo[RY], hi[RY];
-#pragma unroll
-  for (int r = 0; r < RY; ++r) {lo[r] = 0; hi[r] = 0;}
-  int since_flush = 0;
-  // S == 2: poses sit on every other window byte; the window starts at byte cls of its first dword
-  const uint32_t sel = (cls & 1) ? 0x0c030c01u : 0x0c020c00u;
+  // selector A[i][k] of the matrix product D = A B: lane (i = lane & 15, g = lane >> 4) holds k = 16 g .. 16 g + 15, the k
+  // lane (j, g) of B supplies its four dwords for.  A[i][k] = (g == i >> 2 && (k & 3) == (i & 3)): row 4 g + b of D is, column
+  // by column, the sum of byte b of the four dwords of lane (j, g) -- and D[4 g + b][j] is register b of lane (j, g).
+  v4i sel;
+  {
+    const int i = lane & 15;
+    const int one = ((lane >> 4) == (i >> 2)) ? (int)(0x01010101u & (0xffu << (8 * (i & 3)))) : 0;
+    sel = v4i{one, one, one, one};
+  }
   // byte offset of this lane's first row inside a window (the other rows are immediates: fixed pitch)
-  const int lanebase = 4 * lx + (32 * half + ly) * S * kLdsPitch;
+  const int lanebase = 4 * lx + (4 * RQ * quarter + ly) * S * kLdsPitch;
 
   const gbyte * gwin = as_global(job.grid) + job.base0;
   const gint * grel = as_global(job.rel + (size_t)(live ? a : 0) * P);
-  const ChunkDesc * descs = reinterpret_cast<const ChunkDesc *>(job.chunks) + (size_t)group * n_slots * kSlotBeams;
-  const int32_t * counts = job.chunk_counts + (size_t)group * n_slots;
+  // descriptors and counts are wave-uniform: read through the scalar cache (constant address space: K2' wrote them in an
+  // earlier launch), so the chunk loop's control flow stays on the scalar unit
+  typedef const __attribute__((address_space(4))) int32_t cint;
+  cint * cdescs = (cint *)(job.chunks + (size_t)group * kLdsRanges * range_len * kChunkWords);
+  cint * ccounts = (cint *)(job.chunk_counts + (size_t)group * kLdsRanges);
+  struct Chunk {int beam_begin, g0, rows, packed;};
 
-  // LDS-DMA of one region: a wave instruction moves 4 rows x 256 B (lane = 16 bytes: row = lane >> 4, column
-  // block = lane & 15) to 1 KB of LDS starting at a wave-uniform address
-  auto issue_dma = [&](const ChunkDesc & d, int buf) {
+  // LDS-DMA of one region: a wave instruction moves 64 units of 16 bytes (unit u = row * (pitch / 16) + column block) to 1 KB
+  // of LDS starting at a wave-uniform address.  (job.ws is read once, in front of the loop: a load of it inside would put an
+  // s_waitcnt vmcnt(0) -- i.e. a wait for the PREVIOUS DMA -- in front of every DMA instruction.)
+  constexpr int kUnitsPerRow = kLdsPitch / 16;
+  constexpr int kDmaPerWave = (kLdsRegionBytes / 1024 + 2 * NW - 1) / (2 * NW);
+  const int ws = job.ws;
+  auto issue_dma = [&](const Chunk & d, int buf) {
     const gbyte * src = gwin + d.g0;
-    const int nblk = (d.rows + 3) >> 2;
-    for (int blk = wave; blk < nblk; blk += 16) {
-      int row = 4 * blk + (lane >> 4);
-      row = row < d.rows ? row : d.rows - 1;                // the tail block re-reads the last row: stays in bounds
-      const gbyte * g = src + (int64_t)row * job.ws + 16 * (lane & 15);
-      lds_u32 * dst = (lds_u32 *)s_region + buf * (kLdsRegionBytes / 4) + blk * (4 * kLdsPitch / 4);
-      __builtin_amdgcn_global_load_lds((gvoid *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    const int units = d.rows * kUnitsPerRow;
+    const int nblk = (KH_LDS_EXP == 1) ? 0 : (units + 63) >> 6;
+#pragma unroll
+    for (int t = 0; t < kDmaPerWave; ++t) {
+      const int blk = wave + 2 * NW * t;
+      if (blk < nblk) {
+        // (the unit's grid offset is recomputed here: kept in registers across the chunk loop the offsets of all the units a
+        // lane ever moves cost ten VGPRs the scoring loop needs)
+        int u = 64 * blk + lane;
+        u = u < units ? u : units - 1;                      // the tail block re-reads the last unit: stays in bounds
+        const int row = u / kUnitsPerRow, col = u - row * kUnitsPerRow;
+        const int32_t o = row * ws + 16 * col;
+        lds_u32 * dst = (lds_u32 *)s_region + buf * (kLdsRegionBytes / 4) + blk * 256;
+        __builtin_amdgcn_global_load_lds((gvoid *)(src + o), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+      }
     }
   };
-  // this wave's offsets of a sub-chunk: segment `cls` of angle q's class-sorted run
-  auto seg_of = [&](const ChunkDesc & d, int & off, int & cnt) {
-    const int packed = d.cnt[q];
-    off = 0;
-#pragma unroll
-    for (int c = 0; c < kClasses; ++c) {if (c < cls) {off += (packed >> (8 * c)) & 0xff;}}
-    cnt = (packed >> (8 * cls)) & 0xff;
+  // this wave's offsets of a chunk: angle q's class-sorted run, lane k = k-th window
+  auto load_rel = [&](const Chunk & d) -> int32_t {
+    const int cnt = (d.packed & 0xff) + ((d.packed >> 8) & 0xff) + ((d.packed >> 16) & 0xff) + ((d.packed >> 24) & 0xff);
+    return (live && lane < cnt) ? grel[d.beam_begin + lane] : 0;
   };
-  auto load_rel = [&](const ChunkDesc & d) -> int32_t {
-    int off, cnt;
-    seg_of(d, off, cnt);
-    return (live && lane < cnt) ? grel[d.beam_begin + off + lane] : 0;
-  };
-  auto score = [&](const ChunkDesc & d, int buf, int32_t rels) {
+  // One STEP = four windows of the class-sorted run: 4 * RQ single ds_read_b32 (RQ rows x four beams), then RQ MFMAs into the
+  // accumulator set of their class.  The reads are written as asm so that every result lands in its slot of an MFMA operand
+  // tuple (left to itself the compiler pairs the rows of a beam into ds_read2st64_b32 and then shuffles the halves into the
+  // tuples with a dozen v_mov per step); the wait is explicit, the loads' results are tied to it.
+  // The last step of a class may hold fewer than four beams: the missing beams' slots read the zero strip behind the regions
+  // (every lane the same dwords: a broadcast) and add nothing, so every step is the same code.
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)((char *)s_region);
+  const uint32_t lds_lane = lds_base + (uint32_t)lanebase;
+  const uint32_t lds_zero = lds_base + (uint32_t)(2 * kLdsRegionBytes);
+  if (tid < RQ) {s_region[(2 * kLdsRegionBytes + tid * kRowStep) / 4] = 0u;}
+#define KH_DSR(dst, addr, r) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((r) * kRowStep) : "memory")
+  auto score = [&](const Chunk & d, int buf, int32_t rels) {
     if (!live) {return;}
-    int off, cnt;
-    seg_of(d, off, cnt);
-    const char * base = reinterpret_cast<const char *>(s_region) + buf * kLdsRegionBytes + lanebase;
-    for (int k = 0; k < cnt; ++k) {
-      const int32_t rel = __builtin_amdgcn_readlane(rels, k);
-      const uint32_t * pw = reinterpret_cast<const uint32_t *>(base + (rel & ~3));
+    const uint32_t base = lds_lane + (uint32_t)(buf * kLdsRegionBytes);
+    int off = 0;
 #pragma unroll
-      for (int r = 0; r < RY; ++r) {
-        const uint32_t w = pw[r * (4 * S * kLdsPitch / 4)];
-        if (S == 1) {
-          lo[r] += w & 0x00ff00ffu;                                // [0, b2, 0, b0]
-          hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);      // [0, b3, 0, b1]
+    for (int c = 0; c < kClasses; ++c) {
+      const int cnt = (d.packed >> (8 * c)) & 0xff;
+      for (int k = 0; k < cnt; k += 4) {
+        const int i0 = off + k, rem = cnt - k;
+        int32_t w[RQ][4];
+        const uint32_t a0 = base + (uint32_t)__builtin_amdgcn_readlane(rels, i0);
+        const uint32_t a1 = rem > 1 ? base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 1) : lds_zero;
+        const uint32_t a2 = rem > 2 ? base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 2) : lds_zero;
+        const uint32_t a3 = rem > 3 ? base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 3) : lds_zero;
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {KH_DSR(w[r][0], a0, r); KH_DSR(w[r][1], a1, r); KH_DSR(w[r][2], a2, r); KH_DSR(w[r][3], a3, r);}
+        if (RQ == 4) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]),
+            "+v"(w[RQ - 2][0]), "+v"(w[RQ - 2][1]), "+v"(w[RQ - 2][2]), "+v"(w[RQ - 2][3]), "+v"(w[RQ - 1][0]), "+v"(w[RQ - 1][1]), "+v"(w[RQ - 1][2]), "+v"(w[RQ - 1][3]));
         } else {
-          lo[r] += __builtin_amdgcn_perm(0u, w, sel);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]));
         }
-      }
-      if (++since_flush == 512) {
 #pragma unroll
-        for (int r = 0; r < RY; ++r) {
-          if (S == 1) {
-            acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
-            acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
-          } else {
-            acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
-          }
-          lo[r] = 0; hi[r] = 0;
+        for (int r = 0; r < RQ; ++r) {
+          acc[c][r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, (v4i{w[r][0], w[r][1], w[r][2], w[r][3]}), acc[c][r], 0, 0, 0);
         }
-        since_flush = 0;
       }
+      off += cnt;
     }
   };
+#undef KH_DSR
 
-  // descriptors are walked in batches of kMaxLdsDescs (LDS copy), slot by slot
-  int slot_next = 0;
-  while (slot_next < n_slots) {
-    __syncthreads();
-    if (wave == 0) {
-      // take as many whole slots as fit: exclusive scan of the per-slot counts from slot_next on
-      const int sl = slot_next + lane;
-      const int cnt = sl < n_slots ? counts[sl] : 0;
-      int incl = cnt;
-#pragma unroll
-      for (int sft = 1; sft < 64; sft <<= 1) {
-        const int o = __shfl_up(incl, sft);
-        if (lane >= sft) {incl += o;}
-      }
-      const bool take = incl <= kMaxLdsDescs && sl < n_slots;
-      const unsigned long long tmask = __ballot(take);
-      const int n_take = (tmask == ~0ull) ? 64 : __ffsll((long long)~tmask) - 1;     // leading run of takeable slots
-      const int excl = incl - cnt;
-      if (lane < n_take) {
-        for (int k = 0; k < cnt; ++k) {s_desc[excl + k] = descs[(size_t)sl * kSlotBeams + k];}
-      }
-      const int total = __shfl(incl, max(n_take - 1, 0));
-      if (lane == 0) {s_ndesc = n_take > 0 ? total : 0; s_first_slot = slot_next + max(n_take, 1);}
-    }
-    __syncthreads();
-    const int n_desc = s_ndesc;
-    slot_next = s_first_slot;       // a slot with more than kMaxLdsDescs sub-chunks cannot occur (<= 32 per slot)
-    if (n_desc == 0) {continue;}
-    // software pipeline, two descriptors per trip so that the prefetched offsets alternate between two registers
-    issue_dma(s_desc[0], 0);
-    int32_t rel_a = load_rel(s_desc[0]), rel_b = 0;
-    for (int c = 0; c < n_desc; c += 2) {
-      __syncthreads();                               // region c landed (the barrier drains the DMA); region c-1 is free
-      if (c + 1 < n_desc) {issue_dma(s_desc[c + 1], 1); rel_b = load_rel(s_desc[c + 1]);}
-      score(s_desc[c], 0, rel_a);
-      if (c + 1 >= n_desc) {break;}
-      __syncthreads();
-      if (c + 2 < n_desc) {issue_dma(s_desc[c + 2], 0); rel_a = load_rel(s_desc[c + 2]);}
-      score(s_desc[c + 1], 1, rel_b);
-    }
+  // walk the chunks of the four beam ranges in order: [barrier] DMA of the next region, score this one; the descriptor after
+  // the next is already on its way through the scalar cache
+  int range = 0, k_in = 0;
+  static_assert(kLdsRanges == 4, "the four chunk counts are held in scalar registers");
+  const int n_chunks0 = ccounts[0], n_chunks1 = ccounts[1], n_chunks2 = ccounts[2], n_chunks3 = ccounts[3];
+  auto next_chunk = [&](Chunk & d) -> bool {
+    while (range < kLdsRanges && k_in >= (range == 0 ? n_chunks0 : range == 1 ? n_chunks1 : range == 2 ? n_chunks2 : n_chunks3)) {++range; k_in = 0;}
+    if (range >= kLdsRanges) {return false;}
+    cint * w = cdescs + ((size_t)range * range_len + k_in) * kChunkWords;
+    d.beam_begin = w[0]; d.g0 = w[2]; d.rows = w[3]; d.packed = w[4 + q];
+    ++k_in;
+    return true;
+  };
+#ifdef KH_LDS_TIMING
+  // measurement build: clocks a wave spends in the phases of the chunk loop, summed over all waves into load_counter[1 ...]
+  unsigned long long tm_pre = __builtin_readcyclecounter(), tm_bar = 0, tm_issue = 0, tm_score = 0, tm_tail = 0, tm_chunks = 0;
+  const unsigned long long tm_start = tm_pre;
+#define KH_TM(var, since) do {const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - since; since = now_;} while (0)
+#else
+#define KH_TM(var, since)
+#endif
+  Chunk cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0}, aft = {0, 0, 0, 0};
+  bool have = (KH_LDS_EXP != 5) && next_chunk(cur);
+  bool more = have && next_chunk(nxt);
+  int buf = 0;
+  int32_t rel_cur = 0, rel_nxt = 0;
+  if (have) {issue_dma(cur, 0); rel_cur = load_rel(cur);}
+#ifdef KH_LDS_TIMING
+  unsigned long long tm_t = __builtin_readcyclecounter();
+  tm_pre = tm_t - tm_pre;
+#endif
+  while (have) {
+    __syncthreads();                                 // this region landed (the barrier drains the DMA); the other one is free
+    KH_TM(tm_bar, tm_t);
+    if (more) {issue_dma(nxt, buf ^ 1); rel_nxt = load_rel(nxt);}
+    const bool after = more && next_chunk(aft);
+    KH_TM(tm_issue, tm_t);
+    if (KH_LDS_EXP != 4) {score(cur, buf, rel_cur);}
+    KH_TM(tm_score, tm_t);
+    cur = nxt; nxt = aft; rel_cur = rel_nxt; buf ^= 1; have = more; more = after;
+#ifdef KH_LDS_TIMING
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ++tm_chunks;
+#endif
+    KH_TM(tm_tail, tm_t);
   }
   __syncthreads();
+#ifdef KH_LDS_TIMING
+  unsigned long long tm_epi = 0, tm_e1 = 0, tm_e2 = 0, tm_e3 = 0;
+  KH_TM(tm_bar, tm_t);
+#endif
 
-  // merge the eight waves of an angle (4 classes x 2 halves) in LDS, then one pose per thread
+  const size_t plane = (size_t)job.nx * job.ny;
+  const int ta = tid % kThreadsPerAngle;             // thread index inside the angle's team of NW waves
+  // merge the four waves of an angle in LDS (their four accumulator sets with the classes' shifts), then one pose per thread
   int32_t * s_tile = reinterpret_cast<int32_t *>(s_region) + q * (64 * PX);
-  for (int i = tid & 511; i < 64 * PX; i += 512) {s_tile[i] = 0;}
+  for (int i = ta; i < 64 * PX; i += kThreadsPerAngle) {s_tile[i] = 0;}
   __syncthreads();
+  KH_TM(tm_e1, tm_t);
   if (live) {
 #pragma unroll
-    for (int r = 0; r < RY; ++r) {
-      if (S == 1) {
-        acc[r][0] += lo[r] & 0xffffu; acc[r][2] += lo[r] >> 16;
-        acc[r][1] += hi[r] & 0xffffu; acc[r][3] += hi[r] >> 16;
-      } else {
-        acc[r][0] += lo[r] & 0xffffu; acc[r][1] += lo[r] >> 16;
-      }
+    for (int c = 0; c < kClasses; ++c) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int j = 4 * lx + ((S == 1) ? b : 2 * b + (cls & 1));     // byte position inside the aligned tile row
-        const int x = (j - cls) / S;
-        if (j >= cls && x < PX && acc[r][b] != 0) {atomicAdd(&s_tile[(32 * half + 4 * r + ly) * PX + x], acc[r][b]);}
+      for (int r = 0; r < RQ; ++r) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int j = 4 * lx + b;                              // byte position inside the aligned window row
+          const int x = (j - c) / S;
+          const bool pose = j >= c && ((j - c) % S) == 0 && x < PX;
+          if (pose && acc[c][r][b] != 0) {atomicAdd(&s_tile[(4 * RQ * quarter + 4 * r + ly) * PX + x], acc[c][r][b]);}
+        }
       }
     }
   }
-  __syncthreads();
-  if (!live) {return;}
-  const int n_slow = job.counts[kCountsPerAngle * a + kClasses];
-  const int32_t * slow = job.slow + (size_t)a * P;
-  double best = 0.0;
-  const size_t plane = (size_t)job.nx * job.ny;
-  for (int p = tid & 511; p < 64 * PX; p += 512) {
+  // (the pose loop's inputs are fetched here, the accumulators' registers being free: on their way across the barrier)
+  constexpr int kPosesPerThread = (64 * PX + kThreadsPerAngle - 1) / kThreadsPerAngle;
+  // everything the pose loop reads from the job, once: behind a store the compiler has to assume the job block itself changed
+  // and re-reads every field through the scalar cache, a wait per field and pose
+  const int nx = job.nx, ny = job.ny;
+  const bool penal = job.do_penalize != 0, wr_resp = job.write_resp != 0;
+  const double denom = job.denom;
+  int32_t * const sums_out = job.sums + (size_t)(live ? a : 0) * plane;
+  double * const resp_out = wr_resp ? job.resp + (size_t)(live ? a : 0) * plane : nullptr;
+  const int32_t * const jbx = job.bx, * const jby = job.by;
+  const uint8_t * const jgrid = job.grid;
+  const int64_t data_size = job.data_size;
+  // the distance penalties of this thread's poses first, all in flight together
+  double dpen[kPosesPerThread];
+  const double apen = (live && penal) ? job.ang_pen[a] : 1.0;
+#pragma unroll
+  for (int k = 0; k < kPosesPerThread; ++k) {
+    const int p = ta + kThreadsPerAngle * k;
     const int yi = p / PX, xi = p % PX;
-    if (xi >= job.nx || yi >= job.ny) {continue;}
+    dpen[k] = (live && penal && xi < nx && yi < ny) ? job.dist_pen[yi * nx + xi] : 1.0;
+  }
+  __syncthreads();
+  KH_TM(tm_e2, tm_t);
+  const int n_slow = live ? job.counts[kCountsPerAngle * a + kClasses] : 0;
+  const int32_t * slow = job.slow + (size_t)(live ? a : 0) * P;
+  double best = 0.0;
+#pragma unroll
+  for (int k = 0; k < kPosesPerThread; ++k) {
+    const int p = ta + kThreadsPerAngle * k;
+    const int yi = p / PX, xi = p % PX;
+    if (!live || xi >= nx || yi >= ny) {continue;}
     int32_t sum = s_tile[p];
     if (n_slow > 0) {
       // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197)
-      const int64_t pose = (int64_t)job.bx[xi] + (int64_t)job.by[yi];
+      const int64_t pose = (int64_t)jbx[xi] + (int64_t)jby[yi];
       for (int j = 0; j < n_slow; ++j) {
         const int64_t idx = pose + slow[j];
-        if (idx >= 0 && idx < job.data_size) {sum += job.grid[idx];}
+        if (idx >= 0 && idx < data_size) {sum += jgrid[idx];}
       }
     }
-    const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
-    job.sums[o] = sum;
-    const double response = pose_response(job, sum, a, yi, xi);
-    if (job.write_resp) {job.resp[o] = response;}
-    best = response > best ? response : best;
-    if (job.coarse && response > 0.0) {
-      atomicMax(&job.out[kOutHeaderWords + (size_t)yi * job.nx + xi], (unsigned long long)__double_as_longlong(response));
+    const size_t o = (size_t)yi * nx + xi;
+    sums_out[o] = sum;
+    // pose_response with the penalties at hand (same operations: Mapper.cpp:1204, 671-685)
+    double response = (double)sum / denom;
+    if (penal) {
+      const double delta = response - 0.0;
+      const bool is_zero = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;
+      if (!is_zero) {response *= (dpen[k] * apen);}
     }
+    if (wr_resp) {resp_out[o] = response;}
+    best = response > best ? response : best;
   }
+  KH_TM(tm_e3, tm_t);
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) {
     const double o = __shfl_xor(best, sft);
     best = o > best ? o : best;
   }
-  if (lane == 0 && best > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(best));}
+  // angle maximum -> K4 skips the angles without ties (one scoring tile per angle on this path); one atomic per angle
+  __shared__ double s_best[2 * NW];
+  if (lane == 0) {s_best[wave] = best;}
+  __syncthreads();
+  if (live && ta == 0) {
+    const double * wb = s_best + NW * q;
+    double b = wb[0];
+#pragma unroll
+    for (int t = 1; t < NW; ++t) {b = wb[t] > b ? wb[t] : b;}
+    if (job.tile_best) {job.tile_best[a] = b;}
+    if (b > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(b));}
+  }
+#ifdef KH_LDS_TIMING
+  KH_TM(tm_epi, tm_t);
+  if (lane == 0 && job.load_counter && (blockIdx.x % 61) == 0) {     // a sample of the workgroups: the reports must not disturb the run
+    unsigned long long * c = job.load_counter;
+    atomicAdd(c + 1, tm_pre); atomicAdd(c + 2, tm_bar); atomicAdd(c + 3, tm_issue); atomicAdd(c + 4, tm_score);
+    atomicAdd(c + 5, tm_tail); atomicAdd(c + 6, tm_epi); atomicAdd(c + 7, tm_t - tm_start); atomicAdd(c + 8, tm_chunks); atomicAdd(c + 9, 1ull);
+    atomicAdd(c + 10, tm_e1); atomicAdd(c + 11, tm_e2); atomicAdd(c + 12, tm_e3);
+  }
+#endif
 }
+#undef KH_TM
 
 void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream)
 {
@@ -2161,21 +2376,28 @@ void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int
   const int xcd_map = n_jobs >= 8 ? 1 : 0;
   const int jobs_per_xcd = (n_jobs + 7) / 8;
   const long long blocks = xcd_map ? 8ll * jobs_per_xcd * groups : (long long)n_jobs * groups;
-  constexpr int kDyn = 2 * kLdsRegionBytes;
+  constexpr int kDyn = 2 * kLdsRegionBytes + 3 * 4 * 2 * kLdsPitch + 16;      // two regions + the zero strip (row step of the two-cell instance)
+  // KH_LDS_WAVES=4: four waves per angle (16 rows each, 512 threads, 4 waves per SIMD) instead of eight (8 rows each, 1024 threads)
+#ifndef KH_LDS_NW
+#define KH_LDS_NW 4
+#endif
+  static const int nw = std::getenv("KH_LDS_WAVES") ? std::atoi(std::getenv("KH_LDS_WAVES")) : KH_LDS_NW;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_offsets_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(int32_t) * 2 * kGroupAngles * 2048));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
+#define KH_SCORE_LDS(SV, NWV) hipLaunchKernelGGL((k_score_lds<SV, NWV>), dim3((unsigned int)blocks), dim3(128 * NWV), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map)
   if (sx_variant == 2) {
-    hipLaunchKernelGGL(k_score_lds<2>, dim3((unsigned int)blocks), dim3(1024), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
+    if (nw == 4) {KH_SCORE_LDS(2, 4);} else {KH_SCORE_LDS(2, 8);}
   } else {
-    hipLaunchKernelGGL(k_score_lds<1>, dim3((unsigned int)blocks), dim3(1024), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map);
+    if (nw == 4) {KH_SCORE_LDS(1, 4);} else {KH_SCORE_LDS(1, 8);}
   }
+#undef KH_SCORE_LDS
 }
 
 }  // namespace kh

@@ -253,10 +253,14 @@ class ScanMatcher:
         return out
 
     def set_debug(self, keep_response_volume: bool, lds_score: bool = False, dense_score: bool = False,
-                  force_chunks: bool = False, no_dual_copy: bool = False, mfma_score: bool = False):
+                  force_chunks: bool = False, no_dual_copy: bool = False, mfma_score: bool = False,
+                  windowed_score: bool = False):
+        """lds_score: the LDS-staged scoring kernels for every search they can take (default: the large ones only);
+        windowed_score: for none (the windowed kernel scores everything)."""
         capi.check(capi.lib().kh_matcher_set_debug(self._h, int(bool(keep_response_volume)) | (2 if lds_score else 0) |
                                                    (4 if dense_score else 0) | (8 if force_chunks else 0) |
-                                                   (16 if no_dual_copy else 0) | (32 if mfma_score else 0)),
+                                                   (16 if no_dual_copy else 0) | (32 if mfma_score else 0) |
+                                                   (64 if windowed_score else 0)),
                    "kh_matcher_set_debug")
 
     def volume(self, slot=0, responses=True):

@@ -269,9 +269,10 @@ def test_search_resolution_off_the_grid_pitch(kartohip_lib, search_res):
 
 @pytest.mark.parametrize("preset,fine", [("K", False), ("S", False), ("S", True), ("C2", False)])
 def test_lds_staged_scoring_path(kartohip_lib, preset, fine):
-    """The experimental LDS-staged scoring kernels (k_offsets_lds / k_score_lds: window unions of beam
-    sub-chunks staged through LDS, 4 adjacent angles per workgroup) must produce the same volume bit for
-    bit; K also exercises the fallback of beams whose windows are too far apart for the LDS budget."""
+    """The LDS-staged scoring kernels (k_offsets_lds / k_score_lds: the union of the windows of a run of consecutive beams
+    at two adjacent angles staged through LDS, byte sums on the matrix cores) must produce the same volume bit for bit -- on
+    every search shape they can take, not only the large ones they score by default; K also exercises the fallback of beams
+    whose windows at the two angles are too far apart for one region."""
     import math
     sc = Scenario(seed=5, n_base=8, start=60, perturb=(-0.04, 0.06, -0.03))
     oq, ob = sc.oracle_scans()
@@ -315,9 +316,9 @@ def test_empty_window_skipping_is_invisible(kartohip_lib, preset):
     om = make_oracle_matcher(preset, threads=8)
     res = None
     vols = []
-    for dense in (False, True):
+    for dense, windowed in ((False, False), (True, False), (False, True), (True, True)):
         hm = make_hip_matcher(preset)
-        hm.set_debug(True, dense_score=dense)
+        hm.set_debug(True, dense_score=dense, windowed_score=windowed)
         hm.AddScans(hq, hb)
         if res is None:
             om.add_scans(oq, ob)
@@ -389,7 +390,7 @@ def test_dual_copy_layout_follows_the_grid(kartohip_lib):
     args = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
     om = make_oracle_matcher("C2", threads=8)
     hm = make_hip_matcher("C2")
-    hm.set_debug(True)
+    hm.set_debug(True, windowed_score=True)             # the windowed kernel (a config-2 search takes the LDS-staged one by default)
     results = []
     for seed, start in ((7, 0), (8, 120), (9, 40)):
         sc = Scenario(seed=seed, n_base=10, start=start)
@@ -404,17 +405,22 @@ def test_dual_copy_layout_follows_the_grid(kartohip_lib):
         assert np.array_equal(bits(vol[..., 0]), bits(resp)), f"scene {seed}: response volume differs"
         _assert_same(r_o, r_h, "response"); _assert_same(mean_o, mean_h, "mean"); _assert_same(cov_o, cov_h, "covariance")
         results.append((hq, sc.query_pose, sums.copy()))
-    hm.set_debug(True, no_dual_copy=True)
+    hm.set_debug(True, no_dual_copy=True, windowed_score=True)
     hq, pose, sums = results[-1]
     hm.CorrelateScan(hq, pose, *args, True, None, False)
     sums2, _ = hm.volume()
     assert np.array_equal(sums, sums2)
     # the matrix-core instance of the scoring kernel (kh_matcher_set_debug bit 5): the same integer sums
     for no_copies in (False, True):
-        hm.set_debug(True, no_dual_copy=no_copies, mfma_score=True)
+        hm.set_debug(True, no_dual_copy=no_copies, mfma_score=True, windowed_score=True)
         hm.CorrelateScan(hq, pose, *args, True, None, False)
         sums3, _ = hm.volume()
         assert np.array_equal(sums, sums3), f"MFMA scoring differs (copies off: {no_copies})"
+    # ... and the default: the LDS-staged kernels (same slot, same grid)
+    hm.set_debug(True)
+    hm.CorrelateScan(hq, pose, *args, True, None, False)
+    sums4, _ = hm.volume()
+    assert np.array_equal(sums, sums4), "default (LDS-staged) scoring differs from the windowed kernel"
     hm.close()
 
 
