@@ -40,7 +40,10 @@ L1_PEAK_GBS = 64.0 * 256 * 2.4
 L1_MEASURED_CEILING_GBS = 37600.0
 L1_HIT_CLOCKS_PER_LOAD, L1_MISS_CLOCKS_PER_LINE = 4.2, 0.95
 FP64_PEAK_TFLOPS = 78.6            # MI355X FP64 vector = matrix peak (spec); v_mfma_f64_16x16x4_f64
-PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r3_k_score_pmc.json", "r2_k_score_pmc.json", "r1_k_score_pmc.json"))
+# LDS read port for ds_read_b32: 128 B per clock per CU (MI355X_MICROARCH.md, LDS table) x 256 CUs x 2.4 GHz
+LDS_B32_PEAK_GBS = 128.0 * 256 * 2.4
+SCORE_KERNEL = "k_score_lds<1,4>"
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r4_k_score_pmc.json", "r3_k_score_pmc.json", "r2_k_score_pmc.json", "r1_k_score_pmc.json"))
                  if os.path.exists(p)), os.path.join(ROOT, "profiles", "r1_k_score_pmc.json"))
 
 
@@ -809,12 +812,142 @@ def occupancy_leg(device=0, n_scans=1000):
     return out
 
 
+def loop_leg_devices(devices, n_pairs=256):
+    """BASELINE config[2] on the devices of an N > 1 run, from ONE process: the 256 distinct loop-closure pairs dealt round robin
+    over one (preset L, preset S) matcher pair per device, each pair driven by its own host thread through
+    kh_loop_closure_batch (the C call releases the GIL) -- how kh_mapper_create_on_devices deals TryCloseLoop's candidate
+    batches (MapperGraph::TryCloseLoop, Mapper.cpp:1500-1561).  The graph's scans are resident on the device that reads them."""
+    import threading
+    from common import LASER, OFFLINE_PARAMS, PRESETS
+    from slam_toolbox_amd import synth
+    from slam_toolbox_amd.scan_matcher import LocalizedRangeScan, LoopClosureBatch, MapperParams, ScanMatcher
+    lb = synth.loop_batch(n_pairs)
+    nm = len(devices)
+    mp = MapperParams(**OFFLINE_PARAMS)
+    members = []
+    for k, dev in enumerate(devices):
+        ids = list(range(k, n_pairs, nm))
+        cache = {}
+
+        def scan_at(i, dev=dev, cache=cache):
+            if i not in cache:
+                cache[i] = LocalizedRangeScan(lb["ranges"][i], lb["truth"][i], LASER.min_angle, LASER.ang_res).MakeResident(dev)
+            return cache[i]
+        queries = [LocalizedRangeScan(lb["ranges"][lb["pairs"][u][0]], lb["pairs"][u][1], LASER.min_angle, LASER.ang_res) for u in ids]
+        chains = [[scan_at(i) for i in lb["pairs"][u][2]] for u in ids]
+        mL = ScanMatcher.Create(mp, *PRESETS["L"]["create"], device=dev, max_batch=len(ids))
+        mS = ScanMatcher.Create(mp, *PRESETS["S"]["create"], device=dev, max_batch=len(ids))
+        members.append((mL, mS, ScanMatcher.pack_batch(queries, chains), cache))
+    passed = [0] * nm
+
+    def run():
+        def work(k):
+            mL, mS, pack, _ = members[k]
+            o = LoopClosureBatch(mL, mS, None, None, LASER.min_angle, LASER.ang_res, 0.35, 9.0, pieces=1, packed=pack)
+            passed[k] = int(o["passed"].sum())
+        th = [threading.Thread(target=work, args=(k,)) for k in range(nm)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    run()
+    times = []
+    for _ in range(5):
+        t = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t)
+    for mL, mS, _, _ in members:
+        mL.close(); mS.close()
+    med = float(np.median(times))
+    return {"loop_batch_ms": med * 1e3, "loop_pairs_per_s": n_pairs / med, "loop_batch_devices": list(map(int, devices)),
+            "loop_batch_passed_gate": int(sum(passed)),
+            "loop_workload": f"{n_pairs} distinct pairs dealt over {nm} (preset L, preset S) matcher pairs, one per device, from one process "
+                             f"(kh_loop_closure_batch per member, a host thread each)"}
+
+
+def replay_leg_devices(devices, n_scans=1500):
+    """BASELINE config[4] on the devices of an N > 1 run: the lifelong replay through kh_mapper_create_on_devices (candidate
+    batches of TryCloseLoop / near chains dealt over one matcher pair per device), next to the same queue on the first device
+    alone: the two runs must end with the same poses bit for bit (dealing the candidates does not change which one is
+    accepted first)."""
+    from slam_toolbox_amd import replay
+    many = replay.run(n_scans, lifelong=True, mode="sync", device=devices[0], devices=list(devices))
+    one = replay.run(n_scans, lifelong=True, mode="sync", device=devices[0])
+    same = bool(many["poses"].shape == one["poses"].shape and np.array_equal(many["poses"], one["poses"]))
+    st = many["stats"]
+    return {"replay_scans_per_s": many["scans_per_s"], "replay_scans_per_s_one_device": one["scans_per_s"],
+            "replay_devices": list(map(int, devices)), "replay_poses_identical_to_one_device": same,
+            "replay_workload": f"{n_scans}-scan lap circuit, lifelong mode, sync queue through kh_mapper_create_on_devices({list(devices)}): "
+                               f"{many['accepted']} accepted, {many['alive']} alive, {st['loop_closures']} loop closures"}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run on 127.0.0.1) and hand their single JSON line through.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, KH_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# keys of the JSON line in the order they are printed: the contract's first, then every BASELINE metric, then the rest; the
+# long texts (workload descriptions, notes, per-form arrays) go to the details file, not into the line
+LINE_ORDER = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "solve_ms", "solve_ms_cached_analysis", "solve_ms_edge_sharded", "loop_batch_ms", "loop_pairs_per_s", "replay_scans_per_s",
+              "value_windows", "value_no_skipping", "value_dense_world", "roofline", "cpu_baseline"]
+LINE_BUDGET = 6000
+
+
+def is_long_text(v):
+    return isinstance(v, str) and len(v) > 60
+
+
+def compact(v, depth=0):
+    """the value as it goes into the line: notes, per-form arrays and long texts dropped (`sample` and `workload` cut to a
+    sentence), floats rounded to 6 significant digits"""
+    if isinstance(v, float):
+        return float(f"{v:.6g}") if math.isfinite(v) else None
+    if isinstance(v, dict):
+        out = {}
+        for k, x in v.items():
+            if k in ("note", "forms", "traffic_source"):
+                continue
+            if k in ("sample", "workload") and isinstance(x, str):
+                out[k] = x if len(x) <= 140 else x[:137] + "..."
+            elif not is_long_text(x):
+                out[k] = compact(x, depth + 1)
+        return out
+    if isinstance(v, (list, tuple)):
+        return [compact(x, depth + 1) for x in v]
+    return v
+
+
+def build_line(full):
+    """ONE line of at most LINE_BUDGET bytes: ordered keys first, the remaining short scalars after them while they fit."""
+    line = {}
+    for k in LINE_ORDER:
+        if k in full and (full[k] is not None or k == "vs_baseline"):
+            line[k] = compact(full[k])
+    rest = [k for k in full if k not in line and not is_long_text(full[k])]
+    # scalars before containers, so that a tail cut by a reader loses the least
+    rest.sort(key=lambda k: (isinstance(full[k], (dict, list)), k))
+    for k in rest:
+        cand = dict(line)
+        cand[k] = compact(full[k])
+        if len(json.dumps(cand)) <= LINE_BUDGET:
+            line = cand
+    return line
+
+
 def main():
     # ONE JSON line on stdout: everything else a library prints there (RCCL's version banner at communicator creation,
     # gloo's connection notes, karto's "Registering sensor") is pointed at stderr for the whole run
-    sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -822,17 +955,27 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--streams", type=int, default=1,
                     help="matcher handles (each its own HIP stream and host thread) a rank drives concurrently; "
-                         "a step is still ONE batch of --batch matches on one of them.  The default 1 keeps the "
-                         "per-launch kernel time of the roofline unambiguous; 2 overlaps the host half of one step "
-                         "with the kernels of another and is reported as the extra key two_stream_value")
+                         "a step is still ONE batch of --batch matches on one of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solver", action="store_true")
     ap.add_argument("--no-loop", action="store_true")
-    ap.add_argument("--no-two-stream", action="store_true", help="(default) kept for old command lines")
-    ap.add_argument("--two-stream", action="store_true",
-                    help="also time the same steps dealt to two handles on two host threads (extra key two_stream_value); since "
-                         "one handle pipelines its own chunks this no longer beats the single handle")
+    ap.add_argument("--no-variants", action="store_true", help="skip the no-skipping / dense-world variants of the headline")
+    ap.add_argument("--details", default=os.path.join(ROOT, "profiles", "bench_details_latest.json"),
+                    help="where the full record (every key, notes, workload texts) is written; '' = nowhere")
+    ap.add_argument("--verbose", action="store_true", help="print the full record on the line instead of the compact one")
     args = ap.parse_args()
+
+    # --gpus is honoured: N > 1 without a launcher around us -> start the N ranks; a launcher whose world size differs -> refuse
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}: refusing to report a line for the wrong size\n")
+        raise SystemExit(2)
+
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     # last resort against a stuck collective or a teardown that never returns: after KH_BENCH_WATCHDOG seconds
     # (default 30 min, far beyond any default run) every thread's Python stack goes to stderr and the process exits
@@ -848,6 +991,10 @@ def main():
     # one process per GPU.  KH_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a single-GPU box (ranks
     # then share the device); the driver's multi-GPU run uses the default, nccl = RCCL.
     backend = os.environ.get("KH_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s); RCCL needs one device per rank "
+                         f"(KH_BENCH_BACKEND=gloo shares a device for functional runs)\n")
+        raise SystemExit(2)
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -865,95 +1012,121 @@ def main():
     from slam_toolbox_amd import shard
     B = args.batch
     S = max(1, args.streams)
-    # B independent (query, chain of 10 base scans) pairs along the synthetic warehouse trajectory,
-    # different per rank; grids rasterised once -> resident in HBM.  Every handle holds the same B pairs.
-    queries, centers, bases = [], [], []
-    for b in range(B):
-        sc = Scenario(seed=1000 * rank + b, n_base=10, start=(37 * (rank * B + b)) % 380,
-                      perturb=(0.04 * math.sin(b), -0.03 * math.cos(b), 0.01 * (b % 5 - 2)))
-        q, base = sc.hip_scans()
-        queries.append(q)
-        bases.append(base)
-        centers.append(sc.query_pose)
-    handles = []
-    for _ in range(S):
+    corr = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+
+    def make_pairs(n_distinct, **scenario_kw):
+        """(queries, centers, bases) of B pairs; n_distinct < B tiles the distinct ones"""
+        qs, cs, bs = [], [], []
+        for b in range(n_distinct):
+            sc = Scenario(seed=1000 * rank + b, start=(37 * (rank * B + b)) % 380,
+                          perturb=(0.04 * math.sin(b), -0.03 * math.cos(b), 0.01 * (b % 5 - 2)), **scenario_kw)
+            q, base = sc.hip_scans()
+            qs.append(q); bs.append(base); cs.append(sc.query_pose)
+        idx = [b % n_distinct for b in range(B)]
+        return [qs[i] for i in idx], np.asarray([cs[i] for i in idx]), [bs[i] for i in idx]
+
+    def make_handle(queries, bases):
         h = ScanMatcher.Create(MapperParams(**C2_PARAMS), *PRESETS["C2"]["create"], device=local_rank, max_batch=B)
         for b in range(B):
             h.AddScans(queries[b], bases[b], slot=b)
-        handles.append(h)
-    hm = handles[0]
-    arr = (_scan_array(queries), B)
-    centers = np.asarray(centers)
-    corr = ((0.15, 0.15), (0.005, 0.005), math.radians(20.0), math.radians(0.5))
+        return h
 
-    def step(h):
-        return h.CorrelateScanBatch(None, centers, *corr, True, False, scan_array=arr)
+    # B independent (query, chain of 10 base scans) pairs along the synthetic warehouse trajectory,
+    # different per rank; grids rasterised once -> resident in HBM.  Every handle holds the same B pairs.
+    queries, centers, bases = make_pairs(B, n_base=10)
+    handles = [make_handle(queries, bases) for _ in range(S)]
+    arr = (_scan_array(queries), B)
+
+    def step(h, c=centers, a=arr):
+        return h.CorrelateScanBatch(None, c, *corr, True, False, scan_array=a)
+
+    def timed(hs, n_steps, c=centers, a=arr):
+        """n_steps steps dealt round-robin to the handles `hs` (one host thread each); returns (seconds, per-step seconds of the
+        first handle's thread, last result).  Barrier + synchronize on both sides; max over ranks."""
+        import threading
+        results = [None] * len(hs)
+        per_step = []
+
+        def worker(k):
+            out = None
+            for _ in range(k, n_steps, len(hs)):
+                t = time.perf_counter()
+                out = step(hs[k], c, a)
+                if k == 0:
+                    per_step.append(time.perf_counter() - t)
+            results[k] = out
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(hs))]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        for out in results:
+            if out is not None:
+                resp, means, covs, status = out
+                # (KH_BENCH_NO_CHECK: measurement builds whose kernels skip work on purpose, tools/build_variant.sh)
+                assert os.environ.get("KH_BENCH_NO_CHECK") or ((status == 0).all() and (resp > 0.1).all()), "matches failed"
+        return (shard.max_over_ranks(dt, device="cuda") if world > 1 else dt), per_step
 
     for _ in range(args.warmup):
         for h in handles:
             step(h)
     for h in handles:
-        h.profile(True)       # HIP events on the library's stream around every K3 launch
-    # steps are dealt round-robin to the handles; each handle runs its steps on its own host thread (the C ABI
-    # call releases the GIL), so the exact host half of one step overlaps the kernels of another
-    import threading
-    results = [None] * S
-
-    def worker(k):
-        out = None
-        for _ in range(k, args.steps, S):
-            out = step(handles[k])
-        results[k] = out
-    threads = [threading.Thread(target=worker, args=(k,)) for k in range(S)]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+        h.profile(True)       # HIP events on the library's stream around every scoring launch
+    dt, per_step = timed(handles, args.steps)
     wave_loads = sum(h.score_loads() for h in handles)
     profs = [h.profile(False) for h in handles]
     prof = {k: sum(p[k] for p in profs) for k in profs[0]}
-    two_stream = None
-    if S == 1 and args.two_stream and not args.no_two_stream:
-        # extra key: the same steps dealt to TWO handles on two host threads (not the headline: the kernels of the two
-        # streams overlap, so per-launch event times are no longer those of an isolated kernel)
-        h2 = ScanMatcher.Create(MapperParams(**C2_PARAMS), *PRESETS["C2"]["create"], device=local_rank, max_batch=B)
-        for b in range(B):
-            h2.AddScans(queries[b], bases[b], slot=b)
-        pair = [handles[0], h2]
-        for h in pair:
-            step(h)
 
-        def worker2(k):
-            for _ in range(k, args.steps, 2):
-                step(pair[k])
-        th = [threading.Thread(target=worker2, args=(k,)) for k in range(2)]
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t2 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        two_stream = shard.max_over_ranks(time.perf_counter() - t2, device="cuda") if world > 1 else time.perf_counter() - t2
-        h2.close()
-    for out in results:
-        if out is not None:
-            resp, means, covs, status = out
-            # (KH_BENCH_NO_CHECK: measurement builds whose kernels skip work on purpose, tools/build_variant.sh)
-            assert os.environ.get("KH_BENCH_NO_CHECK") or ((status == 0).all() and (resp > 0.1).all()), "matches failed"
-    dt = shard.max_over_ranks(dt, device="cuda")
+    full = {}          # every key of the record; the line is cut from it
+    variants = {}
+    if not args.no_variants and S == 1:
+        # (a) the same batch with empty-window skipping switched off (kh_matcher_set_debug bit 2): every one of the 81 x 1081 windows
+        # of a match is scored whatever the grid holds -- the strict worst case, what a world without free space would cost
+        n_var = max(5, args.steps // 4)
+        hm = handles[0]
+        hm.set_debug(False, dense_score=True)
+        step(hm)
+        hm.profile(True)
+        dtv, _ = timed([hm], n_var)
+        loads_v = hm.score_loads()
+        pv = hm.profile(False)
+        hm.set_debug(False)
+        variants["value_no_skipping"] = world * B * n_var / dtv
+        variants["no_skipping"] = {"steps": n_var, "ms_per_step": dtv / n_var * 1e3, "k3_launch_ms": pv["score_ms"] / max(1, pv["score_launches"]),
+                                   "window_reads_per_launch": loads_v / max(1, pv["score_launches"])}
+        # (b) a denser world: 400 pillars, 40 base scans five poses apart -> 1.5 % of the grid non-zero (default 0.45 %); 16 distinct
+        # pairs tiled over the batch (the slots are what the kernel sees: 256 grids either way)
+        try:
+            q2, c2, b2 = make_pairs(16, n_base=40, step=5, n_pillars=400, n_traj=600)
+            h2 = make_handle(q2, b2)
+            a2 = (_scan_array(q2), B)
+            for _ in range(2):
+                step(h2, c2, a2)
+            h2.profile(True)
+            dtd, _ = timed([h2], n_var, c2, a2)
+            loads_d = h2.score_loads()
+            pd = h2.profile(False)
+            nz = None
+            try:
+                g = h2.GetCorrelationGrid(0)
+                nz = float((np.asarray(g) != 0).mean())
+            except Exception:
+                pass
+            h2.close()
+            variants["value_dense_world"] = world * B * n_var / dtd
+            variants["dense_world"] = {"steps": n_var, "ms_per_step": dtd / n_var * 1e3, "k3_launch_ms": pd["score_ms"] / max(1, pd["score_launches"]),
+                                       "window_reads_per_launch": loads_d / max(1, pd["score_launches"]), "grid_nonzero_frac": nz,
+                                       "distinct_pairs": 16, "base_scans": 40, "pillars": 400}
+        except Exception as exc:
+            variants["dense_world_error"] = repr(exc)[:200]
 
     solver_out = None
     if not args.no_solver:
@@ -978,88 +1151,93 @@ def main():
         if world > 1:
             dist.barrier()
         if rank == 0:
+            devices = list(range(world)) if backend == "nccl" else [local_rank] * world
             try:
-                strong_out["strong_scaling_in_process"] = group_leg(list(range(world)))
+                strong_out["strong_scaling_in_process"] = group_leg(devices)
                 if world == 1:
                     strong_out["strong_scaling_in_process_two_members_one_gpu"] = group_leg([0, 0])
             except Exception as exc:
                 strong_out["group_leg_error"] = repr(exc)[:200]
+            if world > 1:
+                # config[2] and config[4] on the devices of the run, from this one process: the loop-closure batch dealt over one
+                # (preset L, preset S) matcher pair per device, and the lifelong replay through kh_mapper_create_on_devices
+                try:
+                    strong_out.update(loop_leg_devices(devices))
+                except Exception as exc:
+                    strong_out["loop_leg_devices_error"] = repr(exc)[:200]
+                try:
+                    strong_out.update(replay_leg_devices(devices))
+                except Exception as exc:
+                    strong_out["replay_leg_devices_error"] = repr(exc)[:200]
         if world > 1:
             dist.barrier()
     if rank == 0:
         k3_ms = prof["score_ms"] / max(1, prof["score_launches"])
-        # a step's batch is scored in sub-batches (pipelined with the host half): matches per k_score launch
+        # a step's batch is scored in sub-batches (pipelined with the host half): matches per scoring launch
         per_launch = B * args.steps / max(1, prof["score_launches"])
         alg = ALG_BYTES_C2 * per_launch
         alg_gbs = alg / (k3_ms * 1e-3) / 1e9
-        # L1 side, measured live: K2 tallies on the device the wave-level dword loads (256 B each) K3 issues
+        # LDS side, measured live: K2' tallies on the device the wave-level ds_read_b32 (256 B each) K3' issues for the windows it keeps
         loads_per_launch = wave_loads / max(1, prof["score_launches"])
-        l1_gbs = loads_per_launch * 256.0 / (k3_ms * 1e-3) / 1e9
-        rec = pmc_recorded()
+        lds_gbs = loads_per_launch * 256.0 / (k3_ms * 1e-3) / 1e9
         traffic = pmc_traffic(per_launch)
-        rec_scale = per_launch / float(rec.get("matches_per_launch", per_launch)) if rec else 1.0
-        clocks_per_load = k3_ms * 1e-3 * 2.4e9 * 256 / max(1.0, loads_per_launch)
-        model_clocks = None
-        if rec.get("TCP_TCC_READ_REQ_sum") and rec.get("SQ_INSTS_VMEM_RD"):
-            model_clocks = L1_HIT_CLOCKS_PER_LOAD + L1_MISS_CLOCKS_PER_LINE * rec["TCP_TCC_READ_REQ_sum"] / rec["SQ_INSTS_VMEM_RD"]
-        tag_frac = None
-        if rec.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
-            # one tag lookup per clock per CU: recorded TCP accesses per launch against 256 CUs x 2.4 GHz x this run's launch time
-            tag_frac = rec["TCP_TOTAL_CACHE_ACCESSES_sum"] * rec_scale / (256 * 2.4e9 * k3_ms * 1e-3)
-        out = {
+        windows = [per_step[i::5] for i in range(5)] if len(per_step) >= 5 else [per_step]
+        rates = sorted(world * B * len(w) / sum(w) for w in windows if w)
+        full.update({
             "metric": "scan-matches/sec", "value": world * B * args.steps / dt, "unit": "scan-matches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 gather / i32 sum / f64 penalty",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: single-scan CorrelateScan, 1081 beams, 0.3m x 0.3m x +-20deg @ 5mm/0.5deg "
-                                   "(61x61x81 poses), 8087^2 grid", "matches_per_step_per_gpu": B,
-                       "parallelism": f"{world} x independent match shards (no collective)",
-                       "streams_per_gpu": S},
-            # the dominant kernel is a cache-resident gather: the resource it leans on is the L1 (TCP), not HBM.  `frac`
-            # is the live L1->register byte rate against the L1 data path; the HBM side (recorded PMC) and the
-            # reference's algorithmic access stream are kept beside it, each labelled.
-            "roofline": {"bound": "l1", "kernel": "k_score<1,8,1>", "achieved": l1_gbs, "peak": L1_PEAK_GBS,
-                         "unit": "GB/s", "frac": l1_gbs / L1_PEAK_GBS,
-                         "wave_loads_per_launch": loads_per_launch, "avg_launch_ms": k3_ms, "matches_per_launch": per_launch,
-                         "l1_tag_lookup_frac": tag_frac,
-                         "l1_measured_ceiling_gbs": L1_MEASURED_CEILING_GBS, "frac_of_measured_ceiling": l1_gbs / L1_MEASURED_CEILING_GBS,
-                         "clocks_per_load": clocks_per_load, "clocks_per_load_model": model_clocks,
-                         "traffic": traffic, "traffic_source": "recorded: " + os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 PMC passes of this "
-                                                               "command; (2*FETCH_SIZE + WRITE_SIZE)*1024, scaled to this run's matches per launch)",
-                         "hbm_frac": (traffic / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "config": {"workload": "BASELINE config[1]: CorrelateScan 1081 beams 61x61x81 poses", "matches_per_step_per_gpu": B,
+                       "parallelism": f"{world} x independent match shards (no collective)", "streams_per_gpu": S},
+            "config_workload": "BASELINE config[1]: single-scan CorrelateScan, 1081 beams, 0.3m x 0.3m x +-20deg @ 5mm/0.5deg "
+                               "(61x61x81 poses), 8087^2 grid",
+            # per-step wall times of the timed region, dealt into five interleaved windows: spread of the headline
+            "value_windows": {"n": len(rates), "median": float(np.median(rates)) if rates else None, "min": rates[0] if rates else None,
+                              "max": rates[-1] if rates else None, "steps_per_window": len(windows[0]) if windows else 0},
+            # the dominant kernel reads LDS-resident window unions: the resource it leans on is the LDS read port (ds_read_b32:
+            # 128 B / clk / CU), not HBM.  `frac` is the live LDS->register byte rate against that port; the HBM side (recorded
+            # PMC) and the reference's algorithmic access stream are kept beside it, each labelled.
+            "roofline": {"bound": "lds", "kernel": SCORE_KERNEL, "achieved": lds_gbs, "peak": LDS_B32_PEAK_GBS,
+                         "unit": "GB/s", "frac": lds_gbs / LDS_B32_PEAK_GBS,
+                         "window_reads_per_launch": loads_per_launch, "avg_launch_ms": k3_ms, "matches_per_launch": per_launch,
+                         "traffic": traffic, "hbm_frac": (traffic / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "algorithmic_gbs": alg_gbs, "algorithmic_ratio": alg_gbs / HBM_PEAK_GBS,
-                         "note": "bound = the vector L1 (TCP).  `frac` = live L1->register byte rate over the data-path peak (64 B/clk/CU); "
-                                 "`frac_of_measured_ceiling` = the same over what a loop of the same load shape reaches on an L1-resident "
-                                 "window (profiles/r3_tcp_ceiling.txt: 37.6 TB/s, 4.2 clocks per load for 4..8 lines per load -- tag look-ups "
-                                 "and data return overlap, which retires round 2's serial tags+data model and its 'speed of light' reading).  "
-                                 "`clocks_per_load_model` = 4.2 + 0.95 x (L2 read requests per load, recorded PMC) from the same probe's "
-                                 "L1-miss/L2-hit rows; the kernel needs `clocks_per_load`: the rest is not bandwidth of either cache "
-                                 "(DESIGN.md section 4); HBM `hbm_frac` (L2 hit %.1f %%, L1 hit %.1f %% recorded).  "
-                                 "algorithmic_ratio = the reference's own access stream (5 B per lookup, every lookup) over the launch "
-                                 "time against 8 TB/s: it exceeds 1 because the kernel reads cache-resident windows, 4 lookups per "
-                                 "dword, and skips windows that hold only zeros -- it is not a fraction of a hardware limit"
-                                 % pmc_rates()},
-        }
+                         "traffic_source": "recorded: " + os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 PMC passes of this command; "
+                                           "(2*FETCH_SIZE + WRITE_SIZE)*1024, scaled to this run's matches per launch)",
+                         "note": "bound = the LDS read port.  A window (one beam at one angle: 64 bytes x 64 rows) is read from a staged LDS region "
+                                 "with sixteen wave-level ds_read_b32 of 256 B; `achieved` = windows kept x 4 KB over the launch time, `peak` = 128 B/clk/CU "
+                                 "x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS table); the byte sums run on the matrix cores (v_mfma_i32_16x16x64_i8, "
+                                 "one per KB read).  algorithmic_ratio = the reference's own access stream (5 B per lookup, every lookup) over the "
+                                 "launch time against 8 TB/s: it exceeds 1 because the kernel reads LDS-resident windows, 4 lookups per dword, and "
+                                 "skips windows that hold only zeros -- it is not a fraction of a hardware limit"},
+        })
+        full.update(variants)
         if world == 1 and not args.no_cpu_baseline:
             with _StdoutToStderr():
-                out["cpu_baseline"] = cpu_baseline()
-        if two_stream:
-            out["two_stream_value"] = world * B * args.steps / two_stream
-            out["two_stream_ms_per_step"] = two_stream / args.steps * 1e3
+                full["cpu_baseline"] = cpu_baseline()
         if solver_out:
-            out.update(solver_out)
+            full.update(solver_out)
         if strong_out:
-            out.update(strong_out)
+            full.update(strong_out)
         if world == 1 and not args.no_loop:
-            out.update(loop_leg(local_rank, cpu=not args.no_cpu_baseline))
-            out.update(enumeration_leg(local_rank))
-            out.update(occupancy_leg(local_rank))
+            full.update(loop_leg(local_rank, cpu=not args.no_cpu_baseline))
+            full.update(enumeration_leg(local_rank))
+            full.update(occupancy_leg(local_rank))
             try:
-                out.update(replay_leg(local_rank, cpu=not args.no_cpu_baseline))
-                out.update(latency_leg(local_rank))
+                full.update(replay_leg(local_rank, cpu=not args.no_cpu_baseline))
+                full.update(latency_leg(local_rank))
             except Exception as exc:
-                out["replay_leg_error"] = repr(exc)[:200]
-        json_out.write(json.dumps(out) + "\n")
+                full["replay_leg_error"] = repr(exc)[:200]
+        if args.details:
+            try:
+                with open(args.details, "w") as f:
+                    json.dump(full, f, indent=1, sort_keys=True, default=str)
+                full["details_file"] = os.path.relpath(args.details, ROOT)
+            except OSError:
+                pass
+        line = full if args.verbose else build_line(full)
+        json_out.write(json.dumps(line, default=str) + "\n")
         json_out.flush()
     for h in handles:
         h.close()

@@ -30,8 +30,8 @@ PRESETS = {
 class Scenario:
     """n_base consecutive trajectory scans + one query scan whose pose is perturbed from the truth."""
 
-    def __init__(self, seed=7, n_base=10, start=0, perturb=(0.05, -0.03, 0.02), world_seed=12345, n_traj=400, step=1):
-        self.world = synth.make_world(world_seed)
+    def __init__(self, seed=7, n_base=10, start=0, perturb=(0.05, -0.03, 0.02), world_seed=12345, n_traj=400, step=1, n_pillars=40):
+        self.world = synth.make_world(world_seed, n_pillars)
         rng = np.random.default_rng(seed)
         truth, odom = synth.trajectory(n_traj)
         idx = [start + step * i for i in range(n_base + 1)]
