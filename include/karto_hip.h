@@ -315,6 +315,13 @@ KH_API int kh_spa_get_node(kh_spa * s, int32_t id, double pose[3]);    /* getGra
 KH_API int32_t kh_spa_num_nodes(kh_spa * s);
 KH_API int32_t kh_spa_num_constraints(kh_spa * s);
 KH_API int kh_spa_compute(kh_spa * s, kh_spa_summary * summary);       /* Compute (ceres_solver.cpp:214-269) */
+/* Trace of the last Compute(), one row of 8 doubles per trust-region iteration -- what ceres::IterationSummary holds for it, so
+ * that a Ceres run of the same problem (oracle/ceres_driver.cpp, where Ceres is installed) can be laid beside it line by line:
+ * [0] iteration (1-based), [1] cost of the iterate the step starts from, [2] cost of the candidate, [3] model cost change,
+ * [4] trust-region radius the step was computed with, [5] radius after the iteration's update, [6] step norm (scaled space),
+ * [7] verdict: 1 accepted, 0 rejected, -1 invalid step, 2 / 3 terminated on parameter / function tolerance.
+ * Writes min(capacity, rows) rows, *n_rows = rows available. */
+KH_API int kh_spa_iteration_log(kh_spa * s, int32_t capacity, double * rows, int32_t * n_rows);
 /* GetCorrections (ceres_solver.cpp:272): pass ids=NULL to query the count */
 KH_API int kh_spa_get_corrections(kh_spa * s, int32_t * n, int32_t * ids, double * poses /* 3n */);
 /* ---- pose-graph files.  The reference persists a Boost binary archive of the whole

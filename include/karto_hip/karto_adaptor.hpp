@@ -282,31 +282,37 @@ private:
   }
   void MakeResident(const karto::LocalizedRangeScanVector & rScans, std::vector<kh_scan> & base)
   {
+    const uint64_t callStart = m_ResidentClock;        // every scan this call touches gets a stamp above it
     size_t k = 0;
     for (karto::LocalizedRangeScan * p : rScans) {
       if (p == NULL) {continue;}
       MakeResident(p, base[k++]);
     }
-    Trim();
+    Trim(callStart);
   }
   void MakeResident(const karto::LocalizedRangeScanMap & rScans, std::vector<kh_scan> & base)
   {
+    const uint64_t callStart = m_ResidentClock;
     size_t k = 0;
     for (const auto & kv : rScans) {
       if (kv.second == NULL) {continue;}
       MakeResident(kv.second, base[k++]);
     }
-    Trim();
+    Trim(callStart);
   }
-  void Trim()
+  // Evicts least-recently-used scans down to the capacity -- but never one the CURRENT call touched (stamp above callStart):
+  // kh_matcher_match reads those device buffers right after.  A call whose base chain is larger than the capacity simply
+  // leaves the cache over its capacity until the next call trims it.
+  void Trim(uint64_t callStart)
   {
     if (m_Resident.size() <= m_ResidentCapacity) {return;}
-    // drop the least recently used half (never what this call just touched: those carry the newest stamps)
     std::vector<std::pair<uint64_t, int32_t>> order;
     order.reserve(m_Resident.size());
-    for (const auto & kv : m_Resident) {order.emplace_back(kv.second.used, kv.first);}
+    for (const auto & kv : m_Resident) {
+      if (kv.second.used <= callStart) {order.emplace_back(kv.second.used, kv.first);}
+    }
     std::sort(order.begin(), order.end());
-    for (size_t i = 0; i < order.size() / 2; ++i) {
+    for (size_t i = 0; i < order.size() && m_Resident.size() > m_ResidentCapacity; ++i) {
       auto it = m_Resident.find(order[i].second);
       kh_device_free(it->second.device_points);
       m_Resident.erase(it);

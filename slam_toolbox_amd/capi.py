@@ -75,7 +75,7 @@ SYMBOLS = [
     "kh_spa_options_default", "kh_spa_create", "kh_spa_set_debug", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
     "kh_spa_clear", "kh_spa_add_node", "kh_spa_add_constraint", "kh_spa_remove_node",
     "kh_spa_remove_constraint", "kh_spa_modify_node", "kh_spa_get_node", "kh_spa_num_nodes",
-    "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
+    "kh_spa_num_constraints", "kh_spa_compute", "kh_spa_iteration_log", "kh_spa_get_corrections", "kh_link_info", "kh_spa_set_sharding",
     "kh_spa_save", "kh_spa_load", "kh_spa_add_constraint_information", "kh_spa_get_node_at", "kh_spa_get_constraint", "kh_spa_get_nodes",
     "kh_graph_create", "kh_graph_destroy", "kh_graph_set", "kh_graph_set_positions", "kh_graph_find_loop_candidates",
     "kh_graph_last_kernel_ms", "kh_graph_find_near_chains", "kh_graph_closest_scan_to_pose", "kh_weighted_mean",
@@ -212,6 +212,7 @@ def lib():
         L.kh_spa_num_nodes.argtypes = [vp]
         L.kh_spa_num_constraints.argtypes = [vp]
         L.kh_spa_compute.argtypes = [vp, C.POINTER(KhSpaSummary)]
+        L.kh_spa_iteration_log.argtypes = [vp, C.c_int32, vp, C.POINTER(C.c_int32)]
         L.kh_spa_get_corrections.argtypes = [vp, C.POINTER(i32), vp, vp]
         L.kh_link_info.argtypes = [dptr, dptr, dptr, dptr, dptr]
         L.kh_spa_set_sharding.argtypes = [vp, i32, i32, ALLREDUCE_FN, vp]

@@ -171,9 +171,13 @@ int kh_device_malloc(int32_t device, int64_t bytes, void ** out)
     kh::set_error("no usable HIP device (libkartohip has no CPU fallback)");
     return KH_ERR_NO_DEVICE;
   }
-  if (hipSetDevice(device) != hipSuccess || hipMalloc(out, static_cast<size_t>(bytes > 0 ? bytes : 1)) != hipSuccess) {
-    kh::set_error("hipMalloc failed"); return KH_ERR_HIP;
-  }
+  // (the caller's current device is put back: the multi-device mapper calls this for every non-primary slot on the
+  // application's thread, and a host that shares the thread must not find its device switched)
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  const bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(out, static_cast<size_t>(bytes > 0 ? bytes : 1)) == hipSuccess;
+  if (prev >= 0 && prev != device) {(void)hipSetDevice(prev);}
+  if (!ok) {kh::set_error("hipMalloc failed"); return KH_ERR_HIP;}
   return KH_OK;
 }
 

@@ -25,6 +25,7 @@ namespace kh
 {
 void set_error(const std::string & s);
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
+int32_t matcher_max_batch(const kh_matcher * m);
 }
 
 struct kh_matcher_group
@@ -156,7 +157,20 @@ int kh_loop_closure_batch(kh_matcher * coarse, kh_matcher * fine, int32_t n, con
   if (!coarse || !fine || n < 0 || !queries || !base_begin || !coarse_means || !coarse_covs || !coarse_responses || !passed || !fine_means ||
     !fine_covs || !fine_responses) {return KH_ERR_INVALID_ARG;}
   if (n == 0) {return KH_OK;}
+  if (coarse == fine) {
+    // a handle is not thread-safe (slots, staging buffers and stream are shared): the two stages run on two threads
+    kh::set_error("kh_loop_closure_batch: the coarse and the fine matcher must be two handles");
+    return KH_ERR_INVALID_ARG;
+  }
   pieces = std::max(1, std::min(pieces, n));
+  {
+    const int32_t cap = std::min(kh::matcher_max_batch(coarse), kh::matcher_max_batch(fine));
+    if (cap > 0 && (n + pieces - 1) / pieces > cap) {
+      kh::set_error("kh_loop_closure_batch: a piece of " + std::to_string((n + pieces - 1) / pieces) + " candidates exceeds the matchers' max_batch of " +
+        std::to_string(cap) + " (raise `pieces` or create the handles with a larger max_batch)");
+      return KH_ERR_INVALID_ARG;
+    }
+  }
   std::vector<int32_t> bound(pieces + 1);
   for (int32_t k = 0; k <= pieces; ++k) {bound[k] = static_cast<int32_t>(static_cast<int64_t>(n) * k / pieces);}
   std::mutex mu;

@@ -1247,6 +1247,12 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
 
 }  // namespace kh
 
+namespace kh
+{
+// for the other translation units of the library (kh_matcher is private to this one)
+int32_t matcher_max_batch(const kh_matcher * m) {return m ? m->max_batch : 0;}
+}
+
 // =============================================================================================
 //                                         C ABI
 // =============================================================================================

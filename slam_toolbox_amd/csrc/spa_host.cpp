@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -134,6 +135,8 @@ struct kh_spa
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
+  // trace of the last Compute(): one row per LM iteration, see kh_spa_iteration_log
+  std::vector<std::array<double, 8>> iter_log;
   int32_t n_slots = 0;
   std::vector<int32_t> level_offsets, level_max_m, level_max_ns;
   DevBuf<double> d_upd, d_fsb, d_partial;
@@ -363,7 +366,10 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
           for (int32_t f = 0; f < nf; ++f) {if (!placed[f]) {fresh.push_back(f);}}
           if (!fresh.empty()) {sn.insert(sn.begin(), std::move(fresh));}          // build_structure splits it into a chain when long
           sym_rc = build_structure(s->sym, nf, adj_ptr, adj_idx, sopt, sn);
-          if (sym_rc == KH_OK && s->sym.factor_flops <= s->cached_full_flops * 3 / 2 * std::max<int64_t>(1, (nf + s->cached_full_nf - 1) / std::max(1, s->cached_full_nf))) {
+          // fill guard: the factorisation may cost half as much again as the last full dissection's, scaled by how much the
+          // graph has grown since (flops grow at least linearly with the free nodes)
+          const double allowed = 1.5 * static_cast<double>(s->cached_full_flops) * static_cast<double>(nf) / static_cast<double>(std::max(1, s->cached_full_nf));
+          if (sym_rc == KH_OK && static_cast<double>(s->sym.factor_flops) <= allowed) {
             sym_incremental = true;
             return;
           }
@@ -1024,6 +1030,15 @@ int kh_spa_get_node(kh_spa * s, int32_t id, double pose[3])
 int32_t kh_spa_num_nodes(kh_spa * s) {settle(s); return s ? static_cast<int32_t>(s->nodes.size()) : 0;}
 int32_t kh_spa_num_constraints(kh_spa * s) {settle(s); return s ? static_cast<int32_t>(s->cons.size()) : 0;}
 
+int kh_spa_iteration_log(kh_spa * s, int32_t capacity, double * rows, int32_t * n_rows)
+{
+  if (!s || !n_rows || capacity < 0 || (capacity > 0 && !rows)) {return KH_ERR_INVALID_ARG;}
+  *n_rows = static_cast<int32_t>(s->iter_log.size());
+  const int32_t n = std::min(capacity, *n_rows);
+  for (int32_t i = 0; i < n; ++i) {std::copy(s->iter_log[i].begin(), s->iter_log[i].end(), rows + 8 * static_cast<size_t>(i));}
+  return KH_OK;
+}
+
 int kh_spa_get_corrections(kh_spa * s, int32_t * n, int32_t * ids, double * poses)
 {
   if (!s || !n) {return KH_ERR_INVALID_ARG;}
@@ -1194,6 +1209,10 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     return finish(KH_ERR_SOLVER);
   }
 
+  s->iter_log.clear();
+  auto trace = [&](double cost, double cand_cost, double model_change, double radius_used, double radius_next, double step_norm, double verdict) {
+    s->iter_log.push_back({static_cast<double>(iteration), cost, cand_cost, model_change, radius_used, radius_next, step_norm, verdict});
+  };
   while (true) {
     if (iteration >= opt.max_num_iterations) {sum.termination = 1; break;}
     if (step_successful && gmax <= opt.gradient_tolerance) {sum.termination = 0; break;}
@@ -1319,6 +1338,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     if (!step_valid) {
       ++num_invalid;
       if (num_invalid >= opt.max_num_consecutive_invalid_steps) {sum.termination = 2; sum.usable = 0; break;}
+      trace(x_cost, cand_cost, model_cost_change, radius, radius / decrease_factor, step_norm, -1.0);
       radius = radius / decrease_factor;      // StepIsInvalid -> StepRejected(0)
       decrease_factor *= 2.0;
       continue;
@@ -1326,9 +1346,13 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     num_invalid = 0;
     if (!std::isfinite(cand_cost)) {cand_cost = std::numeric_limits<double>::max();}
 
-    if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {sum.termination = 0; break;}
+    if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
+      trace(x_cost, cand_cost, model_cost_change, radius, radius, step_norm, 2.0); sum.termination = 0; break;
+    }
     const double cost_change = x_cost - cand_cost;
-    if (std::fabs(cost_change) <= opt.function_tolerance * x_cost) {sum.termination = 0; break;}
+    if (std::fabs(cost_change) <= opt.function_tolerance * x_cost) {
+      trace(x_cost, cand_cost, model_cost_change, radius, radius, step_norm, 3.0); sum.termination = 0; break;
+    }
 
     double quality;
     if (cand_cost >= std::numeric_limits<double>::max()) {
@@ -1358,8 +1382,10 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       }
       step_successful = true;
       ++sum.successful_steps;
+      const double radius_used = radius;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * quality - 1.0, 3));
       radius = std::min(opt.max_trust_region_radius, radius);
+      trace(ev_cur, cand_cost, model_cost_change, radius_used, radius, step_norm, 1.0);
       decrease_factor = 2.0;
       reuse_diagonal = false;
       // TrustRegionStepEvaluator::StepAccepted
@@ -1375,6 +1401,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       if (ev_nonmono == max_nonmono) {ev_ref = ev_cand; ev_acc_ref = ev_acc_cand;}
       if (x_cost < minimum_cost) {minimum_cost = x_cost; best_is_current = true;}
     } else {
+      trace(x_cost, cand_cost, model_cost_change, radius, radius / decrease_factor, step_norm, 0.0);
       radius = radius / decrease_factor;      // StepRejected
       decrease_factor *= 2.0;
       reuse_diagonal = true;

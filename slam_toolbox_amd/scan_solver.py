@@ -98,6 +98,15 @@ class HipSpaSolver:
         capi.check(rc, "kh_spa_compute")
         return self.summary
 
+    def iteration_log(self):
+        """(n, 8) array: the trust-region iterations of the last Compute() (kh_spa_iteration_log: iteration, cost, candidate cost,
+        model cost change, radius used, radius after, step norm, verdict)."""
+        n = C.c_int32()
+        capi.check(capi.lib().kh_spa_iteration_log(self._h, 0, None, C.byref(n)), "kh_spa_iteration_log")
+        rows = np.zeros((max(1, n.value), 8))
+        capi.check(capi.lib().kh_spa_iteration_log(self._h, n.value, rows.ctypes.data_as(C.c_void_p), C.byref(n)), "kh_spa_iteration_log")
+        return rows[:n.value]
+
     def GetCorrections(self):
         """IdPoseVector: list of (unique id, pose)."""
         n = C.c_int32()

@@ -303,3 +303,22 @@ def test_incremental_reanalysis_after_a_loop_closure(kartohip_lib):
     s4 = a.Compute()
     assert s4["analysis"] == 0
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_iteration_log_describes_the_compute(kartohip_lib):
+    """kh_spa_iteration_log: one row per trust-region iteration of the last Compute(), consistent with its summary (the trace that
+    is laid beside Ceres' IterationSummary in tests/test_spa_vs_ceres.py where Ceres exists)."""
+    from slam_toolbox_amd import synth
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    g = synth.make_pose_graph(400, 1000, seed=3)
+    sol = HipSpaSolver()
+    sol.load(g["init"], g["edges"], g["z"], g["cov"])
+    summ = sol.Compute()
+    log = sol.iteration_log()
+    sol.close()
+    assert len(log) == summ["iterations"] and np.array_equal(log[:, 0], np.arange(1, len(log) + 1))
+    assert int((log[:, 7] == 1.0).sum()) == summ["successful_steps"] - 1          # the start counts as a successful step
+    acc = log[log[:, 7] == 1.0]
+    assert (acc[:, 3] > 0).all() and (log[:, 4] > 0).all()                       # model decrease and radius positive
+    assert abs(log[0, 1] - summ["initial_cost"]) <= 1e-12 * summ["initial_cost"]
