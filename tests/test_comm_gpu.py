@@ -88,6 +88,11 @@ def test_two_rank_rccl_sharded_solve(kartohip_lib, tmp_path):
         p.kill()
     errs = [open(tmp_path / f"init_error_{r}.txt").read() for r in range(2) if os.path.exists(tmp_path / f"init_error_{r}.txt")]
     if errs or hung:
+        # one device: RCCL refuses two ranks on it (ncclCommInitRank: invalid usage) -> nothing to test.  Two or more devices:
+        # the ranks sit on different GPUs and a communicator that does not form is a FAILURE
+        from slam_toolbox_amd import capi
+        if capi.lib().kh_device_count() >= 2:
+            pytest.fail(f"RCCL did not form a 2-rank communicator on {capi.lib().kh_device_count()} devices: {errs or 'init timed out'}")
         pytest.skip(f"RCCL would not form a 2-rank communicator on one device: {errs or 'init timed out'}")
     p0, p1 = np.load(tmp_path / "poses_0.npy"), np.load(tmp_path / "poses_1.npy")
     assert np.array_equal(p0.view(np.uint64), p1.view(np.uint64))     # replicated solve: identical on every rank
