@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <string>
@@ -38,6 +39,7 @@
 namespace kh
 {
 void set_error(const std::string & s);
+void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);      // matcher_host.cpp: the persistent host pool
 
 #define KS_HIP(call)                                                                         \
   do {                                                                                       \
@@ -336,6 +338,9 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     // or after kMaxReuse re-analyses.  kh_spa_reset() forgets the supernodes (a reloaded graph is analysed from scratch).
     const auto t_sym0 = std::chrono::steady_clock::now();
     SymbolicOptions sopt;
+    // the independent subsets of a dissection level run on the library's persistent host pool (KH_SPA_ND_SERIAL=1: in line)
+    static const bool nd_serial = std::getenv("KH_SPA_ND_SERIAL") != nullptr;
+    if (!nd_serial) {sopt.parallel_for = [](size_t n, const std::function<void(size_t)> & fn) {host_parallel_for(n, fn);};}
     if (const char * e = std::getenv("KH_SPA_LEAF")) {sopt.leaf_nodes = std::max(1, std::atoi(e));}
     if (const char * e = std::getenv("KH_SPA_PMAX")) {sopt.max_pivot_nodes = std::min(42, std::max(1, std::atoi(e)));}
     if (const char * e = std::getenv("KH_SPA_CANDS")) {sopt.separator_candidates = std::max(1, std::atoi(e));}

@@ -128,42 +128,29 @@ void cut_vertex_cover(NdContext & ctx, const std::vector<int32_t> & order, const
   for (int32_t r = 0; r < nr; ++r) {if (zr[r]) {cover.push_back(right[r]);}}
 }
 
-// appends the supernodes of `nodes` to `out` in elimination order (A's, B's, then the separator).  `hint`: a vertex of the
-// subset known to lie at one of its ends (the root or the farthest vertex of the parent's level structure, whichever side
-// the subset came from), or -1: with a hint ONE breadth-first search gives connectivity and the level structure.
-void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & out, int depth, int32_t hint = -1)
+// One dissection step: the subset `nodes` is either a leaf (returns false; `nodes` sorted) or split into A, B and the
+// separator `cover` (returns true).  `hint`: a vertex of the subset known to lie at one of its ends (the root or the farthest
+// vertex of the parent's level structure, whichever side the subset came from), or -1: with a hint ONE breadth-first search
+// gives connectivity and the level structure.  A disconnected subset is split into one component and the rest, no separator.
+// Sibling subsets are dissected concurrently: they touch disjoint entries of the context's per-vertex arrays.
+bool nd_split(NdContext & ctx, std::vector<int32_t> & nodes, int32_t hint, std::vector<int32_t> & A, std::vector<int32_t> & B,
+  std::vector<int32_t> & best_cover, int32_t & hint_a, int32_t & hint_b)
 {
-  if (nodes.empty()) {return;}
-  if (static_cast<int32_t>(nodes.size()) <= ctx.opt.leaf_nodes) {
-    std::sort(nodes.begin(), nodes.end());
-    out.push_back(nodes);
-    return;
-  }
+  A.clear(); B.clear(); best_cover.clear(); hint_a = -1; hint_b = -1;
+  auto as_leaf = [&]() {std::sort(nodes.begin(), nodes.end()); return false;};
+  if (static_cast<int32_t>(nodes.size()) <= ctx.opt.leaf_nodes) {return as_leaf();}
   const int32_t st = ++ctx.stamp;
   for (int32_t v : nodes) {ctx.tag[v] = st;}
   std::vector<int32_t> order;
   order.reserve(nodes.size());
   const bool hinted = hint >= 0 && ctx.tag[hint] == st;
   nd_bfs(ctx, hinted ? hint : nodes[0], st, order);
-  auto both = [&](std::vector<int32_t> & A, std::vector<int32_t> & B, int32_t hint_a, int32_t hint_b) {
-    if (depth < ctx.opt.parallel_depth && A.size() > 256 && B.size() > 256) {
-      SupernodeList out_b;
-      std::thread tb([&] {nd_recurse(ctx, B, out_b, depth + 1, hint_b);});
-      nd_recurse(ctx, A, out, depth + 1, hint_a);
-      tb.join();
-      for (auto & sn : out_b) {out.push_back(std::move(sn));}
-    } else {
-      nd_recurse(ctx, A, out, depth + 1, hint_a);
-      nd_recurse(ctx, B, out, depth + 1, hint_b);
-    }
-  };
   if (order.size() < nodes.size()) {
-    // disconnected subset: split off this component, recurse on both parts (independent subtrees)
-    std::vector<int32_t> comp = order, rest;
-    for (int32_t v : comp) {ctx.tag[v] = 0;}
-    for (int32_t v : nodes) {if (ctx.tag[v] == st) {rest.push_back(v);}}
-    both(comp, rest, -1, -1);
-    return;
+    // disconnected subset: split off this component (independent subtrees)
+    for (int32_t v : order) {ctx.tag[v] = 0;}
+    for (int32_t v : nodes) {if (ctx.tag[v] == st) {B.push_back(v);}}
+    A.swap(order);
+    return true;
   }
   // pseudo-peripheral start: restart the BFS from the farthest vertex (a hinted start already is such a vertex)
   if (!hinted) {
@@ -171,11 +158,7 @@ void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & o
     nd_bfs(ctx, far, st, order);
   }
   const int32_t depth_bfs = ctx.dist[order.back()];
-  auto as_leaf = [&]() {
-    std::sort(nodes.begin(), nodes.end());
-    out.push_back(nodes);
-  };
-  if (depth_bfs < 2) {as_leaf(); return;}      // clique-like: no level can separate anything
+  if (depth_bfs < 2) {return as_leaf();}      // clique-like: no level can separate anything
   std::vector<int32_t> lstart(depth_bfs + 2, 0);
   for (int32_t v : order) {lstart[ctx.dist[v] + 1]++;}
   for (int32_t l = 0; l <= depth_bfs; ++l) {lstart[l + 1] += lstart[l];}
@@ -194,7 +177,7 @@ void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & o
   if (cands.empty()) {cands.push_back({0, fallback});}
   std::stable_sort(cands.begin(), cands.end(), [](const Cand & a, const Cand & b) {return a.est < b.est;});
   if (static_cast<int32_t>(cands.size()) > ctx.opt.separator_candidates) {cands.resize(ctx.opt.separator_candidates);}
-  std::vector<int32_t> best_cover, cover;
+  std::vector<int32_t> cover;
   int32_t best_l = -1;
   for (const Cand & c : cands) {
     if (best_l >= 0 && c.est >= static_cast<int32_t>(best_cover.size())) {
@@ -206,17 +189,20 @@ void nd_recurse(NdContext & ctx, std::vector<int32_t> & nodes, SupernodeList & o
     if (cover.empty()) {continue;}
     if (best_l < 0 || cover.size() < best_cover.size()) {best_cover.swap(cover); best_l = c.l;}
   }
-  if (best_l < 0) {as_leaf(); return;}
+  if (best_l < 0) {best_cover.clear(); return as_leaf();}
   for (int32_t v : best_cover) {ctx.tag[v] = 0;}              // out of the subset
-  std::vector<int32_t> A, B;
   for (int32_t v : order) {
     if (ctx.tag[v] != st) {continue;}
     if (ctx.dist[v] < best_l) {A.push_back(v);} else {B.push_back(v);}
   }
-  if (A.empty() || B.empty()) {as_leaf(); return;}
-  both(A, B, order.front(), order.back());      // the near side holds the root of this level structure, the far side its last vertex
+  if (A.empty() || B.empty()) {
+    for (int32_t v : best_cover) {ctx.tag[v] = st;}
+    A.clear(); B.clear(); best_cover.clear();
+    return as_leaf();
+  }
+  hint_a = order.front(); hint_b = order.back();   // the near side holds the root of this level structure, the far side its last vertex
   std::sort(best_cover.begin(), best_cover.end());
-  out.push_back(best_cover);
+  return true;
 }
 
 }  // namespace
@@ -231,10 +217,55 @@ int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, cons
   ctx.tag.assign(n_free, 0);
   ctx.dist.assign(n_free, 0);
   ctx.loc.assign(n_free, -1);
-  std::vector<int32_t> all(n_free);
-  for (int32_t i = 0; i < n_free; ++i) {all[i] = i;}
+  // The dissection tree is grown level by level: the subsets of a level are independent (disjoint vertex sets), so a level is
+  // one parallel loop over its subsets when the caller supplies one (opt.parallel_for: the library's persistent host pool --
+  // a thread per split, as through round 3, cost more in thread creation than the splits saved).  The elimination order is
+  // read off the finished tree in post-order: A's supernodes, B's, then the separator.
+  struct Task {std::vector<int32_t> nodes, cover; int32_t hint = -1, a = -1, b = -1; bool split = false;};
+  std::vector<Task> tree(1);
+  tree[0].nodes.resize(n_free);
+  for (int32_t i = 0; i < n_free; ++i) {tree[0].nodes[i] = i;}
+  size_t level_begin = 0;
+  while (level_begin < tree.size()) {
+    const size_t level_end = tree.size();
+    const size_t count = level_end - level_begin;
+    std::vector<std::vector<int32_t>> As(count), Bs(count);
+    std::vector<int32_t> ha(count, -1), hb(count, -1);
+    auto work = [&](size_t i) {
+      Task & t = tree[level_begin + i];
+      t.split = nd_split(ctx, t.nodes, t.hint, As[i], Bs[i], t.cover, ha[i], hb[i]);
+    };
+    if (opt.parallel_for && count > 1) {opt.parallel_for(count, work);} else {for (size_t i = 0; i < count; ++i) {work(i);}}
+    for (size_t i = 0; i < count; ++i) {
+      if (!tree[level_begin + i].split) {continue;}
+      Task ta, tb;
+      ta.nodes.swap(As[i]); ta.hint = ha[i];
+      tb.nodes.swap(Bs[i]); tb.hint = hb[i];
+      tree[level_begin + i].a = static_cast<int32_t>(tree.size()); tree.push_back(std::move(ta));
+      tree[level_begin + i].b = static_cast<int32_t>(tree.size()); tree.push_back(std::move(tb));
+      std::vector<int32_t>().swap(tree[level_begin + i].nodes);
+    }
+    level_begin = level_end;
+  }
   supernodes.clear();
-  nd_recurse(ctx, all, supernodes, 0);
+  // post-order without recursion: (task, state) stack
+  std::vector<std::pair<int32_t, int>> stack(1, {0, 0});
+  while (!stack.empty()) {
+    const int32_t k = stack.back().first;
+    int & state = stack.back().second;
+    Task & t = tree[k];
+    if (!t.split) {
+      if (!t.nodes.empty()) {supernodes.push_back(std::move(t.nodes));}
+      stack.pop_back();
+    } else if (state == 0) {
+      state = 1; stack.push_back({t.a, 0});
+    } else if (state == 1) {
+      state = 2; stack.push_back({t.b, 0});
+    } else {
+      if (!t.cover.empty()) {supernodes.push_back(std::move(t.cover));}
+      stack.pop_back();
+    }
+  }
   return KH_OK;
 }
 

@@ -5,7 +5,9 @@
 // symbolic factorisation happen inside SuiteSparse/CHOLMOD -- a third-party dependency that is not in the reference tree.
 // This is the equivalent stage of the MI355X solver.
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace kh
@@ -41,7 +43,9 @@ struct SymbolicOptions
   int32_t max_pivot_nodes = 42;     // supernodes with more pivots are split into a chain of fronts (42 nodes = 126 columns:
                                     // the pivot block of a front is factored inside one workgroup's LDS, 128 x 130 doubles)
   int32_t separator_candidates = 2; // BFS levels tried as the cut of a subset (each one refined to a minimum vertex cover)
-  int32_t parallel_depth = 4;       // recursion levels whose two halves run on separate threads
+  // parallel loop the nested dissection runs the independent subsets of a tree level on (the library passes its persistent host
+  // pool); empty = serial
+  std::function<void(size_t, const std::function<void(size_t)> &)> parallel_for;
   double balance_lo = 0.35;         // a cut must leave at least this fraction of the subset on the near side ...
   double balance_hi = 0.65;         // ... and at most this
 };

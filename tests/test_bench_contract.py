@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 # the newest round's line (profiles/rN_bench_line.json) with the rocprof / PMC summaries of the same round
 ROUND = sorted(os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(PROF, "r*_bench_line.json")))[-1]
+# the dominant kernel: the windowed scoring kernel through round 3, the LDS-staged one from round 4 on
+SCORE_KERNEL = "k_score<1, 8, 1" if ROUND in ("r1", "r2", "r3") else "k_score_lds<1, 4>"
 
 
 def _line():
@@ -29,8 +31,8 @@ def test_line_has_the_contract_keys():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    # "l1" / "l2": the dominant kernel is a cache-resident gather (report the resource that binds)
-    assert r["bound"] in ("hbm", "mfma", "l1", "l2") and r["unit"] in ("GB/s", "TFLOP/s")
+    # "l1" / "l2" / "lds": the dominant kernel reads cache- or LDS-resident windows (report the resource that binds)
+    assert r["bound"] in ("hbm", "mfma", "l1", "l2", "lds") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     if ROUND != "r1":
         assert 0.0 < r["frac"] <= 1.0, "a roofline fraction is a fraction"
@@ -47,7 +49,7 @@ def test_line_has_the_contract_keys():
 def test_kernel_time_agrees_with_the_rocprof_summary():
     d = _line()
     with open(os.path.join(PROF, f"{ROUND}_bench_kernel_stats.csv")) as f:
-        rows = [r for r in csv.DictReader(f) if "k_score<1, 8, 1" in r["Name"]]
+        rows = [r for r in csv.DictReader(f) if SCORE_KERNEL in r["Name"]]
     assert len(rows) == 1
     avg_ms = float(rows[0]["AverageNs"]) * 1e-6
     assert abs(avg_ms - d["roofline"]["avg_launch_ms"]) / avg_ms < 0.05

@@ -37,7 +37,7 @@ int main(int argc, char ** argv)
   if (argc > 4) {opt.max_pivot_nodes = std::atoi(argv[4]);}
   if (argc > 5) {opt.separator_candidates = std::atoi(argv[5]);}
   if (argc > 6) {opt.balance_lo = std::atof(argv[6]); opt.balance_hi = 1.0 - opt.balance_lo;}
-  if (argc > 7) {opt.parallel_depth = std::atoi(argv[7]);}
+  (void)argc;
   kh::Symbolic sym;
   double best = 1e30;
   int rc = 0;
