@@ -47,6 +47,13 @@ PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r4_k_s
                  if os.path.exists(p)), os.path.join(ROOT, "profiles", "r1_k_score_pmc.json"))
 
 
+def newest_profile(suffix):
+    """profiles/rN_<suffix> of the newest round that has one (the summaries are re-collected in the rounds that change their kernels)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_" + suffix)))
+    return os.path.basename(found[-1]) if found else "r3_" + suffix
+
+
 def recorded_kernels(name):
     """per-kernel records of a committed rocprofv3 summary (tools/pmc_summary.py): {} when the file is missing"""
     try:
@@ -283,7 +290,8 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
         n_lin = summ["successful_steps"]          # evaluation points linearised (the start + every accepted step)
         lin_bytes = 480.0 * 30000 * n_lin         # 144 B read + 336 B written per edge
         lin_gbs = lin_bytes / (summ["linearize_gpu_ms"] * 1e-3) / 1e9 if summ["linearize_gpu_ms"] > 0 else 0.0
-        spa_doc = recorded_kernels("r3_spa_pmc.json")
+        spa_name = newest_profile("spa_pmc.json")
+        spa_doc = recorded_kernels(spa_name)
         k6_traffic = recorded_traffic(spa_doc, ("k_potrf", "k_trsm", "k_syrk", "k_extend_add"), spa_doc.get("factorizations"))
         k5_traffic = recorded_traffic(spa_doc, ("k_edge_lin", "k_gather_H", "k_gather_g"),
                                       spa_doc.get("kernels", {}).get("k_gather_H", {}).get("calls"))
@@ -294,12 +302,12 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
              "flops_per_factorization": 2.0 * float(summ["factor_flops"]), "multiply_adds_per_factorization": float(summ["factor_flops"]),
              "factorizations": int(summ["factorizations"]),
              "gpu_ms": float(summ["factor_gpu_ms"]), "levels": int(summ["levels"]), "nnz_factor": int(summ["nnz_factor"]),
-             "traffic": k6_traffic, "traffic_source": "recorded: profiles/r3_spa_pmc.json (rocprofv3 PMC passes of tools/quick_spa.py, the same "
+             "traffic": k6_traffic, "traffic_source": "recorded: profiles/" + spa_name + " (rocprofv3 PMC passes of tools/quick_spa.py, the same "
                                                       "graph): HBM bytes of k_potrf + k_trsm + k_syrk + k_extend_add per numeric factorisation"},
             {"kernel": "K5 k_edge_lin + k_gather_H / _g (normal equations)", "bound": "hbm", "achieved": lin_gbs, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": lin_gbs / HBM_PEAK_GBS, "algorithmic_bytes": lin_bytes, "linearizations": int(n_lin),
              "gpu_ms": float(summ["linearize_gpu_ms"]), "traffic": k5_traffic,
-             "traffic_source": "recorded: profiles/r3_spa_pmc.json: HBM bytes of k_edge_lin + k_gather_H + k_gather_g per linearisation",
+             "traffic_source": "recorded: profiles/" + spa_name + ": HBM bytes of k_edge_lin + k_gather_H + k_gather_g per linearisation",
              "note": "480 B per edge algorithmic (SURVEY 8d); 14.4 MB per linearisation is latency-, not bandwidth-sized"},
         ]
         out["solve_backward_gpu_ms"] = float(summ["backward_gpu_ms"])
@@ -402,14 +410,15 @@ def loop_leg(device=0, n_pairs=256, batch=256, cpu=True, resident=True):
     if k1_ms > 0:
         gbs = k1_bytes / (k1_ms * 1e-3) / 1e9
         K1 = ("k_raster_", "k_find_valid", "k_cell_", "k_active_set", "k_repitch")
-        doc = recorded_kernels("r3_loop_pmc.json")
+        loop_name = newest_profile("loop_pmc.json")
+        doc = recorded_kernels(loop_name)
         batches = doc.get("kernels", {}).get("k_raster_scan", {}).get("calls", 0) / 2.0         # one launch per stage (L, S) of a batch
         traffic = recorded_traffic(doc, K1, batches)
         out["loop_rooflines"] = [{"kernel": "K1 k_find_valid + k_cell_* + k_active_set + k_raster_* + k_repitch*, presets L and S", "bound": "hbm",
                                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": k1_bytes,
                                   "gpu_ms": k1_ms, "traffic": traffic,
                                   "traffic_gbs": (traffic / (k1_ms * 1e-3) / 1e9) if traffic else None,
-                                  "traffic_source": "recorded: profiles/r3_loop_pmc.json (rocprofv3 PMC passes of tools/loop_pieces.py, the same 256-pair "
+                                  "traffic_source": "recorded: profiles/" + loop_name + " (rocprofv3 PMC passes of tools/loop_pieces.py, the same 256-pair "
                                                     "batch; (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the K1 kernels, per batch)",
                                   "note": "algorithmic_bytes still prices Grid::Clear at the whole grid (SURVEY 8d); the kernels zero only the tiles "
                                           "the slot's previous rasterisation wrote, so the measured traffic is BELOW the algorithmic figure for the "
