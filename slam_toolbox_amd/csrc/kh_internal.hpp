@@ -19,7 +19,9 @@ constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per cla
 // LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; the beams are cut into chunks of
 // consecutive beams whose windows' union fits one LDS region (built by kLdsRanges waves, a quarter of the beams each)
 constexpr int32_t kGroupAngles = 2;
-constexpr int32_t kLdsRanges = 4;
+constexpr int32_t kLdsRanges = 4;             // builder waves of K2' (each writes its own descriptor list)
+// descriptors one builder wave can write: it sees ceil(P / 256) runs of 64 beams, every beam of a run may end up a chunk of its own
+inline __host__ __device__ int32_t lds_desc_capacity(int32_t n_points) {return 64 * ((n_points + 255) / 256);}
 constexpr int32_t kChunkWords = 8;            // int32 words per chunk descriptor
 constexpr int32_t kLdsPitch = 192;            // bytes per staged grid row (64 mod 128: conflict-free ds_read_b32 of two rows)
 constexpr int32_t kLdsRows = 196;             // rows of one staged region
@@ -116,7 +118,7 @@ struct CorrJob
   int32_t lds_path;
   int32_t sy_cells;          // grid rows per lattice step in y (sy_ws / ws)
   int32_t * rel;             // na*P: byte offset of the beam's window start inside its sub-chunk's LDS region, or -1
-  int32_t * chunks;          // [groups][kLdsRanges][ceil(P / kLdsRanges)][kChunkWords]: chunk descriptors
+  int32_t * chunks;          // [groups][kLdsRanges][lds_desc_capacity(P)][kChunkWords]: chunk descriptors
   int32_t * chunk_counts;    // [groups][kLdsRanges]: chunks of the beam range
   // empty-window skipping: a beam whose whole window lies in blocks no stamp touched adds 0 to every pose
   const uint32_t * blockmap; // see RasterJob; nullptr = do not skip

@@ -754,7 +754,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     {
       // chunk descriptors of the LDS-staged path: at most one per beam, kept per (angle pair, beam range)
       const size_t groups = (static_cast<size_t>(c.na) + kGroupAngles - 1) / kGroupAngles;
-      const size_t range_len = (static_cast<size_t>(c.P) + kLdsRanges - 1) / kLdsRanges;
+      const size_t range_len = static_cast<size_t>(lds_desc_capacity(c.P));
       rc = ensure_device(s.d_chunks, s.cap_chunks, groups * kLdsRanges * range_len * kChunkWords, m->stream); if (rc) {return rc;}
       rc = ensure_device(s.d_chunk_counts, s.cap_chunk_counts, groups * kLdsRanges, m->stream); if (rc) {return rc;}
     }
@@ -1027,7 +1027,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     const CorrHost & c0 = ctx[0];
     const Slot & s0 = m->slots[c0.slot];
     const size_t groups = (static_cast<size_t>(c0.na) + kGroupAngles - 1) / kGroupAngles;
-    const size_t range_len = (static_cast<size_t>(c0.P) + kLdsRanges - 1) / kLdsRanges;
+    const size_t range_len = static_cast<size_t>(lds_desc_capacity(c0.P));
     std::vector<int32_t> cc(groups * kLdsRanges), dd(groups * kLdsRanges * range_len * kChunkWords);
     KH_HIP(hipMemcpy(cc.data(), s0.d_chunk_counts, cc.size() * 4, hipMemcpyDeviceToHost));
     KH_HIP(hipMemcpy(dd.data(), s0.d_chunks, dd.size() * 4, hipMemcpyDeviceToHost));

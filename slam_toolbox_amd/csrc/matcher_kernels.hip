@@ -1678,17 +1678,39 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
     const int na = job.na, nxp = job.nx;
     const int32_t * const sums = job.sums;
     unsigned long long * const probs = job.out + kOutHeaderWords;
+    const bool penal = job.do_penalize != 0;
+    const double denom = job.denom;
     for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < (int)plane; cell += gridDim.x * blockDim.x) {
       const int yi = cell / nxp, xi = cell - yi * nxp;
-      double m = 0.0;
+      // The exact response costs a double-precision division per angle.  The maximum over the angles is found in two passes:
+      // a single-precision key sum x angle penalty first (the distance penalty is common to the cell; the key orders the
+      // responses up to a relative 3e-7), then the exact response of the angles whose key lies within 1e-5 of the largest --
+      // one or two of the 81.  Responses at or below 1e-6 skip the penalty (math::DoubleEqual(response, 0), Mapper.cpp:671-685)
+      // and do not follow the key: a cell whose largest sum is that small takes the exact pass over all its angles.
+      int32_t smax = 0;
+      float kmax = 0.0f;
       for (int a0 = 0; a0 < na; a0 += 8) {
-        int32_t v[8];                                    // eight independent loads in flight, then the eight responses
+        int32_t v[8];                                    // eight independent loads in flight
 #pragma unroll
         for (int t = 0; t < 8; ++t) {v[t] = a0 + t < na ? sums[(size_t)(a0 + t) * plane + cell] : 0;}
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           if (a0 + t < na) {
-            const double response = pose_response(job, v[t], a0 + t, yi, xi);
+            const float key = (float)v[t] * (penal ? (float)job.ang_pen[a0 + t] : 1.0f);
+            kmax = key > kmax ? key : kmax;
+            smax = v[t] > smax ? v[t] : smax;
+          }
+        }
+      }
+      double m = 0.0;
+      if (smax > 0) {
+        const bool all = (double)smax / denom < 4e-6;
+        const float thresh = all ? -1.0f : kmax * (1.0f - 1e-5f);
+        for (int a = 0; a < na; ++a) {
+          const int32_t v = sums[(size_t)a * plane + cell];
+          const float key = (float)v * (penal ? (float)job.ang_pen[a] : 1.0f);
+          if (key >= thresh) {
+            const double response = pose_response(job, v, a, yi, xi);
             m = response > m ? response : m;
           }
         }
@@ -1840,6 +1862,12 @@ __device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w
   return (any & span) != 0;
 }
 
+// K2'.  Thread t of the workgroup owns the beams t, t + 256, t + 512, ...: wave w therefore sees, round after round, a RUN of 64
+// consecutive beams (beam = 256 * round + 64 * w + lane), which is all the chunk builder needs -- a chunk never spans more than 64
+// beams.  Nothing but two counters lives in LDS (the lookup results stay in registers, the occupancy block map is read where it
+// lies: 9 KB per job, shared by the 41 workgroups of the job in L2), so the workgroups of this kernel fit on compute units that
+// already hold two workgroups of K3' (which leave 4 KB of LDS and a quarter of the registers free) and run in the issue slots
+// K3' leaves idle, instead of taking whole compute units away from it.
 __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_t stride)
 {
   const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobs + (size_t)blockIdx.y * stride);
@@ -1861,75 +1889,81 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
     for (int i = group * per + threadIdx.x; i < hi; i += blockDim.x) {job.out[i] = 0ull;}
   }
   const int P = job.n_points;
-  extern __shared__ int32_t s_xy[];              // [kGroupAngles][2][P]: gx, gy (gy = kNotFast: not a fast beam)
   __shared__ int32_t s_slow[kGroupAngles];
-  __shared__ uint32_t s_bm[4096];
   if (threadIdx.x < kGroupAngles) {s_slow[threadIdx.x] = 0;}
-  const uint32_t * bmp = job.blockmap;
-  if (bmp && job.bm_w * job.bm_h <= 4096) {
-    for (int i = threadIdx.x; i < job.bm_w * job.bm_h; i += blockDim.x) {s_bm[i] = job.blockmap[i];}
-    bmp = s_bm;
-  }
+  const uint32_t * const bmp = job.blockmap;
   __syncthreads();
   KH_TK(tk_a);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bmin = job.base0;
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
   const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;   // cells a window covers
-  const float inv_ws = 1.0f / (float)job.ws;
-  // this thread's beams: sensor-frame point and validity, read once for both angles and all in flight together (read between the
-  // stores of the loop below every beam paid a full memory latency)
-  constexpr int kBeamsPerThread = 8;                       // P <= 2048 on this path
-  double plx[kBeamsPerThread], ply[kBeamsPerThread];
-  bool pinv[kBeamsPerThread];
+  const int ws = job.ws, bm_w = job.bm_w, bm_h = job.bm_h, na = job.na, base0 = job.base0;
+  const float inv_ws = 1.0f / (float)ws;
+  const int64_t data_size = job.data_size, pad = job.pad;
+  const double off_x = job.grid_off_x, off_y = job.grid_off_y, scale = job.scale;
+  // rows a wave of K3' reads past a window's first row (63 lattice rows), and rows that have to be staged
+  const int read_rows = 63 * job.sy_cells + 1;
+  const int span_rows = ys;
+  double cosine[kGroupAngles], sine[kGroupAngles];
 #pragma unroll
-  for (int t = 0; t < kBeamsPerThread; ++t) {
+  for (int q = 0; q < kGroupAngles; ++q) {
+    cosine[q] = a0 + q < na ? job.cos_sin[2 * (a0 + q)] : 1.0;
+    sine[q] = a0 + q < na ? job.cos_sin[2 * (a0 + q) + 1] : 0.0;
+  }
+  int32_t * const table = job.table;
+  int32_t * const slow = job.slow;
+  int32_t * const rel_out = job.rel;
+  const int rounds = (P + 255) / 256;
+  const int desc_cap = lds_desc_capacity(P);
+  ChunkDesc * out = reinterpret_cast<ChunkDesc *>(job.chunks) + ((size_t)group * kLdsRanges + wave) * desc_cap;
+  int n_out = 0;
+  long long windows_total = 0;
+  // this thread's beams: sensor-frame point and validity, all rounds in flight together
+  constexpr int kMaxRounds = 8;                            // P <= 2048 on this path
+  double plx[kMaxRounds], ply[kMaxRounds];
+  bool pinv[kMaxRounds];
+#pragma unroll
+  for (int t = 0; t < kMaxRounds; ++t) {
     const int i = threadIdx.x + 256 * t;
-    const bool in = i < P;
+    const bool in = t < rounds && i < P;
     pinv[t] = in ? job.invalid[i] != 0 : true;
     plx[t] = in ? job.local[2 * i] : 0.0;
     ply[t] = in ? job.local[2 * i + 1] : 0.0;
   }
-  const int ws = job.ws, bm_w = job.bm_w, bm_h = job.bm_h;
-  const int64_t data_size = job.data_size, pad = job.pad;
-  const double off_x = job.grid_off_x, off_y = job.grid_off_y, scale = job.scale;
-  for (int q = 0; q < kGroupAngles; ++q) {
-    const int a = a0 + q;
-    int32_t * sgx = s_xy + (size_t)(2 * q) * P;
-    int32_t * sgy = sgx + P;
-    if (a >= job.na) {
-      for (int i = threadIdx.x; i < P; i += blockDim.x) {sgx[i] = 0; sgy[i] = kNotFast;}
-      continue;
-    }
-    const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
-    int32_t * table = job.table + (size_t)a * P;
-    int32_t * slow = job.slow + (size_t)a * P;
 #pragma unroll
-    for (int t = 0; t < kBeamsPerThread; ++t) {
-      const int i = threadIdx.x + 256 * t;
-      if (i >= P) {break;}
-      int32_t idx, gx = 0, gy = kNotFast;
+  for (int t = 0; t < kMaxRounds; ++t) {
+    if (t >= rounds) {break;}
+    const int i = threadIdx.x + 256 * t;                  // this lane's beam of the round; the wave's run starts at i - lane
+    const bool inr = i < P;
+    int gx[kGroupAngles], gy[kGroupAngles];
+#pragma unroll
+    for (int q = 0; q < kGroupAngles; ++q) {
+      gx[q] = 0; gy[q] = kNotFast;
+      if (!inr || a0 + q >= na) {continue;}
+      int32_t idx;
       if (pinv[t]) {
         idx = kInvalidScan;
       } else {
         const double lx = plx[t], ly = ply[t];
         // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
-        const double ox = cosine * lx - sine * ly;
-        const double oy = sine * lx + cosine * ly;
+        const double ox = cosine[q] * lx - sine[q] * ly;
+        const double oy = sine[q] * lx + cosine[q] * ly;
         const double gxd = ((ox + off_x) - off_x) * scale;
         const double gyd = ((oy + off_y) - off_y) * scale;
-        gx = d_to_int(d_round(gxd));
+        const int32_t gxi = d_to_int(d_round(gxd));
         const int32_t gyi = d_to_int(d_round(gyd));
-        idx = (int32_t)((uint32_t)gx + (uint32_t)gyi * (uint32_t)ws);   // base Grid::GridIndex, no ROI
+        idx = (int32_t)((uint32_t)gxi + (uint32_t)gyi * (uint32_t)ws);   // base Grid::GridIndex, no ROI
         if (idx != kInvalidScan) {
           const bool off_grid = (int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= data_size;
           // (a pose whose index falls off the array adds nothing in the reference, Mapper.cpp:1192-1197, and a zero here: the
           // allocation has job.pad zero bytes in front of and behind the grid)
           const bool inside = (int64_t)idx + bmin >= -pad && (int64_t)idx + bmax < data_size + pad;
           // the rectangle arithmetic needs the linear index to be exactly gx + gy * ws
-          const bool exact = (int64_t)gx + (int64_t)gyi * ws == (int64_t)idx && gx > -(1 << 20) && gx < (1 << 20);
+          const bool exact = (int64_t)gxi + (int64_t)gyi * ws == (int64_t)idx && gxi > -(1 << 20) && gxi < (1 << 20);
           if (!off_grid) {
             if (inside && exact) {
-              gy = gyi;
+              gx[q] = gxi; gy[q] = gyi;
               if (bmp) {
                 // a window none of whose 32 x 32 blocks was touched by a stamp adds 0 to every pose of this angle: leave the
                 // beam out (bit-identical sums).  Windows that wrap around the row end are kept (Appendix A.3).
@@ -1939,108 +1973,96 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
                 while (wx0 < 0) {wx0 += ws; --wy0;}
                 while (wx0 >= ws) {wx0 -= ws; ++wy0;}
                 if (wx0 + xs <= ws && !window_has_blocks(bmp, bm_w, bm_h, wx0, wy0, wx0 + xs - 1, wy0 + ys - 1)) {
-                  gy = kNotFast;
+                  gy[q] = kNotFast;
                 }
               }
             } else {
-              slow[atomicAdd(&s_slow[q], 1)] = idx;
+              (slow + (size_t)(a0 + q) * P)[atomicAdd(&s_slow[q], 1)] = idx;
             }
           }
         }
       }
-      table[i] = idx;
-      sgx[i] = gx; sgy[i] = gy;
+      table[(size_t)(a0 + q) * P + i] = idx;
+    }
+    // ---- greedy chunks over this wave's run of 64 beams (lane = beam) ----
+    const int run_lo = i - lane;                          // wave-uniform
+    const int n_run = min(64, P - run_lo);                // beams of the run (<= 0: the run lies behind the scan)
+    int begin = 0;
+    while (begin < n_run) {
+      const bool live_lane = lane >= begin && lane < n_run;
+      int n = 0, x0 = 0, y0 = 0, rows = 0;
+      bool any_chunk = false;
+      for (;;) {
+        int xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
+#pragma unroll
+        for (int q = 0; q < kGroupAngles; ++q) {
+          if (live_lane && gy[q] != kNotFast) {
+            xmin = min(xmin, gx[q]); xmax = max(xmax, gx[q]); ymin = min(ymin, gy[q]); ymax = max(ymax, gy[q]);
+          }
+        }
+        xmin = wave_prefix_min(xmin, lane); xmax = wave_prefix_max(xmax, lane);
+        ymin = wave_prefix_min(ymin, lane); ymax = wave_prefix_max(ymax, lane);
+        const bool any = xmin != INT32_MAX;
+        const int al = (int)(((int64_t)base0 + xmin) & 15);           // 16-byte alignment of the region's first row
+        const int px0 = xmin - al;
+        const bool fits = any && (xmax - px0 + kTileBytes <= kLdsPitch) && (ymax - ymin + read_rows <= kLdsRows);
+        // the union only grows along the lanes: from `begin` on a run of ones, then zeros (lanes in front of `begin` count as ones)
+        const unsigned long long okm = __ballot(!any || fits) | ((1ull << begin) - 1ull);
+        const int first_bad = (okm == ~0ull) ? 64 : __ffsll((long long)~okm) - 1;
+        n = first_bad - begin;
+        if (n > 0) {
+          // the chunk = lanes begin .. first_bad - 1; its rectangle is what the last of them sees
+          x0 = __shfl(px0, first_bad - 1); y0 = __shfl(ymin, first_bad - 1);
+          rows = __shfl(ymax, first_bad - 1) - y0 + span_rows;
+          any_chunk = __shfl((int)any, first_bad - 1) != 0;
+          break;
+        }
+        // the two windows of beam `begin` are too far apart for one region: the second angle's goes the exact per-pose way
+        // (a window alone always fits; the first angle's follows only if it ever did not)
+        if (lane == begin) {
+          const int qd = gy[1] != kNotFast ? 1 : 0;
+          (slow + (size_t)(a0 + qd) * P)[atomicAdd(&s_slow[qd], 1)] = gx[qd] + gy[qd] * ws;
+          gy[qd] = kNotFast;
+        }
+      }
+      n = min(n, n_run - begin);
+      if (any_chunk) {
+        const bool in = lane >= begin && lane < begin + n;
+        ChunkDesc d;
+        d.beam_begin = run_lo + begin; d.beam_end = run_lo + begin + n;
+        d.g0 = y0 * ws + x0; d.rows = rows; d.pad1 = 0;
+        int windows = 0;
+#pragma unroll
+        for (int q = 0; q < kGroupAngles; ++q) {
+          const int a = a0 + q;
+          d.cnt[q] = 0;
+          if (a >= na) {continue;}                             // wave-uniform
+          const bool mine = in && gy[q] != kNotFast;
+          const int rel = (gy[q] - y0) * kLdsPitch + (gx[q] - x0);
+          // sort the chunk's offsets of this angle by alignment class: four contiguous segments
+          const int cls = rel & 3;
+          int offset = 0, my_rank = 0, packed = 0;
+#pragma unroll
+          for (int c = 0; c < kClasses; ++c) {
+            const unsigned long long mask = __ballot(mine && cls == c);
+            const int cnt = __popcll(mask);
+            if (cls == c) {my_rank = offset + __popcll(mask & ((1ull << lane) - 1ull));}
+            offset += cnt;
+            packed |= cnt << (8 * c);
+          }
+          d.cnt[q] = packed;
+          windows += offset;
+          if (mine) {rel_out[(size_t)a * P + run_lo + begin + my_rank] = rel & ~3;}      // K3' reads aligned dwords; the class is the segment
+        }
+        d.windows = windows;
+        windows_total += windows;
+        if (lane == 0) {out[n_out] = d;}
+        ++n_out;
+      }
+      begin += n;
     }
   }
-  __syncthreads();
   KH_TK(tk_b);
-  // ---- four builder waves, lane = beam: greedy chunks over this wave's quarter of the beams ----
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int range_len = (P + kLdsRanges - 1) / kLdsRanges;
-  const int lo = wave * range_len, hi = min(P, lo + range_len);
-  // rows a wave of K3' reads past a window's first row (63 lattice rows), and rows that have to be staged
-  const int read_rows = 63 * job.sy_cells + 1;
-  const int span_rows = ys;
-  ChunkDesc * out = reinterpret_cast<ChunkDesc *>(job.chunks) + ((size_t)group * kLdsRanges + wave) * range_len;
-  const int32_t * sgx0 = s_xy, * sgy0 = s_xy + P, * sgx1 = s_xy + 2 * P, * sgy1 = s_xy + 3 * P;
-  int n_out = 0;
-  long long windows_total = 0;
-  int begin = lo;
-  while (begin < hi) {
-    const int i = begin + lane;
-    const bool inr = i < hi;
-    int gx[kGroupAngles], gy[kGroupAngles];
-    gx[0] = inr ? sgx0[i] : 0; gy[0] = inr ? sgy0[i] : kNotFast;
-    gx[1] = inr ? sgx1[i] : 0; gy[1] = inr ? sgy1[i] : kNotFast;
-    int n = 0, x0 = 0, y0 = 0, rows = 0;
-    bool any_chunk = false;
-    for (;;) {
-      int xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
-#pragma unroll
-      for (int q = 0; q < kGroupAngles; ++q) {
-        if (gy[q] != kNotFast) {
-          xmin = min(xmin, gx[q]); xmax = max(xmax, gx[q]); ymin = min(ymin, gy[q]); ymax = max(ymax, gy[q]);
-        }
-      }
-      xmin = wave_prefix_min(xmin, lane); xmax = wave_prefix_max(xmax, lane);
-      ymin = wave_prefix_min(ymin, lane); ymax = wave_prefix_max(ymax, lane);
-      const bool any = xmin != INT32_MAX;
-      const int al = (int)(((int64_t)job.base0 + xmin) & 15);          // 16-byte alignment of the region's first row
-      const int px0 = xmin - al;
-      const bool fits = any && (xmax - px0 + kTileBytes <= kLdsPitch) && (ymax - ymin + read_rows <= kLdsRows);
-      const unsigned long long okm = __ballot(!any || fits);             // the union only grows: a run of leading ones
-      n = (okm == ~0ull) ? 64 : __ffsll((long long)~okm) - 1;
-      if (n > 0) {
-        // the chunk = lanes 0 .. n - 1; its rectangle is what lane n - 1 sees
-        x0 = __shfl(px0, n - 1); y0 = __shfl(ymin, n - 1);
-        rows = __shfl(ymax, n - 1) - y0 + span_rows;
-        any_chunk = __shfl((int)any, n - 1) != 0;
-        break;
-      }
-      // the two windows of the first beam are too far apart for one region: the second angle's goes the exact per-pose way
-      // (a window alone always fits; the first angle's follows only if it ever did not)
-      if (lane == 0) {
-        const int qd = gy[1] != kNotFast ? 1 : 0;
-        (job.slow + (size_t)(a0 + qd) * P)[atomicAdd(&s_slow[qd], 1)] = gx[qd] + gy[qd] * job.ws;
-        gy[qd] = kNotFast;
-      }
-    }
-    n = min(n, hi - begin);
-    if (any_chunk) {
-      const bool in = lane < n;
-      ChunkDesc d;
-      d.beam_begin = begin; d.beam_end = begin + n;
-      d.g0 = y0 * job.ws + x0; d.rows = rows; d.pad1 = 0;
-      int windows = 0;
-#pragma unroll
-      for (int q = 0; q < kGroupAngles; ++q) {
-        const int a = a0 + q;
-        d.cnt[q] = 0;
-        if (a >= job.na) {continue;}                           // wave-uniform
-        const bool mine = in && gy[q] != kNotFast;
-        const int rel = (gy[q] - y0) * kLdsPitch + (gx[q] - x0);
-        // sort the chunk's offsets of this angle by alignment class: four contiguous segments
-        const int cls = rel & 3;
-        int offset = 0, my_rank = 0, packed = 0;
-#pragma unroll
-        for (int c = 0; c < kClasses; ++c) {
-          const unsigned long long mask = __ballot(mine && cls == c);
-          const int cnt = __popcll(mask);
-          if (cls == c) {my_rank = offset + __popcll(mask & ((1ull << lane) - 1ull));}
-          offset += cnt;
-          packed |= cnt << (8 * c);
-        }
-        d.cnt[q] = packed;
-        windows += offset;
-        if (mine) {job.rel[(size_t)a * P + begin + my_rank] = rel & ~3;}      // K3' reads aligned dwords; the class is the segment
-      }
-      d.windows = windows;
-      windows_total += windows;
-      if (lane == 0) {out[n_out] = d;}
-      ++n_out;
-    }
-    begin += n;
-  }
   if (lane == 0) {
     job.chunk_counts[(size_t)group * kLdsRanges + wave] = n_out;
     // every window costs K3' sixteen wave-level ds_read_b32 (256 B each): the numerator of the roofline
@@ -2065,14 +2087,7 @@ void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, i
 {
   if (n_jobs <= 0 || max_na <= 0) {return;}
   const int groups = (max_na + kGroupAngles - 1) / kGroupAngles;
-  // dynamic LDS: gx, gy of kGroupAngles angles; the host guarantees P <= 2048 on this path
-  const size_t lds = sizeof(int32_t) * 2 * kGroupAngles * 2048;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_offsets_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_offsets_lds, dim3(groups, n_jobs), dim3(256), lds, (hipStream_t)stream, d_jobs, stride);
+  hipLaunchKernelGGL(k_offsets_lds, dim3(groups, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs, stride);
 }
 
 // K3'.  S = grid cells per lattice step (x and y).  2 * NW waves: wave = q * NW + share: angle q of the pair, lattice rows
@@ -2111,7 +2126,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   const int a = group * kGroupAngles + q;
   const bool live = a < job.na;
   const int P = job.n_points;
-  const int range_len = (P + kLdsRanges - 1) / kLdsRanges;
+  const int range_len = lds_desc_capacity(P);         // descriptors one builder wave of K2' may write
 
   v4i acc[kClasses][RQ];
 #pragma unroll
