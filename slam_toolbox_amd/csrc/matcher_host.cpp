@@ -768,8 +768,8 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   }
   std::vector<int32_t> job_sx(n, 1), job_ry(n, 1), job_tiles(n, 1), job_lds(n, 0);
   // LDS-staged scoring (k_offsets_lds / k_score_lds): by default for the searches it was measured faster on -- windows of at most
-  // 61 bytes x 64 rows with >= 1e8 lookups per search (the config-2 CorrelateScan: 0.47 against 0.60 ms per 51 matches); smaller
-  // searches keep the windowed kernel, whose fixed costs per launch are lower.  KH_LDS_SCORE=1 / kh_matcher_set_debug bit 1:
+  // 61 bytes x 64 rows with >= 1e8 lookups per search, in launches of >= 512 angle pairs (the config-2 CorrelateScan in batches:
+  // 0.48 against 0.60 ms per 51 matches); smaller searches and small launches keep the windowed kernel, whose fixed costs are lower.  KH_LDS_SCORE=1 / kh_matcher_set_debug bit 1:
   // every search the path can take; KH_LDS_SCORE=0 / bit 6: none.
   static const int lds_env = std::getenv("KH_LDS_SCORE") ? std::atoi(std::getenv("KH_LDS_SCORE")) : -1;
   const bool lds_never = lds_env == 0 || m->windowed_score;
@@ -892,7 +892,10 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     job->ry = this_ry; job->tile_px = px; job->dec = dec ? 1 : 0;
     job_sx[i] = dec ? 1 : this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
     // LDS-staged scoring: linear lattice whose window fits 64 bytes x 64 rows
-    const bool lds_wanted = lds_always || (!lds_never && static_cast<double>(c.nx) * c.ny * c.na * c.P >= 1e8);
+    // ... and a launch of at least two workgroups (angle pairs) per compute unit: one config-2 search alone is 41 workgroups that
+    // walk their 25 chunks one after the other -- 0.26 ms against the windowed kernel's 0.14
+    const bool lds_wanted = lds_always || (!lds_never && static_cast<double>(c.nx) * c.ny * c.na * c.P >= 1e8 &&
+      static_cast<double>(n) * ((c.na + kGroupAngles - 1) / kGroupAngles) >= 512.0);
     const bool lds_ok = lds_wanted && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
       sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && 63 * sx + 1 <= kLdsRows;
     job_lds[i] = lds_ok ? 1 : 0;
