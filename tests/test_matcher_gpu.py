@@ -416,11 +416,11 @@ def test_dual_copy_layout_follows_the_grid(kartohip_lib):
         hm.CorrelateScan(hq, pose, *args, True, None, False)
         sums3, _ = hm.volume()
         assert np.array_equal(sums, sums3), f"MFMA scoring differs (copies off: {no_copies})"
-    # ... and the default: the LDS-staged kernels (same slot, same grid)
-    hm.set_debug(True)
+    # ... and the LDS-staged kernels (what a batch of these searches takes by default), same slot, same grid
+    hm.set_debug(True, lds_score=True)
     hm.CorrelateScan(hq, pose, *args, True, None, False)
     sums4, _ = hm.volume()
-    assert np.array_equal(sums, sums4), "default (LDS-staged) scoring differs from the windowed kernel"
+    assert np.array_equal(sums, sums4), "LDS-staged scoring differs from the windowed kernel"
     hm.close()
 
 
