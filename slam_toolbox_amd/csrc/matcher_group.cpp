@@ -15,6 +15,7 @@
 #include <functional>
 #include <string>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -28,10 +29,58 @@ void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
 int32_t matcher_max_batch(const kh_matcher * m);
 }
 
+// One persistent host thread per group member beyond the first (the calling thread drives member 0): a batch hands every
+// member its share and waits.  A thread per call cost the mapper about a millisecond per closure, and an exception on a
+// short-lived thread (bad_alloc from the share's vectors) called std::terminate.
+class MemberWorker
+{
+public:
+  MemberWorker() : thread_([this] {loop();}) {}
+  ~MemberWorker()
+  {
+    {std::lock_guard<std::mutex> lk(mu_); quit_ = true;}
+    cv_.notify_all();
+    thread_.join();
+  }
+  void post(std::function<void()> task)
+  {
+    {std::lock_guard<std::mutex> lk(mu_); task_ = std::move(task); busy_ = true;}
+    cv_.notify_all();
+  }
+  void wait()
+  {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] {return !busy_;});
+  }
+private:
+  void loop()
+  {
+    for (;;) {
+      std::function<void()> task;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] {return quit_ || static_cast<bool>(task_);});
+        if (quit_) {return;}
+        task.swap(task_);
+      }
+      task();                                     // (the task catches its own exceptions and reports them through its share)
+      {std::lock_guard<std::mutex> lk(mu_); busy_ = false;}
+      done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::function<void()> task_;
+  bool busy_ = false, quit_ = false;
+  std::thread thread_;
+};
+
 struct kh_matcher_group
 {
   std::vector<kh_matcher *> members;
   std::vector<int32_t> devices;
+  std::vector<std::unique_ptr<MemberWorker>> workers;     // workers[k - 1] drives member k
+  std::mutex call_mu;                                      // one batch at a time per group (the workers hold one task each)
   int32_t max_batch = 0;
 };
 
@@ -51,6 +100,13 @@ int kh_matcher_group_create(double search_size, double resolution, double smear_
     g->members.push_back(m);
     g->devices.push_back(devices[k]);
   }
+  try {
+    for (int32_t k = 1; k < n_devices; ++k) {g->workers.emplace_back(new MemberWorker());}
+  } catch (const std::exception & e) {
+    kh::set_error(std::string("kh_matcher_group_create: ") + e.what());
+    kh_matcher_group_destroy(g);
+    return KH_ERR_HIP;
+  }
   *out = g;
   return KH_OK;
 }
@@ -58,6 +114,7 @@ int kh_matcher_group_create(double search_size, double resolution, double smear_
 void kh_matcher_group_destroy(kh_matcher_group * g)
 {
   if (!g) {return;}
+  g->workers.clear();                            // joins the member threads
   for (kh_matcher * m : g->members) {kh_matcher_destroy(m);}
   delete g;
 }
@@ -98,7 +155,7 @@ int kh_matcher_group_match_batch(kh_matcher_group * g, int32_t n, const kh_scan 
   };
   std::vector<Share> shares(nm);
   for (int32_t i = 0; i < n; ++i) {shares[i % nm].pairs.push_back(i);}
-  auto run = [&](int32_t k) {
+  auto run_share = [&](int32_t k) {
     Share & sh = shares[k];
     const int32_t cap = g->max_batch;
     for (size_t at = 0; at < sh.pairs.size() && sh.rc == KH_OK; at += static_cast<size_t>(cap)) {
@@ -130,13 +187,23 @@ int kh_matcher_group_match_batch(kh_matcher_group * g, int32_t n, const kh_scan 
       }
     }
   };
-  // member 0 works on the calling thread; members without work get no thread
-  std::vector<std::thread> threads;
+  auto run = [&](int32_t k) {
+    try {
+      run_share(k);
+    } catch (const std::exception & e) {         // e.g. bad_alloc from the share's vectors: an error code, not std::terminate
+      shares[k].rc = KH_ERR_HIP;
+      shares[k].error = std::string("kh_matcher_group_match_batch: ") + e.what();
+    }
+  };
+  // member 0 works on the calling thread, the others on their persistent workers; members without work are left alone
+  std::lock_guard<std::mutex> call_lock(g->call_mu);
   for (int32_t k = 1; k < nm; ++k) {
-    if (!shares[k].pairs.empty()) {threads.emplace_back(run, k);}
+    if (!shares[k].pairs.empty()) {g->workers[k - 1]->post([&run, k] {run(k);});}
   }
   if (!shares[0].pairs.empty()) {run(0);}
-  for (std::thread & t : threads) {t.join();}
+  for (int32_t k = 1; k < nm; ++k) {
+    if (!shares[k].pairs.empty()) {g->workers[k - 1]->wait();}
+  }
   for (int32_t k = 0; k < nm; ++k) {
     if (shares[k].rc) {kh::set_error(shares[k].error); return shares[k].rc;}
   }
