@@ -1009,7 +1009,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        pg_timeout = datetime.timedelta(seconds=300)       # a collective that waits longer than this has lost a peer
+        pg_timeout = datetime.timedelta(seconds=900)       # a collective that waits longer than this has lost a peer (rank 0 runs its one-process legs while the others wait)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
                                     timeout=pg_timeout)

@@ -1674,48 +1674,106 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
   if (job.coarse) {
     // search-space probabilities (Mapper.cpp:781-799): the best response over the angles of every cell, recomputed here from
     // the stored sums with the same device function -- one plain store per cell instead of one atomic maximum per POSE in the
-    // scoring kernel's epilogue (301 401 of them per config-2 match, all on the same 30 KB)
+    // scoring kernel's epilogue (301 401 of them per config-2 match, all on the same 30 KB).
+    // The exact response costs a double-precision division per angle.  The maximum over the angles is found in two passes:
+    // a single-precision key sum x angle penalty first (the distance penalty is common to the cell; the key orders the
+    // responses up to a relative 3e-7), then the exact response of the angles whose key lies within 1e-5 of the largest --
+    // one or two of the 81.  Responses at or below 1e-6 skip the penalty (math::DoubleEqual(response, 0), Mapper.cpp:671-685)
+    // and do not follow the key: a cell whose largest sum is that small takes the exact pass over all its angles.
+    // Work split: a workgroup takes 64 cells at a time (lane = cell: coalesced rows of the sums volume), its four waves a
+    // quarter of the angles each -- a thread's sums are read ONCE, all in flight together, and kept in registers for both passes.
     const int na = job.na, nxp = job.nx;
     const int32_t * const sums = job.sums;
     unsigned long long * const probs = job.out + kOutHeaderWords;
     const bool penal = job.do_penalize != 0;
     const double denom = job.denom;
-    for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < (int)plane; cell += gridDim.x * blockDim.x) {
-      const int yi = cell / nxp, xi = cell - yi * nxp;
-      // The exact response costs a double-precision division per angle.  The maximum over the angles is found in two passes:
-      // a single-precision key sum x angle penalty first (the distance penalty is common to the cell; the key orders the
-      // responses up to a relative 3e-7), then the exact response of the angles whose key lies within 1e-5 of the largest --
-      // one or two of the 81.  Responses at or below 1e-6 skip the penalty (math::DoubleEqual(response, 0), Mapper.cpp:671-685)
-      // and do not follow the key: a cell whose largest sum is that small takes the exact pass over all its angles.
-      int32_t smax = 0;
-      float kmax = 0.0f;
-      for (int a0 = 0; a0 < na; a0 += 8) {
-        int32_t v[8];                                    // eight independent loads in flight
+    constexpr int kSlice = 32;                             // angles per wave held in registers
+    __shared__ float s_key[4][64];
+    __shared__ int32_t s_sum[4][64];
+    __shared__ double s_max[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int per = (na + 3) / 4;
+    if (per <= kSlice && blockDim.x == 256) {
+      const int a_lo = slice * per;
+      for (int cell0 = blockIdx.x * 64; cell0 < (int)plane; cell0 += gridDim.x * 64) {
+        const int cell = cell0 + lane;
+        const bool valid = cell < (int)plane;
+        int32_t v[kSlice];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {v[t] = a0 + t < na ? sums[(size_t)(a0 + t) * plane + cell] : 0;}
+        for (int t = 0; t < kSlice; ++t) {v[t] = (valid && t < per && a_lo + t < na) ? sums[(size_t)(a_lo + t) * plane + cell] : 0;}
+        int32_t smax = 0;
+        float kmax = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          if (a0 + t < na) {
-            const float key = (float)v[t] * (penal ? (float)job.ang_pen[a0 + t] : 1.0f);
+        for (int t = 0; t < kSlice; ++t) {
+          if (t < per && a_lo + t < na) {
+            const float key = (float)v[t] * (penal ? (float)job.ang_pen[a_lo + t] : 1.0f);
             kmax = key > kmax ? key : kmax;
             smax = v[t] > smax ? v[t] : smax;
           }
         }
-      }
-      double m = 0.0;
-      if (smax > 0) {
-        const bool all = (double)smax / denom < 4e-6;
-        const float thresh = all ? -1.0f : kmax * (1.0f - 1e-5f);
-        for (int a = 0; a < na; ++a) {
-          const int32_t v = sums[(size_t)a * plane + cell];
-          const float key = (float)v * (penal ? (float)job.ang_pen[a] : 1.0f);
-          if (key >= thresh) {
-            const double response = pose_response(job, v, a, yi, xi);
-            m = response > m ? response : m;
+        s_key[slice][lane] = kmax; s_sum[slice][lane] = smax;
+        __syncthreads();
+        kmax = fmaxf(fmaxf(s_key[0][lane], s_key[1][lane]), fmaxf(s_key[2][lane], s_key[3][lane]));
+        smax = max(max(s_sum[0][lane], s_sum[1][lane]), max(s_sum[2][lane], s_sum[3][lane]));
+        double m = 0.0;
+        if (valid && smax > 0) {
+          const int yi = cell / nxp, xi = cell - yi * nxp;
+          const bool all = (double)smax / denom < 4e-6;
+          const float thresh = all ? -1.0f : kmax * (1.0f - 1e-5f);
+#pragma unroll
+          for (int t = 0; t < kSlice; ++t) {
+            if (t < per && a_lo + t < na) {
+              const float key = (float)v[t] * (penal ? (float)job.ang_pen[a_lo + t] : 1.0f);
+              if (key >= thresh) {
+                const double response = pose_response(job, v[t], a_lo + t, yi, xi);
+                m = response > m ? response : m;
+              }
+            }
           }
         }
+        s_max[slice][lane] = m;
+        __syncthreads();
+        if (slice == 0 && valid) {
+          const double m01 = s_max[0][lane] > s_max[1][lane] ? s_max[0][lane] : s_max[1][lane];
+          const double m23 = s_max[2][lane] > s_max[3][lane] ? s_max[2][lane] : s_max[3][lane];
+          probs[cell] = (unsigned long long)__double_as_longlong(m01 > m23 ? m01 : m23);
+        }
+        __syncthreads();
       }
-      probs[cell] = (unsigned long long)__double_as_longlong(m);
+    } else {
+      // more than 128 angles: a thread per cell walks them all, eight loads at a time
+      for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < (int)plane; cell += gridDim.x * blockDim.x) {
+        const int yi = cell / nxp, xi = cell - yi * nxp;
+        int32_t smax = 0;
+        float kmax = 0.0f;
+        for (int a0 = 0; a0 < na; a0 += 8) {
+          int32_t v[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {v[t] = a0 + t < na ? sums[(size_t)(a0 + t) * plane + cell] : 0;}
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            if (a0 + t < na) {
+              const float key = (float)v[t] * (penal ? (float)job.ang_pen[a0 + t] : 1.0f);
+              kmax = key > kmax ? key : kmax;
+              smax = v[t] > smax ? v[t] : smax;
+            }
+          }
+        }
+        double m = 0.0;
+        if (smax > 0) {
+          const bool all = (double)smax / denom < 4e-6;
+          const float thresh = all ? -1.0f : kmax * (1.0f - 1e-5f);
+          for (int a = 0; a < na; ++a) {
+            const int32_t v = sums[(size_t)a * plane + cell];
+            const float key = (float)v * (penal ? (float)job.ang_pen[a] : 1.0f);
+            if (key >= thresh) {
+              const double response = pose_response(job, v, a, yi, xi);
+              m = response > m ? response : m;
+            }
+          }
+        }
+        probs[cell] = (unsigned long long)__double_as_longlong(m);
+      }
     }
   }
   auto consider = [&](int a, int yi, int xi) {
