@@ -334,7 +334,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     // ago (and lifelong mode removes a few).  The supernodes of the last dissection, kept by node id, are reused -- the
     // nodes that have left drop out, the new ones become leading leaf supernodes (eliminated first: no extra levels; their
     // old neighbours become mutually adjacent, which the structure pass accounts for like any fill) -- and only the structure
-    // is rebuilt.  A full dissection again when the new nodes pass a quarter of the graph, when the fill has grown by half,
+    // is rebuilt.  A full dissection again when the new nodes pass a quarter of the graph, when the factorisation's flops have tripled relative to the graph's growth,
     // or after kMaxReuse re-analyses.  kh_spa_reset() forgets the supernodes (a reloaded graph is analysed from scratch).
     const auto t_sym0 = std::chrono::steady_clock::now();
     SymbolicOptions sopt;
@@ -371,9 +371,11 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
           for (int32_t f = 0; f < nf; ++f) {if (!placed[f]) {fresh.push_back(f);}}
           if (!fresh.empty()) {sn.insert(sn.begin(), std::move(fresh));}          // build_structure splits it into a chain when long
           sym_rc = build_structure(s->sym, nf, adj_ptr, adj_idx, sopt, sn);
-          // fill guard: the factorisation may cost half as much again as the last full dissection's, scaled by how much the
-          // graph has grown since (flops grow at least linearly with the free nodes)
-          const double allowed = 1.5 * static_cast<double>(s->cached_full_flops) * static_cast<double>(nf) / static_cast<double>(std::max(1, s->cached_full_nf));
+          // fill guard: the factorisation may cost three times the last full dissection's, scaled by how much the graph has
+          // grown since (flops grow at least linearly with the free nodes).  Three, not one and a half: the leading leaves of a
+          // closure's few dozen new nodes add little fill, but a bound of 1.5 sent most closures of the 50 000-scan replay back
+          // to a full dissection (5 ms each: the replay's solver time went from 4.1 to 7.5 s)
+          const double allowed = 3.0 * static_cast<double>(s->cached_full_flops) * static_cast<double>(nf) / static_cast<double>(std::max(1, s->cached_full_nf));
           if (sym_rc == KH_OK && static_cast<double>(s->sym.factor_flops) <= allowed) {
             sym_incremental = true;
             return;

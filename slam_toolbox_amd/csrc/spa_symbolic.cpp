@@ -205,6 +205,22 @@ bool nd_split(NdContext & ctx, std::vector<int32_t> & nodes, int32_t hint, std::
   return true;
 }
 
+// A whole subtree, serially: the supernodes of `nodes` in elimination order (A's, B's, then the separator).  The recursion is
+// as deep as the dissection tree: a few dozen frames.
+void dissect_subtree(NdContext & ctx, std::vector<int32_t> & nodes, int32_t hint, std::vector<std::vector<int32_t>> & out)
+{
+  std::vector<int32_t> A, B, cover;
+  int32_t ha = -1, hb = -1;
+  if (!nd_split(ctx, nodes, hint, A, B, cover, ha, hb)) {
+    if (!nodes.empty()) {out.push_back(std::move(nodes));}
+    return;
+  }
+  std::vector<int32_t>().swap(nodes);
+  dissect_subtree(ctx, A, ha, out);
+  dissect_subtree(ctx, B, hb, out);
+  if (!cover.empty()) {out.push_back(std::move(cover));}
+}
+
 }  // namespace
 
 int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, const std::vector<int32_t> & adj_idx,
@@ -217,11 +233,17 @@ int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, cons
   ctx.tag.assign(n_free, 0);
   ctx.dist.assign(n_free, 0);
   ctx.loc.assign(n_free, -1);
-  // The dissection tree is grown level by level: the subsets of a level are independent (disjoint vertex sets), so a level is
-  // one parallel loop over its subsets when the caller supplies one (opt.parallel_for: the library's persistent host pool --
-  // a thread per split, as through round 3, cost more in thread creation than the splits saved).  The elimination order is
-  // read off the finished tree in post-order: A's supernodes, B's, then the separator.
-  struct Task {std::vector<int32_t> nodes, cover; int32_t hint = -1, a = -1, b = -1; bool split = false;};
+  // The top of the dissection tree is grown level by level, serially, until a level holds kWholeSubtrees subsets; each of
+  // those is then dissected to its leaves by one task of ONE parallel loop when the caller supplies one (opt.parallel_for:
+  // the library's persistent host pool; the subsets are disjoint vertex sets, so the tasks share nothing but the read-only
+  // adjacency).  One loop, not one per level: waking the pool's sleeping threads costs about 0.2 ms a time, and a loop per
+  // level (fifteen per analysis, ever smaller subsets) made the mapper's analyses slower than serial ones (+2.7 ms per loop
+  // closure of the 50 000-scan replay); a thread per split, as through round 3, paid thread creation instead.  The three
+  // serial levels are a fifth of the work.  The elimination order is read off the finished tree in post-order: A's
+  // supernodes, B's, then the separator.
+  constexpr size_t kWholeSubtrees = 8;
+  struct Task {std::vector<int32_t> nodes, cover; int32_t hint = -1, a = -1, b = -1; bool split = false, whole = false;
+    std::vector<std::vector<int32_t>> done;};
   std::vector<Task> tree(1);
   tree[0].nodes.resize(n_free);
   for (int32_t i = 0; i < n_free; ++i) {tree[0].nodes[i] = i;}
@@ -229,13 +251,22 @@ int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, cons
   while (level_begin < tree.size()) {
     const size_t level_end = tree.size();
     const size_t count = level_end - level_begin;
+    if (!opt.parallel_for || count >= kWholeSubtrees) {
+      auto whole = [&](size_t i) {
+        Task & t = tree[level_begin + i];
+        t.whole = true;
+        dissect_subtree(ctx, t.nodes, t.hint, t.done);
+      };
+      if (opt.parallel_for && count > 1) {opt.parallel_for(count, whole);} else {for (size_t i = 0; i < count; ++i) {whole(i);}}
+      break;
+    }
     std::vector<std::vector<int32_t>> As(count), Bs(count);
     std::vector<int32_t> ha(count, -1), hb(count, -1);
     auto work = [&](size_t i) {
       Task & t = tree[level_begin + i];
       t.split = nd_split(ctx, t.nodes, t.hint, As[i], Bs[i], t.cover, ha[i], hb[i]);
     };
-    if (opt.parallel_for && count > 1) {opt.parallel_for(count, work);} else {for (size_t i = 0; i < count; ++i) {work(i);}}
+    for (size_t i = 0; i < count; ++i) {work(i);}
     for (size_t i = 0; i < count; ++i) {
       if (!tree[level_begin + i].split) {continue;}
       Task ta, tb;
@@ -254,7 +285,10 @@ int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, cons
     const int32_t k = stack.back().first;
     int & state = stack.back().second;
     Task & t = tree[k];
-    if (!t.split) {
+    if (t.whole) {
+      for (auto & sn : t.done) {supernodes.push_back(std::move(sn));}
+      stack.pop_back();
+    } else if (!t.split) {
       if (!t.nodes.empty()) {supernodes.push_back(std::move(t.nodes));}
       stack.pop_back();
     } else if (state == 0) {
