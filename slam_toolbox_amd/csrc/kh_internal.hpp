@@ -175,6 +175,9 @@ void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32
 void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_tiles, int32_t max_na,
                   int32_t sx_variant, int32_t ry, void * stream, bool mfma = false);
 // poses per tile row of the scoring kernel for a lattice step of sx cells
+// LDS-staged scoring: how many of an angle's four waves share the lattice rows (16 each); the others split the beams.
+// Three is rounded up to four: the parts of the steps are dealt by a power-of-two mask.
+__host__ __device__ inline int32_t lds_row_waves(int32_t ny) {return ny <= 16 ? 1 : ny <= 32 ? 2 : 4;}
 inline int32_t score_tile_poses(int32_t sx) {return sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;}
 void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
 void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream);

@@ -27,6 +27,7 @@
 
 #include "../../include/karto_hip.h"
 #include "kh_internal.hpp"
+#include "host_pool.hpp"
 
 namespace kh
 {
@@ -244,88 +245,7 @@ static int ensure_pinned(T *& p, size_t & cap, size_t need, hipStream_t stream)
 }
 
 
-// ---- host worker pool ---------------------------------------------------------------------------
-// The exact-arithmetic host half (tables, penalties, FindValidPoints, tie averaging, covariances) is
-// O(P + nX*nY + nA) per match and independent between the matches of a batch; with the scoring kernel at
-// ~30 us per match it is what bounds a batch, so it is spread over a few host threads
-// (KH_HOST_THREADS, default min(32, cores): measured 16 / 32 / 64 -> 7.4 / 7.9 / 8.0 k loop-closure pairs/s and
-// 61.6 / 61.9 / 59.4 k config-2 matches/s).  Results do not depend on the thread count.
-class HostPool
-{
-public:
-  static HostPool & instance() {static HostPool p(0); return p;}
-  // the mapper's pose re-projections: milliseconds of uniform work over thousands of scans, kept alive between calls (a team
-  // spawned per call cost a millisecond per loop closure).  64 threads: the work writes 35 KB per scan (points, filtered
-  // points) and is bound by the host's memory bandwidth well before the box runs out of cores -- 192 threads took 7.9 s of
-  // the 50 000-scan replay where 64 take 4
-  static HostPool & wide() {static HostPool p(1); return p;}
-  // runs fn(i) for i in [0, n); returns when all are done
-  void run(size_t n, const std::function<void(size_t)> & fn)
-  {
-    if (n == 0) {return;}
-    if (n == 1 || workers_.empty()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
-    // one parallel region at a time; a second handle arriving from another thread while the workers are taken does its
-    // loop itself instead of queueing behind the first (the regions are short: waiting would idle the caller's GPU stream)
-    std::unique_lock<std::mutex> serial(run_mu_, std::try_to_lock);
-    if (!serial.owns_lock()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn; n_ = n; next_.store(0); pending_ = workers_.size(); ++generation_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] {return pending_ == 0;});
-    fn_ = nullptr;
-  }
-  ~HostPool()
-  {
-    {std::lock_guard<std::mutex> lk(mu_); stop_ = true;}
-    cv_.notify_all();
-    for (auto & t : workers_) {t.join();}
-  }
-private:
-  explicit HostPool(int wide_pool)
-  {
-    unsigned want = std::min(wide_pool ? 64u : 32u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char * e = std::getenv(wide_pool ? "KH_MAPPER_UPDATE_THREADS" : "KH_HOST_THREADS")) {want = static_cast<unsigned>(std::max(1, std::atoi(e)));}
-    for (unsigned t = 1; t < want; ++t) {workers_.emplace_back([this] {loop();});}
-  }
-  void work()
-  {
-    for (;;) {
-      const size_t i = next_.fetch_add(1);
-      if (i >= n_) {break;}
-      (*fn_)(i);
-    }
-  }
-  void loop()
-  {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] {return stop_ || generation_ != seen;});
-        if (stop_) {return;}
-        seen = generation_;
-      }
-      work();
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (--pending_ == 0) {done_cv_.notify_all();}
-      }
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex mu_, run_mu_;
-  std::condition_variable cv_, done_cv_;
-  const std::function<void(size_t)> * fn_ = nullptr;
-  size_t n_ = 0, pending_ = 0;
-  std::atomic<size_t> next_{0};
-  uint64_t generation_ = 0;
-  bool stop_ = false;
-};
-
+// ---- host worker pool: host_pool.hpp ----
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn) {HostPool::instance().run(n, fn);}
 void host_parallel_for_wide(size_t n, const std::function<void(size_t)> & fn) {HostPool::wide().run(n, fn);}
 

@@ -1960,8 +1960,9 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   const float inv_ws = 1.0f / (float)ws;
   const int64_t data_size = job.data_size, pad = job.pad;
   const double off_x = job.grid_off_x, off_y = job.grid_off_y, scale = job.scale;
-  // rows a wave of K3' reads past a window's first row (63 lattice rows), and rows that have to be staged
-  const int read_rows = 63 * job.sy_cells + 1;
+  // rows K3' reads past a window's first row: its row waves cover 16, 32 or 64 lattice rows (lds_row_waves)
+  const int row_waves = lds_row_waves(job.ny);
+  const int read_rows = (16 * row_waves - 1) * job.sy_cells + 1;
   const int span_rows = ys;
   double cosine[kGroupAngles], sine[kGroupAngles];
 #pragma unroll
@@ -2124,7 +2125,7 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   if (lane == 0) {
     job.chunk_counts[(size_t)group * kLdsRanges + wave] = n_out;
     // every window costs K3' sixteen wave-level ds_read_b32 (256 B each): the numerator of the roofline
-    if (job.load_counter && windows_total) {atomicAdd(job.load_counter, (unsigned long long)(windows_total * 16));}
+    if (job.load_counter && windows_total) {atomicAdd(job.load_counter, (unsigned long long)(windows_total * 4 * row_waves));}
   }
   KH_TK(tk_c);
   __syncthreads();
@@ -2180,7 +2181,13 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lx = lane & 15, ly = lane >> 4;
-  const int q = wave / NW, quarter = wave % NW;          // ("quarter": this wave's share of the rows, 4 * RQ of them)
+  const int q = wave / NW, quarter = wave % NW;
+  // The NW waves of an angle: row_waves of them share the lattice rows (4 * RQ each), and when the lattice has fewer rows than
+  // the NW waves cover together (31 rows: two waves) the waves left over take every other STEP of the same rows instead of
+  // scoring rows nobody asked for: wave = (share of the rows, part of the steps).
+  const int row_waves = lds_row_waves(job.ny) * (NW / 4);
+  const int parts = NW / row_waves;
+  const int share = quarter % row_waves, part = quarter / row_waves;
   const int a = group * kGroupAngles + q;
   const bool live = a < job.na;
   const int P = job.n_points;
@@ -2202,7 +2209,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     sel = v4i{one, one, one, one};
   }
   // byte offset of this lane's first row inside a window (the other rows are immediates: fixed pitch)
-  const int lanebase = 4 * lx + (4 * RQ * quarter + ly) * S * kLdsPitch;
+  const int lanebase = 4 * lx + (4 * RQ * share + ly) * S * kLdsPitch;
 
   const gbyte * gwin = as_global(job.grid) + job.base0;
   const gint * grel = as_global(job.rel + (size_t)(live ? a : 0) * P);
@@ -2254,6 +2261,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   const uint32_t lds_zero = lds_base + (uint32_t)(2 * kLdsRegionBytes);
   if (tid < RQ) {s_region[(2 * kLdsRegionBytes + tid * kRowStep) / 4] = 0u;}
 #define KH_DSR(dst, addr, r) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((r) * kRowStep) : "memory")
+  int step_base = 0;
   auto score = [&](const Chunk & d, int buf, int32_t rels) {
     if (!live) {return;}
     const uint32_t base = lds_lane + (uint32_t)(buf * kLdsRegionBytes);
@@ -2261,7 +2269,11 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
 #pragma unroll
     for (int c = 0; c < kClasses; ++c) {
       const int cnt = (d.packed >> (8 * c)) & 0xff;
-      for (int k = 0; k < cnt; k += 4) {
+      // this wave's steps of the class: those whose running number (over the classes and chunks of the angle) is `part`
+      // modulo `parts`
+      const int first = (part - step_base) & (parts - 1);
+      step_base += (cnt + 3) >> 2;
+      for (int k = 4 * first; k < cnt; k += 4 * parts) {
         const int i0 = off + k, rem = cnt - k;
         int32_t w[RQ][4];
         const uint32_t a0 = base + (uint32_t)__builtin_amdgcn_readlane(rels, i0);
@@ -2355,7 +2367,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
           const int j = 4 * lx + b;                              // byte position inside the aligned window row
           const int x = (j - c) / S;
           const bool pose = j >= c && ((j - c) % S) == 0 && x < PX;
-          if (pose && acc[c][r][b] != 0) {atomicAdd(&s_tile[(4 * RQ * quarter + 4 * r + ly) * PX + x], acc[c][r][b]);}
+          if (pose && acc[c][r][b] != 0) {atomicAdd(&s_tile[(4 * RQ * share + 4 * r + ly) * PX + x], acc[c][r][b]);}
         }
       }
     }
