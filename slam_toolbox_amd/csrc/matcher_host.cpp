@@ -1139,12 +1139,29 @@ static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   // waited for), so later main-stream work needs no edge back
   KH_HIP(hipEventRecord(m->batch[0].kdone, m->stream));
   for (auto & b : m->batch) {KH_HIP(hipStreamWaitEvent(b.side, m->batch[0].kdone, 0));}
-  // a shorter first and last chunk: the pipeline fills on the first (its preparation, upload and K2 are exposed) and drains
-  // on the last (its K4, download and finalisation are); 32 measured 71.5 k config-2 matches/s against 69.6 k with
-  // uniform chunks of 64 and 68.7 k with 16.  KH_CHUNK_EDGE=64 restores the uniform split.
-  static const size_t edge = std::getenv("KH_CHUNK_EDGE") ? static_cast<size_t>(std::max(8, std::min(256, std::atoi(std::getenv("KH_CHUNK_EDGE"))))) : 32;
+  // a shorter first chunk: the pipeline fills on it (its preparation, upload and K2 are exposed) and drains on the last (its
+  // K4, download and finalisation are).  256 config-2 matches as 24 + 64 + 64 + 64 + 40 measured 79.9 k and 81.4 k matches/s
+  // on two boxes where 32 + 64 + 64 + 64 + 32 (the split of rounds 2-3) gave 78.4 k and 76.5 k, a first chunk of 16 74.4 k,
+  // uniform chunks of 64 less again; splits sized to whole rounds of workgroups (24 + 62 + 62 + 62 + 46) measured no better
+  // than the plain one.  KH_CHUNK_EDGE=64 restores the uniform split, KH_CHUNK_SIZES=a,b,... sets one by hand.
+  static const size_t edge = std::getenv("KH_CHUNK_EDGE") ? static_cast<size_t>(std::max(8, std::min(256, std::atoi(std::getenv("KH_CHUNK_EDGE"))))) : 24;
   std::vector<size_t> bounds;
-  if (edge < kChunk && n >= 2 * edge + kChunk) {
+  // KH_CHUNK_SIZES=a,b,c,...: an explicit split (measurements); the last size is repeated / cut to cover the batch
+  static const char * sizes_env = std::getenv("KH_CHUNK_SIZES");
+  if (sizes_env) {
+    size_t at = 0, last = kChunk;
+    const char * p = sizes_env;
+    while (at < n) {
+      if (*p) {
+        char * end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end != p && v > 0) {last = static_cast<size_t>(v);}
+        p = (*end == ',') ? end + 1 : end;
+      }
+      bounds.push_back(at);
+      at += last;
+    }
+  } else if (edge < kChunk && n >= 2 * edge + kChunk) {
     bounds.push_back(0);
     for (size_t at = edge; at + edge < n; at += kChunk) {bounds.push_back(at);}
     if (n - bounds.back() > kChunk) {bounds.push_back(n - edge);}
