@@ -32,60 +32,78 @@ struct NdContext
 {
   const std::vector<int32_t> * adj_ptr = nullptr;
   const std::vector<int32_t> * adj_idx = nullptr;
-  std::vector<int32_t> tag;           // subset membership stamp
-  std::vector<int32_t> dist;          // BFS level
+  struct Vertex {int32_t tag, dist;}; // subset membership stamp, BFS level: one cache line brings both
+  std::vector<Vertex> vs;
   std::vector<int32_t> loc;           // scratch: local index of a vertex inside the bipartite cut graph
   std::atomic<int32_t> stamp{0};      // sibling subsets are dissected concurrently on disjoint vertices
   SymbolicOptions opt;
 };
 using SupernodeList = std::vector<std::vector<int32_t>>;
 
-// BFS inside the subset stamped `st`; returns the visit order (sorted by level; levels in ctx.dist)
-void nd_bfs(NdContext & ctx, int32_t start, int32_t st, std::vector<int32_t> & order)
+// What a subset inherits from the split that made it: a vertex at one of its ends, and whether the subset's vertices already
+// ARE the breadth-first order from that vertex with their levels in ctx.dist (the near side of a cut: see nd_split).
+struct NdHint {int32_t vertex = -1; bool levels_ready = false;};
+
+// Work vectors of one dissecting thread, kept across the ~800 splits of an analysis: allocated afresh per split they were
+// 26 000 vector reallocations per analysis of the 10 000-node graph -- half of its time.
+struct NdScratch
+{
+  struct Cand {int32_t est, l;};
+  std::vector<Cand> cands;
+  std::vector<int32_t> order, lstart, cover;
+  std::vector<int32_t> left, right, eptr, eidx, match_l, match_r, seen, stack_v, stack_e, work;
+  std::vector<uint8_t> zl, zr;
+};
+
+// BFS inside the subset stamped `from`; returns the visit order (sorted by level; levels in the vertices' dist).  The vertices it
+// reaches are re-stamped `to`: the subset's stamp from here on (no pass to un-mark them).
+void nd_bfs(NdContext & ctx, int32_t start, int32_t from, int32_t to, std::vector<int32_t> & order)
 {
   const std::vector<int32_t> & ap = *ctx.adj_ptr, & ai = *ctx.adj_idx;
+  NdContext::Vertex * const vs = ctx.vs.data();
   order.clear();
   order.push_back(start);
-  ctx.dist[start] = 0;
-  ctx.tag[start] = -st;               // visited marker
+  vs[start].dist = 0;
+  vs[start].tag = to;
   for (size_t h = 0; h < order.size(); ++h) {
     const int32_t v = order[h];
-    const int32_t dv = ctx.dist[v] + 1;
+    const int32_t dv = vs[v].dist + 1;
     for (int32_t k = ap[v]; k < ap[v + 1]; ++k) {
       const int32_t w = ai[k];
-      if (ctx.tag[w] == st) {ctx.tag[w] = -st; ctx.dist[w] = dv; order.push_back(w);}
+      if (vs[w].tag == from) {vs[w].tag = to; vs[w].dist = dv; order.push_back(w);}
     }
   }
-  for (int32_t v : order) {ctx.tag[v] = st;}
 }
 
 // Minimum vertex cover of the edges between level l - 1 (left) and level l (right) of the level structure in `order`
 // (level q = order[lstart[q] .. lstart[q + 1])).  Kuhn's augmenting paths (the sides hold tens of vertices), then Koenig's
 // construction: with Z = the vertices reachable from the unmatched left vertices by alternating paths, the cover is
 // (left \ Z) + (right & Z).
-void cut_vertex_cover(NdContext & ctx, const std::vector<int32_t> & order, const std::vector<int32_t> & lstart, int32_t l, int32_t st,
-  std::vector<int32_t> & cover)
+void cut_vertex_cover(NdContext & ctx, NdScratch & sc, const std::vector<int32_t> & order, const std::vector<int32_t> & lstart, int32_t l,
+  int32_t st, std::vector<int32_t> & cover)
 {
   const std::vector<int32_t> & ap = *ctx.adj_ptr, & ai = *ctx.adj_idx;
   cover.clear();
-  std::vector<int32_t> left, right;                 // vertex ids
-  std::vector<int32_t> eptr(1, 0), eidx;            // left local -> right locals
+  std::vector<int32_t> & left = sc.left, & right = sc.right;     // vertex ids
+  std::vector<int32_t> & eptr = sc.eptr, & eidx = sc.eidx;       // left local -> right locals
+  left.clear(); right.clear(); eidx.clear(); eptr.assign(1, 0);
   for (int32_t q = lstart[l]; q < lstart[l + 1]; ++q) {ctx.loc[order[q]] = -1;}
   for (int32_t q = lstart[l - 1]; q < lstart[l]; ++q) {
     const int32_t v = order[q];
     const size_t before = eidx.size();
     for (int32_t k = ap[v]; k < ap[v + 1]; ++k) {
       const int32_t w = ai[k];
-      if (ctx.tag[w] != st || ctx.dist[w] != l) {continue;}
+      if (ctx.vs[w].tag != st || ctx.vs[w].dist != l) {continue;}
       if (ctx.loc[w] < 0) {ctx.loc[w] = static_cast<int32_t>(right.size()); right.push_back(w);}
       eidx.push_back(ctx.loc[w]);
     }
     if (eidx.size() > before) {left.push_back(v); eptr.push_back(static_cast<int32_t>(eidx.size()));}
   }
   const int32_t nl = static_cast<int32_t>(left.size()), nr = static_cast<int32_t>(right.size());
-  std::vector<int32_t> match_l(nl, -1), match_r(nr, -1), seen(nr, -1);
+  std::vector<int32_t> & match_l = sc.match_l, & match_r = sc.match_r, & seen = sc.seen;
+  match_l.assign(nl, -1); match_r.assign(nr, -1); seen.assign(nr, -1);
   // iterative augmenting-path search from left vertex `root`
-  std::vector<int32_t> stack_v, stack_e;
+  std::vector<int32_t> & stack_v = sc.stack_v, & stack_e = sc.stack_e;
   for (int32_t root = 0; root < nl; ++root) {
     stack_v.assign(1, root); stack_e.assign(1, eptr[root]);
     bool found = false;
@@ -111,8 +129,10 @@ void cut_vertex_cover(NdContext & ctx, const std::vector<int32_t> & order, const
       }
     }
   }
-  std::vector<uint8_t> zl(nl, 0), zr(nr, 0);
-  std::vector<int32_t> work;
+  std::vector<uint8_t> & zl = sc.zl, & zr = sc.zr;
+  zl.assign(nl, 0); zr.assign(nr, 0);
+  std::vector<int32_t> & work = sc.work;
+  work.clear();
   for (int32_t u = 0; u < nl; ++u) {if (match_l[u] < 0) {zl[u] = 1; work.push_back(u);}}
   while (!work.empty()) {
     const int32_t u = work.back(); work.pop_back();
@@ -133,40 +153,55 @@ void cut_vertex_cover(NdContext & ctx, const std::vector<int32_t> & order, const
 // vertex of the parent's level structure, whichever side the subset came from), or -1: with a hint ONE breadth-first search
 // gives connectivity and the level structure.  A disconnected subset is split into one component and the rest, no separator.
 // Sibling subsets are dissected concurrently: they touch disjoint entries of the context's per-vertex arrays.
-bool nd_split(NdContext & ctx, std::vector<int32_t> & nodes, int32_t hint, std::vector<int32_t> & A, std::vector<int32_t> & B,
-  std::vector<int32_t> & best_cover, int32_t & hint_a, int32_t & hint_b)
+bool nd_split(NdContext & ctx, NdScratch & sc, std::vector<int32_t> & nodes, NdHint hint, std::vector<int32_t> & A, std::vector<int32_t> & B,
+  std::vector<int32_t> & best_cover, NdHint & hint_a, NdHint & hint_b)
 {
-  A.clear(); B.clear(); best_cover.clear(); hint_a = -1; hint_b = -1;
+  A.clear(); B.clear(); best_cover.clear(); hint_a = NdHint(); hint_b = NdHint();
   auto as_leaf = [&]() {std::sort(nodes.begin(), nodes.end()); return false;};
   if (static_cast<int32_t>(nodes.size()) <= ctx.opt.leaf_nodes) {return as_leaf();}
-  const int32_t st = ++ctx.stamp;
-  for (int32_t v : nodes) {ctx.tag[v] = st;}
-  std::vector<int32_t> order;
+  int32_t st = ++ctx.stamp;             // the subset's current stamp: a search re-stamps what it reaches
+  for (int32_t v : nodes) {ctx.vs[v].tag = st;}
+  std::vector<int32_t> & order = sc.order;
+  order.clear();
   order.reserve(nodes.size());
-  const bool hinted = hint >= 0 && ctx.tag[hint] == st;
-  nd_bfs(ctx, hinted ? hint : nodes[0], st, order);
-  if (order.size() < nodes.size()) {
-    // disconnected subset: split off this component (independent subtrees)
-    for (int32_t v : order) {ctx.tag[v] = 0;}
-    for (int32_t v : nodes) {if (ctx.tag[v] == st) {B.push_back(v);}}
-    A.swap(order);
-    return true;
+  const bool hinted = hint.vertex >= 0 && ctx.vs[hint.vertex].tag == st;
+  if (hinted && hint.levels_ready && nodes[0] == hint.vertex) {
+    // the near side of the parent's cut: its vertices came out of the parent's breadth-first order (from this very root) in
+    // that order, and a search from the root inside the subset would find them in the same order at the same levels -- every
+    // vertex below the cut is discovered from the level before it, all of which stayed in the subset.  No search: half of the
+    // dissection's breadth-first work.
+    order.assign(nodes.begin(), nodes.end());
+  } else {
+    const int32_t unreached = st;
+    st = ++ctx.stamp;
+    nd_bfs(ctx, hinted ? hint.vertex : nodes[0], unreached, st, order);
+    if (order.size() < nodes.size()) {
+      // disconnected subset: split off this component (independent subtrees)
+      B.reserve(nodes.size() - order.size());
+      for (int32_t v : nodes) {if (ctx.vs[v].tag == unreached) {B.push_back(v);}}
+      A.assign(order.begin(), order.end());
+      return true;
+    }
   }
   // pseudo-peripheral start: restart the BFS from the farthest vertex (a hinted start already is such a vertex)
   if (!hinted) {
     const int32_t far = order.back();
-    nd_bfs(ctx, far, st, order);
+    const int32_t before = st;
+    st = ++ctx.stamp;
+    nd_bfs(ctx, far, before, st, order);
   }
-  const int32_t depth_bfs = ctx.dist[order.back()];
+  const int32_t depth_bfs = ctx.vs[order.back()].dist;
   if (depth_bfs < 2) {return as_leaf();}      // clique-like: no level can separate anything
-  std::vector<int32_t> lstart(depth_bfs + 2, 0);
-  for (int32_t v : order) {lstart[ctx.dist[v] + 1]++;}
+  std::vector<int32_t> & lstart = sc.lstart;
+  lstart.assign(depth_bfs + 2, 0);
+  for (int32_t v : order) {lstart[ctx.vs[v].dist + 1]++;}
   for (int32_t l = 0; l <= depth_bfs; ++l) {lstart[l + 1] += lstart[l];}
   // candidate cuts "between level l - 1 and level l": those that leave balance_lo .. balance_hi of the vertices on the near
   // side, cheapest boundary estimate first; if the level structure is too coarse for that, the cut closest to the median
   const double total = static_cast<double>(order.size());
-  struct Cand {int32_t est, l;};
-  std::vector<Cand> cands;
+  using Cand = NdScratch::Cand;
+  std::vector<Cand> & cands = sc.cands;
+  cands.clear();
   int32_t fallback = 1; double fallback_dist = 1e300;
   for (int32_t l = 1; l <= depth_bfs; ++l) {
     const double frac = lstart[l] / total;         // vertices at distance < l
@@ -175,9 +210,10 @@ bool nd_split(NdContext & ctx, std::vector<int32_t> & nodes, int32_t hint, std::
     if (frac >= ctx.opt.balance_lo && frac <= ctx.opt.balance_hi) {cands.push_back({std::min(below, at), l});}
   }
   if (cands.empty()) {cands.push_back({0, fallback});}
-  std::stable_sort(cands.begin(), cands.end(), [](const Cand & a, const Cand & b) {return a.est < b.est;});
+  // (by estimate, ties in level order: the candidates were pushed in level order, so this is the stable sort by estimate)
+  std::sort(cands.begin(), cands.end(), [](const Cand & a, const Cand & b) {return a.est != b.est ? a.est < b.est : a.l < b.l;});
   if (static_cast<int32_t>(cands.size()) > ctx.opt.separator_candidates) {cands.resize(ctx.opt.separator_candidates);}
-  std::vector<int32_t> cover;
+  std::vector<int32_t> & cover = sc.cover;
   int32_t best_l = -1;
   for (const Cand & c : cands) {
     if (best_l >= 0 && c.est >= static_cast<int32_t>(best_cover.size())) {
@@ -185,39 +221,41 @@ bool nd_split(NdContext & ctx, std::vector<int32_t> & nodes, int32_t hint, std::
       // already no smaller than the best cover cannot win by much, and the candidates are sorted by that estimate
       if (c.est > static_cast<int32_t>(best_cover.size()) + static_cast<int32_t>(best_cover.size()) / 2) {break;}
     }
-    cut_vertex_cover(ctx, order, lstart, c.l, st, cover);
+    cut_vertex_cover(ctx, sc, order, lstart, c.l, st, cover);
     if (cover.empty()) {continue;}
     if (best_l < 0 || cover.size() < best_cover.size()) {best_cover.swap(cover); best_l = c.l;}
   }
   if (best_l < 0) {best_cover.clear(); return as_leaf();}
-  for (int32_t v : best_cover) {ctx.tag[v] = 0;}              // out of the subset
+  for (int32_t v : best_cover) {ctx.vs[v].tag = 0;}              // out of the subset
+  A.reserve(lstart[best_l]); B.reserve(order.size() - lstart[best_l]);
   for (int32_t v : order) {
-    if (ctx.tag[v] != st) {continue;}
-    if (ctx.dist[v] < best_l) {A.push_back(v);} else {B.push_back(v);}
+    if (ctx.vs[v].tag != st) {continue;}
+    if (ctx.vs[v].dist < best_l) {A.push_back(v);} else {B.push_back(v);}
   }
   if (A.empty() || B.empty()) {
-    for (int32_t v : best_cover) {ctx.tag[v] = st;}
+    for (int32_t v : best_cover) {ctx.vs[v].tag = st;}
     A.clear(); B.clear(); best_cover.clear();
     return as_leaf();
   }
-  hint_a = order.front(); hint_b = order.back();   // the near side holds the root of this level structure, the far side its last vertex
+  // the near side holds the root of this level structure (and is listed in its order), the far side its last vertex
+  hint_a.vertex = order.front(); hint_a.levels_ready = true; hint_b.vertex = order.back();
   std::sort(best_cover.begin(), best_cover.end());
   return true;
 }
 
 // A whole subtree, serially: the supernodes of `nodes` in elimination order (A's, B's, then the separator).  The recursion is
 // as deep as the dissection tree: a few dozen frames.
-void dissect_subtree(NdContext & ctx, std::vector<int32_t> & nodes, int32_t hint, std::vector<std::vector<int32_t>> & out)
+void dissect_subtree(NdContext & ctx, NdScratch & sc, std::vector<int32_t> & nodes, NdHint hint, std::vector<std::vector<int32_t>> & out)
 {
   std::vector<int32_t> A, B, cover;
-  int32_t ha = -1, hb = -1;
-  if (!nd_split(ctx, nodes, hint, A, B, cover, ha, hb)) {
+  NdHint ha, hb;
+  if (!nd_split(ctx, sc, nodes, hint, A, B, cover, ha, hb)) {
     if (!nodes.empty()) {out.push_back(std::move(nodes));}
     return;
   }
   std::vector<int32_t>().swap(nodes);
-  dissect_subtree(ctx, A, ha, out);
-  dissect_subtree(ctx, B, hb, out);
+  dissect_subtree(ctx, sc, A, ha, out);
+  dissect_subtree(ctx, sc, B, hb, out);
   if (!cover.empty()) {out.push_back(std::move(cover));}
 }
 
@@ -230,8 +268,7 @@ int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, cons
   ctx.adj_ptr = &adj_ptr;
   ctx.adj_idx = &adj_idx;
   ctx.opt = opt;
-  ctx.tag.assign(n_free, 0);
-  ctx.dist.assign(n_free, 0);
+  ctx.vs.assign(n_free, NdContext::Vertex{0, 0});
   ctx.loc.assign(n_free, -1);
   // The top of the dissection tree is grown level by level, serially, until a level holds kWholeSubtrees subsets; each of
   // those is then dissected to its leaves by one task of ONE parallel loop when the caller supplies one (opt.parallel_for:
@@ -242,12 +279,13 @@ int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, cons
   // serial levels are a fifth of the work.  The elimination order is read off the finished tree in post-order: A's
   // supernodes, B's, then the separator.
   constexpr size_t kWholeSubtrees = 8;
-  struct Task {std::vector<int32_t> nodes, cover; int32_t hint = -1, a = -1, b = -1; bool split = false, whole = false;
+  struct Task {std::vector<int32_t> nodes, cover; NdHint hint; int32_t a = -1, b = -1; bool split = false, whole = false;
     std::vector<std::vector<int32_t>> done;};
   std::vector<Task> tree(1);
   tree[0].nodes.resize(n_free);
   for (int32_t i = 0; i < n_free; ++i) {tree[0].nodes[i] = i;}
   size_t level_begin = 0;
+  NdScratch top_scratch;
   while (level_begin < tree.size()) {
     const size_t level_end = tree.size();
     const size_t count = level_end - level_begin;
@@ -255,16 +293,17 @@ int nested_dissection(int32_t n_free, const std::vector<int32_t> & adj_ptr, cons
       auto whole = [&](size_t i) {
         Task & t = tree[level_begin + i];
         t.whole = true;
-        dissect_subtree(ctx, t.nodes, t.hint, t.done);
+        NdScratch sc;
+        dissect_subtree(ctx, sc, t.nodes, t.hint, t.done);
       };
       if (opt.parallel_for && count > 1) {opt.parallel_for(count, whole);} else {for (size_t i = 0; i < count; ++i) {whole(i);}}
       break;
     }
     std::vector<std::vector<int32_t>> As(count), Bs(count);
-    std::vector<int32_t> ha(count, -1), hb(count, -1);
+    std::vector<NdHint> ha(count), hb(count);
     auto work = [&](size_t i) {
       Task & t = tree[level_begin + i];
-      t.split = nd_split(ctx, t.nodes, t.hint, As[i], Bs[i], t.cover, ha[i], hb[i]);
+      t.split = nd_split(ctx, top_scratch, t.nodes, t.hint, As[i], Bs[i], t.cover, ha[i], hb[i]);
     };
     for (size_t i = 0; i < count; ++i) {work(i);}
     for (size_t i = 0; i < count; ++i) {

@@ -3,12 +3,16 @@
 //   python -c "from slam_toolbox_amd import synth; import numpy as np; synth.make_pose_graph(10000,30000)['edges'].astype(np.int32).tofile('/tmp/edges.bin')"
 //   /tmp/sym_probe /tmp/edges.bin 10000 [leaf] [pmax] [cands]
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../slam_toolbox_amd/csrc/spa_symbolic.hpp"
+#include "../slam_toolbox_amd/csrc/host_pool.hpp"
 namespace kh {static std::string g_err; void set_error(const std::string & s) {g_err = s;}}
 int main(int argc, char ** argv)
 {
@@ -38,15 +42,32 @@ int main(int argc, char ** argv)
   if (argc > 5) {opt.separator_candidates = std::atoi(argv[5]);}
   if (argc > 6) {opt.balance_lo = std::atof(argv[6]); opt.balance_hi = 1.0 - opt.balance_lo;}
   (void)argc;
+  if (std::getenv("SYM_PROBE_THREADS")) {
+    // the dissection's one parallel loop on plain threads (the library passes its persistent pool)
+    const int nt = std::max(1, std::atoi(std::getenv("SYM_PROBE_THREADS")));
+    opt.parallel_for = [nt](size_t n, const std::function<void(size_t)> & fn) {
+      std::atomic<size_t> next{0};
+      std::vector<std::thread> team;
+      auto work = [&] {for (size_t i; (i = next.fetch_add(1)) < n;) {fn(i);}};
+      for (int t = 1; t < nt; ++t) {team.emplace_back(work);}
+      work();
+      for (auto & t : team) {t.join();}
+    };
+  }
+  if (std::getenv("SYM_PROBE_POOL")) {
+    // ... or on the library's persistent pool (KH_HOST_THREADS), as kh_spa_compute passes it
+    opt.parallel_for = [](size_t n, const std::function<void(size_t)> & fn) {kh::HostPool::instance().run(n, fn);};
+  }
   kh::Symbolic sym;
   double best = 1e30;
   int rc = 0;
-  for (int rep = 0; rep < 5; ++rep) {
+  const int reps = std::getenv("SYM_PROBE_REPS") ? std::atoi(std::getenv("SYM_PROBE_REPS")) : 5;
+  for (int rep = 0; rep < reps; ++rep) {
     const auto t0 = std::chrono::steady_clock::now();
     rc = kh::build_symbolic(sym, N - 1, ptr, idx, opt);
     best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
-  std::printf("rc %d (%s) fronts %d levels %zu nnz(L) %.2fM flops %.0fM front storage %.0f MB winv %.0f MB max m %d max ns %d  best of 5: %.2f ms\n", rc,
+  std::printf("rc %d (%s) fronts %d levels %zu nnz(L) %.2fM flops %.0fM front storage %.0f MB winv %.0f MB max m %d max ns %d  best: %.2f ms\n", rc,
     kh::g_err.c_str(), sym.n_fronts, sym.levels.size(), sym.nnz_factor / 1e6, sym.factor_flops / 1e6, sym.fronts_size * 8e-6, sym.winv_size * 8e-6,
     sym.max_m, sym.max_ns, best);
   int sum_ns = 0;
