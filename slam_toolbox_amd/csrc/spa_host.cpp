@@ -133,6 +133,7 @@ struct kh_spa
   DevBuf<int64_t> d_front_off, d_slot_dest, d_winv_off;
   DevBuf<double> d_winv;                       // L11^-T of every front (level pipeline, round 3)
   DevBuf<FrontDesc> d_desc;
+  uint8_t * h_upload = nullptr; size_t h_upload_cap = 0;     // pinned staging of an analysis' uploads (one block, ~30 copies out of it)
   DevBuf<int32_t> d_cinv;
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
@@ -450,23 +451,32 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     const Symbolic & sym = s->sym;
     std::vector<int64_t> slot_dest(n_slots, -1);
     std::vector<int32_t> slot_ld(n_slots, 0);
-    for (int32_t k = 0; k < n_slots; ++k) {
-      const int32_t ei = sym.elim_of_free[slot_row[k]], ej = sym.elim_of_free[col[k]];
-      if (ei < ej) {continue;}
-      const int32_t f = sym.sn_of_elim[ej];
-      const int32_t ncols = sym.front_ns[f] / 3;
-      const int32_t colpos = ej - sym.front_first[f];
-      int32_t rowpos;
-      if (ei < sym.front_first[f] + ncols) {
-        rowpos = ei - sym.front_first[f];
-      } else {
-        const auto b = sym.rows.begin() + sym.rows_ptr[f], e2 = sym.rows.begin() + sym.rows_ptr[f + 1];
-        auto it = std::lower_bound(b, e2, ei);
-        if (it == e2 || *it != ei) {set_error("symbolic: matrix entry outside its front"); return KH_ERR_SOLVER;}
-        rowpos = ncols + static_cast<int32_t>(it - b);
-      }
-      slot_dest[k] = sym.front_off[f] + 3 * rowpos + static_cast<int64_t>(3 * colpos) * sym.front_m[f];
-      slot_ld[k] = sym.front_m[f];
+    {
+      // where every block of the pattern lands in its front: independent per slot, blocks of slots on the host pool
+      constexpr int32_t kSlotBlock = 8192;
+      std::atomic<int> outside{0};
+      host_parallel_for(static_cast<size_t>((n_slots + kSlotBlock - 1) / kSlotBlock), [&](size_t blk) {
+        const int32_t k_end = std::min(n_slots, static_cast<int32_t>(blk + 1) * kSlotBlock);
+        for (int32_t k = static_cast<int32_t>(blk) * kSlotBlock; k < k_end; ++k) {
+          const int32_t ei = sym.elim_of_free[slot_row[k]], ej = sym.elim_of_free[col[k]];
+          if (ei < ej) {continue;}
+          const int32_t f = sym.sn_of_elim[ej];
+          const int32_t ncols = sym.front_ns[f] / 3;
+          const int32_t colpos = ej - sym.front_first[f];
+          int32_t rowpos;
+          if (ei < sym.front_first[f] + ncols) {
+            rowpos = ei - sym.front_first[f];
+          } else {
+            const auto b = sym.rows.begin() + sym.rows_ptr[f], e2 = sym.rows.begin() + sym.rows_ptr[f + 1];
+            auto it = std::lower_bound(b, e2, ei);
+            if (it == e2 || *it != ei) {outside.store(1); continue;}
+            rowpos = ncols + static_cast<int32_t>(it - b);
+          }
+          slot_dest[k] = sym.front_off[f] + 3 * rowpos + static_cast<int64_t>(3 * colpos) * sym.front_m[f];
+          slot_ld[k] = sym.front_m[f];
+        }
+      });
+      if (outside.load()) {set_error("symbolic: matrix entry outside its front"); return KH_ERR_SOLVER;}
     }
     // level lists, concatenated
     std::vector<int32_t> level_fronts;
@@ -484,20 +494,28 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     std::vector<int32_t> col_and_row = col;
     col_and_row.insert(col_and_row.end(), slot_row.begin(), slot_row.end());
     int r2 = 0;
-    r2 |= s->d_edge_a.upload(ea, st); r2 |= s->d_edge_b.upload(eb, st);
-    r2 |= s->d_free_of_node.upload(s->free_of_node, st); r2 |= s->d_node_of_free.upload(s->node_of_free, st);
-    r2 |= s->d_slot_contrib_ptr.upload(scp, st); r2 |= s->d_slot_contrib.upload(scl, st);
-    r2 |= s->d_bsr_row_ptr.upload(row_ptr, st); r2 |= s->d_bsr_col.upload(col_and_row, st); r2 |= s->d_bsr_diag.upload(diag, st);
-    r2 |= s->d_node_contrib_ptr.upload(ncp, st); r2 |= s->d_node_contrib.upload(ncl, st);
-    r2 |= s->d_front_off.upload(sym.front_off, st); r2 |= s->d_front_m.upload(sym.front_m, st);
-    r2 |= s->d_front_ns.upload(sym.front_ns, st); r2 |= s->d_front_first.upload(sym.front_first, st);
-    r2 |= s->d_rows_ptr.upload(sym.rows_ptr, st); r2 |= s->d_rows.upload(sym.rows, st);
-    r2 |= s->d_child_ptr.upload(sym.child_ptr, st); r2 |= s->d_child_list.upload(sym.child_list, st);
-    r2 |= s->d_relpos_ptr.upload(sym.relpos_ptr, st); r2 |= s->d_relpos.upload(sym.relpos, st);
-    r2 |= s->d_slot_dest.upload(slot_dest, st); r2 |= s->d_slot_ld.upload(slot_ld, st);
-    r2 |= s->d_elim_of_free.upload(sym.elim_of_free, st); r2 |= s->d_free_of_elim.upload(sym.free_of_elim, st);
-    r2 |= s->d_level_fronts.upload(level_fronts, st);
-    r2 |= s->d_winv_off.upload(sym.winv_off, st);
+    // Every array is copied into ONE pinned block first and goes to its device buffer from there: ~30 asynchronous copies the
+    // stream can queue, instead of ~30 copies out of pageable vectors, each of which the runtime stages (and waits for) on its own.
+    struct Pending {void * dst; const void * src; size_t bytes;};
+    std::vector<Pending> pending;
+    auto up = [&](auto & buf, const auto & vec) {
+      r2 |= buf.ensure(std::max<size_t>(vec.size(), 1));
+      if (!vec.empty()) {pending.push_back({buf.p, vec.data(), vec.size() * sizeof(vec[0])});}
+    };
+    up(s->d_edge_a, ea); up(s->d_edge_b, eb);
+    up(s->d_free_of_node, s->free_of_node); up(s->d_node_of_free, s->node_of_free);
+    up(s->d_slot_contrib_ptr, scp); up(s->d_slot_contrib, scl);
+    up(s->d_bsr_row_ptr, row_ptr); up(s->d_bsr_col, col_and_row); up(s->d_bsr_diag, diag);
+    up(s->d_node_contrib_ptr, ncp); up(s->d_node_contrib, ncl);
+    up(s->d_front_off, sym.front_off); up(s->d_front_m, sym.front_m);
+    up(s->d_front_ns, sym.front_ns); up(s->d_front_first, sym.front_first);
+    up(s->d_rows_ptr, sym.rows_ptr); up(s->d_rows, sym.rows);
+    up(s->d_child_ptr, sym.child_ptr); up(s->d_child_list, sym.child_list);
+    up(s->d_relpos_ptr, sym.relpos_ptr); up(s->d_relpos, sym.relpos);
+    up(s->d_slot_dest, slot_dest); up(s->d_slot_ld, slot_ld);
+    up(s->d_elim_of_free, sym.elim_of_free); up(s->d_free_of_elim, sym.free_of_elim);
+    up(s->d_level_fronts, level_fronts);
+    up(s->d_winv_off, sym.winv_off);
     std::vector<FrontDesc> desc(sym.n_fronts);
     for (int32_t k = 0; k < sym.n_fronts; ++k) {
       FrontDesc & fd = desc[k];
@@ -510,8 +528,25 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
         fd.ch[q].off = sym.front_off[c]; fd.ch[q].m = sym.front_m[c]; fd.ch[q].ns = sym.front_ns[c]; fd.ch[q].rows_ptr = sym.rows_ptr[c];
       }
     }
-    r2 |= s->d_cinv.upload(sym.cinv, st);
-    r2 |= s->d_desc.upload(desc, st);
+    up(s->d_cinv, sym.cinv);
+    up(s->d_desc, desc);
+    if (r2) {return KH_ERR_HIP;}
+    {
+      size_t total = 0;
+      for (const Pending & q : pending) {total += (q.bytes + 63) & ~static_cast<size_t>(63);}
+      if (total > s->h_upload_cap) {
+        if (s->h_upload) {KS_HIP(hipHostFree(s->h_upload)); s->h_upload = nullptr; s->h_upload_cap = 0;}
+        const size_t cap = total + total / 2;
+        KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_upload), cap, hipHostMallocDefault));
+        s->h_upload_cap = cap;
+      }
+      size_t at = 0;
+      for (const Pending & q : pending) {
+        std::memcpy(s->h_upload + at, q.src, q.bytes);
+        KS_HIP(hipMemcpyAsync(q.dst, s->h_upload + at, q.bytes, hipMemcpyHostToDevice, st));
+        at += (q.bytes + 63) & ~static_cast<size_t>(63);
+      }
+    }
     r2 |= s->d_winv.ensure(static_cast<size_t>(sym.winv_size) + 16);
     if (r2) {return KH_ERR_HIP;}
     s->n_slots = n_slots;
@@ -634,6 +669,7 @@ void kh_spa_destroy(kh_spa * s)
   for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   for (auto & row : s->ev_lin) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
+  if (s->h_upload) {(void)hipHostFree(s->h_upload);}
   if (s->h_fail) {(void)hipHostFree(s->h_fail);}
   if (s->stream2) {(void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2);}
   for (auto & e : s->ev_level) {if (e) {(void)hipEventDestroy(e);}}
