@@ -311,24 +311,36 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       const int32_t fa = s->free_of_node[ea[e]], fb = s->free_of_node[eb[e]];
       if (fa >= 0 && fb >= 0 && fa != fb) {nbr[fill[fa]++] = fb; nbr[fill[fb]++] = fa;}
     }
-    std::vector<int32_t> adj_ptr(nf + 1, 0), adj_idx;              // sorted, duplicate-free neighbour lists, compact
-    adj_idx.reserve(deg[nf]);
-    std::vector<int32_t> row_ptr(nf + 1, 0), col, diag(nf), slot_row;
-    col.reserve(deg[nf] + nf); slot_row.reserve(deg[nf] + nf);
-    for (int32_t i = 0; i < nf; ++i) {
-      int32_t * b = nbr.data() + deg[i], * e2 = nbr.data() + deg[i + 1];
-      std::sort(b, e2);
-      e2 = std::unique(b, e2);
-      adj_idx.insert(adj_idx.end(), b, e2);
-      adj_ptr[i + 1] = static_cast<int32_t>(adj_idx.size());
-      bool placed = false;
-      for (int32_t * q = b; q < e2; ++q) {
-        if (!placed && *q > i) {diag[i] = static_cast<int32_t>(col.size()); col.push_back(i); slot_row.push_back(i); placed = true;}
-        col.push_back(*q); slot_row.push_back(i);
+    // sorted, duplicate-free neighbour lists (compact) and the BSR pattern (a row's neighbours with the diagonal block in its
+    // sorted place).  Rows are independent: blocks of rows on the host pool sort their lists in place, a serial prefix sum
+    // places the rows, the blocks write them out.
+    std::vector<int32_t> adj_ptr(nf + 1, 0), adj_idx, row_ptr(nf + 1, 0), col, diag(nf), slot_row, ucount(nf, 0);
+    constexpr int32_t kRowBlock = 1024;
+    const size_t row_blocks = static_cast<size_t>((nf + kRowBlock - 1) / kRowBlock);
+    host_parallel_for(row_blocks, [&](size_t blk) {
+      const int32_t i_end = std::min(nf, static_cast<int32_t>(blk + 1) * kRowBlock);
+      for (int32_t i = static_cast<int32_t>(blk) * kRowBlock; i < i_end; ++i) {
+        int32_t * b = nbr.data() + deg[i], * e2 = nbr.data() + deg[i + 1];
+        std::sort(b, e2);
+        ucount[i] = static_cast<int32_t>(std::unique(b, e2) - b);
       }
-      if (!placed) {diag[i] = static_cast<int32_t>(col.size()); col.push_back(i); slot_row.push_back(i);}
-      row_ptr[i + 1] = static_cast<int32_t>(col.size());
-    }
+    });
+    for (int32_t i = 0; i < nf; ++i) {adj_ptr[i + 1] = adj_ptr[i] + ucount[i]; row_ptr[i + 1] = row_ptr[i] + ucount[i] + 1;}
+    adj_idx.resize(adj_ptr[nf]); col.resize(row_ptr[nf]); slot_row.resize(row_ptr[nf]);
+    host_parallel_for(row_blocks, [&](size_t blk) {
+      const int32_t i_end = std::min(nf, static_cast<int32_t>(blk + 1) * kRowBlock);
+      for (int32_t i = static_cast<int32_t>(blk) * kRowBlock; i < i_end; ++i) {
+        const int32_t * b = nbr.data() + deg[i], * e2 = b + ucount[i];
+        std::copy(b, e2, adj_idx.begin() + adj_ptr[i]);
+        int32_t at = row_ptr[i];
+        bool placed = false;
+        for (const int32_t * q = b; q < e2; ++q) {
+          if (!placed && *q > i) {diag[i] = at; col[at] = i; slot_row[at] = i; ++at; placed = true;}
+          col[at] = *q; slot_row[at] = i; ++at;
+        }
+        if (!placed) {diag[i] = at; col[at] = i; slot_row[at] = i; ++at;}
+      }
+    });
     const int32_t n_slots = static_cast<int32_t>(col.size());
     // Ordering + fronts on a thread of their own, beside the contribution lists below (both only read the adjacency).
     // INCREMENTAL re-analysis: a loop closure adds a few dozen nodes and edges to a graph that was dissected milliseconds
