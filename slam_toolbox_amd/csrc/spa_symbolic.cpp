@@ -396,9 +396,11 @@ int build_structure(Symbolic & sym, int32_t n_free, const std::vector<int32_t> &
   std::vector<std::vector<int32_t>> rows(K), children(K);
   std::vector<int32_t> stamp(n_free, -1), parent_o(K, -1), level_o(K, 0), m_o(K, 0);
   int32_t max_level = 0;
+  std::vector<int32_t> r;                      // collected here, stored at its final size (one allocation per front)
+  r.reserve(4096);
   for (int32_t o = 0; o < K; ++o) {
     const int32_t end = first_o[o + 1];
-    std::vector<int32_t> & r = rows[o];
+    r.clear();
     for (int32_t e = first_o[o]; e < end; ++e) {
       const int32_t v = sym.free_of_elim[e];
       for (int32_t q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) {
@@ -413,6 +415,7 @@ int build_structure(Symbolic & sym, int32_t n_free, const std::vector<int32_t> &
       level_o[o] = std::max(level_o[o], level_o[c] + 1);
     }
     std::sort(r.begin(), r.end());
+    rows[o].assign(r.begin(), r.end());
     if (!r.empty()) {
       parent_o[o] = sym.sn_of_elim[r[0]];
       children[parent_o[o]].push_back(o);
@@ -465,29 +468,34 @@ int build_structure(Symbolic & sym, int32_t n_free, const std::vector<int32_t> &
   }
   sym.fronts_size = off;
   sym.winv_size = woff;
-  if (std::getenv("KH_SPA_DEBUG")) {
-    std::fprintf(stderr, "[kh_spa] symbolic: structure %.2f ms\n",
-      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nd1).count());
-  }
   sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);
   for (int32_t k = 0; k < K; ++k) {
     const int32_t o = o_of_k[k];
     sym.rows.insert(sym.rows.end(), rows[o].begin(), rows[o].end());
     for (int32_t c : children[o]) {sym.child_list.push_back(k_of_o[c]);}
-    const int32_t po = parent_o[o];
-    if (po < 0) {continue;}
+  }
+  // where a child's rows sit in its parent's front: the parent's rows are numbered once (`stamp` doubles as the map from a row
+  // to its position, tagged with the parent so that stale entries are recognised), then every child looks its rows up
+  std::vector<int32_t> & where = stamp;
+  std::vector<int32_t> where_of(n_free, -1);
+  for (int32_t po = 0; po < K; ++po) {
+    if (children[po].empty()) {continue;}
     const int32_t pfirst = first_o[po], pend = first_o[po + 1], pcols = pend - pfirst;
-    for (size_t q = 0; q < rows[o].size(); ++q) {
-      const int32_t r = rows[o][q];
-      int32_t at;
-      if (r < pend) {
-        at = r - pfirst;
-      } else {
-        auto it = std::lower_bound(rows[po].begin(), rows[po].end(), r);
-        if (it == rows[po].end() || *it != r) {set_error("symbolic: child row missing in parent front"); return KH_ERR_SOLVER;}
-        at = pcols + static_cast<int32_t>(it - rows[po].begin());
+    const int32_t mark = K + po;                // (the first pass left values < K in `stamp`)
+    for (size_t q = 0; q < rows[po].size(); ++q) {where[rows[po][q]] = mark; where_of[rows[po][q]] = pcols + static_cast<int32_t>(q);}
+    for (int32_t c : children[po]) {
+      const int32_t kc = k_of_o[c];
+      for (size_t q = 0; q < rows[c].size(); ++q) {
+        const int32_t rr = rows[c][q];
+        int32_t at;
+        if (rr < pend) {
+          at = rr - pfirst;
+        } else {
+          if (where[rr] != mark) {set_error("symbolic: child row missing in parent front"); return KH_ERR_SOLVER;}
+          at = where_of[rr];
+        }
+        sym.relpos[sym.relpos_ptr[kc] + q] = at;
       }
-      sym.relpos[sym.relpos_ptr[k] + q] = at;
     }
   }
   // gather maps: the inverse of relpos, per (front, child)
@@ -503,6 +511,10 @@ int build_structure(Symbolic & sym, int32_t n_free, const std::vector<int32_t> &
       int32_t * inv = sym.cinv.data() + sym.cinv_ptr[k] + (ci - sym.child_ptr[k]) * mp;
       for (int32_t q = sym.relpos_ptr[c]; q < sym.relpos_ptr[c + 1]; ++q) {inv[sym.relpos[q]] = q - sym.relpos_ptr[c];}
     }
+  }
+  if (std::getenv("KH_SPA_DEBUG")) {
+    std::fprintf(stderr, "[kh_spa] symbolic: structure %.2f ms\n",
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_nd1).count());
   }
   return KH_OK;
 }
