@@ -211,10 +211,19 @@ KH_API int kh_matcher_read_volume(kh_matcher * m, int32_t slot, int32_t * nx, in
  * of >= 128 searches through the chunked pipeline, which otherwise only large searches take (tests); bit 4: score from the
  * grid itself instead of its re-pitched copies (same results; for measurements); bit 5: the windowed kernel takes the byte
  * sums of one-cell searches on the matrix cores (v_mfma_i32_16x16x32_i8) instead of the vector ALU (same results, same speed
- * within 5 %: DESIGN.md section 4).  Results are identical under every combination. */
+ * within 5 %: DESIGN.md section 4); bit 7: kh_matcher_match takes the general (batch) path instead of the fused path of one
+ * MatchScan (same results; the parity tests compare the two).  Results are identical under every combination. */
 KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t flags);
-/* HIP stream all kernels of this handle are launched on (hipStream_t as void*), so the caller can
- * bracket launches with HIP events on the right stream */
+/* Counters of the fused path ONE MatchScan takes (kh_matcher_match, Mapper.cpp:534-639; csrc/matcher_seq.cpp) since the handle
+ * was made: [0] calls that took it, [1] fine passes finished on the device (the coarse pass had exactly one best pose),
+ * [2] fine passes handed to the general path (several best poses, response expansion, an off-lattice best pose),
+ * [3] fine passes of the device rejected by the host's check of their centre (must stay 0), [4] coarse passes redone by the
+ * general path (degenerate searches: more ties than the result block holds), [5] coarse passes scored by the fused
+ * table + scoring kernel (one-tile windows), [6], [7] reserved. */
+KH_API int kh_matcher_seq_stats(kh_matcher * m, int64_t out[8]);
+/* The handle's main HIP stream (hipStream_t as void*): every kernel of a call that is not a chunked batch is launched on it, so
+ * the caller can bracket launches with HIP events there; chunked batches (>= 128 large searches) run their chunks on two
+ * side streams of the handle that are joined to this stream before the call returns. */
 KH_API void * kh_matcher_stream(kh_matcher * m);
 /* accumulated GPU time of the scoring kernel (K3) since the last reset, measured with HIP events
  * on the handle's stream when profiling is enabled: total ms and launch count */

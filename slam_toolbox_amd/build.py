@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkartohip.so")
-SOURCES = ["matcher_host.cpp", "matcher_group.cpp", "matcher_kernels.hip", "spa_host.cpp", "spa_symbolic.cpp", "spa_kernels.hip", "graph.hip", "occupancy.hip", "lifelong.hip", "comm.cpp", "mapper_host.cpp"]
+SOURCES = ["matcher_host.cpp", "matcher_seq.cpp", "matcher_seq.hip", "matcher_group.cpp", "matcher_kernels.hip", "spa_host.cpp", "spa_symbolic.cpp", "spa_kernels.hip", "graph.hip", "occupancy.hip", "lifelong.hip", "comm.cpp", "mapper_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-fvisibility=hidden", "-Wno-unused-value", "-shared", "-ldl"]
 

@@ -6,206 +6,14 @@
 // Reference: lib/karto_sdk/src/Mapper.cpp:477-1208 (ScanMatcher), Mapper.h:1074-1314
 // (CorrelationGrid), Karto.h:4393-4563 (CoordinateConverter), :6603-6963 (GridIndexLookup),
 // :2946-3041 (Transform), Math.h.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <unordered_map>
-#include <unordered_set>
-#include <vector>
-
-#include "../../include/karto_hip.h"
-#include "kh_internal.hpp"
-#include "host_pool.hpp"
+#include "matcher_private.hpp"
 
 namespace kh
 {
-
 thread_local std::string g_last_error;
 void set_error(const std::string & s) {g_last_error = s;}
-
-#define KH_HIP(call)                                                                         \
-  do {                                                                                       \
-    hipError_t e_ = (call);                                                                  \
-    if (e_ != hipSuccess) {                                                                  \
-      set_error(std::string(#call) + ": " + hipGetErrorString(e_));                          \
-      return KH_ERR_HIP;                                                                     \
-    }                                                                                        \
-  } while (0)
-
-// ---- exact scalar helpers (Math.h) ----------------------------------------------------------
-// cos and sin of ONE angle, the way the reference's Release build computes them: GCC (-O1 and up) merges a cos(a) / sin(a)
-// pair into one sincos(a) call, and glibc's sincos is NOT bit-identical to its cos and sin everywhere (a = 0.11462314399891493:
-// cos(a) = 0.9934379567501339, sincos(a) gives 0.993437956750134).  Every place where the reference takes both of the same
-// angle goes through here, so that the library does not depend on whether ITS compiler merges the pair (clang does not).
-static inline void ref_sincos(double a, double * s, double * c) {::sincos(a, s, c);}
-constexpr double kTolerance = 1e-06;                 // Math.h:41
-constexpr double kPi = 3.14159265358979323846;       // Math.h:31
-constexpr double k2Pi = 6.28318530717958647692;      // Math.h:32
-constexpr double kPi180 = 0.01745329251994329577;    // Math.h:34
-constexpr double kMaxVariance = 500.0;               // Mapper.cpp:52
-constexpr double kDistanceGain = 0.2;                // Mapper.cpp:53
-constexpr double kAngleGain = 0.2;                   // Mapper.cpp:54
-
-static inline double round_half_away(double v) {return v >= 0.0 ? std::floor(v + 0.5) : std::ceil(v - 0.5);}
-static inline int32_t to_int32(double v)
-{
-  if (!(v > -2147483649.0 && v < 2147483648.0)) {return INT32_MIN;}
-  return static_cast<int32_t>(v);
-}
-static inline bool double_equal(double a, double b)
-{
-  const double delta = a - b;
-  return delta < 0.0 ? delta >= -kTolerance : delta <= kTolerance;
-}
-static double normalize_angle(double angle)   // Math.h:181-202
-{
-  while (angle < -kPi) {
-    if (angle < -k2Pi) {angle += static_cast<uint32_t>(angle / -k2Pi) * k2Pi;} else {angle += k2Pi;}
-  }
-  while (angle > kPi) {
-    if (angle > k2Pi) {angle -= static_cast<uint32_t>(angle / k2Pi) * k2Pi;} else {angle -= k2Pi;}
-  }
-  return angle;
-}
-static double normalize_angle_difference(double minuend, double subtrahend)   // Math.h:213-224
-{
-  while (minuend - subtrahend < -kPi) {minuend += k2Pi;}
-  while (minuend - subtrahend > kPi) {minuend -= k2Pi;}
-  return minuend;
-}
-struct Cell {int32_t x, y;};
-static inline Cell world_to_grid(double scale, double ox, double oy, double wx, double wy)   // Karto.h:4421-4436
-{
-  const double gx = (wx - ox) * scale;
-  const double gy = (wy - oy) * scale;
-  return Cell{to_int32(round_half_away(gx)), to_int32(round_half_away(gy))};
-}
-static inline size_t align_up(size_t v, size_t a) {return (v + a - 1) / a * a;}
-
-// ---- per-correlate host context (what finalisation needs) -----------------------------------
-struct CorrHost
-{
-  int32_t slot = 0;
-  int32_t P = 0, nx = 0, ny = 0, na = 0;
-  double center[3] = {0, 0, 0};
-  double off_x = 0, off_y = 0, res_x = 0, res_y = 0, ang_off = 0, ang_res = 0;
-  bool fine = false, penalize = false;
-  std::vector<double> x_poses, y_poses, angles, dist_pen, ang_pen;
-  int32_t lt_alloc = 1;          // tile lists the slot's `fast` buffer was sized for
-  std::vector<int32_t> bx, by;
-  double denom = 1.0;
-};
-
-struct StageLayout {size_t bx, by, dist_pen, ang_pen, cos_sin, local, invalid, total;};
-
-// Staging and bookkeeping of one in-flight sub-batch of CorrelateScan jobs (a handle owns two: pipelining)
-struct CorrBatch
-{
-  std::vector<CorrHost> ctx;
-  std::vector<StageLayout> lay;
-  size_t stride = 0, out_words = 0;
-  int32_t tile_pairs = 0;
-  int32_t max_na = 0, max_tiles = 0, max_poses = 0, sx_variant = -1, ry = -1;
-  bool uniform_kernel = true, use_lds = false;
-  // staging (pinned host + device mirror) for the jobs; pinned result mirror; small fine-pass volumes
-  uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_stage = 0, cap_dstage = 0;
-  unsigned long long * h_out = nullptr; size_t cap_hout = 0;   // words
-  unsigned long long * d_out = nullptr; size_t cap_dout = 0;   // words: one contiguous result block per job
-  int32_t * h_sums = nullptr; size_t cap_hsums = 0;          // fine passes: packed small volumes (pinned) ...
-  int32_t * d_small = nullptr; size_t cap_dsmall = 0; size_t small_stride = 0;   // ... and their device staging
-  hipEvent_t ev[2] = {nullptr, nullptr};      // around the scoring kernel (profiling)
-  hipEvent_t done = nullptr;                  // everything of the sub-batch, downloads included
-  hipEvent_t up = nullptr, kdone = nullptr;   // chunked batches: tables + lists ready (side stream) / scoring finished (main stream)
-  hipStream_t side = nullptr;                 // side stream of this staging set (uploads, K2, K4, downloads of its chunks)
-};
-
-struct Slot
-{
-  uint8_t * d_grid = nullptr;        // first grid byte (256-byte aligned); the allocation has kGridPad zero bytes either side
-  uint8_t * d_grid_alloc = nullptr;
-  uint32_t * d_blockmap = nullptr;   // bm_w x bm_h occupancy blocks of this grid (cleared and marked with it)
-  uint8_t * d_grid2 = nullptr;       // re-pitched copies A and B (CorrJob::grid2), allocated at the first search that profits
-  uint8_t * d_grid2_alloc = nullptr;
-  int32_t copy_kind = 0;             // 0 none, 1 copies A / B of the grid, 2 column-decimated copies (RasterJob::copy_kind)
-  int32_t * d_prev_work = nullptr;   // tiles the previous rasterisation touched (what has to be zeroed in the copies)
-  double off_x = 0.0, off_y = 0.0;      // CoordinateConverter offset of this slot's grid
-  // correlate scratch
-  int32_t * d_table = nullptr, * d_fast = nullptr, * d_slow = nullptr, * d_counts = nullptr;
-  int32_t * d_tcounts = nullptr; size_t cap_tcounts = 0, cap_fast = 0;
-  size_t cap_table = 0, cap_counts = 0;
-  int32_t * d_chunks = nullptr, * d_chunk_counts = nullptr; size_t cap_chunks = 0, cap_chunk_counts = 0;
-  int32_t * d_sums = nullptr; double * d_resp = nullptr; size_t cap_volume = 0, cap_resp = 0;
-  // raster scratch: per-point stamp flags (K0 FindValidPoints + the order-dependent rule), cell table of the order-dependent rule
-  uint8_t * d_ractive = nullptr; size_t cap_ractive = 0;
-  uint32_t * d_hkeys = nullptr; int32_t * d_hvals = nullptr; uint8_t * d_hstate = nullptr; int32_t * d_hnbr = nullptr;
-  size_t cap_hkeys = 0, cap_hvals = 0, cap_hstate = 0, cap_hnbr = 0;
-  double * d_tile_best = nullptr; size_t cap_tile_best = 0;
-  int32_t * d_rtiles = nullptr;      // tile_count | tile_cursor | n_work(+pad) | tile_start | work   (first three zeroed per raster)
-  int32_t * d_rlists = nullptr; size_t cap_rlists = 0;   // cell_xy (2 np) | list (4 np) | rank (4 np)
-  // last correlate (for the introspection calls)
-  CorrHost last;
-  bool has_last = false;
-  bool volume_stale = false;         // the stored volume was overwritten by an off-lattice re-score (introspection reports it)
-  // what ComputePositionalCovariance reads: the search-space probabilities of the last COARSE search (Mapper.cpp:726-732, 781-799)
-  CorrHost last_coarse; std::vector<double> last_lattice; bool has_last_coarse = false;
-};
-
 }  // namespace kh
 
-using namespace kh;
-
-struct kh_matcher
-{
-  double search_size = 0, resolution = 0, smear = 0, range_threshold = 0;
-  int32_t width = 0, height = 0, ws = 0, data_size = 0;
-  int32_t roi_x = 0, roi_y = 0, roi_w = 0, roi_h = 0, kernel_size = 0, side = 0;
-  double scale = 0;
-  std::vector<uint8_t> kernel;
-  std::vector<Cell> footprint100;       // kernel cells equal to 100 (relative offsets)
-  kh_match_params params;
-  int32_t device = 0, max_batch = 1;
-  hipStream_t stream = nullptr;
-  uint8_t * d_kernel = nullptr;
-  std::vector<Slot> slots;
-  CorrBatch batch[2];
-  // raster staging: the distinct base scans' unfiltered points (pinned mirror + device arena), the jobs' scan lists and
-  // the (job, scan) work items of K0 (one int32 block), the jobs
-  double * h_arena = nullptr; double * d_arena = nullptr; size_t cap_harena = 0, cap_darena = 0;
-  int32_t * h_meta = nullptr; int32_t * d_meta = nullptr; size_t cap_hmeta = 0, cap_dmeta = 0;
-  RasterJob * h_rjobs = nullptr; RasterJob * d_rjobs = nullptr;
-  bool keep_responses = false;
-  bool force_chunks = std::getenv("KH_FORCE_CHUNKS") != nullptr;       // kh_matcher_set_debug bit 3: chunk every batch of >= 128 (tests)
-  bool dense_score = false;        // kh_matcher_set_debug bit 2: do not skip beams whose window is empty
-  int32_t bm_w = 0, bm_h = 0;
-  int32_t rt_w = 0, rt_h = 0;      // rasteriser tiles over the grid
-  int32_t pitch2 = 0, copy_b = 0;  // dual-copy layout: row pitch (multiple of 128) and byte offset of copy B
-  int32_t pad_rows = 0;            // zero rows in front of and behind every slot's grid and copies (CorrJob::pad)
-  size_t grid_pad = 0;             // the same in bytes of the grid's own pitch, rounded up to 256, plus kGridPad
-  int32_t pitch_d = 0, copy_q = 0; // column-decimated copies: row pitch and bytes of one of the four; copy_q 0 = too large for int32 offsets
-  bool dual_copy = true;           // kh_matcher_set_debug bit 4 switches the re-pitched copies off (measurements)
-  bool mfma_score = std::getenv("KH_K3_MFMA") != nullptr;   // kh_matcher_set_debug bit 5: byte sums on the matrix cores (k_score<.., MF>)
-  bool lds_score = false;          // kh_matcher_set_debug bit 1: LDS-staged scoring path for every search it can take (default: the large ones)
-  bool windowed_score = false;     // kh_matcher_set_debug bit 6: never (the windowed kernel k_score scores everything)
-  // profiling
-  bool profiling = false;
-  double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0, score_jobs = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned long long * d_load_counter = nullptr;    // see CorrJob::load_counter (only handed to the jobs while profiling)
-
-  double grid_resolution() const {return 1.0 / scale;}   // Karto.h:4518-4521
-};
 
 namespace kh
 {
@@ -215,44 +23,40 @@ static int32_t half_kernel_size(double smear, double resolution)   // Mapper.h:1
   return static_cast<int32_t>(round_half_away(2.0 * smear / resolution));
 }
 
-template <class T>
-static int ensure_device(T *& p, size_t & cap, size_t need, hipStream_t stream)
-{
-  if (need <= cap) {return KH_OK;}
-  if (p) {
-    KH_HIP(hipStreamSynchronize(stream));
-    KH_HIP(hipFree(p));
-    p = nullptr;
-  }
-  size_t n = std::max(need, cap + cap / 2);
-  KH_HIP(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
-  cap = n;
-  return KH_OK;
-}
-template <class T>
-static int ensure_pinned(T *& p, size_t & cap, size_t need, hipStream_t stream)
-{
-  if (need <= cap) {return KH_OK;}
-  if (p) {
-    KH_HIP(hipStreamSynchronize(stream));
-    KH_HIP(hipHostFree(p));
-    p = nullptr;
-  }
-  size_t n = std::max(need, cap + cap / 2);
-  KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocDefault));
-  cap = n;
-  return KH_OK;
-}
-
 
 // ---- host worker pool: host_pool.hpp ----
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn) {HostPool::instance().run(n, fn);}
 void host_parallel_for_wide(size_t n, const std::function<void(size_t)> & fn) {HostPool::wide().run(n, fn);}
 
-// ---- rasterisation of n jobs (slots[i] <- base scans of job i) ------------------------------
-struct RasterReq {int32_t slot; const kh_scan * query; const kh_scan * base; int32_t n_base;};
+// the geometry and scratch pointers of one slot's rasterisation job (the scan list and the order-dependent rule's tables are the
+// caller's)
+void fill_raster_job(const kh_matcher * m, const Slot & s, const double * pose, int32_t n_points, size_t npad, RasterJob & j)
+{
+  std::memset(&j, 0, sizeof(j));
+  j.grid = s.d_grid;
+  j.view_x = pose[0]; j.view_y = pose[1];
+  j.active = s.d_ractive; j.n_points = n_points;
+  j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
+  j.kernel_size = m->kernel_size; j.off_x = s.off_x; j.off_y = s.off_y; j.scale = m->scale;
+  j.blockmap = s.d_blockmap; j.bm_w = m->bm_w; j.bm_h = m->bm_h;
+  const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
+  j.tiles_w = m->rt_w; j.tiles_h = m->rt_h; j.height = m->data_size / m->ws;
+  j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
+  j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
+  j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * npad; j.rank = s.d_rlists + 6 * npad;
+  j.grid2 = s.d_grid2; j.copy_kind = s.copy_kind; j.prev_work = s.d_prev_work;
+  j.pitch2 = s.copy_kind == 2 ? m->pitch_d : m->pitch2; j.copy_b = s.copy_kind == 2 ? m->copy_q : m->copy_b;
+  j.n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
+  int32_t f = 0;
+  for (const Cell & c : m->footprint100) {
+    if (c.x == 0 && c.y == 0) {continue;}
+    j.foot_dx[f] = c.x; j.foot_dy[f] = c.y; ++f;
+  }
+}
 
-static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
+// ---- rasterisation of n jobs (slots[i] <- base scans of job i) ------------------------------
+
+int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
 {
   if (reqs.empty()) {return KH_OK;}
   const double res = m->grid_resolution();
@@ -329,23 +133,10 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     const size_t npad = (std::max<size_t>(np, 1) + 3) & ~static_cast<size_t>(3);      // the rank quadruples are read as int4
     rc = ensure_device(s.d_rlists, s.cap_rlists, npad * 10, m->stream); if (rc) {return rc;}
     RasterJob & j = m->h_rjobs[r];
-    std::memset(&j, 0, sizeof(j));
-    j.grid = s.d_grid;
+    fill_raster_job(m, s, pose, points_of[r], npad, j);
     j.scan_ptr = reinterpret_cast<const double * const *>(m->d_meta + meta_at[r]); j.scan_prefix = m->d_meta + meta_at[r] + 2 * scans_of[r];
     j.n_scans = static_cast<int32_t>(scans_of[r]);
     j.uniform_n = std::max(uniform_n, 0);
-    j.view_x = pose[0]; j.view_y = pose[1];
-    j.active = s.d_ractive; j.n_points = points_of[r];
-    j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
-    j.kernel_size = m->kernel_size; j.off_x = s.off_x; j.off_y = s.off_y; j.scale = m->scale;
-    j.blockmap = s.d_blockmap; j.bm_w = m->bm_w; j.bm_h = m->bm_h;
-    const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
-    j.tiles_w = m->rt_w; j.tiles_h = m->rt_h; j.height = m->data_size / m->ws;
-    j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
-    j.tile_start = s.d_rtiles + 2 * nt + 4; j.work = s.d_rtiles + 3 * nt + 4;
-    j.cell_xy = s.d_rlists; j.list = s.d_rlists + 2 * npad; j.rank = s.d_rlists + 6 * npad;
-    j.grid2 = s.d_grid2; j.copy_kind = s.copy_kind; j.prev_work = s.d_prev_work;
-    j.pitch2 = s.copy_kind == 2 ? m->pitch_d : m->pitch2; j.copy_b = s.copy_kind == 2 ? m->copy_q : m->copy_b;
     any_copies = any_copies || s.d_grid2 != nullptr;
     j.n_foot = n_foot;
     if (n_foot > 0) {
@@ -403,16 +194,6 @@ static int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
 }
 
 // ---- CorrelateScan on a set of slots ---------------------------------------------------------
-struct CorrReq
-{
-  int32_t slot;
-  const kh_scan * scan;
-  double center[3];
-  double off_x, off_y, res_x, res_y, ang_off, ang_res;
-  bool penalize, fine;
-  // results
-  double mean[3]; double cov[9]; double response; int status;
-};
 
 static inline double q_res_x(const CorrReq & q) {return q.res_x;}
 
@@ -445,7 +226,7 @@ static int allocate_copies(kh_matcher * m, Slot & s, int32_t kind)
 }
 
 // (the distance penalties -- nx * ny doubles, 52 KB of a loop-closure search's 70 -- are only staged for searches that penalise)
-static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na, bool penalize)
+StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na, bool penalize)
 {
   StageLayout L;
   size_t o = align_up(sizeof(CorrJob), 256);
@@ -462,7 +243,7 @@ static StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na, b
 
 // rows per lane of the scoring kernel (a tile is 4 * ry lattice rows): the variant that loads the fewest rows for ny --
 // 81 rows are 3 tiles of 28 (ry 7: 21 row loads per beam and column of tiles) rather than 3 tiles of 32 (ry 8: 24)
-static int pick_ry(int32_t ny)
+int pick_ry(int32_t ny)
 {
   if (ny <= 4) {return 1;}
   int best = 8, best_cost = 1 << 30;
@@ -474,7 +255,6 @@ static int pick_ry(int32_t ny)
 }
 
 // Host half of ComputePositionalCovariance (Mapper.cpp:874-966) on the lattice maxima
-struct WalkGeometry {double center[3], off_x, off_y, res_x, res_y, ang_res;};
 static int positional_covariance(
   const kh_matcher * m, const CorrHost & c, const std::vector<double> & lattice_max, const WalkGeometry & w,
   const double best_pose[3], double best_response, double * cov)
@@ -568,6 +348,360 @@ static inline double host_response(const CorrHost & c, int32_t sum, int a, int y
   return response;
 }
 
+// the search lattice of one request (Mapper.cpp:736-756)
+int init_ctx(const CorrReq & q, CorrHost & c)
+{
+  c.slot = q.slot;
+  c.P = q.scan->n;
+  std::copy(q.center, q.center + 3, c.center);
+  c.off_x = q.off_x; c.off_y = q.off_y; c.res_x = q.res_x; c.res_y = q.res_y;
+  c.ang_off = q.ang_off; c.ang_res = q.ang_res; c.fine = q.fine; c.penalize = q.penalize;
+  c.nx = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.off_x * 2.0 / q.res_x) + 1));
+  c.ny = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.off_y * 2.0 / q.res_y) + 1));
+  c.na = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.ang_off * 2.0 / q.ang_res) + 1));
+  if (c.nx <= 0 || c.ny <= 0 || c.na <= 0 || static_cast<int64_t>(c.nx) * c.ny * c.na > (1ll << 28)) {
+    set_error("search volume out of range");
+    return KH_ERR_INVALID_ARG;
+  }
+  const double startX = -q.off_x, startY = -q.off_y;
+  c.x_poses.resize(c.nx); c.y_poses.resize(c.ny);
+  for (int32_t k = 0; k < c.nx; ++k) {c.x_poses[k] = startX + static_cast<uint32_t>(k) * q.res_x;}
+  for (int32_t k = 0; k < c.ny; ++k) {c.y_poses[k] = startY + static_cast<uint32_t>(k) * q.res_y;}
+  c.denom = static_cast<double>(static_cast<uint32_t>(c.P) * 100u);     // Mapper.cpp:1204
+  return KH_OK;
+}
+
+// device scratch of one slot for the search `c` describes (allocation is serial: called before the pool fills the tables)
+int ensure_slot_scratch(kh_matcher * m, const CorrReq & q, CorrHost & c)
+{
+  (void)q;
+  int rc = KH_OK;
+  Slot & s = m->slots[c.slot];
+  // device scratch for this slot
+  const size_t tp = static_cast<size_t>(c.na) * c.P;
+  if (tp > s.cap_table) {
+    if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_slow));}
+    const size_t cap = std::max(tp, s.cap_table + s.cap_table / 2);
+    KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_table), cap * 4));
+    KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_slow), cap * 4));
+    s.cap_table = cap;
+  }
+  rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * kCountsPerAngle, m->stream); if (rc) {return rc;}
+  {
+    // one compacted list per (angle, alignment class, scoring tile): bound of the tile count, the job's real
+    // one (<= it) is set with the rest of the job below
+    size_t lt = static_cast<size_t>((c.nx + 30) / 31) * ((c.ny + 4 * pick_ry(c.ny) - 1) / (4 * pick_ry(c.ny)));
+    if (lt > 32) {lt = 1;}
+    c.lt_alloc = static_cast<int32_t>(lt);
+    // (twice: the second half holds the lists into the re-pitched copies)
+    rc = ensure_device(s.d_fast, s.cap_fast, 2 * tp * kClasses * lt, m->stream); if (rc) {return rc;}
+    rc = ensure_device(s.d_tcounts, s.cap_tcounts, 2 * static_cast<size_t>(c.na) * kClasses * lt, m->stream); if (rc) {return rc;}
+    // dual-copy layout: worth its memory (2 x the grid) and upkeep for full-resolution searches with many angles whose
+    // window is one tile wide -- the config-2 CorrelateScan; decided from the request alone, allocated once per slot
+    const double work = static_cast<double>(c.nx) * c.ny * c.na * c.P;
+    // (the copy is picked per beam and scoring tile, so the lattice is one tile wide or has per-tile lists)
+    const double cells_per_step = q.res_x * m->scale;
+    const bool full_res = c.nx > 1 && std::fabs(cells_per_step - 1.0) < 1e-9 && c.nx <= kTileSpan;
+    const bool tiled_lists = lt > 1 && (std::fabs(cells_per_step - 1.0) < 1e-9 || std::fabs(cells_per_step - 2.0) < 1e-9);
+    if (m->dual_copy && !s.d_grid2 && (full_res || tiled_lists) && work >= 1e8) {
+      // a search that steps two cells (MatchScan's coarse pass) gets the column-decimated copies
+      const bool two_cells = std::fabs(cells_per_step - 2.0) < 1e-9 && m->copy_q > 0 && (m->ws % 8) == 0;
+      rc = allocate_copies(m, s, two_cells ? 2 : 1); if (rc) {return rc;}
+    }
+  }
+  {
+    // chunk descriptors of the LDS-staged path: at most one per beam, kept per (angle pair, beam range)
+    const size_t groups = (static_cast<size_t>(c.na) + kGroupAngles - 1) / kGroupAngles;
+    const size_t range_len = static_cast<size_t>(lds_desc_capacity(c.P));
+    rc = ensure_device(s.d_chunks, s.cap_chunks, groups * kLdsRanges * range_len * kChunkWords, m->stream); if (rc) {return rc;}
+    rc = ensure_device(s.d_chunk_counts, s.cap_chunk_counts, groups * kLdsRanges, m->stream); if (rc) {return rc;}
+  }
+  const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
+  rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
+  // best response per scoring tile: at most ceil(nx / 31) x ceil(ny / 4) tiles per angle
+  rc = ensure_device(s.d_tile_best, s.cap_tile_best,
+      static_cast<size_t>(c.na) * ((c.nx + 30) / 31) * ((c.ny + 3) / 4), m->stream); if (rc) {return rc;}
+  if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
+
+  return KH_OK;
+}
+
+// Host half of one CorrelateScan job: the exact-arithmetic tables into the staging block `hb` (device address `db`) and the job
+// descriptor at its head.  Independent between the jobs of a batch (runs on the pool).
+void prepare_job(kh_matcher * m, const CorrReq & q, CorrHost & c, const StageLayout & L, uint8_t * hb, uint8_t * db,
+  unsigned long long * d_out, size_t out_words, size_t n_launch, bool lds_always, bool lds_never, JobShape & shape)
+{
+  const kh_match_params & mp = m->params;
+  Slot & s = m->slots[c.slot];
+  CorrJob * job = reinterpret_cast<CorrJob *>(hb);
+  int32_t * bx = reinterpret_cast<int32_t *>(hb + L.bx);
+  int32_t * by = reinterpret_cast<int32_t *>(hb + L.by);
+  double * dist_pen = reinterpret_cast<double *>(hb + L.dist_pen);
+  double * ang_pen = reinterpret_cast<double *>(hb + L.ang_pen);
+  double * cos_sin = reinterpret_cast<double *>(hb + L.cos_sin);
+  double * local = reinterpret_cast<double *>(hb + L.local);
+  uint8_t * invalid = hb + L.invalid;
+
+  // lattice base indices: operator()(y), Mapper.cpp:649-662
+  c.bx.resize(c.nx); c.by.resize(c.ny);
+  for (int32_t k = 0; k < c.nx; ++k) {
+    const double newPositionX = c.center[0] + c.x_poses[k];
+    const double gx = (newPositionX - s.off_x) * m->scale;
+    c.bx[k] = to_int32(round_half_away(gx)) + m->roi_x;
+    bx[k] = c.bx[k];
+  }
+  for (int32_t k = 0; k < c.ny; ++k) {
+    const double newPositionY = c.center[1] + c.y_poses[k];
+    const double gy = (newPositionY - s.off_y) * m->scale;
+    c.by[k] = (to_int32(round_half_away(gy)) + m->roi_y) * m->ws;
+    by[k] = c.by[k];
+  }
+  int32_t sx = c.nx > 1 ? c.bx[1] - c.bx[0] : 1;
+  int32_t sy_ws = c.ny > 1 ? c.by[1] - c.by[0] : m->ws;
+  bool linear = (sx == 1 || sx == 2) && sy_ws > 0;
+  for (int32_t k = 1; k < c.nx && linear; ++k) {linear = (c.bx[k] - c.bx[k - 1]) == sx;}
+  for (int32_t k = 1; k < c.ny && linear; ++k) {linear = (c.by[k] - c.by[k - 1]) == sy_ws;}
+  // every window row read by a tile must stay inside the (padded) allocation
+  if (linear) {
+    const int64_t bmax = static_cast<int64_t>(c.bx[0]) + c.by[0] + static_cast<int64_t>(c.ny - 1) * sy_ws;
+    if (c.bx[0] + c.by[0] < 0 || bmax >= m->data_size) {linear = false;}
+  }
+  if (!linear) {sx = 1; sy_ws = m->ws;}
+
+  // penalties, Mapper.cpp:671-685
+  if (q.penalize) {c.dist_pen.assign(static_cast<size_t>(c.nx) * c.ny, 1.0);} else {c.dist_pen.clear();}
+  c.ang_pen.assign(c.na, 1.0);
+  c.angles.resize(c.na);
+  const double startAngle = c.center[2] - c.ang_off;
+  for (int32_t a = 0; a < c.na; ++a) {
+    const double angle = startAngle + static_cast<uint32_t>(a) * c.ang_res;
+    c.angles[a] = angle;
+    ref_sincos(angle, &cos_sin[2 * a + 1], &cos_sin[2 * a]);          // Karto.h:6857-6858
+    const double squaredAngleDistance = (angle - c.center[2]) * (angle - c.center[2]);
+    double anglePenalty = 1.0 - (kAngleGain * squaredAngleDistance / mp.angle_variance_penalty);
+    anglePenalty = anglePenalty > mp.minimum_angle_penalty ? anglePenalty : mp.minimum_angle_penalty;
+    c.ang_pen[a] = anglePenalty;
+    ang_pen[a] = anglePenalty;
+  }
+  if (q.penalize) {
+  for (int32_t yi = 0; yi < c.ny; ++yi) {
+    const double squareY = c.y_poses[yi] * c.y_poses[yi];
+    for (int32_t xi = 0; xi < c.nx; ++xi) {
+      const double squareX = c.x_poses[xi] * c.x_poses[xi];
+      const double squaredDistance = squareX + squareY;
+      double distancePenalty = 1.0 - (kDistanceGain * squaredDistance / mp.distance_variance_penalty);
+      distancePenalty = distancePenalty > mp.minimum_distance_penalty ? distancePenalty : mp.minimum_distance_penalty;
+      c.dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
+      dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
+    }
+  }
+  }
+
+  // scan points in the sensor frame: Transform(sensorPose).InverseTransformPose, Karto.h:6813-6824,
+  // 2987-2994, 3003-3024, 2482-2511, 2654-2666
+  {
+    const double tx = q.scan->sensor_pose[0], ty = q.scan->sensor_pose[1], th = q.scan->sensor_pose[2];
+    double r00, r01, r02, r10, r11, r12;
+    if (tx == 0.0 && ty == 0.0 && th == 0.0) {
+      r00 = 1; r01 = 0; r02 = 0; r10 = 0; r11 = 1; r12 = 0;
+    } else {
+      const double radians = 0.0 - th;
+      double cosR, sinR;
+      ref_sincos(radians, &sinR, &cosR);
+      const double omc = 1.0 - cosR;
+      r00 = 0.0 * omc + cosR;
+      r01 = 0.0 * 0.0 * omc - 1.0 * sinR;
+      r02 = 0.0 * 1.0 * omc + 0.0 * sinR;
+      r10 = 0.0 * 0.0 * omc + 1.0 * sinR;
+      r11 = 0.0 * omc + cosR;
+      r12 = 0.0 * 1.0 * omc - 0.0 * sinR;
+    }
+    for (int32_t k = 0; k < c.P; ++k) {
+      const double sxp = q.scan->points_xy[2 * k] - tx, syp = q.scan->points_xy[2 * k + 1] - ty, sh = 0.0 - th;
+      local[2 * k] = r00 * sxp + r01 * syp + r02 * sh;
+      local[2 * k + 1] = r10 * sxp + r11 * syp + r12 * sh;
+      const double rr = q.scan->ranges[k];
+      invalid[k] = (std::isnan(rr) || std::isinf(rr)) ? 1 : 0;     // Karto.h:6869-6875
+    }
+  }
+
+  std::memset(job, 0, sizeof(CorrJob));
+  job->grid = s.d_grid; job->data_size = m->data_size; job->ws = m->ws;
+  job->n_points = c.P; job->nx = c.nx; job->ny = c.ny; job->na = c.na;
+  job->linear = linear ? 1 : 0; job->sx = sx; job->sy_ws = sy_ws; job->base0 = c.bx[0] + c.by[0];
+  const int this_sx = (linear && sx == 2) ? 2 : 1;
+  const int this_ry = pick_ry(c.ny);
+  job->tiles_y = (c.ny + 4 * this_ry - 1) / (4 * this_ry);
+  // column-decimated copies of the slot: the two-cell search is scored as a one-cell search on them (CorrJob::dec), as long
+  // as the copy can be picked per beam and tile (one tile column, or lists per tile)
+  bool dec = s.copy_kind == 2 && m->dual_copy && this_sx == 2 && sy_ws % m->ws == 0;
+  if (dec) {
+    const int32_t tiles = ((c.nx + kTileSpan - 1) / kTileSpan) * job->tiles_y;
+    dec = c.nx <= kTileSpan || (tiles >= 4 && tiles <= c.lt_alloc);
+  }
+  const int px = dec ? kTileSpan : score_tile_poses(this_sx);
+  job->tiles_x = (c.nx + px - 1) / px;
+  job->ry = this_ry; job->tile_px = px; job->dec = dec ? 1 : 0;
+  shape.sx = dec ? 1 : this_sx; shape.ry = this_ry; shape.tiles = job->tiles_x * job->tiles_y;
+  // LDS-staged scoring: linear lattice whose window fits 64 bytes x 64 rows
+  // ... and a launch of at least two workgroups (angle pairs) per compute unit: one config-2 search alone is 41 workgroups that
+  // walk their 25 chunks one after the other -- 0.26 ms against the windowed kernel's 0.14
+  const bool lds_wanted = lds_always || (!lds_never && static_cast<double>(c.nx) * c.ny * c.na * c.P >= 1e8 &&
+    static_cast<double>(n_launch) * ((c.na + kGroupAngles - 1) / kGroupAngles) >= 512.0);
+  const bool lds_ok = lds_wanted && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
+    sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && 63 * sx + 1 <= kLdsRows;
+  shape.lds = lds_ok ? 1 : 0;
+  job->lds_path = shape.lds; job->sy_cells = sy_ws / m->ws;
+  job->rel = s.d_fast; job->chunks = s.d_chunks; job->chunk_counts = s.d_chunk_counts;
+  job->do_penalize = q.penalize ? 1 : 0; job->coarse = q.fine ? 0 : 1;
+  job->write_resp = m->keep_responses ? 1 : 0;
+  job->denom = c.denom;
+  job->grid_off_x = s.off_x; job->grid_off_y = s.off_y; job->scale = m->scale;
+  job->bx = reinterpret_cast<const int32_t *>(db + L.bx);
+  job->by = reinterpret_cast<const int32_t *>(db + L.by);
+  job->dist_pen = reinterpret_cast<const double *>(db + L.dist_pen);
+  job->ang_pen = reinterpret_cast<const double *>(db + L.ang_pen);
+  job->cos_sin = reinterpret_cast<const double *>(db + L.cos_sin);
+  job->local = reinterpret_cast<const double *>(db + L.local);
+  job->invalid = db + L.invalid;
+  job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
+  job->tcounts = s.d_tcounts; {
+    // tile lists pay for themselves when the window is several tiles large (the tests cost K2 time per tile)
+    const int32_t tiles = job->tiles_x * job->tiles_y;
+    job->list_tiles = (tiles >= 4 && tiles <= c.lt_alloc) ? tiles : 1;
+  }
+  job->sums = s.d_sums; job->resp = s.d_resp; job->out = d_out; job->out_words = static_cast<int32_t>(out_words);
+  job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
+  job->tile_best = s.d_tile_best;
+  // re-pitched copies: linear full-resolution lattice one tile wide (the copy is picked per beam for the tile at x0 = 0)
+  {
+    const bool use2 = dec || (s.copy_kind == 1 && m->dual_copy && linear && (job->tiles_x == 1 || job->list_tiles > 1));
+    const size_t lists = static_cast<size_t>(c.na) * kClasses * static_cast<size_t>(c.lt_alloc);
+    job->grid2 = use2 ? s.d_grid2 : nullptr;
+    job->pitch2 = dec ? m->pitch_d : m->pitch2; job->copy_b = dec ? m->copy_q : m->copy_b;
+    job->fast2 = s.d_fast + lists * static_cast<size_t>(c.P);
+    job->tcounts2 = s.d_tcounts + lists;
+  }
+  job->pad = std::max(0, m->pad_rows * m->ws - 512); job->pad_rows = m->pad_rows;
+  job->load_counter = m->profiling ? m->d_load_counter : nullptr;
+}
+
+// Finalisation of one CorrelateScan (Mapper.cpp:775-862) from its downloaded result block: tie average, covariance, the slot's
+// introspection state.  q.status carries the reference's "unable to find best position".
+int finalize_job(kh_matcher * m, CorrReq & q, CorrHost & c, const ResultView & v)
+{
+  int rc = KH_OK;
+  Slot & s = m->slots[c.slot];
+  s.volume_stale = false;
+  const unsigned long long * out = v.out;
+  double best;
+  std::memcpy(&best, &out[0], 8);
+  const uint64_t tie_count = out[1];
+  const size_t plane = static_cast<size_t>(c.nx) * c.ny;
+  std::vector<uint32_t> ties;
+  std::vector<int32_t> host_sums;     // full volume, only when needed
+  auto fetch_volume = [&]() -> int {
+    if (!host_sums.empty()) {return KH_OK;}
+    if (!v.device_work) {return kNeedGeneric;}
+    host_sums.resize(plane * c.na);
+    KH_HIP(hipMemcpy(host_sums.data(), s.d_sums, host_sums.size() * 4, hipMemcpyDeviceToHost));
+    return KH_OK;
+  };
+  if (tie_count <= static_cast<uint64_t>(kTieCap)) {
+    const uint32_t * idx = reinterpret_cast<const uint32_t *>(out + 2);
+    ties.assign(idx, idx + tie_count);
+    std::sort(ties.begin(), ties.end());
+  } else {
+    // degenerate search (e.g. nothing rasterised: every pose ties at 0): walk the whole volume
+    // on the host in the reference's order
+    rc = fetch_volume(); if (rc) {return rc;}
+    for (int32_t yi = 0; yi < c.ny; ++yi) {
+      for (int32_t xi = 0; xi < c.nx; ++xi) {
+        for (int32_t a = 0; a < c.na; ++a) {
+          const double r = host_response(c, host_sums[static_cast<size_t>(a) * plane + static_cast<size_t>(yi) * c.nx + xi], a, yi, xi);
+          if (double_equal(r, best)) {ties.push_back(static_cast<uint32_t>((static_cast<size_t>(yi) * c.nx + xi) * c.na + a));}
+        }
+      }
+    }
+  }
+  if (ties.empty()) {q.status = KH_ERR_SEARCH; return KH_OK;}     // Mapper.cpp:828
+  // average all poses with the same highest response, Mapper.cpp:802-829
+  double ax = 0.0, ay = 0.0, thetaX = 0.0, thetaY = 0.0;
+  for (uint32_t t : ties) {
+    const int32_t a = static_cast<int32_t>(t % static_cast<uint32_t>(c.na));
+    const uint32_t xy = t / static_cast<uint32_t>(c.na);
+    const int32_t xi = static_cast<int32_t>(xy % static_cast<uint32_t>(c.nx)), yi = static_cast<int32_t>(xy / static_cast<uint32_t>(c.nx));
+    ax += c.center[0] + c.x_poses[xi];
+    ay += c.center[1] + c.y_poses[yi];
+    const double heading = normalize_angle(c.angles[a]);
+    double sin_h, cos_h;
+    ref_sincos(heading, &sin_h, &cos_h);
+    thetaX += cos_h;
+    thetaY += sin_h;
+  }
+  const int32_t count = static_cast<int32_t>(ties.size());
+  ax /= count; ay /= count; thetaX /= count; thetaY /= count;
+  const double avg[3] = {ax, ay, std::atan2(thetaY, thetaX)};
+
+  if (!c.fine) {
+    std::vector<double> lattice(plane);
+    std::memcpy(lattice.data(), out + kOutHeaderWords, plane * 8);
+    WalkGeometry wg;
+    std::copy(c.center, c.center + 3, wg.center);
+    wg.off_x = c.off_x; wg.off_y = c.off_y; wg.res_x = c.res_x; wg.res_y = c.res_y; wg.ang_res = c.ang_res;
+    const int prc = positional_covariance(m, c, lattice, wg, avg, best, q.cov);
+    if (prc != KH_OK) {q.status = prc; return KH_OK;}
+    s.last_coarse = c; s.last_lattice.swap(lattice); s.has_last_coarse = true;     // m_pSearchSpaceProbs of this matcher slot
+  } else {
+    // ComputeAngularCovariance, Mapper.cpp:977-1025
+    const double bestAngle = normalize_angle_difference(avg[2], c.center[2]);
+    const Cell g = world_to_grid(m->scale, s.off_x, s.off_y, avg[0], avg[1]);
+    const int32_t gridIndex = (g.x + m->roi_x) + (g.y + m->roi_y) * m->ws;
+    // the raw responses of all angles at that cell: it is a lattice point unless the tie average
+    // left the lattice, in which case the sums are recomputed by a 1x1 search at that cell
+    int32_t fx = -1, fy = -1;
+    for (int32_t yi = 0; yi < c.ny && fx < 0; ++yi) {
+      for (int32_t xi = 0; xi < c.nx; ++xi) {
+        if (c.bx[xi] + c.by[yi] == gridIndex) {fx = xi; fy = yi; break;}
+      }
+    }
+    std::vector<int32_t> col(c.na, 0);
+    if (fx >= 0 && v.small != nullptr) {
+      const int32_t * vol = v.small;
+      for (int32_t a = 0; a < c.na; ++a) {col[a] = vol[static_cast<size_t>(a) * plane + static_cast<size_t>(fy) * c.nx + fx];}
+    } else if (!v.device_work) {
+      return kNeedGeneric;
+    } else if (fx >= 0) {
+      KH_HIP(hipMemcpy2D(col.data(), 4, s.d_sums + static_cast<size_t>(fy) * c.nx + fx, plane * 4, 4, c.na, hipMemcpyDeviceToHost));
+    } else {
+      // off-lattice best pose: score the single cell through the generic (per-pose checked) path.  Finalisation may
+      // run on pool threads: one of them at a time talks to the stream
+      static std::mutex rescore_mutex;
+      std::lock_guard<std::mutex> rescore_lock(rescore_mutex);
+      s.volume_stale = true;
+      CorrJob * job = v.h_job;
+      CorrJob one = *job;
+      one.nx = 1; one.ny = 1; one.linear = 0; one.sx = 1; one.sy_ws = m->ws; one.base0 = gridIndex;
+      one.tiles_x = 1; one.tiles_y = 1; one.ry = 1; one.do_penalize = 0; one.coarse = 0; one.write_resp = 0;
+      // bx/by of the single pose: reuse the first entries of the staged arrays
+      int32_t one_bx = gridIndex, one_by = 0;
+      KH_HIP(hipMemcpy(const_cast<int32_t *>(job->bx), &one_bx, 4, hipMemcpyHostToDevice));
+      KH_HIP(hipMemcpy(const_cast<int32_t *>(job->by), &one_by, 4, hipMemcpyHostToDevice));
+      KH_HIP(hipMemcpy(v.d_job, &one, sizeof(CorrJob), hipMemcpyHostToDevice));
+      launch_offsets(v.d_job, v.stride, 1, one.na, m->stream);
+      launch_score(v.d_job, v.stride, 1, 1, one.na, 1, 1, m->stream);
+      KH_HIP(hipStreamSynchronize(m->stream));
+      KH_HIP(hipMemcpy(col.data(), s.d_sums, sizeof(int32_t) * c.na, hipMemcpyDeviceToHost));
+      // (the slot's stored volume now holds this 1 x 1 search: kh_matcher_read_volume reports KH_ERR_NOT_FOUND)
+    }
+    q.cov[8] = angular_variance(col, c.denom, c.center[2], c.ang_off, c.ang_res, bestAngle, best);
+  }
+  q.mean[0] = avg[0]; q.mean[1] = avg[1]; q.mean[2] = avg[2];
+  q.response = best > 1.0 ? 1.0 : best;
+  s.last = c; s.has_last = true;
+  return KH_OK;
+}
+
 // One sub-batch of CorrelateScan jobs in two phases so that two sub-batches can be pipelined on the handle's
 // stream: phase 0 = host preparation + upload + kernels + download, all enqueued, ending with an event;
 // phase 1 = wait for that event + finalisation.  Everything phase 1 needs lives in the CorrBatch.
@@ -600,24 +734,8 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     CorrReq & q = reqs[i];
     CorrHost & c = ctx[i];
     q.status = KH_OK;
-    c.slot = q.slot;
-    c.P = q.scan->n;
-    std::copy(q.center, q.center + 3, c.center);
-    c.off_x = q.off_x; c.off_y = q.off_y; c.res_x = q.res_x; c.res_y = q.res_y;
-    c.ang_off = q.ang_off; c.ang_res = q.ang_res; c.fine = q.fine; c.penalize = q.penalize;
-    // Mapper.cpp:736-756
-    c.nx = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.off_x * 2.0 / q.res_x) + 1));
-    c.ny = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.off_y * 2.0 / q.res_y) + 1));
-    c.na = static_cast<int32_t>(static_cast<uint32_t>(round_half_away(q.ang_off * 2.0 / q.ang_res) + 1));
-    if (c.nx <= 0 || c.ny <= 0 || c.na <= 0 || static_cast<int64_t>(c.nx) * c.ny * c.na > (1ll << 28)) {
-      set_error("search volume out of range");
-      return KH_ERR_INVALID_ARG;
-    }
-    const double startX = -q.off_x, startY = -q.off_y;
-    c.x_poses.resize(c.nx); c.y_poses.resize(c.ny);
-    for (int32_t k = 0; k < c.nx; ++k) {c.x_poses[k] = startX + static_cast<uint32_t>(k) * q.res_x;}
-    for (int32_t k = 0; k < c.ny; ++k) {c.y_poses[k] = startY + static_cast<uint32_t>(k) * q.res_y;}
-    c.denom = static_cast<double>(static_cast<uint32_t>(c.P) * 100u);     // Mapper.cpp:1204
+    rc = init_ctx(q, c);
+    if (rc) {return rc;}
     lay[i] = stage_layout(c.P, c.nx, c.ny, c.na, q.penalize);
     stride = std::max(stride, lay[i].total);
     out_words = std::max(out_words, kOutHeaderWords + static_cast<size_t>(c.nx) * c.ny);
@@ -637,56 +755,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   // device scratch of every slot first (allocation is serial); the tables themselves are filled by
   // the host pool
   for (size_t i = 0; i < n; ++i) {
-    CorrHost & c = ctx[i];
-    Slot & s = m->slots[c.slot];
-    // device scratch for this slot
-    const size_t tp = static_cast<size_t>(c.na) * c.P;
-    if (tp > s.cap_table) {
-      if (s.d_table) {KH_HIP(hipStreamSynchronize(m->stream)); KH_HIP(hipFree(s.d_table)); KH_HIP(hipFree(s.d_slow));}
-      const size_t cap = std::max(tp, s.cap_table + s.cap_table / 2);
-      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_table), cap * 4));
-      KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_slow), cap * 4));
-      s.cap_table = cap;
-    }
-    rc = ensure_device(s.d_counts, s.cap_counts, static_cast<size_t>(c.na) * kCountsPerAngle, m->stream); if (rc) {return rc;}
-    {
-      // one compacted list per (angle, alignment class, scoring tile): bound of the tile count, the job's real
-      // one (<= it) is set with the rest of the job below
-      size_t lt = static_cast<size_t>((c.nx + 30) / 31) * ((c.ny + 4 * pick_ry(c.ny) - 1) / (4 * pick_ry(c.ny)));
-      if (lt > 32) {lt = 1;}
-      c.lt_alloc = static_cast<int32_t>(lt);
-      // (twice: the second half holds the lists into the re-pitched copies)
-      rc = ensure_device(s.d_fast, s.cap_fast, 2 * tp * kClasses * lt, m->stream); if (rc) {return rc;}
-      rc = ensure_device(s.d_tcounts, s.cap_tcounts, 2 * static_cast<size_t>(c.na) * kClasses * lt, m->stream); if (rc) {return rc;}
-      // dual-copy layout: worth its memory (2 x the grid) and upkeep for full-resolution searches with many angles whose
-      // window is one tile wide -- the config-2 CorrelateScan; decided from the request alone, allocated once per slot
-      const double work = static_cast<double>(c.nx) * c.ny * c.na * c.P;
-      // (the copy is picked per beam and scoring tile, so the lattice is one tile wide or has per-tile lists)
-      const double cells_per_step = q_res_x(reqs[i]) * m->scale;
-      const bool full_res = c.nx > 1 && std::fabs(cells_per_step - 1.0) < 1e-9 && c.nx <= kTileSpan;
-      const bool tiled_lists = lt > 1 && (std::fabs(cells_per_step - 1.0) < 1e-9 || std::fabs(cells_per_step - 2.0) < 1e-9);
-      if (m->dual_copy && !s.d_grid2 && (full_res || tiled_lists) && work >= 1e8) {
-        // a search that steps two cells (MatchScan's coarse pass) gets the column-decimated copies
-        const bool two_cells = std::fabs(cells_per_step - 2.0) < 1e-9 && m->copy_q > 0 && (m->ws % 8) == 0;
-        rc = allocate_copies(m, s, two_cells ? 2 : 1); if (rc) {return rc;}
-      }
-    }
-    {
-      // chunk descriptors of the LDS-staged path: at most one per beam, kept per (angle pair, beam range)
-      const size_t groups = (static_cast<size_t>(c.na) + kGroupAngles - 1) / kGroupAngles;
-      const size_t range_len = static_cast<size_t>(lds_desc_capacity(c.P));
-      rc = ensure_device(s.d_chunks, s.cap_chunks, groups * kLdsRanges * range_len * kChunkWords, m->stream); if (rc) {return rc;}
-      rc = ensure_device(s.d_chunk_counts, s.cap_chunk_counts, groups * kLdsRanges, m->stream); if (rc) {return rc;}
-    }
-    const size_t vol = static_cast<size_t>(c.nx) * c.ny * c.na;
-    rc = ensure_device(s.d_sums, s.cap_volume, vol, m->stream); if (rc) {return rc;}
-    // best response per scoring tile: at most ceil(nx / 31) x ceil(ny / 4) tiles per angle
-    rc = ensure_device(s.d_tile_best, s.cap_tile_best,
-        static_cast<size_t>(c.na) * ((c.nx + 30) / 31) * ((c.ny + 3) / 4), m->stream); if (rc) {return rc;}
-    if (m->keep_responses) {rc = ensure_device(s.d_resp, s.cap_resp, vol, m->stream); if (rc) {return rc;}}
-
+    rc = ensure_slot_scratch(m, reqs[i], ctx[i]);
+    if (rc) {return rc;}
   }
-  std::vector<int32_t> job_sx(n, 1), job_ry(n, 1), job_tiles(n, 1), job_lds(n, 0);
   // LDS-staged scoring (k_offsets_lds / k_score_lds): by default for the searches it was measured faster on -- windows of at most
   // 61 bytes x 64 rows with >= 1e8 lookups per search, in launches of >= 512 angle pairs (the config-2 CorrelateScan in batches:
   // 0.48 against 0.60 ms per 51 matches); smaller searches and small launches keep the windowed kernel, whose fixed costs are lower.  KH_LDS_SCORE=1 / kh_matcher_set_debug bit 1:
@@ -694,164 +765,10 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   static const int lds_env = std::getenv("KH_LDS_SCORE") ? std::atoi(std::getenv("KH_LDS_SCORE")) : -1;
   const bool lds_never = lds_env == 0 || m->windowed_score;
   const bool lds_always = !lds_never && (lds_env > 0 || m->lds_score);
+  std::vector<JobShape> shapes(n);
   HostPool::instance().run(n, [&](size_t i) {
-    CorrReq & q = reqs[i];
-    CorrHost & c = ctx[i];
-    Slot & s = m->slots[c.slot];
-    const StageLayout & L = lay[i];
-    uint8_t * hb = B.h_stage + stride * i;
-    uint8_t * db = B.d_stage + stride * i;
-    CorrJob * job = reinterpret_cast<CorrJob *>(hb);
-    int32_t * bx = reinterpret_cast<int32_t *>(hb + L.bx);
-    int32_t * by = reinterpret_cast<int32_t *>(hb + L.by);
-    double * dist_pen = reinterpret_cast<double *>(hb + L.dist_pen);
-    double * ang_pen = reinterpret_cast<double *>(hb + L.ang_pen);
-    double * cos_sin = reinterpret_cast<double *>(hb + L.cos_sin);
-    double * local = reinterpret_cast<double *>(hb + L.local);
-    uint8_t * invalid = hb + L.invalid;
-
-    // lattice base indices: operator()(y), Mapper.cpp:649-662
-    c.bx.resize(c.nx); c.by.resize(c.ny);
-    for (int32_t k = 0; k < c.nx; ++k) {
-      const double newPositionX = c.center[0] + c.x_poses[k];
-      const double gx = (newPositionX - s.off_x) * m->scale;
-      c.bx[k] = to_int32(round_half_away(gx)) + m->roi_x;
-      bx[k] = c.bx[k];
-    }
-    for (int32_t k = 0; k < c.ny; ++k) {
-      const double newPositionY = c.center[1] + c.y_poses[k];
-      const double gy = (newPositionY - s.off_y) * m->scale;
-      c.by[k] = (to_int32(round_half_away(gy)) + m->roi_y) * m->ws;
-      by[k] = c.by[k];
-    }
-    int32_t sx = c.nx > 1 ? c.bx[1] - c.bx[0] : 1;
-    int32_t sy_ws = c.ny > 1 ? c.by[1] - c.by[0] : m->ws;
-    bool linear = (sx == 1 || sx == 2) && sy_ws > 0;
-    for (int32_t k = 1; k < c.nx && linear; ++k) {linear = (c.bx[k] - c.bx[k - 1]) == sx;}
-    for (int32_t k = 1; k < c.ny && linear; ++k) {linear = (c.by[k] - c.by[k - 1]) == sy_ws;}
-    // every window row read by a tile must stay inside the (padded) allocation
-    if (linear) {
-      const int64_t bmax = static_cast<int64_t>(c.bx[0]) + c.by[0] + static_cast<int64_t>(c.ny - 1) * sy_ws;
-      if (c.bx[0] + c.by[0] < 0 || bmax >= m->data_size) {linear = false;}
-    }
-    if (!linear) {sx = 1; sy_ws = m->ws;}
-
-    // penalties, Mapper.cpp:671-685
-    if (q.penalize) {c.dist_pen.assign(static_cast<size_t>(c.nx) * c.ny, 1.0);} else {c.dist_pen.clear();}
-    c.ang_pen.assign(c.na, 1.0);
-    c.angles.resize(c.na);
-    const double startAngle = c.center[2] - c.ang_off;
-    for (int32_t a = 0; a < c.na; ++a) {
-      const double angle = startAngle + static_cast<uint32_t>(a) * c.ang_res;
-      c.angles[a] = angle;
-      ref_sincos(angle, &cos_sin[2 * a + 1], &cos_sin[2 * a]);          // Karto.h:6857-6858
-      const double squaredAngleDistance = (angle - c.center[2]) * (angle - c.center[2]);
-      double anglePenalty = 1.0 - (kAngleGain * squaredAngleDistance / mp.angle_variance_penalty);
-      anglePenalty = anglePenalty > mp.minimum_angle_penalty ? anglePenalty : mp.minimum_angle_penalty;
-      c.ang_pen[a] = anglePenalty;
-      ang_pen[a] = anglePenalty;
-    }
-    if (q.penalize) {
-    for (int32_t yi = 0; yi < c.ny; ++yi) {
-      const double squareY = c.y_poses[yi] * c.y_poses[yi];
-      for (int32_t xi = 0; xi < c.nx; ++xi) {
-        const double squareX = c.x_poses[xi] * c.x_poses[xi];
-        const double squaredDistance = squareX + squareY;
-        double distancePenalty = 1.0 - (kDistanceGain * squaredDistance / mp.distance_variance_penalty);
-        distancePenalty = distancePenalty > mp.minimum_distance_penalty ? distancePenalty : mp.minimum_distance_penalty;
-        c.dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
-        dist_pen[static_cast<size_t>(yi) * c.nx + xi] = distancePenalty;
-      }
-    }
-    }
-
-    // scan points in the sensor frame: Transform(sensorPose).InverseTransformPose, Karto.h:6813-6824,
-    // 2987-2994, 3003-3024, 2482-2511, 2654-2666
-    {
-      const double tx = q.scan->sensor_pose[0], ty = q.scan->sensor_pose[1], th = q.scan->sensor_pose[2];
-      double r00, r01, r02, r10, r11, r12;
-      if (tx == 0.0 && ty == 0.0 && th == 0.0) {
-        r00 = 1; r01 = 0; r02 = 0; r10 = 0; r11 = 1; r12 = 0;
-      } else {
-        const double radians = 0.0 - th;
-        double cosR, sinR;
-        ref_sincos(radians, &sinR, &cosR);
-        const double omc = 1.0 - cosR;
-        r00 = 0.0 * omc + cosR;
-        r01 = 0.0 * 0.0 * omc - 1.0 * sinR;
-        r02 = 0.0 * 1.0 * omc + 0.0 * sinR;
-        r10 = 0.0 * 0.0 * omc + 1.0 * sinR;
-        r11 = 0.0 * omc + cosR;
-        r12 = 0.0 * 1.0 * omc - 0.0 * sinR;
-      }
-      for (int32_t k = 0; k < c.P; ++k) {
-        const double sxp = q.scan->points_xy[2 * k] - tx, syp = q.scan->points_xy[2 * k + 1] - ty, sh = 0.0 - th;
-        local[2 * k] = r00 * sxp + r01 * syp + r02 * sh;
-        local[2 * k + 1] = r10 * sxp + r11 * syp + r12 * sh;
-        const double rr = q.scan->ranges[k];
-        invalid[k] = (std::isnan(rr) || std::isinf(rr)) ? 1 : 0;     // Karto.h:6869-6875
-      }
-    }
-
-    std::memset(job, 0, sizeof(CorrJob));
-    job->grid = s.d_grid; job->data_size = m->data_size; job->ws = m->ws;
-    job->n_points = c.P; job->nx = c.nx; job->ny = c.ny; job->na = c.na;
-    job->linear = linear ? 1 : 0; job->sx = sx; job->sy_ws = sy_ws; job->base0 = c.bx[0] + c.by[0];
-    const int this_sx = (linear && sx == 2) ? 2 : 1;
-    const int this_ry = pick_ry(c.ny);
-    job->tiles_y = (c.ny + 4 * this_ry - 1) / (4 * this_ry);
-    // column-decimated copies of the slot: the two-cell search is scored as a one-cell search on them (CorrJob::dec), as long
-    // as the copy can be picked per beam and tile (one tile column, or lists per tile)
-    bool dec = s.copy_kind == 2 && m->dual_copy && this_sx == 2 && sy_ws % m->ws == 0;
-    if (dec) {
-      const int32_t tiles = ((c.nx + kTileSpan - 1) / kTileSpan) * job->tiles_y;
-      dec = c.nx <= kTileSpan || (tiles >= 4 && tiles <= c.lt_alloc);
-    }
-    const int px = dec ? kTileSpan : score_tile_poses(this_sx);
-    job->tiles_x = (c.nx + px - 1) / px;
-    job->ry = this_ry; job->tile_px = px; job->dec = dec ? 1 : 0;
-    job_sx[i] = dec ? 1 : this_sx; job_ry[i] = this_ry; job_tiles[i] = job->tiles_x * job->tiles_y;
-    // LDS-staged scoring: linear lattice whose window fits 64 bytes x 64 rows
-    // ... and a launch of at least two workgroups (angle pairs) per compute unit: one config-2 search alone is 41 workgroups that
-    // walk their 25 chunks one after the other -- 0.26 ms against the windowed kernel's 0.14
-    const bool lds_wanted = lds_always || (!lds_never && static_cast<double>(c.nx) * c.ny * c.na * c.P >= 1e8 &&
-      static_cast<double>(n) * ((c.na + kGroupAngles - 1) / kGroupAngles) >= 512.0);
-    const bool lds_ok = lds_wanted && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
-      sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && 63 * sx + 1 <= kLdsRows;
-    job_lds[i] = lds_ok ? 1 : 0;
-    job->lds_path = job_lds[i]; job->sy_cells = sy_ws / m->ws;
-    job->rel = s.d_fast; job->chunks = s.d_chunks; job->chunk_counts = s.d_chunk_counts;
-    job->do_penalize = q.penalize ? 1 : 0; job->coarse = q.fine ? 0 : 1;
-    job->write_resp = m->keep_responses ? 1 : 0;
-    job->denom = c.denom;
-    job->grid_off_x = s.off_x; job->grid_off_y = s.off_y; job->scale = m->scale;
-    job->bx = reinterpret_cast<const int32_t *>(db + L.bx);
-    job->by = reinterpret_cast<const int32_t *>(db + L.by);
-    job->dist_pen = reinterpret_cast<const double *>(db + L.dist_pen);
-    job->ang_pen = reinterpret_cast<const double *>(db + L.ang_pen);
-    job->cos_sin = reinterpret_cast<const double *>(db + L.cos_sin);
-    job->local = reinterpret_cast<const double *>(db + L.local);
-    job->invalid = db + L.invalid;
-    job->table = s.d_table; job->fast = s.d_fast; job->slow = s.d_slow; job->counts = s.d_counts;
-    job->tcounts = s.d_tcounts; {
-      // tile lists pay for themselves when the window is several tiles large (the tests cost K2 time per tile)
-      const int32_t tiles = job->tiles_x * job->tiles_y;
-      job->list_tiles = (tiles >= 4 && tiles <= c.lt_alloc) ? tiles : 1;
-    }
-    job->sums = s.d_sums; job->resp = s.d_resp; job->out = B.d_out + out_words * i; job->out_words = static_cast<int32_t>(out_words);
-    job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
-    job->tile_best = s.d_tile_best;
-    // re-pitched copies: linear full-resolution lattice one tile wide (the copy is picked per beam for the tile at x0 = 0)
-    {
-      const bool use2 = dec || (s.copy_kind == 1 && m->dual_copy && linear && (job->tiles_x == 1 || job->list_tiles > 1));
-      const size_t lists = static_cast<size_t>(c.na) * kClasses * static_cast<size_t>(c.lt_alloc);
-      job->grid2 = use2 ? s.d_grid2 : nullptr;
-      job->pitch2 = dec ? m->pitch_d : m->pitch2; job->copy_b = dec ? m->copy_q : m->copy_b;
-      job->fast2 = s.d_fast + lists * static_cast<size_t>(c.P);
-      job->tcounts2 = s.d_tcounts + lists;
-    }
-    job->pad = std::max(0, m->pad_rows * m->ws - 512); job->pad_rows = m->pad_rows;
-    job->load_counter = m->profiling ? m->d_load_counter : nullptr;
+    prepare_job(m, reqs[i], ctx[i], lay[i], B.h_stage + stride * i, B.d_stage + stride * i, B.d_out + out_words * i, out_words, n,
+      lds_always, lds_never, shapes[i]);
   });
   if (timing) {
     const CorrJob * j0 = reinterpret_cast<const CorrJob *>(B.h_stage);
@@ -861,10 +778,10 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   }
   bool all_lds = true;
   for (size_t i = 0; i < n; ++i) {
-    if (sx_variant < 0) {sx_variant = job_sx[i]; ry = job_ry[i];}
-    if (sx_variant != job_sx[i] || ry != job_ry[i]) {uniform_kernel = false;}
-    max_tiles = std::max(max_tiles, job_tiles[i]);
-    all_lds = all_lds && job_lds[i] != 0;
+    if (sx_variant < 0) {sx_variant = shapes[i].sx; ry = shapes[i].ry;}
+    if (sx_variant != shapes[i].sx || ry != shapes[i].ry) {uniform_kernel = false;}
+    max_tiles = std::max(max_tiles, shapes[i].tiles);
+    all_lds = all_lds && shapes[i].lds != 0;
   }
   use_lds = all_lds && uniform_kernel;
   int32_t tile_pairs = 0;
@@ -977,115 +894,12 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   // ---- 3. finalisation (Mapper.cpp:775-862) ----
   std::vector<int> final_rc(n, KH_OK);
   auto finalize = [&](size_t i) -> int {
-    int rc = KH_OK;
-    CorrReq & q = reqs[i];
-    CorrHost & c = ctx[i];
-    Slot & s = m->slots[c.slot];
-    s.volume_stale = false;
-    const unsigned long long * out = B.h_out + out_words * i;
-    double best;
-    std::memcpy(&best, &out[0], 8);
-    const uint64_t tie_count = out[1];
-    const size_t plane = static_cast<size_t>(c.nx) * c.ny;
-    std::vector<uint32_t> ties;
-    std::vector<int32_t> host_sums;     // full volume, only when needed
-    auto fetch_volume = [&]() -> int {
-      if (!host_sums.empty()) {return KH_OK;}
-      host_sums.resize(plane * c.na);
-      KH_HIP(hipMemcpy(host_sums.data(), s.d_sums, host_sums.size() * 4, hipMemcpyDeviceToHost));
-      return KH_OK;
-    };
-    if (tie_count <= static_cast<uint64_t>(kTieCap)) {
-      const uint32_t * idx = reinterpret_cast<const uint32_t *>(out + 2);
-      ties.assign(idx, idx + tie_count);
-      std::sort(ties.begin(), ties.end());
-    } else {
-      // degenerate search (e.g. nothing rasterised: every pose ties at 0): walk the whole volume
-      // on the host in the reference's order
-      rc = fetch_volume(); if (rc) {return rc;}
-      for (int32_t yi = 0; yi < c.ny; ++yi) {
-        for (int32_t xi = 0; xi < c.nx; ++xi) {
-          for (int32_t a = 0; a < c.na; ++a) {
-            const double r = host_response(c, host_sums[static_cast<size_t>(a) * plane + static_cast<size_t>(yi) * c.nx + xi], a, yi, xi);
-            if (double_equal(r, best)) {ties.push_back(static_cast<uint32_t>((static_cast<size_t>(yi) * c.nx + xi) * c.na + a));}
-          }
-        }
-      }
-    }
-    if (ties.empty()) {q.status = KH_ERR_SEARCH; return KH_OK;}     // Mapper.cpp:828
-    // average all poses with the same highest response, Mapper.cpp:802-829
-    double ax = 0.0, ay = 0.0, thetaX = 0.0, thetaY = 0.0;
-    for (uint32_t t : ties) {
-      const int32_t a = static_cast<int32_t>(t % static_cast<uint32_t>(c.na));
-      const uint32_t xy = t / static_cast<uint32_t>(c.na);
-      const int32_t xi = static_cast<int32_t>(xy % static_cast<uint32_t>(c.nx)), yi = static_cast<int32_t>(xy / static_cast<uint32_t>(c.nx));
-      ax += c.center[0] + c.x_poses[xi];
-      ay += c.center[1] + c.y_poses[yi];
-      const double heading = normalize_angle(c.angles[a]);
-      double sin_h, cos_h;
-      ref_sincos(heading, &sin_h, &cos_h);
-      thetaX += cos_h;
-      thetaY += sin_h;
-    }
-    const int32_t count = static_cast<int32_t>(ties.size());
-    ax /= count; ay /= count; thetaX /= count; thetaY /= count;
-    const double avg[3] = {ax, ay, std::atan2(thetaY, thetaX)};
-
-    if (!c.fine) {
-      std::vector<double> lattice(plane);
-      std::memcpy(lattice.data(), out + kOutHeaderWords, plane * 8);
-      WalkGeometry wg;
-      std::copy(c.center, c.center + 3, wg.center);
-      wg.off_x = c.off_x; wg.off_y = c.off_y; wg.res_x = c.res_x; wg.res_y = c.res_y; wg.ang_res = c.ang_res;
-      const int prc = positional_covariance(m, c, lattice, wg, avg, best, q.cov);
-      if (prc != KH_OK) {q.status = prc; return KH_OK;}
-      s.last_coarse = c; s.last_lattice.swap(lattice); s.has_last_coarse = true;     // m_pSearchSpaceProbs of this matcher slot
-    } else {
-      // ComputeAngularCovariance, Mapper.cpp:977-1025
-      const double bestAngle = normalize_angle_difference(avg[2], c.center[2]);
-      const Cell g = world_to_grid(m->scale, s.off_x, s.off_y, avg[0], avg[1]);
-      const int32_t gridIndex = (g.x + m->roi_x) + (g.y + m->roi_y) * m->ws;
-      // the raw responses of all angles at that cell: it is a lattice point unless the tie average
-      // left the lattice, in which case the sums are recomputed by a 1x1 search at that cell
-      int32_t fx = -1, fy = -1;
-      for (int32_t yi = 0; yi < c.ny && fx < 0; ++yi) {
-        for (int32_t xi = 0; xi < c.nx; ++xi) {
-          if (c.bx[xi] + c.by[yi] == gridIndex) {fx = xi; fy = yi; break;}
-        }
-      }
-      std::vector<int32_t> col(c.na, 0);
-      if (fx >= 0 && plane * c.na <= kSmallVolume) {
-        const int32_t * vol = B.h_sums + B.small_stride * i;
-        for (int32_t a = 0; a < c.na; ++a) {col[a] = vol[static_cast<size_t>(a) * plane + static_cast<size_t>(fy) * c.nx + fx];}
-      } else if (fx >= 0) {
-        KH_HIP(hipMemcpy2D(col.data(), 4, s.d_sums + static_cast<size_t>(fy) * c.nx + fx, plane * 4, 4, c.na, hipMemcpyDeviceToHost));
-      } else {
-        // off-lattice best pose: score the single cell through the generic (per-pose checked) path.  Finalisation may
-        // run on pool threads: one of them at a time talks to the stream
-        static std::mutex rescore_mutex;
-        std::lock_guard<std::mutex> rescore_lock(rescore_mutex);
-        s.volume_stale = true;
-        CorrJob * job = reinterpret_cast<CorrJob *>(B.h_stage + stride * i);
-        CorrJob one = *job;
-        one.nx = 1; one.ny = 1; one.linear = 0; one.sx = 1; one.sy_ws = m->ws; one.base0 = gridIndex;
-        one.tiles_x = 1; one.tiles_y = 1; one.ry = 1; one.do_penalize = 0; one.coarse = 0; one.write_resp = 0;
-        // bx/by of the single pose: reuse the first entries of the staged arrays
-        int32_t one_bx = gridIndex, one_by = 0;
-        KH_HIP(hipMemcpy(const_cast<int32_t *>(job->bx), &one_bx, 4, hipMemcpyHostToDevice));
-        KH_HIP(hipMemcpy(const_cast<int32_t *>(job->by), &one_by, 4, hipMemcpyHostToDevice));
-        KH_HIP(hipMemcpy(B.d_stage + stride * i, &one, sizeof(CorrJob), hipMemcpyHostToDevice));
-        launch_offsets(B.d_stage + stride * i, stride, 1, one.na, m->stream);
-        launch_score(B.d_stage + stride * i, stride, 1, 1, one.na, 1, 1, m->stream);
-        KH_HIP(hipStreamSynchronize(m->stream));
-        KH_HIP(hipMemcpy(col.data(), s.d_sums, sizeof(int32_t) * c.na, hipMemcpyDeviceToHost));
-        // (the slot's stored volume now holds this 1 x 1 search: kh_matcher_read_volume reports KH_ERR_NOT_FOUND)
-      }
-      q.cov[8] = angular_variance(col, c.denom, c.center[2], c.ang_off, c.ang_res, bestAngle, best);
-    }
-    q.mean[0] = avg[0]; q.mean[1] = avg[1]; q.mean[2] = avg[2];
-    q.response = best > 1.0 ? 1.0 : best;
-    s.last = c; s.has_last = true;
-    return KH_OK;
+    ResultView v;
+    v.out = B.h_out + out_words * i;
+    const size_t vol = static_cast<size_t>(ctx[i].nx) * ctx[i].ny * ctx[i].na;
+    v.small = (ctx[i].fine && vol <= kSmallVolume && B.h_sums) ? B.h_sums + B.small_stride * i : nullptr;
+    v.h_job = reinterpret_cast<CorrJob *>(B.h_stage + stride * i); v.d_job = B.d_stage + stride * i; v.stride = stride;
+    return finalize_job(m, reqs[i], ctx[i], v);
   };
   // big fine volumes and the off-lattice re-score path issue their own copies / launches on the
   // stream: keep such batches off the pool
@@ -1112,7 +926,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   return KH_OK;
 }
 
-static int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
+int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
 {
   const size_t n = reqs.size();
   if (n == 0) {return KH_OK;}
@@ -1364,6 +1178,7 @@ void kh_matcher_destroy(kh_matcher * m)
   if (!m) {return;}
   hipSetDevice(m->device);
   if (m->stream) {hipStreamSynchronize(m->stream);}
+  seq_destroy(m);
   for (auto & s : m->slots) {
     hipFree(s.d_grid_alloc); hipFree(s.d_grid2_alloc); hipFree(s.d_prev_work); hipFree(s.d_blockmap); hipFree(s.d_rtiles); hipFree(s.d_rlists); hipFree(s.d_tile_best); hipFree(s.d_table); hipFree(s.d_fast); hipFree(s.d_tcounts); hipFree(s.d_slow); hipFree(s.d_counts);
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
@@ -1410,6 +1225,7 @@ int kh_matcher_set_debug(kh_matcher * m, int32_t keep_response_volume)
   m->keep_responses = (keep_response_volume & 1) != 0;
   m->lds_score = (keep_response_volume & 2) != 0;
   m->windowed_score = (keep_response_volume & 64) != 0;
+  m->no_seq = (keep_response_volume & 128) != 0;
   m->dense_score = (keep_response_volume & 4) != 0;
   if (keep_response_volume & 32) {m->mfma_score = true;}
   m->force_chunks = (keep_response_volume & 8) != 0 || std::getenv("KH_FORCE_CHUNKS") != nullptr;
@@ -1534,8 +1350,21 @@ int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, c
     active.push_back(i);
     rreqs.push_back(RasterReq{i, &queries[i], base ? base + base_begin[i] : nullptr, nb});
   }
-  int rc = raster_batch(m, rreqs);
-  if (rc) {return rc;}
+  // ONE MatchScan -- what the reference's API issues (Mapper.cpp:2714-2717) -- takes the fused path (matcher_seq.cpp); it hands
+  // back, pass by pass, whatever it could not finish
+  int rc = KH_OK;
+  bool coarse_done = false, fine_done = false;
+  if (n == 1 && active.size() == 1) {
+    int seq_status = KH_OK;
+    rc = seq_match(m, &queries[0], base ? base + base_begin[0] : nullptr, base_begin[1] - base_begin[0], do_penalize != 0, do_refine != 0,
+      means, covs, responses, &seq_status, &coarse_done, &fine_done);
+    if (rc) {return rc;}
+    if (coarse_done) {st[0] = seq_status;}
+  }
+  if (!coarse_done) {
+    rc = raster_batch(m, rreqs);
+    if (rc) {return rc;}
+  }
 
   const double res = m->grid_resolution();
   // Mapper.cpp:577-585
@@ -1578,8 +1407,10 @@ int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, c
   };
 
   // coarse search, Mapper.cpp:588-592
-  rc = run(active, mp.coarse_search_angle_offset, mp.coarse_angle_resolution, false);
-  if (rc) {return rc;}
+  if (!coarse_done) {
+    rc = run(active, mp.coarse_search_angle_offset, mp.coarse_angle_resolution, false);
+    if (rc) {return rc;}
+  }
   // response expansion, Mapper.cpp:594-619
   if (mp.use_response_expansion) {
     std::vector<int32_t> zero;
@@ -1595,7 +1426,7 @@ int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, c
     }
   }
   // fine search, Mapper.cpp:621-629
-  if (do_refine) {
+  if (do_refine && !fine_done) {
     rc = run(alive(active), 0.5 * mp.coarse_angle_resolution, mp.fine_search_angle_offset, true);
     if (rc) {return rc;}
   }
@@ -1732,6 +1563,14 @@ int kh_matcher_angular_covariance(kh_matcher * m, int32_t slot, const kh_scan * 
   KH_HIP(hipMemcpy(col.data(), s.d_sums, sizeof(int32_t) * na, hipMemcpyDeviceToHost));
   const double bestAngle = normalize_angle_difference(best_pose[2], center[2]);
   cov[8] = angular_variance(col, s.last.denom, center[2], angle_offset, angle_resolution, bestAngle, best_response);
+  return KH_OK;
+}
+
+int kh_matcher_seq_stats(kh_matcher * m, int64_t out[8])
+{
+  if (!m || !out) {return KH_ERR_INVALID_ARG;}
+  const int64_t * v = seq_stats(m);
+  std::copy(v, v + kSeqStatWords, out);
   return KH_OK;
 }
 

@@ -19,9 +19,11 @@
 // once per pose in the epilogue.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include "kh_internal.hpp"
+#include "matcher_device.hpp"
 
 #ifndef KH_UB8
 #define KH_UB8 4
@@ -30,14 +32,6 @@
 namespace kh
 {
 
-// ---------------------------------------------------------------------------------------------
-// exact helpers (mirror Math.h:87-90 and the x86-64 double->int32 conversion)
-__device__ __forceinline__ double d_round(double v) {return v >= 0.0 ? floor(v + 0.5) : ceil(v - 0.5);}
-__device__ __forceinline__ int32_t d_to_int(double v)
-{
-  if (!(v > -2147483649.0 && v < 2147483648.0)) {return INT32_MIN;}   // cvttsd2si "integer indefinite"
-  return (int32_t)v;
-}
 // ---------------------------------------------------------------------------------------------
 // K0: FindValidPoints (Mapper.cpp:1113-1164) for every (job, base scan) pair of a batch, one LANE per pair.  The walk is
 // a sequential state machine (each 0.1 m trigger depends on the previous trigger's point), but the pairs are independent:
@@ -190,118 +184,17 @@ __global__ __launch_bounds__(256) void k_find_valid(const RasterJob * jobs, cons
   for (int i = trailing + lane; i < n; i += 64) {out[i] = 0;}        // the tail after the last trigger is never emitted
 }
 
-// FindValidPoints, data parallel inside one scan (workgroup per scan).  The state machine hops from trigger to trigger -- a
-// trigger is the first reading more than 0.1 m from the current anchor, and it becomes the next anchor -- so its path is a
-// walk along next(i) = "first reading after i more than 0.1 m from reading i", which every lane can evaluate for its own
-// readings.  Which readings the walk visits (reachability from the first valid reading) comes from pointer doubling in
-// LDS: 11 rounds for <= 2048 readings instead of one dependent hop per trigger (several hundred per scan when the beams
-// are long: 156 us for the 20 running scans of a sequential match with the hop-by-hop kernel k_find_valid).  The
-// side-of-line sign of every visited trigger and the fate of every run follow in parallel: reading i is emitted iff the
-// first trigger after it lies on the viewpoint's side (Mapper.cpp:1145-1160); the tail after the last trigger never is.
-// Same comparisons, same operand order as the sequential form: bit-identical flags.
 __global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n)
 {
   // one workgroup per scan: a lane owns every 256th reading, so the divergent forward scans of next() cost a lane four or
   // five readings' worth of its slowest neighbour instead of seventeen (one wave per scan: 56 us for 20 scans)
   extern __shared__ double2 s_fv[];
-  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int t = blockIdx.x;
-  const int stride_i = max_n + 64;                        // ints per pointer array
-  double2 * P = s_fv;
-  int32_t * nxt0 = reinterpret_cast<int32_t *>(P + max_n);
-  int32_t * nxa = nxt0 + stride_i;
-  int32_t * nxb = nxa + stride_i;
-  uint8_t * reach = reinterpret_cast<uint8_t *>(nxb + stride_i);
-  uint8_t * keep = reach + stride_i;
-  __shared__ int s_pos0;
-  __shared__ unsigned long long s_mask[40];               // triggers of every chunk of 64 readings (max_n <= 2048 -> 32 chunks)
-  __shared__ int s_later[40];                             // first trigger in the chunks behind chunk c, -1 = none
   const RasterJob & job = jobs[items[t].job];
   const int k = items[t].scan;
   const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
-  const double2 * pts = reinterpret_cast<const double2 *>(job.scan_ptr[k]);
-  uint8_t * out = job.active + job.scan_prefix[k];
-  if (tid == 0) {s_pos0 = n;}
-  for (int i = tid; i < n; i += nthreads) {P[i] = pts[i]; reach[i] = 0; keep[i] = 0;}
-  __syncthreads();
-  const double vx = job.view_x, vy = job.view_y;
-  const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
-  // the first reading without a NaN coordinate is the first anchor (Mapper.cpp:1127-1136)
-  {
-    int mine = n;
-    for (int i = tid; i < n; i += nthreads) {
-      if (!isnan(P[i].x) && !isnan(P[i].y)) {mine = i; break;}
-    }
-    if (mine < n) {atomicMin(&s_pos0, mine);}
-  }
-  // next(i): the trigger that follows if reading i is the anchor (n = none)
-  for (int i = tid; i < n; i += nthreads) {
-    const double fx = P[i].x, fy = P[i].y;
-    int j = (isnan(fx) || isnan(fy)) ? n : i + 1;         // a NaN reading is never an anchor (nothing is "farther" than NaN)
-    for (; j < n; ++j) {
-      const double dx = fx - P[j].x, dy = fy - P[j].y;
-      if (dx * dx + dy * dy > min_square_distance) {break;}
-    }
-    nxt0[i] = j;
-  }
-  if (tid == 0) {nxt0[n] = n; reach[n] = 0;}
-  __syncthreads();
-  const int pos0 = s_pos0;
-  if (pos0 >= n) {
-    for (int i = tid; i < n; i += nthreads) {out[i] = 0;}
-    return;
-  }
-  if (tid == 0) {reach[pos0] = 1;}
-  __syncthreads();
-  // reachability from pos0 by pointer doubling
-  const int32_t * cur = nxt0;
-  int32_t * nxt_w = nxa;
-  for (int span = 1; span < n; span <<= 1) {
-    for (int i = tid; i <= n; i += nthreads) {
-      const int j = cur[i];
-      if (i < n && reach[i] && j < n) {reach[j] = 1;}
-      nxt_w[i] = j < n ? cur[j] : n;
-    }
-    __syncthreads();
-    cur = nxt_w;
-    nxt_w = (nxt_w == nxa) ? nxb : nxa;
-  }
-  // every visited trigger: which side of the line viewpoint -> anchor it lies on (its anchor is the visited reading whose
-  // next() it is)
-  for (int i = tid; i < n; i += nthreads) {
-    const int j = nxt0[i];
-    if (reach[i] && j < n) {
-      const double fx = P[i].x, fy = P[i].y, cx = P[j].x, cy = P[j].y;
-      const double a = vy - fy;
-      const double b = fx - vx;
-      const double cc = fy * vx - fx * vy;
-      const double ss = cx * a + cy * b + cc;
-      keep[j] = ss < 0.0 ? 0 : 1;
-    }
-  }
-  // reading i belongs to the run that ends at the first trigger after it
-  const int n_chunks = (n + 63) >> 6;
-  for (int base = 64 * (tid >> 6); base < n; base += nthreads) {     // wave w takes chunks w, w + 4, ...
-    const int i = base + lane;
-    const bool trig = i < n && i != pos0 && reach[min(i, n - 1)];
-    const unsigned long long mask = __ballot(trig);
-    if (lane == 0) {s_mask[base >> 6] = mask;}
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int later = -1;
-    for (int c = n_chunks - 1; c >= 0; --c) {
-      s_later[c] = later;
-      if (s_mask[c]) {later = 64 * c + __builtin_ctzll(s_mask[c]);}
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += nthreads) {
-    const int c = i >> 6, l = i & 63;
-    const unsigned long long above = l < 63 ? (s_mask[c] >> (l + 1)) : 0ull;
-    const int j = above ? i + 1 + __builtin_ctzll(above) : s_later[c];
-    out[i] = j >= 0 ? keep[j] : 0;
-  }
+  uint8_t * flags = nullptr;
+  find_valid_scan(reinterpret_cast<const double2 *>(job.scan_ptr[k]), n, job.active + job.scan_prefix[k], job.view_x, job.view_y, max_n, s_fv, flags);
 }
 
 void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream)
@@ -328,11 +221,8 @@ void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int3
   }
   const size_t stride_i = (size_t)max_n + 64;
   const size_t lds = (size_t)max_n * sizeof(double2) + 3 * stride_i * sizeof(int32_t) + 2 * stride_i;
-  static bool attr2_set = false;
-  if (!attr2_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid_par), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr2_set = true;
-  }
+  static std::atomic<unsigned long long> attr2_done{0};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_find_valid_par), 64 * 1024, attr2_done);
   hipLaunchKernelGGL(k_find_valid_par, dim3(n_items), dim3(256), lds, (hipStream_t)stream, d_jobs, d_items, (int)n_items, (int)max_n);
 }
 
@@ -395,28 +285,6 @@ void launch_raster_clear(const RasterJob * d_jobs, int32_t n_jobs, void * stream
   hipLaunchKernelGGL(k_raster_clear, dim3(512, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs);
 }
 
-// job point p -> its world coordinates: base scan by bisection of the prefix (<= a few dozen scans), then the arena
-__device__ __forceinline__ double2 job_point(const RasterJob & job, int p)
-{
-  if (job.uniform_n > 0) {                      // the usual case: one laser, every scan has the same number of beams
-    const int k = p / job.uniform_n;
-    return reinterpret_cast<const double2 *>(job.scan_ptr[k])[p - k * job.uniform_n];
-  }
-  int lo = 0, hi = job.n_scans;                 // scan_prefix[lo] <= p < scan_prefix[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (job.scan_prefix[mid] <= p) {lo = mid;} else {hi = mid;}
-  }
-  return reinterpret_cast<const double2 *>(job.scan_ptr[lo])[p - job.scan_prefix[lo]];
-}
-// CoordinateConverter::WorldToGrid (Karto.h:4421-4436) + the ROI test of AddScan (Mapper.cpp:1083-1088)
-__device__ __forceinline__ bool roi_cell(const RasterJob & job, double2 w, int32_t & gx, int32_t & gy)
-{
-  const double gxd = (w.x - job.off_x) * job.scale;
-  const double gyd = (w.y - job.off_y) * job.scale;
-  gx = d_to_int(d_round(gxd)); gy = d_to_int(d_round(gyd));
-  return (gx >= 0 && gx < job.roi_w) && (gy >= 0 && gy < job.roi_h);
-}
 __device__ __forceinline__ uint32_t hash_slot(const RasterJob & job, uint32_t key)
 {
   return (key * 0x9E3779B1u) & (uint32_t)(job.hcap - 1);
@@ -1005,15 +873,11 @@ __global__ __launch_bounds__(256) void k_raster_tile_reg(const RasterJob * jobs,
   }
 }
 
-void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
+void launch_raster_tiles(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
   void * stream)
 {
   if (n_jobs <= 0 || max_points <= 0) {return;}
   hipStream_t s = (hipStream_t)stream;
-  dim3 per_point((max_points + 255) / 256, n_jobs);
-  hipLaunchKernelGGL(k_raster_bin, dim3((max_points + 256 * kBinPoints - 1) / (256 * kBinPoints), n_jobs), dim3(256), 0, s, d_jobs);
-  hipLaunchKernelGGL(k_raster_scan, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
-  hipLaunchKernelGGL(k_raster_fill, per_point, dim3(256), 0, s, d_jobs);
   // non-empty tiles <= 4 per point and <= all tiles; a workgroup walks several when there are more
   static const int tile_blocks = std::getenv("KH_TILE_BLOCKS") ? std::atoi(std::getenv("KH_TILE_BLOCKS")) : 2048;
   int blocks = std::min(std::min(max_tiles, 4 * max_points), tile_blocks);
@@ -1024,6 +888,18 @@ void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points,
   } else {
     hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
   }
+}
+
+void launch_raster(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
+  void * stream)
+{
+  if (n_jobs <= 0 || max_points <= 0) {return;}
+  hipStream_t s = (hipStream_t)stream;
+  dim3 per_point((max_points + 255) / 256, n_jobs);
+  hipLaunchKernelGGL(k_raster_bin, dim3((max_points + 256 * kBinPoints - 1) / (256 * kBinPoints), n_jobs), dim3(256), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_raster_scan, dim3(n_jobs), dim3(1024), 0, s, d_jobs);
+  hipLaunchKernelGGL(k_raster_fill, per_point, dim3(256), 0, s, d_jobs);
+  launch_raster_tiles(d_jobs, n_jobs, max_points, max_tiles, d_kernel, kernel_size, stream);
 }
 
 // Re-pitched copies (CorrJob::grid2): the tiles the previous rasterisation touched are zeroed, the tiles this one touched
@@ -1303,29 +1179,6 @@ void launch_offsets(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32
   if (n_jobs <= 0 || max_na <= 0) {return;}
   hipLaunchKernelGGL(k_offsets, dim3(max_na, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs, stride);
 }
-
-// ---------------------------------------------------------------------------------------------
-// response of one pose from its integer sum: GetResponse's normalisation (Mapper.cpp:1204) and the
-// odometry penalty (Mapper.cpp:671-685).  Shared by K3 and K4 so both see identical bits.
-__device__ __forceinline__ double pose_response(const CorrJob & job, int32_t sum, int a, int yi, int xi)
-{
-  double response = (double)sum / job.denom;
-  if (job.do_penalize) {
-    const double delta = response - 0.0;
-    const bool is_zero = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;   // math::DoubleEqual, Math.h:135-139
-    if (!is_zero) {
-      response *= (job.dist_pen[yi * job.nx + xi] * job.ang_pen[a]);
-    }
-  }
-  return response;
-}
-
-// global-address-space views: keeps the hot loads on global_load (vmcnt only) instead of flat_load
-typedef __attribute__((address_space(1))) uint8_t gbyte;
-typedef __attribute__((address_space(1))) int32_t gint;
-typedef __attribute__((address_space(1))) uint32_t gu32;
-__device__ __forceinline__ const gbyte * as_global(const uint8_t * p) {return (const gbyte *)p;}
-__device__ __forceinline__ const gint * as_global(const int32_t * p) {return (const gint *)p;}
 
 // K3.  SX = grid cells per lattice step in x (1: fine / full-resolution search, 2: coarse search).
 // Tile = 64 aligned grid bytes x 4*RY lattice rows, of which 61 bytes (61 poses at SX=1, 31 at SX=2)
@@ -1672,109 +1525,9 @@ __global__ __launch_bounds__(256) void k_ties(const uint8_t * jobs, size_t strid
   const double best = __longlong_as_double((long long)job.out[0]);
   uint32_t * tie_idx = reinterpret_cast<uint32_t *>(job.out + 2);
   if (job.coarse) {
-    // search-space probabilities (Mapper.cpp:781-799): the best response over the angles of every cell, recomputed here from
-    // the stored sums with the same device function -- one plain store per cell instead of one atomic maximum per POSE in the
-    // scoring kernel's epilogue (301 401 of them per config-2 match, all on the same 30 KB).
-    // The exact response costs a double-precision division per angle.  The maximum over the angles is found in two passes:
-    // a single-precision key sum x angle penalty first (the distance penalty is common to the cell; the key orders the
-    // responses up to a relative 3e-7), then the exact response of the angles whose key lies within 1e-5 of the largest --
-    // one or two of the 81.  Responses at or below 1e-6 skip the penalty (math::DoubleEqual(response, 0), Mapper.cpp:671-685)
-    // and do not follow the key: a cell whose largest sum is that small takes the exact pass over all its angles.
-    // Work split: a workgroup takes 64 cells at a time (lane = cell: coalesced rows of the sums volume), its four waves a
-    // quarter of the angles each -- a thread's sums are read ONCE, all in flight together, and kept in registers for both passes.
-    const int na = job.na, nxp = job.nx;
-    const int32_t * const sums = job.sums;
-    unsigned long long * const probs = job.out + kOutHeaderWords;
-    const bool penal = job.do_penalize != 0;
-    const double denom = job.denom;
-    constexpr int kSlice = 32;                             // angles per wave held in registers
-    __shared__ float s_key[4][64];
-    __shared__ int32_t s_sum[4][64];
-    __shared__ double s_max[4][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int per = (na + 3) / 4;
-    if (per <= kSlice && blockDim.x == 256) {
-      const int a_lo = slice * per;
-      for (int cell0 = blockIdx.x * 64; cell0 < (int)plane; cell0 += gridDim.x * 64) {
-        const int cell = cell0 + lane;
-        const bool valid = cell < (int)plane;
-        int32_t v[kSlice];
-#pragma unroll
-        for (int t = 0; t < kSlice; ++t) {v[t] = (valid && t < per && a_lo + t < na) ? sums[(size_t)(a_lo + t) * plane + cell] : 0;}
-        int32_t smax = 0;
-        float kmax = 0.0f;
-#pragma unroll
-        for (int t = 0; t < kSlice; ++t) {
-          if (t < per && a_lo + t < na) {
-            const float key = (float)v[t] * (penal ? (float)job.ang_pen[a_lo + t] : 1.0f);
-            kmax = key > kmax ? key : kmax;
-            smax = v[t] > smax ? v[t] : smax;
-          }
-        }
-        s_key[slice][lane] = kmax; s_sum[slice][lane] = smax;
-        __syncthreads();
-        kmax = fmaxf(fmaxf(s_key[0][lane], s_key[1][lane]), fmaxf(s_key[2][lane], s_key[3][lane]));
-        smax = max(max(s_sum[0][lane], s_sum[1][lane]), max(s_sum[2][lane], s_sum[3][lane]));
-        double m = 0.0;
-        if (valid && smax > 0) {
-          const int yi = cell / nxp, xi = cell - yi * nxp;
-          const bool all = (double)smax / denom < 4e-6;
-          const float thresh = all ? -1.0f : kmax * (1.0f - 1e-5f);
-#pragma unroll
-          for (int t = 0; t < kSlice; ++t) {
-            if (t < per && a_lo + t < na) {
-              const float key = (float)v[t] * (penal ? (float)job.ang_pen[a_lo + t] : 1.0f);
-              if (key >= thresh) {
-                const double response = pose_response(job, v[t], a_lo + t, yi, xi);
-                m = response > m ? response : m;
-              }
-            }
-          }
-        }
-        s_max[slice][lane] = m;
-        __syncthreads();
-        if (slice == 0 && valid) {
-          const double m01 = s_max[0][lane] > s_max[1][lane] ? s_max[0][lane] : s_max[1][lane];
-          const double m23 = s_max[2][lane] > s_max[3][lane] ? s_max[2][lane] : s_max[3][lane];
-          probs[cell] = (unsigned long long)__double_as_longlong(m01 > m23 ? m01 : m23);
-        }
-        __syncthreads();
-      }
-    } else {
-      // more than 128 angles: a thread per cell walks them all, eight loads at a time
-      for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < (int)plane; cell += gridDim.x * blockDim.x) {
-        const int yi = cell / nxp, xi = cell - yi * nxp;
-        int32_t smax = 0;
-        float kmax = 0.0f;
-        for (int a0 = 0; a0 < na; a0 += 8) {
-          int32_t v[8];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {v[t] = a0 + t < na ? sums[(size_t)(a0 + t) * plane + cell] : 0;}
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            if (a0 + t < na) {
-              const float key = (float)v[t] * (penal ? (float)job.ang_pen[a0 + t] : 1.0f);
-              kmax = key > kmax ? key : kmax;
-              smax = v[t] > smax ? v[t] : smax;
-            }
-          }
-        }
-        double m = 0.0;
-        if (smax > 0) {
-          const bool all = (double)smax / denom < 4e-6;
-          const float thresh = all ? -1.0f : kmax * (1.0f - 1e-5f);
-          for (int a = 0; a < na; ++a) {
-            const int32_t v = sums[(size_t)a * plane + cell];
-            const float key = (float)v * (penal ? (float)job.ang_pen[a] : 1.0f);
-            if (key >= thresh) {
-              const double response = pose_response(job, v, a, yi, xi);
-              m = response > m ? response : m;
-            }
-          }
-        }
-        probs[cell] = (unsigned long long)__double_as_longlong(m);
-      }
-    }
+    // search-space probabilities (Mapper.cpp:781-799): one plain store per cell instead of one atomic maximum per POSE in the
+    // scoring kernel's epilogue (301 401 of them per config-2 match, all on the same 30 KB)
+    (void)cell_maxima(job, (int)blockIdx.x, (int)gridDim.x, nullptr);
   }
   auto consider = [&](int a, int yi, int xi) {
     const size_t o = (size_t)a * plane + (size_t)yi * job.nx + xi;
@@ -1902,23 +1655,6 @@ __device__ __forceinline__ int wave_prefix(int v)
 }
 __device__ __forceinline__ int wave_prefix_min(int v, int) {return wave_prefix<true>(v);}
 __device__ __forceinline__ int wave_prefix_max(int v, int) {return wave_prefix<false>(v);}
-
-// Does any stamp footprint overlap the window [x_lo, x_hi] x [y_lo, y_hi] (grid cells)?  One bit per 32 x 32 block, rows padded
-// by a word; rows above and below the array hold nothing.  No early exit: the probes are independent loads.
-__device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w, int bm_h, int x_lo, int y_lo, int x_hi, int y_hi)
-{
-  const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
-  const int by0 = max(y_lo, 0) >> kBlockShift, by1 = min(y_hi >> kBlockShift, bm_h - 1);
-  const int wi = bx0 >> 5, sh = bx0 & 31, nb = bx1 - bx0 + 1;
-  if (nb > 32) {return true;}
-  const unsigned long long span = (1ull << nb) - 1ull;
-  unsigned long long any = 0;
-  for (int by = by0; by <= by1; ++by) {
-    const uint32_t * row = bmp + (size_t)by * bm_w + wi;
-    any |= (((unsigned long long)row[1] << 32) | row[0]) >> sh;
-  }
-  return (any & span) != 0;
-}
 
 // K2'.  Thread t of the workgroup owns the beams t, t + 256, t + 512, ...: wave w therefore sees, round after round, a RUN of 64
 // consecutive beams (beam = 256 * round + 64 * w + lane), which is all the chunk builder needs -- a chunk never spans more than 64
@@ -2467,14 +2203,12 @@ void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int
 #define KH_LDS_NW 4
 #endif
   static const int nw = std::getenv("KH_LDS_WAVES") ? std::atoi(std::getenv("KH_LDS_WAVES")) : KH_LDS_NW;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_lds<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
-    attr_set = true;
-  }
+  // (per device: a group's members on other devices launch this kernel from their own threads)
+  static std::atomic<unsigned long long> attr_done[4] = {{0}, {0}, {0}, {0}};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 4>), kDyn, attr_done[0]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 4>), kDyn, attr_done[1]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 8>), kDyn, attr_done[2]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 8>), kDyn, attr_done[3]);
   hipStream_t s = (hipStream_t)stream;
 #define KH_SCORE_LDS(SV, NWV) hipLaunchKernelGGL((k_score_lds<SV, NWV>), dim3((unsigned int)blocks), dim3(128 * NWV), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map)
   if (sx_variant == 2) {

@@ -1,0 +1,705 @@
+// gfx950 kernels of the fused path of ONE MatchScan (see matcher_seq.hpp for the plan).  Same arithmetic as the batch kernels
+// (matcher_kernels.hip), bit for bit; what differs is the layout of the work for a single job on a nearly empty chip: no
+// hash table, state of the order-dependent rule in LDS, one workgroup where the batch path takes five launches, table and
+// scoring in one launch with the beams cut into slices, the fine pass finished on the device.
+// Build with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include "kh_internal.hpp"
+#include "matcher_device.hpp"
+#include "matcher_seq.hpp"
+
+namespace kh
+{
+
+// ---------------------------------------------------------------------------------------------
+// kseq_prep.  Blocks [0, n_scans): FindValidPoints of scan b (Mapper.cpp:1113-1164; find_valid_scan, 1024 threads: the walk is
+// bound by LDS latency, and sixteen waves hide four times what four do), then -- the scan's points and flags still in LDS --
+// WorldToGrid + the ROI test of AddScan (Mapper.cpp:1083-1088) for every kept reading and the FIRST point of every cell:
+// atomicMin of the job point index into first[cell].  A second point of a cell stamps the same footprint (n_foot == 0), or is
+// skipped by the "cell already 100" rule whatever happened to the first (n_foot > 0): only firsts are stamp candidates.
+// Blocks behind them: Grid::Clear (Karto.h:4612-4615) = the tiles the slot's previous rasterisation wrote, the counters.
+__global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
+{
+  extern __shared__ double2 s_fv[];
+  const RasterJob & job = args.job;
+  const int b = blockIdx.x;
+  if (b < args.n_scans) {
+    const int p0 = args.prefix[b], n = args.prefix[b + 1] - p0;
+    uint8_t * flags = nullptr;
+    find_valid_scan(reinterpret_cast<const double2 *>(args.scans[b]), n, job.active + p0, job.view_x, job.view_y, args.max_n, s_fv, flags);
+    const double2 * P = s_fv;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      int32_t gx = 0, gy = 0;
+      bool on = flags[i] != 0;
+      if (on) {on = roi_cell(job, P[i], gx, gy);}
+      int2 cell = make_int2(-1, -1);
+      if (on) {
+        cell = make_int2(gx + job.roi_x, gy + job.roi_y);              // CorrelationGrid::GridIndex, Mapper.h:1122-1128
+        atomicMin(&args.first[(size_t)gy * job.roi_w + gx], p0 + i);
+      }
+      *reinterpret_cast<int2 *>(job.cell_xy + 2 * (size_t)(p0 + i)) = cell;
+    }
+    return;
+  }
+  const int c = b - args.n_scans, nc = args.clear_blocks;
+  {
+    const int n_prev = job.prev_work[0];
+    for (int w = c; w < n_prev; w += nc) {
+      const int t = job.prev_work[4 + w];
+      const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
+      // 64 rows x 64 bytes: 1024 threads x 4 bytes (ws is a multiple of 8, the tile starts on a multiple of 64)
+      const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
+      const int y = ty * kRasterTile + row, x = tx * kRasterTile + 4 * part;
+      if (y < job.height && x < job.ws) {*reinterpret_cast<uint32_t *>(job.grid + (size_t)y * job.ws + x) = 0u;}
+    }
+  }
+  if (c == 0) {
+    if (threadIdx.x < 4) {job.n_work[threadIdx.x] = 0;}
+    if (threadIdx.x < kSeqCtlWords) {args.ctl[threadIdx.x] = 0;}
+    // the job for the launches that follow
+    const uint32_t * src = reinterpret_cast<const uint32_t *>(&args.job);
+    uint32_t * dst = reinterpret_cast<uint32_t *>(args.d_job);
+    for (int i = threadIdx.x; i < (int)(sizeof(RasterJob) / 4); i += blockDim.x) {dst[i] = src[i];}
+  }
+}
+
+void launch_seq_prep(const SeqPrepArgs & args, void * stream)
+{
+  const size_t stride_i = (size_t)args.max_n + 64;
+  const size_t lds = (size_t)args.max_n * sizeof(double2) + 3 * stride_i * sizeof(int32_t) + 2 * stride_i;
+  static std::atomic<unsigned long long> done{0};
+  allow_dynamic_lds(reinterpret_cast<const void *>(kseq_prep), 64 * 1024, done);
+  hipLaunchKernelGGL(kseq_prep, dim3(args.n_scans + args.clear_blocks), dim3(1024), lds, (hipStream_t)stream, args);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kseq_links.  Thread per job point: the firsts become stamp candidates (point, cell); with the order-dependent rule
+// (Mapper.cpp:1093-1096, n_foot > 0) each takes along the first points of the cells in its 100-footprint that come EARLIER
+// (a later one can never block it) -- four independent loads where the batch path probes a hash table.
+__global__ __launch_bounds__(256) void kseq_links(const RasterJob * jobp, const int32_t * __restrict__ first, int32_t * cand, int32_t * ctl)
+{
+  const RasterJob & job = *jobp;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  bool is_first = false;
+  int cx = -1, cy = -1;
+  int nb[kMaxFootprint] = {-1, -1, -1, -1};
+  if (p < job.n_points) {
+    const int2 c = *reinterpret_cast<const int2 *>(job.cell_xy + 2 * (size_t)p);
+    cx = c.x; cy = c.y;
+    if (cx >= 0) {
+      const int gx = cx - job.roi_x, gy = cy - job.roi_y;
+      int32_t v[kMaxFootprint] = {kFirstNone, kFirstNone, kFirstNone, kFirstNone};
+      const int32_t mine = first[(size_t)gy * job.roi_w + gx];
+#pragma unroll
+      for (int f = 0; f < kMaxFootprint; ++f) {
+        if (f < job.n_foot) {
+          const int nx = gx + job.foot_dx[f], ny = gy + job.foot_dy[f];
+          if (nx >= 0 && nx < job.roi_w && ny >= 0 && ny < job.roi_h) {v[f] = first[(size_t)ny * job.roi_w + nx];}
+        }
+      }
+      is_first = mine == p;
+#pragma unroll
+      for (int f = 0; f < kMaxFootprint; ++f) {nb[f] = v[f] < p ? v[f] : -1;}
+    }
+  }
+  // candidate list: one atomic per wave
+  const unsigned long long mask = __ballot(is_first);
+  if (mask == 0) {return;}
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(mask);
+  int base = 0;
+  if (lane == leader) {base = atomicAdd(&ctl[0], __builtin_popcountll(mask));}
+  base = __shfl(base, leader);
+  if (is_first) {
+    const int i = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    int4 * rec = reinterpret_cast<int4 *>(cand + (size_t)kSeqCandWords * i);
+    rec[0] = make_int4(p, cx, cy, 0);
+    rec[1] = make_int4(nb[0], nb[1], nb[2], nb[3]);
+  }
+}
+
+void launch_seq_links(const RasterJob * d_job, int32_t n_points, const int32_t * first, int32_t * cand, int32_t * ctl, void * stream)
+{
+  if (n_points <= 0) {return;}
+  hipLaunchKernelGGL(kseq_links, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_job, first, cand, ctl);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive prefix sum over the 1024 threads of a block (two 32-bit sums packed in one 64-bit word); total to every thread
+__device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long long v, unsigned long long * s_w, unsigned long long & total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long o = __shfl_up(inc, d);
+    if (lane >= d) {inc += o;}
+  }
+  if (lane == 63) {s_w[wave] = inc;}
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const unsigned long long x = s_w[w];
+    if (w < wave) {base += x;}
+    tot += x;
+  }
+  total = tot;
+  return base + inc - v;
+}
+
+// kseq_bin.  ONE workgroup of 1024 threads does what the batch path spreads over k_active_set, k_raster_bin, k_raster_scan,
+// k_raster_fill and k_repitch_keep -- for one job those are five launches of dependent round trips to L2 on a handful of
+// compute units; here the state lives in LDS:
+//  1. the order-dependent rule: a candidate is stamped iff no EARLIER STAMPED candidate has its cell in its 100-footprint -- the
+//     greedy independent set in point order (see k_active_set).  State byte per job point in LDS (0 undecided, 1 stamped,
+//     2 skipped); a candidate decides as soon as its earlier neighbours have; sweeps until nothing is undecided.  The first
+//     8192 candidates keep their neighbour links in registers.
+//  2. every stamped candidate marks the occupancy blocks its footprint overlaps and takes its rank in the <= 2 x 2 tiles it
+//     overlaps from LDS counters; scan of the counters -> list starts, the list of non-empty tiles (which also becomes the
+//     "previous" list Grid::Clear of the next match zeroes); the lists are written from the ranks.
+//  3. first[] goes back to "none" for the cells this match touched (every touched cell has exactly one candidate).
+constexpr int kBinRegs = 8;
+__global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t * first, int32_t * cand, const int32_t * ctl, int keep_prev)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  __shared__ unsigned long long s_w[16];
+  const RasterJob & job = *jobp;
+  const int tid = threadIdx.x;
+  const int n_cand = ctl[0];
+  const int tiles = job.tiles_w * job.tiles_h, bm_words = job.bm_w * job.bm_h;
+  const int state_bytes = job.n_foot > 0 ? ((job.n_points + 15) & ~15) : 0;
+  uint8_t * state = s_dyn;
+  int32_t * s_cnt = reinterpret_cast<int32_t *>(s_dyn + state_bytes);
+  uint32_t * s_bm = reinterpret_cast<uint32_t *>(s_cnt + tiles);
+  for (int i = tid; i < tiles; i += 1024) {s_cnt[i] = 0;}
+  for (int i = tid; i < bm_words; i += 1024) {s_bm[i] = 0u;}
+  const int4 * rec = reinterpret_cast<const int4 *>(cand);
+  if (job.n_foot > 0) {
+    int pr[kBinRegs];
+    int4 nbr[kBinRegs];
+#pragma unroll
+    for (int k = 0; k < kBinRegs; ++k) {
+      const int i = tid + 1024 * k;
+      pr[k] = -1; nbr[k] = make_int4(-1, -1, -1, -1);
+      if (i < n_cand) {pr[k] = rec[2 * (size_t)i].x; nbr[k] = rec[2 * (size_t)i + 1];}
+    }
+#pragma unroll
+    for (int k = 0; k < kBinRegs; ++k) {if (pr[k] >= 0) {state[pr[k]] = 0;}}
+    for (int i = tid + 1024 * kBinRegs; i < n_cand; i += 1024) {state[rec[2 * (size_t)i].x] = 0;}
+    __syncthreads();
+    // a candidate's fate is fixed once all its earlier neighbours are decided, decisions never change: whatever the order the
+    // lanes get to their candidates in, the fixpoint is the sequential answer
+    auto decide = [&](int p, const int4 nb) -> bool {             // true = still undecided
+      bool blocked = false, waiting = false;
+      const int n4[4] = {nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+      for (int f = 0; f < kMaxFootprint; ++f) {
+        if (n4[f] >= 0) {
+          const uint8_t st = state[n4[f]];
+          blocked = blocked || st == 1;
+          waiting = waiting || st == 0;
+        }
+      }
+      if (blocked) {state[p] = 2; return false;}
+      if (!waiting) {state[p] = 1; return false;}
+      return true;
+    };
+    uint32_t undecided = 0;
+#pragma unroll
+    for (int k = 0; k < kBinRegs; ++k) {if (pr[k] >= 0) {undecided |= 1u << k;}}
+    for (int sweep = 0; sweep <= n_cand; ++sweep) {
+      bool left = false;
+#pragma unroll
+      for (int k = 0; k < kBinRegs; ++k) {
+        if ((undecided >> k) & 1u) {
+          if (decide(pr[k], nbr[k])) {left = true;} else {undecided &= ~(1u << k);}
+        }
+      }
+      for (int i = tid + 1024 * kBinRegs; i < n_cand; i += 1024) {
+        const int p = rec[2 * (size_t)i].x;
+        if (state[p] == 0 && decide(p, rec[2 * (size_t)i + 1])) {left = true;}
+      }
+      if (!__syncthreads_or(left ? 1 : 0)) {break;}
+    }
+  }
+  __syncthreads();
+  const int hk = job.kernel_size / 2;
+  auto tile_of = [&](int cx, int cy, int q) -> int {
+    const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
+    const int ty0 = (cy - hk) / kRasterTile, ty1 = (cy + hk) / kRasterTile;
+    const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
+    return (tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
+  };
+  for (int i = tid; i < n_cand; i += 1024) {
+    const int4 a = rec[2 * (size_t)i];
+    const int p = a.x, cx = a.y, cy = a.z;
+    first[(size_t)(cy - job.roi_y) * job.roi_w + (cx - job.roi_x)] = kFirstNone;
+    const bool stamped = job.n_foot > 0 ? state[p] == 1 : true;
+    if (!stamped) {continue;}
+    cand[(size_t)kSeqCandWords * i + 3] = 1;
+    const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
+    const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
+    for (int by = fy0; by <= fy1; ++by) {
+      for (int bx = fx0; bx <= fx1; ++bx) {atomicOr(&s_bm[by * job.bm_w + (bx >> 5)], 1u << (bx & 31));}
+    }
+    int rk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = tile_of(cx, cy, q);
+      rk[q] = t >= 0 ? atomicAdd(&s_cnt[t], 1) : -1;
+    }
+    *reinterpret_cast<int4 *>(job.rank + 4 * (size_t)p) = make_int4(rk[0], rk[1], rk[2], rk[3]);
+  }
+  __syncthreads();
+  // list starts and the list of non-empty tiles: each thread a run of consecutive tiles
+  {
+    const int per = (tiles + 1023) / 1024;
+    const int lo = min(tiles, tid * per), hi = min(tiles, lo + per);
+    unsigned int sum = 0, nonempty = 0;
+    for (int t = lo; t < hi; ++t) {const int c = s_cnt[t]; sum += (unsigned int)c; nonempty += c > 0 ? 1u : 0u;}
+    unsigned long long total = 0;
+    const unsigned long long before = block_exscan_1024(((unsigned long long)nonempty << 32) | sum, s_w, total);
+    int run = (int)(before & 0xffffffffull), wpos = (int)(before >> 32);
+    for (int t = lo; t < hi; ++t) {
+      const int c = s_cnt[t];
+      if (c > 0) {
+        job.tile_start[t] = run; job.tile_count[t] = c;
+        job.work[wpos] = t;
+        if (keep_prev) {job.prev_work[4 + wpos] = t;}
+        ++wpos;
+      }
+      s_cnt[t] = run;
+      run += c;
+    }
+    if (tid == 0) {
+      job.n_work[0] = (int)(total >> 32);
+      if (keep_prev) {job.prev_work[0] = (int)(total >> 32);}
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n_cand; i += 1024) {
+    const int4 a = rec[2 * (size_t)i];
+    if (cand[(size_t)kSeqCandWords * i + 3] == 0) {continue;}
+    const int p = a.x, cx = a.y, cy = a.z;
+    const int4 r4 = *reinterpret_cast<const int4 *>(job.rank + 4 * (size_t)p);
+    const int rk[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = tile_of(cx, cy, q);
+      if (t >= 0) {job.list[s_cnt[t] + rk[q]] = p;}
+    }
+  }
+  for (int i = tid; i < bm_words; i += 1024) {job.blockmap[i] = s_bm[i];}
+}
+
+size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words)
+{
+  const size_t state_bytes = n_foot > 0 ? (((size_t)n_points + 15) & ~(size_t)15) : 0;
+  return state_bytes + 4 * (size_t)tiles + 4 * (size_t)bm_words + 16;
+}
+
+int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int device, void * stream)
+{
+  (void)device;
+  static std::atomic<unsigned long long> done{0};
+  allow_dynamic_lds(reinterpret_cast<const void *>(kseq_bin), 158 * 1024, done);
+  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, first, cand, ctl, (int)keep_prev);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kseq_stage: the host's tables (pinned, host-coherent) into device memory -- one read of each byte over the link instead of one
+// per workgroup that uses them -- and the sums volume / result block of the coarse pass zeroed.
+__global__ __launch_bounds__(256) void kseq_stage(const uint4 * __restrict__ src, uint4 * dst, int units, int32_t * sums, int n_sums,
+  unsigned long long * out, int out_words)
+{
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int i = tid; i < units; i += nth) {dst[i] = src[i];}
+  for (int i = tid; i < n_sums; i += nth) {sums[i] = 0;}
+  for (int i = tid; i < out_words; i += nth) {out[i] = 0ull;}
+}
+
+void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words,
+  void * stream)
+{
+  const int units = (int)((bytes + 15) / 16);
+  const int blocks = std::max(1, std::min(64, (int)((std::max<size_t>(units, n_sums) + 255) / 256)));
+  hipLaunchKernelGGL(kseq_stage, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4 *>(h_stage),
+    reinterpret_cast<uint4 *>(d_stage), units, sums, (int)n_sums, out, (int)out_words);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kseq_score: GridIndexLookup::ComputeOffsets (Karto.h:6844-6894) and GetResponse (Mapper.cpp:1172-1208) of one search whose
+// window is one scoring tile, in one launch.  Workgroup = (angle, slice of kSeqSlice beams); its four waves compute the slice's
+// table entries (bit-exact, as k_offsets: every wave for itself, 64 beams at a time, lane = beam), wave c then walks the
+// beams of alignment class c exactly as k_score does -- aligned dword loads of the window's rows, packed 16-bit sums -- and
+// the slice's sums are ADDED to the volume (integers: the order does not matter).  One job has 21 angles: with the beams of
+// an angle in one workgroup (K3) the search is 21 workgroups walking 270 beams per wave one after the other; cut into slices
+// it is 189 workgroups of 32.  Responses, best and ties follow in kseq_cells / kseq_final.
+template <int SX, int RY>
+__global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slices)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobp);
+  const int a = blockIdx.x / slices, sl = blockIdx.x - a * slices;
+  constexpr int PX = (SX == 1) ? kTileSpan : (kTileSpan + 1) / 2;
+  constexpr int TY = 4 * RY;
+  constexpr int NB = (SX == 1) ? 4 : 2;
+  constexpr int UB = (RY >= 7) ? 4 : 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lx = lane & 15, ly = lane >> 4;
+  __shared__ int32_t s_tile[TY * PX];
+  __shared__ int32_t s_list[4][64];
+  __shared__ int32_t s_slow[kSeqSlice];
+  __shared__ int32_t s_nslow;
+  for (int i = threadIdx.x; i < TY * PX; i += 256) {s_tile[i] = 0;}
+  if (threadIdx.x == 0) {s_nslow = 0;}
+  __syncthreads();
+  const int P = job.n_points;
+  const int b0 = sl * kSeqSlice, b1 = min(P, b0 + kSeqSlice);
+  const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
+  const int64_t bmin = job.base0;
+  const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
+  const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;
+  const int ws = job.ws;
+  const float inv_ws = 1.0f / (float)ws;
+  const int64_t data_size = job.data_size, pad = job.pad;
+  const uint32_t * const bmp = job.blockmap;
+  const int cls = wave & 3;
+  const int s = cls;                                         // byte of a class-c window's first dword that belongs to pose 0
+  const uint32_t sel = (s & 1) ? 0x0c030c01u : 0x0c020c00u;   // SX == 2: the even or the odd bytes
+  const gbyte * gbase = as_global(job.grid) + ((int64_t)job.base0 - s);
+  uint32_t voff[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    int yi = r * 4 + ly;
+    yi = yi < job.ny ? yi : job.ny - 1;                       // rows beyond ny are clamped (sums discarded)
+    voff[r] = (uint32_t)(4 * lx) + (uint32_t)yi * (uint32_t)job.sy_ws;
+  }
+  int32_t acc[RY][NB];
+  uint32_t lo[RY], hi[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    lo[r] = 0; hi[r] = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {acc[r][b] = 0;}
+  }
+  // (a slice is at most 128 beams x 100 per byte: the packed 16-bit sums cannot overflow, one flush at the end)
+  for (int base = b0; base < b1; base += 64) {
+    const int i = base + lane;
+    int32_t idx = kInvalidScan;
+    bool fast = false;
+    int mycls = 0;
+    if (i < b1) {
+      if (!job.invalid[i]) {
+        const double lxp = job.local[2 * i], lyp = job.local[2 * i + 1];
+        // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
+        const double ox = cosine * lxp - sine * lyp;
+        const double oy = sine * lxp + cosine * lyp;
+        const double gxd = ((ox + job.grid_off_x) - job.grid_off_x) * job.scale;
+        const double gyd = ((oy + job.grid_off_y) - job.grid_off_y) * job.scale;
+        const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
+        idx = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)ws);   // base Grid::GridIndex, no ROI
+      }
+      if (wave == 0) {job.table[(size_t)a * P + i] = idx;}
+      if (idx != kInvalidScan && !((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= data_size)) {
+        if ((int64_t)idx + bmin >= -pad && (int64_t)idx + bmax < data_size + pad) {
+          fast = true;
+          if (bmp) {
+            // a window none of whose 32 x 32 blocks was touched by a stamp adds 0 to every pose (as k_offsets)
+            const int32_t start = (int32_t)((int64_t)idx + bmin);
+            int32_t wy0 = (int32_t)((float)start * inv_ws);
+            int32_t wx0 = start - wy0 * ws;
+            while (wx0 < 0) {wx0 += ws; --wy0;}
+            while (wx0 >= ws) {wx0 -= ws; ++wy0;}
+            if (wx0 + xs <= ws && !window_has_blocks(bmp, job.bm_w, job.bm_h, wx0, wy0, wx0 + xs - 1, wy0 + ys - 1)) {fast = false;}
+          }
+          mycls = (int)(((int64_t)idx + bmin) & 3);
+        } else if (wave == 0) {
+          s_slow[atomicAdd(&s_nslow, 1)] = idx;               // needs the per-pose range check
+        }
+      }
+    }
+    const bool mine_here = fast && mycls == cls;
+    const unsigned long long mask = __ballot(mine_here);
+    const int cnt = __builtin_popcountll(mask);
+    if (mine_here) {s_list[wave][__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = idx;}
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes have landed (only it reads them)
+    __builtin_amdgcn_wave_barrier();
+    const int32_t mine = lane < cnt ? s_list[wave][lane] : 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    int k = 0;
+    for (; k + UB <= cnt; k += UB) {
+      uint32_t w[UB][RY];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const gbyte * wb = gbase + __builtin_amdgcn_readlane(mine, k + u);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {w[u][r] = *reinterpret_cast<const gu32 *>(wb + voff[r]);}
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+          if (SX == 1) {
+            lo[r] += w[u][r] & 0x00ff00ffu;                                // [0, b2, 0, b0]
+            hi[r] += __builtin_amdgcn_perm(0u, w[u][r], 0x0c030c01u);      // [0, b3, 0, b1]
+          } else {
+            lo[r] += __builtin_amdgcn_perm(0u, w[u][r], sel);
+          }
+        }
+      }
+    }
+    for (; k < cnt; ++k) {
+      const gbyte * wb = gbase + __builtin_amdgcn_readlane(mine, k);
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        const uint32_t w = *reinterpret_cast<const gu32 *>(wb + voff[r]);
+        if (SX == 1) {
+          lo[r] += w & 0x00ff00ffu;
+          hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);
+        } else {
+          lo[r] += __builtin_amdgcn_perm(0u, w, sel);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    if (SX == 1) {
+      acc[r][0] = lo[r] & 0xffffu; acc[r][2] = lo[r] >> 16;
+      acc[r][1] = hi[r] & 0xffffu; acc[r][3] = hi[r] >> 16;
+    } else {
+      acc[r][0] = lo[r] & 0xffffu; acc[r][1] = lo[r] >> 16;
+    }
+  }
+  // merge the four waves' partial sums: byte position j of the aligned tile row is pose (j - s) / SX
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int j = 4 * lx + ((SX == 1) ? b : 2 * b + (s & 1));
+      const int x = (j - s) / SX;
+      if (j >= s && x < PX && acc[r][b] != 0) {atomicAdd(&s_tile[(r * 4 + ly) * PX + x], acc[r][b]);}
+    }
+  }
+  __syncthreads();
+  const int n_slow = s_nslow;
+  const size_t plane = (size_t)job.nx * job.ny;
+  for (int p = threadIdx.x; p < TY * PX; p += 256) {
+    const int xi = p % PX, yi = p / PX;
+    if (xi >= job.nx || yi >= job.ny) {continue;}
+    int32_t sum = s_tile[p];
+    if (n_slow > 0) {
+      // per-pose range check exactly as GetResponse does it (Mapper.cpp:1192-1197)
+      const int64_t pose = (int64_t)job.bx[xi] + (int64_t)job.by[yi];
+      for (int j = 0; j < n_slow; ++j) {
+        const int64_t at = pose + s_slow[j];
+        if (at >= 0 && at < data_size) {sum += job.grid[at];}
+      }
+    }
+    if (sum != 0) {atomicAdd(&job.sums[(size_t)a * plane + (size_t)yi * job.nx + xi], sum);}
+  }
+}
+
+void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t sx, int32_t ry, void * stream)
+{
+  const int slices = (n_points + kSeqSlice - 1) / kSeqSlice;
+  const dim3 grid((unsigned int)(na * slices));
+  hipStream_t s = (hipStream_t)stream;
+#define KH_SEQ_SCORE(SXV, RYV) hipLaunchKernelGGL((kseq_score<SXV, RYV>), grid, dim3(256), 0, s, d_job, slices)
+  if (sx == 2) {
+    if (ry == 8) {KH_SEQ_SCORE(2, 8);} else if (ry == 7) {KH_SEQ_SCORE(2, 7);} else if (ry == 4) {KH_SEQ_SCORE(2, 4);} else {KH_SEQ_SCORE(2, 1);}
+  } else {
+    if (ry == 8) {KH_SEQ_SCORE(1, 8);} else if (ry == 7) {KH_SEQ_SCORE(1, 7);} else if (ry == 4) {KH_SEQ_SCORE(1, 4);} else {KH_SEQ_SCORE(1, 1);}
+  }
+#undef KH_SEQ_SCORE
+}
+
+// ---------------------------------------------------------------------------------------------
+// kseq_cells: the search-space probabilities (per-cell maxima, cell_maxima) into the device's result block and the host's, and
+// the best response of the search (Mapper.cpp:775-800): the largest cell maximum.
+__global__ __launch_bounds__(256) void kseq_cells(const uint8_t * jobp, unsigned long long * h_lattice)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobp);
+  double best = cell_maxima(job, (int)blockIdx.x, (int)gridDim.x, h_lattice);
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const double o = __shfl_xor(best, sft);
+      best = o > best ? o : best;
+    }
+    if (threadIdx.x == 0 && best > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(best));}
+  }
+}
+
+void launch_seq_cells(const uint8_t * d_job, int32_t plane, unsigned long long * h_lattice, void * stream)
+{
+  const int blocks = std::max(1, std::min(1024, (plane + 63) / 64));
+  hipLaunchKernelGGL(kseq_cells, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_job, h_lattice);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kseq_final, ONE workgroup.  (1) the poses within KT_TOLERANCE of the best (Mapper.cpp:802-817): only cells whose maximum ties
+// with the best can hold one.  (2) When the coarse pass has exactly ONE best pose -- the common case -- its average is that
+// pose: x and y are lattice values (centre + offset, the host's doubles), the heading atan2(sin h, cos h) comes from a table
+// the host made per search angle.  The fine pass around it (Mapper.cpp:621-629: 3 x 3 cells, naf angles) is then scored right
+// here: lattice indices by WorldToGrid's IEEE operations, the angles' cosines and sines from the host's table for coarse angle a
+// (no libm on the device), every lookup with GetResponse's range check, responses, best, ties.  The host checks the centre and
+// the lattice indices the device used against its own and redoes the fine pass itself if they differ or if the coarse pass had
+// several best poses (their mean needs atan2).  (3) Everything the host needs goes to host-coherent memory, then the flag.
+__global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
+{
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(A.job);
+  __shared__ int s_nt, s_fnt, s_a;
+  __shared__ uint32_t s_tie0;
+  __shared__ double s_centre[3];
+  __shared__ int32_t s_bx[4], s_by[4];
+  __shared__ int32_t s_fsum[kSeqMaxFine];
+  __shared__ unsigned long long s_fbest;
+  const int tid = threadIdx.x;
+  const int nx = job.nx, na = job.na;
+  const int plane = job.nx * job.ny;
+  const double best = __longlong_as_double((long long)job.out[0]);
+  const unsigned long long * lattice = job.out + kOutHeaderWords;
+  uint32_t * tie_idx = reinterpret_cast<uint32_t *>(job.out + 2);
+  uint32_t * h_tie = reinterpret_cast<uint32_t *>(A.h_out + 2);
+  if (tid == 0) {s_nt = 0; s_fnt = 0; s_fbest = 0ull; s_tie0 = 0u;}
+  for (int i = tid; i < kSeqMaxFine; i += 1024) {s_fsum[i] = 0;}
+  __syncthreads();
+  for (int cell = tid; cell < plane; cell += 1024) {
+    const double m = __longlong_as_double((long long)lattice[cell]);
+    const double dm = m - best;
+    if (!(dm < 0.0 ? dm >= -1e-06 : dm <= 1e-06)) {continue;}
+    const int yi = cell / nx, xi = cell - yi * nx;
+    for (int a = 0; a < na; ++a) {
+      const double response = pose_response(job, job.sums[(size_t)a * plane + cell], a, yi, xi);
+      const double delta = response - best;
+      if (delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06) {
+        const int slot = atomicAdd(&s_nt, 1);
+        const uint32_t idx = (uint32_t)(((size_t)yi * nx + xi) * na + a);
+        if (slot < kTieCap) {tie_idx[slot] = idx; h_tie[slot] = idx;}
+        if (slot == 0) {s_tie0 = idx;}
+      }
+    }
+  }
+  __syncthreads();
+  const int n_ties = s_nt;
+  if (tid == 0) {
+    job.out[1] = (unsigned long long)n_ties;
+    A.h_out[0] = job.out[0]; A.h_out[1] = (unsigned long long)n_ties;
+  }
+  const bool fine = A.refine != 0 && n_ties == 1;
+  if (fine && tid == 0) {
+    const uint32_t t = s_tie0;
+    const int a = (int)(t % (uint32_t)na);
+    const uint32_t xy = t / (uint32_t)na;
+    const int xi = (int)(xy % (uint32_t)nx), yi = (int)(xy / (uint32_t)nx);
+    // the mean of one pose, the way the host takes it (sum from zero, divided by the count)
+    double ax = 0.0, ay = 0.0;
+    ax += A.cx + A.xp[xi];
+    ay += A.cy + A.yp[yi];
+    const int32_t count = 1;
+    ax /= count; ay /= count;
+    s_centre[0] = ax; s_centre[1] = ay; s_centre[2] = A.heading[a];
+    s_a = a;
+    // lattice base indices of the fine search: operator()(y), Mapper.cpp:649-662
+    for (int k = 0; k < 3; ++k) {
+      const double newPositionX = ax + A.fxp[k];
+      const double gx = (newPositionX - job.grid_off_x) * job.scale;
+      s_bx[k] = d_to_int(d_round(gx)) + A.roi_x;
+      const double newPositionY = ay + A.fyp[k];
+      const double gy = (newPositionY - job.grid_off_y) * job.scale;
+      s_by[k] = (d_to_int(d_round(gy)) + A.roi_y) * job.ws;
+    }
+    A.h_fine->a = a; A.h_fine->xi = xi; A.h_fine->yi = yi;
+    for (int k = 0; k < 3; ++k) {A.h_fine->centre[k] = s_centre[k]; A.h_fine->bx[k] = s_bx[k]; A.h_fine->by[k] = s_by[k];}
+  }
+  __syncthreads();
+  if (fine) {
+    const int a = s_a, naf = A.naf, P = job.n_points;
+    const double * cs = A.fine_cos_sin + (size_t)a * naf * 2;
+    const int64_t data_size = job.data_size;
+    const int32_t bx0 = s_bx[0], bx1 = s_bx[1], bx2 = s_bx[2], by0 = s_by[0], by1 = s_by[1], by2 = s_by[2];
+    const int lane = tid & 63;
+    for (int k = 0; k < naf; ++k) {
+      const double cosine = cs[2 * k], sine = cs[2 * k + 1];
+      int32_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = tid; i < P; i += 1024) {
+        int32_t idx = kInvalidScan;
+        if (!job.invalid[i]) {
+          const double lxp = job.local[2 * i], lyp = job.local[2 * i + 1];
+          const double ox = cosine * lxp - sine * lyp;
+          const double oy = sine * lxp + cosine * lyp;
+          const double gxd = ((ox + job.grid_off_x) - job.grid_off_x) * job.scale;
+          const double gyd = ((oy + job.grid_off_y) - job.grid_off_y) * job.scale;
+          const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
+          idx = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)job.ws);
+        }
+        A.fine_table[(size_t)k * P + i] = idx;
+        if (idx == kInvalidScan) {continue;}                   // Mapper.cpp:1194
+        const int64_t row[3] = {(int64_t)by0 + idx, (int64_t)by1 + idx, (int64_t)by2 + idx};
+        const int32_t col[3] = {bx0, bx1, bx2};
+        uint8_t v[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const int64_t at = row[j / 3] + col[j % 3];
+          v[j] = (at >= 0 && at < data_size) ? job.grid[at] : (uint8_t)0;      // Mapper.cpp:1192-1197
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {acc[j] += v[j];}
+      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        int32_t x = acc[j];
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {x += __shfl_xor(x, sft);}
+        if (lane == 0 && x != 0) {atomicAdd(&s_fsum[k * 9 + j], x);}
+      }
+    }
+  }
+  __syncthreads();
+  double response = -1.0;
+  int fk = 0, fj = 0;
+  if (fine && tid < A.naf * 9) {
+    fk = tid / 9; fj = tid - 9 * fk;
+    const int32_t sum = s_fsum[tid];
+    A.fine_sums[tid] = sum;                                    // [a][y][x] with a 3 x 3 plane
+    A.h_fine->sums[tid] = sum;
+    response = (double)sum / job.denom;                        // Mapper.cpp:1204
+    if (A.fine_penalize) {
+      const double delta = response - 0.0;
+      const bool is_zero = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;
+      if (!is_zero) {response *= (A.fine_dist_pen[fj] * A.fine_ang_pen[(size_t)s_a * A.naf + fk]);}
+    }
+    atomicMax(&s_fbest, (unsigned long long)__double_as_longlong(response));
+  }
+  __syncthreads();
+  if (fine && tid < A.naf * 9) {
+    const double fbest = __longlong_as_double((long long)s_fbest);
+    const double delta = response - fbest;
+    if (delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06) {
+      const int slot = atomicAdd(&s_fnt, 1);
+      reinterpret_cast<uint32_t *>(A.h_fine->out + 2)[slot] = (uint32_t)(fj * A.naf + fk);      // (y * nx + x) * na + a
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (fine) {A.h_fine->out[0] = s_fbest; A.h_fine->out[1] = (unsigned long long)s_fnt;}
+    A.h_fine->valid = fine ? 1 : 0;
+    __threadfence_system();
+    __hip_atomic_store(A.h_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+void launch_seq_final(const SeqFinalArgs & args, void * stream)
+{
+  hipLaunchKernelGGL(kseq_final, dim3(1), dim3(1024), 0, (hipStream_t)stream, args);
+}
+
+}  // namespace kh

@@ -1,0 +1,94 @@
+// The fused path of ONE MatchScan (ScanMatcher::MatchScan, Mapper.cpp:534-639 -- the only way the reference's API is ever
+// called: Mapper.cpp:2714-2717, 1472, 1653).  Kernel argument blocks shared by matcher_seq.cpp (host) and matcher_seq.hip.
+//
+// The general path (matcher_host.cpp) is built for batches: per stage one launch over all jobs, descriptors uploaded, results
+// downloaded, the host between the coarse and the fine pass.  One job through it is 19 launches, three copies, two stream
+// waits and 0.41 ms, every kernel a chain of dependent memory round trips on a nearly empty chip.  Here the same arithmetic
+// (bit for bit: tests/test_seq_gpu.py) is laid out for one job:
+//
+//   kseq_prep    FindValidPoints per scan (1024 threads per scan), the kept readings' grid cells, the FIRST point of every cell
+//                (atomicMin into a per-slot table over the region of interest: no hash table, no probing), Grid::Clear of
+//                the tiles the previous match wrote -- descriptors arrive as kernel arguments, nothing is uploaded
+//   kseq_links   per first point the first points of the cells in its 100-footprint (four independent loads)
+//   kseq_bin     ONE workgroup: the order-dependent "cell already 100" rule as a fixpoint over state bytes in LDS, then tile
+//                counts, list starts and lists with LDS counters only (the batch path: five launches, global atomics)
+//   k_raster_tile(_reg), k_repitch*   as in the batch path
+//   kseq_stage   the host's exact tables (computed while the kernels above run) into device memory, volume and result zeroed
+//   kseq_score   lookup table + scoring in one launch (K2 + K3), the beams of an angle cut into slices of 128 (9 x as many
+//                workgroups as K3 has for one job), sums added to the volume
+//   kseq_cells   per-cell maxima (the search-space probabilities) and the best response
+//   kseq_final   ONE workgroup: ties; when the coarse pass has exactly one best pose, the fine pass around it (centre from
+//                host-made tables indexed by the coarse angle: no libm on the device) scored and finalised in place; results
+//                into host-coherent memory, then a flag the host polls -- no host round trip between coarse and fine, no copies
+#pragma once
+#include <cstdint>
+#include "kh_internal.hpp"
+
+namespace kh
+{
+
+constexpr int32_t kSeqMaxScans = 48;       // base scans of one match (pointers travel as kernel arguments)
+constexpr int32_t kSeqMaxReadings = 2048;  // readings per scan (k_find_valid_par's LDS working set)
+constexpr int32_t kSeqMaxPoints = 65536;   // job points: one state byte each in LDS
+constexpr int32_t kSeqMaxTiles = 16384;    // rasteriser tiles: one counter each in LDS
+constexpr int32_t kSeqMaxFine = 1024;      // poses of the fine volume
+constexpr int32_t kSeqCandWords = 8;       // int32 per stamp candidate: point, cx, cy, selected | four neighbour points
+constexpr int32_t kFirstNone = INT32_MAX;
+constexpr int32_t kSeqSlice = 128;         // beams per workgroup of kseq_score
+constexpr int32_t kSeqCtlWords = 16;
+
+struct SeqPrepArgs
+{
+  RasterJob job;                           // (scan_ptr / scan_prefix unused: the arrays below)
+  const double * scans[kSeqMaxScans];
+  int32_t prefix[kSeqMaxScans + 1];
+  int32_t n_scans, max_n;
+  RasterJob * d_job;                       // device copy for the launches that follow
+  int32_t * first;                         // roi_w * roi_h: smallest job point in the cell, kFirstNone = none (left clean by kseq_bin)
+  int32_t * ctl;                           // [0] candidates (zeroed here)
+  int32_t clear_blocks;
+};
+
+// fine pass of the device (results in host-coherent memory)
+struct SeqFineOut
+{
+  int32_t valid;                           // 1 = the device ran the fine pass
+  int32_t a, xi, yi;                       // the coarse pass's single best pose
+  double centre[3];                        // what the device took as the fine search's centre -- the host checks it against its own
+  int32_t bx[4], by[4];                    // ... and the lattice indices it derived
+  unsigned long long out[2 + kSeqMaxFine / 2];   // best bits | ties | tie indices (uint32), as in a result block
+  int32_t sums[kSeqMaxFine];               // [a][y][x]
+};
+
+struct SeqFinalArgs
+{
+  const uint8_t * job;                     // coarse job (device staging block)
+  unsigned long long * h_out;              // host-coherent result block of the coarse pass (lattice part written by kseq_cells)
+  SeqFineOut * h_fine;
+  int32_t * h_flag; int32_t seq;           // published last, system scope
+  int32_t refine, naf, fine_penalize;
+  double cx, cy;                           // centre of the coarse search
+  const double * xp, * yp;                 // coarse x_poses [nx], y_poses [ny]
+  const double * heading;                  // [na]: atan2(sin h, cos h), h = NormalizeAngle(angle a) -- the mean of ONE pose
+  const double * fine_cos_sin;             // [na][naf][2]: the fine search's angles around heading[a]
+  const double * fine_ang_pen;             // [na][naf]
+  const double * fine_dist_pen;            // [9]
+  double fxp[3], fyp[3];                   // fine lattice offsets
+  int32_t roi_x, roi_y;
+  int32_t * fine_table; int32_t * fine_sums;   // the slot's table / volume (introspection reads the last search)
+};
+
+void launch_seq_prep(const SeqPrepArgs & args, void * stream);
+void launch_seq_links(const RasterJob * d_job, int32_t n_points, const int32_t * first, int32_t * cand, int32_t * ctl, void * stream);
+// dynamic LDS of kseq_bin for a job (the host checks it against the device's limit)
+size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words);
+int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int device, void * stream);
+void launch_raster_tiles(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
+  void * stream);
+void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words,
+  void * stream);
+void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t sx, int32_t ry, void * stream);
+void launch_seq_cells(const uint8_t * d_job, int32_t plane, unsigned long long * h_lattice, void * stream);
+void launch_seq_final(const SeqFinalArgs & args, void * stream);
+
+}  // namespace kh

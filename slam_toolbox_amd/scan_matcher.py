@@ -63,8 +63,11 @@ class LocalizedRangeScan:
         self.SetSensorPose(sensor_pose)
 
     _resident = None
+    _c_points = None
+    _c = None          # the kh_scan view of this scan, rebuilt after Update() / MakeResident (building one costs more than a match's launch)
 
     def SetSensorPose(self, pose):
+        self._c = None
         self.sensor_pose = _d(pose).copy()
         self.points = np.zeros((self.ranges.shape[0], 2))
         capi.check(capi.lib().kh_scan_points(self.ranges, self.ranges.shape[0], self.sensor_pose, self.min_angle,
@@ -79,6 +82,7 @@ class LocalizedRangeScan:
         if self._resident is None and self.points.size > 0:
             self._resident = DeviceBuffer(self.points.size, device)
             self._resident.upload(self.points)
+            self._c = None
         return self
 
     def GetSensorPose(self):
@@ -88,6 +92,8 @@ class LocalizedRangeScan:
         return self.ranges.shape[0]
 
     def c(self) -> capi.KhScan:
+        if self._c is not None and self._c_points is self.points:
+            return self._c
         s = capi.KhScan()
         s.n = self.ranges.shape[0]
         s.ranges = self.ranges.ctypes.data_as(C.POINTER(C.c_double))
@@ -95,6 +101,7 @@ class LocalizedRangeScan:
         for i in range(3):
             s.sensor_pose[i] = self.sensor_pose[i]
         s.device_points_xy = self._resident.ptr if self._resident is not None else None
+        self._c, self._c_points = s, self.points
         return s
 
 
@@ -254,13 +261,14 @@ class ScanMatcher:
 
     def set_debug(self, keep_response_volume: bool, lds_score: bool = False, dense_score: bool = False,
                   force_chunks: bool = False, no_dual_copy: bool = False, mfma_score: bool = False,
-                  windowed_score: bool = False):
+                  windowed_score: bool = False, no_fused_match: bool = False):
         """lds_score: the LDS-staged scoring kernels for every search they can take (default: the large ones only);
-        windowed_score: for none (the windowed kernel scores everything)."""
+        windowed_score: for none (the windowed kernel scores everything); no_fused_match: MatchScan takes the general
+        (batch) path instead of the fused path of one match."""
         capi.check(capi.lib().kh_matcher_set_debug(self._h, int(bool(keep_response_volume)) | (2 if lds_score else 0) |
                                                    (4 if dense_score else 0) | (8 if force_chunks else 0) |
                                                    (16 if no_dual_copy else 0) | (32 if mfma_score else 0) |
-                                                   (64 if windowed_score else 0)),
+                                                   (64 if windowed_score else 0) | (128 if no_fused_match else 0)),
                    "kh_matcher_set_debug")
 
     def volume(self, slot=0, responses=True):
@@ -274,6 +282,13 @@ class ScanMatcher:
                                                      resp.ctypes.data_as(C.c_void_p) if responses else None),
                    "read_volume")
         return sums, resp
+
+    def seq_stats(self):
+        """counters of the fused path of ONE MatchScan (kh_matcher_seq_stats)"""
+        out = (C.c_int64 * 8)()
+        capi.check(capi.lib().kh_matcher_seq_stats(self._h, out), "kh_matcher_seq_stats")
+        keys = ("calls", "fine_on_device", "fine_fallbacks", "fine_mismatches", "coarse_fallbacks", "fused_score")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def stream(self):
         return capi.lib().kh_matcher_stream(self._h)
