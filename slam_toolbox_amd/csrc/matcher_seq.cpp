@@ -24,6 +24,10 @@ struct SeqState
   SeqFineOut * h_fine = nullptr;
   int32_t * h_flag = nullptr;
   int32_t seq = 0;
+  uint8_t * d_tab = nullptr;              // padded image of the smear kernel for kseq_tile
+  int32_t * d_work2 = nullptr; size_t cap_work2 = 0;
+  long long * d_dbg = nullptr;            // KH_SEQ_TIMING=1: phase stamps of kseq_bin [0..15] and kseq_final [16..31]
+  double dbg_acc[32] = {0}; long dbg_calls = 0;
   std::vector<uint8_t> fine_scratch;
   int64_t stats[kSeqStatWords] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -41,7 +45,7 @@ void seq_destroy(kh_matcher * m)
 {
   SeqState * q = m->seq;
   if (!q) {return;}
-  (void)hipFree(q->d_first); (void)hipFree(q->d_cand); (void)hipFree(q->d_ctl); (void)hipFree(q->d_job); (void)hipFree(q->d_stage); (void)hipFree(q->d_out);
+  (void)hipFree(q->d_dbg); (void)hipFree(q->d_tab); (void)hipFree(q->d_work2); (void)hipFree(q->d_first); (void)hipFree(q->d_cand); (void)hipFree(q->d_ctl); (void)hipFree(q->d_job); (void)hipFree(q->d_stage); (void)hipFree(q->d_out);
   if (q->h_stage) {(void)hipHostFree(q->h_stage);}
   if (q->h_out) {(void)hipHostFree(q->h_out);}
   if (q->h_fine) {(void)hipHostFree(q->h_fine);}
@@ -125,6 +129,20 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     one = 0;
     rc = ensure_coherent(Q.h_flag, one, 16); if (rc) {return rc;}
     Q.h_flag[0] = 0;
+    if (std::getenv("KH_SEQ_TIMING")) {
+      KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_dbg), sizeof(long long) * 32));
+      KS_HIP(hipMemset(Q.d_dbg, 0, sizeof(long long) * 32));
+    }
+  }
+  const bool fused_tiles = m->kernel_size >= 8;
+  if (fused_tiles) {
+    rc = ensure_device(Q.d_work2, Q.cap_work2, 4 * static_cast<size_t>(tiles), st); if (rc) {return rc;}
+    if (!Q.d_tab) {
+      std::vector<uint8_t> tab(seq_tile_table_bytes());
+      seq_tile_table(m->kernel.data(), m->kernel_size, tab.data());
+      KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_tab), tab.size()));
+      KS_HIP(hipMemcpy(Q.d_tab, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    }
   }
   const size_t roi_cells = static_cast<size_t>(m->roi_w) * m->roi_h;
   if (roi_cells > Q.cap_first) {
@@ -178,14 +196,12 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     for (int32_t r = k; r < kSeqMaxScans; ++r) {pa.scans[r] = nullptr; pa.prefix[r + 1] = run;}
   }
   pa.n_scans = n_scans; pa.max_n = max_n;
-  pa.d_job = Q.d_job; pa.first = Q.d_first; pa.ctl = Q.d_ctl; pa.clear_blocks = 48;
+  pa.d_job = Q.d_job; pa.first = Q.d_first; pa.ctl = Q.d_ctl; pa.clear_blocks = 128;     // 2048 waves: one tile of the previous match each
   Q.first_clean = false;                                  // until kseq_bin has run (an error in between leaves marks behind)
   launch_seq_prep(pa, st);
   launch_seq_links(Q.d_job, np, Q.d_first, Q.d_cand, Q.d_ctl, st);
   const bool has_copies = s.d_grid2 != nullptr;
-  launch_seq_bin(Q.d_job, Q.d_first, Q.d_cand, Q.d_ctl, has_copies ? 0 : 1, bin_lds, m->device, st);
-  launch_raster_tiles(Q.d_job, 1, np, tiles, m->d_kernel, m->kernel_size, st);
-  if (has_copies) {launch_repitch(Q.d_job, 1, tiles, st, true);}
+  launch_seq_bin(Q.d_job, Q.d_first, Q.d_cand, Q.d_ctl, has_copies ? 0 : 1, bin_lds, fused_tiles ? Q.d_work2 : nullptr, Q.d_dbg, st);
   KS_HIP(hipGetLastError());
   Q.first_clean = true;
 
@@ -271,9 +287,15 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
       }
     }
   }
-  // ---- 3. tables to the device, scoring, finalisation on the device
+  // ---- 3. the stamps (with the tables' way to the device in the same launch), scoring, finalisation on the device
   const size_t plane = static_cast<size_t>(c.nx) * c.ny;
-  launch_seq_stage(Q.h_stage, Q.d_stage, X.total, s.d_sums, plane * c.na, Q.d_out, out_words, st);
+  if (fused_tiles) {
+    launch_seq_tile(Q.d_job, Q.d_tab, Q.d_work2, np, tiles, Q.h_stage, Q.d_stage, X.total, s.d_sums, plane * c.na, Q.d_out, out_words, st);
+  } else {
+    launch_raster_tiles(Q.d_job, 1, np, tiles, m->d_kernel, m->kernel_size, st);
+    launch_seq_stage(Q.h_stage, Q.d_stage, X.total, s.d_sums, plane * c.na, Q.d_out, out_words, st);
+  }
+  if (s.d_grid2 != nullptr) {launch_repitch(Q.d_job, 1, tiles, st, true);}
   const bool fused_score = job->linear != 0 && shape.tiles == 1 && job->dec == 0 && job->lds_path == 0;
   if (fused_score) {
     launch_seq_score(Q.d_stage, c.na, c.P, shape.sx, shape.ry, st);
@@ -298,6 +320,7 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   for (int32_t k = 0; k < 3; ++k) {fa.fxp[k] = device_fine ? cf.x_poses[k] : 0.0; fa.fyp[k] = device_fine ? cf.y_poses[k] : 0.0;}
   fa.roi_x = m->roi_x; fa.roi_y = m->roi_y;
   fa.fine_table = s.d_table; fa.fine_sums = s.d_sums;
+  fa.dbg = Q.d_dbg ? Q.d_dbg + 16 : nullptr;
   launch_seq_final(fa, st);
   KS_HIP(hipGetLastError());
   Q.stats[kSeqStatCalls] += 1;
@@ -316,6 +339,22 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
         }
         if (e != hipErrorNotReady) {set_error(std::string("fused MatchScan: ") + hipGetErrorString(e)); return KH_ERR_HIP;}
       }
+    }
+  }
+  if (Q.d_dbg) {
+    // measurement aid: where kseq_bin and kseq_final spend their time (wall_clock64 = 100 MHz), averaged over 64 calls
+    long long w[32];
+    KS_HIP(hipStreamSynchronize(st));
+    KS_HIP(hipMemcpy(w, Q.d_dbg, sizeof(w), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) {Q.dbg_acc[1 + k] += (w[k + 1] - w[k]) * 0.01;}
+    Q.dbg_acc[5] += static_cast<double>(w[5]);
+    for (int k = 0; k < 4; ++k) {Q.dbg_acc[16 + k] += (w[16 + k + 1] - w[16 + k]) * 0.01;}
+    if (++Q.dbg_calls % 64 == 0) {
+      const double n = 64.0;
+      std::fprintf(stderr, "[kh seq] kseq_bin us: active set %.1f  count %.1f  scan %.1f  fill %.1f  (candidates %.0f);  kseq_final us: ties %.1f  "
+        "centre %.1f  fine scoring %.1f  finish %.1f\n", Q.dbg_acc[1] / n, Q.dbg_acc[2] / n, Q.dbg_acc[3] / n, Q.dbg_acc[4] / n, Q.dbg_acc[5] / n,
+        Q.dbg_acc[16] / n, Q.dbg_acc[17] / n, Q.dbg_acc[18] / n, Q.dbg_acc[19] / n);
+      for (double & v : Q.dbg_acc) {v = 0.0;}
     }
   }
   // ---- 5. finalisation of the coarse pass (tie average, positional covariance: exact host arithmetic)

@@ -44,16 +44,22 @@ __global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
     }
     return;
   }
-  const int c = b - args.n_scans, nc = args.clear_blocks;
+  // Grid::Clear: one WAVE per tile the previous match wrote (lane = tile row, 64 bytes each) -- a workgroup walking its tiles one
+  // after the other waited a memory latency per tile for the tile's index (21 of this kernel's first 21 us)
+  const int c = b - args.n_scans;
   {
     const int n_prev = job.prev_work[0];
-    for (int w = c; w < n_prev; w += nc) {
+    const int waves = args.clear_blocks * 16;
+    const int lane = threadIdx.x & 63;
+    for (int w = c * 16 + (int)(threadIdx.x >> 6); w < n_prev; w += waves) {
       const int t = job.prev_work[4 + w];
       const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
-      // 64 rows x 64 bytes: 1024 threads x 4 bytes (ws is a multiple of 8, the tile starts on a multiple of 64)
-      const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
-      const int y = ty * kRasterTile + row, x = tx * kRasterTile + 4 * part;
-      if (y < job.height && x < job.ws) {*reinterpret_cast<uint32_t *>(job.grid + (size_t)y * job.ws + x) = 0u;}
+      const int y = ty * kRasterTile + lane, x = tx * kRasterTile;
+      if (y < job.height) {
+        uint8_t * at = job.grid + (size_t)y * job.ws + x;           // ws is a multiple of 8, the tile starts on a multiple of 64
+        const int nb = min(kRasterTile, job.ws - x);
+        for (int i = 0; i < nb; i += 8) {*reinterpret_cast<uint2 *>(at + i) = make_uint2(0u, 0u);}
+      }
     }
   }
   if (c == 0) {
@@ -163,13 +169,27 @@ __device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long lo
 //     "previous" list Grid::Clear of the next match zeroes); the lists are written from the ranks.
 //  3. first[] goes back to "none" for the cells this match touched (every touched cell has exactly one candidate).
 constexpr int kBinRegs = 8;
-__global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t * first, int32_t * cand, const int32_t * ctl, int keep_prev)
+__global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t * __restrict__ first, int32_t * cand, const int32_t * ctl, int keep_prev,
+  int4 * work2, long long * dbg)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   __shared__ unsigned long long s_w[16];
-  const RasterJob & job = *jobp;
+  // everything the kernel reads from the job, once: behind a store the compiler has to assume the job block itself changed and
+  // re-reads every field through the scalar cache -- a wait per field and loop trip
+  struct {int n_points, n_foot, tiles_w, tiles_h, bm_w, bm_h, roi_x, roi_y, roi_w, kernel_size;
+          int32_t * rank, * list, * tile_start, * tile_count, * work, * prev_work, * n_work; uint32_t * blockmap;} job;
+  {
+    const RasterJob & j = *jobp;
+    job.n_points = j.n_points; job.n_foot = j.n_foot; job.tiles_w = j.tiles_w; job.tiles_h = j.tiles_h; job.bm_w = j.bm_w; job.bm_h = j.bm_h;
+    job.roi_x = j.roi_x; job.roi_y = j.roi_y; job.roi_w = j.roi_w; job.kernel_size = j.kernel_size;
+    job.rank = j.rank; job.list = j.list; job.tile_start = j.tile_start; job.tile_count = j.tile_count; job.work = j.work;
+    job.prev_work = j.prev_work; job.n_work = j.n_work; job.blockmap = j.blockmap;
+  }
   const int tid = threadIdx.x;
   const int n_cand = ctl[0];
+  int stamp = 0;
+  auto phase = [&]() {if (dbg && tid == 0) {dbg[stamp] = (long long)wall_clock64();} ++stamp;};
+  phase();
   const int tiles = job.tiles_w * job.tiles_h, bm_words = job.bm_w * job.bm_h;
   const int state_bytes = job.n_foot > 0 ? ((job.n_points + 15) & ~15) : 0;
   uint8_t * state = s_dyn;
@@ -227,6 +247,7 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
     }
   }
   __syncthreads();
+  phase();
   const int hk = job.kernel_size / 2;
   auto tile_of = [&](int cx, int cy, int q) -> int {
     const int tx0 = (cx - hk) / kRasterTile, tx1 = (cx + hk) / kRasterTile;
@@ -255,6 +276,7 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
     *reinterpret_cast<int4 *>(job.rank + 4 * (size_t)p) = make_int4(rk[0], rk[1], rk[2], rk[3]);
   }
   __syncthreads();
+  phase();
   // list starts and the list of non-empty tiles: each thread a run of consecutive tiles
   {
     const int per = (tiles + 1023) / 1024;
@@ -269,6 +291,7 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
       if (c > 0) {
         job.tile_start[t] = run; job.tile_count[t] = c;
         job.work[wpos] = t;
+        if (work2) {work2[wpos] = make_int4(t, run, c, 0);}         // kseq_tile: tile, list start, count in ONE load
         if (keep_prev) {job.prev_work[4 + wpos] = t;}
         ++wpos;
       }
@@ -281,6 +304,7 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
     }
   }
   __syncthreads();
+  phase();
   for (int i = tid; i < n_cand; i += 1024) {
     const int4 a = rec[2 * (size_t)i];
     if (cand[(size_t)kSeqCandWords * i + 3] == 0) {continue;}
@@ -290,10 +314,12 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int t = tile_of(cx, cy, q);
-      if (t >= 0) {job.list[s_cnt[t] + rk[q]] = p;}
+      if (t >= 0) {job.list[s_cnt[t] + rk[q]] = work2 ? (cx | (cy << 16)) : p;}    // kseq_tile reads the cell from the entry itself
     }
   }
   for (int i = tid; i < bm_words; i += 1024) {job.blockmap[i] = s_bm[i];}
+  phase();
+  if (dbg && tid == 0) {dbg[stamp] = n_cand;}
 }
 
 size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words)
@@ -302,34 +328,132 @@ size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_
   return state_bytes + 4 * (size_t)tiles + 4 * (size_t)bm_words + 16;
 }
 
-int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int device, void * stream)
+int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
+  void * stream)
 {
-  (void)device;
   static std::atomic<unsigned long long> done{0};
   allow_dynamic_lds(reinterpret_cast<const void *>(kseq_bin), 158 * 1024, done);
-  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, first, cand, ctl, (int)keep_prev);
+  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, first, cand, ctl, (int)keep_prev, reinterpret_cast<int4 *>(work2), dbg);
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// kseq_stage: the host's tables (pinned, host-coherent) into device memory -- one read of each byte over the link instead of one
-// per workgroup that uses them -- and the sums volume / result block of the coarse pass zeroed.
-__global__ __launch_bounds__(256) void kseq_stage(const uint4 * __restrict__ src, uint4 * dst, int units, int32_t * sums, int n_sums,
-  unsigned long long * out, int out_words)
+// The host's tables (pinned, host-coherent) into device memory -- one read of each byte over the link instead of one per
+// workgroup that uses them -- and the sums volume / result block of the coarse pass zeroed.  Runs as the last workgroups of the
+// stamping launch (the host makes the tables while kseq_prep .. kseq_bin run, and nothing reads them before kseq_score), or
+// as a launch of its own in front of the batch path's stamping kernel.
+struct SeqStage {const uint4 * src; uint4 * dst; int units; int32_t * sums; int n_sums; unsigned long long * out; int out_words;};
+__device__ __forceinline__ void stage_copy(const SeqStage & g, int tid, int nth)
 {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-  for (int i = tid; i < units; i += nth) {dst[i] = src[i];}
-  for (int i = tid; i < n_sums; i += nth) {sums[i] = 0;}
-  for (int i = tid; i < out_words; i += nth) {out[i] = 0ull;}
+  for (int i = tid; i < g.units; i += nth) {g.dst[i] = g.src[i];}
+  for (int i = tid; i < g.n_sums; i += nth) {g.sums[i] = 0;}
+  for (int i = tid; i < g.out_words; i += nth) {g.out[i] = 0ull;}
+}
+__global__ __launch_bounds__(256) void kseq_stage(const SeqStage g)
+{
+  stage_copy(g, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// kseq_tile: SmearPoint (Mapper.h:1152-1183) of one job's stamped points, tile by tile, for smear kernels of 8 x 8 .. 41 x 41
+// cells -- k_raster_tile_reg laid out for latency: eight waves per tile (8 tile rows each: twice the waves per point list), a
+// point's eight row values read without a test (the kernel table has 15 zero rows above and below: a footprint that overlaps
+// the wave's band at all stays inside it), the table copied from a ready-made image instead of built per workgroup, and the
+// dependent loads in front of the first stamp cut from five to two: (tile, list start, count) in one record, the cell in the
+// list entry itself.
+constexpr int kTabPitch = 192;               // 64 zeros | <= 41 values | zeros: index 64 + lane - fx is in [1, 167]
+constexpr int kTabGuard = 15;                // zero rows above and below
+constexpr int kTabRows = 41 + 2 * kTabGuard;
+constexpr int kTileStageBlocks = 16;
+__global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobp, const uint4 * __restrict__ tab, const int4 * __restrict__ work2, int tile_blocks,
+  const SeqStage stage)
+{
+  if ((int)blockIdx.x >= tile_blocks) {
+    stage_copy(stage, ((int)blockIdx.x - tile_blocks) * 512 + (int)threadIdx.x, ((int)gridDim.x - tile_blocks) * 512);
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) uint8_t s_tab[kTabRows * kTabPitch];
+  __shared__ int32_t s_pxy[512];
+  const RasterJob & job = *jobp;
+  const int n_work = job.n_work[0];
+  if ((int)blockIdx.x >= n_work) {return;}
+  const int k = job.kernel_size, hk = k / 2, ws = job.ws, height = job.height, tiles_w = job.tiles_w;
+  uint8_t * const grid = job.grid;
+  const int32_t * const list = job.list;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kTabRows * kTabPitch / 16; i += 512) {reinterpret_cast<uint4 *>(s_tab)[i] = tab[i];}
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int band = 8 * wave;                   // first tile row of this wave
+  for (int w = blockIdx.x; w < n_work; w += tile_blocks) {
+    const int4 wk = work2[w];
+    const int t = wk.x, begin = wk.y, count = wk.z;
+    const int ty = t / tiles_w, tx = t - ty * tiles_w;
+    const int ox = tx * kRasterTile, oy = ty * kRasterTile;       // grid cell of the tile's corner
+    uint32_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {acc[j] = 0u;}
+    for (int chunk = 0; chunk < count; chunk += 512) {
+      const int here = min(512, count - chunk);
+      __syncthreads();                                            // table complete / previous chunk consumed
+      if (tid < here) {s_pxy[tid] = list[begin + chunk + tid];}
+      __syncthreads();
+      for (int q0 = 0; q0 < here; q0 += 64) {
+        const int cnt = min(64, here - q0);
+        const int pk = s_pxy[q0 + lane];                          // (entries beyond `here` are stale: not read out below)
+        for (int q = 0; q < cnt; ++q) {
+          const int v = __builtin_amdgcn_readlane(pk, q);
+          const int fx = (v & 0xffff) - hk - ox, fy = (v >> 16) - hk - oy;      // footprint corner relative to the tile
+          const int d = fy - band;                                // footprint row of tile row band + j: j - d
+          if (d > 7 || d + k <= 0) {continue;}                    // the footprint misses this wave's eight rows
+          const uint8_t * row0 = s_tab + (kTabGuard - d) * kTabPitch + 64 - fx + lane;
+          uint32_t r[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {r[j] = row0[j * kTabPitch];}
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {acc[j] = max(acc[j], r[j]);}
+        }
+      }
+    }
+    // write the band: 8 rows x 64 bytes, lane = column (clipped to the grid)
+    const int x = ox + lane;
+    if (x < ws) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int y = oy + band + j;
+        if (y < height) {grid[(size_t)y * ws + x] = (uint8_t)acc[j];}
+      }
+    }
+  }
 }
 
 void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words,
   void * stream)
 {
-  const int units = (int)((bytes + 15) / 16);
-  const int blocks = std::max(1, std::min(64, (int)((std::max<size_t>(units, n_sums) + 255) / 256)));
-  hipLaunchKernelGGL(kseq_stage, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4 *>(h_stage),
-    reinterpret_cast<uint4 *>(d_stage), units, sums, (int)n_sums, out, (int)out_words);
+  SeqStage g;
+  g.src = reinterpret_cast<const uint4 *>(h_stage); g.dst = reinterpret_cast<uint4 *>(d_stage); g.units = (int)((bytes + 15) / 16);
+  g.sums = sums; g.n_sums = (int)n_sums; g.out = out; g.out_words = (int)out_words;
+  const int blocks = std::max(1, std::min(64, (int)((std::max<size_t>(g.units, n_sums) + 255) / 256)));
+  hipLaunchKernelGGL(kseq_stage, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+}
+
+// the padded image of the smear kernel kseq_tile copies into LDS (host memory, kTabRows x kTabPitch bytes)
+size_t seq_tile_table_bytes() {return (size_t)kTabRows * kTabPitch;}
+void seq_tile_table(const uint8_t * kernel, int32_t kernel_size, uint8_t * out)
+{
+  std::fill(out, out + seq_tile_table_bytes(), (uint8_t)0);
+  for (int row = 0; row < kernel_size; ++row) {
+    for (int col = 0; col < kernel_size; ++col) {out[(kTabGuard + row) * kTabPitch + 64 + col] = kernel[row * kernel_size + col];}
+  }
+}
+
+void launch_seq_tile(const RasterJob * d_job, const uint8_t * d_tab, const int32_t * d_work2, int32_t max_points, int32_t max_tiles,
+  const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words, void * stream)
+{
+  SeqStage g;
+  g.src = reinterpret_cast<const uint4 *>(h_stage); g.dst = reinterpret_cast<uint4 *>(d_stage); g.units = (int)((bytes + 15) / 16);
+  g.sums = sums; g.n_sums = (int)n_sums; g.out = out; g.out_words = (int)out_words;
+  const int tile_blocks = std::max(1, std::min(std::min(max_tiles, 4 * max_points), 1024));
+  hipLaunchKernelGGL(kseq_tile, dim3(tile_blocks + kTileStageBlocks), dim3(512), 0, (hipStream_t)stream, d_job, reinterpret_cast<const uint4 *>(d_tab),
+    reinterpret_cast<const int4 *>(d_work2), tile_blocks, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,7 +463,7 @@ void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_
 // beams of alignment class c exactly as k_score does -- aligned dword loads of the window's rows, packed 16-bit sums -- and
 // the slice's sums are ADDED to the volume (integers: the order does not matter).  One job has 21 angles: with the beams of
 // an angle in one workgroup (K3) the search is 21 workgroups walking 270 beams per wave one after the other; cut into slices
-// it is 189 workgroups of 32.  Responses, best and ties follow in kseq_cells / kseq_final.
+// it is 357 workgroups of 16 per wave, eight beams' rows in flight.  Responses, best and ties follow in kseq_cells / kseq_final.
 template <int SX, int RY>
 __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slices)
 {
@@ -348,7 +472,7 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
   constexpr int PX = (SX == 1) ? kTileSpan : (kTileSpan + 1) / 2;
   constexpr int TY = 4 * RY;
   constexpr int NB = (SX == 1) ? 4 : 2;
-  constexpr int UB = (RY >= 7) ? 4 : 8;
+  constexpr int UB = 8;                    // beams (UB * RY row loads) in flight per wave
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lx = lane & 15, ly = lane >> 4;
@@ -388,7 +512,7 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
 #pragma unroll
     for (int b = 0; b < NB; ++b) {acc[r][b] = 0;}
   }
-  // (a slice is at most 128 beams x 100 per byte: the packed 16-bit sums cannot overflow, one flush at the end)
+  // (a slice is at most kSeqSlice = 64 beams x 100 per byte: the packed 16-bit sums cannot overflow, one flush at the end)
   for (int base = b0; base < b1; base += 64) {
     const int i = base + lane;
     int32_t idx = kInvalidScan;
@@ -545,156 +669,217 @@ void launch_seq_cells(const uint8_t * d_job, int32_t plane, unsigned long long *
 }
 
 // ---------------------------------------------------------------------------------------------
+// inclusive prefix sum over the lanes of a wave in registers (DPP row shifts + the two row broadcasts): lane 63 holds the total
+__device__ __forceinline__ int wave_prefix_add(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // kseq_final, ONE workgroup.  (1) the poses within KT_TOLERANCE of the best (Mapper.cpp:802-817): only cells whose maximum ties
-// with the best can hold one.  (2) When the coarse pass has exactly ONE best pose -- the common case -- its average is that
-// pose: x and y are lattice values (centre + offset, the host's doubles), the heading atan2(sin h, cos h) comes from a table
-// the host made per search angle.  The fine pass around it (Mapper.cpp:621-629: 3 x 3 cells, naf angles) is then scored right
-// here: lattice indices by WorldToGrid's IEEE operations, the angles' cosines and sines from the host's table for coarse angle a
-// (no libm on the device), every lookup with GetResponse's range check, responses, best, ties.  The host checks the centre and
-// the lattice indices the device used against its own and redoes the fine pass itself if they differ or if the coarse pass had
-// several best poses (their mean needs atan2).  (3) Everything the host needs goes to host-coherent memory, then the flag.
+// with the best can hold one; the (cell, angle) pairs of those cells are dealt over the threads.  (2) When the coarse pass has
+// exactly ONE best pose -- the common case -- its average is that pose: x and y are lattice values (centre + offset, the host's
+// doubles), the heading atan2(sin h, cos h) comes from a table the host made per search angle.  The fine pass around it
+// (Mapper.cpp:621-629: 3 x 3 cells, naf angles) is then scored right here: lattice indices by WorldToGrid's IEEE operations, the
+// angles' cosines and sines from the host's table for coarse angle a (no libm on the device), every lookup with GetResponse's
+// range check -- the naf x P (angle, beam) pairs dealt over the threads two at a time, nine byte loads each, wave-level sums in
+// registers -- then responses, best, ties.  The host checks the centre and the lattice indices the device used against its own
+// and redoes the fine pass itself if they differ or if the coarse pass had several best poses (their mean needs atan2).
+// (3) Everything the host needs goes to host-coherent memory, then the flag.
 __global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
 {
-  const CorrJob & job = *reinterpret_cast<const CorrJob *>(A.job);
-  __shared__ int s_nt, s_fnt, s_a;
+  __shared__ int s_nt, s_fnt, s_a, s_ncell;
   __shared__ uint32_t s_tie0;
+  __shared__ int32_t s_cells[1024];
   __shared__ double s_centre[3];
   __shared__ int32_t s_bx[4], s_by[4];
   __shared__ int32_t s_fsum[kSeqMaxFine];
+  __shared__ double s_cs[2 * (kSeqMaxFine / 9)];
   __shared__ unsigned long long s_fbest;
-  const int tid = threadIdx.x;
-  const int nx = job.nx, na = job.na;
-  const int plane = job.nx * job.ny;
-  const double best = __longlong_as_double((long long)job.out[0]);
-  const unsigned long long * lattice = job.out + kOutHeaderWords;
-  uint32_t * tie_idx = reinterpret_cast<uint32_t *>(job.out + 2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  // everything read from the job, once (behind a store the compiler must assume the job block itself changed)
+  const CorrJob & jr = *reinterpret_cast<const CorrJob *>(A.job);
+  const int nx = jr.nx, na = jr.na, plane = jr.nx * jr.ny, P = jr.n_points, ws = jr.ws;
+  const bool penal = jr.do_penalize != 0;
+  const double denom = jr.denom, goff_x = jr.grid_off_x, goff_y = jr.grid_off_y, scale = jr.scale;
+  const int64_t data_size = jr.data_size;
+  const int32_t * const sums = jr.sums;
+  unsigned long long * const out = jr.out;
+  const double * const dist_pen = jr.dist_pen, * const ang_pen = jr.ang_pen, * const local = jr.local;
+  const uint8_t * const grid = jr.grid, * const invalid = jr.invalid;
+  int stamp = 0;
+  auto phase = [&]() {if (A.dbg && tid == 0) {A.dbg[stamp] = (long long)wall_clock64();} ++stamp;};
+  phase();
+  const double best = __longlong_as_double((long long)out[0]);
+  const unsigned long long * lattice = out + kOutHeaderWords;
+  uint32_t * tie_idx = reinterpret_cast<uint32_t *>(out + 2);
   uint32_t * h_tie = reinterpret_cast<uint32_t *>(A.h_out + 2);
   if (tid == 0) {s_nt = 0; s_fnt = 0; s_fbest = 0ull; s_tie0 = 0u;}
   for (int i = tid; i < kSeqMaxFine; i += 1024) {s_fsum[i] = 0;}
-  __syncthreads();
-  for (int cell = tid; cell < plane; cell += 1024) {
-    const double m = __longlong_as_double((long long)lattice[cell]);
-    const double dm = m - best;
-    if (!(dm < 0.0 ? dm >= -1e-06 : dm <= 1e-06)) {continue;}
-    const int yi = cell / nx, xi = cell - yi * nx;
-    for (int a = 0; a < na; ++a) {
-      const double response = pose_response(job, job.sums[(size_t)a * plane + cell], a, yi, xi);
+  for (int cell0 = 0; cell0 < plane; cell0 += 1024) {
+    if (tid == 0) {s_ncell = 0;}
+    __syncthreads();
+    const int cell = cell0 + tid;
+    if (cell < plane) {
+      const double dm = __longlong_as_double((long long)lattice[cell]) - best;
+      if (dm < 0.0 ? dm >= -1e-06 : dm <= 1e-06) {s_cells[atomicAdd(&s_ncell, 1)] = cell;}
+    }
+    __syncthreads();
+    const int pairs = s_ncell * na;
+    for (int pr = tid; pr < pairs; pr += 1024) {
+      const int c = s_cells[pr / na], a = pr % na;
+      // pose_response (Mapper.cpp:1204, 671-685)
+      double response = (double)sums[(size_t)a * plane + c] / denom;
+      if (penal) {
+        const double d0 = response - 0.0;
+        if (!(d0 < 0.0 ? d0 >= -1e-06 : d0 <= 1e-06)) {response *= (dist_pen[c] * ang_pen[a]);}
+      }
       const double delta = response - best;
       if (delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06) {
         const int slot = atomicAdd(&s_nt, 1);
-        const uint32_t idx = (uint32_t)(((size_t)yi * nx + xi) * na + a);
+        const uint32_t idx = (uint32_t)((size_t)c * na + a);          // (y * nX + x) * nA + a
         if (slot < kTieCap) {tie_idx[slot] = idx; h_tie[slot] = idx;}
         if (slot == 0) {s_tie0 = idx;}
       }
     }
   }
   __syncthreads();
+  phase();
   const int n_ties = s_nt;
   if (tid == 0) {
-    job.out[1] = (unsigned long long)n_ties;
-    A.h_out[0] = job.out[0]; A.h_out[1] = (unsigned long long)n_ties;
+    out[1] = (unsigned long long)n_ties;
+    A.h_out[0] = out[0]; A.h_out[1] = (unsigned long long)n_ties;
   }
   const bool fine = A.refine != 0 && n_ties == 1;
-  if (fine && tid == 0) {
+  const int naf = A.naf;
+  if (fine) {
     const uint32_t t = s_tie0;
     const int a = (int)(t % (uint32_t)na);
-    const uint32_t xy = t / (uint32_t)na;
-    const int xi = (int)(xy % (uint32_t)nx), yi = (int)(xy / (uint32_t)nx);
-    // the mean of one pose, the way the host takes it (sum from zero, divided by the count)
-    double ax = 0.0, ay = 0.0;
-    ax += A.cx + A.xp[xi];
-    ay += A.cy + A.yp[yi];
-    const int32_t count = 1;
-    ax /= count; ay /= count;
-    s_centre[0] = ax; s_centre[1] = ay; s_centre[2] = A.heading[a];
-    s_a = a;
-    // lattice base indices of the fine search: operator()(y), Mapper.cpp:649-662
-    for (int k = 0; k < 3; ++k) {
-      const double newPositionX = ax + A.fxp[k];
-      const double gx = (newPositionX - job.grid_off_x) * job.scale;
-      s_bx[k] = d_to_int(d_round(gx)) + A.roi_x;
-      const double newPositionY = ay + A.fyp[k];
-      const double gy = (newPositionY - job.grid_off_y) * job.scale;
-      s_by[k] = (d_to_int(d_round(gy)) + A.roi_y) * job.ws;
+    if (tid == 0) {
+      const uint32_t xy = t / (uint32_t)na;
+      const int xi = (int)(xy % (uint32_t)nx), yi = (int)(xy / (uint32_t)nx);
+      // the mean of one pose, the way the host takes it (sum from zero, divided by the count)
+      double ax = 0.0, ay = 0.0;
+      ax += A.cx + A.xp[xi];
+      ay += A.cy + A.yp[yi];
+      const int32_t count = 1;
+      ax /= count; ay /= count;
+      s_centre[0] = ax; s_centre[1] = ay; s_centre[2] = A.heading[a];
+      s_a = a;
+      // lattice base indices of the fine search: operator()(y), Mapper.cpp:649-662
+      for (int k = 0; k < 3; ++k) {
+        const double newPositionX = ax + A.fxp[k];
+        const double gx = (newPositionX - goff_x) * scale;
+        s_bx[k] = d_to_int(d_round(gx)) + A.roi_x;
+        const double newPositionY = ay + A.fyp[k];
+        const double gy = (newPositionY - goff_y) * scale;
+        s_by[k] = (d_to_int(d_round(gy)) + A.roi_y) * ws;
+      }
+      A.h_fine->a = a; A.h_fine->xi = xi; A.h_fine->yi = yi;
+      for (int k = 0; k < 3; ++k) {A.h_fine->centre[k] = s_centre[k]; A.h_fine->bx[k] = s_bx[k]; A.h_fine->by[k] = s_by[k];}
     }
-    A.h_fine->a = a; A.h_fine->xi = xi; A.h_fine->yi = yi;
-    for (int k = 0; k < 3; ++k) {A.h_fine->centre[k] = s_centre[k]; A.h_fine->bx[k] = s_bx[k]; A.h_fine->by[k] = s_by[k];}
+    // the fine search's cosines and sines for coarse angle a
+    if (tid < 2 * naf) {s_cs[tid] = A.fine_cos_sin[(size_t)a * naf * 2 + tid];}
   }
   __syncthreads();
+  phase();
   if (fine) {
-    const int a = s_a, naf = A.naf, P = job.n_points;
-    const double * cs = A.fine_cos_sin + (size_t)a * naf * 2;
-    const int64_t data_size = job.data_size;
-    const int32_t bx0 = s_bx[0], bx1 = s_bx[1], bx2 = s_bx[2], by0 = s_by[0], by1 = s_by[1], by2 = s_by[2];
-    const int lane = tid & 63;
-    for (int k = 0; k < naf; ++k) {
-      const double cosine = cs[2 * k], sine = cs[2 * k + 1];
-      int32_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = tid; i < P; i += 1024) {
-        int32_t idx = kInvalidScan;
-        if (!job.invalid[i]) {
-          const double lxp = job.local[2 * i], lyp = job.local[2 * i + 1];
-          const double ox = cosine * lxp - sine * lyp;
-          const double oy = sine * lxp + cosine * lyp;
-          const double gxd = ((ox + job.grid_off_x) - job.grid_off_x) * job.scale;
-          const double gyd = ((oy + job.grid_off_y) - job.grid_off_y) * job.scale;
+    const int32_t bxs[3] = {s_bx[0], s_bx[1], s_bx[2]};
+    const int64_t bys[3] = {s_by[0], s_by[1], s_by[2]};
+    const int total = naf * P;
+    constexpr int kPairs = 2;                                // (angle, beam) pairs a thread has in flight
+    for (int p0 = tid; p0 - lane < total; p0 += kPairs * 1024) {    // (the trip count is the wave's: every lane takes part in the sums below)
+      int kk[kPairs], ii[kPairs];
+      int32_t idx[kPairs];
+      bool on[kPairs];
+      uint8_t v[kPairs][9];
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) {
+        const int p = p0 + 1024 * u;
+        on[u] = p < total;
+        kk[u] = on[u] ? p / P : naf - 1;
+        ii[u] = on[u] ? p - kk[u] * P : 0;
+      }
+      double lxp[kPairs], lyp[kPairs];
+      uint8_t inv[kPairs];
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) {lxp[u] = local[2 * ii[u]]; lyp[u] = local[2 * ii[u] + 1]; inv[u] = invalid[ii[u]];}
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) {
+        idx[u] = kInvalidScan;
+        if (!inv[u]) {
+          const double cosine = s_cs[2 * kk[u]], sine = s_cs[2 * kk[u] + 1];
+          // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
+          const double ox = cosine * lxp[u] - sine * lyp[u];
+          const double oy = sine * lxp[u] + cosine * lyp[u];
+          const double gxd = ((ox + goff_x) - goff_x) * scale;
+          const double gyd = ((oy + goff_y) - goff_y) * scale;
           const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
-          idx = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)job.ws);
+          idx[u] = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)ws);
         }
-        A.fine_table[(size_t)k * P + i] = idx;
-        if (idx == kInvalidScan) {continue;}                   // Mapper.cpp:1194
-        const int64_t row[3] = {(int64_t)by0 + idx, (int64_t)by1 + idx, (int64_t)by2 + idx};
-        const int32_t col[3] = {bx0, bx1, bx2};
-        uint8_t v[9];
+        if (on[u]) {A.fine_table[(size_t)kk[u] * P + ii[u]] = idx[u];}
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-          const int64_t at = row[j / 3] + col[j % 3];
-          v[j] = (at >= 0 && at < data_size) ? job.grid[at] : (uint8_t)0;      // Mapper.cpp:1192-1197
+          const int64_t at = bys[j / 3] + bxs[j % 3] + idx[u];
+          v[u][j] = (on[u] && idx[u] != kInvalidScan && at >= 0 && at < data_size) ? grid[at] : (uint8_t)0;      // Mapper.cpp:1192-1197
         }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {acc[j] += v[j];}
       }
+      // wave-level sums per angle (the lanes of a wave hold consecutive pairs: one angle, two where a wave straddles P)
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        int32_t x = acc[j];
+      for (int u = 0; u < kPairs; ++u) {
+        const int k_lo = __builtin_amdgcn_readfirstlane(kk[u]), k_hi = __builtin_amdgcn_readlane(kk[u], 63);
+        for (int k = k_lo; k <= k_hi; ++k) {
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) {x += __shfl_xor(x, sft);}
-        if (lane == 0 && x != 0) {atomicAdd(&s_fsum[k * 9 + j], x);}
+          for (int j = 0; j < 9; ++j) {
+            const int sum = wave_prefix_add(kk[u] == k ? (int)v[u][j] : 0);
+            if (lane == 63 && sum != 0) {atomicAdd(&s_fsum[k * 9 + j], sum);}
+          }
+        }
       }
     }
   }
   __syncthreads();
+  phase();
   double response = -1.0;
   int fk = 0, fj = 0;
-  if (fine && tid < A.naf * 9) {
+  if (fine && tid < naf * 9) {
     fk = tid / 9; fj = tid - 9 * fk;
     const int32_t sum = s_fsum[tid];
     A.fine_sums[tid] = sum;                                    // [a][y][x] with a 3 x 3 plane
     A.h_fine->sums[tid] = sum;
-    response = (double)sum / job.denom;                        // Mapper.cpp:1204
+    response = (double)sum / denom;                            // Mapper.cpp:1204
     if (A.fine_penalize) {
       const double delta = response - 0.0;
       const bool is_zero = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;
-      if (!is_zero) {response *= (A.fine_dist_pen[fj] * A.fine_ang_pen[(size_t)s_a * A.naf + fk]);}
+      if (!is_zero) {response *= (A.fine_dist_pen[fj] * A.fine_ang_pen[(size_t)s_a * naf + fk]);}
     }
     atomicMax(&s_fbest, (unsigned long long)__double_as_longlong(response));
   }
   __syncthreads();
-  if (fine && tid < A.naf * 9) {
+  if (fine && tid < naf * 9) {
     const double fbest = __longlong_as_double((long long)s_fbest);
     const double delta = response - fbest;
     if (delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06) {
       const int slot = atomicAdd(&s_fnt, 1);
-      reinterpret_cast<uint32_t *>(A.h_fine->out + 2)[slot] = (uint32_t)(fj * A.naf + fk);      // (y * nx + x) * na + a
+      reinterpret_cast<uint32_t *>(A.h_fine->out + 2)[slot] = (uint32_t)(fj * naf + fk);      // (y * nx + x) * na + a
     }
   }
+  // every wave's stores have reached the L2 before the flag's release writes the L2 back
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     if (fine) {A.h_fine->out[0] = s_fbest; A.h_fine->out[1] = (unsigned long long)s_fnt;}
     A.h_fine->valid = fine ? 1 : 0;
     __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(A.h_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  phase();
 }
 
 void launch_seq_final(const SeqFinalArgs & args, void * stream)

@@ -12,9 +12,10 @@
 //   kseq_links   per first point the first points of the cells in its 100-footprint (four independent loads)
 //   kseq_bin     ONE workgroup: the order-dependent "cell already 100" rule as a fixpoint over state bytes in LDS, then tile
 //                counts, list starts and lists with LDS counters only (the batch path: five launches, global atomics)
-//   k_raster_tile(_reg), k_repitch*   as in the batch path
-//   kseq_stage   the host's exact tables (computed while the kernels above run) into device memory, volume and result zeroed
-//   kseq_score   lookup table + scoring in one launch (K2 + K3), the beams of an angle cut into slices of 128 (9 x as many
+//   kseq_tile    the stamps, tile by tile (eight waves per tile, two dependent loads in front of the first stamp; smear kernels
+//                below 8 x 8 cells: k_raster_tile of the batch path), k_repitch* for slots with copies; its last workgroups pull
+//                the host's exact tables (computed while the kernels above run) into device memory and zero volume and result
+//   kseq_score   lookup table + scoring in one launch (K2 + K3), the beams of an angle cut into slices of 64 (17 x as many
 //                workgroups as K3 has for one job), sums added to the volume
 //   kseq_cells   per-cell maxima (the search-space probabilities) and the best response
 //   kseq_final   ONE workgroup: ties; when the coarse pass has exactly one best pose, the fine pass around it (centre from
@@ -34,7 +35,7 @@ constexpr int32_t kSeqMaxTiles = 16384;    // rasteriser tiles: one counter each
 constexpr int32_t kSeqMaxFine = 1024;      // poses of the fine volume
 constexpr int32_t kSeqCandWords = 8;       // int32 per stamp candidate: point, cx, cy, selected | four neighbour points
 constexpr int32_t kFirstNone = INT32_MAX;
-constexpr int32_t kSeqSlice = 128;         // beams per workgroup of kseq_score
+constexpr int32_t kSeqSlice = 64;          // beams per workgroup of kseq_score
 constexpr int32_t kSeqCtlWords = 16;
 
 struct SeqPrepArgs
@@ -76,13 +77,22 @@ struct SeqFinalArgs
   double fxp[3], fyp[3];                   // fine lattice offsets
   int32_t roi_x, roi_y;
   int32_t * fine_table; int32_t * fine_sums;   // the slot's table / volume (introspection reads the last search)
+  long long * dbg;                         // nullptr, or where the kernel leaves wall_clock64 at its phase boundaries (measurements)
 };
 
 void launch_seq_prep(const SeqPrepArgs & args, void * stream);
 void launch_seq_links(const RasterJob * d_job, int32_t n_points, const int32_t * first, int32_t * cand, int32_t * ctl, void * stream);
 // dynamic LDS of kseq_bin for a job (the host checks it against the device's limit)
 size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words);
-int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int device, void * stream);
+// work2 (nullptr = the batch path's list format for k_raster_tile): one (tile, list start, count) record per non-empty tile and the
+// cell packed into the list entries, for kseq_tile; dbg (nullptr = none): wall_clock64 at the kernel's phase boundaries
+int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
+  void * stream);
+size_t seq_tile_table_bytes();
+void seq_tile_table(const uint8_t * kernel, int32_t kernel_size, uint8_t * out);
+// stamping (smear kernels of >= 8 x 8 cells) + the staging copy of launch_seq_stage in one launch
+void launch_seq_tile(const RasterJob * d_job, const uint8_t * d_tab, const int32_t * d_work2, int32_t max_points, int32_t max_tiles,
+  const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words, void * stream);
 void launch_raster_tiles(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
   void * stream);
 void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words,
