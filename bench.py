@@ -43,14 +43,29 @@ FP64_PEAK_TFLOPS = 78.6            # MI355X FP64 vector = matrix peak (spec); v_
 # LDS read port for ds_read_b32: 128 B per clock per CU (MI355X_MICROARCH.md, LDS table) x 256 CUs x 2.4 GHz
 LDS_B32_PEAK_GBS = 128.0 * 256 * 2.4
 SCORE_KERNEL = "k_score_lds<1,4>"
-PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r4_k_score_pmc.json", "r3_k_score_pmc.json", "r2_k_score_pmc.json", "r1_k_score_pmc.json"))
-                 if os.path.exists(p)), os.path.join(ROOT, "profiles", "r1_k_score_pmc.json"))
+
+
+def _newest_pmc():
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_k_score_pmc.json")),
+                   key=lambda p: int("".join(ch for ch in os.path.basename(p).split("_")[0] if ch.isdigit()) or 0))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r1_k_score_pmc.json")
+
+
+PMC_FILE = _newest_pmc()
+
+
+def round_of(path):
+    """round number of profiles/rN_<name> (numeric: r10 is newer than r9)"""
+    name = os.path.basename(path)
+    digits = name[1:name.index("_")] if "_" in name else ""
+    return int("".join(ch for ch in digits if ch.isdigit()) or 0)
 
 
 def newest_profile(suffix):
     """profiles/rN_<suffix> of the newest round that has one (the summaries are re-collected in the rounds that change their kernels)"""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_" + suffix)))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_" + suffix)), key=round_of)
     return os.path.basename(found[-1]) if found else "r3_" + suffix
 
 
@@ -123,6 +138,25 @@ class _StdoutToStderr:
         return False
 
 
+def cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max, else v1 cfs quota / period); None = no limit set.  `cores` of the
+    CPU baselines is what the box HAS (os.cpu_count()); this is what the process GETS."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(budget_s=24.0):
     """The reference's own CorrelateScan (oracle/_ref, row-parallel thread-pool stand-in for tbb::parallel_for_each) --
     or the C restatement when _ref is absent -- on the host cores, in two forms: ONE search spread over all cores (the
@@ -182,7 +216,7 @@ def cpu_baseline(budget_s=24.0):
                       "matches_per_s": n / dt if dt > 0 else 0.0})
         del ms
     best = max(forms, key=lambda f: f["matches_per_s"])
-    return {"value": best["matches_per_s"], "unit": "scan-matches/s", "cores": cores, "kind": kind,
+    return {"value": best["matches_per_s"], "unit": "scan-matches/s", "cores": cores, "cpu_quota": cpu_quota(), "kind": kind,
             "sample": f"config-2 CorrelateScan (61x61x81 poses x 1081 beams) for ~{budget_s:.0f} s: best of "
                       f"{[f['concurrent_matchers'] for f in forms]} concurrent matchers = {best['concurrent_matchers']} x "
                       f"{best['threads_each']} threads; single search over all {cores} cores: {forms[0]['matches_per_s']:.1f}/s",
@@ -1091,8 +1125,14 @@ def main():
         h.profile(True)       # HIP events on the library's stream around every scoring launch
     dt, per_step = timed(handles, args.steps)
     wave_loads = sum(h.score_loads() for h in handles)
+    sides = [h.profile_side() for h in handles]
     profs = [h.profile(False) for h in handles]
     prof = {k: sum(p[k] for p in profs) for k in profs[0]}
+    side = {k: sum(p[k] for p in sides) for k in sides[0]}
+    # `value` is the K steps asked for; beside it a region of at least 160 steps (half a second) in five windows, so that the
+    # headline can be read against the box-to-box spread (a 20-step region is 0.07 s)
+    long_steps = max(args.steps, 160)
+    dt_long, per_step_long = (dt, per_step) if long_steps == args.steps else timed(handles, long_steps)
 
     full = {}          # every key of the record; the line is cut from it
     variants = {}
@@ -1190,8 +1230,15 @@ def main():
         loads_per_launch = wave_loads / max(1, prof["score_launches"])
         lds_gbs = loads_per_launch * 256.0 / (k3_ms * 1e-3) / 1e9
         traffic = pmc_traffic(per_launch)
-        windows = [per_step[i::5] for i in range(5)] if len(per_step) >= 5 else [per_step]
+        chunk = max(1, len(per_step_long) // 5)
+        windows = [per_step_long[i * chunk:(i + 1) * chunk] for i in range(5)] if len(per_step_long) >= 5 else [per_step_long]
         rates = sorted(world * B * len(w) / sum(w) for w in windows if w)
+        # reference lookups per CU clock (one figure that does not change its denominator from round to round):
+        # every lookup of the reference's access stream (nX * nY * nA * P per match) over the scoring kernel's time, and the part
+        # of them the kernel really reads (windows it keeps: 64 x 64 bytes each, of which 61 x 61 are poses)
+        cu_clocks = 256 * 2.4e9 * (k3_ms * 1e-3)
+        lookups_all = C2["nx"] * C2["ny"] * C2["na"] * P_BEAMS * per_launch
+        lookups_read = loads_per_launch / 16.0 * C2["nx"] * C2["ny"]
         full.update({
             "metric": "scan-matches/sec", "value": world * B * args.steps / dt, "unit": "scan-matches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -1203,13 +1250,18 @@ def main():
                                "(61x61x81 poses), 8087^2 grid",
             # per-step wall times of the timed region, dealt into five interleaved windows: spread of the headline
             "value_windows": {"n": len(rates), "median": float(np.median(rates)) if rates else None, "min": rates[0] if rates else None,
-                              "max": rates[-1] if rates else None, "steps_per_window": len(windows[0]) if windows else 0},
+                              "max": rates[-1] if rates else None, "steps_per_window": len(windows[0]) if windows else 0,
+                              "steps": long_steps, "seconds": dt_long, "value": world * B * long_steps / dt_long},
             # the dominant kernel reads LDS-resident window unions: the resource it leans on is the LDS read port (ds_read_b32:
             # 128 B / clk / CU), not HBM.  `frac` is the live LDS->register byte rate against that port; the HBM side (recorded
             # PMC) and the reference's algorithmic access stream are kept beside it, each labelled.
             "roofline": {"bound": "lds", "kernel": SCORE_KERNEL, "achieved": lds_gbs, "peak": LDS_B32_PEAK_GBS,
                          "unit": "GB/s", "frac": lds_gbs / LDS_B32_PEAK_GBS,
                          "window_reads_per_launch": loads_per_launch, "avg_launch_ms": k3_ms, "matches_per_launch": per_launch,
+                         "lookups_per_cu_clk": lookups_all / cu_clocks, "lookups_per_cu_clk_read": lookups_read / cu_clocks,
+                         "lookups_per_cu_clk_peak_b32": 128.0, "lds_array_frac": lds_gbs / (2.0 * LDS_B32_PEAK_GBS),
+                         "side_kernels_ms_per_launch": {"k_offsets_lds": side["offsets_ms"] / max(1, prof["score_launches"]),
+                                                        "k_ties": side["ties_ms"] / max(1, prof["score_launches"])},
                          "traffic": traffic, "hbm_frac": (traffic / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_launch": alg, "algorithmic_gbs": alg_gbs, "algorithmic_ratio": alg_gbs / HBM_PEAK_GBS,
                          "traffic_source": "recorded: " + os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 PMC passes of this command; "

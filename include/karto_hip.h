@@ -230,6 +230,11 @@ KH_API void * kh_matcher_stream(kh_matcher * m);
 KH_API int kh_matcher_profile(kh_matcher * m, int32_t enable, double * score_ms, int64_t * score_launches,
                               double * raster_ms, int64_t * raster_launches);
 
+/* GPU time of the kernels either side of the scoring kernel in the same launches (HIP events on their stream while profiling is
+ * enabled): the table / list kernel (K2, K2') and the tie kernel (K4), total ms since the last call (which this one resets).
+ * Call it BEFORE kh_matcher_profile(m, 0, ...) reads and resets the launch count. */
+KH_API int kh_matcher_profile_side(kh_matcher * m, double * offsets_ms, double * ties_ms);
+
 /* wave-level dword-load instructions (256 B each: 16 lanes x 4 B across, 4 grid rows down) the scoring kernel issued
  * for the searches run while profiling was enabled, tallied on the device by K2 from the beam lists it hands to K3
  * (slow-path beams, which need the per-pose range check, are not included).  This is the L1 (TCP) side of the

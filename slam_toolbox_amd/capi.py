@@ -69,7 +69,7 @@ SYMBOLS = [
     "kh_matcher_match_batch", "kh_matcher_add_scans", "kh_matcher_correlate", "kh_matcher_correlate_batch",
     "kh_matcher_grid_info", "kh_matcher_read_grid", "kh_matcher_read_kernel", "kh_matcher_read_lookup",
     "kh_matcher_positional_covariance", "kh_matcher_angular_covariance",
-    "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile", "kh_matcher_score_loads", "kh_matcher_seq_stats",
+    "kh_matcher_read_volume", "kh_matcher_set_debug", "kh_matcher_stream", "kh_matcher_profile", "kh_matcher_score_loads", "kh_matcher_seq_stats", "kh_matcher_profile_side",
     "kh_matcher_group_create", "kh_matcher_group_destroy", "kh_matcher_group_set_params", "kh_matcher_group_size", "kh_matcher_group_member",
     "kh_matcher_group_device", "kh_matcher_group_match_batch", "kh_loop_closure_batch",
     "kh_spa_options_default", "kh_spa_create", "kh_spa_set_debug", "kh_spa_destroy", "kh_spa_set_options", "kh_spa_reset",
@@ -195,6 +195,7 @@ def lib():
     L.kh_matcher_profile.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(C.c_int64), C.POINTER(dbl), C.POINTER(C.c_int64)]
     L.kh_matcher_score_loads.argtypes = [vp, C.POINTER(C.c_int64), i32]
     L.kh_matcher_seq_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.kh_matcher_profile_side.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if hasattr(L, "kh_spa_create"):
         L.kh_spa_options_default.argtypes = [C.POINTER(KhSpaOptions)]
         L.kh_spa_create.argtypes = [i32, C.POINTER(vp)]

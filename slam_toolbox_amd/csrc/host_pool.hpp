@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -37,17 +38,21 @@ public:
   void run(size_t n, const std::function<void(size_t)> & fn)
   {
     if (n == 0) {return;}
-    if (n == 1 || workers_.empty()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
+    // a region entered from inside a region (fn calling run() again, on the caller thread or on a worker) runs in line: the
+    // flag, not a try_lock on a mutex this thread may already own (undefined behaviour)
+    if (n == 1 || workers_.empty() || inside_region()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
     // one parallel region at a time; a second handle arriving from another thread while the workers are taken does its
     // loop itself instead of queueing behind the first (the regions are short: waiting would idle the caller's GPU stream)
     std::unique_lock<std::mutex> serial(run_mu_, std::try_to_lock);
     if (!serial.owns_lock()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
     fn_ = &fn; n_ = n; next_.store(0, std::memory_order_relaxed);
+    failed_.store(false, std::memory_order_relaxed);
     pending_.store(static_cast<uint32_t>(workers_.size()), std::memory_order_relaxed);
     generation_.fetch_add(1, std::memory_order_release);
     futex_wake_all(&generation_);
     work();
-    // every worker checks in (the last one wakes this thread): nobody can still be reading fn_ / n_ when run() returns
+    // every worker checks in (the last one wakes this thread): nobody can still be reading fn_ / n_ when run() returns --
+    // also when fn threw: the first exception is kept and rethrown here, after the region has drained
     const uint64_t t0 = ticks();
     for (;;) {
       const uint32_t left = pending_.load(std::memory_order_acquire);
@@ -55,6 +60,11 @@ public:
       if (ticks() - t0 < kSpinTicks) {__builtin_ia32_pause();} else {futex_wait(&pending_, left);}
     }
     fn_ = nullptr;
+    if (failed_.load(std::memory_order_acquire)) {
+      std::exception_ptr e;
+      std::swap(e, error_);
+      std::rethrow_exception(e);
+    }
   }
   ~HostPool()
   {
@@ -87,13 +97,22 @@ private:
     if (const char * e = std::getenv(wide_pool ? "KH_MAPPER_UPDATE_THREADS" : "KH_HOST_THREADS")) {want = static_cast<unsigned>(std::max(1, std::atoi(e)));}
     for (unsigned t = 1; t < want; ++t) {workers_.emplace_back([this] {loop();});}
   }
+  static bool & inside_region() {static thread_local bool inside = false; return inside;}
   void work()
   {
+    inside_region() = true;
     for (;;) {
       const size_t i = next_.fetch_add(1);
       if (i >= n_) {break;}
-      (*fn_)(i);
+      try {
+        (*fn_)(i);
+      } catch (...) {
+        // keep the first exception, drop the rest of the region's items
+        if (!failed_.exchange(true, std::memory_order_acq_rel)) {error_ = std::current_exception();}
+        next_.store(n_, std::memory_order_relaxed);
+      }
     }
+    inside_region() = false;
   }
   void loop()
   {
@@ -118,7 +137,8 @@ private:
   size_t n_ = 0;
   std::atomic<size_t> next_{0};
   std::atomic<uint32_t> pending_{0}, generation_{0};
-  std::atomic<bool> stop_{false};
+  std::atomic<bool> stop_{false}, failed_{false};
+  std::exception_ptr error_;
 };
 
 }  // namespace kh

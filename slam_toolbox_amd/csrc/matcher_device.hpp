@@ -104,6 +104,7 @@ __device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w
 // (device function: k_find_valid_par runs it per (job, scan) item, the fused sequential path's kseq_prep per scan of its one job and
 // then goes on with the scan's points -- they stay in LDS as P[i], their flags as flags_lds[i] = reach[i].)
 // s_fv: max_n double2 + 3 * (max_n + 64) int32 + 2 * (max_n + 64) bytes of dynamic LDS.  Any block size that is a multiple of 64.
+template <bool kWaveSearch>
 __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n, uint8_t * out, const double vx, const double vy,
   const int max_n, double2 * s_fv, uint8_t *& flags_lds)
 {
@@ -134,14 +135,39 @@ __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n
     if (mine < n) {atomicMin(&s_pos0, mine);}
   }
   // next(i): the trigger that follows if reading i is the anchor (n = none)
-  for (int i = tid; i < n; i += nthreads) {
-    const double fx = P[i].x, fy = P[i].y;
-    int j = (isnan(fx) || isnan(fy)) ? n : i + 1;         // a NaN reading is never an anchor (nothing is "farther" than NaN)
-    for (; j < n; ++j) {
-      const double dx = fx - P[j].x, dy = fy - P[j].y;
-      if (dx * dx + dy * dy > min_square_distance) {break;}
+  if (kWaveSearch) {
+    // a WAVE per anchor, the lanes on the 64 readings behind it (ballot, first set bit): one step for almost every anchor.  With a
+    // lane per anchor the kernel waits for its slowest lane -- a reading with dozens of neighbours within 0.1 m (an obstacle half
+    // a metre away, a run of NaN) walks them one LDS round trip at a time, and the other lanes' work does not shorten that walk.
+    // 64 x the comparisons: for one job on an idle chip, not for batches.
+    const int wave = tid >> 6, nwaves = nthreads >> 6;
+    for (int i = wave; i < n; i += nwaves) {
+      const double fx = P[i].x, fy = P[i].y;
+      int j = n;
+      if (!(isnan(fx) || isnan(fy))) {                       // a NaN reading is never an anchor (nothing is "farther" than NaN)
+        for (int base = i + 1; base < n; base += 64) {
+          const int jj = base + lane;
+          bool hit = false;
+          if (jj < n) {
+            const double dx = fx - P[jj].x, dy = fy - P[jj].y;
+            hit = dx * dx + dy * dy > min_square_distance;
+          }
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {j = base + __builtin_ctzll(mask); break;}
+        }
+      }
+      if (lane == 0) {nxt0[i] = j;}
     }
-    nxt0[i] = j;
+  } else {
+    for (int i = tid; i < n; i += nthreads) {
+      const double fx = P[i].x, fy = P[i].y;
+      int j = (isnan(fx) || isnan(fy)) ? n : i + 1;         // a NaN reading is never an anchor (nothing is "farther" than NaN)
+      for (; j < n; ++j) {
+        const double dx = fx - P[j].x, dy = fy - P[j].y;
+        if (dx * dx + dy * dy > min_square_distance) {break;}
+      }
+      nxt0[i] = j;
+    }
   }
   if (tid == 0) {nxt0[n] = n; reach[n] = 0;}
   __syncthreads();

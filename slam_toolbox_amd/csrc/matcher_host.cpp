@@ -372,7 +372,7 @@ int init_ctx(const CorrReq & q, CorrHost & c)
 }
 
 // device scratch of one slot for the search `c` describes (allocation is serial: called before the pool fills the tables)
-int ensure_slot_scratch(kh_matcher * m, const CorrReq & q, CorrHost & c)
+int ensure_slot_scratch(kh_matcher * m, const CorrReq & q, CorrHost & c, bool allow_copies)
 {
   (void)q;
   int rc = KH_OK;
@@ -403,7 +403,7 @@ int ensure_slot_scratch(kh_matcher * m, const CorrReq & q, CorrHost & c)
     const double cells_per_step = q.res_x * m->scale;
     const bool full_res = c.nx > 1 && std::fabs(cells_per_step - 1.0) < 1e-9 && c.nx <= kTileSpan;
     const bool tiled_lists = lt > 1 && (std::fabs(cells_per_step - 1.0) < 1e-9 || std::fabs(cells_per_step - 2.0) < 1e-9);
-    if (m->dual_copy && !s.d_grid2 && (full_res || tiled_lists) && work >= 1e8) {
+    if (allow_copies && m->dual_copy && !s.d_grid2 && (full_res || tiled_lists) && work >= 1e8) {
       // a search that steps two cells (MatchScan's coarse pass) gets the column-decimated copies
       const bool two_cells = std::fabs(cells_per_step - 2.0) < 1e-9 && m->copy_q > 0 && (m->ws % 8) == 0;
       rc = allocate_copies(m, s, two_cells ? 2 : 1); if (rc) {return rc;}
@@ -804,11 +804,13 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   hipStream_t cs = overlap ? B.side : m->stream;
   KH_HIP(hipMemcpyAsync(B.d_stage, B.h_stage, stride * n, hipMemcpyHostToDevice, cs));
   // (the result blocks are zeroed by K2)
+  if (m->profiling) {KH_HIP(hipEventRecord(B.evs[0], cs));}
   if (use_lds) {
     launch_offsets_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, cs);
   } else {
     launch_offsets(B.d_stage, stride, static_cast<int32_t>(n), max_na, cs);
   }
+  if (m->profiling) {KH_HIP(hipEventRecord(B.evs[1], cs));}
   // The scoring kernel of a chunk goes on the chunk's own side stream as well (KH_K3_MAIN=1: on the handle's main stream, one
   // scoring kernel after the other, as through round 3): the two staging sets then are two independent in-order queues, and the
   // workgroups of chunk i + 1 fill the compute units the tail of chunk i leaves idle (2099 workgroups on 512 slots are 4.1
@@ -836,7 +838,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     KH_HIP(hipEventRecord(B.kdone, ks));
     KH_HIP(hipStreamWaitEvent(cs, B.kdone, 0));
   }
+  if (m->profiling) {KH_HIP(hipEventRecord(B.evs[2], cs));}
   launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, B.tile_pairs, cs);
+  if (m->profiling) {KH_HIP(hipEventRecord(B.evs[3], cs));}
   KH_HIP(hipGetLastError());
   KH_HIP(hipMemcpyAsync(B.h_out, B.d_out, out_words * 8 * n, hipMemcpyDeviceToHost, cs));
   // fine passes need the raw sums of every angle at the best cell (ComputeAngularCovariance): their
@@ -889,6 +893,8 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     float ms = 0;
     KH_HIP(hipEventElapsedTime(&ms, B.ev[0], B.ev[1]));
     m->score_ms += ms; m->score_launches += 1; m->score_jobs += static_cast<int64_t>(n);
+    KH_HIP(hipEventElapsedTime(&ms, B.evs[0], B.evs[1])); m->offsets_ms += ms;
+    KH_HIP(hipEventElapsedTime(&ms, B.evs[2], B.evs[3])); m->ties_ms += ms;
   }
 
   // ---- 3. finalisation (Mapper.cpp:775-862) ----
@@ -1125,6 +1131,9 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
     for (auto & ev : b.ev) {
       if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
     }
+    for (auto & ev : b.evs) {
+      if ((e = hipEventCreate(&ev)) != hipSuccess) {return fail(e, "hipEventCreate");}
+    }
     if ((e = hipEventCreateWithFlags(&b.done, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
     if ((e = hipEventCreateWithFlags(&b.up, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
     if ((e = hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
@@ -1192,6 +1201,7 @@ void kh_matcher_destroy(kh_matcher * m)
     if (b.h_out) {hipHostFree(b.h_out);}
     if (b.h_sums) {hipHostFree(b.h_sums);}
     for (auto & ev : b.ev) {if (ev) {hipEventDestroy(ev);}}
+    for (auto & ev : b.evs) {if (ev) {hipEventDestroy(ev);}}
     if (b.done) {hipEventDestroy(b.done);}
     if (b.up) {hipEventDestroy(b.up);}
     if (b.kdone) {hipEventDestroy(b.kdone);}
@@ -1586,6 +1596,14 @@ int kh_matcher_profile(kh_matcher * m, int32_t enable, double * score_ms, int64_
   if (raster_launches) {*raster_launches = m->raster_launches;}
   m->profiling = enable != 0;
   m->score_ms = 0; m->raster_ms = 0; m->score_launches = 0; m->raster_launches = 0; m->score_jobs = 0;
+  return KH_OK;
+}
+
+int kh_matcher_profile_side(kh_matcher * m, double * offsets_ms, double * ties_ms)
+{
+  if (!m || !offsets_ms || !ties_ms) {return KH_ERR_INVALID_ARG;}
+  *offsets_ms = m->offsets_ms; *ties_ms = m->ties_ms;
+  m->offsets_ms = 0; m->ties_ms = 0;
   return KH_OK;
 }
 

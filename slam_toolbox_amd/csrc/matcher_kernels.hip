@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, 
   const int k = items[t].scan;
   const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
   uint8_t * flags = nullptr;
-  find_valid_scan(reinterpret_cast<const double2 *>(job.scan_ptr[k]), n, job.active + job.scan_prefix[k], job.view_x, job.view_y, max_n, s_fv, flags);
+  find_valid_scan<false>(reinterpret_cast<const double2 *>(job.scan_ptr[k]), n, job.active + job.scan_prefix[k], job.view_x, job.view_y, max_n, s_fv, flags);
 }
 
 void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream)

@@ -121,6 +121,7 @@ struct CorrBatch
   int32_t * h_sums = nullptr; size_t cap_hsums = 0;          // fine passes: packed small volumes (pinned) ...
   int32_t * d_small = nullptr; size_t cap_dsmall = 0; size_t small_stride = 0;   // ... and their device staging
   hipEvent_t ev[2] = {nullptr, nullptr};      // around the scoring kernel (profiling)
+  hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};   // around the table / list kernel (K2) and the tie kernel (K4) (profiling)
   hipEvent_t done = nullptr;                  // everything of the sub-batch, downloads included
   hipEvent_t up = nullptr, kdone = nullptr;   // chunked batches: tables + lists ready (side stream) / scoring finished (main stream)
   hipStream_t side = nullptr;                 // side stream of this staging set (uploads, K2, K4, downloads of its chunks)
@@ -199,6 +200,7 @@ struct kh_matcher
   // profiling
   bool profiling = false;
   double score_ms = 0, raster_ms = 0; int64_t score_launches = 0, raster_launches = 0, score_jobs = 0;
+  double offsets_ms = 0, ties_ms = 0;      // the kernels either side of the scoring kernel, same launches (kh_matcher_profile_side)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long * d_load_counter = nullptr;    // see CorrJob::load_counter (only handed to the jobs while profiling)
 
@@ -270,7 +272,9 @@ struct ResultView
 StageLayout stage_layout(int32_t P, int32_t nx, int32_t ny, int32_t na, bool penalize);
 int pick_ry(int32_t ny);
 int init_ctx(const CorrReq & q, CorrHost & c);
-int ensure_slot_scratch(kh_matcher * m, const CorrReq & q, CorrHost & c);
+// allow_copies = false: the slot is not given re-pitched copies of its grid by this call (the fused path of one match scores from
+// the grid itself; copies the slot already has are kept in step all the same)
+int ensure_slot_scratch(kh_matcher * m, const CorrReq & q, CorrHost & c, bool allow_copies = true);
 void prepare_job(kh_matcher * m, const CorrReq & q, CorrHost & c, const StageLayout & L, uint8_t * hb, uint8_t * db,
   unsigned long long * d_out, size_t out_words, size_t n_launch, bool lds_always, bool lds_never, JobShape & shape);
 int finalize_job(kh_matcher * m, CorrReq & q, CorrHost & c, const ResultView & v);

@@ -176,9 +176,35 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     }
     KS_HIP(hipMemcpyAsync(m->d_arena, m->h_arena, sizeof(double) * 2 * arena_points, hipMemcpyHostToDevice, st));
   }
-  // ---- 1. rasteriser: everything it needs travels as kernel arguments
+  // the two searches of the match (Mapper.cpp:577-592, 621-629) and their device scratch -- first: a slot that earns re-pitched
+  // copies of its grid gets them here, and the rasteriser's job below must know them
   const double res = m->grid_resolution();
   const double * pose = query->sensor_pose;
+  const double cso = 0.5 * (static_cast<double>(m->side) - 1) * res;
+  const double csr = 2 * res;
+  CorrReq q;
+  q.slot = 0; q.scan = query;
+  std::copy(pose, pose + 3, q.center);
+  q.off_x = cso; q.off_y = cso; q.res_x = csr; q.res_y = csr;
+  q.ang_off = mp.coarse_search_angle_offset; q.ang_res = mp.coarse_angle_resolution; q.penalize = penalize; q.fine = false;
+  std::copy(cov, cov + 9, q.cov);
+  q.response = 0; q.status = KH_OK;
+  CorrHost c;
+  rc = init_ctx(q, c); if (rc) {return rc;}
+  rc = ensure_slot_scratch(m, q, c, false); if (rc) {return rc;}
+  CorrReq qf;
+  qf.slot = 0; qf.scan = query;
+  qf.center[0] = qf.center[1] = qf.center[2] = 0.0;
+  qf.off_x = csr * 0.5; qf.off_y = csr * 0.5; qf.res_x = res; qf.res_y = res;
+  qf.ang_off = 0.5 * mp.coarse_angle_resolution; qf.ang_res = mp.fine_search_angle_offset; qf.penalize = penalize; qf.fine = true;
+  qf.response = 0; qf.status = KH_OK;
+  CorrHost cf;
+  bool device_fine = refine;
+  if (device_fine) {
+    if (init_ctx(qf, cf) != KH_OK || cf.nx != 3 || cf.ny != 3 || cf.na * 9 > kSeqMaxFine) {device_fine = false;}
+    else {rc = ensure_slot_scratch(m, qf, cf, false); if (rc) {return rc;}}
+  }
+  // ---- 1. rasteriser: everything it needs travels as kernel arguments
   // MatchScan steps 1-4, Mapper.cpp:543-569
   s.off_x = pose[0] - (0.5 * (m->roi_w - 1) * res);
   s.off_y = pose[1] - (0.5 * (m->roi_h - 1) * res);
@@ -196,6 +222,7 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     for (int32_t r = k; r < kSeqMaxScans; ++r) {pa.scans[r] = nullptr; pa.prefix[r + 1] = run;}
   }
   pa.n_scans = n_scans; pa.max_n = max_n;
+  pa.dbg = Q.d_dbg ? Q.d_dbg + 8 : nullptr;
   pa.d_job = Q.d_job; pa.first = Q.d_first; pa.ctl = Q.d_ctl; pa.clear_blocks = 128;     // 2048 waves: one tile of the previous match each
   Q.first_clean = false;                                  // until kseq_bin has run (an error in between leaves marks behind)
   launch_seq_prep(pa, st);
@@ -205,32 +232,7 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   KS_HIP(hipGetLastError());
   Q.first_clean = true;
 
-  // ---- 2. the coarse search's host half, while the kernels above run (Mapper.cpp:577-592)
-  const double cso = 0.5 * (static_cast<double>(m->side) - 1) * res;
-  const double csr = 2 * res;
-  CorrReq q;
-  q.slot = 0; q.scan = query;
-  std::copy(pose, pose + 3, q.center);
-  q.off_x = cso; q.off_y = cso; q.res_x = csr; q.res_y = csr;
-  q.ang_off = mp.coarse_search_angle_offset; q.ang_res = mp.coarse_angle_resolution; q.penalize = penalize; q.fine = false;
-  std::copy(cov, cov + 9, q.cov);
-  q.response = 0; q.status = KH_OK;
-  CorrHost c;
-  rc = init_ctx(q, c); if (rc) {return rc;}
-  rc = ensure_slot_scratch(m, q, c); if (rc) {return rc;}
-  // the fine search the device may run: Mapper.cpp:621-629
-  CorrReq qf;
-  qf.slot = 0; qf.scan = query;
-  qf.center[0] = qf.center[1] = qf.center[2] = 0.0;
-  qf.off_x = csr * 0.5; qf.off_y = csr * 0.5; qf.res_x = res; qf.res_y = res;
-  qf.ang_off = 0.5 * mp.coarse_angle_resolution; qf.ang_res = mp.fine_search_angle_offset; qf.penalize = penalize; qf.fine = true;
-  qf.response = 0; qf.status = KH_OK;
-  CorrHost cf;
-  bool device_fine = refine;
-  if (device_fine) {
-    if (init_ctx(qf, cf) != KH_OK || cf.nx != 3 || cf.ny != 3 || cf.na * 9 > kSeqMaxFine) {device_fine = false;}
-    else {rc = ensure_slot_scratch(m, qf, cf); if (rc) {return rc;}}
-  }
+  // ---- 2. the coarse search's host half (tables with libm), while the kernels above run
   const int32_t naf = device_fine ? cf.na : 1;
   const StageLayout L = stage_layout(c.P, c.nx, c.ny, c.na, q.penalize);
   const SeqLayout X = seq_layout(L.total, c.nx, c.ny, c.na, naf);
@@ -296,9 +298,10 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     launch_seq_stage(Q.h_stage, Q.d_stage, X.total, s.d_sums, plane * c.na, Q.d_out, out_words, st);
   }
   if (s.d_grid2 != nullptr) {launch_repitch(Q.d_job, 1, tiles, st, true);}
-  const bool fused_score = job->linear != 0 && shape.tiles == 1 && job->dec == 0 && job->lds_path == 0;
+  // table + scoring in one launch for every linear lattice (from the grid itself: a slot's copies, if it has any, are not used)
+  const bool fused_score = job->linear != 0 && job->lds_path == 0 && (job->sx == 1 || job->sx == 2);
   if (fused_score) {
-    launch_seq_score(Q.d_stage, c.na, c.P, shape.sx, shape.ry, st);
+    launch_seq_score(Q.d_stage, c.na, c.P, c.nx, c.ny, job->sx, pick_ry(c.ny), st);
     Q.stats[kSeqStatFusedScore] += 1;
   } else {
     launch_offsets(Q.d_stage, L.total, 1, c.na, st);
@@ -349,9 +352,11 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     for (int k = 0; k < 4; ++k) {Q.dbg_acc[1 + k] += (w[k + 1] - w[k]) * 0.01;}
     Q.dbg_acc[5] += static_cast<double>(w[5]);
     for (int k = 0; k < 4; ++k) {Q.dbg_acc[16 + k] += (w[16 + k + 1] - w[16 + k]) * 0.01;}
+    for (int k = 0; k < 2; ++k) {Q.dbg_acc[8 + k] += (w[8 + k + 1] - w[8 + k]) * 0.01;}
     if (++Q.dbg_calls % 64 == 0) {
       const double n = 64.0;
-      std::fprintf(stderr, "[kh seq] kseq_bin us: active set %.1f  count %.1f  scan %.1f  fill %.1f  (candidates %.0f);  kseq_final us: ties %.1f  "
+      std::fprintf(stderr, "[kh seq] kseq_prep (first scan) us: FindValidPoints %.1f  cells %.1f;  ", Q.dbg_acc[8] / 64.0, Q.dbg_acc[9] / 64.0);
+      std::fprintf(stderr, "kseq_bin us: active set %.1f  count %.1f  scan %.1f  fill %.1f  (candidates %.0f);  kseq_final us: ties %.1f  "
         "centre %.1f  fine scoring %.1f  finish %.1f\n", Q.dbg_acc[1] / n, Q.dbg_acc[2] / n, Q.dbg_acc[3] / n, Q.dbg_acc[4] / n, Q.dbg_acc[5] / n,
         Q.dbg_acc[16] / n, Q.dbg_acc[17] / n, Q.dbg_acc[18] / n, Q.dbg_acc[19] / n);
       for (double & v : Q.dbg_acc) {v = 0.0;}

@@ -29,8 +29,10 @@ __global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
   if (b < args.n_scans) {
     const int p0 = args.prefix[b], n = args.prefix[b + 1] - p0;
     uint8_t * flags = nullptr;
-    find_valid_scan(reinterpret_cast<const double2 *>(args.scans[b]), n, job.active + p0, job.view_x, job.view_y, args.max_n, s_fv, flags);
+    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[0] = (long long)wall_clock64();}
+    find_valid_scan<true>(reinterpret_cast<const double2 *>(args.scans[b]), n, job.active + p0, job.view_x, job.view_y, args.max_n, s_fv, flags);
     const double2 * P = s_fv;
+    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[1] = (long long)wall_clock64();}
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       int32_t gx = 0, gy = 0;
       bool on = flags[i] != 0;
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
       }
       *reinterpret_cast<int2 *>(job.cell_xy + 2 * (size_t)(p0 + i)) = cell;
     }
+    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[2] = (long long)wall_clock64();}
     return;
   }
   // Grid::Clear: one WAVE per tile the previous match wrote (lane = tile row, 64 bytes each) -- a workgroup walking its tiles one
@@ -159,11 +162,14 @@ __device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long lo
 
 // kseq_bin.  ONE workgroup of 1024 threads does what the batch path spreads over k_active_set, k_raster_bin, k_raster_scan,
 // k_raster_fill and k_repitch_keep -- for one job those are five launches of dependent round trips to L2 on a handful of
-// compute units; here the state lives in LDS:
+// compute units; here the state lives in LDS and the candidates (the first 8192: tid + 1024 k) in registers from the first
+// phase to the last:
 //  1. the order-dependent rule: a candidate is stamped iff no EARLIER STAMPED candidate has its cell in its 100-footprint -- the
 //     greedy independent set in point order (see k_active_set).  State byte per job point in LDS (0 undecided, 1 stamped,
-//     2 skipped); a candidate decides as soon as its earlier neighbours have; sweeps until nothing is undecided.  The first
-//     8192 candidates keep their neighbour links in registers.
+//     2 skipped); a candidate decides as soon as its earlier neighbours have.  NO barrier between the rounds: decisions never
+//     change, a stale read only delays, and every wave of the workgroup is resident -- the owner of the earliest undecided
+//     candidate always runs -- so each thread simply polls until its own candidates are decided (a barrier per round made the
+//     dependency chains along walls, a hundred cells long, cost a hundred barriers: 20 of the kernel's 47 us).
 //  2. every stamped candidate marks the occupancy blocks its footprint overlaps and takes its rank in the <= 2 x 2 tiles it
 //     overlaps from LDS counters; scan of the counters -> list starts, the list of non-empty tiles (which also becomes the
 //     "previous" list Grid::Clear of the next match zeroes); the lists are written from the ranks.
@@ -192,27 +198,30 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
   phase();
   const int tiles = job.tiles_w * job.tiles_h, bm_words = job.bm_w * job.bm_h;
   const int state_bytes = job.n_foot > 0 ? ((job.n_points + 15) & ~15) : 0;
-  uint8_t * state = s_dyn;
+  volatile uint8_t * state = s_dyn;
   int32_t * s_cnt = reinterpret_cast<int32_t *>(s_dyn + state_bytes);
   uint32_t * s_bm = reinterpret_cast<uint32_t *>(s_cnt + tiles);
   for (int i = tid; i < tiles; i += 1024) {s_cnt[i] = 0;}
   for (int i = tid; i < bm_words; i += 1024) {s_bm[i] = 0u;}
   const int4 * rec = reinterpret_cast<const int4 *>(cand);
-  if (job.n_foot > 0) {
-    int pr[kBinRegs];
-    int4 nbr[kBinRegs];
+  const int extra0 = 1024 * kBinRegs;                        // candidates from here on (rare) go through memory
+  int pr[kBinRegs], cxy[kBinRegs];
+  int4 nbr[kBinRegs];
 #pragma unroll
-    for (int k = 0; k < kBinRegs; ++k) {
-      const int i = tid + 1024 * k;
-      pr[k] = -1; nbr[k] = make_int4(-1, -1, -1, -1);
-      if (i < n_cand) {pr[k] = rec[2 * (size_t)i].x; nbr[k] = rec[2 * (size_t)i + 1];}
+  for (int k = 0; k < kBinRegs; ++k) {
+    const int i = tid + 1024 * k;
+    pr[k] = -1; cxy[k] = 0; nbr[k] = make_int4(-1, -1, -1, -1);
+    if (i < n_cand) {
+      const int4 a = rec[2 * (size_t)i];
+      pr[k] = a.x; cxy[k] = a.y | (a.z << 16);
+      if (job.n_foot > 0) {nbr[k] = rec[2 * (size_t)i + 1];}
     }
+  }
+  if (job.n_foot > 0) {
 #pragma unroll
     for (int k = 0; k < kBinRegs; ++k) {if (pr[k] >= 0) {state[pr[k]] = 0;}}
-    for (int i = tid + 1024 * kBinRegs; i < n_cand; i += 1024) {state[rec[2 * (size_t)i].x] = 0;}
+    for (int i = tid + extra0; i < n_cand; i += 1024) {state[rec[2 * (size_t)i].x] = 0;}
     __syncthreads();
-    // a candidate's fate is fixed once all its earlier neighbours are decided, decisions never change: whatever the order the
-    // lanes get to their candidates in, the fixpoint is the sequential answer
     auto decide = [&](int p, const int4 nb) -> bool {             // true = still undecided
       bool blocked = false, waiting = false;
       const int n4[4] = {nb.x, nb.y, nb.z, nb.w};
@@ -231,19 +240,19 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
     uint32_t undecided = 0;
 #pragma unroll
     for (int k = 0; k < kBinRegs; ++k) {if (pr[k] >= 0) {undecided |= 1u << k;}}
-    for (int sweep = 0; sweep <= n_cand; ++sweep) {
-      bool left = false;
+    bool extra_left = tid + extra0 < n_cand;
+    for (int spin = 0; (undecided != 0 || extra_left) && spin < (1 << 24); ++spin) {
 #pragma unroll
       for (int k = 0; k < kBinRegs; ++k) {
-        if ((undecided >> k) & 1u) {
-          if (decide(pr[k], nbr[k])) {left = true;} else {undecided &= ~(1u << k);}
+        if (((undecided >> k) & 1u) && !decide(pr[k], nbr[k])) {undecided &= ~(1u << k);}
+      }
+      if (extra_left) {
+        extra_left = false;
+        for (int i = tid + extra0; i < n_cand; i += 1024) {
+          const int p = rec[2 * (size_t)i].x;
+          if (state[p] == 0 && decide(p, rec[2 * (size_t)i + 1])) {extra_left = true;}
         }
       }
-      for (int i = tid + 1024 * kBinRegs; i < n_cand; i += 1024) {
-        const int p = rec[2 * (size_t)i].x;
-        if (state[p] == 0 && decide(p, rec[2 * (size_t)i + 1])) {left = true;}
-      }
-      if (!__syncthreads_or(left ? 1 : 0)) {break;}
     }
   }
   __syncthreads();
@@ -255,25 +264,37 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
     const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
     return (tx <= tx1 && ty <= ty1) ? ty * job.tiles_w + tx : -1;
   };
-  for (int i = tid; i < n_cand; i += 1024) {
-    const int4 a = rec[2 * (size_t)i];
-    const int p = a.x, cx = a.y, cy = a.z;
+  // one candidate: its cell goes back to "none" in the first-point table; if it is stamped: occupancy blocks, ranks in its tiles
+  auto count_one = [&](int p, int cx, int cy, int (&rk)[4]) -> bool {
     first[(size_t)(cy - job.roi_y) * job.roi_w + (cx - job.roi_x)] = kFirstNone;
-    const bool stamped = job.n_foot > 0 ? state[p] == 1 : true;
-    if (!stamped) {continue;}
-    cand[(size_t)kSeqCandWords * i + 3] = 1;
+    rk[0] = rk[1] = rk[2] = rk[3] = -1;
+    if (job.n_foot > 0 && state[p] != 1) {return false;}
     const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
     const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
     for (int by = fy0; by <= fy1; ++by) {
       for (int bx = fx0; bx <= fx1; ++bx) {atomicOr(&s_bm[by * job.bm_w + (bx >> 5)], 1u << (bx & 31));}
     }
-    int rk[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int t = tile_of(cx, cy, q);
-      rk[q] = t >= 0 ? atomicAdd(&s_cnt[t], 1) : -1;
+      if (t >= 0) {rk[q] = atomicAdd(&s_cnt[t], 1);}
     }
-    *reinterpret_cast<int4 *>(job.rank + 4 * (size_t)p) = make_int4(rk[0], rk[1], rk[2], rk[3]);
+    return true;
+  };
+  int rks[kBinRegs][4];
+  uint32_t stamped = 0;
+#pragma unroll
+  for (int k = 0; k < kBinRegs; ++k) {
+    rks[k][0] = rks[k][1] = rks[k][2] = rks[k][3] = -1;
+    if (pr[k] >= 0 && count_one(pr[k], cxy[k] & 0xffff, cxy[k] >> 16, rks[k])) {stamped |= 1u << k;}
+  }
+  for (int i = tid + extra0; i < n_cand; i += 1024) {
+    const int4 a = rec[2 * (size_t)i];
+    int rk[4];
+    if (count_one(a.x, a.y, a.z, rk)) {
+      cand[(size_t)kSeqCandWords * i + 3] = 1;
+      *reinterpret_cast<int4 *>(job.rank + 4 * (size_t)a.x) = make_int4(rk[0], rk[1], rk[2], rk[3]);
+    }
   }
   __syncthreads();
   phase();
@@ -305,17 +326,24 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
   }
   __syncthreads();
   phase();
-  for (int i = tid; i < n_cand; i += 1024) {
-    const int4 a = rec[2 * (size_t)i];
-    if (cand[(size_t)kSeqCandWords * i + 3] == 0) {continue;}
-    const int p = a.x, cx = a.y, cy = a.z;
-    const int4 r4 = *reinterpret_cast<const int4 *>(job.rank + 4 * (size_t)p);
-    const int rk[4] = {r4.x, r4.y, r4.z, r4.w};
+  // the lists, from the ranks (kseq_tile reads the cell from the entry itself)
+  auto fill_one = [&](int p, int cx, int cy, const int (&rk)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int t = tile_of(cx, cy, q);
-      if (t >= 0) {job.list[s_cnt[t] + rk[q]] = work2 ? (cx | (cy << 16)) : p;}    // kseq_tile reads the cell from the entry itself
+      if (t >= 0) {job.list[s_cnt[t] + rk[q]] = work2 ? (cx | (cy << 16)) : p;}
     }
+  };
+#pragma unroll
+  for (int k = 0; k < kBinRegs; ++k) {
+    if ((stamped >> k) & 1u) {fill_one(pr[k], cxy[k] & 0xffff, cxy[k] >> 16, rks[k]);}
+  }
+  for (int i = tid + extra0; i < n_cand; i += 1024) {
+    if (cand[(size_t)kSeqCandWords * i + 3] == 0) {continue;}
+    const int4 a = rec[2 * (size_t)i];
+    const int4 r4 = *reinterpret_cast<const int4 *>(job.rank + 4 * (size_t)a.x);
+    const int rk[4] = {r4.x, r4.y, r4.z, r4.w};
+    fill_one(a.x, a.y, a.z, rk);
   }
   for (int i = tid; i < bm_words; i += 1024) {job.blockmap[i] = s_bm[i];}
   phase();
@@ -457,20 +485,26 @@ void launch_seq_tile(const RasterJob * d_job, const uint8_t * d_tab, const int32
 }
 
 // ---------------------------------------------------------------------------------------------
-// kseq_score: GridIndexLookup::ComputeOffsets (Karto.h:6844-6894) and GetResponse (Mapper.cpp:1172-1208) of one search whose
-// window is one scoring tile, in one launch.  Workgroup = (angle, slice of kSeqSlice beams); its four waves compute the slice's
+// kseq_score: GridIndexLookup::ComputeOffsets (Karto.h:6844-6894) and GetResponse (Mapper.cpp:1172-1208) of one search on a
+// linear lattice, in one launch.  Workgroup = (angle, scoring tile, slice of kSeqSlice beams); its four waves compute the slice's
 // table entries (bit-exact, as k_offsets: every wave for itself, 64 beams at a time, lane = beam), wave c then walks the
 // beams of alignment class c exactly as k_score does -- aligned dword loads of the window's rows, packed 16-bit sums -- and
 // the slice's sums are ADDED to the volume (integers: the order does not matter).  One job has 21 angles: with the beams of
 // an angle in one workgroup (K3) the search is 21 workgroups walking 270 beams per wave one after the other; cut into slices
-// it is 357 workgroups of 16 per wave, eight beams' rows in flight.  Responses, best and ties follow in kseq_cells / kseq_final.
+// it is 357 workgroups of 16 per wave, eight beams' rows in flight.  A window of several tiles (the loop-closure search: 81 x 81
+// poses two cells apart = 3 x 3 tiles of 31 x 28) has a workgroup per tile and slice, and each tests ITS tile's rectangle against
+// the occupancy block map (what k_offsets' per-tile lists do): 126 workgroups walking long lists become 3 213 short ones, and the
+// column-decimated copies of the grid are not needed.  Responses, best and ties follow in kseq_cells / kseq_final.
 template <int SX, int RY>
-__global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slices)
+__global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slices, int tiles_x, int tiles_y)
 {
   const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobp);
-  const int a = blockIdx.x / slices, sl = blockIdx.x - a * slices;
   constexpr int PX = (SX == 1) ? kTileSpan : (kTileSpan + 1) / 2;
   constexpr int TY = 4 * RY;
+  const int tiles = tiles_x * tiles_y;
+  const int a = blockIdx.x / (slices * tiles), rest = blockIdx.x - a * (slices * tiles);
+  const int tile = rest / slices, sl = rest - tile * slices;
+  const int x0 = (tile % tiles_x) * PX, y0 = (tile / tiles_x) * TY;      // first pose of the tile
   constexpr int NB = (SX == 1) ? 4 : 2;
   constexpr int UB = 8;                    // beams (UB * RY row loads) in flight per wave
   const int lane = threadIdx.x & 63;
@@ -488,19 +522,22 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
   const double cosine = job.cos_sin[2 * a], sine = job.cos_sin[2 * a + 1];
   const int64_t bmin = job.base0;
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
-  const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;
+  const int32_t xs = (job.nx - 1) * job.sx + 1;              // cells a window covers in x
   const int ws = job.ws;
   const float inv_ws = 1.0f / (float)ws;
   const int64_t data_size = job.data_size, pad = job.pad;
   const uint32_t * const bmp = job.blockmap;
   const int cls = wave & 3;
-  const int s = cls;                                         // byte of a class-c window's first dword that belongs to pose 0
+  const int s = (cls + x0 * SX) & 3;                         // byte of a class-c window's first dword (of this tile) that belongs to pose x0
   const uint32_t sel = (s & 1) ? 0x0c030c01u : 0x0c020c00u;   // SX == 2: the even or the odd bytes
-  const gbyte * gbase = as_global(job.grid) + ((int64_t)job.base0 - s);
+  const gbyte * gbase = as_global(job.grid) + ((int64_t)job.base0 + x0 * SX - s);
+  // the tile's rectangle relative to the window start (cells), for the occupancy test
+  const int32_t tx_lo = x0 * job.sx, tx_hi = (min(job.nx, x0 + PX) - 1) * job.sx;
+  const int32_t ty_lo = y0 * job.sy_cells, ty_hi = (min(job.ny, y0 + TY) - 1) * job.sy_cells;
   uint32_t voff[RY];
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
-    int yi = r * 4 + ly;
+    int yi = y0 + r * 4 + ly;
     yi = yi < job.ny ? yi : job.ny - 1;                       // rows beyond ny are clamped (sums discarded)
     voff[r] = (uint32_t)(4 * lx) + (uint32_t)yi * (uint32_t)job.sy_ws;
   }
@@ -529,7 +566,7 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
         const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
         idx = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)ws);   // base Grid::GridIndex, no ROI
       }
-      if (wave == 0) {job.table[(size_t)a * P + i] = idx;}
+      if (wave == 0 && tile == 0) {job.table[(size_t)a * P + i] = idx;}
       if (idx != kInvalidScan && !((int64_t)idx + bmax < 0 || (int64_t)idx + bmin >= data_size)) {
         if ((int64_t)idx + bmin >= -pad && (int64_t)idx + bmax < data_size + pad) {
           fast = true;
@@ -540,7 +577,7 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
             int32_t wx0 = start - wy0 * ws;
             while (wx0 < 0) {wx0 += ws; --wy0;}
             while (wx0 >= ws) {wx0 -= ws; ++wy0;}
-            if (wx0 + xs <= ws && !window_has_blocks(bmp, job.bm_w, job.bm_h, wx0, wy0, wx0 + xs - 1, wy0 + ys - 1)) {fast = false;}
+            if (wx0 + xs <= ws && !window_has_blocks(bmp, job.bm_w, job.bm_h, wx0 + tx_lo, wy0 + ty_lo, wx0 + tx_hi, wy0 + ty_hi)) {fast = false;}
           }
           mycls = (int)(((int64_t)idx + bmin) & 3);
         } else if (wave == 0) {
@@ -616,7 +653,7 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
   const int n_slow = s_nslow;
   const size_t plane = (size_t)job.nx * job.ny;
   for (int p = threadIdx.x; p < TY * PX; p += 256) {
-    const int xi = p % PX, yi = p / PX;
+    const int xi = x0 + p % PX, yi = y0 + p / PX;
     if (xi >= job.nx || yi >= job.ny) {continue;}
     int32_t sum = s_tile[p];
     if (n_slow > 0) {
@@ -631,12 +668,14 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
   }
 }
 
-void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t sx, int32_t ry, void * stream)
+void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t nx, int32_t ny, int32_t sx, int32_t ry, void * stream)
 {
   const int slices = (n_points + kSeqSlice - 1) / kSeqSlice;
-  const dim3 grid((unsigned int)(na * slices));
+  const int px = sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;
+  const int tiles_x = (nx + px - 1) / px, tiles_y = (ny + 4 * ry - 1) / (4 * ry);
+  const dim3 grid((unsigned int)(na * slices * tiles_x * tiles_y));
   hipStream_t s = (hipStream_t)stream;
-#define KH_SEQ_SCORE(SXV, RYV) hipLaunchKernelGGL((kseq_score<SXV, RYV>), grid, dim3(256), 0, s, d_job, slices)
+#define KH_SEQ_SCORE(SXV, RYV) hipLaunchKernelGGL((kseq_score<SXV, RYV>), grid, dim3(256), 0, s, d_job, slices, tiles_x, tiles_y)
   if (sx == 2) {
     if (ry == 8) {KH_SEQ_SCORE(2, 8);} else if (ry == 7) {KH_SEQ_SCORE(2, 7);} else if (ry == 4) {KH_SEQ_SCORE(2, 4);} else {KH_SEQ_SCORE(2, 1);}
   } else {
@@ -711,7 +750,8 @@ __global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
   const int32_t * const sums = jr.sums;
   unsigned long long * const out = jr.out;
   const double * const dist_pen = jr.dist_pen, * const ang_pen = jr.ang_pen, * const local = jr.local;
-  const uint8_t * const grid = jr.grid, * const invalid = jr.invalid;
+  const gbyte * const grid = as_global(jr.grid);             // (global address space: the loads count on vmcnt only)
+  const uint8_t * const invalid = jr.invalid;
   int stamp = 0;
   auto phase = [&]() {if (A.dbg && tid == 0) {A.dbg[stamp] = (long long)wall_clock64();} ++stamp;};
   phase();
@@ -792,7 +832,7 @@ __global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
     const int32_t bxs[3] = {s_bx[0], s_bx[1], s_bx[2]};
     const int64_t bys[3] = {s_by[0], s_by[1], s_by[2]};
     const int total = naf * P;
-    constexpr int kPairs = 2;                                // (angle, beam) pairs a thread has in flight
+    constexpr int kPairs = 4;                                // (angle, beam) pairs a thread has in flight: 36 byte loads
     for (int p0 = tid; p0 - lane < total; p0 += kPairs * 1024) {    // (the trip count is the wave's: every lane takes part in the sums below)
       int kk[kPairs], ii[kPairs];
       int32_t idx[kPairs];
@@ -823,11 +863,27 @@ __global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
           idx[u] = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)ws);
         }
         if (on[u]) {A.fine_table[(size_t)kk[u] * P + ii[u]] = idx[u];}
+      }
+      // every load unconditional, at an address clamped into the array (a load under a condition is a branch and a wait of its
+      // own: eighteen of them one after the other were 59 of this kernel's 68 us); what GetResponse's range check
+      // (Mapper.cpp:1192-1197) or the beam's validity (:1194) excludes is zeroed afterwards
+      uint32_t ok[kPairs];
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) {
+        ok[u] = 0u;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
           const int64_t at = bys[j / 3] + bxs[j % 3] + idx[u];
-          v[u][j] = (on[u] && idx[u] != kInvalidScan && at >= 0 && at < data_size) ? grid[at] : (uint8_t)0;      // Mapper.cpp:1192-1197
+          const bool in = at >= 0 && at < data_size;
+          ok[u] |= in ? (1u << j) : 0u;
+          v[u][j] = grid[in ? (uint32_t)at : 0u];              // (32-bit offset from the grid's base: data_size < 2^31)
         }
+        if (!on[u] || idx[u] == kInvalidScan) {ok[u] = 0u;}
+      }
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {if (!((ok[u] >> j) & 1u)) {v[u][j] = 0;}}
       }
       // wave-level sums per angle (the lanes of a wave hold consecutive pairs: one angle, two where a wave straddles P)
 #pragma unroll

@@ -48,6 +48,7 @@ struct SeqPrepArgs
   int32_t * first;                         // roi_w * roi_h: smallest job point in the cell, kFirstNone = none (left clean by kseq_bin)
   int32_t * ctl;                           // [0] candidates (zeroed here)
   int32_t clear_blocks;
+  long long * dbg;                         // nullptr, or three wall_clock64 stamps of the first scan's workgroup (measurements)
 };
 
 // fine pass of the device (results in host-coherent memory)
@@ -97,7 +98,8 @@ void launch_raster_tiles(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_p
   void * stream);
 void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words,
   void * stream);
-void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t sx, int32_t ry, void * stream);
+// (sx = grid cells per lattice step, ry = rows per lane: the windowed kernel's tile shape, pick_ry)
+void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t nx, int32_t ny, int32_t sx, int32_t ry, void * stream);
 void launch_seq_cells(const uint8_t * d_job, int32_t plane, unsigned long long * h_lattice, void * stream);
 void launch_seq_final(const SeqFinalArgs & args, void * stream);
 

@@ -555,12 +555,16 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       size_t at = 0;
       for (const Pending & q : pending) {
         std::memcpy(s->h_upload + at, q.src, q.bytes);
-        KS_HIP(hipMemcpyAsync(q.dst, s->h_upload + at, q.bytes, hipMemcpyHostToDevice, st));
+        if (hipMemcpyAsync(q.dst, s->h_upload + at, q.bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+          (void)hipStreamSynchronize(st);        // the copies already queued read the staging block: nobody may reuse it under them
+          set_error("hipMemcpyAsync: upload of the analysis");
+          return KH_ERR_HIP;
+        }
         at += (q.bytes + 63) & ~static_cast<size_t>(63);
       }
     }
     r2 |= s->d_winv.ensure(static_cast<size_t>(sym.winv_size) + 16);
-    if (r2) {return KH_ERR_HIP;}
+    if (r2) {(void)hipStreamSynchronize(st); return KH_ERR_HIP;}
     s->n_slots = n_slots;
     const size_t scratch = std::max<size_t>(static_cast<size_t>(21) * E, static_cast<size_t>(9) * nf + 16);
     r2 |= s->d_edge_lin.ensure(scratch); r2 |= s->d_edge_cost.ensure(std::max(E, 1));
@@ -575,7 +579,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_upd.ensure(static_cast<size_t>(3) * sym.rows_ptr[sym.n_fronts] + 16);
     r2 |= s->d_partial.ensure(static_cast<size_t>(5) * ((nf + 255) / 256) + (E + 255) / 256 + static_cast<size_t>(2) * ((3 * nf + 255) / 256) + 32);
     r2 |= s->d_fsb.ensure(static_cast<size_t>(3) * (static_cast<size_t>(nf) + sym.rows_ptr[sym.n_fronts]) + 16);
-    if (r2) {return KH_ERR_HIP;}
+    if (r2) {(void)hipStreamSynchronize(st); return KH_ERR_HIP;}
     // the uploads above read pageable host vectors of this block: they must have landed before the block ends
     KS_HIP(hipStreamSynchronize(st));
     s->topology_dirty = false;
@@ -1392,7 +1396,10 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     bool step_valid = s->h_fail[0] == 0 && nonfinite == 0.0 && std::isfinite(model_cost_change) && model_cost_change > 0.0;
     if (!step_valid) {
       ++num_invalid;
-      if (num_invalid >= opt.max_num_consecutive_invalid_steps) {sum.termination = 2; sum.usable = 0; break;}
+      if (num_invalid >= opt.max_num_consecutive_invalid_steps) {
+        trace(x_cost, cand_cost, model_cost_change, radius, radius, step_norm, -1.0);     // (one log row per iteration, this one included)
+        sum.termination = 2; sum.usable = 0; break;
+      }
       trace(x_cost, cand_cost, model_cost_change, radius, radius / decrease_factor, step_norm, -1.0);
       radius = radius / decrease_factor;      // StepIsInvalid -> StepRejected(0)
       decrease_factor *= 2.0;

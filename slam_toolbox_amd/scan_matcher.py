@@ -300,6 +300,12 @@ class ScanMatcher:
                    "kh_matcher_profile")
         return {"score_ms": sm.value, "score_launches": sl.value, "raster_ms": rm.value, "raster_launches": rl.value}
 
+    def profile_side(self):
+        """GPU ms of the table / list kernel (K2) and the tie kernel (K4) of the launches profiled since the last call"""
+        o, t = C.c_double(), C.c_double()
+        capi.check(capi.lib().kh_matcher_profile_side(self._h, C.byref(o), C.byref(t)), "kh_matcher_profile_side")
+        return {"offsets_ms": o.value, "ties_ms": t.value}
+
     def score_loads(self, reset=True):
         """wave-level dword-load instructions (256 B each) K3 issued for the searches run while profiling was on"""
         n = C.c_int64()
