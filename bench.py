@@ -1259,7 +1259,7 @@ def main():
                          "unit": "GB/s", "frac": lds_gbs / LDS_B32_PEAK_GBS,
                          "window_reads_per_launch": loads_per_launch, "avg_launch_ms": k3_ms, "matches_per_launch": per_launch,
                          "lookups_per_cu_clk": lookups_all / cu_clocks, "lookups_per_cu_clk_read": lookups_read / cu_clocks,
-                         "lookups_per_cu_clk_peak_b32": 128.0, "lds_array_frac": lds_gbs / (2.0 * LDS_B32_PEAK_GBS),
+                         "lookups_per_cu_clk_peak_b32": 128.0 * C2["nx"] * C2["ny"] / 4096.0, "lds_array_frac": lds_gbs / (2.0 * LDS_B32_PEAK_GBS),
                          "side_kernels_ms_per_launch": {"k_offsets_lds": side["offsets_ms"] / max(1, prof["score_launches"]),
                                                         "k_ties": side["ties_ms"] / max(1, prof["score_launches"])},
                          "traffic": traffic, "hbm_frac": (traffic / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
