@@ -106,8 +106,10 @@ __device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w
 // s_fv: max_n double2 + 3 * (max_n + 64) int32 + 2 * (max_n + 64) bytes of dynamic LDS.  Any block size that is a multiple of 64.
 template <bool kWaveSearch>
 __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n, uint8_t * out, const double vx, const double vy,
-  const int max_n, double2 * s_fv, uint8_t *& flags_lds)
+  const int max_n, double2 * s_fv, uint8_t *& flags_lds, long long * dbg = nullptr)
 {
+  // (dbg: wall_clock64 stamps of the phases, one workgroup's thread 0 -- measurements)
+#define KH_FV_STAMP(k) do {if (dbg && threadIdx.x == 0) {dbg[k] = (long long)wall_clock64();}} while (0)
   // one workgroup per scan: a lane owns every 256th reading, so the divergent forward scans of next() cost a lane four or
   // five readings' worth of its slowest neighbour instead of seventeen (one wave per scan: 56 us for 20 scans)
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
@@ -123,8 +125,10 @@ __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n
   __shared__ unsigned long long s_mask[40];               // triggers of every chunk of 64 readings (max_n <= 2048 -> 32 chunks)
   __shared__ int s_later[40];                             // first trigger in the chunks behind chunk c, -1 = none
   if (tid == 0) {s_pos0 = n;}
+  KH_FV_STAMP(0);
   for (int i = tid; i < n; i += nthreads) {P[i] = pts[i]; reach[i] = 0; keep[i] = 0;}
   __syncthreads();
+  KH_FV_STAMP(1);
   const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
   // the first reading without a NaN coordinate is the first anchor (Mapper.cpp:1127-1136)
   {
@@ -171,6 +175,7 @@ __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n
   }
   if (tid == 0) {nxt0[n] = n; reach[n] = 0;}
   __syncthreads();
+  KH_FV_STAMP(2);
   const int pos0 = s_pos0;
   if (pos0 >= n) {
     for (int i = tid; i < n; i += nthreads) {out[i] = 0; flags_lds[i] = 0;}
@@ -192,6 +197,7 @@ __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n
     cur = nxt_w;
     nxt_w = (nxt_w == nxa) ? nxb : nxa;
   }
+  KH_FV_STAMP(3);
   // every visited trigger: which side of the line viewpoint -> anchor it lies on (its anchor is the visited reading whose
   // next() it is)
   for (int i = tid; i < n; i += nthreads) {
@@ -214,6 +220,7 @@ __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n
     if (lane == 0) {s_mask[base >> 6] = mask;}
   }
   __syncthreads();
+  KH_FV_STAMP(4);
   if (tid == 0) {
     int later = -1;
     for (int c = n_chunks - 1; c >= 0; --c) {
@@ -231,6 +238,8 @@ __device__ __forceinline__ void find_valid_scan(const double2 * pts, const int n
     flags_lds[i] = flag;
   }
   __syncthreads();
+  KH_FV_STAMP(5);
+#undef KH_FV_STAMP
 }
 
 // The search-space probabilities (Mapper.cpp:781-799): the best response over the angles of every cell of the lattice, from the

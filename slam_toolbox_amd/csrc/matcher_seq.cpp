@@ -18,6 +18,7 @@ struct SeqState
   int32_t * d_first = nullptr; size_t cap_first = 0; bool first_clean = false;
   int32_t * d_cand = nullptr; size_t cap_cand = 0;
   int32_t * d_ctl = nullptr;
+  SeqMid * d_mid = nullptr; int32_t * d_fsum = nullptr;
   RasterJob * d_job = nullptr;
   uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_hstage = 0, cap_dstage = 0;
   unsigned long long * h_out = nullptr; unsigned long long * d_out = nullptr; size_t cap_hout = 0, cap_dout = 0;
@@ -26,7 +27,7 @@ struct SeqState
   int32_t seq = 0;
   uint8_t * d_tab = nullptr;              // padded image of the smear kernel for kseq_tile
   int32_t * d_work2 = nullptr; size_t cap_work2 = 0;
-  long long * d_dbg = nullptr;            // KH_SEQ_TIMING=1: phase stamps of kseq_bin [0..15] and kseq_final [16..31]
+  long long * d_dbg = nullptr;            // KH_SEQ_TIMING=1: phase stamps of kseq_bin [0..7], kseq_prep [8..15], the final kernels [16..31]
   double dbg_acc[32] = {0}; long dbg_calls = 0;
   std::vector<uint8_t> fine_scratch;
   int64_t stats[kSeqStatWords] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -45,7 +46,7 @@ void seq_destroy(kh_matcher * m)
 {
   SeqState * q = m->seq;
   if (!q) {return;}
-  (void)hipFree(q->d_dbg); (void)hipFree(q->d_tab); (void)hipFree(q->d_work2); (void)hipFree(q->d_first); (void)hipFree(q->d_cand); (void)hipFree(q->d_ctl); (void)hipFree(q->d_job); (void)hipFree(q->d_stage); (void)hipFree(q->d_out);
+  (void)hipFree(q->d_dbg); (void)hipFree(q->d_tab); (void)hipFree(q->d_work2); (void)hipFree(q->d_first); (void)hipFree(q->d_cand); (void)hipFree(q->d_ctl); (void)hipFree(q->d_mid); (void)hipFree(q->d_fsum); (void)hipFree(q->d_job); (void)hipFree(q->d_stage); (void)hipFree(q->d_out);
   if (q->h_stage) {(void)hipHostFree(q->h_stage);}
   if (q->h_out) {(void)hipHostFree(q->h_out);}
   if (q->h_fine) {(void)hipHostFree(q->h_fine);}
@@ -124,6 +125,8 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   if (!Q.d_ctl) {
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_ctl), sizeof(int32_t) * kSeqCtlWords));
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_job), sizeof(RasterJob)));
+    KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_mid), sizeof(SeqMid)));
+    KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_fsum), sizeof(int32_t) * kSeqMaxFine));
     size_t one = 0;
     rc = ensure_coherent(Q.h_fine, one, 1); if (rc) {return rc;}
     one = 0;
@@ -224,13 +227,12 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   pa.n_scans = n_scans; pa.max_n = max_n;
   pa.dbg = Q.d_dbg ? Q.d_dbg + 8 : nullptr;
   pa.d_job = Q.d_job; pa.first = Q.d_first; pa.ctl = Q.d_ctl; pa.clear_blocks = 128;     // 2048 waves: one tile of the previous match each
-  Q.first_clean = false;                                  // until kseq_bin has run (an error in between leaves marks behind)
+  Q.first_clean = false;                                  // until the stamping launch has handed the table back (an error in between leaves marks behind)
   launch_seq_prep(pa, st);
   launch_seq_links(Q.d_job, np, Q.d_first, Q.d_cand, Q.d_ctl, st);
   const bool has_copies = s.d_grid2 != nullptr;
-  launch_seq_bin(Q.d_job, Q.d_first, Q.d_cand, Q.d_ctl, has_copies ? 0 : 1, bin_lds, fused_tiles ? Q.d_work2 : nullptr, Q.d_dbg, st);
+  launch_seq_bin(Q.d_job, Q.d_cand, Q.d_ctl, has_copies ? 0 : 1, bin_lds, fused_tiles ? Q.d_work2 : nullptr, Q.d_dbg, st);
   KS_HIP(hipGetLastError());
-  Q.first_clean = true;
 
   // ---- 2. the coarse search's host half (tables with libm), while the kernels above run
   const int32_t naf = device_fine ? cf.na : 1;
@@ -291,12 +293,18 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   }
   // ---- 3. the stamps (with the tables' way to the device in the same launch), scoring, finalisation on the device
   const size_t plane = static_cast<size_t>(c.nx) * c.ny;
+  SeqStageArgs sa;
+  sa.h_stage = Q.h_stage; sa.d_stage = Q.d_stage; sa.bytes = X.total;
+  sa.sums = s.d_sums; sa.n_sums = plane * c.na; sa.out = Q.d_out; sa.out_words = out_words;
+  sa.cand = Q.d_cand; sa.ctl = Q.d_ctl; sa.first = Q.d_first; sa.roi_x = m->roi_x; sa.roi_y = m->roi_y; sa.roi_w = m->roi_w;
   if (fused_tiles) {
-    launch_seq_tile(Q.d_job, Q.d_tab, Q.d_work2, np, tiles, Q.h_stage, Q.d_stage, X.total, s.d_sums, plane * c.na, Q.d_out, out_words, st);
+    launch_seq_tile(Q.d_job, Q.d_tab, Q.d_work2, np, tiles, sa, st);
   } else {
     launch_raster_tiles(Q.d_job, 1, np, tiles, m->d_kernel, m->kernel_size, st);
-    launch_seq_stage(Q.h_stage, Q.d_stage, X.total, s.d_sums, plane * c.na, Q.d_out, out_words, st);
+    launch_seq_stage(sa, st);
   }
+  KS_HIP(hipGetLastError());
+  Q.first_clean = true;
   if (s.d_grid2 != nullptr) {launch_repitch(Q.d_job, 1, tiles, st, true);}
   // table + scoring in one launch for every linear lattice (from the grid itself: a slot's copies, if it has any, are not used)
   const bool fused_score = job->linear != 0 && job->lds_path == 0 && (job->sx == 1 || job->sx == 2);
@@ -324,7 +332,8 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   fa.roi_x = m->roi_x; fa.roi_y = m->roi_y;
   fa.fine_table = s.d_table; fa.fine_sums = s.d_sums;
   fa.dbg = Q.d_dbg ? Q.d_dbg + 16 : nullptr;
-  launch_seq_final(fa, st);
+  fa.mid = Q.d_mid; fa.fsum = Q.d_fsum;
+  launch_seq_final(fa, c.P, st);
   KS_HIP(hipGetLastError());
   Q.stats[kSeqStatCalls] += 1;
   // ---- 4. wait for the flag (the kernel's last store, system scope); the stream is asked now and then so that a failed launch
@@ -351,14 +360,15 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     KS_HIP(hipMemcpy(w, Q.d_dbg, sizeof(w), hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; ++k) {Q.dbg_acc[1 + k] += (w[k + 1] - w[k]) * 0.01;}
     Q.dbg_acc[5] += static_cast<double>(w[5]);
-    for (int k = 0; k < 4; ++k) {Q.dbg_acc[16 + k] += (w[16 + k + 1] - w[16 + k]) * 0.01;}
-    for (int k = 0; k < 2; ++k) {Q.dbg_acc[8 + k] += (w[8 + k + 1] - w[8 + k]) * 0.01;}
+    for (int k = 0; k < 3; ++k) {Q.dbg_acc[16 + k] += (w[16 + k + 1] - w[16 + k]) * 0.01;}
+    for (int k = 0; k < 6; ++k) {Q.dbg_acc[8 + k] += (w[8 + k + 1] - w[8 + k]) * 0.01;}
     if (++Q.dbg_calls % 64 == 0) {
       const double n = 64.0;
-      std::fprintf(stderr, "[kh seq] kseq_prep (first scan) us: FindValidPoints %.1f  cells %.1f;  ", Q.dbg_acc[8] / 64.0, Q.dbg_acc[9] / 64.0);
-      std::fprintf(stderr, "kseq_bin us: active set %.1f  count %.1f  scan %.1f  fill %.1f  (candidates %.0f);  kseq_final us: ties %.1f  "
-        "centre %.1f  fine scoring %.1f  finish %.1f\n", Q.dbg_acc[1] / n, Q.dbg_acc[2] / n, Q.dbg_acc[3] / n, Q.dbg_acc[4] / n, Q.dbg_acc[5] / n,
-        Q.dbg_acc[16] / n, Q.dbg_acc[17] / n, Q.dbg_acc[18] / n, Q.dbg_acc[19] / n);
+      std::fprintf(stderr, "[kh seq] kseq_prep (first scan) us: load %.1f  next %.1f  reach %.1f  sides+masks %.1f  flags %.1f  cells %.1f;  ", Q.dbg_acc[8] / 64.0,
+        Q.dbg_acc[9] / 64.0, Q.dbg_acc[10] / 64.0, Q.dbg_acc[11] / 64.0, Q.dbg_acc[12] / 64.0, Q.dbg_acc[13] / 64.0);
+      std::fprintf(stderr, "kseq_bin us: active set %.1f  count %.1f  scan %.1f  fill %.1f  (candidates %.0f);  the end us: kseq_ties %.1f  "
+        "kseq_fine (+ boundaries) %.1f  kseq_done %.1f\n", Q.dbg_acc[1] / n, Q.dbg_acc[2] / n, Q.dbg_acc[3] / n, Q.dbg_acc[4] / n, Q.dbg_acc[5] / n,
+        Q.dbg_acc[16] / n, Q.dbg_acc[17] / n, Q.dbg_acc[18] / n);
       for (double & v : Q.dbg_acc) {v = 0.0;}
     }
   }

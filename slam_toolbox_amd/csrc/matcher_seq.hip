@@ -29,10 +29,9 @@ __global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
   if (b < args.n_scans) {
     const int p0 = args.prefix[b], n = args.prefix[b + 1] - p0;
     uint8_t * flags = nullptr;
-    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[0] = (long long)wall_clock64();}
-    find_valid_scan<true>(reinterpret_cast<const double2 *>(args.scans[b]), n, job.active + p0, job.view_x, job.view_y, args.max_n, s_fv, flags);
+    find_valid_scan<false>(reinterpret_cast<const double2 *>(args.scans[b]), n, job.active + p0, job.view_x, job.view_y, args.max_n, s_fv, flags,
+      b == 0 ? args.dbg : nullptr);
     const double2 * P = s_fv;
-    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[1] = (long long)wall_clock64();}
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       int32_t gx = 0, gy = 0;
       bool on = flags[i] != 0;
@@ -44,7 +43,7 @@ __global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
       }
       *reinterpret_cast<int2 *>(job.cell_xy + 2 * (size_t)(p0 + i)) = cell;
     }
-    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[2] = (long long)wall_clock64();}
+    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[6] = (long long)wall_clock64();}
     return;
   }
   // Grid::Clear: one WAVE per tile the previous match wrote (lane = tile row, 64 bytes each) -- a workgroup walking its tiles one
@@ -164,6 +163,7 @@ __device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long lo
 // k_raster_fill and k_repitch_keep -- for one job those are five launches of dependent round trips to L2 on a handful of
 // compute units; here the state lives in LDS and the candidates (the first 8192: tid + 1024 k) in registers from the first
 // phase to the last:
+//  (the first-point table is handed back clean by the launch that follows: stage_copy)
 //  1. the order-dependent rule: a candidate is stamped iff no EARLIER STAMPED candidate has its cell in its 100-footprint -- the
 //     greedy independent set in point order (see k_active_set).  State byte per job point in LDS (0 undecided, 1 stamped,
 //     2 skipped); a candidate decides as soon as its earlier neighbours have.  NO barrier between the rounds: decisions never
@@ -173,9 +173,8 @@ __device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long lo
 //  2. every stamped candidate marks the occupancy blocks its footprint overlaps and takes its rank in the <= 2 x 2 tiles it
 //     overlaps from LDS counters; scan of the counters -> list starts, the list of non-empty tiles (which also becomes the
 //     "previous" list Grid::Clear of the next match zeroes); the lists are written from the ranks.
-//  3. first[] goes back to "none" for the cells this match touched (every touched cell has exactly one candidate).
 constexpr int kBinRegs = 8;
-__global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t * __restrict__ first, int32_t * cand, const int32_t * ctl, int keep_prev,
+__global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t * cand, const int32_t * ctl, int keep_prev,
   int4 * work2, long long * dbg)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -207,11 +206,15 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
   const int extra0 = 1024 * kBinRegs;                        // candidates from here on (rare) go through memory
   int pr[kBinRegs], cxy[kBinRegs];
   int4 nbr[kBinRegs];
+  // a thread's candidates are NEIGHBOURS in the list: kseq_links appends wave by wave, each wave's firsts in point order, and the
+  // dependency chains of the rule run along walls in point order -- so a chain link is mostly decided by the thread that decided
+  // the link before it, in the same trip of its loop, instead of waiting for another wave's next trip
+  const int per = min(kBinRegs, (n_cand + 1023) / 1024);
 #pragma unroll
   for (int k = 0; k < kBinRegs; ++k) {
-    const int i = tid + 1024 * k;
+    const int i = tid * per + k;
     pr[k] = -1; cxy[k] = 0; nbr[k] = make_int4(-1, -1, -1, -1);
-    if (i < n_cand) {
+    if (k < per && i < n_cand) {
       const int4 a = rec[2 * (size_t)i];
       pr[k] = a.x; cxy[k] = a.y | (a.z << 16);
       if (job.n_foot > 0) {nbr[k] = rec[2 * (size_t)i + 1];}
@@ -266,13 +269,16 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
   };
   // one candidate: its cell goes back to "none" in the first-point table; if it is stamped: occupancy blocks, ranks in its tiles
   auto count_one = [&](int p, int cx, int cy, int (&rk)[4]) -> bool {
-    first[(size_t)(cy - job.roi_y) * job.roi_w + (cx - job.roi_x)] = kFirstNone;
     rk[0] = rk[1] = rk[2] = rk[3] = -1;
     if (job.n_foot > 0 && state[p] != 1) {return false;}
     const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
     const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
     for (int by = fy0; by <= fy1; ++by) {
-      for (int bx = fx0; bx <= fx1; ++bx) {atomicOr(&s_bm[by * job.bm_w + (bx >> 5)], 1u << (bx & 31));}
+      for (int bx = fx0; bx <= fx1; ++bx) {
+        uint32_t * word = &s_bm[by * job.bm_w + (bx >> 5)];
+        const uint32_t bit = 1u << (bx & 31);
+        if ((*reinterpret_cast<volatile uint32_t *>(word) & bit) == 0u) {atomicOr(word, bit);}      // (set already for all but the first stamps of a block)
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -356,12 +362,12 @@ size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_
   return state_bytes + 4 * (size_t)tiles + 4 * (size_t)bm_words + 16;
 }
 
-int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
+int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
   void * stream)
 {
   static std::atomic<unsigned long long> done{0};
   allow_dynamic_lds(reinterpret_cast<const void *>(kseq_bin), 158 * 1024, done);
-  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, first, cand, ctl, (int)keep_prev, reinterpret_cast<int4 *>(work2), dbg);
+  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, cand, ctl, (int)keep_prev, reinterpret_cast<int4 *>(work2), dbg);
   return 0;
 }
 
@@ -370,12 +376,22 @@ int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int
 // workgroup that uses them -- and the sums volume / result block of the coarse pass zeroed.  Runs as the last workgroups of the
 // stamping launch (the host makes the tables while kseq_prep .. kseq_bin run, and nothing reads them before kseq_score), or
 // as a launch of its own in front of the batch path's stamping kernel.
-struct SeqStage {const uint4 * src; uint4 * dst; int units; int32_t * sums; int n_sums; unsigned long long * out; int out_words;};
+// ... and the first-point table handed back clean: every cell this match touched has exactly one candidate.
+struct SeqStage
+{
+  const uint4 * src; uint4 * dst; int units; int32_t * sums; int n_sums; unsigned long long * out; int out_words;
+  const int32_t * cand; const int32_t * ctl; int32_t * first; int roi_x, roi_y, roi_w;
+};
 __device__ __forceinline__ void stage_copy(const SeqStage & g, int tid, int nth)
 {
+  const int n_cand = g.ctl[0];
   for (int i = tid; i < g.units; i += nth) {g.dst[i] = g.src[i];}
   for (int i = tid; i < g.n_sums; i += nth) {g.sums[i] = 0;}
   for (int i = tid; i < g.out_words; i += nth) {g.out[i] = 0ull;}
+  for (int i = tid; i < n_cand; i += nth) {
+    const int4 a = reinterpret_cast<const int4 *>(g.cand)[2 * (size_t)i];
+    g.first[(size_t)(a.z - g.roi_y) * g.roi_w + (a.y - g.roi_x)] = kFirstNone;
+  }
 }
 __global__ __launch_bounds__(256) void kseq_stage(const SeqStage g)
 {
@@ -453,12 +469,19 @@ __global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobp, const u
   }
 }
 
-void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words,
-  void * stream)
+static SeqStage make_stage(const SeqStageArgs & a)
 {
   SeqStage g;
-  g.src = reinterpret_cast<const uint4 *>(h_stage); g.dst = reinterpret_cast<uint4 *>(d_stage); g.units = (int)((bytes + 15) / 16);
-  g.sums = sums; g.n_sums = (int)n_sums; g.out = out; g.out_words = (int)out_words;
+  g.src = reinterpret_cast<const uint4 *>(a.h_stage); g.dst = reinterpret_cast<uint4 *>(a.d_stage); g.units = (int)((a.bytes + 15) / 16);
+  g.sums = a.sums; g.n_sums = (int)a.n_sums; g.out = a.out; g.out_words = (int)a.out_words;
+  g.cand = a.cand; g.ctl = a.ctl; g.first = a.first; g.roi_x = a.roi_x; g.roi_y = a.roi_y; g.roi_w = a.roi_w;
+  return g;
+}
+
+void launch_seq_stage(const SeqStageArgs & a, void * stream)
+{
+  const SeqStage g = make_stage(a);
+  const size_t n_sums = a.n_sums;
   const int blocks = std::max(1, std::min(64, (int)((std::max<size_t>(g.units, n_sums) + 255) / 256)));
   hipLaunchKernelGGL(kseq_stage, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
 }
@@ -474,11 +497,9 @@ void seq_tile_table(const uint8_t * kernel, int32_t kernel_size, uint8_t * out)
 }
 
 void launch_seq_tile(const RasterJob * d_job, const uint8_t * d_tab, const int32_t * d_work2, int32_t max_points, int32_t max_tiles,
-  const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words, void * stream)
+  const SeqStageArgs & a, void * stream)
 {
-  SeqStage g;
-  g.src = reinterpret_cast<const uint4 *>(h_stage); g.dst = reinterpret_cast<uint4 *>(d_stage); g.units = (int)((bytes + 15) / 16);
-  g.sums = sums; g.n_sums = (int)n_sums; g.out = out; g.out_words = (int)out_words;
+  const SeqStage g = make_stage(a);
   const int tile_blocks = std::max(1, std::min(std::min(max_tiles, 4 * max_points), 1024));
   hipLaunchKernelGGL(kseq_tile, dim3(tile_blocks + kTileStageBlocks), dim3(512), 0, (hipStream_t)stream, d_job, reinterpret_cast<const uint4 *>(d_tab),
     reinterpret_cast<const int4 *>(d_work2), tile_blocks, g);
@@ -720,47 +741,41 @@ __device__ __forceinline__ int wave_prefix_add(int v)
   return v;
 }
 
-// kseq_final, ONE workgroup.  (1) the poses within KT_TOLERANCE of the best (Mapper.cpp:802-817): only cells whose maximum ties
-// with the best can hold one; the (cell, angle) pairs of those cells are dealt over the threads.  (2) When the coarse pass has
-// exactly ONE best pose -- the common case -- its average is that pose: x and y are lattice values (centre + offset, the host's
-// doubles), the heading atan2(sin h, cos h) comes from a table the host made per search angle.  The fine pass around it
-// (Mapper.cpp:621-629: 3 x 3 cells, naf angles) is then scored right here: lattice indices by WorldToGrid's IEEE operations, the
-// angles' cosines and sines from the host's table for coarse angle a (no libm on the device), every lookup with GetResponse's
-// range check -- the naf x P (angle, beam) pairs dealt over the threads two at a time, nine byte loads each, wave-level sums in
-// registers -- then responses, best, ties.  The host checks the centre and the lattice indices the device used against its own
-// and redoes the fine pass itself if they differ or if the coarse pass had several best poses (their mean needs atan2).
-// (3) Everything the host needs goes to host-coherent memory, then the flag.
-__global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
+// The end of a match in three short launches (a kernel boundary costs 1.5 us; ONE workgroup pulling the fine pass's 107 000
+// scattered grid bytes through its compute unit's miss queue cost 58):
+//   kseq_ties  ONE workgroup: the poses within KT_TOLERANCE of the best (Mapper.cpp:802-817) -- only cells whose maximum ties
+//              with the best can hold one; their (cell, angle) pairs are dealt over the threads.  When the coarse pass has exactly
+//              ONE best pose -- the common case -- its average is that pose: x and y are lattice values (centre + offset, the
+//              host's doubles), the heading atan2(sin h, cos h) comes from a table the host made per search angle; the fine
+//              search's lattice indices (Mapper.cpp:649-662) follow by WorldToGrid's IEEE operations.
+//   kseq_fine  the fine pass around it (Mapper.cpp:621-629: 3 x 3 cells, naf angles), a WAVE per (angle, 64 beams): the angles'
+//              cosines and sines from the host's table for coarse angle a (no libm on the device), every lookup with
+//              GetResponse's range check, wave-level sums, nine atomics per wave.
+//   kseq_done  ONE workgroup: responses, best, ties of the fine pass; everything the host needs into host-coherent memory, then
+//              the flag.
+// The host checks the centre and the lattice indices the device used against its own and redoes the fine pass itself if they
+// differ or if the coarse pass had several best poses (their mean needs atan2).
+__global__ __launch_bounds__(1024) void kseq_ties(const SeqFinalArgs A)
 {
-  __shared__ int s_nt, s_fnt, s_a, s_ncell;
+  __shared__ int s_nt, s_ncell;
   __shared__ uint32_t s_tie0;
   __shared__ int32_t s_cells[1024];
-  __shared__ double s_centre[3];
-  __shared__ int32_t s_bx[4], s_by[4];
-  __shared__ int32_t s_fsum[kSeqMaxFine];
-  __shared__ double s_cs[2 * (kSeqMaxFine / 9)];
-  __shared__ unsigned long long s_fbest;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   // everything read from the job, once (behind a store the compiler must assume the job block itself changed)
   const CorrJob & jr = *reinterpret_cast<const CorrJob *>(A.job);
-  const int nx = jr.nx, na = jr.na, plane = jr.nx * jr.ny, P = jr.n_points, ws = jr.ws;
+  const int nx = jr.nx, na = jr.na, plane = jr.nx * jr.ny, ws = jr.ws;
   const bool penal = jr.do_penalize != 0;
   const double denom = jr.denom, goff_x = jr.grid_off_x, goff_y = jr.grid_off_y, scale = jr.scale;
-  const int64_t data_size = jr.data_size;
   const int32_t * const sums = jr.sums;
   unsigned long long * const out = jr.out;
-  const double * const dist_pen = jr.dist_pen, * const ang_pen = jr.ang_pen, * const local = jr.local;
-  const gbyte * const grid = as_global(jr.grid);             // (global address space: the loads count on vmcnt only)
-  const uint8_t * const invalid = jr.invalid;
-  int stamp = 0;
-  auto phase = [&]() {if (A.dbg && tid == 0) {A.dbg[stamp] = (long long)wall_clock64();} ++stamp;};
-  phase();
+  const double * const dist_pen = jr.dist_pen, * const ang_pen = jr.ang_pen;
+  if (A.dbg && tid == 0) {A.dbg[0] = (long long)wall_clock64();}
   const double best = __longlong_as_double((long long)out[0]);
   const unsigned long long * lattice = out + kOutHeaderWords;
   uint32_t * tie_idx = reinterpret_cast<uint32_t *>(out + 2);
   uint32_t * h_tie = reinterpret_cast<uint32_t *>(A.h_out + 2);
-  if (tid == 0) {s_nt = 0; s_fnt = 0; s_fbest = 0ull; s_tie0 = 0u;}
-  for (int i = tid; i < kSeqMaxFine; i += 1024) {s_fsum[i] = 0;}
+  if (tid == 0) {s_nt = 0; s_tie0 = 0u;}
+  for (int i = tid; i < A.naf * 9; i += 1024) {A.fsum[i] = 0;}
   for (int cell0 = 0; cell0 < plane; cell0 += 1024) {
     if (tid == 0) {s_ncell = 0;}
     __syncthreads();
@@ -789,130 +804,108 @@ __global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
     }
   }
   __syncthreads();
-  phase();
+  if (tid != 0) {return;}
   const int n_ties = s_nt;
-  if (tid == 0) {
-    out[1] = (unsigned long long)n_ties;
-    A.h_out[0] = out[0]; A.h_out[1] = (unsigned long long)n_ties;
-  }
+  out[1] = (unsigned long long)n_ties;
+  A.h_out[0] = out[0]; A.h_out[1] = (unsigned long long)n_ties;
   const bool fine = A.refine != 0 && n_ties == 1;
-  const int naf = A.naf;
+  SeqMid mid;
+  mid.fine = fine ? 1 : 0; mid.a = 0; mid.pad = 0;
+  for (int k = 0; k < 3; ++k) {mid.bx[k] = 0; mid.by[k] = 0; mid.centre[k] = 0.0;}
   if (fine) {
     const uint32_t t = s_tie0;
     const int a = (int)(t % (uint32_t)na);
-    if (tid == 0) {
-      const uint32_t xy = t / (uint32_t)na;
-      const int xi = (int)(xy % (uint32_t)nx), yi = (int)(xy / (uint32_t)nx);
-      // the mean of one pose, the way the host takes it (sum from zero, divided by the count)
-      double ax = 0.0, ay = 0.0;
-      ax += A.cx + A.xp[xi];
-      ay += A.cy + A.yp[yi];
-      const int32_t count = 1;
-      ax /= count; ay /= count;
-      s_centre[0] = ax; s_centre[1] = ay; s_centre[2] = A.heading[a];
-      s_a = a;
-      // lattice base indices of the fine search: operator()(y), Mapper.cpp:649-662
-      for (int k = 0; k < 3; ++k) {
-        const double newPositionX = ax + A.fxp[k];
-        const double gx = (newPositionX - goff_x) * scale;
-        s_bx[k] = d_to_int(d_round(gx)) + A.roi_x;
-        const double newPositionY = ay + A.fyp[k];
-        const double gy = (newPositionY - goff_y) * scale;
-        s_by[k] = (d_to_int(d_round(gy)) + A.roi_y) * ws;
-      }
-      A.h_fine->a = a; A.h_fine->xi = xi; A.h_fine->yi = yi;
-      for (int k = 0; k < 3; ++k) {A.h_fine->centre[k] = s_centre[k]; A.h_fine->bx[k] = s_bx[k]; A.h_fine->by[k] = s_by[k];}
+    const uint32_t xy = t / (uint32_t)na;
+    const int xi = (int)(xy % (uint32_t)nx), yi = (int)(xy / (uint32_t)nx);
+    // the mean of one pose, the way the host takes it (sum from zero, divided by the count)
+    double ax = 0.0, ay = 0.0;
+    ax += A.cx + A.xp[xi];
+    ay += A.cy + A.yp[yi];
+    const int32_t count = 1;
+    ax /= count; ay /= count;
+    mid.a = a; mid.centre[0] = ax; mid.centre[1] = ay; mid.centre[2] = A.heading[a];
+    // lattice base indices of the fine search: operator()(y), Mapper.cpp:649-662
+    for (int k = 0; k < 3; ++k) {
+      const double newPositionX = ax + A.fxp[k];
+      const double gx = (newPositionX - goff_x) * scale;
+      mid.bx[k] = d_to_int(d_round(gx)) + A.roi_x;
+      const double newPositionY = ay + A.fyp[k];
+      const double gy = (newPositionY - goff_y) * scale;
+      mid.by[k] = (d_to_int(d_round(gy)) + A.roi_y) * ws;
     }
-    // the fine search's cosines and sines for coarse angle a
-    if (tid < 2 * naf) {s_cs[tid] = A.fine_cos_sin[(size_t)a * naf * 2 + tid];}
+    A.h_fine->a = a; A.h_fine->xi = xi; A.h_fine->yi = yi;
+    for (int k = 0; k < 3; ++k) {A.h_fine->centre[k] = mid.centre[k]; A.h_fine->bx[k] = mid.bx[k]; A.h_fine->by[k] = mid.by[k];}
   }
-  __syncthreads();
-  phase();
-  if (fine) {
-    const int32_t bxs[3] = {s_bx[0], s_bx[1], s_bx[2]};
-    const int64_t bys[3] = {s_by[0], s_by[1], s_by[2]};
-    const int total = naf * P;
-    constexpr int kPairs = 4;                                // (angle, beam) pairs a thread has in flight: 36 byte loads
-    for (int p0 = tid; p0 - lane < total; p0 += kPairs * 1024) {    // (the trip count is the wave's: every lane takes part in the sums below)
-      int kk[kPairs], ii[kPairs];
-      int32_t idx[kPairs];
-      bool on[kPairs];
-      uint8_t v[kPairs][9];
-#pragma unroll
-      for (int u = 0; u < kPairs; ++u) {
-        const int p = p0 + 1024 * u;
-        on[u] = p < total;
-        kk[u] = on[u] ? p / P : naf - 1;
-        ii[u] = on[u] ? p - kk[u] * P : 0;
-      }
-      double lxp[kPairs], lyp[kPairs];
-      uint8_t inv[kPairs];
-#pragma unroll
-      for (int u = 0; u < kPairs; ++u) {lxp[u] = local[2 * ii[u]]; lyp[u] = local[2 * ii[u] + 1]; inv[u] = invalid[ii[u]];}
-#pragma unroll
-      for (int u = 0; u < kPairs; ++u) {
-        idx[u] = kInvalidScan;
-        if (!inv[u]) {
-          const double cosine = s_cs[2 * kk[u]], sine = s_cs[2 * kk[u] + 1];
-          // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
-          const double ox = cosine * lxp[u] - sine * lyp[u];
-          const double oy = sine * lxp[u] + cosine * lyp[u];
-          const double gxd = ((ox + goff_x) - goff_x) * scale;
-          const double gyd = ((oy + goff_y) - goff_y) * scale;
-          const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
-          idx[u] = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)ws);
-        }
-        if (on[u]) {A.fine_table[(size_t)kk[u] * P + ii[u]] = idx[u];}
-      }
-      // every load unconditional, at an address clamped into the array (a load under a condition is a branch and a wait of its
-      // own: eighteen of them one after the other were 59 of this kernel's 68 us); what GetResponse's range check
-      // (Mapper.cpp:1192-1197) or the beam's validity (:1194) excludes is zeroed afterwards
-      uint32_t ok[kPairs];
-#pragma unroll
-      for (int u = 0; u < kPairs; ++u) {
-        ok[u] = 0u;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-          const int64_t at = bys[j / 3] + bxs[j % 3] + idx[u];
-          const bool in = at >= 0 && at < data_size;
-          ok[u] |= in ? (1u << j) : 0u;
-          v[u][j] = grid[in ? (uint32_t)at : 0u];              // (32-bit offset from the grid's base: data_size < 2^31)
-        }
-        if (!on[u] || idx[u] == kInvalidScan) {ok[u] = 0u;}
-      }
-#pragma unroll
-      for (int u = 0; u < kPairs; ++u) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {if (!((ok[u] >> j) & 1u)) {v[u][j] = 0;}}
-      }
-      // wave-level sums per angle (the lanes of a wave hold consecutive pairs: one angle, two where a wave straddles P)
-#pragma unroll
-      for (int u = 0; u < kPairs; ++u) {
-        const int k_lo = __builtin_amdgcn_readfirstlane(kk[u]), k_hi = __builtin_amdgcn_readlane(kk[u], 63);
-        for (int k = k_lo; k <= k_hi; ++k) {
-#pragma unroll
-          for (int j = 0; j < 9; ++j) {
-            const int sum = wave_prefix_add(kk[u] == k ? (int)v[u][j] : 0);
-            if (lane == 63 && sum != 0) {atomicAdd(&s_fsum[k * 9 + j], sum);}
-          }
-        }
-      }
-    }
+  *A.mid = mid;
+  if (A.dbg) {A.dbg[1] = (long long)wall_clock64();}
+}
+
+__global__ __launch_bounds__(64) void kseq_fine(const SeqFinalArgs A, int slices)
+{
+  const SeqMid & mid = *A.mid;
+  if (mid.fine == 0) {return;}
+  const CorrJob & job = *reinterpret_cast<const CorrJob *>(A.job);
+  const int lane = threadIdx.x;
+  const int k = blockIdx.x / slices, i = (blockIdx.x - k * slices) * 64 + lane;
+  const int P = job.n_points, naf = A.naf;
+  const bool on = i < P;
+  const double * cs = A.fine_cos_sin + ((size_t)mid.a * naf + k) * 2;
+  const double cosine = cs[0], sine = cs[1];
+  const int64_t data_size = job.data_size;
+  int32_t idx = kInvalidScan;
+  if (on && !job.invalid[i]) {
+    const double lxp = job.local[2 * i], lyp = job.local[2 * i + 1];
+    // Karto.h:6879-6887: rotate, add the grid offset, WorldToGrid subtracts it again
+    const double ox = cosine * lxp - sine * lyp;
+    const double oy = sine * lxp + cosine * lyp;
+    const double gxd = ((ox + job.grid_off_x) - job.grid_off_x) * job.scale;
+    const double gyd = ((oy + job.grid_off_y) - job.grid_off_y) * job.scale;
+    const int32_t gx = d_to_int(d_round(gxd)), gy = d_to_int(d_round(gyd));
+    idx = (int32_t)((uint32_t)gx + (uint32_t)gy * (uint32_t)job.ws);
   }
+  if (on) {A.fine_table[(size_t)k * P + i] = idx;}
+  const gbyte * grid = as_global(job.grid);
+  uint32_t v[9];
+  uint32_t ok = 0u;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int64_t at = (int64_t)mid.by[j / 3] + mid.bx[j % 3] + idx;
+    const bool in = at >= 0 && at < data_size;                 // Mapper.cpp:1192-1197
+    ok |= in ? (1u << j) : 0u;
+    v[j] = grid[in ? (uint32_t)at : 0u];
+  }
+  if (!on || idx == kInvalidScan) {ok = 0u;}                   // Mapper.cpp:1194
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int sum = wave_prefix_add(((ok >> j) & 1u) ? (int)v[j] : 0);
+    if (lane == 63 && sum != 0) {atomicAdd(&A.fsum[k * 9 + j], sum);}
+  }
+}
+
+__global__ __launch_bounds__(1024) void kseq_done(const SeqFinalArgs A)
+{
+  __shared__ int s_fnt;
+  __shared__ unsigned long long s_fbest;
+  const int tid = threadIdx.x;
+  const SeqMid mid = *A.mid;
+  const bool fine = mid.fine != 0;
+  const int naf = A.naf;
+  const double denom = reinterpret_cast<const CorrJob *>(A.job)->denom;
+  if (A.dbg && tid == 0) {A.dbg[2] = (long long)wall_clock64();}
+  if (tid == 0) {s_fnt = 0; s_fbest = 0ull;}
   __syncthreads();
-  phase();
   double response = -1.0;
   int fk = 0, fj = 0;
   if (fine && tid < naf * 9) {
     fk = tid / 9; fj = tid - 9 * fk;
-    const int32_t sum = s_fsum[tid];
+    const int32_t sum = A.fsum[tid];
     A.fine_sums[tid] = sum;                                    // [a][y][x] with a 3 x 3 plane
     A.h_fine->sums[tid] = sum;
     response = (double)sum / denom;                            // Mapper.cpp:1204
     if (A.fine_penalize) {
       const double delta = response - 0.0;
       const bool is_zero = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;
-      if (!is_zero) {response *= (A.fine_dist_pen[fj] * A.fine_ang_pen[(size_t)s_a * naf + fk]);}
+      if (!is_zero) {response *= (A.fine_dist_pen[fj] * A.fine_ang_pen[(size_t)mid.a * naf + fk]);}
     }
     atomicMax(&s_fbest, (unsigned long long)__double_as_longlong(response));
   }
@@ -934,13 +927,19 @@ __global__ __launch_bounds__(1024) void kseq_final(const SeqFinalArgs A)
     __threadfence_system();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(A.h_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (A.dbg) {A.dbg[3] = (long long)wall_clock64();}
   }
-  phase();
 }
 
-void launch_seq_final(const SeqFinalArgs & args, void * stream)
+void launch_seq_final(const SeqFinalArgs & args, int32_t n_points, void * stream)
 {
-  hipLaunchKernelGGL(kseq_final, dim3(1), dim3(1024), 0, (hipStream_t)stream, args);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(kseq_ties, dim3(1), dim3(1024), 0, s, args);
+  if (args.refine) {
+    const int slices = (n_points + 63) / 64;
+    hipLaunchKernelGGL(kseq_fine, dim3(args.naf * slices), dim3(64), 0, s, args, slices);
+  }
+  hipLaunchKernelGGL(kseq_done, dim3(1), dim3(1024), 0, s, args);
 }
 
 }  // namespace kh

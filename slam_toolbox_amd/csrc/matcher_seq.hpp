@@ -18,9 +18,11 @@
 //   kseq_score   lookup table + scoring in one launch (K2 + K3), the beams of an angle cut into slices of 64 (17 x as many
 //                workgroups as K3 has for one job), sums added to the volume
 //   kseq_cells   per-cell maxima (the search-space probabilities) and the best response
-//   kseq_final   ONE workgroup: ties; when the coarse pass has exactly one best pose, the fine pass around it (centre from
-//                host-made tables indexed by the coarse angle: no libm on the device) scored and finalised in place; results
-//                into host-coherent memory, then a flag the host polls -- no host round trip between coarse and fine, no copies
+//   kseq_ties    ONE workgroup: ties; when the coarse pass has exactly one best pose, the fine search's centre (from host-made
+//                tables indexed by the coarse angle: no libm on the device) and lattice
+//   kseq_fine    the fine pass around it, a wave per (angle, 64 beams)
+//   kseq_done    ONE workgroup: the fine pass's responses, best and ties; results into host-coherent memory, then a flag the
+//                host polls -- no host round trip between coarse and fine, no copies
 #pragma once
 #include <cstdint>
 #include "kh_internal.hpp"
@@ -62,6 +64,9 @@ struct SeqFineOut
   int32_t sums[kSeqMaxFine];               // [a][y][x]
 };
 
+// what kseq_ties hands to kseq_fine / kseq_done (device memory)
+struct SeqMid {int32_t fine, a, bx[3], by[3], pad; double centre[3];};
+
 struct SeqFinalArgs
 {
   const uint8_t * job;                     // coarse job (device staging block)
@@ -78,6 +83,7 @@ struct SeqFinalArgs
   double fxp[3], fyp[3];                   // fine lattice offsets
   int32_t roi_x, roi_y;
   int32_t * fine_table; int32_t * fine_sums;   // the slot's table / volume (introspection reads the last search)
+  SeqMid * mid; int32_t * fsum;                // device: the hand-over block, the fine pass's sums while they are added up
   long long * dbg;                         // nullptr, or where the kernel leaves wall_clock64 at its phase boundaries (measurements)
 };
 
@@ -87,20 +93,28 @@ void launch_seq_links(const RasterJob * d_job, int32_t n_points, const int32_t *
 size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words);
 // work2 (nullptr = the batch path's list format for k_raster_tile): one (tile, list start, count) record per non-empty tile and the
 // cell packed into the list entries, for kseq_tile; dbg (nullptr = none): wall_clock64 at the kernel's phase boundaries
-int launch_seq_bin(const RasterJob * d_job, int32_t * first, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
+int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
   void * stream);
 size_t seq_tile_table_bytes();
 void seq_tile_table(const uint8_t * kernel, int32_t kernel_size, uint8_t * out);
-// stamping (smear kernels of >= 8 x 8 cells) + the staging copy of launch_seq_stage in one launch
+// what the launch between kseq_bin and the scoring does besides the stamps: the host's tables (host-coherent memory) into device
+// memory, volume and result block of the coarse pass zeroed, the first-point table handed back clean
+struct SeqStageArgs
+{
+  const void * h_stage; void * d_stage; size_t bytes;
+  int32_t * sums; size_t n_sums; unsigned long long * out; size_t out_words;
+  const int32_t * cand; const int32_t * ctl; int32_t * first; int32_t roi_x, roi_y, roi_w;
+};
+// stamping (smear kernels of >= 8 x 8 cells) + the staging work in one launch
 void launch_seq_tile(const RasterJob * d_job, const uint8_t * d_tab, const int32_t * d_work2, int32_t max_points, int32_t max_tiles,
-  const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words, void * stream);
+  const SeqStageArgs & stage, void * stream);
 void launch_raster_tiles(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
   void * stream);
-void launch_seq_stage(const void * h_stage, void * d_stage, size_t bytes, int32_t * sums, size_t n_sums, unsigned long long * out, size_t out_words,
-  void * stream);
+// ... or on its own, behind the batch path's stamping kernel (smaller smear kernels)
+void launch_seq_stage(const SeqStageArgs & stage, void * stream);
 // (sx = grid cells per lattice step, ry = rows per lane: the windowed kernel's tile shape, pick_ry)
 void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t nx, int32_t ny, int32_t sx, int32_t ry, void * stream);
 void launch_seq_cells(const uint8_t * d_job, int32_t plane, unsigned long long * h_lattice, void * stream);
-void launch_seq_final(const SeqFinalArgs & args, void * stream);
+void launch_seq_final(const SeqFinalArgs & args, int32_t n_points, void * stream);      // kseq_ties, kseq_fine, kseq_done
 
 }  // namespace kh
