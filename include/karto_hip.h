@@ -539,6 +539,8 @@ typedef struct kh_mapper_params {               /* Mapper::InitializeParameters 
 typedef struct kh_mapper_stats {
   int64_t scans_processed, matches, loop_candidates, loop_closures, speculation_discarded, nodes_removed;
   double process_ms, match_ms, solver_ms, update_ms, lifelong_ms;
+  int64_t fused_matches, fused_fine_passes;     /* sequential matches that took the fused path of one MatchScan / whose fine pass
+                                                   the device finished (kh_matcher_seq_stats of the sequential matcher) */
 } kh_mapper_stats;
 /* config/mapper_params_offline.yaml:31-66 */
 KH_API void kh_mapper_params_default(kh_mapper_params * p);

@@ -225,29 +225,45 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
     for (int k = 0; k < kBinRegs; ++k) {if (pr[k] >= 0) {state[pr[k]] = 0;}}
     for (int i = tid + extra0; i < n_cand; i += 1024) {state[rec[2 * (size_t)i].x] = 0;}
     __syncthreads();
-    auto decide = [&](int p, const int4 nb) -> bool {             // true = still undecided
+    // a candidate's verdict from the states of its earlier neighbours (0 = still undecided)
+    auto verdict = [&](const uint8_t (&st)[kMaxFootprint]) -> uint8_t {
       bool blocked = false, waiting = false;
-      const int n4[4] = {nb.x, nb.y, nb.z, nb.w};
 #pragma unroll
-      for (int f = 0; f < kMaxFootprint; ++f) {
-        if (n4[f] >= 0) {
-          const uint8_t st = state[n4[f]];
-          blocked = blocked || st == 1;
-          waiting = waiting || st == 0;
-        }
-      }
-      if (blocked) {state[p] = 2; return false;}
-      if (!waiting) {state[p] = 1; return false;}
-      return true;
+      for (int f = 0; f < kMaxFootprint; ++f) {blocked = blocked || st[f] == 1; waiting = waiting || st[f] == 0;}
+      return blocked ? (uint8_t)2 : (waiting ? (uint8_t)0 : (uint8_t)1);
+    };
+    auto decide = [&](int p, const int4 nb) -> bool {             // true = still undecided (candidates beyond the registers)
+      const int n4[4] = {nb.x, nb.y, nb.z, nb.w};
+      uint8_t st[kMaxFootprint];
+#pragma unroll
+      for (int f = 0; f < kMaxFootprint; ++f) {st[f] = n4[f] >= 0 ? state[n4[f]] : (uint8_t)2;}
+      const uint8_t v = verdict(st);
+      if (v) {state[p] = v;}
+      return v == 0;
     };
     uint32_t undecided = 0;
-#pragma unroll
-    for (int k = 0; k < kBinRegs; ++k) {if (pr[k] >= 0) {undecided |= 1u << k;}}
+    uint8_t mine[kBinRegs];                                      // this thread's own verdicts: a chain link whose predecessor is the
+#pragma unroll                                                   // thread's previous candidate reads it here, not through LDS
+    for (int k = 0; k < kBinRegs; ++k) {mine[k] = 0; if (pr[k] >= 0) {undecided |= 1u << k;}}
     bool extra_left = tid + extra0 < n_cand;
     for (int spin = 0; (undecided != 0 || extra_left) && spin < (1 << 24); ++spin) {
 #pragma unroll
       for (int k = 0; k < kBinRegs; ++k) {
-        if (((undecided >> k) & 1u) && !decide(pr[k], nbr[k])) {undecided &= ~(1u << k);}
+        if ((undecided >> k) & 1u) {
+          const int n4[4] = {nbr[k].x, nbr[k].y, nbr[k].z, nbr[k].w};
+          uint8_t st[kMaxFootprint];
+#pragma unroll
+          for (int f = 0; f < kMaxFootprint; ++f) {
+            st[f] = 2;
+            if (n4[f] >= 0) {
+              if (k > 0 && n4[f] == pr[k > 0 ? k - 1 : 0]) {st[f] = mine[k > 0 ? k - 1 : 0];}
+              else if (k > 1 && n4[f] == pr[k > 1 ? k - 2 : 0]) {st[f] = mine[k > 1 ? k - 2 : 0];}
+              else {st[f] = state[n4[f]];}
+            }
+          }
+          const uint8_t v = verdict(st);
+          if (v) {mine[k] = v; state[pr[k]] = v; undecided &= ~(1u << k);}
+        }
       }
       if (extra_left) {
         extra_left = false;
