@@ -1121,18 +1121,23 @@ def main():
     for _ in range(args.warmup):
         for h in handles:
             step(h)
-    for h in handles:
-        h.profile(True)       # HIP events on the library's stream around every scoring launch
+    # THE timed region: exactly K steps, nothing but the work in it.  (Through round 4 the library's profiling events were on
+    # during it: two records per chunk around the scoring kernel cost 10 % of the step -- 74 k with them, 87 k without, same box.)
     dt, per_step = timed(handles, args.steps)
+    # `value` is the K steps asked for; beside it a region of at least 160 steps (half a second) in five windows, so that the
+    # headline can be read against the box-to-box spread (a 20-step region is 0.07 s)
+    long_steps = max(args.steps, 160)
+    dt_long, per_step_long = (dt, per_step) if long_steps == args.steps else timed(handles, long_steps)
+    # the roofline's kernel durations: the same K steps once more with HIP events on the library's streams around the table,
+    # scoring and tie kernels of every launch (kh_matcher_profile / kh_matcher_profile_side)
+    for h in handles:
+        h.profile(True)
+    dt_profiled, _ = timed(handles, args.steps)
     wave_loads = sum(h.score_loads() for h in handles)
     sides = [h.profile_side() for h in handles]
     profs = [h.profile(False) for h in handles]
     prof = {k: sum(p[k] for p in profs) for k in profs[0]}
     side = {k: sum(p[k] for p in sides) for k in sides[0]}
-    # `value` is the K steps asked for; beside it a region of at least 160 steps (half a second) in five windows, so that the
-    # headline can be read against the box-to-box spread (a 20-step region is 0.07 s)
-    long_steps = max(args.steps, 160)
-    dt_long, per_step_long = (dt, per_step) if long_steps == args.steps else timed(handles, long_steps)
 
     full = {}          # every key of the record; the line is cut from it
     variants = {}
@@ -1258,6 +1263,7 @@ def main():
             "roofline": {"bound": "lds", "kernel": SCORE_KERNEL, "achieved": lds_gbs, "peak": LDS_B32_PEAK_GBS,
                          "unit": "GB/s", "frac": lds_gbs / LDS_B32_PEAK_GBS,
                          "window_reads_per_launch": loads_per_launch, "avg_launch_ms": k3_ms, "matches_per_launch": per_launch,
+                         "ms_per_step_with_events": dt_profiled / args.steps * 1e3,
                          "lookups_per_cu_clk": lookups_all / cu_clocks, "lookups_per_cu_clk_read": lookups_read / cu_clocks,
                          "lookups_per_cu_clk_peak_b32": 128.0 * C2["nx"] * C2["ny"] / 4096.0, "lds_array_frac": lds_gbs / (2.0 * LDS_B32_PEAK_GBS),
                          "side_kernels_ms_per_launch": {"k_offsets_lds": side["offsets_ms"] / max(1, prof["score_launches"]),

@@ -219,7 +219,9 @@ KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t flags);
  * [2] fine passes handed to the general path (several best poses, response expansion, an off-lattice best pose),
  * [3] fine passes of the device rejected by the host's check of their centre (must stay 0), [4] coarse passes redone by the
  * general path (degenerate searches: more ties than the result block holds), [5] coarse passes scored by the fused
- * table + scoring kernel (one-tile windows), [6], [7] reserved. */
+ * table + scoring kernel (linear lattices), [6] calls that went the general way because the fused kernels' fixed-size tables
+ * cannot take them, [7] the last such call's reason (1 profiling / kept volume, 2 query beams, 3 readings per base scan,
+ * 4 no base readings, 5 scans / points / tiles, 6 LDS). */
 KH_API int kh_matcher_seq_stats(kh_matcher * m, int64_t out[8]);
 /* The handle's main HIP stream (hipStream_t as void*): every kernel of a call that is not a chunked batch is launched on it, so
  * the caller can bracket launches with HIP events there; chunked batches (>= 128 large searches) run their chunks on two
@@ -539,6 +541,7 @@ typedef struct kh_mapper_params {               /* Mapper::InitializeParameters 
 typedef struct kh_mapper_stats {
   int64_t scans_processed, matches, loop_candidates, loop_closures, speculation_discarded, nodes_removed;
   double process_ms, match_ms, solver_ms, update_ms, lifelong_ms;
+  int64_t fused_declined, fused_declined_reason;   /* ... that went the general way, and why the last one did (kh_matcher_seq_stats [6], [7]) */
   int64_t fused_matches, fused_fine_passes;     /* sequential matches that took the fused path of one MatchScan / whose fine pass
                                                    the device finished (kh_matcher_seq_stats of the sequential matcher) */
 } kh_mapper_stats;

@@ -128,7 +128,7 @@ class KhMapperParams(C.Structure):
 class KhMapperStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("scans_processed", "matches", "loop_candidates", "loop_closures", "speculation_discarded", "nodes_removed")] + \
                [(k, C.c_double) for k in ("process_ms", "match_ms", "solver_ms", "update_ms", "lifelong_ms")] + \
-               [(k, C.c_int64) for k in ("fused_matches", "fused_fine_passes")]
+               [(k, C.c_int64) for k in ("fused_declined", "fused_declined_reason", "fused_matches", "fused_fine_passes")]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)

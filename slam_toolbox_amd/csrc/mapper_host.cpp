@@ -1018,7 +1018,9 @@ int kh_mapper_get_stats(const kh_mapper * m, kh_mapper_stats * out)
   if (!m || !out) {return KH_ERR_INVALID_ARG;}
   *out = m->stats;
   int64_t seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (m->seq && kh_matcher_seq_stats(m->seq, seq) == KH_OK) {out->fused_matches = seq[0]; out->fused_fine_passes = seq[1];}
+  if (m->seq && kh_matcher_seq_stats(m->seq, seq) == KH_OK) {
+    out->fused_matches = seq[0]; out->fused_fine_passes = seq[1]; out->fused_declined = seq[6]; out->fused_declined_reason = seq[7];
+  }
   return KH_OK;
 }
 

@@ -1616,22 +1616,6 @@ int kh_matcher_score_loads(kh_matcher * m, int64_t * wave_loads, int32_t reset)
   unsigned long long v = 0;
   KH_HIP(hipMemcpy(&v, m->d_load_counter, 8, hipMemcpyDeviceToHost));
   *wave_loads = static_cast<int64_t>(v);
-#ifdef KH_LDS_TIMING
-  {
-    // measurement build of k_score_lds: clocks per phase, summed over all waves since the last reset
-    unsigned long long w[32];
-    KH_HIP(hipMemcpy(w, m->d_load_counter, sizeof(w), hipMemcpyDeviceToHost));
-    {
-      const double nk = static_cast<double>(std::max<unsigned long long>(1, w[22]));
-      std::fprintf(stderr, "[kh lds timing] k_offsets_lds per wave (%llu waves): setup %.0f  beams %.0f  builder %.0f  end %.0f  total %.0f clocks\n",
-        w[22], w[17] / nk, w[18] / nk, w[19] / nk, w[20] / nk, w[21] / nk);
-    }
-    const double n = static_cast<double>(std::max<unsigned long long>(1, w[9]));
-    std::fprintf(stderr, "[kh lds timing] per wave (%llu waves, %.1f chunks each): setup %.0f  barrier %.0f  issue %.0f  score %.0f  tail %.0f  epilogue: zero %.0f  "
-      "merge %.0f  poses %.0f  rest %.0f  total %.0f clocks\n", w[9], w[8] / n, w[1] / n, w[2] / n, w[3] / n, w[4] / n, w[5] / n, w[10] / n, w[11] / n, w[12] / n,
-      w[6] / n, w[7] / n);
-  }
-#endif
   if (reset) {KH_HIP(hipMemset(m->d_load_counter, 0, 512));}
   return KH_OK;
 }

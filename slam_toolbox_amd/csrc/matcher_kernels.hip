@@ -25,10 +25,6 @@
 #include "kh_internal.hpp"
 #include "matcher_device.hpp"
 
-#ifndef KH_UB8
-#define KH_UB8 4
-#endif
-
 namespace kh
 {
 
@@ -111,79 +107,6 @@ __global__ __launch_bounds__(64) void k_find_valid_lane(const RasterJob * jobs, 
   }
 }
 
-// The same state machine with one WAVE per (job, base scan) pair: the readings sit in LDS, and "the next reading more
-// than 0.1 m from the reference point" -- the only thing the machine waits for between two triggers -- is found for 64
-// readings at a time (per-lane distance test, ballot, count trailing zeros).  The chain is then one step per TRIGGER
-// (a few hundred per scan) instead of one per reading, and a step costs an LDS read, ten FP64 operations and a ballot:
-// ~30 us per scan against 275 us for the lane-per-scan walk -- which is what a single MatchScan (10 running scans: ten
-// busy lanes on the whole chip) used to spend in this kernel.  The operations on the values are the reference's, in its
-// order; only the search between triggers is parallel.
-__device__ __forceinline__ double wave_bcast(double v, int lane)
-{
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-__global__ __launch_bounds__(256) void k_find_valid(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n)
-{
-  extern __shared__ double2 s_pts_all[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + wave;
-  if (t >= n_items) {return;}                             // wave-uniform; no block-wide barrier below
-  double2 * s_pts = s_pts_all + (size_t)wave * max_n;
-  const RasterJob & job = jobs[items[t].job];
-  const int k = items[t].scan;
-  const int n = job.scan_prefix[k + 1] - job.scan_prefix[k];
-  const double2 * pts = reinterpret_cast<const double2 *>(job.scan_ptr[k]);
-  uint8_t * out = job.active + job.scan_prefix[k];
-  for (int i = lane; i < n; i += 64) {s_pts[i] = pts[i];}
-  __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's LDS writes have landed (only it reads them)
-  __builtin_amdgcn_wave_barrier();
-  const double vx = job.view_x, vy = job.view_y;
-  const double min_square_distance = 0.1 * 0.1;          // math::Square(0.1), folded in double like the host does
-  // the reference point starts at the first reading without a NaN coordinate (Mapper.cpp:1127-1136); nothing can trigger
-  // before it (the distances to NaN readings are NaN) nor at it (distance zero)
-  int pos = n;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const bool ok = i < n && !isnan(s_pts[min(i, n - 1)].x) && !isnan(s_pts[min(i, n - 1)].y);
-    const unsigned long long mask = __ballot(ok);
-    if (mask) {pos = base + __builtin_ctzll(mask); break;}
-  }
-  int trailing = 0;
-  if (pos < n) {
-    double fx = s_pts[pos].x, fy = s_pts[pos].y;
-    ++pos;
-    while (pos < n) {
-      // first reading at or after pos that lies more than 0.1 m from (fx, fy)
-      int j = -1;
-      for (int base = pos & ~63; base < n; base += 64) {
-        const int i = base + lane;
-        const double2 c = s_pts[min(i, n - 1)];
-        const double dx = fx - c.x, dy = fy - c.y;
-        const bool hit = i >= pos && i < n && (dx * dx + dy * dy > min_square_distance);
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {j = base + __builtin_ctzll(mask); break;}
-      }
-      if (j < 0) {break;}
-      const double cx = s_pts[j].x, cy = s_pts[j].y;
-      const double a = vy - fy;
-      const double b = fx - vx;
-      const double cc = fy * vx - fx * vy;
-      const double ss = cx * a + cy * b + cc;
-      fx = cx; fy = cy;
-      // the run [trailing, j) is emitted iff the trigger lies on the viewpoint's side; either way it ends here
-      const uint8_t keep = ss < 0.0 ? 0 : 1;
-      for (int i = trailing + lane; i < j; i += 64) {out[i] = keep;}
-      trailing = j;
-      pos = j + 1;
-    }
-  }
-  for (int i = trailing + lane; i < n; i += 64) {out[i] = 0;}        // the tail after the last trigger is never emitted
-}
-
 __global__ __launch_bounds__(256) void k_find_valid_par(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n)
 {
   // one workgroup per scan: a lane owns every 256th reading, so the divergent forward scans of next() cost a lane four or
@@ -203,20 +126,8 @@ void launch_find_valid(const RasterJob * d_jobs, const ValidItem * d_items, int3
   // one lane per scan only when a scan's working set would not fit the LDS (> 2048 readings): 6400 scans of the
   // loop-closure batch take 0.29 ms lane-per-scan (every lane busy, one memory latency per reading), 0.6 ms with a wave
   // hopping from trigger to trigger, ~0.13 ms with the data-parallel workgroup per scan
-  static const int form = std::getenv("KH_FIND_VALID") ? std::atoi(std::getenv("KH_FIND_VALID")) : 0;   // 1: hop-by-hop wave kernel
-  static const int lane_from = std::getenv("KH_FIND_VALID_LANE_FROM") ? std::atoi(std::getenv("KH_FIND_VALID_LANE_FROM")) : (1 << 30);
-  if (max_n > 2048 || n_items > lane_from) {
+  if (max_n > 2048) {
     hipLaunchKernelGGL(k_find_valid_lane, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_jobs, d_items, (int)n_items);
-    return;
-  }
-  if (form == 1) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_find_valid), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2048 * 16);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(k_find_valid, dim3((n_items + 3) / 4), dim3(256), (size_t)4 * max_n * sizeof(double2), (hipStream_t)stream, d_jobs,
-                       d_items, (int)n_items, (int)max_n);
     return;
   }
   const size_t stride_i = (size_t)max_n + 64;
@@ -719,19 +630,13 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int kWaves = 4;
-  // lanes over footprint cells.  kk >= 64: one point per wave pass, lane walks cells lane, lane + 64, ...
-  // kk < 64: 64 / kk points per wave pass, one cell per lane.  The inner loop was instruction bound (incremental
-  // row / column, byte load of the kernel value, two range tests: ~20 instructions per cell, 2.6 ms for the 224
-  // sequential-preset jobs of the loop-closure batch), hence the packed per-cell table.
-  const int ppw = kk >= 64 ? 1 : 64 / kk;                 // points per wave pass
-  const int sub = kk >= 64 ? 0 : lane / kk;               // which of them this lane works for
-  const int c0 = kk >= 64 ? lane : lane - sub * kk;       // first cell of this lane
-  const bool lane_on = kk >= 64 || sub < ppw;
-  // kk >= 64: lane l < k keeps column l of the smear kernel in registers, one value per footprint row
-  uint32_t colv[41];
+  // (kernels of fewer than 8 x 8 cells: larger ones take k_raster_tile_reg / kseq_tile.)  64 / kk points per wave pass, one
+  // footprint cell per lane; the packed per-cell table keeps the inner loop at a handful of instructions per cell.
+  const int ppw = max(1, 64 / kk);                        // points per wave pass
+  const int sub = lane / kk;                              // which of them this lane works for
+  const int c0 = lane - sub * kk;                         // first cell of this lane
+  const bool lane_on = sub < ppw;
   __syncthreads();                                         // s_cells is complete
-#pragma unroll
-  for (int r = 0; r < 41; ++r) {colv[r] = (kk >= 64 && r < k && lane < k) ? (s_cells[r * k + lane] >> 16) : 0u;}
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int t = job.work[w];
     const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
@@ -748,38 +653,14 @@ __global__ __launch_bounds__(256) void k_raster_tile(const RasterJob * jobs, con
         s_py[threadIdx.x] = job.cell_xy[2 * (size_t)p + 1] - hk - oy;
       }
       __syncthreads();
-      if (kk >= 64) {
-        // lane = footprint COLUMN, rows in a fully unrolled loop: whether a row of the footprint lies inside the tile is the
-        // same for the whole wave (scalar branch), whether the lane's column does is decided once per point (exec mask), and
-        // the row advances through the instruction's offset field -- per footprint row ONE ds_max and nothing else, the
-        // lanes on consecutive words of a tile row (no bank conflicts).  The round-2 mapping (lanes over the k * k cells
-        // in row-major order) spent six VALU instructions per ds_max on two range tests and lost half of the LDS cycles to
-        // conflicts where a lane group wrapped into the next footprint row (rocprofv3: SQ_LDS_BANK_CONFLICT 51 % of
-        // SQ_ACTIVE_INST_LDS, 325 M VALU against 55 M LDS instructions per launch).
-        for (int q = wave; q < here; q += kWaves) {
-          const int fx = __builtin_amdgcn_readfirstlane(s_px[q]), fy = __builtin_amdgcn_readfirstlane(s_py[q]);   // the wave's point
-          const int x = fx + lane;
-          const int r_lo = max(0, -fy), r_hi = min(k - 1, kRasterTile - 1 - fy);        // footprint rows inside the tile
-          if (r_hi < r_lo) {continue;}
-          const unsigned long long rows = ((2ull << r_hi) - 1ull) & ~((1ull << r_lo) - 1ull);    // one scalar bit test per row
-          if (lane < k && (unsigned)x < (unsigned)kRasterTile) {
-            uint32_t * col = &s_tile[fy * kRasterTile + x];
-#pragma unroll
-            for (int r = 0; r < 41; ++r) {
-              if ((rows >> r) & 1ull) {atomicMax(col + r * kRasterTile, colv[r]);}          // (a 0 at a corner: a no-op)
-            }
-          }
-        }
-      } else {
-        for (int q = wave * ppw + sub; q < here; q += kWaves * ppw) {
-          if (!lane_on) {break;}
-          const int fx = s_px[q], fy = s_py[q];
-          for (int c = c0; c < kk; c += 64) {
-            const uint32_t e = s_cells[c];
-            const int x = fx + (int)(e & 0xffu), y = fy + (int)((e >> 8) & 0xffu);
-            // both inside [0, 64): for two's complement ints, (x | y) is in [0, 64) iff both are
-            if ((unsigned)(x | y) < (unsigned)kRasterTile && (e >> 16) != 0) {atomicMax(&s_tile[y * kRasterTile + x], e >> 16);}
-          }
+      for (int q = wave * ppw + sub; q < here; q += kWaves * ppw) {
+        if (!lane_on) {break;}
+        const int fx = s_px[q], fy = s_py[q];
+        for (int c = c0; c < kk; c += 64) {
+          const uint32_t e = s_cells[c];
+          const int x = fx + (int)(e & 0xffu), y = fy + (int)((e >> 8) & 0xffu);
+          // both inside [0, 64): for two's complement ints, (x | y) is in [0, 64) iff both are
+          if ((unsigned)(x | y) < (unsigned)kRasterTile && (e >> 16) != 0) {atomicMax(&s_tile[y * kRasterTile + x], e >> 16);}
         }
       }
     }
@@ -881,9 +762,8 @@ void launch_raster_tiles(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_p
   // non-empty tiles <= 4 per point and <= all tiles; a workgroup walks several when there are more
   static const int tile_blocks = std::getenv("KH_TILE_BLOCKS") ? std::atoi(std::getenv("KH_TILE_BLOCKS")) : 2048;
   int blocks = std::min(std::min(max_tiles, 4 * max_points), tile_blocks);
-  // kernels of >= 8 x 8 cells: tile in registers; KH_RASTER_TILE_LDS=1 keeps the LDS-atomic form (measurements)
-  static const bool lds_form = std::getenv("KH_RASTER_TILE_LDS") != nullptr;
-  if (kernel_size >= 8 && !lds_form) {
+  // kernels of >= 8 x 8 cells: tile in registers; smaller ones: LDS atomics, a lane per footprint cell
+  if (kernel_size >= 8) {
     hipLaunchKernelGGL(k_raster_tile_reg, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
   } else {
     hipLaunchKernelGGL(k_raster_tile, dim3(blocks, n_jobs), dim3(256), 0, s, d_jobs, d_kernel);
@@ -1225,7 +1105,7 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
   constexpr int PX = (SX == 1) ? kTileSpan : (kTileSpan + 1) / 2;   // poses per tile row
   constexpr int TY = 4 * RY;            // lattice rows per tile
   constexpr int NB = (SX == 1) ? 4 : 2; // byte positions per lane per row
-  constexpr int UB = (RY >= 7) ? KH_UB8 : 8;   // beams per inner iteration
+  constexpr int UB = (RY >= 7) ? 4 : 8;   // beams per inner iteration
   const int tx = tile % job.tiles_x, ty = tile / job.tiles_x;
   const int x0 = tx * PX, y0 = ty * TY;
   const int lane = threadIdx.x & 63;
@@ -1486,10 +1366,7 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
 {
   if (n_jobs <= 0 || max_tiles <= 0 || max_na <= 0) {return;}
   // AW = 4 (four adjacent angles sharing a CU) was measured: L1 hit rate 31 -> 38 %, no gain in time
-#ifndef KH_AW
-#define KH_AW 1
-#endif
-  constexpr int AW = KH_AW;
+  constexpr int AW = 1;
   const int groups = (max_na + AW - 1) / AW;      // angle groups per job
   // units of XCD-local work: whole jobs, or contiguous ranges of angle groups when jobs are scarce
   int chunks = 1;
@@ -1500,11 +1377,9 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
   const long long blocks = 8ll * units_per_xcd * na_chunk * max_tiles;
   dim3 grid((unsigned int)blocks);
   hipStream_t s = (hipStream_t)stream;
-  // KH_K3_LDS_PAD=<bytes>: dynamic LDS nobody uses, to cap the workgroups per CU (occupancy experiment of DESIGN.md section 4)
-  static const int lds_pad = std::getenv("KH_K3_LDS_PAD") ? std::atoi(std::getenv("KH_K3_LDS_PAD")) : 0;
   // mfma: the matrix-core instance of the one-cell kernel (bit-identical sums; measured within +-5 % of the vector-ALU one --
   // 0.636 against 0.611 ms per 51 config-2 matches, 2.44 against 2.56 ms on the loop preset: the VALU is not what binds)
-#define KH_SCORE(SXV, RYV, MFV) hipLaunchKernelGGL((k_score<SXV, RYV, AW, MFV>), grid, dim3(256 * AW), lds_pad, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
+#define KH_SCORE(SXV, RYV, MFV) hipLaunchKernelGGL((k_score<SXV, RYV, AW, MFV>), grid, dim3(256 * AW), 0, s, d_jobs, stride, (int)n_jobs, chunks, na_chunk, (int)max_tiles)
   if (sx_variant == 2) {
     if (ry == 8) {KH_SCORE(2, 8, false);} else if (ry == 7) {KH_SCORE(2, 7, false);} else if (ry == 4) {KH_SCORE(2, 4, false);} else {KH_SCORE(2, 1, false);}
   } else if (!mfma) {
@@ -1625,9 +1500,6 @@ void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t 
 namespace kh
 {
 
-#ifndef KH_LDS_EXP
-#define KH_LDS_EXP 0          // measurement builds only: 1 = no region DMA, 4 = no scoring, 5 = no chunk loop (results are then wrong)
-#endif
 struct ChunkDesc {int32_t beam_begin, beam_end, g0, rows, cnt[kGroupAngles], windows, pad1;};
 static_assert(sizeof(ChunkDesc) == kChunkWords * 4, "descriptor size");
 static_assert(kGroupAngles == 2, "the wave roles below assume two angles per workgroup");
@@ -1668,13 +1540,6 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   const int group = blockIdx.x;
   const int a0 = group * kGroupAngles;
   if (a0 >= job.na) {return;}
-#ifdef KH_LDS_TIMING
-  unsigned long long tk_t = __builtin_readcyclecounter(), tk_a = 0, tk_b = 0, tk_c = 0, tk_d = 0;
-  const unsigned long long tk_start = tk_t;
-#define KH_TK(var) do {const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - tk_t; tk_t = now_;} while (0)
-#else
-#define KH_TK(var)
-#endif
   {
     // the job's result block starts from zero: every group's workgroup clears its share
     const int groups = (job.na + kGroupAngles - 1) / kGroupAngles;
@@ -1687,7 +1552,6 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   if (threadIdx.x < kGroupAngles) {s_slow[threadIdx.x] = 0;}
   const uint32_t * const bmp = job.blockmap;
   __syncthreads();
-  KH_TK(tk_a);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bmin = job.base0;
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
@@ -1857,26 +1721,16 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
       begin += n;
     }
   }
-  KH_TK(tk_b);
   if (lane == 0) {
     job.chunk_counts[(size_t)group * kLdsRanges + wave] = n_out;
     // every window costs K3' sixteen wave-level ds_read_b32 (256 B each): the numerator of the roofline
     if (job.load_counter && windows_total) {atomicAdd(job.load_counter, (unsigned long long)(windows_total * 4 * row_waves));}
   }
-  KH_TK(tk_c);
   __syncthreads();
   if (threadIdx.x < kGroupAngles && a0 + (int)threadIdx.x < job.na) {
     job.counts[kCountsPerAngle * (a0 + threadIdx.x) + kClasses] = s_slow[threadIdx.x];
   }
-#ifdef KH_LDS_TIMING
-  KH_TK(tk_d);
-  if (lane == 0 && job.load_counter && (blockIdx.x % 7) == 0) {
-    unsigned long long * c = job.load_counter + 16;
-    atomicAdd(c + 1, tk_a); atomicAdd(c + 2, tk_b); atomicAdd(c + 3, tk_c); atomicAdd(c + 4, tk_d); atomicAdd(c + 5, tk_t - tk_start); atomicAdd(c + 6, 1ull);
-  }
-#endif
 }
-#undef KH_TK
 
 void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream)
 {
@@ -1965,7 +1819,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   auto issue_dma = [&](const Chunk & d, int buf) {
     const gbyte * src = gwin + d.g0;
     const int units = d.rows * kUnitsPerRow;
-    const int nblk = (KH_LDS_EXP == 1) ? 0 : (units + 63) >> 6;
+    const int nblk = (units + 63) >> 6;
 #pragma unroll
     for (int t = 0; t < kDmaPerWave; ++t) {
       const int blk = wave + 2 * NW * t;
@@ -2047,44 +1901,20 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     ++k_in;
     return true;
   };
-#ifdef KH_LDS_TIMING
-  // measurement build: clocks a wave spends in the phases of the chunk loop, summed over all waves into load_counter[1 ...]
-  unsigned long long tm_pre = __builtin_readcyclecounter(), tm_bar = 0, tm_issue = 0, tm_score = 0, tm_tail = 0, tm_chunks = 0;
-  const unsigned long long tm_start = tm_pre;
-#define KH_TM(var, since) do {const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - since; since = now_;} while (0)
-#else
-#define KH_TM(var, since)
-#endif
   Chunk cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0}, aft = {0, 0, 0, 0};
-  bool have = (KH_LDS_EXP != 5) && next_chunk(cur);
+  bool have = next_chunk(cur);
   bool more = have && next_chunk(nxt);
   int buf = 0;
   int32_t rel_cur = 0, rel_nxt = 0;
   if (have) {issue_dma(cur, 0); rel_cur = load_rel(cur);}
-#ifdef KH_LDS_TIMING
-  unsigned long long tm_t = __builtin_readcyclecounter();
-  tm_pre = tm_t - tm_pre;
-#endif
   while (have) {
     __syncthreads();                                 // this region landed (the barrier drains the DMA); the other one is free
-    KH_TM(tm_bar, tm_t);
     if (more) {issue_dma(nxt, buf ^ 1); rel_nxt = load_rel(nxt);}
     const bool after = more && next_chunk(aft);
-    KH_TM(tm_issue, tm_t);
-    if (KH_LDS_EXP != 4) {score(cur, buf, rel_cur);}
-    KH_TM(tm_score, tm_t);
+    score(cur, buf, rel_cur);
     cur = nxt; nxt = aft; rel_cur = rel_nxt; buf ^= 1; have = more; more = after;
-#ifdef KH_LDS_TIMING
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    ++tm_chunks;
-#endif
-    KH_TM(tm_tail, tm_t);
   }
   __syncthreads();
-#ifdef KH_LDS_TIMING
-  unsigned long long tm_epi = 0, tm_e1 = 0, tm_e2 = 0, tm_e3 = 0;
-  KH_TM(tm_bar, tm_t);
-#endif
 
   const size_t plane = (size_t)job.nx * job.ny;
   const int ta = tid % kThreadsPerAngle;             // thread index inside the angle's team of NW waves
@@ -2092,7 +1922,6 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   int32_t * s_tile = reinterpret_cast<int32_t *>(s_region) + q * (64 * PX);
   for (int i = ta; i < 64 * PX; i += kThreadsPerAngle) {s_tile[i] = 0;}
   __syncthreads();
-  KH_TM(tm_e1, tm_t);
   if (live) {
 #pragma unroll
     for (int c = 0; c < kClasses; ++c) {
@@ -2130,7 +1959,6 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     dpen[k] = (live && penal && xi < nx && yi < ny) ? job.dist_pen[yi * nx + xi] : 1.0;
   }
   __syncthreads();
-  KH_TM(tm_e2, tm_t);
   const int n_slow = live ? job.counts[kCountsPerAngle * a + kClasses] : 0;
   const int32_t * slow = job.slow + (size_t)(live ? a : 0) * P;
   double best = 0.0;
@@ -2160,7 +1988,6 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     if (wr_resp) {resp_out[o] = response;}
     best = response > best ? response : best;
   }
-  KH_TM(tm_e3, tm_t);
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) {
     const double o = __shfl_xor(best, sft);
@@ -2178,17 +2005,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     if (job.tile_best) {job.tile_best[a] = b;}
     if (b > 0.0) {atomicMax(&job.out[0], (unsigned long long)__double_as_longlong(b));}
   }
-#ifdef KH_LDS_TIMING
-  KH_TM(tm_epi, tm_t);
-  if (lane == 0 && job.load_counter && (blockIdx.x % 61) == 0) {     // a sample of the workgroups: the reports must not disturb the run
-    unsigned long long * c = job.load_counter;
-    atomicAdd(c + 1, tm_pre); atomicAdd(c + 2, tm_bar); atomicAdd(c + 3, tm_issue); atomicAdd(c + 4, tm_score);
-    atomicAdd(c + 5, tm_tail); atomicAdd(c + 6, tm_epi); atomicAdd(c + 7, tm_t - tm_start); atomicAdd(c + 8, tm_chunks); atomicAdd(c + 9, 1ull);
-    atomicAdd(c + 10, tm_e1); atomicAdd(c + 11, tm_e2); atomicAdd(c + 12, tm_e3);
-  }
-#endif
 }
-#undef KH_TM
 
 void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream)
 {
@@ -2198,24 +2015,14 @@ void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int
   const int jobs_per_xcd = (n_jobs + 7) / 8;
   const long long blocks = xcd_map ? 8ll * jobs_per_xcd * groups : (long long)n_jobs * groups;
   constexpr int kDyn = 2 * kLdsRegionBytes + 3 * 4 * 2 * kLdsPitch + 16;      // two regions + the zero strip (row step of the two-cell instance)
-  // KH_LDS_WAVES=4: four waves per angle (16 rows each, 512 threads, 4 waves per SIMD) instead of eight (8 rows each, 1024 threads)
-#ifndef KH_LDS_NW
-#define KH_LDS_NW 4
-#endif
-  static const int nw = std::getenv("KH_LDS_WAVES") ? std::atoi(std::getenv("KH_LDS_WAVES")) : KH_LDS_NW;
+  // four waves per angle (16 rows each, 512 threads, 4 waves per SIMD); eight (8 rows each) saturate the SIMD's VALU port: DESIGN.md
   // (per device: a group's members on other devices launch this kernel from their own threads)
-  static std::atomic<unsigned long long> attr_done[4] = {{0}, {0}, {0}, {0}};
+  static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
   allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 4>), kDyn, attr_done[0]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 4>), kDyn, attr_done[1]);
-  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 8>), kDyn, attr_done[2]);
-  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 8>), kDyn, attr_done[3]);
   hipStream_t s = (hipStream_t)stream;
 #define KH_SCORE_LDS(SV, NWV) hipLaunchKernelGGL((k_score_lds<SV, NWV>), dim3((unsigned int)blocks), dim3(128 * NWV), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map)
-  if (sx_variant == 2) {
-    if (nw == 4) {KH_SCORE_LDS(2, 4);} else {KH_SCORE_LDS(2, 8);}
-  } else {
-    if (nw == 4) {KH_SCORE_LDS(1, 4);} else {KH_SCORE_LDS(1, 8);}
-  }
+  if (sx_variant == 2) {KH_SCORE_LDS(2, 4);} else {KH_SCORE_LDS(1, 4);}
 #undef KH_SCORE_LDS
 }
 

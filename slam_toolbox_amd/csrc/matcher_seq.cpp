@@ -93,7 +93,12 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
 {
   *coarse_done = false; *fine_done = false;
   static const bool env_off = std::getenv("KH_SEQ_FUSED") != nullptr && std::atoi(std::getenv("KH_SEQ_FUSED")) == 0;
-  if (env_off || m->no_seq || m->profiling || m->keep_responses || query->n <= 0 || query->n > kSeqMaxReadings) {return KH_OK;}
+  if (env_off || m->no_seq) {return KH_OK;}
+  if (!m->seq) {m->seq = new SeqState();}
+  // a call the kernels' fixed-size tables cannot take goes the general way; stats [6] counts them, [7] keeps the last reason
+  auto ineligible = [&](int64_t reason) {m->seq->stats[6] += 1; m->seq->stats[7] = reason; return KH_OK;};
+  if (m->profiling || m->keep_responses) {return ineligible(1);}
+  if (query->n <= 0 || query->n > kSeqMaxReadings) {return ineligible(2);}
   // ---- eligibility: what the kernels' fixed-size tables can take
   int32_t n_scans = 0, max_n = 1;
   int64_t pts = 0;
@@ -101,17 +106,17 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   for (int32_t b = 0; b < n_base; ++b) {
     const kh_scan & sc = base[b];
     if (sc.points_xy == nullptr || sc.n <= 0) {continue;}        // NULL scan: skipped (Mapper.cpp:1039-1041)
-    if (sc.n > kSeqMaxReadings) {return KH_OK;}
+    if (sc.n > kSeqMaxReadings) {return ineligible(3);}
     ++n_scans; pts += sc.n; max_n = std::max(max_n, sc.n);
     any_upload = any_upload || sc.device_points_xy == nullptr;
   }
   const int32_t tiles = m->rt_w * m->rt_h, bm_words = m->bm_w * m->bm_h;
   const int32_t n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
-  if (n_scans == 0 || n_scans > kSeqMaxScans || pts <= 0 || pts > kSeqMaxPoints || tiles > kSeqMaxTiles) {return KH_OK;}
+  if (n_scans == 0 || pts <= 0) {return ineligible(4);}
+  if (n_scans > kSeqMaxScans || pts > kSeqMaxPoints || tiles > kSeqMaxTiles) {return ineligible(5);}
   const size_t bin_lds = seq_bin_lds_bytes(static_cast<int32_t>(pts), n_foot, tiles, bm_words);
-  if (bin_lds > 150 * 1024) {return KH_OK;}
+  if (bin_lds > 150 * 1024) {return ineligible(6);}
   const int32_t np = static_cast<int32_t>(pts);
-  if (!m->seq) {m->seq = new SeqState();}
   SeqState & Q = *m->seq;
   Slot & s = m->slots[0];
   hipStream_t st = m->stream;

@@ -30,9 +30,9 @@
 namespace kh
 {
 
-constexpr int32_t kSeqMaxScans = 48;       // base scans of one match (pointers travel as kernel arguments)
+constexpr int32_t kSeqMaxScans = 128;      // base scans of one match (pointers travel as kernel arguments: 1.5 KB of the 4 KB)
 constexpr int32_t kSeqMaxReadings = 2048;  // readings per scan (k_find_valid_par's LDS working set)
-constexpr int32_t kSeqMaxPoints = 65536;   // job points: one state byte each in LDS
+constexpr int32_t kSeqMaxPoints = 131072;  // job points: one state byte each in LDS (the host checks the sum against the LDS)
 constexpr int32_t kSeqMaxTiles = 16384;    // rasteriser tiles: one counter each in LDS
 constexpr int32_t kSeqMaxFine = 1024;      // poses of the fine volume
 constexpr int32_t kSeqCandWords = 8;       // int32 per stamp candidate: point, cx, cy, selected | four neighbour points

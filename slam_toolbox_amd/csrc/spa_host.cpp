@@ -1285,26 +1285,18 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       spa_launch_diag(dev, s->d_scale.p, s->d_diag.p, opt.min_lm_diagonal, opt.max_lm_diagonal, st);
       have_diagonal = true;
     }
-    static const bool dbg_sync = std::getenv("KH_SPA_SYNC") != nullptr;
-    auto dbg = [&](const char * what, int l) {
-      if (dbg_sync) {
-        hipError_t e = hipStreamSynchronize(st);
-        std::fprintf(stderr, "[kh_spa] %s level %d (max m %d): %s\n", what, l, l >= 0 ? s->level_max_m[l] : 0, hipGetErrorString(e));
-      }
-    };
     const bool timed = n_timed < kh_spa::kMaxTimed;
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][0], st));}
     spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
     KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
-    dbg("assemble", -1);
     // factorisation and forward solve are one kernel per level (the forward step of a panel runs while its
     // L11 / L21 are still in LDS), so the right-hand side has to be in place first
     spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, st);
     KS_HIP(hipMemsetAsync(s->d_sync.p, 0, sizeof(int32_t) * 4 * static_cast<size_t>(sym.n_fronts), st));
     static const int ea_limit = std::getenv("KH_SPA_EXTEND_ADD") ? std::atoi(std::getenv("KH_SPA_EXTEND_ADD")) : 128;
-    // KH_SPA_FACTOR: 3 (default) the level pipeline potrf -> trsm -> syrk, 2 the panel-pair kernels of round 2, 1 their first form
-    static const int factor_env = std::getenv("KH_SPA_FACTOR") ? std::atoi(std::getenv("KH_SPA_FACTOR")) : 3;
-    const int factor_mode = ((s->debug_flags >> 4) & 15) ? ((s->debug_flags >> 4) & 15) : factor_env;
+    // the level pipeline potrf -> trsm -> syrk wherever its fronts fit the LDS; kh_spa_set_debug factor mode 1 / 2 sends every level
+    // through the any-size kernel k_factor instead (the tests' second opinion, and the path of fronts beyond ~2700 rows)
+    const int factor_mode = ((s->debug_flags >> 4) & 15) ? ((s->debug_flags >> 4) & 15) : 3;
     const bool pipeline = factor_mode >= 3 && spa_level_pipeline_fits(sym.max_m, sym.max_ns);
     for (int l = 0; l < n_levels; ++l) {
       const int32_t n_level = s->level_offsets[l + 1] - s->level_offsets[l];
@@ -1315,7 +1307,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
         // (measured on the 10k / 30k graph: 14.7 ms per solve with the split against 13.2 without -- two event records and two
         // stream waits per level on the critical stream cost more than the overlap wins; off unless KH_SPA_EA_OVERLAP=1)
         static const bool overlap_ea = std::getenv("KH_SPA_EA_OVERLAP") && std::atoi(std::getenv("KH_SPA_EA_OVERLAP")) != 0;
-        const bool split_ea = l > 0 && !dev.gather && overlap_ea && s->stream2 && !dbg_sync;
+        const bool split_ea = l > 0 && !dev.gather && overlap_ea && s->stream2;
         if (l > 0 && !dev.gather) {
           if (split_ea) {
             KS_HIP(hipEventRecord(s->ev_level[0], st));                    // the level below is complete
@@ -1330,7 +1322,6 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
         spa_launch_potrf_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
         if (split_ea) {KS_HIP(hipStreamWaitEvent(st, s->ev_level[1], 0));}
         spa_launch_update_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_rhs.p, s->d_upd.p, st);
-        dbg("potrf+trsm+syrk", l);
         continue;
       }
       // narrow levels: the extend-add runs chip-wide in its own launch instead of on each front's single CU
@@ -1338,7 +1329,6 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       if (split) {spa_launch_extend_add(dev, lf, n_level, s->level_max_m[l], st);}
       spa_launch_factor_level(dev, lf, n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p,
         s->d_rhs.p, s->d_upd.p, s->d_fsb.p, s->d_sync.p + 4 * s->level_offsets[l], split ? 1 : 0, st);
-      dbg("factor+forward", l);
     }
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][1], st));}
     for (int l = n_levels - 1; l >= 0; --l) {
@@ -1349,7 +1339,6 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       } else {
         spa_launch_backward_level(dev, lf, n_level, s->level_max_m[l], s->d_rhs.p, st);
       }
-      dbg("backward", l);
     }
     static const bool speculate = !(std::getenv("KH_SPA_SPECULATE") && std::atoi(std::getenv("KH_SPA_SPECULATE")) == 0);
     static const bool lin_check_env = std::getenv("KH_SPA_CHECK") != nullptr;

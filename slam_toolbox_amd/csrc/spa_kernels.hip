@@ -14,9 +14,11 @@
 // CPU restatement, not bit equality).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include "lds_attr.hpp"
 #include "spa_internal.hpp"
 
 #pragma clang fp contract(fast)
@@ -1061,33 +1063,6 @@ __global__ __launch_bounds__(1024) void k_factor(SpaDev d, const int32_t * __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6b, panel-resident form (fronts of at most kMaxLdsRows2 rows: every level of the 10 k-node benchmark graph).
-//
-// Stage timers of the first form showed the dependent chain of a panel pair -- diagonal block, row solve, thin update,
-// diagonal block, row solve: 31 us -- to be four round trips through L2 (each stage read what the previous one had just
-// stored to the front) around ~10 us of arithmetic, and the K = 32 update to run load -> MFMA -> store in lock step on all
-// waves.  Here the pair's columns are read ONCE into an LDS panel P[row][32] (rows from the pair's first pivot down),
-// every stage of the chain works in LDS, and the L columns go back to the front in one pass that overlaps the tail of
-// the trailing update:
-//   (1) load the panel | wave 0 factors the first diagonal block straight from the front          -> barrier
-//   (2) row solve A in LDS                                                                          -> barrier
-//   (3) thin update of the second panel's columns (MFMA, accumulators in LDS) | wave 0 factors the second diagonal block
-//       as soon as its own tile is done                                                             -> barrier
-//   (4) row solve B in LDS                                                                          -> barrier
-//   (5) trailing update C -= X X^T with the accumulator loads of the NEXT tile group issued before the MFMAs of the
-//       current one, then the write-back of the pair's L columns                                    -> barrier
-// A last pair may have fewer than 16 pivots in its second panel, a last single panel fewer than 16: non-pivot columns
-// are never loaded into P (they stay zero there, so they drop out of the MFMA sums) and the trailing update starts at the
-// first 16-aligned row that is not inside a full panel (R0), masking the pivot columns: no extra pass for the remainder.
-constexpr int kMaxLdsRows2 = 544;          // (544 * 34 + 544) * 8 B = 152 KB of the CU's 160 KB LDS
-// Row stride of the panel, in doubles.  The MFMA operand reads dominate the LDS traffic (8 KB per 16 x 16 tile at K = 32);
-// a lane (lr = lane & 15, lk = lane >> 4) reads row lr of a block at k = (K / 4) * lk + 0 .. K / 4 - 1 -- the k slots of
-// the four lanes-groups are CONTIGUOUS runs, so the reads are ds_read_b128 -- and with an even stride whose half is odd
-// the sixteen rows of a group fall into sixteen different 16-byte bank groups: conflict free.  (Stride 33 with k = lk + 4 kk,
-// the first form's layout, is a 4-way conflict on every operand read: lanes with equal lr + lk share a bank pair.  The
-// first form's update was LDS bound because of it, not memory bound.)
-constexpr int XS2 = 2 * NB + 2;
-
 // lane n of every row of 16 lanes, to all lanes of that row: two v_mov_b32_dpp row_newbcast (full-rate VALU; a v_readlane
 // pair goes through SGPRs and stalls on the VALU->SGPR->VALU hazards: 30 of them per pivot were most of a pivot's 230 ns)
 template <int N>
@@ -1109,446 +1084,28 @@ __device__ __forceinline__ double row_bcast(double v, int n)      // n is a cons
   }
 }
 
-// 16 x 16 Cholesky in the registers of lanes 0..15 (lane = row); lanes 16..63 carry identity rows along.
-__device__ __forceinline__ bool diag_chain(double (&row)[NB], int lane, double & rdiag)
-{
-  bool bad = false;
-  rdiag = 1.0;
-  const int l16 = lane & 15;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double djj = row_bcast(row[j], j);
-    if (!(djj > 0.0)) {bad = true; djj = 1.0;}
-    double r = __builtin_amdgcn_rsq(djj);
-    const double h = 0.5 * djj;
-    r = r * (1.5 - h * r * r);
-    r = r * (1.5 - h * r * r);
-    row[j] = (l16 == j) ? djj * r : row[j] * r;
-    if (l16 == j) {rdiag = r;}
-#pragma unroll
-    for (int c = j + 1; c < NB; ++c) {
-      const double lcj = row_bcast(row[j], c);          // L[c][j]
-      row[c] -= row[j] * lcj;
-    }
-  }
-  return bad;
-}
-
-// Diagonal block of a panel, lane l = row l of the block.  kGlobal: the block is read from the front (F = its first
-// entry, leading dimension m), otherwise from the LDS panel (row stride XS2).  L goes to the LDS panel `out` (upper part
-// zeroed), L and the reciprocal diagonal to `ld`; the fused forward solve as in factor_diag_block.
-template <bool kGlobal>
-__device__ __noinline__ bool factor_diag_block2(const double * src, int m, int nb, int lane, double * out, double * ld, double * rhs_seg)
-{
-  double row[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    const bool in = lane < nb && c < nb && c <= lane;
-    row[c] = in ? (kGlobal ? src[lane + (int64_t)c * m] : src[lane * XS2 + c]) : ((c == (lane & 15)) ? 1.0 : 0.0);
-  }
-  double rdiag;
-  const bool bad = diag_chain(row, lane, rdiag);
-  if (lane < NB) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      ld[lane * (NB + 1) + c] = (c <= lane) ? row[c] : 0.0;
-      if (lane < nb) {out[lane * XS2 + c] = (c <= lane) ? row[c] : 0.0;}
-    }
-    ld[lane * (NB + 1) + NB] = rdiag;
-  }
-  {
-    double v = lane < nb ? rhs_seg[lane] : 0.0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const double yj = row_bcast(v, j) * row_bcast(rdiag, j);
-      if (lane == j) {v = yj;} else if (lane > j) {v -= row[j] * yj;}
-    }
-    if (lane < nb) {rhs_seg[lane] = v;}
-  }
-  return bad && lane < nb;
-}
-
-// Row solve in the LDS panel: prow = the row's 16 panel columns (columns >= nb hold zeros and stay untouched)
-__device__ __forceinline__ void panel_row_solve2(double * prow, int nb, const double * ld, const double * y, double * rhs_row)
-{
-  // x L11^T = a, column by column: x[c] = a[c] / L[c][c], then a[j] -= x[c] L[j][c] for every j > c -- the 15 - c updates of
-  // a step are independent of each other (the row-oriented form of the first kernel is one chain of c dependent FMAs per
-  // column).  L11's column c is a broadcast read; its address hangs (through an opaque zero) on x[c-2], so the reads of at
-  // most two columns are in flight and the unrolled solve does not ask for 136 L entries at once.
-  double xr[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {xr[c] = prow[c];}
-  double dot = 0.0;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    int zero = 0;
-    if (c >= 2) {asm volatile("v_mov_b32 %0, 0" : "=v"(zero) : "v"(__double2loint(xr[c - 2])));}
-    const double * lcol = ld + c + zero;                 // L[j][c] = lcol[j * (NB + 1)]
-    const double x = xr[c] * lcol[c * (NB + 1) + (NB - c)];          // reciprocal diagonal: ld[c][NB]
-    xr[c] = x;
-#pragma unroll
-    for (int j = c + 1; j < NB; ++j) {xr[j] -= x * lcol[j * (NB + 1)];}
-    if (c < nb) {prow[c] = x; dot += x * y[c];}
-  }
-  *rhs_row -= dot;
-}
-
-// Trailing update from the LDS panel, software pipelined: the accumulator loads of the next group of tiles are in flight
-// while the matrix cores work on the current one.  Rows / columns are local to the pair (0 = its first pivot); tiles of
-// 16 x 16 from R0; an entry is kept iff it lies in the lower triangle, inside the front, and its column is not a pivot of
-// this pair.  The code is branch free on purpose: a load or store under a branch makes the compiler's s_waitcnt
-// bookkeeping merge paths with different numbers of outstanding operations, and it then waits for vmcnt(0) before the
-// first MFMA -- which serialises exactly what is meant to overlap.  So every lane always loads (from a clamped, valid
-// address) and always stores (entries that are not kept go to `dump`, 16 spare doubles behind the front storage).
-template <int KD>
-__device__ __forceinline__ void trailing_update2(double * F, const double * P, int m, int jb, int M, int Mp, int R0, int npiv,
-                                                 int lane, int wave, int nwaves, double * dump)
-{
-  constexpr int TU = 4;
-  const int nt = (Mp - R0) >> 4;
-  const int ntiles = nt * (nt + 1) / 2;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int stride = nwaves * TU;
-  auto decode = [&](int t, int & I, int & J) {
-    t = t < ntiles ? t : 0;
-    I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    I -= (I * (I + 1) / 2 > t) ? 1 : 0;
-    I += ((I + 1) * (I + 2) / 2 <= t) ? 1 : 0;
-    J = t - I * (I + 1) / 2;
-  };
-  auto load = [&](v4d (&acc)[TU], int t0) {
-#pragma unroll
-    for (int u = 0; u < TU; ++u) {
-      int I, J;
-      decode(t0 + u * nwaves, I, J);
-      const int row = min(R0 + 16 * I + lr, M - 1), col0 = R0 + 16 * J + lk;
-      const double * p = F + (jb + row);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {acc[u][r] = p[(int64_t)(jb + min(col0 + 4 * r, M - 1)) * m];}
-    }
-  };
-  auto finish = [&](v4d (&acc)[TU], int t0) {
-    int tI[TU], tJ[TU];
-#pragma unroll
-    for (int u = 0; u < TU; ++u) {decode(t0 + u * nwaves, tI[u], tJ[u]);}
-#pragma unroll
-    for (int kk = 0; kk < KD / 4; ++kk) {
-#pragma unroll
-      for (int u = 0; u < TU; ++u) {
-        const double a = P[(R0 + 16 * tJ[u] + lr) * XS2 + (KD / 4) * lk + kk];
-        const double b = P[(R0 + 16 * tI[u] + lr) * XS2 + (KD / 4) * lk + kk];
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc[u], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < TU; ++u) {
-      const int row = R0 + 16 * tI[u] + lr, col0 = R0 + 16 * tJ[u] + lk;
-      const bool live = t0 + u * nwaves < ntiles && row < M;
-      double * p = F + (jb + row);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = col0 + 4 * r;
-        double * q = (live && col <= row && col >= npiv) ? p + (int64_t)(jb + col) * m : dump;
-        *q = acc[u][r];
-      }
-    }
-  };
-  // three groups of TU tiles per wave: two groups' accumulator loads are in flight while the third is multiplied (the
-  // trailing matrix of a level does not fit the XCD's L2: a load is a ~2.4 us round trip, the MFMAs of a group 0.9 us)
-  v4d a0[TU], a1[TU], a2[TU];
-  int t0 = __builtin_amdgcn_readfirstlane(wave);
-  if (t0 >= ntiles) {return;}
-  load(a0, t0);
-  load(a1, t0 + stride);                   // past the last tile: tile 0 again, nothing kept
-  while (true) {
-    load(a2, t0 + 2 * stride);
-    finish(a0, t0);
-    t0 += stride;
-    if (t0 >= ntiles) {break;}
-    load(a0, t0 + 2 * stride);
-    finish(a1, t0);
-    t0 += stride;
-    if (t0 >= ntiles) {break;}
-    load(a1, t0 + 2 * stride);
-    finish(a2, t0);
-    t0 += stride;
-    if (t0 >= ntiles) {break;}
-  }
-}
-
-// Split form (levels with few, large fronts): one launch works through the panel pairs [step_lo, step_hi) only and, with
-// do_update = 0, leaves the trailing update of a pair to k_update2 -- many workgroups per front, a kernel boundary either
-// side (1.5-2 us each, cheaper than any in-kernel hand-off between workgroups).  Between the launches of a front the
-// right-hand-side slice of the fused forward solve waits in fsb.
-__global__ __launch_bounds__(512) void k_factor2(SpaDev d, const int32_t * __restrict__ level_fronts, int32_t * fail_flag, long long * tbuf,
-               double * rhs, double * upd, double * fsb, int lds_rows, int matrix_added, int step_lo, int step_hi, int do_update)
-{
-  int tcount = 0;
-  TSTAMP();
-  const int k = level_fronts[blockIdx.x];
-  const int m = d.front_m[k], ns = d.front_ns[k];
-  if (step_lo > 0 && 2 * NB * step_lo >= ns) {return;}            // this front's pivots were done by earlier launches
-  double * fsb_k = fsb + 3 * ((int64_t)d.front_first[k] + d.front_rows_ptr[k]);
-  double * F = d.fronts + d.front_off[k];
-  const int tid = threadIdx.x, nthreads = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-  extern __shared__ double smem[];
-  double * P = smem;                                   // [lds_rows][XS2]: the pair's columns, rows from its first pivot
-  double * sb = smem + (size_t)lds_rows * XS2;          // the front's slice of the right-hand side (fused forward solve)
-  __shared__ double Ld[NB][NB + 1];
-  __shared__ int s_fail;
-  const int first = 3 * d.front_first[k];
-  if (step_lo > 0) {
-    for (int t = tid; t < m; t += nthreads) {sb[t] = fsb_k[t];}
-  } else {
-    for (int t = tid; t < m; t += nthreads) {sb[t] = t < ns ? rhs[first + t] : 0.0;}
-  }
-  if (tid == 0) {s_fail = 0;}
-  __syncthreads();
-
-  // children: forward-solve contributions always; update matrices unless k_extend_add has summed them already
-  int * pos = reinterpret_cast<int *>(P);
-  for (int ci = d.child_ptr[k]; ci < d.child_ptr[k + 1] && step_lo == 0; ++ci) {
-    const int c = d.child_list[ci];
-    const int mc = d.front_m[c], nsc = d.front_ns[c], nuc = mc - nsc;
-    const double * Uc = d.fronts + d.front_off[c] + nsc + (int64_t)nsc * mc;
-    const int32_t * rp = d.relpos + d.relpos_ptr[c];
-    for (int a = tid; a < nuc; a += nthreads) {pos[a] = 3 * rp[a / 3] + a % 3;}
-    __syncthreads();
-    const double * uc = upd + 3 * (int64_t)d.front_rows_ptr[c];
-    for (int a = tid; a < nuc; a += nthreads) {sb[pos[a]] += uc[a];}
-    constexpr int CB = 8;
-    for (int b0 = wave * CB; b0 < nuc && !matrix_added; b0 += nwaves * CB) {
-      for (int a0 = b0; a0 < nuc; a0 += 64) {
-        const int a = a0 + lane;
-        double u[CB], f[CB];
-        double * dst[CB];
-        bool on[CB];
-        const int pa = a < nuc ? pos[a] : 0;
-#pragma unroll
-        for (int q = 0; q < CB; ++q) {
-          const int b = b0 + q;
-          on[q] = a < nuc && b < nuc && a >= b;
-          dst[q] = F + pa + (int64_t)(on[q] ? pos[b] : 0) * m;
-          u[q] = on[q] ? Uc[a + (int64_t)b * mc] : 0.0;
-          f[q] = on[q] ? *dst[q] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < CB; ++q) {if (on[q]) {*dst[q] = f[q] + u[q];}}
-      }
-    }
-    __syncthreads();
-  }
-  TSTAMP();
-
-  int jb = 2 * NB * step_lo;
-  for (int step = step_lo; jb < ns && step < step_hi; ++step) {
-    const int rem = ns - jb;
-    const int nb_a = min(NB, rem);
-    const int nb_b = rem > NB ? min(NB, rem - NB) : 0;
-    const int npiv = nb_a + nb_b;
-    const int M = m - jb, Mp = (M + 15) & ~15;
-    const int R0 = (nb_a == NB ? NB : 0) + (nb_b == NB ? NB : 0);
-    double * Fp = F + jb + (int64_t)jb * m;                // the pair's first pivot
-    // (1) panel -> LDS (pivot columns only, lower part, zeros elsewhere) | first diagonal block on wave 0
-    if (wave == 0) {
-      if (factor_diag_block2<true>(Fp, m, nb_a, lane, P, &Ld[0][0], sb + jb)) {s_fail = 1;}
-    } else {
-      const int nload = nthreads - 64;
-      for (int i = tid - 64; i < Mp; i += nload) {
-        double * prow = P + i * XS2;
-        const double * frow = Fp + i;
-        // 32 unconditional loads in flight (an entry that is not wanted reads the pivot instead), selected afterwards
-        double v[2 * NB];
-#pragma unroll
-        for (int c = 0; c < 2 * NB; ++c) {
-          const bool want = i < M && c < npiv && i >= c;
-          v[c] = *(want ? frow + (int64_t)c * m : Fp);
-        }
-#pragma unroll
-        for (int c = 0; c < 2 * NB; ++c) {
-          const bool want = i < M && c < npiv && i >= c;
-          if (!(i < nb_a && c < NB)) {prow[c] = want ? v[c] : 0.0;}       // rows < nb_a of the first panel are wave 0's
-        }
-      }
-    }
-    __syncthreads();
-    TSTAMP();
-    // (2) row solve A: every row below the first panel's pivots
-    for (int i = nb_a + tid; i < M; i += nthreads) {panel_row_solve2(P + i * XS2, nb_a, &Ld[0][0], sb + jb, sb + jb + i);}
-    __syncthreads();
-    TSTAMP();
-    if (nb_b > 0) {
-      // (3) thin update: the second panel's pivot columns, rows from its diagonal block down; accumulators live in LDS.
-      //     Wave 0 owns the tile with the diagonal block and factors it right away (its LDS accesses are in order).
-      const int ntt = (Mp - NB) >> 4;
-      const int lr = lane & 15, lk = lane >> 4;
-      for (int t = wave; t < ntt; t += nwaves) {
-        const int i = NB + 16 * t + lr;
-        double * prow = P + i * XS2 + NB + lk;
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {acc[r] = prow[4 * r];}
-        const double * xa = P + (NB + lr) * XS2 + (NB / 4) * lk;
-        const double * xb = P + i * XS2 + (NB / 4) * lk;
-#pragma unroll
-        for (int kk = 0; kk < NB / 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb[kk], acc, 0, 0, 0);}
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {if (lk + 4 * r < nb_b && i < M) {prow[4 * r] = acc[r];}}
-        if (t == 0) {
-          if (factor_diag_block2<false>(P + NB * XS2 + NB, 0, nb_b, lane, P + NB * XS2 + NB, &Ld[0][0], sb + jb + NB)) {s_fail = 1;}
-        }
-      }
-      __syncthreads();
-      TSTAMP();
-      // (4) row solve B
-      for (int i = NB + nb_b + tid; i < M; i += nthreads) {panel_row_solve2(P + i * XS2 + NB, nb_b, &Ld[0][0], sb + jb + NB, sb + jb + i);}
-      __syncthreads();
-      TSTAMP();
-    }
-    // (5) trailing update, then the L columns back to the front
-    if (M > npiv && do_update) {
-      if (nb_b > 0) {
-        trailing_update2<2 * NB>(F, P, m, jb, M, Mp, R0, npiv, lane, wave, nwaves, d.fronts + d.fronts_size);
-      } else {
-        trailing_update2<NB>(F, P, m, jb, M, Mp, R0, npiv, lane, wave, nwaves, d.fronts + d.fronts_size);
-      }
-    }
-    for (int c = 0; c < npiv; ++c) {
-      for (int i = c + tid; i < M; i += nthreads) {Fp[i + (int64_t)c * m] = P[i * XS2 + c];}
-    }
-    __syncthreads();
-    TSTAMP();
-    jb += npiv;
-  }
-  if (jb < ns) {
-    for (int t = tid; t < m; t += nthreads) {fsb_k[t] = sb[t];}        // more pairs to come in a later launch
-  } else {
-    for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = sb[t];}
-    double * uk = upd + 3 * (int64_t)d.front_rows_ptr[k];
-    for (int q = tid; q < m - ns; q += nthreads) {uk[q] = sb[ns + q];}
-  }
-  if (tbuf && blockIdx.x == 0 && threadIdx.x == 0) {tbuf[0] = tcount; tbuf[63] = ((long long)m << 32) | ns;}
-  if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
-}
-
-// Trailing update of panel pair `step` of every front of a level, G workgroups per front.  Block b runs on XCD b % 8
-// (observed placement, used for speed only): all workgroups of a front are given block ids of the residue its
-// k_factor2 workgroup had, so the panel it has just written is read from that XCD's L2.
-__global__ __launch_bounds__(512) void k_update2(SpaDev d, const int32_t * __restrict__ level_fronts, int n, int step, int G, int lds_rows)
-{
-  const int x = (int)blockIdx.x & 7, t8 = (int)blockIdx.x >> 3;
-  const int q = t8 / G, g = t8 - q * G;
-  const int slot = 8 * q + x;
-  if (slot >= n) {return;}
-  const int k = level_fronts[slot];
-  const int m = d.front_m[k], ns = d.front_ns[k];
-  const int jb = 2 * NB * step;
-  if (jb >= ns) {return;}
-  const int rem = ns - jb;
-  const int nb_a = min(NB, rem);
-  const int nb_b = rem > NB ? min(NB, rem - NB) : 0;
-  const int npiv = nb_a + nb_b;
-  const int M = m - jb, Mp = (M + 15) & ~15;
-  const int R0 = (nb_a == NB ? NB : 0) + (nb_b == NB ? NB : 0);
-  if (M <= npiv) {return;}
-  double * F = d.fronts + d.front_off[k];
-  const int tid = threadIdx.x, nthreads = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-  extern __shared__ double smem[];
-  double * P = smem;
-  (void)lds_rows;
-  const double * Fp = F + jb + (int64_t)jb * m;
-  for (int i = R0 + tid; i < Mp; i += nthreads) {
-    double * prow = P + i * XS2;
-    const double * frow = Fp + i;
-    double v[2 * NB];
-#pragma unroll
-    for (int c = 0; c < 2 * NB; ++c) {
-      const bool want = i < M && c < npiv && i >= c;
-      v[c] = *(want ? frow + (int64_t)c * m : Fp);
-    }
-#pragma unroll
-    for (int c = 0; c < 2 * NB; ++c) {prow[c] = (i < M && c < npiv && i >= c) ? v[c] : 0.0;}
-  }
-  __syncthreads();
-  if (nb_b > 0) {
-    trailing_update2<2 * NB>(F, P, m, jb, M, Mp, R0, npiv, lane, g * nwaves + wave, G * nwaves, d.fronts + d.fronts_size);
-  } else {
-    trailing_update2<NB>(F, P, m, jb, M, Mp, R0, npiv, lane, g * nwaves + wave, G * nwaves, d.fronts + d.fronts_size);
-  }
-}
 
 void spa_launch_factor_level(const SpaDev & d, const int32_t * level_fronts, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
                              double * rhs, double * upd, double * fsb, int32_t * sync, int32_t matrix_added, void * stream)
 {
+  // The any-size form: what factorises a level whose fronts do not fit the level pipeline's LDS (spa_level_pipeline_fits: more
+  // than ~2700 rows), and what `kh_spa_set_debug` factor mode 1 / 2 selects so that the tests can lay an independent
+  // factorisation beside the pipeline's.  One workgroup per front (the round-2 panel-pair kernels, a subset of the pipeline's
+  // domain, are gone).
+  (void)max_ns; (void)fsb;
   if (n <= 0) {return;}
-  // workgroups per front: all of a launch's workgroups have to be resident at once (they wait for each other), and a
-  // workgroup of this kernel takes a CU (1024 threads, up to 150 KB of LDS) -> at most 224 of the 256; small fronts gain
-  // nothing.  KH_SPA_GROUP=1 switches the sharing off.
-  // Measured (10k / 30k graph, stage timers): with G = 5..8 the K = 32 update of a 456-row front drops from 44 to 25 us,
-  // but the leader's own panel chain (2 x diagonal block + 2 x row solve + thin update, ~33 us per pair) gets 8 us slower
-  // with the helpers polling beside it, and the level times do not move: opt-in (KH_SPA_GROUP=8), off by default.
-  static const int group_cap = std::getenv("KH_SPA_GROUP") ? std::atoi(std::getenv("KH_SPA_GROUP")) : 1;
-  int G = 1;
-  if (max_m >= 160 && n <= 112) {G = std::max(1, std::min(group_cap, 224 / n));}
+  const int G = 1;
   const int threads = max_m <= 96 ? 256 : (max_m <= 192 ? 512 : 1024);
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
   if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 64 * sizeof(long long), hipHostMallocDefault);}
-  // KH_SPA_FACTOR=1: the first form of the kernel (panel stages through the front) for every level
-  static const bool first_form = std::getenv("KH_SPA_FACTOR") && std::atoi(std::getenv("KH_SPA_FACTOR")) == 1;
-  if (G == 1 && max_m <= kMaxLdsRows2 && !first_form) {
-    const int rows2 = (max_m + 15) & ~15;
-    const size_t lds2 = sizeof(double) * ((size_t)rows2 * XS2 + max_m + 8);
-    static bool attr2_set = false;
-    if (!attr2_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_factor2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * ((size_t)kMaxLdsRows2 * XS2 + kMaxLdsRows2 + 16)));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_update2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * ((size_t)kMaxLdsRows2 * XS2 + kMaxLdsRows2 + 16)));
-      attr2_set = true;
-    }
-    // 512 threads at most: 256 VGPRs per wave hold two groups of four accumulator tiles (the software pipeline of the update)
-    // Split form: a level of few, large fronts leaves most of the chip idle while each front's single CU grinds through its
-    // trailing updates (60 % of that CU's FP64 matrix rate: there is nothing left to win inside the CU).  G workgroups per
-    // front take the update of every panel pair in a launch of their own.  KH_SPA_SPLIT=0 switches it off.
-    static const int split_cap = std::getenv("KH_SPA_SPLIT") ? std::atoi(std::getenv("KH_SPA_SPLIT")) : 8;
-    const int slots8 = 8 * ((n + 7) / 8);
-    const int G = std::min(split_cap, 224 / slots8);
-    const int threads2 = max_m <= 96 ? 256 : 512;
-    static const int split_min_g = std::getenv("KH_SPA_SPLIT_MIN_G") ? std::atoi(std::getenv("KH_SPA_SPLIT_MIN_G")) : 4;
-    static const int split_min_m = std::getenv("KH_SPA_SPLIT_MIN_M") ? std::atoi(std::getenv("KH_SPA_SPLIT_MIN_M")) : 270;
-    if (G >= split_min_g && max_m >= split_min_m && !timing) {
-      const int steps = (max_ns + 2 * NB - 1) / (2 * NB);
-      for (int p = 0; p < steps; ++p) {
-        hipLaunchKernelGGL(k_factor2, dim3(n), dim3(threads2), lds2, (hipStream_t)stream, d, level_fronts, fail_flag, (long long *)nullptr, rhs, upd, fsb,
-                           rows2, (int)matrix_added, p, p + 1, 0);
-        hipLaunchKernelGGL(k_update2, dim3(slots8 * G), dim3(512), lds2, (hipStream_t)stream, d, level_fronts, n, p, G, rows2);
-      }
-      return;
-    }
-    hipLaunchKernelGGL(k_factor2, dim3(n), dim3(threads2), lds2, (hipStream_t)stream, d, level_fronts, fail_flag, timing ? tbuf : nullptr, rhs, upd, fsb,
-                       rows2, (int)matrix_added, 0, 1 << 20, 1);
-    if (timing) {
-      (void)hipStreamSynchronize((hipStream_t)stream);
-      std::fprintf(stderr, "[k_factor2] n=%d max_m=%d front0 m=%lld ns=%lld stamps(x10ns):", n, max_m, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
-      for (int i = 1; i < (int)tbuf[0]; ++i) {std::fprintf(stderr, " %lld", tbuf[1 + i] - tbuf[i]);}
-      std::fprintf(stderr, "\n");
-    }
-    return;
-  }
   const int lds_rows = ((max_m < kMaxLdsRows ? max_m : kMaxLdsRows) + 15) & ~15;
   // panel + the front's right-hand side behind it; fronts beyond the LDS panel keep only the rhs (+ the
   // extend-add position table) in LDS
   const int small_m = max_m < kMaxLdsRows ? max_m : kMaxLdsRows;
   const size_t lds = sizeof(double) * std::max((size_t)lds_rows * XS + small_m, (size_t)max_m + (max_m + 1) / 2 + 8);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(double) * ((size_t)kMaxLdsRows * XS + kMaxLdsRows + 16)));
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_factor), (int)(sizeof(double) * ((size_t)kMaxLdsRows * XS + kMaxLdsRows + 16)), attr_done);
   hipLaunchKernelGGL(k_factor, dim3(n * G), dim3(threads), lds, (hipStream_t)stream, d, level_fronts, fail_flag, timing ? tbuf : nullptr, rhs, upd,
                      lds_rows, G, sync, (int)matrix_added);
   if (timing) {
@@ -2254,17 +1811,14 @@ bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns)
 
 static void pipeline_attributes()
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    const int big = 160 * 1024 - 256;       // static LDS (a flag word) counts against the same 160 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsm<32>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_trsm<64>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_syrk<32>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_syrk<64>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  // (per device: the attribute is kept per device, and solvers of several devices may live in one process)
+  const int big = 160 * 1024 - 256;       // static LDS (a flag word) counts against the same 160 KB
+  static std::atomic<unsigned long long> done[5] = {{0}, {0}, {0}, {0}, {0}};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_potrf), big, done[0]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_trsm<32>), big, done[1]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_trsm<64>), big, done[2]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_syrk<32>), big, done[3]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_syrk<64>), big, done[4]);
 }
 
 void spa_launch_potrf_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,

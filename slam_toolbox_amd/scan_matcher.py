@@ -287,7 +287,7 @@ class ScanMatcher:
         """counters of the fused path of ONE MatchScan (kh_matcher_seq_stats)"""
         out = (C.c_int64 * 8)()
         capi.check(capi.lib().kh_matcher_seq_stats(self._h, out), "kh_matcher_seq_stats")
-        keys = ("calls", "fine_on_device", "fine_fallbacks", "fine_mismatches", "coarse_fallbacks", "fused_score")
+        keys = ("calls", "fine_on_device", "fine_fallbacks", "fine_mismatches", "coarse_fallbacks", "fused_score", "ineligible", "ineligible_reason")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def stream(self):

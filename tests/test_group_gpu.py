@@ -86,6 +86,6 @@ def test_mapper_on_two_members_runs_identically(kartohip_lib, tmp_path):
     # every sequential match of both runs took the fused path of one MatchScan (csrc/matcher_seq.cpp), its fine pass mostly
     # finished on the device
     for st in stats:
-        assert st["fused_matches"] == st["matches"] > 400 and st["fused_fine_passes"] > 0.8 * st["matches"]
+        assert st["fused_matches"] == st["matches"] > 300 and st["fused_fine_passes"] > 0.8 * st["matches"], st
     assert logs[0] == logs[1]
     assert np.array_equal(bits(poses[0]), bits(poses[1]))

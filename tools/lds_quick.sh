@@ -8,8 +8,8 @@ timeout 600 python -m pytest tests/test_matcher_gpu.py -x -q -m gpu -k "lds" 2>&
 export KH_LDS_SCORE=1
 cmd="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-solver --no-loop"
 $cmd > $out/bench_default.json 2> $out/bench_default.err
-KH_LDS_WAVES=4 $cmd > $out/bench_default_nw4.json 2> $out/bench_default_nw4.err
-KH_LDS_WAVES=4 timeout 600 python -m pytest tests/test_matcher_gpu.py -x -q -m gpu -k "lds" 2>&1 | tail -1
+
+
 grep "kh lds" $out/bench_*.err | head -6
 for v in $GRAFT_REPO_ROOT/variants/*.so; do
   [ -e "$v" ] || continue
