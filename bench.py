@@ -758,7 +758,9 @@ def replay_leg(device=0, n_scans=3000, cpu=True):
     st = out["stats"]
     res = {"replay_scans_per_s": out["scans_per_s"], "replay_workload": f"{n_scans}-scan lap circuit (odometry noise 1 % / 0.2 deg per m), "
            f"lifelong mode, sync queue: {out['accepted']} accepted, {out['alive']} alive after node decay, {st['loop_closures']} loop closures, "
-           f"{st['matches']} matches", "replay_wall_s": out["wall_s"],
+           f"{st['matches']} matches", "replay_wall_s": out["wall_s"], "replay_closures": int(st["loop_closures"]),
+           "replay_matches": int(st["matches"]), "replay_fused_matches": int(st.get("fused_matches", 0)),
+           "replay_fused_fine_passes": int(st.get("fused_fine_passes", 0)),
            "replay_ms_split": {"match": st["match_ms"], "solver": st["solver_ms"], "pose_updates": st["update_ms"], "node_decay": st["lifelong_ms"]},
            "replay_map_build_ms": out["map_build_ms"], "replay_map_iou_vs_truth_poses": out["map_iou_vs_truth_poses"],
            "replay_map_occupied_within_one_cell_of_truth_map": out["map_occupied_within_one_cell_of_truth_map"],

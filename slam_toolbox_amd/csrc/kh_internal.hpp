@@ -14,7 +14,9 @@ constexpr int32_t kGridPad = 512;             // zeroed slack before and after t
 constexpr int32_t kTileBytes = 64;            // bytes of one grid row a scoring tile reads (16 lanes x aligned dword)
 constexpr int32_t kTileSpan = 61;             // bytes of it that hold poses whatever the alignment class (64 - 3)
 constexpr int32_t kClasses = 4;               // alignment classes of a beam offset: (base0 + offset) & 3
-constexpr int32_t kBlockShift = 5;             // occupancy block map: one byte per 32 x 32 grid cells ("a stamp touched this block")
+constexpr int32_t kBlockShift = 5;             // occupancy block map: one bit per 32 x 32 grid cells ("a stamp touched this block") -- the coarse
+                                               // form; handles whose searches are small and whose smear kernel is small keep 8 x 8 blocks
+                                               // (RasterJob::bshift / CorrJob::bshift = 3: 9 % fewer windows to score on the config-2 search)
 constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per class, [4] = slow beams
 // LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; the beams are cut into chunks of
 // consecutive beams whose windows' union fits one LDS region (built by kLdsRanges waves, a quarter of the beams each)
@@ -51,6 +53,7 @@ struct RasterJob
   uint32_t * blockmap;       // bm_h rows of bm_w words, one BIT per 32 x 32-cell block (bit bx & 31 of word bx >> 5; the last
                              // word of a row is padding), cleared with the grid: 1 = some stamp's footprint overlaps the block
   int32_t bm_w, bm_h;
+  int32_t bshift;            // log2 of the block side in cells (5 or 3)
   // tiled stamping (k_raster_*): kRasterTile x kRasterTile cell tiles, points binned to the <= 2 x 2 tiles
   // their footprint overlaps.  All int32 scratch, zeroed with the grid where noted.
   int32_t tiles_w, tiles_h, height;
@@ -122,7 +125,7 @@ struct CorrJob
   int32_t * chunk_counts;    // [groups][kLdsRanges]: chunks of the beam range
   // empty-window skipping: a beam whose whole window lies in blocks no stamp touched adds 0 to every pose
   const uint32_t * blockmap; // see RasterJob; nullptr = do not skip
-  int32_t bm_w, bm_h;
+  int32_t bm_w, bm_h, bshift;
   double * tile_best;        // [na][tiles_y * tiles_x] best response of every scoring tile (K3 -> K4); nullptr = K4 scans everything
   int32_t * sums;            // [na][ny][nx] raw GetResponse numerators (Mapper.cpp:1200)
   double * resp;             // [na][ny][nx] penalised responses (only when write_resp)

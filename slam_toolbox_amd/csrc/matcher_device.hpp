@@ -63,12 +63,12 @@ typedef __attribute__((address_space(1))) uint32_t gu32;
 __device__ __forceinline__ const gbyte * as_global(const uint8_t * p) {return (const gbyte *)p;}
 __device__ __forceinline__ const gint * as_global(const int32_t * p) {return (const gint *)p;}
 
-// Does any stamp footprint overlap the window [x_lo, x_hi] x [y_lo, y_hi] (grid cells)?  One bit per 32 x 32 block, rows padded
+// Does any stamp footprint overlap the window [x_lo, x_hi] x [y_lo, y_hi] (grid cells)?  One bit per block of 2^bshift cells squared, rows padded
 // by a word; rows above and below the array hold nothing.  No early exit: the probes are independent loads.
-__device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w, int bm_h, int x_lo, int y_lo, int x_hi, int y_hi)
+__device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w, int bm_h, int x_lo, int y_lo, int x_hi, int y_hi, int bshift)
 {
-  const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
-  const int by0 = max(y_lo, 0) >> kBlockShift, by1 = min(y_hi >> kBlockShift, bm_h - 1);
+  const int bx0 = x_lo >> bshift, bx1 = x_hi >> bshift;
+  const int by0 = max(y_lo, 0) >> bshift, by1 = min(y_hi >> bshift, bm_h - 1);
   const int wi = bx0 >> 5, sh = bx0 & 31, nb = bx1 - bx0 + 1;
   if (nb > 32) {return true;}
   const unsigned long long span = (1ull << nb) - 1ull;

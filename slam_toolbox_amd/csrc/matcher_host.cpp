@@ -38,7 +38,7 @@ void fill_raster_job(const kh_matcher * m, const Slot & s, const double * pose, 
   j.active = s.d_ractive; j.n_points = n_points;
   j.ws = m->ws; j.roi_x = m->roi_x; j.roi_y = m->roi_y; j.roi_w = m->roi_w; j.roi_h = m->roi_h;
   j.kernel_size = m->kernel_size; j.off_x = s.off_x; j.off_y = s.off_y; j.scale = m->scale;
-  j.blockmap = s.d_blockmap; j.bm_w = m->bm_w; j.bm_h = m->bm_h;
+  j.blockmap = s.d_blockmap; j.bm_w = m->bm_w; j.bm_h = m->bm_h; j.bshift = m->bshift;
   const size_t nt = static_cast<size_t>(m->rt_w) * m->rt_h;
   j.tiles_w = m->rt_w; j.tiles_h = m->rt_h; j.height = m->data_size / m->ws;
   j.tile_count = s.d_rtiles; j.tile_cursor = s.d_rtiles + nt; j.n_work = s.d_rtiles + 2 * nt;
@@ -571,7 +571,7 @@ void prepare_job(kh_matcher * m, const CorrReq & q, CorrHost & c, const StageLay
     job->list_tiles = (tiles >= 4 && tiles <= c.lt_alloc) ? tiles : 1;
   }
   job->sums = s.d_sums; job->resp = s.d_resp; job->out = d_out; job->out_words = static_cast<int32_t>(out_words);
-  job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h;
+  job->blockmap = m->dense_score ? nullptr : s.d_blockmap; job->bm_w = m->bm_w; job->bm_h = m->bm_h; job->bshift = m->bshift;
   job->tile_best = s.d_tile_best;
   // re-pitched copies: linear full-resolution lattice one tile wide (the copy is picked per beam for the tile at x0 = 0)
   {
@@ -1161,8 +1161,12 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   }
   m->rt_w = (m->ws + kRasterTile - 1) / kRasterTile;
   m->rt_h = (m->data_size / m->ws + kRasterTile - 1) / kRasterTile;
-  m->bm_w = (((m->ws >> kBlockShift) + 1) + 31) / 32 + 1;     // words per block row (+1 padding word)
-  m->bm_h = (m->data_size / m->ws >> kBlockShift) + 2;
+  // occupancy block map: 8 x 8-cell blocks where the searches are small and a stamp is (a stamp marks every block its footprint
+  // overlaps: 41 x 41 cells are 49 blocks of 8 x 8), 32 x 32-cell blocks otherwise.  On the config-2 search the finer map leaves
+  // out 9 % more windows.
+  m->bshift = (m->kernel_size <= 25 && m->side <= 64) ? 3 : kBlockShift;
+  m->bm_w = (((m->ws >> m->bshift) + 1) + 31) / 32 + 1;     // words per block row (+1 padding word)
+  m->bm_h = (m->data_size / m->ws >> m->bshift) + 2;
   m->slots.resize(max_batch);
   for (auto & s : m->slots) {
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid_alloc), static_cast<size_t>(m->data_size) + 2 * m->grid_pad)) != hipSuccess) {return fail(e, "hipMalloc grid");}

@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256) void k_raster_bin(const RasterJob * jobs)
     int32_t * cell = job.cell_xy + 2 * (size_t)pe[e];
     if (pe[e] < job.n_points) {cell[0] = on[e] ? cx[e] : -1; cell[1] = on[e] ? cy[e] : -1;}
     if (on[e]) {
-      const int fx0 = (cx[e] - hk) >> kBlockShift, fx1 = (cx[e] + hk) >> kBlockShift;
-      const int fy0 = (cy[e] - hk) >> kBlockShift, fy1 = (cy[e] + hk) >> kBlockShift;
+      const int fx0 = (cx[e] - hk) >> job.bshift, fx1 = (cx[e] + hk) >> job.bshift;
+      const int fy0 = (cy[e] - hk) >> job.bshift, fy1 = (cy[e] + hk) >> job.bshift;
       for (int by = fy0; by <= fy1; ++by) {
         for (int bx = fx0; bx <= fx1; ++bx) {
           uint32_t * word = job.blockmap + (size_t)by * job.bm_w + (bx >> 5);
@@ -976,9 +976,9 @@ __global__ __launch_bounds__(256) void k_offsets(const uint8_t * jobs, size_t st
           const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;
           if (in_row) {
             auto any_block = [&](int x_lo, int y_lo, int x_hi, int y_hi) {
-              const int bx0 = x_lo >> kBlockShift, bx1 = x_hi >> kBlockShift;
+              const int bx0 = x_lo >> job.bshift, bx1 = x_hi >> job.bshift;
               // rows above and below the array hold nothing
-              const int by0 = max(y_lo, 0) >> kBlockShift, by1 = min(y_hi >> kBlockShift, job.bm_h - 1);
+              const int by0 = max(y_lo, 0) >> job.bshift, by1 = min(y_hi >> job.bshift, job.bm_h - 1);
               // bits bx0 .. bx1 of every block row: two adjacent words cover them (the rows carry a padding
               // word).  No early exit: the probes are independent loads.
               const int wi = bx0 >> 5, sh = bx0 & 31, nb = bx1 - bx0 + 1;
@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   const int64_t bmin = job.base0;
   const int64_t bmax = (int64_t)job.base0 + (int64_t)(job.nx - 1) * job.sx + (int64_t)(job.ny - 1) * job.sy_ws;
   const int32_t xs = (job.nx - 1) * job.sx + 1, ys = (job.ny - 1) * job.sy_cells + 1;   // cells a window covers
-  const int ws = job.ws, bm_w = job.bm_w, bm_h = job.bm_h, na = job.na, base0 = job.base0;
+  const int ws = job.ws, bm_w = job.bm_w, bm_h = job.bm_h, bshift = job.bshift, na = job.na, base0 = job.base0;
   const float inv_ws = 1.0f / (float)ws;
   const int64_t data_size = job.data_size, pad = job.pad;
   const double off_x = job.grid_off_x, off_y = job.grid_off_y, scale = job.scale;
@@ -1631,7 +1631,7 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
                 int32_t wx0 = start - wy0 * ws;
                 while (wx0 < 0) {wx0 += ws; --wy0;}
                 while (wx0 >= ws) {wx0 -= ws; ++wy0;}
-                if (wx0 + xs <= ws && !window_has_blocks(bmp, bm_w, bm_h, wx0, wy0, wx0 + xs - 1, wy0 + ys - 1)) {
+                if (wx0 + xs <= ws && !window_has_blocks(bmp, bm_w, bm_h, wx0, wy0, wx0 + xs - 1, wy0 + ys - 1, bshift)) {
                   gy[q] = kNotFast;
                 }
               }

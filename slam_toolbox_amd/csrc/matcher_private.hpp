@@ -185,7 +185,7 @@ struct kh_matcher
   bool keep_responses = false;
   bool force_chunks = std::getenv("KH_FORCE_CHUNKS") != nullptr;       // kh_matcher_set_debug bit 3: chunk every batch of >= 128 (tests)
   bool dense_score = false;        // kh_matcher_set_debug bit 2: do not skip beams whose window is empty
-  int32_t bm_w = 0, bm_h = 0;
+  int32_t bm_w = 0, bm_h = 0, bshift = kBlockShift;    // occupancy block map: words per row, rows, log2 of the block side
   int32_t rt_w = 0, rt_h = 0;      // rasteriser tiles over the grid
   int32_t pitch2 = 0, copy_b = 0;  // dual-copy layout: row pitch (multiple of 128) and byte offset of copy B
   int32_t pad_rows = 0;            // zero rows in front of and behind every slot's grid and copies (CorrJob::pad)

@@ -114,7 +114,9 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   const int32_t n_foot = static_cast<int32_t>(m->footprint100.size()) - 1;
   if (n_scans == 0 || pts <= 0) {return ineligible(4);}
   if (n_scans > kSeqMaxScans || pts > kSeqMaxPoints || tiles > kSeqMaxTiles) {return ineligible(5);}
-  const size_t bin_lds = seq_bin_lds_bytes(static_cast<int32_t>(pts), n_foot, tiles, bm_words);
+  size_t bin_lds = seq_bin_lds_bytes(static_cast<int32_t>(pts), n_foot, tiles, bm_words);
+  const bool bm_global = bin_lds > 150 * 1024;
+  if (bm_global) {bin_lds = seq_bin_lds_bytes(static_cast<int32_t>(pts), n_foot, tiles, 0);}
   if (bin_lds > 150 * 1024) {return ineligible(6);}
   const int32_t np = static_cast<int32_t>(pts);
   SeqState & Q = *m->seq;
@@ -236,7 +238,7 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   launch_seq_prep(pa, st);
   launch_seq_links(Q.d_job, np, Q.d_first, Q.d_cand, Q.d_ctl, st);
   const bool has_copies = s.d_grid2 != nullptr;
-  launch_seq_bin(Q.d_job, Q.d_cand, Q.d_ctl, has_copies ? 0 : 1, bin_lds, fused_tiles ? Q.d_work2 : nullptr, Q.d_dbg, st);
+  launch_seq_bin(Q.d_job, Q.d_cand, Q.d_ctl, has_copies ? 0 : 1, bin_lds, fused_tiles ? Q.d_work2 : nullptr, bm_global ? 1 : 0, Q.d_dbg, st);
   KS_HIP(hipGetLastError());
 
   // ---- 2. the coarse search's host half (tables with libm), while the kernels above run

@@ -175,17 +175,17 @@ __device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long lo
 //     "previous" list Grid::Clear of the next match zeroes); the lists are written from the ranks.
 constexpr int kBinRegs = 8;
 __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t * cand, const int32_t * ctl, int keep_prev,
-  int4 * work2, long long * dbg)
+  int4 * work2, int bm_global, long long * dbg)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   __shared__ unsigned long long s_w[16];
   // everything the kernel reads from the job, once: behind a store the compiler has to assume the job block itself changed and
   // re-reads every field through the scalar cache -- a wait per field and loop trip
-  struct {int n_points, n_foot, tiles_w, tiles_h, bm_w, bm_h, roi_x, roi_y, roi_w, kernel_size;
+  struct {int n_points, n_foot, tiles_w, tiles_h, bm_w, bm_h, bshift, roi_x, roi_y, roi_w, kernel_size;
           int32_t * rank, * list, * tile_start, * tile_count, * work, * prev_work, * n_work; uint32_t * blockmap;} job;
   {
     const RasterJob & j = *jobp;
-    job.n_points = j.n_points; job.n_foot = j.n_foot; job.tiles_w = j.tiles_w; job.tiles_h = j.tiles_h; job.bm_w = j.bm_w; job.bm_h = j.bm_h;
+    job.n_points = j.n_points; job.n_foot = j.n_foot; job.tiles_w = j.tiles_w; job.tiles_h = j.tiles_h; job.bm_w = j.bm_w; job.bm_h = j.bm_h; job.bshift = j.bshift;
     job.roi_x = j.roi_x; job.roi_y = j.roi_y; job.roi_w = j.roi_w; job.kernel_size = j.kernel_size;
     job.rank = j.rank; job.list = j.list; job.tile_start = j.tile_start; job.tile_count = j.tile_count; job.work = j.work;
     job.prev_work = j.prev_work; job.n_work = j.n_work; job.blockmap = j.blockmap;
@@ -199,7 +199,9 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
   const int state_bytes = job.n_foot > 0 ? ((job.n_points + 15) & ~15) : 0;
   volatile uint8_t * state = s_dyn;
   int32_t * s_cnt = reinterpret_cast<int32_t *>(s_dyn + state_bytes);
-  uint32_t * s_bm = reinterpret_cast<uint32_t *>(s_cnt + tiles);
+  // the occupancy block map is built in LDS and written out once -- or, when it does not fit beside the rest (8 x 8-cell blocks
+  // of a large grid: 134 KB for the config-2 geometry), marked in place
+  uint32_t * s_bm = bm_global ? job.blockmap : reinterpret_cast<uint32_t *>(s_cnt + tiles);
   for (int i = tid; i < tiles; i += 1024) {s_cnt[i] = 0;}
   for (int i = tid; i < bm_words; i += 1024) {s_bm[i] = 0u;}
   const int4 * rec = reinterpret_cast<const int4 *>(cand);
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
   auto count_one = [&](int p, int cx, int cy, int (&rk)[4]) -> bool {
     rk[0] = rk[1] = rk[2] = rk[3] = -1;
     if (job.n_foot > 0 && state[p] != 1) {return false;}
-    const int fx0 = (cx - hk) >> kBlockShift, fx1 = (cx + hk) >> kBlockShift;
-    const int fy0 = (cy - hk) >> kBlockShift, fy1 = (cy + hk) >> kBlockShift;
+    const int fx0 = (cx - hk) >> job.bshift, fx1 = (cx + hk) >> job.bshift;
+    const int fy0 = (cy - hk) >> job.bshift, fy1 = (cy + hk) >> job.bshift;
     for (int by = fy0; by <= fy1; ++by) {
       for (int bx = fx0; bx <= fx1; ++bx) {
         uint32_t * word = &s_bm[by * job.bm_w + (bx >> 5)];
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
     const int rk[4] = {r4.x, r4.y, r4.z, r4.w};
     fill_one(a.x, a.y, a.z, rk);
   }
-  for (int i = tid; i < bm_words; i += 1024) {job.blockmap[i] = s_bm[i];}
+  if (!bm_global) {for (int i = tid; i < bm_words; i += 1024) {job.blockmap[i] = s_bm[i];}}
   phase();
   if (dbg && tid == 0) {dbg[stamp] = n_cand;}
 }
@@ -375,15 +377,15 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
 size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words)
 {
   const size_t state_bytes = n_foot > 0 ? (((size_t)n_points + 15) & ~(size_t)15) : 0;
-  return state_bytes + 4 * (size_t)tiles + 4 * (size_t)bm_words + 16;
+  return state_bytes + 4 * (size_t)tiles + 4 * (size_t)std::max(bm_words, 0) + 16;        // (bm_words = 0: the block map stays in global memory)
 }
 
-int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
-  void * stream)
+int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, int32_t bm_global,
+  long long * dbg, void * stream)
 {
   static std::atomic<unsigned long long> done{0};
   allow_dynamic_lds(reinterpret_cast<const void *>(kseq_bin), 158 * 1024, done);
-  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, cand, ctl, (int)keep_prev, reinterpret_cast<int4 *>(work2), dbg);
+  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, cand, ctl, (int)keep_prev, reinterpret_cast<int4 *>(work2), (int)bm_global, dbg);
   return 0;
 }
 
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slic
             int32_t wx0 = start - wy0 * ws;
             while (wx0 < 0) {wx0 += ws; --wy0;}
             while (wx0 >= ws) {wx0 -= ws; ++wy0;}
-            if (wx0 + xs <= ws && !window_has_blocks(bmp, job.bm_w, job.bm_h, wx0 + tx_lo, wy0 + ty_lo, wx0 + tx_hi, wy0 + ty_hi)) {fast = false;}
+            if (wx0 + xs <= ws && !window_has_blocks(bmp, job.bm_w, job.bm_h, wx0 + tx_lo, wy0 + ty_lo, wx0 + tx_hi, wy0 + ty_hi, job.bshift)) {fast = false;}
           }
           mycls = (int)(((int64_t)idx + bmin) & 3);
         } else if (wave == 0) {

@@ -93,8 +93,9 @@ void launch_seq_links(const RasterJob * d_job, int32_t n_points, const int32_t *
 size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words);
 // work2 (nullptr = the batch path's list format for k_raster_tile): one (tile, list start, count) record per non-empty tile and the
 // cell packed into the list entries, for kseq_tile; dbg (nullptr = none): wall_clock64 at the kernel's phase boundaries
-int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, long long * dbg,
-  void * stream);
+// bm_global: the occupancy block map is marked in global memory (it does not fit the LDS beside the rest)
+int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, int32_t bm_global,
+  long long * dbg, void * stream);
 size_t seq_tile_table_bytes();
 void seq_tile_table(const uint8_t * kernel, int32_t kernel_size, uint8_t * out);
 // what the launch between kseq_bin and the scoring does besides the stamps: the host's tables (host-coherent memory) into device

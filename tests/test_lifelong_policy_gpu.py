@@ -99,3 +99,34 @@ def test_lifelong_policy_equals_the_oracle_control_flow(kartohip_lib, tmp_path):
         assert x == y, f"solver-call logs diverge at line {k}:\n  library policy: {x}\n  oracle policy : {y}"
     assert len(la) == len(lb)
     a.close(); b.close()
+
+
+def test_lifelong_removals_do_not_depend_on_the_elimination_order(kartohip_lib, tmp_path, monkeypatch):
+    """A different elimination order (nested-dissection leaves of 16 instead of 24 nodes: another assembly tree, another
+    summation order inside every factorisation) changes the last bits of a solve.  Over this 700-scan lifelong queue that must
+    change no DECISION: the same closures, the same nodes removed at the same scans in the same order, poses equal to 1e-9.
+    (Over the 50 000-scan replay it does move the closure count by a few per cent -- DESIGN.md section 7: thousands of
+    borderline accept / reject decisions downstream of poses that differ in their last bits; the reference itself is not
+    reproducible there across Ceres / SuiteSparse builds for the same reason.)"""
+    from slam_toolbox_amd.mapper import Mapper
+    n_scans = 700
+    ranges, odom = _queue(n_scans)
+    runs = []
+    for leaf in ("24", "16"):
+        monkeypatch.setenv("KH_SPA_LEAF", leaf)
+        m = Mapper(synth.Laser())
+        m.SetLifelong(True)
+        removed = []
+        for i in range(n_scans):
+            before = set(m.alive().tolist())
+            m.Process(ranges[i], odom[i], 0.1 * i)
+            removed.append(sorted(before - set(m.alive().tolist())))
+        runs.append((removed, m.stats()["loop_closures"], m.alive().copy(), m.poses().copy()))
+        m.close()
+    monkeypatch.delenv("KH_SPA_LEAF")
+    (rem_a, closures_a, alive_a, poses_a), (rem_b, closures_b, alive_b, poses_b) = runs
+    assert sum(len(r) for r in rem_a) > 100 and closures_a >= 1
+    assert closures_a == closures_b
+    assert rem_a == rem_b
+    assert np.array_equal(alive_a, alive_b)
+    assert np.abs(poses_a - poses_b).max() < 1e-9
