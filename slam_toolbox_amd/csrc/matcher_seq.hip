@@ -295,7 +295,10 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
       for (int bx = fx0; bx <= fx1; ++bx) {
         uint32_t * word = &s_bm[by * job.bm_w + (bx >> 5)];
         const uint32_t bit = 1u << (bx & 31);
-        if ((*reinterpret_cast<volatile uint32_t *>(word) & bit) == 0u) {atomicOr(word, bit);}      // (set already for all but the first stamps of a block)
+        // in LDS: test first (the bit is set already for all but the first stamps of a block); in global memory the test would be
+        // a memory round trip per block -- the atomics leave the wave without waiting for anything
+        if (bm_global) {atomicOr(word, bit);}
+        else if ((*reinterpret_cast<volatile uint32_t *>(word) & bit) == 0u) {atomicOr(word, bit);}
       }
     }
 #pragma unroll

@@ -10,9 +10,17 @@ import glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 # the newest round's line (profiles/rN_bench_line.json) with the rocprof / PMC summaries of the same round
-ROUND = sorted(os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(PROF, "r*_bench_line.json")))[-1]
+def _round_number(tag):
+    return int("".join(ch for ch in tag if ch.isdigit()) or 0)
+
+
+ROUND = sorted((os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(PROF, "r*_bench_line.json"))), key=_round_number)[-1]
 # the dominant kernel: the windowed scoring kernel through round 3, the LDS-staged one from round 4 on
 SCORE_KERNEL = "k_score<1, 8, 1" if ROUND in ("r1", "r2", "r3") else "k_score_lds<1, 4>"
+
+
+def per_step_matches(d):
+    return d["config"]["matches_per_step_per_gpu"] * d["n_gpus"]
 
 
 def _line():
@@ -41,6 +49,22 @@ def test_line_has_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port")
+    if _round_number(ROUND) >= 5:
+        # the figures that keep their denominator from round to round: reference lookups per CU clock with and
+        # without the skipped windows, the LDS array fraction, the kernels either side of the scoring kernel from the same HIP
+        # events, the CPU quota beside the core count, and a timed region of at least 150 steps beside the K steps asked for
+        for k in ("lookups_per_cu_clk", "lookups_per_cu_clk_read", "lookups_per_cu_clk_peak_b32", "lds_array_frac", "side_kernels_ms_per_launch"):
+            assert k in r, k
+        assert 0.0 < r["lookups_per_cu_clk_read"] <= r["lookups_per_cu_clk"]
+        assert r["lookups_per_cu_clk_read"] < r["lookups_per_cu_clk_peak_b32"]
+        assert abs(r["lds_array_frac"] - 0.5 * r["frac"]) < 1e-9
+        assert set(r["side_kernels_ms_per_launch"]) == {"k_offsets_lds", "k_ties"}
+        assert "cpu_quota" in c and (c["cpu_quota"] is None or 0.0 < c["cpu_quota"] <= c["cores"])
+        w = d["value_windows"]
+        assert w["steps"] >= 150 and w["n"] >= 5 and w["min"] <= w["median"] <= w["max"]
+        assert abs(w["value"] - per_step_matches(d) * w["steps"] / w["seconds"]) / w["value"] < 1e-6
+        # the fused path of one MatchScan carried the replay's sequential matches
+        assert d["replay_fused_matches"] >= 1000 and d["replay_fused_fine_passes"] > 0.8 * d["replay_fused_matches"]
     # whole-job throughput and step time describe the same run
     per_step = d["config"]["matches_per_step_per_gpu"]
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
@@ -65,7 +89,8 @@ def _recorded(name):
     """the summary of this round, or of the newest earlier round that collected one (a round re-collects the summaries of the
     kernels it changed; bench.py reads the newest the same way)"""
     suffix = name.split("_", 1)[1]
-    have = sorted(p for p in glob.glob(os.path.join(PROF, "r[0-9]*_" + suffix)) if os.path.basename(p).split("_")[0] <= ROUND)
+    have = sorted((p for p in glob.glob(os.path.join(PROF, "r[0-9]*_" + suffix))
+                   if _round_number(os.path.basename(p).split("_")[0]) <= _round_number(ROUND)), key=lambda p: _round_number(os.path.basename(p).split("_")[0]))
     with open(have[-1]) as f:
         return json.load(f)
 
