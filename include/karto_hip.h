@@ -393,6 +393,8 @@ KH_API int kh_comm_allgather_f64(kh_comm * c, const double * device_send, double
 KH_API int kh_device_malloc(int32_t device, int64_t bytes, void ** out);
 KH_API void kh_device_free(void * p);
 KH_API int kh_device_upload(void * device_dst, const void * host_src, int64_t bytes);
+/* the upload queued on a HIP stream (hipStream_t as void *, e.g. kh_matcher_stream): ordered in front of whatever is launched there next */
+KH_API int kh_device_upload_on(void * device_dst, const void * host_src, int64_t bytes, void * hip_stream);
 KH_API int kh_device_download(void * host_dst, const void * device_src, int64_t bytes);
 
 /* ---------------------------------------------------------------- loop-candidate enumeration (next row f-1) */

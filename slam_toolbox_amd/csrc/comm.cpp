@@ -190,6 +190,17 @@ int kh_device_upload(void * device_dst, const void * host_src, int64_t bytes)
   return KH_OK;
 }
 
+/* The same copy queued on `hip_stream` (what a kernel launched on that stream afterwards reads is the new content); the host
+ * buffer may be reused when the call returns (pageable memory is staged by the runtime before it does). */
+int kh_device_upload_on(void * device_dst, const void * host_src, int64_t bytes, void * hip_stream)
+{
+  if (!device_dst || !host_src || bytes < 0) {return KH_ERR_INVALID_ARG;}
+  if (hipMemcpyAsync(device_dst, host_src, static_cast<size_t>(bytes), hipMemcpyHostToDevice, static_cast<hipStream_t>(hip_stream)) != hipSuccess) {
+    kh::set_error("hipMemcpyAsync H2D failed"); return KH_ERR_HIP;
+  }
+  return KH_OK;
+}
+
 int kh_device_download(void * host_dst, const void * device_src, int64_t bytes)
 {
   if (!host_dst || !device_src || bytes < 0) {return KH_ERR_INVALID_ARG;}

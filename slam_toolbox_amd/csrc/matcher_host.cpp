@@ -1161,10 +1161,11 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   }
   m->rt_w = (m->ws + kRasterTile - 1) / kRasterTile;
   m->rt_h = (m->data_size / m->ws + kRasterTile - 1) / kRasterTile;
-  // occupancy block map: 8 x 8-cell blocks where the searches are small and a stamp is (a stamp marks every block its footprint
+  // occupancy block map: 8 x 8-cell blocks where the searches are small, a stamp is, and the handle is made for batches (a stamp marks every block its footprint
   // overlaps: 41 x 41 cells are 49 blocks of 8 x 8), 32 x 32-cell blocks otherwise.  On the config-2 search the finer map leaves
   // out 9 % more windows.
-  m->bshift = (m->kernel_size <= 25 && m->side <= 64) ? 3 : kBlockShift;
+  // (handles made for batches: one match at a time builds its map inside one workgroup, where the coarse map is the cheaper one)
+  m->bshift = (m->kernel_size <= 25 && m->side <= 64 && max_batch >= 8) ? 3 : kBlockShift;
   m->bm_w = (((m->ws >> m->bshift) + 1) + 31) / 32 + 1;     // words per block row (+1 padding word)
   m->bm_h = (m->data_size / m->ws >> m->bshift) + 2;
   m->slots.resize(max_batch);
