@@ -80,6 +80,11 @@ struct RasterJob
   int32_t copy_kind;         // 1 = copies A / B of the grid itself; 2 = column-decimated copies (CorrJob::dec): pitch2 = their row
                              // pitch, copy_b = bytes of one of the four (even A | odd A | even B | odd B)
   int32_t * prev_work;       // [0] = number of tiles the PREVIOUS rasterisation touched, [4 ...] = their indices
+  // first-point rasteriser (matcher_seq.hip: the fused path of one MatchScan, and batches on handles whose tables fit)
+  int32_t * first;           // roi_w * roi_h: smallest job point in the cell, INT32_MAX = none (handed back clean by every rasterisation)
+  int32_t * cand;            // n_points * 8: stamp candidates (point, cx, cy, stamped | four earlier neighbour points)
+  int32_t * seq_ctl;         // 16 control words: [0] candidates
+  int32_t * work2;           // 4 * tiles: (tile, list start, count, -) per non-empty tile, for kseq_tile; nullptr = lists hold point indices
 };
 constexpr int32_t kRasterTile = 64;
 

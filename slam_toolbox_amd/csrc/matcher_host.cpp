@@ -7,6 +7,7 @@
 // (CorrelationGrid), Karto.h:4393-4563 (CoordinateConverter), :6603-6963 (GridIndexLookup),
 // :2946-3041 (Transform), Math.h.
 #include "matcher_private.hpp"
+#include "matcher_seq.hpp"
 
 namespace kh
 {
@@ -54,6 +55,35 @@ void fill_raster_job(const kh_matcher * m, const Slot & s, const double * pose, 
   }
 }
 
+int ensure_seq_tables(kh_matcher * m, Slot & s, int32_t n_points, RasterJob & j)
+{
+  hipStream_t st = m->stream;
+  int rc = ensure_device(s.d_cand, s.cap_cand, static_cast<size_t>(std::max(n_points, 1)) * 8, st); if (rc) {return rc;}
+  if (!s.d_seqctl) {KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_seqctl), sizeof(int32_t) * 16));}
+  const bool fused_tiles = m->kernel_size >= 8;
+  if (fused_tiles) {
+    rc = ensure_device(s.d_work2, s.cap_work2, 4 * static_cast<size_t>(m->rt_w) * m->rt_h, st); if (rc) {return rc;}
+    if (!m->d_tab) {
+      std::vector<uint8_t> tab(seq_tile_table_bytes());
+      seq_tile_table(m->kernel.data(), m->kernel_size, tab.data());
+      KH_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_tab), tab.size()));
+      KH_HIP(hipMemcpy(m->d_tab, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    }
+  }
+  const size_t roi_cells = static_cast<size_t>(m->roi_w) * m->roi_h;
+  if (roi_cells > s.cap_first) {
+    if (s.d_first) {KH_HIP(hipStreamSynchronize(st)); KH_HIP(hipFree(s.d_first)); s.d_first = nullptr;}
+    KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_first), roi_cells * sizeof(int32_t)));
+    s.cap_first = roi_cells; s.first_clean = false;
+  }
+  if (!s.first_clean) {
+    KH_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.d_first), INT32_MAX, roi_cells, st));
+    s.first_clean = true;
+  }
+  j.first = s.d_first; j.cand = s.d_cand; j.seq_ctl = s.d_seqctl; j.work2 = fused_tiles ? s.d_work2 : nullptr;
+  return KH_OK;
+}
+
 // ---- rasterisation of n jobs (slots[i] <- base scans of job i) ------------------------------
 
 int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
@@ -94,6 +124,24 @@ int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     n_items += scans_of[r];
   }
   const size_t items_at = meta_words;
+  // The first-point rasteriser (matcher_seq.hip) for the whole batch: no hash tables, the order-dependent rule and the binning of
+  // a job in ONE workgroup with its state in LDS.  Needs every job inside its fixed-size tables.
+  const int32_t n_foot_all = static_cast<int32_t>(m->footprint100.size()) - 1;
+  bool use_table = m->table_raster;
+  size_t bin_lds = 0;
+  bool bm_global = false;
+  if (use_table) {
+    const int32_t tiles = m->rt_w * m->rt_h, bm_words = m->bm_w * m->bm_h;
+    int32_t most = 0;
+    for (size_t r = 0; r < n_jobs; ++r) {
+      most = std::max(most, points_of[r]);
+      for (int32_t b = 0; b < reqs[r].n_base; ++b) {use_table = use_table && reqs[r].base[b].n <= kSeqMaxReadings;}
+    }
+    bin_lds = seq_bin_lds_bytes(most, n_foot_all, tiles, bm_words);
+    bm_global = bin_lds > 150 * 1024;
+    if (bm_global) {bin_lds = seq_bin_lds_bytes(most, n_foot_all, tiles, 0);}
+    use_table = use_table && most <= kSeqMaxPoints && bin_lds <= 150 * 1024;
+  }
   meta_words += 2 * n_items;
   int rc = ensure_pinned(m->h_arena, m->cap_harena, std::max<size_t>(arena_points, 1) * 2, m->stream); if (rc) {return rc;}
   rc = ensure_device(m->d_arena, m->cap_darena, std::max<size_t>(arena_points, 1) * 2, m->stream); if (rc) {return rc;}
@@ -139,7 +187,10 @@ int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     j.uniform_n = std::max(uniform_n, 0);
     any_copies = any_copies || s.d_grid2 != nullptr;
     j.n_foot = n_foot;
-    if (n_foot > 0) {
+    if (use_table) {
+      rc = ensure_seq_tables(m, s, points_of[r], j); if (rc) {return rc;}
+      s.first_clean = false;                      // until this batch's stamping launch has handed the table back
+    } else if (n_foot > 0) {
       // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon as the smear kernel
       // writes 100 off-centre: cell table for k_cell_first / k_active_set
       size_t cap = 1024;
@@ -165,7 +216,7 @@ int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   }
   KH_HIP(hipMemcpyAsync(m->d_rjobs, m->h_rjobs, sizeof(RasterJob) * n_jobs, hipMemcpyHostToDevice, m->stream));
   if (m->profiling) {KH_HIP(hipEventRecord(m->ev[2], m->stream));}
-  launch_raster_clear(m->d_rjobs, static_cast<int32_t>(n_jobs), m->stream);
+  if (!use_table) {launch_raster_clear(m->d_rjobs, static_cast<int32_t>(n_jobs), m->stream);}
   HostPool::instance().run(copies.size(), [&](size_t i) {
     std::memcpy(m->h_arena + 2 * copies[i].dst, copies[i].src, sizeof(double) * 2 * static_cast<size_t>(copies[i].n));
   });
@@ -173,9 +224,23 @@ int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     KH_HIP(hipMemcpyAsync(m->d_arena, m->h_arena, sizeof(double) * 2 * arena_points, hipMemcpyHostToDevice, m->stream));
   }
   // 3. FindValidPoints, stamps
-  launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), max_scan_n, m->stream);
-  if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
-  launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->kernel_size, m->stream);
+  if (use_table) {
+    const int32_t nj = static_cast<int32_t>(n_jobs), tiles = m->rt_w * m->rt_h;
+    launch_seq_prep_batch(m->d_rjobs, nj, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), max_scan_n, m->stream);
+    launch_seq_links(m->d_rjobs, nj, max_points, m->stream);
+    launch_seq_bin(m->d_rjobs, nj, bin_lds, bm_global ? 1 : 0, nullptr, m->stream);
+    if (m->kernel_size >= 8) {
+      launch_seq_tile(m->d_rjobs, nj, m->d_tab, max_points, tiles, nullptr, m->stream);
+    } else {
+      launch_raster_tiles(m->d_rjobs, nj, max_points, tiles, m->d_kernel, m->kernel_size, m->stream);
+      launch_seq_stage(m->d_rjobs, nj, nullptr, m->stream);
+    }
+    for (size_t r = 0; r < n_jobs; ++r) {m->slots[reqs[r].slot].first_clean = true;}
+  } else {
+    launch_find_valid(m->d_rjobs, reinterpret_cast<const ValidItem *>(m->d_meta + items_at), static_cast<int32_t>(n_items), max_scan_n, m->stream);
+    if (n_foot > 0) {launch_active_set(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, max_cap, m->stream);}
+    launch_raster(m->d_rjobs, static_cast<int32_t>(n_jobs), max_points, m->rt_w * m->rt_h, m->d_kernel, m->kernel_size, m->stream);
+  }
   launch_repitch(m->d_rjobs, static_cast<int32_t>(n_jobs), m->rt_w * m->rt_h, m->stream, any_copies);
   KH_HIP(hipGetLastError());
   if (timing) {
@@ -1168,6 +1233,14 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
   m->bshift = (m->kernel_size <= 25 && m->side <= 64 && max_batch >= 8) ? 3 : kBlockShift;
   m->bm_w = (((m->ws >> m->bshift) + 1) + 31) / 32 + 1;     // words per block row (+1 padding word)
   m->bm_h = (m->data_size / m->ws >> m->bshift) + 2;
+  // Batches take the first-point rasteriser (matcher_seq.hip) where every slot can have its table over the region of interest --
+  // 4 bytes per cell: 66 MB for the sequential preset, 260 MB for the config-2 geometry -- within 24 GB per handle; KH_TABLE_RASTER=0
+  // keeps the hash-table passes (measurements)
+  {
+    const double table_bytes = 4.0 * static_cast<double>(m->roi_w) * m->roi_h * max_batch;
+    static const bool env_off = std::getenv("KH_TABLE_RASTER") != nullptr && std::atoi(std::getenv("KH_TABLE_RASTER")) == 0;
+    m->table_raster = !env_off && table_bytes <= 24e9 && m->rt_w * m->rt_h <= 16384;
+  }
   m->slots.resize(max_batch);
   for (auto & s : m->slots) {
     if ((e = hipMalloc(reinterpret_cast<void **>(&s.d_grid_alloc), static_cast<size_t>(m->data_size) + 2 * m->grid_pad)) != hipSuccess) {return fail(e, "hipMalloc grid");}
@@ -1198,8 +1271,9 @@ void kh_matcher_destroy(kh_matcher * m)
     hipFree(s.d_chunks); hipFree(s.d_chunk_counts);
     hipFree(s.d_sums); hipFree(s.d_resp); hipFree(s.d_ractive);
     hipFree(s.d_hkeys); hipFree(s.d_hvals); hipFree(s.d_hstate); hipFree(s.d_hnbr);
+    hipFree(s.d_first); hipFree(s.d_cand); hipFree(s.d_seqctl); hipFree(s.d_work2);
   }
-  hipFree(m->d_kernel); hipFree(m->d_rjobs); hipFree(m->d_load_counter);
+  hipFree(m->d_kernel); hipFree(m->d_rjobs); hipFree(m->d_load_counter); hipFree(m->d_tab);
   for (auto & b : m->batch) {
     hipFree(b.d_stage); hipFree(b.d_out); hipFree(b.d_small);
     if (b.h_stage) {hipHostFree(b.h_stage);}

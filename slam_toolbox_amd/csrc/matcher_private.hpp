@@ -150,6 +150,12 @@ struct Slot
   double * d_tile_best = nullptr; size_t cap_tile_best = 0;
   int32_t * d_rtiles = nullptr;      // tile_count | tile_cursor | n_work(+pad) | tile_start | work   (first three zeroed per raster)
   int32_t * d_rlists = nullptr; size_t cap_rlists = 0;   // cell_xy (2 np) | list (4 np) | rank (4 np)
+  // first-point rasteriser (matcher_seq.hip): the table over the region of interest (kept clean between rasterisations), the
+  // candidate records, the control words, the (tile, start, count) records of kseq_tile
+  int32_t * d_first = nullptr; size_t cap_first = 0; bool first_clean = false;
+  int32_t * d_cand = nullptr; size_t cap_cand = 0;
+  int32_t * d_seqctl = nullptr;
+  int32_t * d_work2 = nullptr; size_t cap_work2 = 0;
   // last correlate (for the introspection calls)
   CorrHost last;
   bool has_last = false;
@@ -195,6 +201,8 @@ struct kh_matcher
   bool mfma_score = std::getenv("KH_K3_MFMA") != nullptr;   // kh_matcher_set_debug bit 5: byte sums on the matrix cores (k_score<.., MF>)
   bool lds_score = false;          // kh_matcher_set_debug bit 1: LDS-staged scoring path for every search it can take (default: the large ones)
   bool windowed_score = false;     // kh_matcher_set_debug bit 6: never (the windowed kernel k_score scores everything)
+  uint8_t * d_tab = nullptr;       // padded image of the smear kernel for kseq_tile (kernels of >= 8 x 8 cells)
+  bool table_raster = false;       // batches are rasterised by the first-point kernels too (the slots' tables fit: kh_matcher_create)
   bool no_seq = false;             // kh_matcher_set_debug bit 7: one MatchScan takes the general (batch) path instead of the fused one
   kh::SeqState * seq = nullptr;    // state of the fused path of ONE MatchScan (matcher_seq.cpp), made at its first use
   // profiling
@@ -289,5 +297,8 @@ constexpr int kSeqStatWords = 8;
 enum {kSeqStatCalls = 0, kSeqStatFineOnDevice = 1, kSeqStatFineFallback = 2, kSeqStatFineMismatch = 3, kSeqStatCoarseFallback = 4, kSeqStatFusedScore = 5};
 const int64_t * seq_stats(const kh_matcher * m);
 void fill_raster_job(const kh_matcher * m, const Slot & s, const double * pose, int32_t n_points, size_t npad, RasterJob & j);
+// the slot's tables of the first-point rasteriser for a job of n_points (allocated / grown / cleaned as needed) and the handle's
+// tile-kernel image; fills them into the job
+int ensure_seq_tables(kh_matcher * m, Slot & s, int32_t n_points, RasterJob & j);
 
 }  // namespace kh

@@ -15,9 +15,6 @@ namespace kh
 
 struct SeqState
 {
-  int32_t * d_first = nullptr; size_t cap_first = 0; bool first_clean = false;
-  int32_t * d_cand = nullptr; size_t cap_cand = 0;
-  int32_t * d_ctl = nullptr;
   SeqMid * d_mid = nullptr; int32_t * d_fsum = nullptr;
   RasterJob * d_job = nullptr;
   uint8_t * h_stage = nullptr; uint8_t * d_stage = nullptr; size_t cap_hstage = 0, cap_dstage = 0;
@@ -25,8 +22,6 @@ struct SeqState
   SeqFineOut * h_fine = nullptr;
   int32_t * h_flag = nullptr;
   int32_t seq = 0;
-  uint8_t * d_tab = nullptr;              // padded image of the smear kernel for kseq_tile
-  int32_t * d_work2 = nullptr; size_t cap_work2 = 0;
   long long * d_dbg = nullptr;            // KH_SEQ_TIMING=1: phase stamps of kseq_bin [0..7], kseq_prep [8..15], the final kernels [16..31]
   double dbg_acc[32] = {0}; long dbg_calls = 0;
   std::vector<uint8_t> fine_scratch;
@@ -46,7 +41,7 @@ void seq_destroy(kh_matcher * m)
 {
   SeqState * q = m->seq;
   if (!q) {return;}
-  (void)hipFree(q->d_dbg); (void)hipFree(q->d_tab); (void)hipFree(q->d_work2); (void)hipFree(q->d_first); (void)hipFree(q->d_cand); (void)hipFree(q->d_ctl); (void)hipFree(q->d_mid); (void)hipFree(q->d_fsum); (void)hipFree(q->d_job); (void)hipFree(q->d_stage); (void)hipFree(q->d_out);
+  (void)hipFree(q->d_dbg); (void)hipFree(q->d_mid); (void)hipFree(q->d_fsum); (void)hipFree(q->d_job); (void)hipFree(q->d_stage); (void)hipFree(q->d_out);
   if (q->h_stage) {(void)hipHostFree(q->h_stage);}
   if (q->h_out) {(void)hipHostFree(q->h_out);}
   if (q->h_fine) {(void)hipHostFree(q->h_fine);}
@@ -128,9 +123,7 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   const size_t npad = (static_cast<size_t>(np) + 3) & ~static_cast<size_t>(3);
   rc = ensure_device(s.d_ractive, s.cap_ractive, static_cast<size_t>(np), st); if (rc) {return rc;}
   rc = ensure_device(s.d_rlists, s.cap_rlists, npad * 10, st); if (rc) {return rc;}
-  rc = ensure_device(Q.d_cand, Q.cap_cand, static_cast<size_t>(np) * kSeqCandWords, st); if (rc) {return rc;}
-  if (!Q.d_ctl) {
-    KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_ctl), sizeof(int32_t) * kSeqCtlWords));
+  if (!Q.d_job) {
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_job), sizeof(RasterJob)));
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_mid), sizeof(SeqMid)));
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_fsum), sizeof(int32_t) * kSeqMaxFine));
@@ -145,25 +138,6 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     }
   }
   const bool fused_tiles = m->kernel_size >= 8;
-  if (fused_tiles) {
-    rc = ensure_device(Q.d_work2, Q.cap_work2, 4 * static_cast<size_t>(tiles), st); if (rc) {return rc;}
-    if (!Q.d_tab) {
-      std::vector<uint8_t> tab(seq_tile_table_bytes());
-      seq_tile_table(m->kernel.data(), m->kernel_size, tab.data());
-      KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_tab), tab.size()));
-      KS_HIP(hipMemcpy(Q.d_tab, tab.data(), tab.size(), hipMemcpyHostToDevice));
-    }
-  }
-  const size_t roi_cells = static_cast<size_t>(m->roi_w) * m->roi_h;
-  if (roi_cells > Q.cap_first) {
-    if (Q.d_first) {KS_HIP(hipStreamSynchronize(st)); KS_HIP(hipFree(Q.d_first)); Q.d_first = nullptr;}
-    KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_first), roi_cells * sizeof(int32_t)));
-    Q.cap_first = roi_cells; Q.first_clean = false;
-  }
-  if (!Q.first_clean) {
-    KS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(Q.d_first), kFirstNone, roi_cells, st));
-    Q.first_clean = true;
-  }
   // scans the caller does not keep on the device: one upload of their points (the matcher's arena, as in the batch path)
   std::vector<const double *> dev_ptr(static_cast<size_t>(n_base), nullptr);
   if (any_upload) {
@@ -220,6 +194,7 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   s.off_y = pose[1] - (0.5 * (m->roi_h - 1) * res);
   SeqPrepArgs pa;
   fill_raster_job(m, s, pose, np, npad, pa.job);
+  rc = ensure_seq_tables(m, s, np, pa.job); if (rc) {return rc;}
   {
     int32_t k = 0, run = 0;
     for (int32_t b = 0; b < n_base; ++b) {
@@ -233,12 +208,11 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   }
   pa.n_scans = n_scans; pa.max_n = max_n;
   pa.dbg = Q.d_dbg ? Q.d_dbg + 8 : nullptr;
-  pa.d_job = Q.d_job; pa.first = Q.d_first; pa.ctl = Q.d_ctl; pa.clear_blocks = 128;     // 2048 waves: one tile of the previous match each
-  Q.first_clean = false;                                  // until the stamping launch has handed the table back (an error in between leaves marks behind)
+  pa.d_job = Q.d_job; pa.clear_blocks = 128;     // 2048 waves: one tile of the previous match each
+  s.first_clean = false;                                  // until the stamping launch has handed the table back (an error in between leaves marks behind)
   launch_seq_prep(pa, st);
-  launch_seq_links(Q.d_job, np, Q.d_first, Q.d_cand, Q.d_ctl, st);
-  const bool has_copies = s.d_grid2 != nullptr;
-  launch_seq_bin(Q.d_job, Q.d_cand, Q.d_ctl, has_copies ? 0 : 1, bin_lds, fused_tiles ? Q.d_work2 : nullptr, bm_global ? 1 : 0, Q.d_dbg, st);
+  launch_seq_links(Q.d_job, 1, np, st);
+  launch_seq_bin(Q.d_job, 1, bin_lds, bm_global ? 1 : 0, Q.d_dbg, st);
   KS_HIP(hipGetLastError());
 
   // ---- 2. the coarse search's host half (tables with libm), while the kernels above run
@@ -303,15 +277,14 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   SeqStageArgs sa;
   sa.h_stage = Q.h_stage; sa.d_stage = Q.d_stage; sa.bytes = X.total;
   sa.sums = s.d_sums; sa.n_sums = plane * c.na; sa.out = Q.d_out; sa.out_words = out_words;
-  sa.cand = Q.d_cand; sa.ctl = Q.d_ctl; sa.first = Q.d_first; sa.roi_x = m->roi_x; sa.roi_y = m->roi_y; sa.roi_w = m->roi_w;
   if (fused_tiles) {
-    launch_seq_tile(Q.d_job, Q.d_tab, Q.d_work2, np, tiles, sa, st);
+    launch_seq_tile(Q.d_job, 1, m->d_tab, np, tiles, &sa, st);
   } else {
     launch_raster_tiles(Q.d_job, 1, np, tiles, m->d_kernel, m->kernel_size, st);
-    launch_seq_stage(sa, st);
+    launch_seq_stage(Q.d_job, 1, &sa, st);
   }
   KS_HIP(hipGetLastError());
-  Q.first_clean = true;
+  s.first_clean = true;
   if (s.d_grid2 != nullptr) {launch_repitch(Q.d_job, 1, tiles, st, true);}
   // table + scoring in one launch for every linear lattice (from the grid itself: a slot's copies, if it has any, are not used)
   const bool fused_score = job->linear != 0 && job->lds_path == 0 && (job->sx == 1 || job->sx == 2);

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstring>
 #include "kh_internal.hpp"
 #include "matcher_device.hpp"
 #include "matcher_seq.hpp"
@@ -15,58 +16,68 @@ namespace kh
 {
 
 // ---------------------------------------------------------------------------------------------
-// kseq_prep.  Blocks [0, n_scans): FindValidPoints of scan b (Mapper.cpp:1113-1164; find_valid_scan, 1024 threads: the walk is
-// bound by LDS latency, and sixteen waves hide four times what four do), then -- the scan's points and flags still in LDS --
-// WorldToGrid + the ROI test of AddScan (Mapper.cpp:1083-1088) for every kept reading and the FIRST point of every cell:
-// atomicMin of the job point index into first[cell].  A second point of a cell stamps the same footprint (n_foot == 0), or is
-// skipped by the "cell already 100" rule whatever happened to the first (n_foot > 0): only firsts are stamp candidates.
-// Blocks behind them: Grid::Clear (Karto.h:4612-4615) = the tiles the slot's previous rasterisation wrote, the counters.
+// kseq_prep.  One workgroup per (job, base scan): FindValidPoints of the scan (Mapper.cpp:1113-1164; find_valid_scan), then --
+// the scan's points and flags still in LDS -- WorldToGrid + the ROI test of AddScan (Mapper.cpp:1083-1088) for every kept
+// reading and the FIRST point of every cell: atomicMin of the job point index into first[cell].  A second point of a cell
+// stamps the same footprint (n_foot == 0), or is skipped by the "cell already 100" rule whatever happened to the first
+// (n_foot > 0): only firsts are stamp candidates.  Workgroups behind them: Grid::Clear (Karto.h:4612-4615) = the tiles the
+// slot's previous rasterisation wrote, the counters.  One job: everything arrives as kernel arguments; a batch: job
+// descriptors and (job, scan) items in device memory, as for k_find_valid_par.
+__device__ __forceinline__ void prep_scan(const RasterJob & job, const double2 * pts, int n, int p0, int max_n, double2 * s_fv, long long * dbg)
+{
+  uint8_t * flags = nullptr;
+  find_valid_scan<false>(pts, n, job.active + p0, job.view_x, job.view_y, max_n, s_fv, flags, dbg);
+  const double2 * P = s_fv;
+  int32_t * const first = job.first;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int32_t gx = 0, gy = 0;
+    bool on = flags[i] != 0;
+    if (on) {on = roi_cell(job, P[i], gx, gy);}
+    int2 cell = make_int2(-1, -1);
+    if (on) {
+      cell = make_int2(gx + job.roi_x, gy + job.roi_y);              // CorrelationGrid::GridIndex, Mapper.h:1122-1128
+      atomicMin(&first[(size_t)gy * job.roi_w + gx], p0 + i);
+    }
+    *reinterpret_cast<int2 *>(job.cell_xy + 2 * (size_t)(p0 + i)) = cell;
+  }
+  if (dbg && threadIdx.x == 0) {dbg[6] = (long long)wall_clock64();}
+}
+// Grid::Clear: one WAVE per tile the previous rasterisation wrote (lane = tile row, 64 bytes each) -- a workgroup walking its
+// tiles one after the other waits a memory latency per tile for the tile's index
+__device__ __forceinline__ void prep_clear(const RasterJob & job, int c, int clear_blocks)
+{
+  const int n_prev = job.prev_work[0];
+  const int waves = clear_blocks * (int)(blockDim.x >> 6);
+  const int lane = threadIdx.x & 63;
+  for (int w = c * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); w < n_prev; w += waves) {
+    const int t = job.prev_work[4 + w];
+    const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
+    const int y = ty * kRasterTile + lane, x = tx * kRasterTile;
+    if (y < job.height) {
+      uint8_t * at = job.grid + (size_t)y * job.ws + x;           // ws is a multiple of 8, the tile starts on a multiple of 64
+      const int nb = min(kRasterTile, job.ws - x);
+      for (int i = 0; i < nb; i += 8) {*reinterpret_cast<uint2 *>(at + i) = make_uint2(0u, 0u);}
+    }
+  }
+  if (c == 0) {
+    if (threadIdx.x < 4) {job.n_work[threadIdx.x] = 0;}
+    if (threadIdx.x < kSeqCtlWords) {job.seq_ctl[threadIdx.x] = 0;}
+  }
+}
+
 __global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
 {
   extern __shared__ double2 s_fv[];
   const RasterJob & job = args.job;
   const int b = blockIdx.x;
   if (b < args.n_scans) {
-    const int p0 = args.prefix[b], n = args.prefix[b + 1] - p0;
-    uint8_t * flags = nullptr;
-    find_valid_scan<false>(reinterpret_cast<const double2 *>(args.scans[b]), n, job.active + p0, job.view_x, job.view_y, args.max_n, s_fv, flags,
-      b == 0 ? args.dbg : nullptr);
-    const double2 * P = s_fv;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      int32_t gx = 0, gy = 0;
-      bool on = flags[i] != 0;
-      if (on) {on = roi_cell(job, P[i], gx, gy);}
-      int2 cell = make_int2(-1, -1);
-      if (on) {
-        cell = make_int2(gx + job.roi_x, gy + job.roi_y);              // CorrelationGrid::GridIndex, Mapper.h:1122-1128
-        atomicMin(&args.first[(size_t)gy * job.roi_w + gx], p0 + i);
-      }
-      *reinterpret_cast<int2 *>(job.cell_xy + 2 * (size_t)(p0 + i)) = cell;
-    }
-    if (args.dbg && b == 0 && threadIdx.x == 0) {args.dbg[6] = (long long)wall_clock64();}
+    const int p0 = args.prefix[b];
+    prep_scan(job, reinterpret_cast<const double2 *>(args.scans[b]), args.prefix[b + 1] - p0, p0, args.max_n, s_fv, b == 0 ? args.dbg : nullptr);
     return;
   }
-  // Grid::Clear: one WAVE per tile the previous match wrote (lane = tile row, 64 bytes each) -- a workgroup walking its tiles one
-  // after the other waited a memory latency per tile for the tile's index (21 of this kernel's first 21 us)
   const int c = b - args.n_scans;
-  {
-    const int n_prev = job.prev_work[0];
-    const int waves = args.clear_blocks * 16;
-    const int lane = threadIdx.x & 63;
-    for (int w = c * 16 + (int)(threadIdx.x >> 6); w < n_prev; w += waves) {
-      const int t = job.prev_work[4 + w];
-      const int ty = t / job.tiles_w, tx = t - ty * job.tiles_w;
-      const int y = ty * kRasterTile + lane, x = tx * kRasterTile;
-      if (y < job.height) {
-        uint8_t * at = job.grid + (size_t)y * job.ws + x;           // ws is a multiple of 8, the tile starts on a multiple of 64
-        const int nb = min(kRasterTile, job.ws - x);
-        for (int i = 0; i < nb; i += 8) {*reinterpret_cast<uint2 *>(at + i) = make_uint2(0u, 0u);}
-      }
-    }
-  }
+  prep_clear(job, c, args.clear_blocks);
   if (c == 0) {
-    if (threadIdx.x < 4) {job.n_work[threadIdx.x] = 0;}
-    if (threadIdx.x < kSeqCtlWords) {args.ctl[threadIdx.x] = 0;}
     // the job for the launches that follow
     const uint32_t * src = reinterpret_cast<const uint32_t *>(&args.job);
     uint32_t * dst = reinterpret_cast<uint32_t *>(args.d_job);
@@ -74,22 +85,55 @@ __global__ __launch_bounds__(1024) void kseq_prep(const SeqPrepArgs args)
   }
 }
 
+__global__ __launch_bounds__(256) void kseq_prep_batch(const RasterJob * jobs, const ValidItem * items, int n_items, int max_n, int clear_blocks)
+{
+  extern __shared__ double2 s_fv[];
+  const int b = blockIdx.x;
+  if (b < n_items) {
+    const RasterJob & job = jobs[items[b].job];
+    const int k = items[b].scan;
+    const int p0 = job.scan_prefix[k];
+    prep_scan(job, reinterpret_cast<const double2 *>(job.scan_ptr[k]), job.scan_prefix[k + 1] - p0, p0, max_n, s_fv, nullptr);
+    return;
+  }
+  const int c = b - n_items;
+  prep_clear(jobs[c / clear_blocks], c % clear_blocks, clear_blocks);
+}
+
+static size_t prep_lds_bytes(int max_n)
+{
+  const size_t stride_i = (size_t)max_n + 64;
+  return (size_t)max_n * sizeof(double2) + 3 * stride_i * sizeof(int32_t) + 2 * stride_i;
+}
+
 void launch_seq_prep(const SeqPrepArgs & args, void * stream)
 {
-  const size_t stride_i = (size_t)args.max_n + 64;
-  const size_t lds = (size_t)args.max_n * sizeof(double2) + 3 * stride_i * sizeof(int32_t) + 2 * stride_i;
   static std::atomic<unsigned long long> done{0};
   allow_dynamic_lds(reinterpret_cast<const void *>(kseq_prep), 64 * 1024, done);
-  hipLaunchKernelGGL(kseq_prep, dim3(args.n_scans + args.clear_blocks), dim3(1024), lds, (hipStream_t)stream, args);
+  hipLaunchKernelGGL(kseq_prep, dim3(args.n_scans + args.clear_blocks), dim3(1024), prep_lds_bytes(args.max_n), (hipStream_t)stream, args);
+}
+
+// a batch: 256 threads per (job, scan) -- thousands of scans keep the chip busy without the extra waves
+void launch_seq_prep_batch(const RasterJob * d_jobs, int32_t n_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream)
+{
+  if (n_jobs <= 0) {return;}
+  static std::atomic<unsigned long long> done{0};
+  allow_dynamic_lds(reinterpret_cast<const void *>(kseq_prep_batch), 64 * 1024, done);
+  const int clear_blocks = 16;                // per job: 64 waves a pass
+  hipLaunchKernelGGL(kseq_prep_batch, dim3(n_items + n_jobs * clear_blocks), dim3(256), prep_lds_bytes(max_n), (hipStream_t)stream, d_jobs, d_items,
+    (int)n_items, (int)max_n, clear_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------
 // kseq_links.  Thread per job point: the firsts become stamp candidates (point, cell); with the order-dependent rule
 // (Mapper.cpp:1093-1096, n_foot > 0) each takes along the first points of the cells in its 100-footprint that come EARLIER
 // (a later one can never block it) -- four independent loads where the batch path probes a hash table.
-__global__ __launch_bounds__(256) void kseq_links(const RasterJob * jobp, const int32_t * __restrict__ first, int32_t * cand, int32_t * ctl)
+__global__ __launch_bounds__(256) void kseq_links(const RasterJob * jobs)
 {
-  const RasterJob & job = *jobp;
+  const RasterJob & job = jobs[blockIdx.y];
+  const int32_t * __restrict__ first = job.first;
+  int32_t * cand = job.cand;
+  int32_t * ctl = job.seq_ctl;
   const int p = blockIdx.x * 256 + threadIdx.x;
   bool is_first = false;
   int cx = -1, cy = -1;
@@ -129,10 +173,10 @@ __global__ __launch_bounds__(256) void kseq_links(const RasterJob * jobp, const 
   }
 }
 
-void launch_seq_links(const RasterJob * d_job, int32_t n_points, const int32_t * first, int32_t * cand, int32_t * ctl, void * stream)
+void launch_seq_links(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, void * stream)
 {
-  if (n_points <= 0) {return;}
-  hipLaunchKernelGGL(kseq_links, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_job, first, cand, ctl);
+  if (n_jobs <= 0 || max_points <= 0) {return;}
+  hipLaunchKernelGGL(kseq_links, dim3((max_points + 255) / 256, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -174,8 +218,7 @@ __device__ __forceinline__ unsigned long long block_exscan_1024(unsigned long lo
 //     overlaps from LDS counters; scan of the counters -> list starts, the list of non-empty tiles (which also becomes the
 //     "previous" list Grid::Clear of the next match zeroes); the lists are written from the ranks.
 constexpr int kBinRegs = 8;
-__global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t * cand, const int32_t * ctl, int keep_prev,
-  int4 * work2, int bm_global, long long * dbg)
+__global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobs, int bm_global, long long * dbg)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   __shared__ unsigned long long s_w[16];
@@ -183,8 +226,14 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobp, int32_t
   // re-reads every field through the scalar cache -- a wait per field and loop trip
   struct {int n_points, n_foot, tiles_w, tiles_h, bm_w, bm_h, bshift, roi_x, roi_y, roi_w, kernel_size;
           int32_t * rank, * list, * tile_start, * tile_count, * work, * prev_work, * n_work; uint32_t * blockmap;} job;
+  int32_t * cand;
+  const int32_t * ctl;
+  int4 * work2;
+  int keep_prev;
   {
-    const RasterJob & j = *jobp;
+    const RasterJob & j = jobs[blockIdx.x];
+    cand = j.cand; ctl = j.seq_ctl; work2 = reinterpret_cast<int4 *>(j.work2);
+    keep_prev = j.grid2 == nullptr ? 1 : 0;          // a slot with copies of its grid: k_repitch* read the previous list first, then keep this one
     job.n_points = j.n_points; job.n_foot = j.n_foot; job.tiles_w = j.tiles_w; job.tiles_h = j.tiles_h; job.bm_w = j.bm_w; job.bm_h = j.bm_h; job.bshift = j.bshift;
     job.roi_x = j.roi_x; job.roi_y = j.roi_y; job.roi_w = j.roi_w; job.kernel_size = j.kernel_size;
     job.rank = j.rank; job.list = j.list; job.tile_start = j.tile_start; job.tile_count = j.tile_count; job.work = j.work;
@@ -383,12 +432,12 @@ size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_
   return state_bytes + 4 * (size_t)tiles + 4 * (size_t)std::max(bm_words, 0) + 16;        // (bm_words = 0: the block map stays in global memory)
 }
 
-int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, int32_t bm_global,
-  long long * dbg, void * stream)
+int launch_seq_bin(const RasterJob * d_jobs, int32_t n_jobs, size_t lds_bytes, int32_t bm_global, long long * dbg, void * stream)
 {
+  if (n_jobs <= 0) {return 0;}
   static std::atomic<unsigned long long> done{0};
   allow_dynamic_lds(reinterpret_cast<const void *>(kseq_bin), 158 * 1024, done);
-  hipLaunchKernelGGL(kseq_bin, dim3(1), dim3(1024), lds_bytes, (hipStream_t)stream, d_job, cand, ctl, (int)keep_prev, reinterpret_cast<int4 *>(work2), (int)bm_global, dbg);
+  hipLaunchKernelGGL(kseq_bin, dim3(n_jobs), dim3(1024), lds_bytes, (hipStream_t)stream, d_jobs, (int)bm_global, dbg);
   return 0;
 }
 
@@ -397,26 +446,25 @@ int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32
 // workgroup that uses them -- and the sums volume / result block of the coarse pass zeroed.  Runs as the last workgroups of the
 // stamping launch (the host makes the tables while kseq_prep .. kseq_bin run, and nothing reads them before kseq_score), or
 // as a launch of its own in front of the batch path's stamping kernel.
-// ... and the first-point table handed back clean: every cell this match touched has exactly one candidate.
-struct SeqStage
+// ... and the first-point table handed back clean: every cell a rasterisation touched has exactly one candidate.
+struct SeqStage {const uint4 * src; uint4 * dst; int units; int32_t * sums; int n_sums; unsigned long long * out; int out_words;};
+__device__ __forceinline__ void stage_copy(const SeqStage & g, const RasterJob & job, int tid, int nth)
 {
-  const uint4 * src; uint4 * dst; int units; int32_t * sums; int n_sums; unsigned long long * out; int out_words;
-  const int32_t * cand; const int32_t * ctl; int32_t * first; int roi_x, roi_y, roi_w;
-};
-__device__ __forceinline__ void stage_copy(const SeqStage & g, int tid, int nth)
-{
-  const int n_cand = g.ctl[0];
+  const int n_cand = job.seq_ctl[0];
+  const int roi_x = job.roi_x, roi_y = job.roi_y, roi_w = job.roi_w;
+  int32_t * const first = job.first;
+  const int4 * const rec = reinterpret_cast<const int4 *>(job.cand);
   for (int i = tid; i < g.units; i += nth) {g.dst[i] = g.src[i];}
   for (int i = tid; i < g.n_sums; i += nth) {g.sums[i] = 0;}
   for (int i = tid; i < g.out_words; i += nth) {g.out[i] = 0ull;}
   for (int i = tid; i < n_cand; i += nth) {
-    const int4 a = reinterpret_cast<const int4 *>(g.cand)[2 * (size_t)i];
-    g.first[(size_t)(a.z - g.roi_y) * g.roi_w + (a.y - g.roi_x)] = kFirstNone;
+    const int4 a = rec[2 * (size_t)i];
+    first[(size_t)(a.z - roi_y) * roi_w + (a.y - roi_x)] = kFirstNone;
   }
 }
-__global__ __launch_bounds__(256) void kseq_stage(const SeqStage g)
+__global__ __launch_bounds__(256) void kseq_stage(const RasterJob * jobs, const SeqStage g)
 {
-  stage_copy(g, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  stage_copy(g, jobs[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // kseq_tile: SmearPoint (Mapper.h:1152-1183) of one job's stamped points, tile by tile, for smear kernels of 8 x 8 .. 41 x 41
@@ -429,16 +477,16 @@ constexpr int kTabPitch = 192;               // 64 zeros | <= 41 values | zeros:
 constexpr int kTabGuard = 15;                // zero rows above and below
 constexpr int kTabRows = 41 + 2 * kTabGuard;
 constexpr int kTileStageBlocks = 16;
-__global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobp, const uint4 * __restrict__ tab, const int4 * __restrict__ work2, int tile_blocks,
-  const SeqStage stage)
+__global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobs, const uint4 * __restrict__ tab, int tile_blocks, const SeqStage stage)
 {
+  const RasterJob & job = jobs[blockIdx.y];
   if ((int)blockIdx.x >= tile_blocks) {
-    stage_copy(stage, ((int)blockIdx.x - tile_blocks) * 512 + (int)threadIdx.x, ((int)gridDim.x - tile_blocks) * 512);
+    stage_copy(stage, job, ((int)blockIdx.x - tile_blocks) * 512 + (int)threadIdx.x, ((int)gridDim.x - tile_blocks) * 512);
     return;
   }
   __shared__ __attribute__((aligned(16))) uint8_t s_tab[kTabRows * kTabPitch];
   __shared__ int32_t s_pxy[512];
-  const RasterJob & job = *jobp;
+  const int4 * __restrict__ work2 = reinterpret_cast<const int4 *>(job.work2);
   const int n_work = job.n_work[0];
   if ((int)blockIdx.x >= n_work) {return;}
   const int k = job.kernel_size, hk = k / 2, ws = job.ws, height = job.height, tiles_w = job.tiles_w;
@@ -490,21 +538,23 @@ __global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobp, const u
   }
 }
 
-static SeqStage make_stage(const SeqStageArgs & a)
+static SeqStage make_stage(const SeqStageArgs * a)
 {
   SeqStage g;
-  g.src = reinterpret_cast<const uint4 *>(a.h_stage); g.dst = reinterpret_cast<uint4 *>(a.d_stage); g.units = (int)((a.bytes + 15) / 16);
-  g.sums = a.sums; g.n_sums = (int)a.n_sums; g.out = a.out; g.out_words = (int)a.out_words;
-  g.cand = a.cand; g.ctl = a.ctl; g.first = a.first; g.roi_x = a.roi_x; g.roi_y = a.roi_y; g.roi_w = a.roi_w;
+  std::memset(&g, 0, sizeof(g));
+  if (a) {
+    g.src = reinterpret_cast<const uint4 *>(a->h_stage); g.dst = reinterpret_cast<uint4 *>(a->d_stage); g.units = (int)((a->bytes + 15) / 16);
+    g.sums = a->sums; g.n_sums = (int)a->n_sums; g.out = a->out; g.out_words = (int)a->out_words;
+  }
   return g;
 }
 
-void launch_seq_stage(const SeqStageArgs & a, void * stream)
+void launch_seq_stage(const RasterJob * d_jobs, int32_t n_jobs, const SeqStageArgs * a, void * stream)
 {
+  if (n_jobs <= 0) {return;}
   const SeqStage g = make_stage(a);
-  const size_t n_sums = a.n_sums;
-  const int blocks = std::max(1, std::min(64, (int)((std::max<size_t>(g.units, n_sums) + 255) / 256)));
-  hipLaunchKernelGGL(kseq_stage, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  const int blocks = a ? std::max(1, std::min(64, (int)((std::max<size_t>(g.units, a->n_sums) + 255) / 256))) : 8;
+  hipLaunchKernelGGL(kseq_stage, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, d_jobs, g);
 }
 
 // the padded image of the smear kernel kseq_tile copies into LDS (host memory, kTabRows x kTabPitch bytes)
@@ -517,13 +567,14 @@ void seq_tile_table(const uint8_t * kernel, int32_t kernel_size, uint8_t * out)
   }
 }
 
-void launch_seq_tile(const RasterJob * d_job, const uint8_t * d_tab, const int32_t * d_work2, int32_t max_points, int32_t max_tiles,
-  const SeqStageArgs & a, void * stream)
+void launch_seq_tile(const RasterJob * d_jobs, int32_t n_jobs, const uint8_t * d_tab, int32_t max_points, int32_t max_tiles, const SeqStageArgs * a,
+  void * stream)
 {
+  if (n_jobs <= 0) {return;}
   const SeqStage g = make_stage(a);
-  const int tile_blocks = std::max(1, std::min(std::min(max_tiles, 4 * max_points), 1024));
-  hipLaunchKernelGGL(kseq_tile, dim3(tile_blocks + kTileStageBlocks), dim3(512), 0, (hipStream_t)stream, d_job, reinterpret_cast<const uint4 *>(d_tab),
-    reinterpret_cast<const int4 *>(d_work2), tile_blocks, g);
+  const int tile_blocks = std::max(1, std::min(std::min(max_tiles, 4 * max_points), n_jobs > 1 ? 2048 : 1024));
+  hipLaunchKernelGGL(kseq_tile, dim3(tile_blocks + (a ? kTileStageBlocks : 4), n_jobs), dim3(512), 0, (hipStream_t)stream, d_jobs,
+    reinterpret_cast<const uint4 *>(d_tab), tile_blocks, g);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -47,8 +47,6 @@ struct SeqPrepArgs
   int32_t prefix[kSeqMaxScans + 1];
   int32_t n_scans, max_n;
   RasterJob * d_job;                       // device copy for the launches that follow
-  int32_t * first;                         // roi_w * roi_h: smallest job point in the cell, kFirstNone = none (left clean by kseq_bin)
-  int32_t * ctl;                           // [0] candidates (zeroed here)
   int32_t clear_blocks;
   long long * dbg;                         // nullptr, or three wall_clock64 stamps of the first scan's workgroup (measurements)
 };
@@ -88,31 +86,30 @@ struct SeqFinalArgs
 };
 
 void launch_seq_prep(const SeqPrepArgs & args, void * stream);
-void launch_seq_links(const RasterJob * d_job, int32_t n_points, const int32_t * first, int32_t * cand, int32_t * ctl, void * stream);
-// dynamic LDS of kseq_bin for a job (the host checks it against the device's limit)
+// The rasteriser's launches, for one job (the descriptor kseq_prep left in device memory) or a batch (blockIdx.y = job): the
+// per-job tables travel in the RasterJob (first, cand, seq_ctl, work2)
+void launch_seq_prep_batch(const RasterJob * d_jobs, int32_t n_jobs, const ValidItem * d_items, int32_t n_items, int32_t max_n, void * stream);
+void launch_seq_links(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, void * stream);
+// dynamic LDS of kseq_bin for a job (the host checks it against the device's limit; bm_words = 0: the block map stays in global memory)
 size_t seq_bin_lds_bytes(int32_t n_points, int32_t n_foot, int32_t tiles, int32_t bm_words);
-// work2 (nullptr = the batch path's list format for k_raster_tile): one (tile, list start, count) record per non-empty tile and the
-// cell packed into the list entries, for kseq_tile; dbg (nullptr = none): wall_clock64 at the kernel's phase boundaries
-// bm_global: the occupancy block map is marked in global memory (it does not fit the LDS beside the rest)
-int launch_seq_bin(const RasterJob * d_job, int32_t * cand, int32_t * ctl, int32_t keep_prev, size_t lds_bytes, int32_t * work2, int32_t bm_global,
-  long long * dbg, void * stream);
+// bm_global: the occupancy block map is marked in global memory; dbg (nullptr = none): wall_clock64 at the kernel's phase boundaries
+int launch_seq_bin(const RasterJob * d_jobs, int32_t n_jobs, size_t lds_bytes, int32_t bm_global, long long * dbg, void * stream);
 size_t seq_tile_table_bytes();
 void seq_tile_table(const uint8_t * kernel, int32_t kernel_size, uint8_t * out);
-// what the launch between kseq_bin and the scoring does besides the stamps: the host's tables (host-coherent memory) into device
-// memory, volume and result block of the coarse pass zeroed, the first-point table handed back clean
+// what the launch between kseq_bin and the scoring of ONE match does besides the stamps: the host's tables (host-coherent memory)
+// into device memory, volume and result block of the coarse pass zeroed.  (Always: the first-point table handed back clean.)
 struct SeqStageArgs
 {
   const void * h_stage; void * d_stage; size_t bytes;
   int32_t * sums; size_t n_sums; unsigned long long * out; size_t out_words;
-  const int32_t * cand; const int32_t * ctl; int32_t * first; int32_t roi_x, roi_y, roi_w;
 };
-// stamping (smear kernels of >= 8 x 8 cells) + the staging work in one launch
-void launch_seq_tile(const RasterJob * d_job, const uint8_t * d_tab, const int32_t * d_work2, int32_t max_points, int32_t max_tiles,
-  const SeqStageArgs & stage, void * stream);
+// stamping (smear kernels of >= 8 x 8 cells) + the staging work (stage = nullptr: only the table's reset) in one launch
+void launch_seq_tile(const RasterJob * d_jobs, int32_t n_jobs, const uint8_t * d_tab, int32_t max_points, int32_t max_tiles, const SeqStageArgs * stage,
+  void * stream);
 void launch_raster_tiles(const RasterJob * d_jobs, int32_t n_jobs, int32_t max_points, int32_t max_tiles, const uint8_t * d_kernel, int32_t kernel_size,
   void * stream);
 // ... or on its own, behind the batch path's stamping kernel (smaller smear kernels)
-void launch_seq_stage(const SeqStageArgs & stage, void * stream);
+void launch_seq_stage(const RasterJob * d_jobs, int32_t n_jobs, const SeqStageArgs * stage, void * stream);
 // (sx = grid cells per lattice step, ry = rows per lane: the windowed kernel's tile shape, pick_ry)
 void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32_t nx, int32_t ny, int32_t sx, int32_t ry, void * stream);
 void launch_seq_cells(const uint8_t * d_job, int32_t plane, unsigned long long * h_lattice, void * stream);
