@@ -443,12 +443,15 @@ def loop_leg(device=0, n_pairs=256, batch=256, cpu=True, resident=True):
     k1_ms = pL["raster_ms"] + pS["raster_ms"]
     if k1_ms > 0:
         gbs = k1_bytes / (k1_ms * 1e-3) / 1e9
-        K1 = ("k_raster_", "k_find_valid", "k_cell_", "k_active_set", "k_repitch")
+        # (round 5: the first-point rasteriser kseq_prep_batch / kseq_links / kseq_bin / kseq_tile / kseq_stage carries the batches of
+        # both presets; the hash-table passes k_cell_* / k_active_set / k_raster_bin remain for handles whose tables do not fit)
+        K1 = ("k_raster_", "k_find_valid", "k_cell_", "k_active_set", "k_repitch", "kseq_prep", "kseq_links", "kseq_bin", "kseq_tile", "kseq_stage")
         loop_name = newest_profile("loop_pmc.json")
         doc = recorded_kernels(loop_name)
-        batches = doc.get("kernels", {}).get("k_raster_scan", {}).get("calls", 0) / 2.0         # one launch per stage (L, S) of a batch
+        per_stage = doc.get("kernels", {}).get("kseq_bin", doc.get("kernels", {}).get("k_raster_scan", {}))
+        batches = per_stage.get("calls", 0) / 2.0                                                # one launch per stage (L, S) of a batch
         traffic = recorded_traffic(doc, K1, batches)
-        out["loop_rooflines"] = [{"kernel": "K1 k_find_valid + k_cell_* + k_active_set + k_raster_* + k_repitch*, presets L and S", "bound": "hbm",
+        out["loop_rooflines"] = [{"kernel": "K1 rasteriser (kseq_prep_batch + kseq_links + kseq_bin + kseq_tile / k_raster_tile + k_repitch*), presets L and S", "bound": "hbm",
                                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": k1_bytes,
                                   "gpu_ms": k1_ms, "traffic": traffic,
                                   "traffic_gbs": (traffic / (k1_ms * 1e-3) / 1e9) if traffic else None,

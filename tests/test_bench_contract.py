@@ -109,8 +109,9 @@ def test_loop_and_solver_rooflines_carry_the_recorded_traffic():
         return
     d = _line()
     loop = _recorded(f"{ROUND}_loop_pmc.json")
-    batches = loop["kernels"]["k_raster_scan"]["calls"] / 2.0
-    want = _traffic(loop, ("k_raster_", "k_find_valid", "k_cell_", "k_active_set", "k_repitch"), batches)
+    per_stage = loop["kernels"].get("kseq_bin", loop["kernels"].get("k_raster_scan"))
+    batches = per_stage["calls"] / 2.0
+    want = _traffic(loop, ("k_raster_", "k_find_valid", "k_cell_", "k_active_set", "k_repitch", "kseq_prep", "kseq_links", "kseq_bin", "kseq_tile", "kseq_stage"), batches)
     got = d["loop_rooflines"][0]["traffic"]
     assert got is not None and abs(got - want) / want < 0.03
     assert 0.0 < d["loop_rooflines"][0]["frac"] <= 1.0
