@@ -62,7 +62,7 @@ static int ensure_coherent(T *& p, size_t & cap, size_t need)
   if (need <= cap) {return KH_OK;}
   if (p) {KS_HIP(hipHostFree(p)); p = nullptr;}
   const size_t n = std::max(need, cap + cap / 2);
-  KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent));
+  KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
   cap = n;
   return KH_OK;
 }
