@@ -221,7 +221,7 @@ KH_API int kh_matcher_set_debug(kh_matcher * m, int32_t flags);
  * general path (degenerate searches: more ties than the result block holds), [5] coarse passes scored by the fused
  * table + scoring kernel (linear lattices), [6] calls that went the general way because the fused kernels' fixed-size tables
  * cannot take them, [7] the last such call's reason (1 profiling / kept volume, 2 query beams, 3 readings per base scan,
- * 4 no base readings, 5 scans / points / tiles, 6 LDS). */
+ * 4 no base readings, 5 scans / points / tiles, 6 LDS, 7 no host-coherent memory: the handle keeps the general path). */
 KH_API int kh_matcher_seq_stats(kh_matcher * m, int64_t out[8]);
 /* The handle's main HIP stream (hipStream_t as void*): every kernel of a call that is not a chunked batch is launched on it, so
  * the caller can bracket launches with HIP events there; chunked batches (>= 128 large searches) run their chunks on two

@@ -92,6 +92,8 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   if (!m->seq) {m->seq = new SeqState();}
   // a call the kernels' fixed-size tables cannot take goes the general way; stats [6] counts them, [7] keeps the last reason
   auto ineligible = [&](int64_t reason) {m->seq->stats[6] += 1; m->seq->stats[7] = reason; return KH_OK;};
+  // a platform that does not hand out host-coherent mapped memory keeps the general path for this handle (reason 7)
+  auto no_coherent_memory = [&]() {m->no_seq = true; (void)hipStreamSynchronize(m->stream); m->slots[0].first_clean = false; return ineligible(7);};
   if (m->profiling || m->keep_responses) {return ineligible(1);}
   if (query->n <= 0 || query->n > kSeqMaxReadings) {return ineligible(2);}
   // ---- eligibility: what the kernels' fixed-size tables can take
@@ -128,9 +130,9 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_mid), sizeof(SeqMid)));
     KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_fsum), sizeof(int32_t) * kSeqMaxFine));
     size_t one = 0;
-    rc = ensure_coherent(Q.h_fine, one, 1); if (rc) {return rc;}
+    rc = ensure_coherent(Q.h_fine, one, 1); if (rc) {return no_coherent_memory();}
     one = 0;
-    rc = ensure_coherent(Q.h_flag, one, 16); if (rc) {return rc;}
+    rc = ensure_coherent(Q.h_flag, one, 16); if (rc) {return no_coherent_memory();}
     Q.h_flag[0] = 0;
     if (std::getenv("KH_SEQ_TIMING")) {
       KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_dbg), sizeof(long long) * 32));
@@ -220,9 +222,9 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   const StageLayout L = stage_layout(c.P, c.nx, c.ny, c.na, q.penalize);
   const SeqLayout X = seq_layout(L.total, c.nx, c.ny, c.na, naf);
   const size_t out_words = align_up(kOutHeaderWords + static_cast<size_t>(c.nx) * c.ny, 32);
-  rc = ensure_coherent(Q.h_stage, Q.cap_hstage, X.total); if (rc) {return rc;}
+  rc = ensure_coherent(Q.h_stage, Q.cap_hstage, X.total); if (rc) {return no_coherent_memory();}
   rc = ensure_device(Q.d_stage, Q.cap_dstage, Q.cap_hstage, st); if (rc) {return rc;}
-  rc = ensure_coherent(Q.h_out, Q.cap_hout, out_words); if (rc) {return rc;}
+  rc = ensure_coherent(Q.h_out, Q.cap_hout, out_words); if (rc) {return no_coherent_memory();}
   rc = ensure_device(Q.d_out, Q.cap_dout, out_words, st); if (rc) {return rc;}
   JobShape shape;
   prepare_job(m, q, c, L, Q.h_stage, Q.d_stage, Q.d_out, out_words, 1, false, true, shape);
