@@ -188,7 +188,8 @@ void launch_score(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t
 __host__ __device__ inline int32_t lds_row_waves(int32_t ny) {return ny <= 16 ? 1 : ny <= 32 ? 2 : 4;}
 inline int32_t score_tile_poses(int32_t sx) {return sx == 2 ? (kTileSpan + 1) / 2 : kTileSpan;}
 void launch_offsets_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, void * stream);
-void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream);
+// full_rows: every job's lattice has more than 32 rows (lds_row_waves = 4)
+void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, bool full_rows, void * stream);
 void launch_gather_small(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t * d_out, int32_t small_stride, void * stream);
 void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_poses, int32_t tile_pairs, void * stream);
 

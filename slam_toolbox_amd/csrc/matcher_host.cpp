@@ -888,7 +888,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   }
   if (m->profiling) {KH_HIP(hipEventRecord(B.ev[0], ks));}
   if (use_lds) {
-    launch_score_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, ks);
+    bool full_rows = true;
+    for (size_t i = 0; i < n; ++i) {full_rows = full_rows && lds_row_waves(ctx[i].ny) == 4;}
+    launch_score_lds(B.d_stage, stride, static_cast<int32_t>(n), max_na, sx_variant, full_rows, ks);
   } else if (uniform_kernel) {
     launch_score(B.d_stage, stride, static_cast<int32_t>(n), max_tiles, max_na, sx_variant, ry, ks, m->mfma_score);
   } else {

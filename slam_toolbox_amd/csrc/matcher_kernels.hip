@@ -1747,9 +1747,11 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(1))) const void gvoid;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int S, int NW>
+template <int S, int NW, bool kFull>
 __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
 {
+  // kFull: every job of the launch has a lattice of more than 32 rows -- each of an angle's NW waves has its own rows and takes every
+  // step (the bookkeeping of who takes which step leaves the chunk loop)
   constexpr int RQ = 16 / NW;                              // rows per lane (NW waves share the 64 rows of an angle's windows)
   constexpr int kThreadsPerAngle = 64 * NW;
   constexpr int PX = (S == 1) ? kTileSpan : (kTileSpan + 1) / 2;
@@ -1775,9 +1777,9 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   // The NW waves of an angle: row_waves of them share the lattice rows (4 * RQ each), and when the lattice has fewer rows than
   // the NW waves cover together (31 rows: two waves) the waves left over take every other STEP of the same rows instead of
   // scoring rows nobody asked for: wave = (share of the rows, part of the steps).
-  const int row_waves = lds_row_waves(job.ny) * (NW / 4);
-  const int parts = NW / row_waves;
-  const int share = quarter % row_waves, part = quarter / row_waves;
+  const int row_waves = kFull ? NW : lds_row_waves(job.ny) * (NW / 4);
+  const int parts = kFull ? 1 : NW / row_waves;
+  const int share = kFull ? quarter : quarter % row_waves, part = kFull ? 0 : quarter / row_waves;
   const int a = group * kGroupAngles + q;
   const bool live = a < job.na;
   const int P = job.n_points;
@@ -1816,23 +1818,26 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   constexpr int kUnitsPerRow = kLdsPitch / 16;
   constexpr int kDmaPerWave = (kLdsRegionBytes / 1024 + 2 * NW - 1) / (2 * NW);
   const int ws = job.ws;
+  // the grid offset (relative to the region's first byte) of the unit this lane moves in the wave's t-th DMA instruction is the same
+  // for every chunk: computed once (a division per instruction and chunk otherwise); past the region's last unit it is clamped to
+  // that unit's (offsets grow with the unit number): the tail block re-reads the last unit and stays in bounds
+  uint32_t dma_off[kDmaPerWave];
+#pragma unroll
+  for (int t = 0; t < kDmaPerWave; ++t) {
+    const int u = 64 * (wave + 2 * NW * t) + lane;
+    const int row = u / kUnitsPerRow, col = u - row * kUnitsPerRow;
+    dma_off[t] = (uint32_t)(row * ws + 16 * col);
+  }
   auto issue_dma = [&](const Chunk & d, int buf) {
     const gbyte * src = gwin + d.g0;
-    const int units = d.rows * kUnitsPerRow;
-    const int nblk = (units + 63) >> 6;
+    const int nblk = (d.rows * kUnitsPerRow + 63) >> 6;
+    const uint32_t o_last = (uint32_t)((d.rows - 1) * ws + 16 * (kUnitsPerRow - 1));
+    lds_u32 * dst = (lds_u32 *)s_region + buf * (kLdsRegionBytes / 4) + wave * 256;
 #pragma unroll
     for (int t = 0; t < kDmaPerWave; ++t) {
-      const int blk = wave + 2 * NW * t;
-      if (blk < nblk) {
-        // (the unit's grid offset is recomputed here: kept in registers across the chunk loop the offsets of all the units a
-        // lane ever moves cost ten VGPRs the scoring loop needs)
-        int u = 64 * blk + lane;
-        u = u < units ? u : units - 1;                      // the tail block re-reads the last unit: stays in bounds
-        const int row = u / kUnitsPerRow, col = u - row * kUnitsPerRow;
-        const int32_t o = row * ws + 16 * col;
-        lds_u32 * dst = (lds_u32 *)s_region + buf * (kLdsRegionBytes / 4) + blk * 256;
-        __builtin_amdgcn_global_load_lds((gvoid *)(src + o), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-      }
+      if (wave + 2 * NW * t >= nblk) {break;}
+      const uint32_t o = dma_off[t] < o_last ? dma_off[t] : o_last;
+      __builtin_amdgcn_global_load_lds((gvoid *)(src + o), (__attribute__((address_space(3))) void *)(dst + 2 * NW * t * 256), 16, 0, 0);
     }
   };
   // this wave's offsets of a chunk: angle q's class-sorted run, lane k = k-th window
@@ -1844,13 +1849,27 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   // accumulator set of their class.  The reads are written as asm so that every result lands in its slot of an MFMA operand
   // tuple (left to itself the compiler pairs the rows of a beam into ds_read2st64_b32 and then shuffles the halves into the
   // tuples with a dozen v_mov per step); the wait is explicit, the loads' results are tied to it.
-  // The last step of a class may hold fewer than four beams: the missing beams' slots read the zero strip behind the regions
-  // (every lane the same dwords: a broadcast) and add nothing, so every step is the same code.
+  // A wave issues one instruction per turn of its SIMD whatever the instruction is, so the step is kept to the instructions it
+  // needs -- four readlanes, four adds, sixteen reads, a wait, four MFMAs, three of loop control -- and free of branches.  The
+  // last step of a class may hold fewer than four beams: its missing slots read the step's first window again and the selector
+  // of THAT step's MFMAs leaves their dwords out, so it is the same code with a different selector (round 4: a zero strip in LDS
+  // and a branch per missing slot, in every step: 49 instructions and four taken branches where 32 and one do).
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)((char *)s_region);
   const uint32_t lds_lane = lds_base + (uint32_t)lanebase;
-  const uint32_t lds_zero = lds_base + (uint32_t)(2 * kLdsRegionBytes);
-  if (tid < RQ) {s_region[(2 * kLdsRegionBytes + tid * kRowStep) / 4] = 0u;}
 #define KH_DSR(dst, addr, r) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"((r) * kRowStep) : "memory")
+#define KH_STEP(selector) do { \
+    int32_t w[RQ][4]; \
+    _Pragma("unroll") for (int r = 0; r < RQ; ++r) {KH_DSR(w[r][0], a0, r); KH_DSR(w[r][1], a1, r); KH_DSR(w[r][2], a2, r); KH_DSR(w[r][3], a3, r);} \
+    if (RQ == 4) { \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]), \
+        "+v"(w[RQ - 2][0]), "+v"(w[RQ - 2][1]), "+v"(w[RQ - 2][2]), "+v"(w[RQ - 2][3]), "+v"(w[RQ - 1][0]), "+v"(w[RQ - 1][1]), "+v"(w[RQ - 1][2]), "+v"(w[RQ - 1][3])); \
+    } else { \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3])); \
+    } \
+    _Pragma("unroll") for (int r = 0; r < RQ; ++r) { \
+      acc[c][r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(selector, (v4i{w[r][0], w[r][1], w[r][2], w[r][3]}), acc[c][r], 0, 0, 0); \
+    } \
+  } while (0)
   int step_base = 0;
   auto score = [&](const Chunk & d, int buf, int32_t rels) {
     if (!live) {return;}
@@ -1861,44 +1880,45 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
       const int cnt = (d.packed >> (8 * c)) & 0xff;
       // this wave's steps of the class: those whose running number (over the classes and chunks of the angle) is `part`
       // modulo `parts`
-      const int first = (part - step_base) & (parts - 1);
-      step_base += (cnt + 3) >> 2;
-      for (int k = 4 * first; k < cnt; k += 4 * parts) {
-        const int i0 = off + k, rem = cnt - k;
-        int32_t w[RQ][4];
+      const int first = kFull ? 0 : (part - step_base) & (parts - 1);
+      if (!kFull) {step_base += (cnt + 3) >> 2;}
+      int k = 4 * first;
+      for (; k + 4 <= cnt; k += 4 * parts) {
+        const int i0 = off + k;
         const uint32_t a0 = base + (uint32_t)__builtin_amdgcn_readlane(rels, i0);
-        const uint32_t a1 = rem > 1 ? base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 1) : lds_zero;
-        const uint32_t a2 = rem > 2 ? base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 2) : lds_zero;
-        const uint32_t a3 = rem > 3 ? base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 3) : lds_zero;
-#pragma unroll
-        for (int r = 0; r < RQ; ++r) {KH_DSR(w[r][0], a0, r); KH_DSR(w[r][1], a1, r); KH_DSR(w[r][2], a2, r); KH_DSR(w[r][3], a3, r);}
-        if (RQ == 4) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]),
-            "+v"(w[RQ - 2][0]), "+v"(w[RQ - 2][1]), "+v"(w[RQ - 2][2]), "+v"(w[RQ - 2][3]), "+v"(w[RQ - 1][0]), "+v"(w[RQ - 1][1]), "+v"(w[RQ - 1][2]), "+v"(w[RQ - 1][3]));
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]));
-        }
-#pragma unroll
-        for (int r = 0; r < RQ; ++r) {
-          acc[c][r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, (v4i{w[r][0], w[r][1], w[r][2], w[r][3]}), acc[c][r], 0, 0, 0);
-        }
+        const uint32_t a1 = base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 1);
+        const uint32_t a2 = base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 2);
+        const uint32_t a3 = base + (uint32_t)__builtin_amdgcn_readlane(rels, i0 + 3);
+        KH_STEP(sel);
+      }
+      if (k < cnt) {
+        const int i0 = off + k, rem = cnt - k;             // 1 .. 3 windows
+        const uint32_t a0 = base + (uint32_t)__builtin_amdgcn_readlane(rels, i0);
+        const uint32_t a1 = base + (uint32_t)__builtin_amdgcn_readlane(rels, rem > 1 ? i0 + 1 : i0);
+        const uint32_t a2 = base + (uint32_t)__builtin_amdgcn_readlane(rels, rem > 2 ? i0 + 2 : i0);
+        const uint32_t a3 = a0;
+        const v4i sel_tail = v4i{sel[0], rem > 1 ? sel[1] : 0, rem > 2 ? sel[2] : 0, 0};
+        KH_STEP(sel_tail);
       }
       off += cnt;
     }
   };
+#undef KH_STEP
 #undef KH_DSR
 
   // walk the chunks of the four beam ranges in order: [barrier] DMA of the next region, score this one; the descriptor after
   // the next is already on its way through the scalar cache
-  int range = 0, k_in = 0;
   static_assert(kLdsRanges == 4, "the four chunk counts are held in scalar registers");
-  const int n_chunks0 = ccounts[0], n_chunks1 = ccounts[1], n_chunks2 = ccounts[2], n_chunks3 = ccounts[3];
+  // (chunk number -> builder range and place in it without branches: the ranges' ends)
+  const int end0 = ccounts[0], end1 = end0 + ccounts[1], end2 = end1 + ccounts[2], n_chunks = end2 + ccounts[3];
+  int fetched = 0;
   auto next_chunk = [&](Chunk & d) -> bool {
-    while (range < kLdsRanges && k_in >= (range == 0 ? n_chunks0 : range == 1 ? n_chunks1 : range == 2 ? n_chunks2 : n_chunks3)) {++range; k_in = 0;}
-    if (range >= kLdsRanges) {return false;}
-    cint * w = cdescs + ((size_t)range * range_len + k_in) * kChunkWords;
+    if (fetched >= n_chunks) {return false;}
+    const int range = (fetched >= end0 ? 1 : 0) + (fetched >= end1 ? 1 : 0) + (fetched >= end2 ? 1 : 0);
+    const int start = fetched >= end2 ? end2 : fetched >= end1 ? end1 : fetched >= end0 ? end0 : 0;
+    cint * w = cdescs + ((size_t)range * range_len + (fetched - start)) * kChunkWords;
     d.beam_begin = w[0]; d.g0 = w[2]; d.rows = w[3]; d.packed = w[4 + q];
-    ++k_in;
+    ++fetched;
     return true;
   };
   Chunk cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0}, aft = {0, 0, 0, 0};
@@ -2007,22 +2027,28 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   }
 }
 
-void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, void * stream)
+void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t max_na, int32_t sx_variant, bool full_rows, void * stream)
 {
   if (n_jobs <= 0 || max_na <= 0) {return;}
   const int groups = (max_na + kGroupAngles - 1) / kGroupAngles;
   const int xcd_map = n_jobs >= 8 ? 1 : 0;
   const int jobs_per_xcd = (n_jobs + 7) / 8;
   const long long blocks = xcd_map ? 8ll * jobs_per_xcd * groups : (long long)n_jobs * groups;
-  constexpr int kDyn = 2 * kLdsRegionBytes + 3 * 4 * 2 * kLdsPitch + 16;      // two regions + the zero strip (row step of the two-cell instance)
+  constexpr int kDyn = 2 * kLdsRegionBytes;                                  // two regions
   // four waves per angle (16 rows each, 512 threads, 4 waves per SIMD); eight (8 rows each) saturate the SIMD's VALU port: DESIGN.md
   // (per device: a group's members on other devices launch this kernel from their own threads)
-  static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
-  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 4>), kDyn, attr_done[0]);
-  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 4>), kDyn, attr_done[1]);
+  static std::atomic<unsigned long long> attr_done[4] = {{0}, {0}, {0}, {0}};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 4, true>), kDyn, attr_done[0]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 4, true>), kDyn, attr_done[1]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 4, false>), kDyn, attr_done[2]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 4, false>), kDyn, attr_done[3]);
   hipStream_t s = (hipStream_t)stream;
-#define KH_SCORE_LDS(SV, NWV) hipLaunchKernelGGL((k_score_lds<SV, NWV>), dim3((unsigned int)blocks), dim3(128 * NWV), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map)
-  if (sx_variant == 2) {KH_SCORE_LDS(2, 4);} else {KH_SCORE_LDS(1, 4);}
+#define KH_SCORE_LDS(SV, FV) hipLaunchKernelGGL((k_score_lds<SV, 4, FV>), dim3((unsigned int)blocks), dim3(512), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map)
+  if (sx_variant == 2) {
+    if (full_rows) {KH_SCORE_LDS(2, true);} else {KH_SCORE_LDS(2, false);}
+  } else {
+    if (full_rows) {KH_SCORE_LDS(1, true);} else {KH_SCORE_LDS(1, false);}
+  }
 #undef KH_SCORE_LDS
 }
 
