@@ -1938,21 +1938,44 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
 
   const size_t plane = (size_t)job.nx * job.ny;
   const int ta = tid % kThreadsPerAngle;             // thread index inside the angle's team of NW waves
-  // merge the four waves of an angle in LDS (their four accumulator sets with the classes' shifts), then one pose per thread
+  // merge the four accumulator sets of every wave with the classes' shifts, the four waves of an angle in LDS, then one pose per thread
   int32_t * s_tile = reinterpret_cast<int32_t *>(s_region) + q * (64 * PX);
-  for (int i = ta; i < 64 * PX; i += kThreadsPerAngle) {s_tile[i] = 0;}
-  __syncthreads();
-  if (live) {
-#pragma unroll
-    for (int c = 0; c < kClasses; ++c) {
+  if (S == 1 && kFull) {
+    // In registers: pose x = 4 lx + b of a row collects byte x + c of class c -- register (b + c) & 3 of this lane, or of the next
+    // lane of the row of 16 (DPP row_shl:1) where b + c reaches the next dword.  Every pose of the wave's rows comes out of exactly
+    // one lane: plain stores, no zeroing pass in front (through LDS atomics the merge was 64 of them per lane: 14 of a wave's 200
+    // thousand clocks).
+    if (live) {
 #pragma unroll
       for (int r = 0; r < RQ; ++r) {
+        int32_t * const row = s_tile + (4 * RQ * share + 4 * r + ly) * PX + 4 * lx;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int j = 4 * lx + b;                              // byte position inside the aligned window row
-          const int x = (j - c) / S;
-          const bool pose = j >= c && ((j - c) % S) == 0 && x < PX;
-          if (pose && acc[c][r][b] != 0) {atomicAdd(&s_tile[(4 * RQ * share + 4 * r + ly) * PX + x], acc[c][r][b]);}
+          int32_t total = acc[0][r][b];
+#pragma unroll
+          for (int c = 1; c < kClasses; ++c) {
+            const int32_t v = acc[c][r][(b + c) & 3];
+            total += (b + c) < 4 ? v : __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true);      // row_shl:1: lane i reads lane i + 1
+          }
+          if (4 * lx + b < PX) {row[b] = total;}
+        }
+      }
+    }
+  } else {
+    for (int i = ta; i < 64 * PX; i += kThreadsPerAngle) {s_tile[i] = 0;}
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < kClasses; ++c) {
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int j = 4 * lx + b;                              // byte position inside the aligned window row
+            const int x = (j - c) / S;
+            const bool pose = j >= c && ((j - c) % S) == 0 && x < PX;
+            if (pose && acc[c][r][b] != 0) {atomicAdd(&s_tile[(4 * RQ * share + 4 * r + ly) * PX + x], acc[c][r][b]);}
+          }
         }
       }
     }
