@@ -64,7 +64,9 @@ __device__ __forceinline__ const gbyte * as_global(const uint8_t * p) {return (c
 __device__ __forceinline__ const gint * as_global(const int32_t * p) {return (const gint *)p;}
 
 // Does any stamp footprint overlap the window [x_lo, x_hi] x [y_lo, y_hi] (grid cells)?  One bit per block of 2^bshift cells squared, rows padded
-// by a word; rows above and below the array hold nothing.  No early exit: the probes are independent loads.
+// by a word; rows above and below the array hold nothing.  The probes of up to nine block rows -- a 61-cell window on 8 x 8 blocks -- are
+// independent loads issued together: as a loop of load, wait, or (what the compiler makes of the plain form) the test of one window
+// was nine dependent trips to the L2, and K2' -- two windows per beam, five beams per thread -- 0.19 ms per 64 matches.
 __device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w, int bm_h, int x_lo, int y_lo, int x_hi, int y_hi, int bshift)
 {
   const int bx0 = x_lo >> bshift, bx1 = x_hi >> bshift;
@@ -72,12 +74,21 @@ __device__ __forceinline__ bool window_has_blocks(const uint32_t * bmp, int bm_w
   const int wi = bx0 >> 5, sh = bx0 & 31, nb = bx1 - bx0 + 1;
   if (nb > 32) {return true;}
   const unsigned long long span = (1ull << nb) - 1ull;
+  typedef __attribute__((address_space(1))) const uint32_t gword;
+  gword * const words = (gword *)bmp + wi;
+  constexpr int kRowsAtOnce = 9;
   unsigned long long any = 0;
-  for (int by = by0; by <= by1; ++by) {
-    const uint32_t * row = bmp + (size_t)by * bm_w + wi;
-    any |= (((unsigned long long)row[1] << 32) | row[0]) >> sh;
+  for (int by = by0; by <= by1; by += kRowsAtOnce) {
+    uint32_t lo[kRowsAtOnce], hi[kRowsAtOnce];
+#pragma unroll
+    for (int k = 0; k < kRowsAtOnce; ++k) {
+      gword * row = words + (size_t)min(by + k, by1) * bm_w;         // past the last row: the last row again
+      lo[k] = row[0]; hi[k] = row[1];
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsAtOnce; ++k) {any |= ((unsigned long long)hi[k] << 32) | lo[k];}
   }
-  return (any & span) != 0;
+  return ((any >> sh) & span) != 0;
 }
 
 // FindValidPoints, data parallel inside one scan (workgroup per scan).  The state machine hops from trigger to trigger -- a
@@ -259,17 +270,29 @@ __device__ __forceinline__ double cell_maxima(const CorrJob & job, const int fir
   double seen = 0.0;
   if (per <= kSlice) {
     const int a_lo = slice * per;
+    // the wave's angle penalties: ONE load (lane t = angle a_lo + t), handed out by readlane where they are used.  (Read where
+    // they are used -- job.ang_pen[a_lo + t] inside the two loops below -- every one of them was a flat load with its own wait:
+    // two dozen dependent memory round trips per workgroup, 0.14 ms per launch of 64 matches for a kernel that moves 77 MB.)
+    const double lane_pen = (penal && lane < per && a_lo + lane < na) ? job.ang_pen[a_lo + lane] : 1.0;
+    auto angle_penalty = [&](int t) -> double {
+      const long long bits = __double_as_longlong(lane_pen);
+      const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), t), hi = __builtin_amdgcn_readlane((int)(bits >> 32), t);
+      return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    const gint * const gsums = as_global(sums);
     for (int cell0 = first_group * 64; cell0 < (int)plane; cell0 += group_stride * 64) {
       const int cell = cell0 + lane;
       const bool valid = cell < (int)plane;
       int32_t v[kSlice];
 #pragma unroll
-      for (int t = 0; t < kSlice; ++t) {v[t] = (valid && t < per && a_lo + t < na) ? sums[(size_t)(a_lo + t) * plane + cell] : 0;}
+      for (int t = 0; t < kSlice; ++t) {v[t] = (valid && t < per && a_lo + t < na) ? gsums[(size_t)(a_lo + t) * plane + cell] : 0;}
+      // (the cell's distance penalty with the same batch of loads)
+      const double dpen = (valid && penal) ? job.dist_pen[cell] : 1.0;
       float kmax = 0.0f;
 #pragma unroll
       for (int t = 0; t < kSlice; ++t) {
         if (t < per && a_lo + t < na) {
-          const float key = fmaxf((float)v[t] * (penal ? (float)job.ang_pen[a_lo + t] : 1.0f), v[t] > 0 ? 1e-30f : 0.0f);
+          const float key = fmaxf((float)v[t] * (float)angle_penalty(t), v[t] > 0 ? 1e-30f : 0.0f);
           kmax = key > kmax ? key : kmax;
         }
       }
@@ -278,14 +301,20 @@ __device__ __forceinline__ double cell_maxima(const CorrJob & job, const int fir
       kmax = fmaxf(fmaxf(s_key[0][lane], s_key[1][lane]), fmaxf(s_key[2][lane], s_key[3][lane]));
       double m = 0.0;
       if (valid && kmax > 0.0f) {
-        const int yi = cell / nxp, xi = cell - yi * nxp;
         const float thresh = kmax * (1.0f - 1e-5f);
 #pragma unroll
         for (int t = 0; t < kSlice; ++t) {
           if (t < per && a_lo + t < na && v[t] > 0) {
-            const float key = fmaxf((float)v[t] * (penal ? (float)job.ang_pen[a_lo + t] : 1.0f), 1e-30f);
+            const double ap = angle_penalty(t);
+            const float key = fmaxf((float)v[t] * (float)ap, 1e-30f);
             if (key >= thresh || v[t] <= v_small) {
-              const double response = pose_response(job, v[t], a_lo + t, yi, xi);
+              // pose_response with the penalties at hand (same operations: Mapper.cpp:1204, 671-685)
+              double response = (double)v[t] / denom;
+              if (penal) {
+                const double delta = response - 0.0;
+                const bool is_zero = delta < 0.0 ? delta >= -1e-06 : delta <= 1e-06;
+                if (!is_zero) {response *= (dpen * ap);}
+              }
               m = response > m ? response : m;
             }
           }

@@ -1582,13 +1582,27 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
   constexpr int kMaxRounds = 8;                            // P <= 2048 on this path
   double plx[kMaxRounds], ply[kMaxRounds];
   bool pinv[kMaxRounds];
+  // (unconditional loads at a clamped index, global address space: as `in ? load : default` every one of them sat in a branch of its
+  // own with a wait behind it -- twenty-four dependent round trips in front of the first beam)
+  {
+    typedef __attribute__((address_space(1))) const uint8_t gflag;
+    typedef __attribute__((address_space(1))) const double gdouble;
+    gflag * const ginvalid = (gflag *)job.invalid;
+    gdouble * const glocal = (gdouble *)job.local;
+    uint8_t fl[kMaxRounds];
 #pragma unroll
-  for (int t = 0; t < kMaxRounds; ++t) {
-    const int i = threadIdx.x + 256 * t;
-    const bool in = t < rounds && i < P;
-    pinv[t] = in ? job.invalid[i] != 0 : true;
-    plx[t] = in ? job.local[2 * i] : 0.0;
-    ply[t] = in ? job.local[2 * i + 1] : 0.0;
+    for (int t = 0; t < kMaxRounds; ++t) {
+      const int ic = min((int)threadIdx.x + 256 * t, P - 1);
+      fl[t] = ginvalid[ic]; plx[t] = glocal[2 * ic]; ply[t] = glocal[2 * ic + 1];
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxRounds; ++t) {
+      const int i = threadIdx.x + 256 * t;
+      const bool in = t < rounds && i < P;
+      pinv[t] = in ? fl[t] != 0 : true;
+      plx[t] = in ? plx[t] : 0.0;
+      ply[t] = in ? ply[t] : 0.0;
+    }
   }
 #pragma unroll
   for (int t = 0; t < kMaxRounds; ++t) {
