@@ -246,7 +246,9 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobs, int bm_
   phase();
   const int tiles = job.tiles_w * job.tiles_h, bm_words = job.bm_w * job.bm_h;
   const int state_bytes = job.n_foot > 0 ? ((job.n_points + 15) & ~15) : 0;
-  volatile uint8_t * state = s_dyn;
+  // (an LDS pointer by type: through a generic one every volatile read of a state byte is a FLAT load with a full wait behind it)
+  typedef __attribute__((address_space(3))) volatile uint8_t lds_state;
+  lds_state * const state = (lds_state *)(__attribute__((address_space(3))) uint8_t *)s_dyn;
   int32_t * s_cnt = reinterpret_cast<int32_t *>(s_dyn + state_bytes);
   // the occupancy block map is built in LDS and written out once -- or, when it does not fit beside the rest (8 x 8-cell blocks
   // of a large grid: 134 KB for the config-2 geometry), marked in place
@@ -261,14 +263,25 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobs, int bm_
   // dependency chains of the rule run along walls in point order -- so a chain link is mostly decided by the thread that decided
   // the link before it, in the same trip of its loop, instead of waiting for another wave's next trip
   const int per = min(kBinRegs, (n_cand + 1023) / 1024);
+  {
+    // (all of a thread's records requested together -- unconditional loads at a clamped index: as `if (mine) {load}` every record sat
+    // in a branch of its own with a wait behind it, seven dependent round trips in front of the first verdict)
+    typedef int rec4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const rec4 grec;
+    grec * const grecs = (grec *)rec;
+    rec4 ra[kBinRegs], rb[kBinRegs];
+    const int last = max(n_cand - 1, 0);
 #pragma unroll
-  for (int k = 0; k < kBinRegs; ++k) {
-    const int i = tid * per + k;
-    pr[k] = -1; cxy[k] = 0; nbr[k] = make_int4(-1, -1, -1, -1);
-    if (k < per && i < n_cand) {
-      const int4 a = rec[2 * (size_t)i];
-      pr[k] = a.x; cxy[k] = a.y | (a.z << 16);
-      if (job.n_foot > 0) {nbr[k] = rec[2 * (size_t)i + 1];}
+    for (int k = 0; k < kBinRegs; ++k) {
+      const int ic = min(tid * per + k, last);
+      ra[k] = grecs[2 * (size_t)ic]; rb[k] = grecs[2 * (size_t)ic + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < kBinRegs; ++k) {
+      const int i = tid * per + k;
+      const bool have = k < per && i < n_cand;
+      pr[k] = have ? ra[k].x : -1; cxy[k] = have ? (ra[k].y | (ra[k].z << 16)) : 0;
+      nbr[k] = (have && job.n_foot > 0) ? make_int4(rb[k].x, rb[k].y, rb[k].z, rb[k].w) : make_int4(-1, -1, -1, -1);
     }
   }
   if (job.n_foot > 0) {
