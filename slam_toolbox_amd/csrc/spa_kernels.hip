@@ -796,18 +796,20 @@ __global__ __launch_bounds__(1024) void k_extend_add(SpaDev d, const int32_t * _
       const int a_begin = part == 2 && pivot_col ? max(b, a_piv) : b;
       const int a_end = part == 1 ? (pivot_col ? a_piv : 0) : nuc;
       for (int a0 = a_begin; a0 < a_end; a0 += 256) {
-        // four rows per lane in flight
+        // four rows per lane in flight: unconditional loads at a clamped row (as `a < a_end ? load : 0` every load sat in a branch
+        // of its own with a wait behind it: twelve dependent round trips per 256 rows where two do)
         double u[4], f[4];
         int pa[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int a = a0 + lane + 64 * q;
-          pa[q] = a < a_end ? pos(a) : -1;
-          u[q] = a < a_end ? src[a] : 0.0;
-          f[q] = a < a_end ? dst[pa[q]] : 0.0;
+          const int ac = min(a0 + lane + 64 * q, a_end - 1);
+          pa[q] = pos(ac);
+          u[q] = src[ac];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {if (pa[q] >= 0) {dst[pa[q]] = f[q] + u[q];}}
+        for (int q = 0; q < 4; ++q) {f[q] = dst[pa[q]];}
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {if (a0 + lane + 64 * q < a_end) {dst[pa[q]] = f[q] + u[q];}}
       }
     }
     __syncthreads();       // the next child may add into the same entries (and restages s_rp)
