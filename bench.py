@@ -42,7 +42,7 @@ L1_HIT_CLOCKS_PER_LOAD, L1_MISS_CLOCKS_PER_LINE = 4.2, 0.95
 FP64_PEAK_TFLOPS = 78.6            # MI355X FP64 vector = matrix peak (spec); v_mfma_f64_16x16x4_f64
 # LDS read port for ds_read_b32: 128 B per clock per CU (MI355X_MICROARCH.md, LDS table) x 256 CUs x 2.4 GHz
 LDS_B32_PEAK_GBS = 128.0 * 256 * 2.4
-SCORE_KERNEL = "k_score_lds<1,4>"
+SCORE_KERNEL = "k_score_lds<1,4,true>"
 
 
 def _newest_pmc():

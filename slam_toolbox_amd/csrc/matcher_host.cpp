@@ -905,17 +905,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     KH_HIP(hipEventRecord(B.kdone, ks));
     KH_HIP(hipStreamWaitEvent(cs, B.kdone, 0));
   }
-  // What follows the scoring kernel of a chunk -- the tie kernel, the downloads -- is short, and the host waits for it before it can
-  // finalise the chunk and prepare the next but one; queued behind it on the same stream it competes for workgroup slots with the
-  // OTHER staging set's scoring kernel, which fills the chip: the tie kernel of 64 matches (0.14 ms alone) finished 0.2 - 0.35 ms
-  // after it started.  On a stream of the highest priority its workgroups go first whenever a slot frees up.
-  static const bool tail_priority = std::getenv("KH_TAIL_PRIORITY") && std::atoi(std::getenv("KH_TAIL_PRIORITY")) != 0;
   hipStream_t ts = cs;
-  if (overlap && tail_priority) {
-    ts = B.tail;
-    KH_HIP(hipEventRecord(B.scored, cs));
-    KH_HIP(hipStreamWaitEvent(ts, B.scored, 0));
-  }
   if (m->profiling) {KH_HIP(hipEventRecord(B.evs[2], ts));}
   launch_ties(B.d_stage, stride, static_cast<int32_t>(n), max_poses, B.tile_pairs, ts);
   if (m->profiling) {KH_HIP(hipEventRecord(B.evs[3], ts));}
@@ -1075,7 +1065,7 @@ int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
   if (rc) {return rc;}
   for (size_t c = 1; c < chunks; ++c) {
     rc = correlate_stage(m, reqs.data() + begin_of(c), size_of(c), m->batch[c & 1], 0, true);
-    if (rc) {(void)hipStreamSynchronize(m->stream); for (auto & b : m->batch) {(void)hipStreamSynchronize(b.side); (void)hipStreamSynchronize(b.tail);} return rc;}
+    if (rc) {(void)hipStreamSynchronize(m->stream); for (auto & b : m->batch) {(void)hipStreamSynchronize(b.side);} return rc;}
     rc = correlate_stage(m, reqs.data() + begin_of(c - 1), size_of(c - 1), m->batch[(c - 1) & 1], 1, true);
     if (rc && !first_rc) {first_rc = rc;}
   }
@@ -1216,12 +1206,6 @@ int kh_matcher_create(double search_size, double resolution, double smear, doubl
     if ((e = hipEventCreateWithFlags(&b.up, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
     if ((e = hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
     if ((e = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking)) != hipSuccess) {return fail(e, "hipStreamCreate");}
-    {
-      int least = 0, greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      if ((e = hipStreamCreateWithPriority(&b.tail, hipStreamNonBlocking, greatest)) != hipSuccess) {return fail(e, "hipStreamCreateWithPriority");}
-      if ((e = hipEventCreateWithFlags(&b.scored, hipEventDisableTiming)) != hipSuccess) {return fail(e, "hipEventCreate");}
-    }
   }
   if ((e = hipMalloc(reinterpret_cast<void **>(&m->d_kernel), m->kernel.size())) != hipSuccess) {return fail(e, "hipMalloc kernel");}
   // (word 0 = the tally; the words behind it are used by measurement builds of the kernels only)
@@ -1304,8 +1288,6 @@ void kh_matcher_destroy(kh_matcher * m)
     if (b.up) {hipEventDestroy(b.up);}
     if (b.kdone) {hipEventDestroy(b.kdone);}
     if (b.side) {hipStreamSynchronize(b.side); hipStreamDestroy(b.side);}
-    if (b.tail) {hipStreamSynchronize(b.tail); hipStreamDestroy(b.tail);}
-    if (b.scored) {hipEventDestroy(b.scored);}
   }
   hipFree(m->d_arena); hipFree(m->d_meta);
   if (m->h_arena) {hipHostFree(m->h_arena);}
@@ -1712,7 +1694,7 @@ int kh_matcher_score_loads(kh_matcher * m, int64_t * wave_loads, int32_t reset)
   if (!m || !wave_loads) {return KH_ERR_INVALID_ARG;}
   KH_HIP(hipSetDevice(m->device));
   KH_HIP(hipStreamSynchronize(m->stream));
-  for (auto & b : m->batch) {KH_HIP(hipStreamSynchronize(b.side)); KH_HIP(hipStreamSynchronize(b.tail));}
+  for (auto & b : m->batch) {KH_HIP(hipStreamSynchronize(b.side));}
   unsigned long long v = 0;
   KH_HIP(hipMemcpy(&v, m->d_load_counter, 8, hipMemcpyDeviceToHost));
   *wave_loads = static_cast<int64_t>(v);

@@ -125,8 +125,6 @@ struct CorrBatch
   hipEvent_t done = nullptr;                  // everything of the sub-batch, downloads included
   hipEvent_t up = nullptr, kdone = nullptr;   // chunked batches: tables + lists ready (side stream) / scoring finished (main stream)
   hipStream_t side = nullptr;                 // side stream of this staging set (uploads, K2, K4, downloads of its chunks)
-  hipStream_t tail = nullptr;                 // highest-priority stream for what follows a chunk's scoring kernel (K4, downloads): see correlate_stage
-  hipEvent_t scored = nullptr;                // the chunk's scoring kernel has finished
 };
 
 struct Slot

@@ -16,7 +16,7 @@ def _round_number(tag):
 
 ROUND = sorted((os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(PROF, "r*_bench_line.json"))), key=_round_number)[-1]
 # the dominant kernel: the windowed scoring kernel through round 3, the LDS-staged one from round 4 on
-SCORE_KERNEL = "k_score<1, 8, 1" if ROUND in ("r1", "r2", "r3") else "k_score_lds<1, 4>"
+SCORE_KERNEL = "k_score<1, 8, 1" if ROUND in ("r1", "r2", "r3") else "k_score_lds<1, 4"     # (r5: k_score_lds<1, 4, true>)
 
 
 def per_step_matches(d):
