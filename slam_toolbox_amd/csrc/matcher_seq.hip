@@ -130,7 +130,9 @@ void launch_seq_prep_batch(const RasterJob * d_jobs, int32_t n_jobs, const Valid
 // (a later one can never block it) -- four independent loads where the batch path probes a hash table.
 __global__ __launch_bounds__(256) void kseq_links(const RasterJob * jobs)
 {
-  const RasterJob & job = jobs[blockIdx.y];
+  // (a COPY: its fields are fetched in one batch of scalar loads here; through a reference every field was fetched at its first use,
+  // each behind a wait of its own -- a dozen dependent round trips in kernels that live for five to twenty microseconds)
+  const RasterJob job = jobs[blockIdx.y];
   const int32_t * __restrict__ first = job.first;
   int32_t * cand = job.cand;
   int32_t * ctl = job.seq_ctl;
@@ -477,7 +479,8 @@ __device__ __forceinline__ void stage_copy(const SeqStage & g, const RasterJob &
 }
 __global__ __launch_bounds__(256) void kseq_stage(const RasterJob * jobs, const SeqStage g)
 {
-  stage_copy(g, jobs[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  const RasterJob job = jobs[blockIdx.y];          // (a copy: kseq_links)
+  stage_copy(g, job, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // kseq_tile: SmearPoint (Mapper.h:1152-1183) of one job's stamped points, tile by tile, for smear kernels of 8 x 8 .. 41 x 41
@@ -492,7 +495,7 @@ constexpr int kTabRows = 41 + 2 * kTabGuard;
 constexpr int kTileStageBlocks = 16;
 __global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobs, const uint4 * __restrict__ tab, int tile_blocks, const SeqStage stage)
 {
-  const RasterJob & job = jobs[blockIdx.y];
+  const RasterJob job = jobs[blockIdx.y];          // (a copy: kseq_links)
   if ((int)blockIdx.x >= tile_blocks) {
     stage_copy(stage, job, ((int)blockIdx.x - tile_blocks) * 512 + (int)threadIdx.x, ((int)gridDim.x - tile_blocks) * 512);
     return;
@@ -604,7 +607,7 @@ void launch_seq_tile(const RasterJob * d_jobs, int32_t n_jobs, const uint8_t * d
 template <int SX, int RY>
 __global__ __launch_bounds__(256) void kseq_score(const uint8_t * jobp, int slices, int tiles_x, int tiles_y)
 {
-  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobp);
+  const CorrJob job = *reinterpret_cast<const CorrJob *>(jobp);          // (a copy: kseq_links)
   constexpr int PX = (SX == 1) ? kTileSpan : (kTileSpan + 1) / 2;
   constexpr int TY = 4 * RY;
   const int tiles = tiles_x * tiles_y;
@@ -795,7 +798,7 @@ void launch_seq_score(const uint8_t * d_job, int32_t na, int32_t n_points, int32
 // the best response of the search (Mapper.cpp:775-800): the largest cell maximum.
 __global__ __launch_bounds__(256) void kseq_cells(const uint8_t * jobp, unsigned long long * h_lattice)
 {
-  const CorrJob & job = *reinterpret_cast<const CorrJob *>(jobp);
+  const CorrJob job = *reinterpret_cast<const CorrJob *>(jobp);          // (a copy: kseq_links)
   double best = cell_maxima(job, (int)blockIdx.x, (int)gridDim.x, h_lattice);
   if (threadIdx.x < 64) {
 #pragma unroll
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(1024) void kseq_ties(const SeqFinalArgs A)
   __shared__ int32_t s_cells[1024];
   const int tid = threadIdx.x;
   // everything read from the job, once (behind a store the compiler must assume the job block itself changed)
-  const CorrJob & jr = *reinterpret_cast<const CorrJob *>(A.job);
+  const CorrJob jr = *reinterpret_cast<const CorrJob *>(A.job);          // (a copy: kseq_links)
   const int nx = jr.nx, na = jr.na, plane = jr.nx * jr.ny, ws = jr.ws;
   const bool penal = jr.do_penalize != 0;
   const double denom = jr.denom, goff_x = jr.grid_off_x, goff_y = jr.grid_off_y, scale = jr.scale;
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(64) void kseq_fine(const SeqFinalArgs A, int slices
 {
   const SeqMid & mid = *A.mid;
   if (mid.fine == 0) {return;}
-  const CorrJob & job = *reinterpret_cast<const CorrJob *>(A.job);
+  const CorrJob job = *reinterpret_cast<const CorrJob *>(A.job);          // (a copy: kseq_links)
   const int lane = threadIdx.x;
   const int k = blockIdx.x / slices, i = (blockIdx.x - k * slices) * 64 + lane;
   const int P = job.n_points, naf = A.naf;
