@@ -34,8 +34,11 @@ public:
   // points) and is bound by the host's memory bandwidth well before the box runs out of cores -- 192 threads took 7.9 s of
   // the 50 000-scan replay where 64 take 4
   static HostPool & wide() {static HostPool p(1); return p;}
-  // runs fn(i) for i in [0, n); returns when all are done
-  void run(size_t n, const std::function<void(size_t)> & fn)
+  // runs fn(i) for i in [0, n); returns when all are done.  linger_ticks: how long the workers stay awake (spinning) BEHIND this
+  // region before they sleep, where the caller knows that another region follows within that time and that its wake-up (~50 us: a
+  // futex wake and the scheduler) would be exposed -- the two ends of a chunked batch call, csrc/matcher_host.cpp.  Never for
+  // regions that follow one another all through a call: the boxes run under a CPU quota (see kSpinTicks).
+  void run(size_t n, const std::function<void(size_t)> & fn, uint64_t linger_ticks = 0)
   {
     if (n == 0) {return;}
     // a region entered from inside a region (fn calling run() again, on the caller thread or on a worker) runs in line: the
@@ -46,6 +49,7 @@ public:
     std::unique_lock<std::mutex> serial(run_mu_, std::try_to_lock);
     if (!serial.owns_lock()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
     fn_ = &fn; n_ = n; next_.store(0, std::memory_order_relaxed);
+    linger_.store(linger_ticks, std::memory_order_relaxed);
     failed_.store(false, std::memory_order_relaxed);
     pending_.store(static_cast<uint32_t>(workers_.size()), std::memory_order_relaxed);
     generation_.fetch_add(1, std::memory_order_release);
@@ -81,6 +85,9 @@ private:
   // next chunk's preparation) find the workers awake.  Never longer: a container with a CPU quota throttles a process whose
   // idle threads spin (measured: workers spinning for the length of a batch call halved the throughput of the bench).
   static constexpr uint64_t kSpinTicks = 60000;
+public:
+  static constexpr uint64_t kTicksPerMicrosecond = 2400;      // (nominal: the spin windows are not measurements)
+private:
   static uint64_t ticks() {return __builtin_ia32_rdtsc();}
   static void futex_wait(std::atomic<uint32_t> * a, uint32_t expected)
   {
@@ -117,16 +124,17 @@ private:
   void loop()
   {
     uint32_t seen = 0;
-    uint64_t idle_since = ticks();
+    uint64_t idle_since = ticks(), spin_for = kSpinTicks;
     for (;;) {
       if (generation_.load(std::memory_order_acquire) == seen) {
-        if (ticks() - idle_since < kSpinTicks) {__builtin_ia32_pause();} else {futex_wait(&generation_, seen);}
+        if (ticks() - idle_since < spin_for) {__builtin_ia32_pause();} else {futex_wait(&generation_, seen);}
         continue;
       }
       if (stop_.load(std::memory_order_acquire)) {return;}
       // every worker checks in for every generation: run() does not return (and no new generation starts) before all have
       ++seen;
       work();
+      spin_for = std::max<uint64_t>(kSpinTicks, linger_.load(std::memory_order_relaxed));       // (read before the check-in: run() may not have returned yet)
       if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {futex_wake_all(&pending_);}
       idle_since = ticks();
     }
@@ -138,6 +146,7 @@ private:
   std::atomic<size_t> next_{0};
   std::atomic<uint32_t> pending_{0}, generation_{0};
   std::atomic<bool> stop_{false}, failed_{false};
+  std::atomic<uint64_t> linger_{0};
   std::exception_ptr error_;
 };
 

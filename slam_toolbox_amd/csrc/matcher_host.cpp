@@ -770,7 +770,9 @@ int finalize_job(kh_matcher * m, CorrReq & q, CorrHost & c, const ResultView & v
 // One sub-batch of CorrelateScan jobs in two phases so that two sub-batches can be pipelined on the handle's
 // stream: phase 0 = host preparation + upload + kernels + download, all enqueued, ending with an event;
 // phase 1 = wait for that event + finalisation.  Everything phase 1 needs lives in the CorrBatch.
-static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch & B, int phase, bool overlap = false)
+// last_of_call (phase 1 of the last chunk of a chunked call): nothing hides the host's work any more -- the worker pool is woken while
+// this thread still waits for the chunk's results, and stays awake behind the finalisation for the first chunk of the caller's next call.
+static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch & B, int phase, bool overlap = false, bool last_of_call = false)
 {
   if (n == 0) {return KH_OK;}
   const kh_match_params & mp = m->params;
@@ -932,6 +934,10 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
   lap(1, t_enqueue);
   return KH_OK;
   }   // phase 0
+  // (what a wake-up costs -- a futex wake and the scheduler, ~50 us -- is hidden under the scoring kernels for every chunk but the
+  // last, and for every preparation but the first of the next call)
+  constexpr uint64_t kAwaitResults = 200 * HostPool::kTicksPerMicrosecond, kAwaitNextCall = 120 * HostPool::kTicksPerMicrosecond;
+  if (last_of_call) {HostPool::instance().run(2, [](size_t) {}, kAwaitResults);}
   KH_HIP(hipEventSynchronize(B.done));
   lap(2, t_enter);
   const auto t_final = std::chrono::steady_clock::now();
@@ -987,7 +993,7 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     HostPool::instance().run(n, [&](size_t i) {
       (void)hipSetDevice(m->device);
       final_rc[i] = finalize(i);
-    });
+    }, last_of_call ? kAwaitNextCall : 0);
   }
   lap(3, t_final);
   static const long period = (std::getenv("KH_MATCH_TIMING") && std::atoi(std::getenv("KH_MATCH_TIMING")) > 1) ? 1 : 64;
@@ -1069,7 +1075,7 @@ int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs)
     rc = correlate_stage(m, reqs.data() + begin_of(c - 1), size_of(c - 1), m->batch[(c - 1) & 1], 1, true);
     if (rc && !first_rc) {first_rc = rc;}
   }
-  rc = correlate_stage(m, reqs.data() + begin_of(chunks - 1), size_of(chunks - 1), m->batch[(chunks - 1) & 1], 1, true);
+  rc = correlate_stage(m, reqs.data() + begin_of(chunks - 1), size_of(chunks - 1), m->batch[(chunks - 1) & 1], 1, true, true);
   return first_rc ? first_rc : rc;
 }
 

@@ -17,7 +17,8 @@ static int run_regions(unsigned seed, int regions, bool back_to_back, std::atomi
     const size_t n = rng() % 97;
     std::vector<std::atomic<int>> hits(n);
     for (auto & h : hits) {h.store(0);}
-    pool.run(n, [&](size_t i) {hits[i].fetch_add(1); total.fetch_add(static_cast<long long>(i) + 1);});
+    // (every seventh region asks the workers to stay awake behind it: the hint must change nothing but their sleep)
+    pool.run(n, [&](size_t i) {hits[i].fetch_add(1); total.fetch_add(static_cast<long long>(i) + 1);}, (r % 7) == 0 ? 100000 : 0);
     for (size_t i = 0; i < n; ++i) {if (hits[i].load() != 1) {++bad;}}
     if (!back_to_back && (r % 16) == 0) {std::this_thread::sleep_for(std::chrono::microseconds(200));}      // let the workers fall asleep
   }
