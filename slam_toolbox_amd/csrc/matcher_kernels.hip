@@ -1495,7 +1495,10 @@ void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t 
 //                      wave's four accumulator sets a beam adds to; the sets are merged with their shifts in the epilogue.
 //
 // LDS staging alone (round 1: ds_read_b32 + 4 VALU per dword) lost to the vector ALU, the matrix-core sums alone (round 3)
-// to the L1; together neither is on the critical path: what remains is the LDS read itself, 128 B / clk / CU for b32.
+// to the L1; together neither is on the critical path.  What is: the waves' own instruction streams (a wave issues one instruction
+// per turn of its SIMD, four waves per SIMD: round 5 took the step from 49 instructions to 35 and the kernel from 0.54 to 0.44 ms
+// per 51 config-2 matches; reading 39 % fewer bytes -- the quad-skipping experiment, tools/patches/ -- made it SLOWER), and, for
+// K2' and the tie kernel beside it, dependent memory round trips the compiler makes of conditional loads.
 // =============================================================================================
 namespace kh
 {
