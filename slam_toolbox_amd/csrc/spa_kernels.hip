@@ -1261,6 +1261,119 @@ __device__ __forceinline__ bool potrf_diag(double * blk, int LD, int lane, doubl
   return bad && lane < NB;
 }
 
+// ---- the same diagonal block on the matrix cores, four pivots at a time (round 6) ----
+// The chain above issues ~670 double-precision instructions for 16 pivots on a wave of which a quarter of the lanes work
+// (3.2 us, measured: the floor under every level of the factorisation).  Here the 16 x 16 tile never leaves the accumulator
+// layout of v_mfma_f64_16x16x4 -- lane (lr, lk) holds M[lr][lk + 4 r] in register r, i.e. register p IS column block p and
+// its entry is exactly what the lane has to supply, as the A and as the B operand, for the rank-4 update of the columns
+// behind block p:
+//   gather   the 4 x 4 diagonal block of column block p: one ds_write of register p (64 doubles of scratch), ten uniform reads
+//   chol4    its Cholesky factor and T = L_pp^-T in uniform registers (every lane the same ~60 operations)
+//   panel    M[:, 4p .. 4p+3] <- M[:, 4p .. 4p+3] T   ONE MFMA: b = register p, a = T[lk][lr - 4p] on the lanes lr of block p
+//   update   M[:, behind] -= panel panel^T             ONE MFMA: a = b = the new register p
+// and the identity that rides along (E -> L^-T) takes the same two MFMAs with its own register p as b.  Entries above the
+// diagonal hold garbage that stays in registers nobody reads (rows above block p only feed rows above block p); the rows
+// of the diagonal block itself come out of `chol4`, not of the panel product.  ~700 clocks per four pivots.
+// One over the square root to full double precision: v_rsq_f64 is good to ~2^-26 or better (tools/diag_probe.hip prints its
+// worst error), so one THIRD-order step r (1 + e/2 + 3 e^2/8), e = 1 - d r^2, lands below 2^-70: five dependent operations
+// where two Newton steps take seven.
+__device__ __forceinline__ double rsqrt_full(double d)
+{
+  const double r = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-d * r, r, 1.0);
+  const double c = __builtin_fma(e, 0.375, 0.5) * e;
+  return __builtin_fma(r, c, r);
+}
+
+// T = L^-T of the 4 x 4 block a (a[i][j], j <= i), as v = L^-1 (lower): the factor itself is not formed -- nobody reads the
+// diagonal tile's L (the panel product leaves the rows below it, and every consumer of the pivot block works with L^-T).
+// A pivot that is not positive is reported and replaced by a tiny positive number (the factorisation has failed; the numbers
+// only have to stay harmless).
+__device__ __forceinline__ bool chol4_inverse(double (&m)[4][4], double (&v)[4][4])
+{
+  double r[4], l[4][4];
+  double dmin = m[0][0];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dmin = fmin(dmin, m[j][j]);
+    r[j] = rsqrt_full(fmax(m[j][j], 1e-300));
+#pragma unroll
+    for (int i = j + 1; i < 4; ++i) {l[i][j] = m[i][j] * r[j];}
+#pragma unroll
+    for (int i = j + 1; i < 4; ++i) {
+#pragma unroll
+      for (int c = j + 1; c <= i; ++c) {m[i][c] -= l[i][j] * l[c][j];}
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i][i] = r[i];
+#pragma unroll
+    for (int j = i - 1; j >= 0; --j) {
+      double acc = l[i][j] * v[j][j];
+#pragma unroll
+      for (int k = j + 1; k < i; ++k) {acc += l[i][k] * v[k][j];}
+      v[i][j] = -acc * r[i];
+    }
+  }
+  return dmin > 0.0;
+}
+
+// tile: the diagonal tile in accumulator layout (lower part meaningful, identity on the padding).  Outputs as potrf_diag,
+// except that the lower triangle of blk (L itself) is left alone.  sc: 64 doubles of LDS scratch owned by this wave.
+__device__ __forceinline__ bool potrf_diag_mfma(v4d tile, double * blk, int LD, int lane, double * xd, double * rdv, double * sc)
+{
+  const int lr = lane & 15, lk = lane >> 4;
+  const int c4 = lr & 3, b4 = lr >> 2;
+  v4d E;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {E[r] = (lk + 4 * r == lr) ? 1.0 : 0.0;}
+  bool bad = false;
+  const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    // gather the diagonal 4 x 4 block: sc[lr + 16 lk] = M[lr][4 p + lk]
+    sc[lane] = tile[p];
+    double a[4][4], v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {a[i][j] = sc[(4 * p + i) + 16 * j];}
+    }
+    if (!chol4_inverse(a, v)) {bad = true;}
+    // T[k][c] = v[c][k] on lane (lr = 4 p + c, lk = k), zero elsewhere
+    double tsel = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int k = 0; k <= c; ++k) {tsel = (c4 == c && lk == k) ? v[c][k] : tsel;}
+    }
+    const double ta = (b4 == p) ? tsel : 0.0;
+    const v4d pn = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, tile[p], zero, 0, 0, 0);
+    tile[p] = pn[p];
+    if (p < 3) {
+      const v4d tu = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile[p], tile[p], tile, 0, 0, 0);
+#pragma unroll
+      for (int r = p + 1; r < 4; ++r) {tile[r] = tu[r];}
+    }
+    const v4d en = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, E[p], zero, 0, 0, 0);
+    E[p] = en[p];
+    if (p < 3) {
+      const v4d eu = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile[p], E[p], E, 0, 0, 0);
+#pragma unroll
+      for (int r = p + 1; r < 4; ++r) {E[r] = eu[r];}
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = lk + 4 * r;
+    if (c > lr) {blk[lr * LD + c] = E[r];}
+    xd[lr * XDS + c] = E[r];
+    if (c == lr) {rdv[lr] = E[r];}
+  }
+  return bad;
+}
+
 // row "solve" of one 16-row tile: T <- T Dinv^T  (Dinv^T = L_jj^-T in xd), in place, one wave
 __device__ __forceinline__ void potrf_rowsolve_tile(double * tile, int LD, const double * xd, int lane)
 {
@@ -1307,18 +1420,33 @@ __device__ __forceinline__ double gather_entry(const double * __restrict__ front
 
 // Initial value of the 16 x 16 tile (rows row0.., columns col0..) of the pivot block in MFMA accumulator layout: the
 // front's own (assembled) entries plus the children's update matrices; identity on the padding; entries above the
-// diagonal are not meaningful
-__device__ __forceinline__ v4d pivot_tile_init(const SpaDev & d, const FrontDesc & fd, const double * __restrict__ F, int nchild, int row0, int col0, int lane)
+// diagonal are not meaningful.  In two halves: pivot_tile_load only REQUESTS the front's entries (nothing in it touches a
+// loaded value, so the wave goes on to its pivot chain while they travel -- with the padding select next to the loads, as in
+// round 3, the wave sat out a full memory latency, about a microsecond, in front of every diagonal block);
+// pivot_tile_finish, one step later, adds the children's entries (gather mode only) and puts the identity on the padding.
+__device__ __forceinline__ v4d pivot_tile_load(const FrontDesc & fd, const double * __restrict__ F, int row0, int col0, int lane)
+{
+  const int lr = lane & 15, lk = lane >> 4;
+  const int row = row0 + lr, m = fd.m, ns = fd.ns;
+  v4d v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int col = col0 + lk + 4 * r;
+    const bool want = row < ns && col <= row;
+    v[r] = *(want ? F + row + (int64_t)col * m : F);
+  }
+  return v;
+}
+
+__device__ __forceinline__ v4d pivot_tile_finish(v4d v, const SpaDev & d, const FrontDesc & fd, int nchild, int row0, int col0, int lane)
 {
   const int lr = lane & 15, lk = lane >> 4;
   const int row = row0 + lr, m = fd.m, ns = fd.ns, mp = m / 3;
-  v4d v;
   bool want[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int col = col0 + lk + 4 * r;
     want[r] = row < ns && col <= row;
-    v[r] = *(want[r] ? F + row + (int64_t)col * m : F);
   }
   for (int s = 0; s < nchild; ++s) {
     const ChildInfo c = child_info(d, fd, s);
@@ -1359,6 +1487,7 @@ __device__ __forceinline__ void ll_accumulate(v4d & acc, const double * X, int L
 //   R  row solves: every tile of the column times L_jj^-T (MFMA).
 // LDS holds only SOLVED tiles: L11 in the lower triangle, L11^-T strictly above it.  Nothing is staged in a prologue and
 // nothing but the last block of W is left for the epilogue.
+template <bool kMfmaDiag>
 __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
                                                long long * tbuf)
 {
@@ -1377,7 +1506,8 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
   double * rd = smem + (size_t)lds_nsp * (lds_nsp + 2);            // [lds_nsp] reciprocal diagonal of L11 = diagonal of L11^-T
   double * yv = rd + lds_nsp;                                      // [lds_nsp] y1
   double * Xd = yv + lds_nsp;                                      // [2][16][XDS] L_jj^-T of the current / previous panel
-  double * sb = Xd + 2 * NB * XDS;                                 // [m] the front's slice of the right-hand side
+  double * sc = Xd + 2 * NB * XDS;                                 // [64] scratch of the diagonal block's wave
+  double * sb = sc + 64;                                           // [m] the front's slice of the right-hand side
   __shared__ int s_fail;
   if (tid == 0) {s_fail = 0;}
   const int nchild = fd.child_end - fd.child_ptr;
@@ -1389,12 +1519,12 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
   auto prefetch = [&](int jb) {
     if (jb >= nt) {return;}
     if (wave == 0) {
-      cur[0] = pivot_tile_init(d, fd, F, nkids, NB * jb, NB * jb, lane);
+      cur[0] = pivot_tile_load(fd, F, NB * jb, NB * jb, lane);
     } else {
 #pragma unroll
       for (int q = 0; q < SL; ++q) {
         const int I = jb + 1 + (wave - 1) + 3 * q;
-        if (I < nt) {cur[q] = pivot_tile_init(d, fd, F, nkids, NB * I, NB * jb, lane);}
+        if (I < nt) {cur[q] = pivot_tile_load(fd, F, NB * I, NB * jb, lane);}
       }
     }
   };
@@ -1418,17 +1548,24 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
     double * xd = Xd + (jb & 1) * NB * XDS;
     const double * xp = Xd + ((jb + 1) & 1) * NB * XDS;            // L^-T of the previous diagonal block
     if (wave == 0) {
-      v4d acc = cur[0];
+      v4d acc = pivot_tile_finish(cur[0], d, fd, nkids, c0, c0, lane);
       prefetch(jb + 1);
       ll_accumulate(acc, X, LD, c0, c0, 0, jb, lane);
-      double * cp = X + (c0 + lr) * LD + c0 + lk;
+      if (kMfmaDiag) {
+        if (potrf_diag_mfma(acc, X + c0 * LD + c0, LD, lane, xd, rd + c0, sc)) {s_fail = 1;}
+      } else {
+        double * cp = X + (c0 + lr) * LD + c0 + lk;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {if (lk + 4 * r <= lr) {cp[4 * r] = acc[r];}}
-      if (potrf_diag(X + c0 * LD + c0, LD, lane, xd, rd + c0)) {s_fail = 1;}
+        for (int r = 0; r < 4; ++r) {if (lk + 4 * r <= lr) {cp[4 * r] = acc[r];}}
+        if (potrf_diag(X + c0 * LD + c0, LD, lane, xd, rd + c0)) {s_fail = 1;}
+      }
     } else {
       v4d mine[SL];
 #pragma unroll
-      for (int q = 0; q < SL; ++q) {mine[q] = cur[q];}
+      for (int q = 0; q < SL; ++q) {
+        const int I = jb + 1 + (wave - 1) + 3 * q;
+        mine[q] = I < nt ? pivot_tile_finish(cur[q], d, fd, nkids, NB * I, c0, lane) : cur[q];
+      }
       prefetch(jb + 1);
       // regular tiles (I, jb), I > jb
 #pragma unroll
@@ -1802,7 +1939,7 @@ __global__ __launch_bounds__(1024) void k_backward3(SpaDev d, int first_front, d
 
 static size_t potrf_lds_bytes(int nsp, int max_m)
 {
-  return sizeof(double) * ((size_t)nsp * (nsp + 2) + 2 * (size_t)nsp + 2 * NB * XDS + (size_t)max_m + 8);
+  return sizeof(double) * ((size_t)nsp * (nsp + 2) + 2 * (size_t)nsp + 2 * NB * XDS + 64 + (size_t)max_m + 8);
 }
 
 bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns)
@@ -1815,8 +1952,9 @@ static void pipeline_attributes()
 {
   // (per device: the attribute is kept per device, and solvers of several devices may live in one process)
   const int big = 160 * 1024 - 256;       // static LDS (a flag word) counts against the same 160 KB
-  static std::atomic<unsigned long long> done[5] = {{0}, {0}, {0}, {0}, {0}};
-  allow_dynamic_lds(reinterpret_cast<const void *>(k_potrf), big, done[0]);
+  static std::atomic<unsigned long long> done[6] = {{0}, {0}, {0}, {0}, {0}, {0}};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_potrf<true>), big, done[0]);
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_potrf<false>), big, done[5]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_trsm<32>), big, done[1]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_trsm<64>), big, done[2]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_syrk<32>), big, done[3]);
@@ -1833,8 +1971,14 @@ void spa_launch_potrf_level(const SpaDev & d, int32_t first_front, int32_t n, in
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
   if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 128 * sizeof(long long), hipHostMallocDefault);}
-  hipLaunchKernelGGL(k_potrf, dim3(n), dim3(256), potrf_lds_bytes(nsp, max_m), s, d, first_front, fail_flag, rhs, upd, nsp,
-                     timing ? tbuf : (long long *)nullptr);
+  static const bool chain_diag = std::getenv("KH_SPA_DIAG_CHAIN") != nullptr;      // the round-3 pivot chain (A/B measurements)
+  if (chain_diag) {
+    hipLaunchKernelGGL(k_potrf<false>, dim3(n), dim3(256), potrf_lds_bytes(nsp, max_m), s, d, first_front, fail_flag, rhs, upd, nsp,
+                       timing ? tbuf : (long long *)nullptr);
+  } else {
+    hipLaunchKernelGGL(k_potrf<true>, dim3(n), dim3(256), potrf_lds_bytes(nsp, max_m), s, d, first_front, fail_flag, rhs, upd, nsp,
+                       timing ? tbuf : (long long *)nullptr);
+  }
   if (timing) {
     (void)hipStreamSynchronize(s);
     std::fprintf(stderr, "[k_potrf] n=%d front0 m=%lld ns=%lld stamps(x10ns):", n, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
