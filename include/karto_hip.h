@@ -298,8 +298,10 @@ typedef struct kh_spa_summary {
 KH_API int kh_spa_create(int32_t device, kh_spa ** out);
 /* Test / measurement switches, 0 = none.  Bit 0: every LM iteration also evaluates the residual of its linear solve from
  * the block-sparse matrix (kh_spa_summary.worst_linear_residual).  Bits 4-7: numeric factorisation kernels -- 0 default
- * (3), 3 level pipeline potrf/trsm/syrk, 2 panel-pair kernels, 1 their first form; all give the same factor.  Bit 8: the
- * level pipeline reads the children's update matrices in place instead of running the extend-add launches. */
+ * (3), 3 level pipeline potrf/trsm/syrk, 2 panel-pair kernels, 1 their first form; all give the same factor.  How a front's
+ * update matrix reaches its parent in the level pipeline: added into the parent front by the kernel that computes it
+ * (default); bit 8: every front reads its children's update matrices in place; bit 9: an extend-add launch per level sums
+ * them in (rounds 3-5). */
 KH_API int kh_spa_set_debug(kh_spa * s, int32_t flags);
 /* Multi-GPU (one process per GPU, every rank holds the same graph): rank r linearises the edge block
  * [E*r/world, E*(r+1)/world) into PARTIAL normal equations, and `allreduce` -- supplied by the host

@@ -92,6 +92,11 @@ struct kh_spa
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;               // the part of a level's extend-add that k_potrf does not read
   hipEvent_t ev_level[2] = {};
+  // self-cleaning fronts (scatter mode): the buffers these pointers name are all zeros (every kernel of the last factorisation
+  // and its backward sweep ran, each zeroing what it was the last to read)
+  const double * clean_a = nullptr; const double * clean_b = nullptr;
+  DevBuf<int32_t> d_deferred;                  // fronts whose update matrix stays in place (Symbolic::scatter_mode == 0, not a root)
+  int32_t n_deferred_fronts = 0, deferred_max_m = 0;
   kh_spa_options opt;
   std::vector<Node> nodes;                       // insertion order
   std::unordered_map<int32_t, int32_t> index_of; // id -> position in nodes
@@ -135,6 +140,7 @@ struct kh_spa
   DevBuf<FrontDesc> d_desc;
   uint8_t * h_upload = nullptr; size_t h_upload_cap = 0;     // pinned staging of an analysis' uploads (one block, ~30 copies out of it)
   DevBuf<int32_t> d_cinv;
+  DevBuf<double> d_fronts_b;                   // buffer B of the fronts (Symbolic::scatter_mode)
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
@@ -527,6 +533,16 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     up(s->d_slot_dest, slot_dest); up(s->d_slot_ld, slot_ld);
     up(s->d_elim_of_free, sym.elim_of_free); up(s->d_free_of_elim, sym.free_of_elim);
     up(s->d_level_fronts, level_fronts);
+    std::vector<int32_t> deferred;
+    s->deferred_max_m = 0;
+    for (int32_t k = 0; k < sym.n_fronts; ++k) {
+      if (sym.scatter_mode[k] == 0 && sym.parent[k] >= 0 && sym.front_m[k] > sym.front_ns[k]) {
+        deferred.push_back(k); s->deferred_max_m = std::max(s->deferred_max_m, sym.front_m[k]);
+      }
+    }
+    s->n_deferred_fronts = static_cast<int32_t>(deferred.size());
+    if (deferred.empty()) {deferred.push_back(0);}
+    up(s->d_deferred, deferred);
     up(s->d_winv_off, sym.winv_off);
     std::vector<FrontDesc> desc(sym.n_fronts);
     for (int32_t k = 0; k < sym.n_fronts; ++k) {
@@ -535,6 +551,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       fd.off = sym.front_off[k]; fd.woff = sym.winv_off[k]; fd.m = sym.front_m[k]; fd.ns = sym.front_ns[k]; fd.first = sym.front_first[k];
       fd.rows_ptr = sym.rows_ptr[k]; fd.child_ptr = sym.child_ptr[k]; fd.child_end = sym.child_ptr[k + 1];
       fd.relpos_ptr = sym.relpos_ptr[k]; fd.parent = sym.parent[k]; fd.cinv_ptr = sym.cinv_ptr[k];
+      fd.flags = sym.scatter_mode[k] | (sym.has_b[k] ? 4 : 0) | (sym.n_deferred[k] << 8);
       for (int32_t q = 0; q < 3 && fd.child_ptr + q < fd.child_end; ++q) {
         const int32_t c = sym.child_list[fd.child_ptr + q];
         fd.ch[q].off = sym.front_off[c]; fd.ch[q].m = sym.front_m[c]; fd.ch[q].ns = sym.front_ns[c]; fd.ch[q].rows_ptr = sym.rows_ptr[c];
@@ -572,6 +589,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_Hg.ensure(static_cast<size_t>(n_slots) * 9 + static_cast<size_t>(nf) * 3 + 8);
     r2 |= s->d_Hg_alt.ensure(static_cast<size_t>(n_slots) * 9 + static_cast<size_t>(nf) * 3 + 8);
     r2 |= s->d_fronts.ensure(static_cast<size_t>(sym.fronts_size) + 16);
+    r2 |= s->d_fronts_b.ensure(static_cast<size_t>(sym.fronts_size) + 16);
     r2 |= s->d_scale.ensure(3 * nf); r2 |= s->d_diag.ensure(3 * nf); r2 |= s->d_rhs.ensure(3 * nf);
     r2 |= s->d_step.ensure(3 * nf); r2 |= s->d_delta.ensure(3 * nf);
     r2 |= s->d_fail.ensure(4);
@@ -619,7 +637,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
   dev.child_ptr = s->d_child_ptr.p; dev.child_list = s->d_child_list.p; dev.relpos_ptr = s->d_relpos_ptr.p; dev.relpos = s->d_relpos.p;
   dev.slot_dest = s->d_slot_dest.p; dev.slot_ld = s->d_slot_ld.p;
   dev.elim_of_free = s->d_elim_of_free.p; dev.free_of_elim = s->d_free_of_elim.p;
-  dev.fronts = s->d_fronts.p; dev.fronts_size = sym.fronts_size;
+  dev.fronts = s->d_fronts.p; dev.fronts_size = sym.fronts_size; dev.fronts_b = s->d_fronts_b.p;
   dev.winv = s->d_winv.p; dev.winv_off = s->d_winv_off.p; dev.desc = s->d_desc.p; dev.cinv = s->d_cinv.p;
   has_work = true;
   return KH_OK;
@@ -679,7 +697,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_child_ptr.release(); s->d_child_list.release(); s->d_relpos_ptr.release(); s->d_relpos.release();
   s->d_slot_ld.release(); s->d_elim_of_free.release(); s->d_free_of_elim.release(); s->d_level_fronts.release();
   s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_winv_off.release(); s->d_winv.release(); s->d_desc.release(); s->d_cinv.release(); s->d_edge_z.release(); s->d_edge_u.release();
-  s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release();
+  s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release(); s->d_fronts_b.release(); s->d_deferred.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
   s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release(); s->d_partial.release(); s->d_Hg_alt.release(); s->d_best.release();
   for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
@@ -1232,6 +1250,25 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   // A rejected step simply leaves the second buffer unused.
   SpaDev alt = dev;
   alt.H = s->d_Hg_alt.p; alt.g = s->d_Hg_alt.p + static_cast<size_t>(s->n_slots) * 9;
+  // how a front's update matrix reaches its parent (kh_spa_set_debug bits 8, 9): added in by k_syrk (default), read in place by the
+  // parent, or summed in by an extend-add launch per level (rounds 3-5)
+  const int factor_mode = ((s->debug_flags >> 4) & 15) ? ((s->debug_flags >> 4) & 15) : 3;
+  const bool pipeline = factor_mode >= 3 && spa_level_pipeline_fits(sym.max_m, sym.max_ns);
+  dev.gather = pipeline && (s->debug_flags & 256) ? 1 : 0;
+  dev.scatter = pipeline && !dev.gather && !(s->debug_flags & 512) ? 1 : 0;
+  // The fronts (and buffer B) start every factorisation as zeros: 2 x 190 MB on the 10k-node graph, 27 us each at the head of
+  // the critical stream.  In scatter mode the fronts are SELF-CLEANING instead: every entry has exactly one last reader in a
+  // factorisation (k_potrf the pivot block, k_trsm buffer B under L21, k_syrk the update block, k_backward3 L21), and that reader
+  // stores a zero behind itself; only the update matrices that stay in place take a (small) kernel of their own.  (Zeroing on a
+  // second stream beside the step evaluation was tried first: the fill kernels take every compute unit, k_step_fused and the
+  // linearisation ran 2-3 x longer and the iteration gained 10 us of the 54.)
+  auto zero_fronts = [&]() -> int {
+    if (dev.scatter && s->clean_a == dev.fronts && s->clean_b == dev.fronts_b) {s->clean_a = nullptr; return KH_OK;}
+    s->clean_a = nullptr;
+    KS_HIP(hipMemsetAsync(dev.fronts, 0, sizeof(double) * dev.fronts_size, st));
+    if (dev.scatter) {KS_HIP(hipMemsetAsync(dev.fronts_b, 0, sizeof(double) * dev.fronts_size, st));}
+    return KH_OK;
+  };
   rc = linearize(dev, x, scal + 0); if (rc) {return finish(rc);}
   if (opt.jacobi_scaling) {
     spa_launch_jacobi_scale(dev, s->d_scale.p, st);
@@ -1287,17 +1324,13 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     }
     const bool timed = n_timed < kh_spa::kMaxTimed;
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][0], st));}
+    rc = zero_fronts(); if (rc) {return finish(rc);}
     spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
-    KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
     // factorisation and forward solve are one kernel per level (the forward step of a panel runs while its
-    // L11 / L21 are still in LDS), so the right-hand side has to be in place first
-    spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, st);
-    KS_HIP(hipMemsetAsync(s->d_sync.p, 0, sizeof(int32_t) * 4 * static_cast<size_t>(sym.n_fronts), st));
+    // L11 / L21 are still in LDS), so the right-hand side has to be in place first (the kernel also clears the fail flag)
+    spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, s->d_fail.p, st);
+    if (!pipeline) {KS_HIP(hipMemsetAsync(s->d_sync.p, 0, sizeof(int32_t) * 4 * static_cast<size_t>(sym.n_fronts), st));}
     static const int ea_limit = std::getenv("KH_SPA_EXTEND_ADD") ? std::atoi(std::getenv("KH_SPA_EXTEND_ADD")) : 128;
-    // the level pipeline potrf -> trsm -> syrk wherever its fronts fit the LDS; kh_spa_set_debug factor mode 1 / 2 sends every level
-    // through the any-size kernel k_factor instead (the tests' second opinion, and the path of fronts beyond ~2700 rows)
-    const int factor_mode = ((s->debug_flags >> 4) & 15) ? ((s->debug_flags >> 4) & 15) : 3;
-    const bool pipeline = factor_mode >= 3 && spa_level_pipeline_fits(sym.max_m, sym.max_ns);
     for (int l = 0; l < n_levels; ++l) {
       const int32_t n_level = s->level_offsets[l + 1] - s->level_offsets[l];
       const int32_t * lf = s->d_level_fronts.p + s->level_offsets[l];
@@ -1307,8 +1340,8 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
         // (measured on the 10k / 30k graph: 14.7 ms per solve with the split against 13.2 without -- two event records and two
         // stream waits per level on the critical stream cost more than the overlap wins; off unless KH_SPA_EA_OVERLAP=1)
         static const bool overlap_ea = std::getenv("KH_SPA_EA_OVERLAP") && std::atoi(std::getenv("KH_SPA_EA_OVERLAP")) != 0;
-        const bool split_ea = l > 0 && !dev.gather && overlap_ea && s->stream2;
-        if (l > 0 && !dev.gather) {
+        const bool split_ea = l > 0 && !dev.gather && !dev.scatter && overlap_ea && s->stream2;
+        if (l > 0 && !dev.gather && !dev.scatter) {
           if (split_ea) {
             KS_HIP(hipEventRecord(s->ev_level[0], st));                    // the level below is complete
             KS_HIP(hipStreamWaitEvent(s->stream2, s->ev_level[0], 0));
@@ -1339,6 +1372,10 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       } else {
         spa_launch_backward_level(dev, lf, n_level, s->level_max_m[l], s->d_rhs.p, st);
       }
+    }
+    if (dev.scatter) {
+      spa_launch_zero_update_blocks(dev, s->d_deferred.p, s->n_deferred_fronts, s->deferred_max_m, st);
+      s->clean_a = dev.fronts; s->clean_b = dev.fronts_b;
     }
     static const bool speculate = !(std::getenv("KH_SPA_SPECULATE") && std::atoi(std::getenv("KH_SPA_SPECULATE")) == 0);
     static const bool lin_check_env = std::getenv("KH_SPA_CHECK") != nullptr;
@@ -1459,6 +1496,19 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     }
   }
 
+  if ((s->debug_flags & 1) && dev.scatter && s->clean_a == dev.fronts && iteration > 0) {
+    // the self-cleaning fronts must be all zeros now (kh_spa_set_debug bit 0: every test that checks its linear solves checks this)
+    KS_HIP(hipMemsetAsync(s->d_fail.p, 0, sizeof(int32_t), st));
+    spa_launch_count_nonzero(dev.fronts, dev.fronts_size, s->d_fail.p, st);
+    spa_launch_count_nonzero(dev.fronts_b, dev.fronts_size, s->d_fail.p, st);
+    KS_HIP(hipMemcpyAsync(s->h_fail, s->d_fail.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KS_HIP(hipStreamSynchronize(st));
+    if (s->h_fail[0] != 0) {
+      s->clean_a = nullptr;
+      set_error("kh_spa: " + std::to_string(s->h_fail[0]) + " entries of the self-cleaning fronts were left behind by the last factorisation");
+      return finish(KH_ERR_SOLVER);
+    }
+  }
   sum.iterations = iteration;
   sum.final_cost = minimum_cost;
   sum.linearize_ms = lin_ms; sum.solve_ms = solve_ms;

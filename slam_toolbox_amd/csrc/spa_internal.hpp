@@ -27,7 +27,8 @@ struct alignas(16) FrontDesc
   int32_t relpos_ptr;      // positions of its struct rows inside the parent front (node units) in relpos
   int32_t parent;
   int32_t cinv_ptr;        // gather maps in cinv: child number s -> cinv[cinv_ptr + s * (m / 3) + position] = child row or -1
-  int32_t pad0;
+  int32_t flags;           // bits 0-1: where its update matrix goes (Symbolic::scatter_mode); bit 2: a child adds into buffer B;
+                           // bits 8..: children it reads in place (the first ones of its child list)
   ChildInfo ch[3];
 };
 static_assert(sizeof(FrontDesc) == 128, "FrontDesc is one 128-byte record");
@@ -84,7 +85,11 @@ struct SpaDev
   const int64_t * winv_off;
   const FrontDesc * desc;
   const int32_t * cinv;
-  int32_t gather;          // 1: fronts read their children's update matrices in place; 0: spa_launch_extend_add has summed them in
+  int32_t gather;          // 1: fronts read ALL their children's update matrices in place; 0: they have been summed in
+  // round 6: k_syrk adds a front's update matrix into its parent (buffer A = fronts, or buffer B = fronts_b, same offsets; see
+  // Symbolic::scatter_mode), no extend-add pass; 0: spa_launch_extend_add sums the update matrices into the fronts
+  int32_t scatter;
+  double * fronts_b;
 };
 
 // [e_lo, e_hi): edge block linearised by this rank (0, n_edges on a single GPU)
@@ -114,10 +119,14 @@ void spa_launch_potrf_level(const SpaDev & d, int32_t first_front, int32_t n, in
                             double * rhs, double * upd, void * stream);
 void spa_launch_update_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, double * upd, void * stream);
 void spa_launch_backward3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, void * stream);
+// self-cleaning fronts (scatter mode): zero the update matrices of the fronts in `list` (children read in place by their parents)
+void spa_launch_zero_update_blocks(const SpaDev & d, const int32_t * list, int32_t n, int32_t max_m, void * stream);
+// debugging aid: *count += entries of p[0..n) whose bit pattern is not zero
+void spa_launch_count_nonzero(const double * p, int64_t n, int32_t * count, void * stream);
 // whether the largest front of a problem fits the LDS budgets of the level pipeline (otherwise: panel-pair kernels)
 bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns);
-// rhs (elimination order) <- scale * g ; and back: step = -y (free order), delta = step * scale
-void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, void * stream);
+// rhs (elimination order) <- scale * g, *fail_flag <- 0 ; and back: step = -y (free order), delta = step * scale
+void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, int32_t * fail_flag, void * stream);
 void spa_launch_finish_step(const SpaDev & d, const double * scale, const double * rhs, double * step, double * delta, void * stream);
 // out[0] = step.gs, out[1] = step^T Hs step, out[2] = any non-finite in step
 void spa_launch_model(const SpaDev & d, const double * scale, const double * step, double * out3, void * stream);

@@ -208,6 +208,9 @@ __global__ void k_assemble(SpaDev d, const int32_t * slot_row, const double * sc
   if (dest < 0) {return;}
   const int r = el / 3, c = el - r * 3;
   const int i = slot_row[slot], j = d.bsr_col[slot];
+  // self-cleaning fronts: nothing is written that no kernel of the factorisation reads (and zeroes) -- the entries of a diagonal
+  // block above the diagonal would outlive a change of the fronts' layout
+  if (d.scatter && i == j && r < c) {return;}
   double v = scale[3 * i + r] * d.H[t] * scale[3 * j + c];
   if (i == j && r == c) {v += diagonal[3 * i + r] * inv_radius;}
   d.fronts[dest + r + (int64_t)c * d.slot_ld[slot]] = v;
@@ -217,20 +220,21 @@ __global__ void k_assemble(SpaDev d, const int32_t * slot_row, const double * sc
 void spa_launch_assemble(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, void * stream)
 {
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(d.fronts, 0, sizeof(double) * d.fronts_size, s);
+  // (the fronts have been zeroed by the caller)
   hipLaunchKernelGGL(k_assemble, dim3((d.n_slots * 9 + 255) / 256), dim3(256), 0, s, d, d.bsr_col + d.n_slots, scale, diagonal, inv_radius);
 }
 
-__global__ void k_make_rhs(SpaDev d, const double * scale, double * rhs)
+__global__ void k_make_rhs(SpaDev d, const double * scale, double * rhs, int32_t * fail_flag)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && fail_flag) {*fail_flag = 0;}        // (a memset node of its own cost 4 us and a gap on the critical stream)
   if (t >= d.n_free * 3) {return;}
   const int i = t / 3, c = t - i * 3;
   rhs[3 * d.elim_of_free[i] + c] = scale[t] * d.g[t];
 }
-void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, void * stream)
+void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, int32_t * fail_flag, void * stream)
 {
-  hipLaunchKernelGGL(k_make_rhs, dim3((d.n_free * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, scale, rhs);
+  hipLaunchKernelGGL(k_make_rhs, dim3((d.n_free * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, scale, rhs, fail_flag);
 }
 
 __global__ void k_finish_step(SpaDev d, const double * scale, const double * rhs, double * step, double * delta)
@@ -1407,6 +1411,17 @@ __device__ __forceinline__ ChildInfo child_info(const SpaDev & d, const FrontDes
   return ci;
 }
 
+// round 6 (Symbolic::scatter_mode): children read in place come first in the child list
+__device__ __forceinline__ int front_nkids(const SpaDev & d, const FrontDesc & fd)
+{
+  return d.gather ? fd.child_end - fd.child_ptr : (d.scatter ? (fd.flags >> 8) : 0);
+}
+// buffer B of a front, or nullptr when no child adds into it
+__device__ __forceinline__ const double * front_b(const SpaDev & d, const FrontDesc & fd)
+{
+  return (d.scatter && (fd.flags & 4)) ? d.fronts_b + fd.off : nullptr;
+}
+
 // entry (i, j), i >= j (scalar positions in the parent front), of one child's update matrix, 0 where the child has none
 __device__ __forceinline__ double gather_entry(const double * __restrict__ fronts, const ChildInfo & c, const int32_t * __restrict__ inv, int i, int j)
 {
@@ -1424,22 +1439,33 @@ __device__ __forceinline__ double gather_entry(const double * __restrict__ front
 // loaded value, so the wave goes on to its pivot chain while they travel -- with the padding select next to the loads, as in
 // round 3, the wave sat out a full memory latency, about a microsecond, in front of every diagonal block);
 // pivot_tile_finish, one step later, adds the children's entries (gather mode only) and puts the identity on the padding.
-__device__ __forceinline__ v4d pivot_tile_load(const FrontDesc & fd, const double * __restrict__ F, int row0, int col0, int lane)
+struct TileRaw {v4d a, b;};
+__device__ __forceinline__ TileRaw pivot_tile_load(const FrontDesc & fd, const double * F, const double * B, bool clean, int row0, int col0, int lane)
 {
   const int lr = lane & 15, lk = lane >> 4;
   const int row = row0 + lr, m = fd.m, ns = fd.ns;
-  v4d v;
+  TileRaw t;
+  t.b = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int col = col0 + lk + 4 * r;
     const bool want = row < ns && col <= row;
-    v[r] = *(want ? F + row + (int64_t)col * m : F);
+    const int64_t at = want ? row + (int64_t)col * m : 0;
+    t.a[r] = F[at];
+    if (B) {t.b[r] = B[at];}
+    // self-cleaning fronts (round 6): what has been read is zero again for the next factorisation -- no 2 x 190 MB memset per
+    // factorisation (L11 itself lives in LDS and leaves the kernel as W)
+    if (clean && want) {
+      const_cast<double *>(F)[at] = 0.0;
+      if (B) {const_cast<double *>(B)[at] = 0.0;}
+    }
   }
-  return v;
+  return t;
 }
 
-__device__ __forceinline__ v4d pivot_tile_finish(v4d v, const SpaDev & d, const FrontDesc & fd, int nchild, int row0, int col0, int lane)
+__device__ __forceinline__ v4d pivot_tile_finish(const TileRaw & t, const SpaDev & d, const FrontDesc & fd, int nchild, int row0, int col0, int lane)
 {
+  v4d v = t.a + t.b;
   const int lr = lane & 15, lk = lane >> 4;
   const int row = row0 + lr, m = fd.m, ns = fd.ns, mp = m / 3;
   bool want[4];
@@ -1511,20 +1537,21 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
   __shared__ int s_fail;
   if (tid == 0) {s_fail = 0;}
   const int nchild = fd.child_end - fd.child_ptr;
-  const int nkids = d.gather ? nchild : 0;            // children whose update matrices are read in place
+  const int nkids = front_nkids(d, fd);               // children whose update matrices are read in place
   const int mp = m / 3;
   // first column block's tiles: wave 0 the diagonal tile, waves 1..3 the tiles below it (round robin, up to three each)
   constexpr int SL = 3;
-  v4d cur[SL];
+  TileRaw cur[SL];
+  const double * Bf = front_b(d, fd);
   auto prefetch = [&](int jb) {
     if (jb >= nt) {return;}
     if (wave == 0) {
-      cur[0] = pivot_tile_load(fd, F, NB * jb, NB * jb, lane);
+      cur[0] = pivot_tile_load(fd, F, Bf, d.scatter != 0, NB * jb, NB * jb, lane);
     } else {
 #pragma unroll
       for (int q = 0; q < SL; ++q) {
         const int I = jb + 1 + (wave - 1) + 3 * q;
-        if (I < nt) {cur[q] = pivot_tile_load(fd, F, NB * I, NB * jb, lane);}
+        if (I < nt) {cur[q] = pivot_tile_load(fd, F, Bf, d.scatter != 0, NB * I, NB * jb, lane);}
       }
     }
   };
@@ -1564,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
 #pragma unroll
       for (int q = 0; q < SL; ++q) {
         const int I = jb + 1 + (wave - 1) + 3 * q;
-        mine[q] = I < nt ? pivot_tile_finish(cur[q], d, fd, nkids, NB * I, c0, lane) : cur[q];
+        mine[q] = I < nt ? pivot_tile_finish(cur[q], d, fd, nkids, NB * I, c0, lane) : cur[q].a;
       }
       prefetch(jb + 1);
       // regular tiles (I, jb), I > jb
@@ -1672,11 +1699,12 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
 // same thread handles the same entry in every pass: no barrier in between)
 template <int R>
 __device__ __forceinline__ void stage_rows(double * S, int LD, const SpaDev & d, const FrontDesc & fd, int prow0, int nr, int ns, int nsp, int nkids,
-                                           int tid, int nthreads)
+                                           const double * Bfront, int tid, int nthreads)
 {
   constexpr int LU = 16;
   const int m = fd.m, mp = m / 3;
   const double * Fcol0 = d.fronts + fd.off + prow0;
+  const double * Bcol0 = Bfront ? Bfront + prow0 : nullptr;
   for (int base = 0; base < R * nsp; base += LU * nthreads) {
     double v[LU];
 #pragma unroll
@@ -1685,6 +1713,17 @@ __device__ __forceinline__ void stage_rows(double * S, int LD, const SpaDev & d,
       const int c = idx / R, i = idx - c * R;
       const bool want = idx < R * nsp && i < nr && c < ns;
       v[u] = *(want ? Fcol0 + i + (int64_t)c * m : Fcol0);
+    }
+    if (Bcol0) {
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int idx = base + u * nthreads + tid;
+        const int c = idx / R, i = idx - c * R;
+        const bool want = idx < R * nsp && i < nr && c < ns;
+        const double * bp = want ? Bcol0 + i + (int64_t)c * m : Bcol0;
+        v[u] += *bp;
+        if (want) {*const_cast<double *>(bp) = 0.0;}          // self-cleaning (buffer A's entries become L21)
+      }
     }
     for (int s = 0; s < nkids; ++s) {
       const ChildInfo ci = child_info(d, fd, s);
@@ -1735,7 +1774,7 @@ __global__ __launch_bounds__(256) void k_trsm(SpaDev d, int first_front, const d
   const double uold = tid < nr ? uk[r0 + tid] : 0.0;
   for (int j = tid; j < nsp; j += nthreads) {yv[j] = j < ns ? rhs[first + j] : 0.0;}
   for (int j = tid; j < 4 * R; j += nthreads) {red[j] = 0.0;}
-  stage_rows<R>(S, LD, d, fd, ns + r0, nr, ns, nsp, d.gather ? fd.child_end - fd.child_ptr : 0, tid, nthreads);
+  stage_rows<R>(S, LD, d, fd, ns + r0, nr, ns, nsp, front_nkids(d, fd), front_b(d, fd), tid, nthreads);
   __syncthreads();
   double part[RT];
 #pragma unroll
@@ -1806,6 +1845,7 @@ __global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int 
   const int J = t - I * (I + 1) / 2;
   const int nsp = (ns + NB - 1) & ~(NB - 1), LD = nsp + 2;
   double * F = d.fronts + fd.off;
+  const double * Bf = front_b(d, fd);
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -1828,13 +1868,40 @@ __global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int 
     for (int r = 0; r < 4; ++r) {
       const int col = col0 + 4 * r;
       const bool ok = live[u] && row < nu && col <= row;
-      const double v = *(ok ? F + (ns + row) + (int64_t)(ns + col) * m : F);
+      const int64_t at = ok ? (ns + row) + (int64_t)(ns + col) * m : 0;
+      double v = F[at];
+      if (Bf) {v += Bf[at];}
       acc[u][r] = ok ? v : 0.0;
+      if (d.scatter && ok) {                                   // self-cleaning: the tile leaves for the parent front (or is stored below)
+        F[at] = 0.0;
+        if (Bf) {const_cast<double *>(Bf)[at] = 0.0;}
+      }
     }
+  }
+  // where the tile goes: into the parent front (round 6), or back where it came from
+  const int mode = d.scatter ? (fd.flags & 3) : 0;
+  int prow = 0, pcol[UT][4];
+  int64_t pm = 0;
+  double * P = nullptr;
+  if (mode != 0) {
+    const FrontDesc & pd = d.desc[fd.parent];
+    const int32_t * rp = d.relpos + fd.relpos_ptr;
+    const int rowc = min(row, nu - 1);
+    prow = 3 * rp[rowc / 3] + rowc % 3;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int colc = min(TS * J + NB * (sj0 + u) + lk + 4 * r, nu - 1);
+        pcol[u][r] = 3 * rp[colc / 3] + colc % 3;
+      }
+    }
+    pm = pd.m;
+    P = (mode == 1 ? d.fronts : d.fronts_b) + pd.off;
   }
   {
     // the children's update matrices join here (the front's own F22 holds only its assembled entries)
-    const int nkids = d.gather ? fd.child_end - fd.child_ptr : 0, mp = m / 3;
+    const int nkids = front_nkids(d, fd), mp = m / 3;
     for (int s = 0; s < nkids; ++s) {
       const ChildInfo ci = child_info(d, fd, s);
       const int32_t * inv = d.cinv + fd.cinv_ptr + s * mp;
@@ -1851,8 +1918,8 @@ __global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int 
       }
     }
   }
-  stage_rows<TS>(XA, LD, d, fd, ns + TS * I, min(TS, nu - TS * I), ns, nsp, 0, tid, nthreads);      // L21 is final: no children
-  if (I != J) {stage_rows<TS>(XB, LD, d, fd, ns + TS * J, min(TS, nu - TS * J), ns, nsp, 0, tid, nthreads);}
+  stage_rows<TS>(XA, LD, d, fd, ns + TS * I, min(TS, nu - TS * I), ns, nsp, 0, nullptr, tid, nthreads);      // L21 is final: no children
+  if (I != J) {stage_rows<TS>(XB, LD, d, fd, ns + TS * J, min(TS, nu - TS * J), ns, nsp, 0, nullptr, tid, nthreads);}
   __syncthreads();
   if (live[0]) {
     const double * xb = XA + (NB * si + lr) * LD + 4 * lk;
@@ -1880,7 +1947,13 @@ __global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int col = col0 + 4 * r;
-      if (live[u] && row < nu && col <= row) {F[(ns + row) + (int64_t)(ns + col) * m] = acc[u][r];}
+      if (live[u] && row < nu && col <= row) {
+        if (mode != 0) {
+          unsafeAtomicAdd(P + prow + pcol[u][r] * pm, acc[u][r]);
+        } else {
+          F[(ns + row) + (int64_t)(ns + col) * m] = acc[u][r];
+        }
+      }
     }
   }
 }
@@ -1913,6 +1986,10 @@ __global__ __launch_bounds__(1024) void k_backward3(SpaDev d, int first_front, d
       const double x = sb[ns + i];
       a0 += col0[i] * x;
       a1 += col1[i] * x;
+      if (d.scatter) {                        // self-cleaning fronts: this was the last reader of L21
+        const_cast<double *>(col0)[i] = 0.0;
+        if (c + 1 < ns) {const_cast<double *>(col1)[i] = 0.0;}
+      }
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
@@ -1935,6 +2012,37 @@ __global__ __launch_bounds__(1024) void k_backward3(SpaDev d, int first_front, d
   }
   __syncthreads();
   for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = xo[t];}
+}
+
+// self-cleaning fronts: the update matrices that stayed in place (children their parent reads through cinv) are zeroed here,
+// after the factorisation; list = those fronts, one workgroup per (front, 16 columns)
+__global__ __launch_bounds__(256) void k_zero_update_blocks(SpaDev d, const int32_t * __restrict__ list)
+{
+  const FrontDesc fd = d.desc[list[blockIdx.x]];
+  const int m = fd.m, ns = fd.ns, nu = m - ns;
+  double * U = d.fronts + fd.off + ns + (int64_t)ns * m;
+  for (int c = 16 * (int)blockIdx.y + ((int)threadIdx.x >> 4); c < nu; c += 16 * (int)gridDim.y) {
+    for (int i = c + ((int)threadIdx.x & 15); i < nu; i += 16) {U[i + (int64_t)c * m] = 0.0;}
+  }
+}
+void spa_launch_zero_update_blocks(const SpaDev & d, const int32_t * list, int32_t n, int32_t max_m, void * stream)
+{
+  if (n <= 0) {return;}
+  hipLaunchKernelGGL(k_zero_update_blocks, dim3(n, std::max(1, std::min(16, max_m / 16))), dim3(256), 0, (hipStream_t)stream, d, list);
+}
+
+// debugging aid (kh_spa_set_debug bit 0): entries of a buffer that are not zero (bit pattern), counted into *count
+__global__ __launch_bounds__(256) void k_count_nonzero(const double * __restrict__ p, int64_t n, int32_t * count)
+{
+  int mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    mine += __double_as_longlong(p[i]) != 0 ? 1 : 0;
+  }
+  if (mine) {atomicAdd(count, mine);}
+}
+void spa_launch_count_nonzero(const double * p, int64_t n, int32_t * count, void * stream)
+{
+  hipLaunchKernelGGL(k_count_nonzero, dim3(1024), dim3(256), 0, (hipStream_t)stream, p, n, count);
 }
 
 static size_t potrf_lds_bytes(int nsp, int max_m)

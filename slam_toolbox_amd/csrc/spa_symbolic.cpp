@@ -469,10 +469,28 @@ int build_structure(Symbolic & sym, int32_t n_free, const std::vector<int32_t> &
   sym.fronts_size = off;
   sym.winv_size = woff;
   sym.rows.reserve(sym.rows_ptr[K]); sym.child_list.reserve(sym.child_ptr[K]); sym.relpos.assign(sym.relpos_ptr[K], 0);
+  sym.scatter_mode.assign(K, 0); sym.n_deferred.assign(K, 0); sym.has_b.assign(K, 0);
   for (int32_t k = 0; k < K; ++k) {
     const int32_t o = o_of_k[k];
     sym.rows.insert(sym.rows.end(), rows[o].begin(), rows[o].end());
-    for (int32_t c : children[o]) {sym.child_list.push_back(k_of_o[c]);}
+    // destinations of the children's update matrices (see Symbolic::scatter_mode): level by level, lowest front number first
+    std::vector<int32_t> kids;
+    for (int32_t c : children[o]) {kids.push_back(k_of_o[c]);}
+    std::sort(kids.begin(), kids.end());           // fronts are numbered level by level
+    bool b_used = false;
+    for (size_t g0 = 0; g0 < kids.size();) {
+      size_t g1 = g0;
+      while (g1 < kids.size() && sym.level[kids[g1]] == sym.level[kids[g0]]) {++g1;}
+      for (size_t q = g0; q < g1; ++q) {
+        const size_t idx = q - g0;
+        sym.scatter_mode[kids[q]] = idx == 0 ? 1 : (idx == 1 || (idx == 2 && !b_used)) ? 2 : 0;
+      }
+      if (g1 - g0 >= 2) {b_used = true;}
+      g0 = g1;
+    }
+    for (int32_t c : kids) {if (sym.scatter_mode[c] == 0) {sym.child_list.push_back(c); ++sym.n_deferred[k];}}
+    for (int32_t c : kids) {if (sym.scatter_mode[c] != 0) {sym.child_list.push_back(c);}}
+    for (int32_t c : kids) {if (sym.scatter_mode[c] == 2) {sym.has_b[k] = 1;}}
   }
   // where a child's rows sit in its parent's front: the parent's rows are numbered once (`stamp` doubles as the map from a row
   // to its position, tagged with the parent so that stale entries are recognised), then every child looks its rows up

@@ -30,6 +30,15 @@ struct Symbolic
   // for child number s of front k, cinv[cinv_ptr[k] + s * (front_m[k] / 3) + i] = index of the child's struct row that sits
   // at position i (node units) of front k, or -1
   std::vector<int32_t> cinv_ptr, cinv;
+  // round 6: where a front's update matrix goes (the level pipeline's k_syrk adds it straight into the parent front instead of
+  // leaving it for an extend-add pass).  Two destination buffers make the sums independent of the order in which the workgroups
+  // of one launch arrive: buffer A (the fronts themselves, holding the assembled entries) takes ONE child per level of the tree,
+  // buffer B (zero before every factorisation) takes one more, or two while nothing has been added to it yet (0 + x + y is
+  // commutative).  Further children of the same level are `deferred`: their update matrices stay where they are and the parent
+  // reads them in place through cinv (they come FIRST in the parent's child list).
+  std::vector<uint8_t> scatter_mode;     // per front: 0 deferred (or root), 1 into the parent in buffer A, 2 in buffer B
+  std::vector<int32_t> n_deferred;       // per front: children it reads in place
+  std::vector<uint8_t> has_b;            // per front: a child adds into buffer B
   // inverse of the pivot block's Cholesky factor, one nsp x nsp block per front (nsp = ns rounded up to 16)
   std::vector<int64_t> winv_off;
   int64_t winv_size = 0;
