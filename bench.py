@@ -307,7 +307,15 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
             last = dict(sol.Compute())
             if rep:
                 cached.append(time.time() - t)
+        # GPU time per phase: one more solve with HIP events around the phases (kh_spa_set_debug bit 1; the timed solves above run
+        # without them -- an event record is a 5-6 us bubble on the stream)
+        sol.set_debug(phase_timing=True)
+        sol.load_graph(paths[0])
+        phases = dict(sol.Compute())
+        sol.set_debug()
     summ = summs[int(np.argsort(times)[len(times) // 2])]        # the median run's own summary
+    for key_ms in ("factor_gpu_ms", "backward_gpu_ms", "linearize_gpu_ms"):
+        summ[key_ms] = phases[key_ms]
     key = "solve_ms" if world == 1 else "solve_ms_edge_sharded"
     out = {key: float(np.median(times)) * 1e3, "solve_graph_load_ms": float(np.median(loads)) * 1e3,
            "solve_iterations": int(summ["iterations"]),

@@ -297,7 +297,8 @@ typedef struct kh_spa_summary {
 
 KH_API int kh_spa_create(int32_t device, kh_spa ** out);
 /* Test / measurement switches, 0 = none.  Bit 0: every LM iteration also evaluates the residual of its linear solve from
- * the block-sparse matrix (kh_spa_summary.worst_linear_residual).  Bits 4-7: numeric factorisation kernels -- 0 default
+ * the block-sparse matrix (kh_spa_summary.worst_linear_residual).  Bit 1: HIP events around the phases of every iteration
+ * (kh_spa_summary.factor_gpu_ms, backward_gpu_ms, linearize_gpu_ms; 0 without it -- each event costs the stream 5-6 us).  Bits 4-7: numeric factorisation kernels -- 0 default
  * (3), 3 level pipeline potrf/trsm/syrk, 2 panel-pair kernels, 1 their first form; all give the same factor.  How a front's
  * update matrix reaches its parent in the level pipeline: added into the parent front by the kernel that computes it
  * (default); bit 8: every front reads its children's update matrices in place; bit 9: an extend-add launch per level sums

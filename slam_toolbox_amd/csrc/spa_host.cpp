@@ -595,7 +595,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     r2 |= s->d_fail.ensure(4);
     r2 |= s->d_sync.ensure(4 * static_cast<size_t>(sym.n_fronts) + 4);
     r2 |= s->d_upd.ensure(static_cast<size_t>(3) * sym.rows_ptr[sym.n_fronts] + 16);
-    r2 |= s->d_partial.ensure(static_cast<size_t>(5) * ((nf + 255) / 256) + (E + 255) / 256 + static_cast<size_t>(2) * ((3 * nf + 255) / 256) + 32);
+    r2 |= s->d_partial.ensure(static_cast<size_t>(5) * ((4 * nf + 255) / 256) + (E + 255) / 256 + static_cast<size_t>(2) * ((3 * nf + 255) / 256) + 32);
     r2 |= s->d_fsb.ensure(static_cast<size_t>(3) * (static_cast<size_t>(nf) + sym.rows_ptr[sym.n_fronts]) + 16);
     if (r2) {(void)hipStreamSynchronize(st); return KH_ERR_HIP;}
     // the uploads above read pageable host vectors of this block: they must have landed before the block ends
@@ -1226,6 +1226,9 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   const int32_t e_hi = static_cast<int32_t>(static_cast<int64_t>(dev.n_edges) * (s->shard_rank + 1) / s->shard_world);
   const int64_t hg_count = static_cast<int64_t>(s->n_slots) * 9 + static_cast<int64_t>(dev.n_free) * 3;
   int n_lin = 0, n_timed = 0;
+  // kh_spa_set_debug bit 1: HIP events around the phases of every LM iteration (kh_spa_summary.*_gpu_ms).  Off by default: an event
+  // record between two kernels is a 5-6 us bubble on the stream, three of them per iteration were 0.15 ms of a 9 ms solve.
+  const bool phase_events = (s->debug_flags & 2) != 0;
   auto allreduce_Hg = [&](const SpaDev & into) -> int {
     if (s->comm) {
       // H || g of this rank's edge block -> sums over all ranks, on the solver's stream (RCCL over xGMI)
@@ -1238,7 +1241,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     return KH_OK;
   };
   auto linearize = [&](const SpaDev & into, const double * at, double * cost_slot) -> int {
-    const bool timed = n_lin < 2 * kh_spa::kMaxTimed + 2;
+    const bool timed = phase_events && n_lin < 2 * kh_spa::kMaxTimed + 2;
     if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
     spa_launch_linearize(into, at, cost_slot, e_lo, e_hi, st);
     if (timed) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
@@ -1322,7 +1325,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       spa_launch_diag(dev, s->d_scale.p, s->d_diag.p, opt.min_lm_diagonal, opt.max_lm_diagonal, st);
       have_diagonal = true;
     }
-    const bool timed = n_timed < kh_spa::kMaxTimed;
+    const bool timed = phase_events && n_timed < kh_spa::kMaxTimed;
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][0], st));}
     rc = zero_fronts(); if (rc) {return finish(rc);}
     spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
@@ -1383,7 +1386,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     const bool fused_step = speculate && !(std::getenv("KH_SPA_FUSED_STEP") && std::atoi(std::getenv("KH_SPA_FUSED_STEP")) == 0);
     if (fused_step) {
       // the candidate's cost AND its normal equations (speculative: a step is nearly always accepted) ride in the same batch
-      const bool timed_lin = n_lin < 2 * kh_spa::kMaxTimed + 2;
+      const bool timed_lin = phase_events && n_lin < 2 * kh_spa::kMaxTimed + 2;
       if (timed_lin) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][0], st));}
       spa_launch_step_and_linearize(dev, alt, s->d_scale.p, s->d_rhs.p, x, s->d_step.p, s->d_delta.p, cand, s->d_partial.p, e_lo, e_hi, st);
       if (timed_lin) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}

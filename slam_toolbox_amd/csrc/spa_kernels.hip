@@ -36,16 +36,36 @@ __device__ __forceinline__ double d_normalize_angle(double a) {return a - kTwoPi
 // [e_lo, e_hi) = the edge block this GPU linearises (all edges on one GPU); edges outside it get a zero
 // record, so the gather kernels below produce this rank's PARTIAL H and g, summed across ranks by the
 // caller's all-reduce.
-template <bool kJac>
-__global__ __launch_bounds__(256) void k_edge_lin(SpaDev d, const double * __restrict__ x, int e_lo, int e_hi)
+template <int N>
+__device__ __forceinline__ void block_reduce_store(double (&v)[N], int max_mask, double * out)      // bit q of max_mask: entry q is a maximum
 {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d.n_edges) {return;}
+  __shared__ double red[N][256];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {red[q][threadIdx.x] = v[q];}
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const double a = red[q][threadIdx.x], b = red[q][threadIdx.x + w];
+        red[q][threadIdx.x] = ((max_mask >> q) & 1) ? fmax(a, b) : a + b;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < N) {out[threadIdx.x] = red[threadIdx.x][0];}
+}
+
+// device half of k_edge_lin: returns rho(s) of the edge (0 for the threads behind the last edge)
+template <bool kJac>
+__device__ __forceinline__ double edge_lin(const SpaDev & d, const double * __restrict__ x, int e, int e_lo, int e_hi)
+{
+  if (e >= d.n_edges) {return 0.0;}
   if (kJac && (e < e_lo || e >= e_hi)) {
     double * out = d.edge_lin + 21 * (size_t)e;
 #pragma unroll
     for (int q = 0; q < 21; ++q) {out[q] = 0.0;}
-    return;
+    return 0.0;
   }
   const int a = d.edge_a[e], b = d.edge_b[e];
   const double xa = x[3 * a], ya = x[3 * a + 1], ta = x[3 * a + 2];
@@ -78,7 +98,7 @@ __global__ __launch_bounds__(256) void k_edge_lin(SpaDev d, const double * __res
     w = sqrt(fmax(2.2250738585072014e-308, 1.0 / sum));
   }
   d.edge_cost[e] = rho0;
-  if (!kJac) {return;}
+  if (!kJac) {return rho0;}
   double * out = d.edge_lin + 21 * (size_t)e;
   f0 *= w; f1 *= w; f2 *= w;
   out[0] = f0; out[1] = f1; out[2] = f2;
@@ -94,11 +114,20 @@ __global__ __launch_bounds__(256) void k_edge_lin(SpaDev d, const double * __res
     out[12 + 3 + col] = w * (U[4] * jb[3 + col] + U[5] * jb[6 + col]);
     out[12 + 6 + col] = w * (U[8] * jb[6 + col]);
   }
+  return rho0;
 }
 
-__global__ __launch_bounds__(256) void k_gather_H(SpaDev d)
+// cost_partial: per-workgroup sums of rho (the step evaluation's form; nullptr: none).  A sharded linearisation (edges outside
+// [e_lo, e_hi) get a zero record) does not produce them: the cost is evaluated over all edges by the <false> instance.
+template <bool kJac>
+__global__ __launch_bounds__(256) void k_edge_lin(SpaDev d, const double * __restrict__ x, int e_lo, int e_hi, double * cost_partial)
 {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double p[1] = {edge_lin<kJac>(d, x, blockIdx.x * blockDim.x + threadIdx.x, e_lo, e_hi)};
+  if (cost_partial) {block_reduce_store<1>(p, 0, cost_partial + blockIdx.x);}
+}
+
+__device__ __forceinline__ void gather_H(const SpaDev & d, int t)
+{
   if (t >= d.n_slots * 9) {return;}
   const int slot = t / 9, el = t - slot * 9;
   const int row = el / 3, col = el - row * 3;
@@ -113,6 +142,7 @@ __global__ __launch_bounds__(256) void k_gather_H(SpaDev d)
   }
   d.H[t] = acc;
 }
+__global__ __launch_bounds__(256) void k_gather_H(SpaDev d) {gather_H(d, blockIdx.x * blockDim.x + threadIdx.x);}
 
 __global__ __launch_bounds__(256) void k_gather_g(SpaDev d)
 {
@@ -151,9 +181,9 @@ void spa_launch_linearize(const SpaDev & d, const double * x, double * cost_out,
   if (d.n_edges > 0) {
     if (e_lo > 0 || e_hi < d.n_edges) {
       // sharded: the cost is still evaluated over all edges on every rank (E threads, microseconds)
-      hipLaunchKernelGGL(k_edge_lin<false>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, 0, d.n_edges);
+      hipLaunchKernelGGL(k_edge_lin<false>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, 0, d.n_edges, (double *)nullptr);
     }
-    hipLaunchKernelGGL(k_edge_lin<true>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, e_lo, e_hi);
+    hipLaunchKernelGGL(k_edge_lin<true>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, e_lo, e_hi, (double *)nullptr);
     hipLaunchKernelGGL(k_gather_H, dim3((d.n_slots * 9 + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_gather_g, dim3((d.n_free * 3 + 255) / 256), dim3(256), 0, s, d);
   }
@@ -164,7 +194,7 @@ void spa_launch_cost(const SpaDev & d, const double * x, double * cost_out, void
 {
   hipStream_t s = (hipStream_t)stream;
   if (d.n_edges > 0) {
-    hipLaunchKernelGGL(k_edge_lin<false>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, 0, d.n_edges);
+    hipLaunchKernelGGL(k_edge_lin<false>, dim3((d.n_edges + 255) / 256), dim3(256), 0, s, d, x, 0, d.n_edges, (double *)nullptr);
   }
   hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, d.edge_cost, d.n_edges, 0.5, cost_out);
 }
@@ -378,37 +408,19 @@ void spa_launch_grad_norms(const SpaDev & d, const double * x, double * out2, vo
 //   k_edge_lin<true, true>  candidate cost + linearisation, cost partials
 //   k_gather_H, k_gather_g<true>  normal equations at the candidate, gradient-norm partials
 //   k_reduce_partials
-template <int N>
-__device__ __forceinline__ void block_reduce_store(double (&v)[N], int max_mask, double * out)      // bit q of max_mask: entry q is a maximum
-{
-  __shared__ double red[N][256];
-#pragma unroll
-  for (int q = 0; q < N; ++q) {red[q][threadIdx.x] = v[q];}
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) {
-#pragma unroll
-      for (int q = 0; q < N; ++q) {
-        const double a = red[q][threadIdx.x], b = red[q][threadIdx.x + w];
-        red[q][threadIdx.x] = ((max_mask >> q) & 1) ? fmax(a, b) : a + b;
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < N) {out[threadIdx.x] = red[threadIdx.x][0];}
-}
-
+// four lanes per free node: its row of H holds ~7 blocks, each a dependent (column -> step of the column) pair of loads; with one
+// thread per node the kernel was 40 workgroups walking them one after the other (20 us for 10 000 nodes)
+constexpr int kStepLanes = 4;
 __global__ __launch_bounds__(256) void k_step_fused(SpaDev d, const double * __restrict__ scale, const double * __restrict__ rhs,
                                                     const double * __restrict__ x, double * step, double * delta, double * cand, double * partial)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t / kStepLanes, sub = t % kStepLanes;
   double p[5] = {0.0, 0.0, 0.0, 0.0, 0.0};        // step.gs, step^T Hs step, non-finite marker, |x - cand|^2, |cand|^2
-  if (i < d.n_free) {
-    const int e = d.elim_of_free[i];
-    double st[3], acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {st[c] = -rhs[3 * e + c];}                 // levenberg_marquardt_strategy.cc: step *= -1
-    for (int k = d.bsr_row_ptr[i]; k < d.bsr_row_ptr[i + 1]; ++k) {
+  const bool live = i < d.n_free;
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (live) {
+    for (int k = d.bsr_row_ptr[i] + sub; k < d.bsr_row_ptr[i + 1]; k += kStepLanes) {
       const int j = d.bsr_col[k];
       const int ej = d.elim_of_free[j];
       const double * blk = d.H + (size_t)k * 9;
@@ -418,6 +430,17 @@ __global__ __launch_bounds__(256) void k_step_fused(SpaDev d, const double * __r
 #pragma unroll
       for (int r = 0; r < 3; ++r) {acc[r] += blk[3 * r] * sj[0] + blk[3 * r + 1] * sj[1] + blk[3 * r + 2] * sj[2];}
     }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    acc[r] += __shfl_xor(acc[r], 1);
+    acc[r] += __shfl_xor(acc[r], 2);
+  }
+  if (live && sub == 0) {
+    const int e = d.elim_of_free[i];
+    double st[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {st[c] = -rhs[3 * e + c];}                 // levenberg_marquardt_strategy.cc: step *= -1
     double dl[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -441,9 +464,12 @@ __global__ __launch_bounds__(256) void k_step_fused(SpaDev d, const double * __r
   block_reduce_store<5>(p, 0, partial + 5 * blockIdx.x);
 }
 
-// gradient at the candidate + the projected-gradient norms (k_gather_g and k_grad_norms in one)
-__global__ __launch_bounds__(256) void k_gather_g_norms(SpaDev d, const double * __restrict__ x, double * partial)
+// The normal equations at the candidate in ONE launch: the first nbg workgroups gather the gradient (and leave the projected-
+// gradient norm partials), the others the blocks of H -- two launches in round 5, the shorter one (10 us) a boundary and a ramp
+// of its own on the critical stream.
+__global__ __launch_bounds__(256) void k_gather_Hg_norms(SpaDev d, const double * __restrict__ x, double * partial, int nbg)
 {
+  if ((int)blockIdx.x >= nbg) {gather_H(d, ((int)blockIdx.x - nbg) * 256 + (int)threadIdx.x); return;}
   const int t = blockIdx.x * 256 + threadIdx.x;
   double p[2] = {0.0, 0.0};                       // max |x - Plus(x, -g)|, |x_free|^2
   if (t < d.n_free * 3) {
@@ -463,13 +489,6 @@ __global__ __launch_bounds__(256) void k_gather_g_norms(SpaDev d, const double *
     p[1] = v * v;
   }
   block_reduce_store<2>(p, 1, partial + 2 * blockIdx.x);
-}
-
-__global__ __launch_bounds__(256) void k_edge_cost_partials(SpaDev d, double * partial)
-{
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  double p[1] = {e < d.n_edges ? d.edge_cost[e] : 0.0};
-  block_reduce_store<1>(p, 0, partial + blockIdx.x);
 }
 
 // out[3..7] <- step partials, out[8] <- 0.5 * cost partials, out[9], out[10] <- gradient norm partials
@@ -493,7 +512,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double * ps, int 
 
 int64_t spa_step_partials_size(const SpaDev & d)
 {
-  return 5 * (int64_t)((d.n_free + 255) / 256) + (d.n_edges + 255) / 256 + 2 * (int64_t)((3 * d.n_free + 255) / 256) + 16;
+  return 5 * (int64_t)((kStepLanes * d.n_free + 255) / 256) + (d.n_edges + 255) / 256 + 2 * (int64_t)((3 * d.n_free + 255) / 256) + 16;
 }
 
 // projected-gradient norm partials on their own (sharded runs: g is only complete after the all-reduce); the same
@@ -519,21 +538,25 @@ void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const
                                    double * delta, double * cand, double * partial, int e_lo, int e_hi, void * stream)
 {
   hipStream_t s = (hipStream_t)stream;
-  const int nbs = (cur.n_free + 255) / 256, nbe = (cur.n_edges + 255) / 256, nbg = (3 * cur.n_free + 255) / 256;
+  const int nbs = (kStepLanes * cur.n_free + 255) / 256, nbe = (cur.n_edges + 255) / 256, nbg = (3 * cur.n_free + 255) / 256;
   double * ps = partial, * pe = ps + 5 * (size_t)nbs, * pg = pe + nbe;
   const bool sharded = e_lo > 0 || e_hi < alt.n_edges;
   hipLaunchKernelGGL(k_step_fused, dim3(nbs), dim3(256), 0, s, cur, scale, rhs, x, step, delta, cand, ps);
   if (alt.n_edges > 0) {
     // sharded: the cost is still evaluated over all edges on every rank (E threads, microseconds)
-    if (sharded) {hipLaunchKernelGGL(k_edge_lin<false>, dim3(nbe), dim3(256), 0, s, alt, cand, 0, alt.n_edges);}
-    hipLaunchKernelGGL(k_edge_lin<true>, dim3(nbe), dim3(256), 0, s, alt, cand, e_lo, e_hi);
-    hipLaunchKernelGGL(k_edge_cost_partials, dim3(nbe), dim3(256), 0, s, alt, pe);
-    hipLaunchKernelGGL(k_gather_H, dim3((alt.n_slots * 9 + 255) / 256), dim3(256), 0, s, alt);
+    if (sharded) {
+      hipLaunchKernelGGL(k_edge_lin<false>, dim3(nbe), dim3(256), 0, s, alt, cand, 0, alt.n_edges, pe);
+      hipLaunchKernelGGL(k_edge_lin<true>, dim3(nbe), dim3(256), 0, s, alt, cand, e_lo, e_hi, (double *)nullptr);
+    } else {
+      hipLaunchKernelGGL(k_edge_lin<true>, dim3(nbe), dim3(256), 0, s, alt, cand, e_lo, e_hi, pe);
+    }
   }
+  const int nbh = alt.n_edges > 0 ? (alt.n_slots * 9 + 255) / 256 : 0;
   if (sharded) {
+    if (nbh > 0) {hipLaunchKernelGGL(k_gather_H, dim3(nbh), dim3(256), 0, s, alt);}
     hipLaunchKernelGGL(k_gather_g, dim3(nbg), dim3(256), 0, s, alt);
   } else {
-    hipLaunchKernelGGL(k_gather_g_norms, dim3(nbg), dim3(256), 0, s, alt, cand, pg);
+    hipLaunchKernelGGL(k_gather_Hg_norms, dim3(nbg + nbh), dim3(256), 0, s, alt, cand, pg, nbg);
   }
 }
 
@@ -541,7 +564,7 @@ void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const
 void spa_launch_step_scalars(const SpaDev & alt, const double * cand, double * partial, bool sharded, double * scal, void * stream)
 {
   hipStream_t s = (hipStream_t)stream;
-  const int nbs = (alt.n_free + 255) / 256, nbe = (alt.n_edges + 255) / 256, nbg = (3 * alt.n_free + 255) / 256;
+  const int nbs = (kStepLanes * alt.n_free + 255) / 256, nbe = (alt.n_edges + 255) / 256, nbg = (3 * alt.n_free + 255) / 256;
   double * ps = partial, * pe = ps + 5 * (size_t)nbs, * pg = pe + nbe;
   if (sharded) {hipLaunchKernelGGL(k_grad_norm_partials, dim3(nbg), dim3(256), 0, s, alt, cand, pg);}
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, ps, nbs, pe, alt.n_edges > 0 ? nbe : 0, pg, nbg, scal);
@@ -1291,16 +1314,19 @@ __device__ __forceinline__ double rsqrt_full(double d)
 
 // T = L^-T of the 4 x 4 block a (a[i][j], j <= i), as v = L^-1 (lower): the factor itself is not formed -- nobody reads the
 // diagonal tile's L (the panel product leaves the rows below it, and every consumer of the pivot block works with L^-T).
-// A pivot that is not positive is reported and replaced by a tiny positive number (the factorisation has failed; the numbers
-// only have to stay harmless).
-__device__ __forceinline__ bool chol4_inverse(double (&m)[4][4], double (&v)[4][4])
+// A pivot that is not positive is reported; its reciprocal square root (NaN or infinite) flows on, the factorisation has failed
+// and every number behind it is flagged by the caller's fail word.  `mid` runs after the second pivot: the place where the
+// caller parks matrix-core work that must not sit between the pivots' dependent operations and their issue slots.
+template <typename Mid>
+__device__ __forceinline__ bool chol4_inverse(double (&m)[4][4], double (&v)[4][4], Mid mid)
 {
   double r[4], l[4][4];
   double dmin = m[0][0];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if (j == 2) {mid();}
     dmin = fmin(dmin, m[j][j]);
-    r[j] = rsqrt_full(fmax(m[j][j], 1e-300));
+    r[j] = rsqrt_full(m[j][j]);
 #pragma unroll
     for (int i = j + 1; i < 4; ++i) {l[i][j] = m[i][j] * r[j];}
 #pragma unroll
@@ -1323,8 +1349,19 @@ __device__ __forceinline__ bool chol4_inverse(double (&m)[4][4], double (&v)[4][
   return dmin > 0.0;
 }
 
-// tile: the diagonal tile in accumulator layout (lower part meaningful, identity on the padding).  Outputs as potrf_diag,
-// except that the lower triangle of blk (L itself) is left alone.  sc: 64 doubles of LDS scratch owned by this wave.
+// tile: the diagonal tile in accumulator layout (lower part meaningful, identity on the padding).  Outputs: the strictly upper
+// part of L^-T over the strictly upper part of blk (row stride LD; the lower triangle of blk, L itself, is left alone), all of
+// L^-T to xd (16 x XDS), the reciprocal pivots (= diagonal of L^-T) to rdv.  sc: 64 doubles of LDS scratch owned by this wave.
+// The identity's two matrix-core operations of block p are issued inside block p + 1 -- the panel product while the next
+// block's gather is on its way through LDS, the update between its second and third pivot -- so that the matrix pipe is free
+// when the tile's own panel and update arrive: those two are the only ones the next pivot waits for.
+#ifdef KH_DIAG_STAMPS
+#define DSTAMP(i, v) do { asm volatile("s_nop 0" : "+v"(v)); long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  asm volatile("s_nop 0" : "+v"(v)); g_dstamp[i] = t_; } while (0)
+__device__ long long g_dstamp[32];
+#else
+#define DSTAMP(i, v) do {} while (0)
+#endif
 __device__ __forceinline__ bool potrf_diag_mfma(v4d tile, double * blk, int LD, int lane, double * xd, double * rdv, double * sc)
 {
   const int lr = lane & 15, lk = lane >> 4;
@@ -1334,17 +1371,33 @@ __device__ __forceinline__ bool potrf_diag_mfma(v4d tile, double * blk, int LD, 
   for (int r = 0; r < 4; ++r) {E[r] = (lk + 4 * r == lr) ? 1.0 : 0.0;}
   bool bad = false;
   const v4d zero = v4d{0.0, 0.0, 0.0, 0.0};
+  double ta_prev = 0.0;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     // gather the diagonal 4 x 4 block: sc[lr + 16 lk] = M[lr][4 p + lk]
+    DSTAMP(5 * p + 0, tile[p]);
     sc[lane] = tile[p];
+    v4d en = zero;
+    if (p > 0) {en = __builtin_amdgcn_mfma_f64_16x16x4f64(ta_prev, E[p - 1], zero, 0, 0, 0);}
     double a[4][4], v[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j <= i; ++j) {a[i][j] = sc[(4 * p + i) + 16 * j];}
     }
-    if (!chol4_inverse(a, v)) {bad = true;}
+    DSTAMP(5 * p + 1, a[3][3]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool ok = chol4_inverse(a, v, [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      if (p > 0) {
+        E[p - 1] = en[p - 1];
+        const v4d eu = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile[p - 1], E[p - 1], E, 0, 0, 0);
+#pragma unroll
+        for (int r = p; r < 4; ++r) {E[r] = eu[r];}
+      }
+    });
+    if (!ok) {bad = true;}
+    DSTAMP(5 * p + 2, v[3][0]);
     // T[k][c] = v[c][k] on lane (lr = 4 p + c, lk = k), zero elsewhere
     double tsel = 0.0;
 #pragma unroll
@@ -1352,21 +1405,22 @@ __device__ __forceinline__ bool potrf_diag_mfma(v4d tile, double * blk, int LD, 
 #pragma unroll
       for (int k = 0; k <= c; ++k) {tsel = (c4 == c && lk == k) ? v[c][k] : tsel;}
     }
-    const double ta = (b4 == p) ? tsel : 0.0;
+    double ta = (b4 == p) ? tsel : 0.0;
+    DSTAMP(5 * p + 3, ta);
     const v4d pn = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, tile[p], zero, 0, 0, 0);
     tile[p] = pn[p];
+    DSTAMP(5 * p + 4, tile[p]);
     if (p < 3) {
       const v4d tu = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile[p], tile[p], tile, 0, 0, 0);
 #pragma unroll
       for (int r = p + 1; r < 4; ++r) {tile[r] = tu[r];}
     }
-    const v4d en = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, E[p], zero, 0, 0, 0);
-    E[p] = en[p];
-    if (p < 3) {
-      const v4d eu = __builtin_amdgcn_mfma_f64_16x16x4f64(-tile[p], E[p], E, 0, 0, 0);
-#pragma unroll
-      for (int r = p + 1; r < 4; ++r) {E[r] = eu[r];}
-    }
+    ta_prev = ta;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    const v4d en = __builtin_amdgcn_mfma_f64_16x16x4f64(ta_prev, E[3], zero, 0, 0, 0);
+    E[3] = en[3];
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1379,7 +1433,7 @@ __device__ __forceinline__ bool potrf_diag_mfma(v4d tile, double * blk, int LD, 
 }
 
 // row "solve" of one 16-row tile: T <- T Dinv^T  (Dinv^T = L_jj^-T in xd), in place, one wave
-__device__ __forceinline__ void potrf_rowsolve_tile(double * tile, int LD, const double * xd, int lane)
+__device__ __forceinline__ v4d potrf_rowsolve_tile(double * tile, int LD, const double * xd, int lane)
 {
   const int lr = lane & 15, lk = lane >> 4;
   const double * tb = tile + lr * LD + 4 * lk;         // b: T[lr][k]
@@ -1393,9 +1447,17 @@ __device__ __forceinline__ void potrf_rowsolve_tile(double * tile, int LD, const
   double * cp = tile + lr * LD + lk;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
+  return acc;
 }
 
-#define PSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {tbuf[64 + tcount] = clock64(); tbuf[1 + tcount++] = wall_clock64();} } while (0)
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter, and k_potrf's waves
+// keep the NEXT step's tile loads in flight across a step -- with the full barrier every step ended by sitting out a memory
+// latency (1-2 us of a 3 us step)
+__device__ __forceinline__ void lds_barrier() {asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");}
+
+// KH_SPA_TIMING: shader-clock stamps of workgroup 0's thread 0, kept in LDS (behind the kernel's own dynamic LDS) and written out by
+// the kernel's last statement -- stamps stored straight to host memory put a PCIe round trip into the next vector-memory wait
+#define PSTAMP() do { if (tbuf && blockIdx.x == 0 && threadIdx.x == 0 && tcount < 60) {stamps[tcount++] = clock64();} } while (0)
 
 // ---- children's update matrices, read in place (no extend-add pass) ----
 // child number s of a front: the first three sit in the front's own descriptor, further ones (rare: a separator above
@@ -1504,20 +1566,27 @@ __device__ __forceinline__ void ll_accumulate(v4d & acc, const double * X, int L
   }
 }
 
-// Pivot block of every front of a level, LEFT-LOOKING, 256 threads (= 4 waves) per front.  Step jb (16 columns):
+// Pivot block of every front of a level, LEFT-LOOKING, 512 threads (= 8 waves) per front.  Step jb (16 columns):
 //   U  the tiles of column block jb get their final values: initial value (regular tiles: the front's entries + the
-//      children's, read straight into MFMA accumulators one step ahead; identity rows: zero) minus the products with every
-//      earlier column block.  Wave 0 takes the diagonal tile and runs its pivot chain (with L_jj^-T riding along) while waves
-//      1-3 do the rest, write block jb - 1 of W = L11^-T to memory and give the identity rows of block jb - 1 their first
-//      term (the one that needs L_(jb-1)(jb-1)^-T, which only lives for one step).
-//   R  row solves: every tile of the column times L_jj^-T (MFMA).
-// LDS holds only SOLVED tiles: L11 in the lower triangle, L11^-T strictly above it.  Nothing is staged in a prologue and
-// nothing but the last block of W is left for the epilogue.
-template <bool kMfmaDiag>
-__global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
-                                               long long * tbuf)
+//      children's, requested one step ahead; identity rows: zero) minus the products with every earlier column block.
+//      Wave 0 owns the DIAGONAL tile and its pivot chain (potrf_diag_mfma, with L_jj^-T riding along): the critical path of
+//      the kernel.  Everything else belongs to the seven helper waves, dealt out task by task: the regular tiles (I, jb), the
+//      identity-row tiles, block jb - 1 of W = L11^-T on its way to memory, the first term of the identity rows of block jb - 1
+//      (the one that needs L_(jb-1)(jb-1)^-T, which only lives for one step) -- and the LOOK-AHEAD: the products of the NEXT
+//      diagonal tile with the column blocks before jb, so that wave 0 opens step jb + 1 with one product instead of jb + 1.
+//   R  row solves: every tile of the column times L_jj^-T (MFMA), one tile per wave.
+// LDS holds only SOLVED tiles: L11 in the lower triangle, L11^-T strictly above it.
+// Round 6: with four waves (round 3) every wave ran its tiles' products one after the other, each a chain of dependent
+// v_mfma_f64_16x16x4 (81 clocks apiece, measured): on a 126-pivot front the three helper waves took 5-6 us per step, three
+// times the pivot chain they were meant to hide behind (the kernel ran as long WITHOUT the chain).  The barriers of a step
+// order LDS traffic only (lds_barrier): the next step's tile requests and the stores of W stay in flight across them.
+constexpr int kPotrfThreads = 512, kPotrfHelpers = kPotrfThreads / 64 - 1;
+__global__ __launch_bounds__(kPotrfThreads) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
+                                                         long long * tbuf, int stamp_off)
 {
   int tcount = 0;
+  extern __shared__ double smem[];
+  long long * stamps = reinterpret_cast<long long *>(smem) + stamp_off;
   PSTAMP();
   const FrontDesc fd = d.desc[first_front + blockIdx.x];
   const int m = fd.m, ns = fd.ns;
@@ -1527,7 +1596,6 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  extern __shared__ double smem[];
   double * X = smem;                                               // [nsp][LD]: lower = L11, strictly upper = L11^-T
   double * rd = smem + (size_t)lds_nsp * (lds_nsp + 2);            // [lds_nsp] reciprocal diagonal of L11 = diagonal of L11^-T
   double * yv = rd + lds_nsp;                                      // [lds_nsp] y1
@@ -1539,95 +1607,101 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
   const int nchild = fd.child_end - fd.child_ptr;
   const int nkids = front_nkids(d, fd);               // children whose update matrices are read in place
   const int mp = m / 3;
-  // first column block's tiles: wave 0 the diagonal tile, waves 1..3 the tiles below it (round robin, up to three each)
-  constexpr int SL = 3;
-  TileRaw cur[SL];
+  const int h = wave - 1;                             // helper number
   const double * Bf = front_b(d, fd);
-  auto prefetch = [&](int jb) {
+  const bool clean = d.scatter != 0;
+  // Tiles requested from memory one step before they are used.  Helper h opens step jb with the regular tile (jb + 1 + h, jb)
+  // (nt <= 8: a column block has at most seven tiles below the diagonal); the helper that will run the look-ahead of step jb
+  // holds the diagonal tile (jb + 1, jb + 1); wave 0 loads the first diagonal tile and nothing after it.
+  TileRaw cur, curd;
+  auto look_helper = [&](int jb) {return (nt - jb - 1) % kPotrfHelpers;};
+  auto prefetch = [&](int jb) {                        // for step jb
     if (jb >= nt) {return;}
     if (wave == 0) {
-      cur[0] = pivot_tile_load(fd, F, Bf, d.scatter != 0, NB * jb, NB * jb, lane);
-    } else {
-#pragma unroll
-      for (int q = 0; q < SL; ++q) {
-        const int I = jb + 1 + (wave - 1) + 3 * q;
-        if (I < nt) {cur[q] = pivot_tile_load(fd, F, Bf, d.scatter != 0, NB * I, NB * jb, lane);}
-      }
+      if (jb == 0) {cur = pivot_tile_load(fd, F, Bf, clean, 0, 0, lane);}
+      return;
     }
+    const int I = jb + 1 + h;
+    if (I < nt) {cur = pivot_tile_load(fd, F, Bf, clean, NB * I, NB * jb, lane);}
+    if (jb + 1 < nt && look_helper(jb) == h) {curd = pivot_tile_load(fd, F, Bf, clean, NB * (jb + 1), NB * (jb + 1), lane);}
   };
   prefetch(0);
-  // right-hand side: the pivots' entries + the children's forward-solve contributions (gathered through the same maps)
+  // right-hand side: the pivots' entries + the children's forward-solve contributions (gathered through the same maps).  A
+  // chain of two dependent loads per entry that nobody needs before the epilogue: the maps are requested here, the
+  // contributions after the first step, the sums are formed behind the last one (entries beyond the first 512, and children
+  // beyond the third, take the loop there).
   const int first = 3 * fd.first;
-  for (int t = tid; t < m; t += nthreads) {
-    double v = t < ns ? rhs[first + t] : 0.0;
-    const int tn = t / 3;
-    for (int s = 0; s < nchild; ++s) {
-      const ChildInfo c = child_info(d, fd, s);
-      const int a = d.cinv[fd.cinv_ptr + s * mp + tn];
-      const double u = upd[3 * (int64_t)c.rows_ptr + (a >= 0 ? 3 * a + (t - 3 * tn) : 0)];
-      v += a >= 0 ? u : 0.0;
-    }
-    sb[t] = v;
+  const int tn = tid / 3;
+  double rv = 0.0;
+  int ca[3] = {-1, -1, -1};
+  double cu[3] = {0.0, 0.0, 0.0};
+  if (tid < m) {
+    if (tid < ns) {rv = rhs[first + tid];}
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {if (s < nchild) {ca[s] = d.cinv[fd.cinv_ptr + s * mp + tn];}}
   }
   PSTAMP();
+  v4d res = v4d{0.0, 0.0, 0.0, 0.0};      // wave 0: the solved tile (jb, jb - 1), kept in registers from the row solves of step jb - 1
   for (int jb = 0; jb < nt; ++jb) {
     const int c0 = jb * NB;
     double * xd = Xd + (jb & 1) * NB * XDS;
     const double * xp = Xd + ((jb + 1) & 1) * NB * XDS;            // L^-T of the previous diagonal block
     if (wave == 0) {
-      v4d acc = pivot_tile_finish(cur[0], d, fd, nkids, c0, c0, lane);
-      prefetch(jb + 1);
-      ll_accumulate(acc, X, LD, c0, c0, 0, jb, lane);
-      if (kMfmaDiag) {
-        if (potrf_diag_mfma(acc, X + c0 * LD + c0, LD, lane, xd, rd + c0, sc)) {s_fail = 1;}
+      // the diagonal tile: everything but the last product was left in the tile's own place by the look-ahead of step jb - 1;
+      // the last product's operand is `res` -- register r of the accumulator layout is column block r of the tile, which is what
+      // a lane supplies to the matrix core for k = lk + 4 r
+      v4d acc;
+      if (jb == 0) {
+        acc = pivot_tile_finish(cur, d, fd, nkids, 0, 0, lane);
       } else {
-        double * cp = X + (c0 + lr) * LD + c0 + lk;
+        const double * sp = X + (c0 + lr) * LD + c0 + lk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {if (lk + 4 * r <= lr) {cp[4 * r] = acc[r];}}
-        if (potrf_diag(X + c0 * LD + c0, LD, lane, xd, rd + c0)) {s_fail = 1;}
+        for (int r = 0; r < 4; ++r) {acc[r] = sp[4 * r];}
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-res[kk], res[kk], acc, 0, 0, 0);}
       }
+      if (potrf_diag_mfma(acc, X + c0 * LD + c0, LD, lane, xd, rd + c0, sc)) {s_fail = 1;}
     } else {
-      v4d mine[SL];
+      // regular tile (I, jb), I = jb + 1 + h
+      {
+        const int I = jb + 1 + h;
+        if (I < nt) {
+          v4d acc = pivot_tile_finish(cur, d, fd, nkids, NB * I, c0, lane);
+          ll_accumulate(acc, X, LD, c0, NB * I, 0, jb, lane);
+          double * cp = X + (NB * I + lr) * LD + c0 + lk;
 #pragma unroll
-      for (int q = 0; q < SL; ++q) {
-        const int I = jb + 1 + (wave - 1) + 3 * q;
-        mine[q] = I < nt ? pivot_tile_finish(cur[q], d, fd, nkids, NB * I, c0, lane) : cur[q].a;
+          for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
+        }
       }
-      prefetch(jb + 1);
-      // regular tiles (I, jb), I > jb
-#pragma unroll
-      for (int q = 0; q < SL; ++q) {
-        const int I = jb + 1 + (wave - 1) + 3 * q;
-        if (I >= nt) {break;}
-        v4d acc = mine[q];
-        ll_accumulate(acc, X, LD, c0, NB * I, 0, jb, lane);
-        double * cp = X + (NB * I + lr) * LD + c0 + lk;
+      // the other tasks of the step, dealt round robin starting behind the helpers that hold a regular tile
+      int slot = look_helper(jb);
+      auto mine = [&]() {const bool take = slot == h; slot = slot + 1 == kPotrfHelpers ? 0 : slot + 1; return take;};
+      // look-ahead: the next diagonal tile's initial value - sum_{p < jb} L[jb+1][p] L[jb+1][p]^T, parked in the tile's own place
+      if (jb + 1 < nt && mine()) {
+        v4d acc = pivot_tile_finish(curd, d, fd, nkids, c0 + NB, c0 + NB, lane);
+        ll_accumulate(acc, X, LD, c0 + NB, c0 + NB, 0, jb, lane);
+        double * cp = X + (c0 + NB + lr) * LD + c0 + NB + lk;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
       }
-      // identity rows (I, jb), I < jb: their value so far (block I's own term, written one step after block I) minus the
-      // products with the column blocks I + 1 .. jb - 1; block jb - 1 starts here, with its own term
-      for (int I = wave - 1; I < jb; I += 3) {
+      prefetch(jb + 1);
+      // identity rows (I, jb), I < jb - 1: their value so far (block I's own term, written one step after block I) minus the
+      // products with the column blocks I + 1 .. jb - 1 (longest first)
+      for (int I = 0; I < jb - 1; ++I) {
+        if (!mine()) {continue;}
         double * cp = X + (NB * I + lr) * LD + c0 + lk;
         v4d acc;
-        if (I == jb - 1) {
-          acc = v4d{0.0, 0.0, 0.0, 0.0};
-          const double * xa = X + (c0 + lr) * LD + NB * I + 4 * lk;
-          const double * xb = xp + lr * XDS + 4 * lk;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb[kk], acc, 0, 0, 0);}
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {acc[r] = cp[4 * r];}
-          ll_accumulate(acc, X, LD, c0, NB * I, I + 1, jb, lane);
-        }
+        for (int r = 0; r < 4; ++r) {acc[r] = cp[4 * r];}
+        ll_accumulate(acc, X, LD, c0, NB * I, I + 1, jb, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
       }
       if (jb > 0) {
         const int I = jb - 1;
-        // block I's own term for the later column blocks J > jb:  E[I][J] = -L_II^-T L[J][I]^T
-        for (int J = jb + 1 + (wave - 1); J < nt; J += 3) {
+        // block I's own term for this and the later column blocks J >= jb:  E[I][J] = -L_II^-T L[J][I]^T
+        for (int J = jb; J < nt; ++J) {
+          if (!mine()) {continue;}
           v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
           const double * xa = X + (NB * J + lr) * LD + NB * I + 4 * lk;
           const double * xb = xp + lr * XDS + 4 * lk;
@@ -1638,7 +1712,8 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
           for (int r = 0; r < 4; ++r) {cp[4 * r] = acc[r];}
         }
         // column block I of W is final: tiles (q <= I, I); W[(16 I + j) + (16 q + i) * nsp] = (L^-T)[16 q + i][16 I + j]
-        for (int q = wave - 1; q <= I; q += 3) {
+        for (int q = 0; q <= I; ++q) {
+          if (!mine()) {continue;}
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int idx = lane + 64 * e, i = idx >> 4, j = idx & 15;
@@ -1647,22 +1722,31 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
         }
       }
     }
-    __syncthreads();                     // the tiles of column block jb and L_jj^-T are in place
+    lds_barrier();                       // the tiles of column block jb and L_jj^-T are in place
     PSTAMP();
-    // row solves, one 16-row tile per wave: rows below the block (L11 part) and the identity rows above it; the block's
-    // own identity rows ARE xd
-    for (int t = wave; t < nt - 1; t += 4) {
-      const int bi = t < jb ? t : t + 1;
-      potrf_rowsolve_tile(X + NB * bi * LD + c0, LD, xd, lane);
+    if (jb == 0 && tid < m) {
+      // second hop of the right-hand side's gather (the maps have long arrived)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (ca[s] >= 0) {cu[s] = upd[3 * (int64_t)fd.ch[s].rows_ptr + 3 * ca[s] + (tid - 3 * tn)];}
+      }
     }
-    __syncthreads();
+    // row solves, one 16-row tile per wave: rows below the block (L11 part) and the identity rows above it (the block's own
+    // identity rows ARE xd).  Wave 0 takes the tile under the diagonal and keeps the result: its next diagonal tile needs it.
+    if (wave == 0) {
+      if (jb + 1 < nt) {res = potrf_rowsolve_tile(X + NB * (jb + 1) * LD + c0, LD, xd, lane);}
+    } else {
+      const int bi = h < jb ? h : h + 2;
+      if (bi < nt) {(void)potrf_rowsolve_tile(X + NB * bi * LD + c0, LD, xd, lane);}
+    }
+    lds_barrier();
     PSTAMP();
   }
   // last column block of W
   {
     const int I = nt - 1;
     const double * xl = Xd + (I & 1) * NB * XDS;
-    for (int q = wave; q <= I; q += 4) {
+    for (int q = wave; q <= I; q += kPotrfThreads / 64) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int idx = lane + 64 * e, i = idx >> 4, j = idx & 15;
@@ -1670,18 +1754,43 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
       }
     }
   }
-  // y1 = L11^-1 b1 = W^T b1: two threads per entry, each with half of the sum
+  // the right-hand side slice: the sums of the staged gather, then whatever it did not cover
+  for (int t = tid; t < m; t += nthreads) {
+    double v;
+    int s0;
+    if (t == tid) {
+      v = (rv + cu[0]) + cu[1];
+      v += cu[2];
+      s0 = 3;
+      if (nchild < 3) {v = rv; for (int s = 0; s < nchild; ++s) {v += cu[s];}}
+    } else {
+      v = t < ns ? rhs[first + t] : 0.0;
+      s0 = 0;
+    }
+    const int tq = t / 3;
+    for (int s = s0; s < nchild; ++s) {
+      const ChildInfo c = child_info(d, fd, s);
+      const int a = d.cinv[fd.cinv_ptr + s * mp + tq];
+      const double u = upd[3 * (int64_t)c.rows_ptr + (a >= 0 ? 3 * a + (t - 3 * tq) : 0)];
+      v += a >= 0 ? u : 0.0;
+    }
+    sb[t] = v;
+  }
+  __syncthreads();
+  // y1 = L11^-1 b1 = W^T b1: four threads per entry, each with a quarter of the sum
   {
-    const int j = tid >> 1, half = tid & 1;
+    const int j = tid >> 2, part = tid & 3;
     double acc = 0.0;
     if (j < ns) {
-      const int q0 = half ? (j + 1) >> 1 : 0, q1 = half ? j : (j + 1) >> 1;
+      // rows q < j of column j, split in four runs of equal length; the last run also takes the diagonal term
+      const int q0 = (j * part) >> 2, q1 = (j * (part + 1)) >> 2;
 #pragma unroll 8
       for (int q = q0; q < q1; ++q) {acc += X[q * LD + j] * sb[q];}
-      if (half) {acc += rd[j] * sb[j];}
+      if (part == 3) {acc += rd[j] * sb[j];}
     }
     acc += __shfl_xor(acc, 1);
-    if (j < ns && !half) {yv[j] = acc;}
+    acc += __shfl_xor(acc, 2);
+    if (j < ns && part == 0) {yv[j] = acc;}
   }
   __syncthreads();
   for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = yv[t];}
@@ -1690,7 +1799,10 @@ __global__ __launch_bounds__(256) void k_potrf(SpaDev d, int first_front, int32_
     for (int q = tid; q < m - ns; q += nthreads) {uk[q] = sb[ns + q];}
   }
   PSTAMP();
-  if (tbuf && blockIdx.x == 0 && threadIdx.x == 0) {tbuf[0] = tcount; tbuf[63] = ((long long)m << 32) | ns;}
+  if (tbuf && blockIdx.x == 0 && threadIdx.x == 0) {
+    tbuf[0] = tcount; tbuf[63] = ((long long)m << 32) | ns;
+    for (int i = 0; i < tcount; ++i) {tbuf[1 + i] = stamps[i];}
+  }
   if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
 }
 
@@ -2060,9 +2172,8 @@ static void pipeline_attributes()
 {
   // (per device: the attribute is kept per device, and solvers of several devices may live in one process)
   const int big = 160 * 1024 - 256;       // static LDS (a flag word) counts against the same 160 KB
-  static std::atomic<unsigned long long> done[6] = {{0}, {0}, {0}, {0}, {0}, {0}};
-  allow_dynamic_lds(reinterpret_cast<const void *>(k_potrf<true>), big, done[0]);
-  allow_dynamic_lds(reinterpret_cast<const void *>(k_potrf<false>), big, done[5]);
+  static std::atomic<unsigned long long> done[5] = {{0}, {0}, {0}, {0}, {0}};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_potrf), big, done[0]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_trsm<32>), big, done[1]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_trsm<64>), big, done[2]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_syrk<32>), big, done[3]);
@@ -2079,22 +2190,13 @@ void spa_launch_potrf_level(const SpaDev & d, int32_t first_front, int32_t n, in
   static long long * tbuf = nullptr;
   static const bool timing = std::getenv("KH_SPA_TIMING") != nullptr;
   if (timing && !tbuf) {(void)hipHostMalloc(reinterpret_cast<void **>(&tbuf), 128 * sizeof(long long), hipHostMallocDefault);}
-  static const bool chain_diag = std::getenv("KH_SPA_DIAG_CHAIN") != nullptr;      // the round-3 pivot chain (A/B measurements)
-  if (chain_diag) {
-    hipLaunchKernelGGL(k_potrf<false>, dim3(n), dim3(256), potrf_lds_bytes(nsp, max_m), s, d, first_front, fail_flag, rhs, upd, nsp,
-                       timing ? tbuf : (long long *)nullptr);
-  } else {
-    hipLaunchKernelGGL(k_potrf<true>, dim3(n), dim3(256), potrf_lds_bytes(nsp, max_m), s, d, first_front, fail_flag, rhs, upd, nsp,
-                       timing ? tbuf : (long long *)nullptr);
-  }
+  const size_t lds = potrf_lds_bytes(nsp, max_m);
+  hipLaunchKernelGGL(k_potrf, dim3(n), dim3(kPotrfThreads), lds + (timing ? 512 : 0), s, d, first_front, fail_flag, rhs, upd, nsp,
+                     timing ? tbuf : (long long *)nullptr, (int)(lds / 8));
   if (timing) {
     (void)hipStreamSynchronize(s);
-    std::fprintf(stderr, "[k_potrf] n=%d front0 m=%lld ns=%lld stamps(x10ns):", n, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
+    std::fprintf(stderr, "[k_potrf] n=%d front0 m=%lld ns=%lld stamps (shader clocks):", n, tbuf[63] >> 32, tbuf[63] & 0xffffffff);
     for (int i = 1; i < (int)tbuf[0]; ++i) {std::fprintf(stderr, " %lld", tbuf[1 + i] - tbuf[i]);}
-    const int last = (int)tbuf[0] - 1;
-    if (last > 0) {
-      std::fprintf(stderr, "  | shader clock %.0f MHz", (double)(tbuf[64 + last] - tbuf[64]) / (double)(tbuf[1 + last] - tbuf[1]) * 100.0);
-    }
     std::fprintf(stderr, "\n");
   }
 }

@@ -80,11 +80,12 @@ class HipSpaSolver:
         capi.check(rc, "kh_spa_remove_constraint")
 
     def set_debug(self, check_linear_solves: bool = False, factor_kernels: int = 0, gather_children: bool = False,
-                  extend_add_pass: bool = False):
+                  extend_add_pass: bool = False, phase_timing: bool = False):
         """kh_spa_set_debug: residual check of every linear solve; numeric kernels 0 default, 3 level pipeline, 2 panel pairs;
         level pipeline reading ALL the children's update matrices in place / summing them in with an extend-add launch per level
-        (default: k_syrk adds a front's update matrix straight into its parent)"""
-        flags = (1 if check_linear_solves else 0) | (int(factor_kernels) << 4) | (256 if gather_children else 0) | (512 if extend_add_pass else 0)
+        (default: k_syrk adds a front's update matrix straight into its parent); HIP events around the phases of an iteration
+        (the *_gpu_ms fields of the summary)"""
+        flags = (1 if check_linear_solves else 0) | (int(factor_kernels) << 4) | (256 if gather_children else 0) | (512 if extend_add_pass else 0) | (2 if phase_timing else 0)
         capi.check(capi.lib().kh_spa_set_debug(self._h, flags), "kh_spa_set_debug")
 
     def Compute(self):

@@ -2,6 +2,9 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/diag_probe.hip -o /tmp/diag_probe && /tmp/diag_probe
 // prints clocks per call of the round-3 pivot chain (potrf_diag) and of the matrix-core form (potrf_diag_mfma), and the
 // error of both against a host Cholesky.
+#ifdef STAMPS
+#define KH_DIAG_STAMPS
+#endif
 #include "../slam_toolbox_amd/csrc/spa_kernels.hip"
 #include <cmath>
 #include <vector>
@@ -82,6 +85,15 @@ int main()
                   (double)clk[0] / reps, clk[1], eL, eX, eR);
     }
   }
+#ifdef STAMPS
+  {
+    long long st[32];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(kh::g_dstamp), sizeof(st));
+    std::printf("segments per block (gather, chol4, select, panel mfma, update mfma -> next):");
+    for (int i = 1; i < 20; ++i) {std::printf(" %lld%s", st[i] - st[i - 1], i % 5 == 0 ? " |" : "");}
+    std::printf("\n");
+  }
+#endif
   hipLaunchKernelGGL(k_rsq_error, dim3(1), dim3(64), 0, 0, dout);
   std::vector<double> e(128); hipMemcpy(e.data(), dout, 128 * 8, hipMemcpyDeviceToHost);
   double hw = 0, full = 0; for (int i = 0; i < 64; ++i) {hw = std::max(hw, e[i]); full = std::max(full, e[64 + i]);}

@@ -7,6 +7,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 e = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
 g = synth.make_pose_graph(n, e, seed=12345)
 sol = HipSpaSolver()
+if "--phases" in sys.argv:
+    sol.set_debug(phase_timing=True)
 for rep in range(3):
     t = time.time(); sol.load(g["init"], g["edges"], g["z"], g["cov"]); tl = time.time() - t
     t = time.time(); summ = sol.Compute(); tc = time.time() - t
