@@ -14,6 +14,7 @@
 // the elimination tree is processed level by level.
 #include <hip/hip_runtime.h>
 
+#include <immintrin.h>
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -144,6 +145,8 @@ struct kh_spa
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
   double * h_scal = nullptr; int32_t * h_fail = nullptr;
+  // host-coherent block the last kernel of an iteration writes its scalars to, and the flag it raises behind them
+  double * h_res = nullptr; int32_t * h_res_flag = nullptr; int32_t res_seq = 0;
   // trace of the last Compute(): one row per LM iteration, see kh_spa_iteration_log
   std::vector<std::array<double, 8>> iter_log;
   int32_t n_slots = 0;
@@ -679,6 +682,14 @@ int kh_spa_create(int32_t device, kh_spa ** out)
   for (auto & e : s->ev_level) {KS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));}
   KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_scal), sizeof(double) * 32, hipHostMallocDefault));
   KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_fail), sizeof(int32_t) * 4, hipHostMallocDefault));
+  // (a platform without host-coherent mappings keeps the copies + stream drain)
+  if (hipHostMalloc(reinterpret_cast<void **>(&s->h_res), sizeof(double) * 16 + 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    s->h_res_flag = reinterpret_cast<int32_t *>(s->h_res + 16);
+    s->h_res_flag[0] = 0;
+  } else {
+    (void)hipGetLastError();
+    s->h_res = nullptr;
+  }
   for (auto & row : s->ev_phase) {for (auto & e : row) {KS_HIP(hipEventCreate(&e));}}
   for (auto & row : s->ev_lin) {for (auto & e : row) {KS_HIP(hipEventCreate(&e));}}
   *out = s;
@@ -703,6 +714,7 @@ void kh_spa_destroy(kh_spa * s)
   for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   for (auto & row : s->ev_lin) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
   if (s->h_scal) {(void)hipHostFree(s->h_scal);}
+  if (s->h_res) {(void)hipHostFree(s->h_res);}
   if (s->h_upload) {(void)hipHostFree(s->h_upload);}
   if (s->h_fail) {(void)hipHostFree(s->h_fail);}
   if (s->stream2) {(void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2);}
@@ -1321,17 +1333,14 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
 
     // ---- ComputeTrustRegionStep ----
     auto t1 = now();
-    if (!reuse_diagonal || !have_diagonal) {
-      spa_launch_diag(dev, s->d_scale.p, s->d_diag.p, opt.min_lm_diagonal, opt.max_lm_diagonal, st);
-      have_diagonal = true;
-    }
+    const bool new_diagonal = !reuse_diagonal || !have_diagonal;
+    have_diagonal = true;
     const bool timed = phase_events && n_timed < kh_spa::kMaxTimed;
     if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][0], st));}
     rc = zero_fronts(); if (rc) {return finish(rc);}
-    spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, st);
-    // factorisation and forward solve are one kernel per level (the forward step of a panel runs while its
-    // L11 / L21 are still in LDS), so the right-hand side has to be in place first (the kernel also clears the fail flag)
-    spa_launch_make_rhs(dev, s->d_scale.p, s->d_rhs.p, s->d_fail.p, st);
+    // one launch: the scaled + damped matrix into the fronts (forming the LM diagonal on the way when a new one is due), the
+    // right-hand side in elimination order (factorisation and forward solve are one kernel per level) and the fail word's reset
+    spa_launch_assemble(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, new_diagonal, opt.min_lm_diagonal, opt.max_lm_diagonal, s->d_rhs.p, s->d_fail.p, st);
     if (!pipeline) {KS_HIP(hipMemsetAsync(s->d_sync.p, 0, sizeof(int32_t) * 4 * static_cast<size_t>(sym.n_fronts), st));}
     static const int ea_limit = std::getenv("KH_SPA_EXTEND_ADD") ? std::atoi(std::getenv("KH_SPA_EXTEND_ADD")) : 128;
     for (int l = 0; l < n_levels; ++l) {
@@ -1383,6 +1392,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
     static const bool speculate = !(std::getenv("KH_SPA_SPECULATE") && std::atoi(std::getenv("KH_SPA_SPECULATE")) == 0);
     static const bool lin_check_env = std::getenv("KH_SPA_CHECK") != nullptr;
     const bool lin_check = lin_check_env || (s->debug_flags & 1);
+    bool direct = false;
     const bool fused_step = speculate && !(std::getenv("KH_SPA_FUSED_STEP") && std::atoi(std::getenv("KH_SPA_FUSED_STEP")) == 0);
     if (fused_step) {
       // the candidate's cost AND its normal equations (speculative: a step is nearly always accepted) ride in the same batch
@@ -1392,7 +1402,10 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       if (timed_lin) {KS_HIP(hipEventRecord(s->ev_lin[n_lin][1], st)); ++n_lin;}
       // a communicator (or a sharding callback) sums this rank's H || g with the others', also with one rank (identity)
       rc = allreduce_Hg(alt); if (rc) {return finish(rc);}
-      spa_launch_step_scalars(alt, cand, s->d_partial.p, e_lo > 0 || e_hi < dev.n_edges, scal, st);
+      direct = s->h_res != nullptr && !lin_check;
+      if (direct) {s->res_seq = s->res_seq == 0x7fffffff ? 1 : s->res_seq + 1;}
+      spa_launch_step_scalars(alt, cand, s->d_partial.p, e_lo > 0 || e_hi < dev.n_edges, scal, st, direct ? s->h_res : nullptr, s->h_res_flag, s->d_fail.p,
+                              s->res_seq);
       if (lin_check) {spa_launch_lin_check(dev, s->d_scale.p, s->d_diag.p, 1.0 / radius, s->d_step.p, scal + 12, st);}
       if (timed) {KS_HIP(hipEventRecord(s->ev_phase[n_timed][2], st)); ++n_timed;}
     } else {
@@ -1409,7 +1422,27 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
       }
     }
     KS_HIP(hipGetLastError());
-    rc = fetch(); if (rc) {return finish(rc);}
+    if (direct) {
+      // the iteration's last kernel writes its scalars to host-coherent memory and raises the flag behind them; the stream is asked
+      // now and then so that a failed launch cannot hang the caller
+      volatile int32_t * flag = s->h_res_flag;
+      uint64_t spins = 0;
+      while (*flag != s->res_seq) {
+        _mm_pause();
+        if ((++spins & 0x3fff) == 0) {
+          const hipError_t e = hipStreamQuery(st);
+          if (e == hipSuccess) {
+            if (*flag == s->res_seq) {break;}
+            set_error("kh_spa: the stream drained without the iteration's result flag"); return finish(KH_ERR_HIP);
+          }
+          if (e != hipErrorNotReady) {set_error(std::string("kh_spa: ") + hipGetErrorString(e)); return finish(KH_ERR_HIP);}
+        }
+      }
+      for (int q = 3; q <= 10; ++q) {s->h_scal[q] = s->h_res[q];}
+      s->h_fail[0] = static_cast<int32_t>(s->h_res[11]);
+    } else {
+      rc = fetch(); if (rc) {return finish(rc);}
+    }
     solve_ms += ms_since(t1);
     if (lin_check) {
       std::fprintf(stderr, "[kh_spa] iteration %d: relative residual of the linear solve %.3e (fail flag %d)\n", iteration,

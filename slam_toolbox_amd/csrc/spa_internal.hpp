@@ -95,9 +95,11 @@ struct SpaDev
 // [e_lo, e_hi): edge block linearised by this rank (0, n_edges on a single GPU)
 void spa_launch_linearize(const SpaDev & d, const double * x, double * cost_out, int e_lo, int e_hi, void * stream);
 void spa_launch_cost(const SpaDev & d, const double * x, double * cost_out, void * stream);
-void spa_launch_diag(const SpaDev & d, const double * scale, double * diag_out, double min_diag, double max_diag, void * stream);
 void spa_launch_jacobi_scale(const SpaDev & d, double * scale_out, void * stream);
-void spa_launch_assemble(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, void * stream);
+// the head of a factorisation: scaled + damped H into the fronts; with compute_diag the LM diagonal clamp(diag(S H S)) is formed
+// (and left in `diagonal`) on the way; rhs (elimination order) <- scale * g; *fail_flag <- 0
+void spa_launch_assemble(const SpaDev & d, const double * scale, double * diagonal, double inv_radius, bool compute_diag, double min_diag, double max_diag,
+                         double * rhs, int32_t * fail_flag, void * stream);
 // max_m = largest front dimension of the level (sizes the LDS panel / vector)
 // also does the forward solve of the level: rhs (elimination order) in, y out; upd as for the backward level
 // sync: 4 ints per front of the level (zeroed before every factorisation): hand-offs between the workgroups sharing a front
@@ -125,8 +127,7 @@ void spa_launch_zero_update_blocks(const SpaDev & d, const int32_t * list, int32
 void spa_launch_count_nonzero(const double * p, int64_t n, int32_t * count, void * stream);
 // whether the largest front of a problem fits the LDS budgets of the level pipeline (otherwise: panel-pair kernels)
 bool spa_level_pipeline_fits(int32_t max_m, int32_t max_ns);
-// rhs (elimination order) <- scale * g, *fail_flag <- 0 ; and back: step = -y (free order), delta = step * scale
-void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, int32_t * fail_flag, void * stream);
+// step = -y (free order), delta = step * scale
 void spa_launch_finish_step(const SpaDev & d, const double * scale, const double * rhs, double * step, double * delta, void * stream);
 // out[0] = step.gs, out[1] = step^T Hs step, out[2] = any non-finite in step
 void spa_launch_model(const SpaDev & d, const double * scale, const double * step, double * out3, void * stream);
@@ -137,7 +138,10 @@ void spa_launch_model(const SpaDev & d, const double * scale, const double * ste
 int64_t spa_step_partials_size(const SpaDev & d);
 void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const double * scale, const double * rhs, const double * x, double * step,
                                    double * delta, double * cand, double * partial, int e_lo, int e_hi, void * stream);
-void spa_launch_step_scalars(const SpaDev & alt, const double * cand, double * partial, bool sharded, double * scal, void * stream);
+// h_out (host-coherent, 16 doubles; nullptr: none): scal[3..10] and the fail word (h_out[11]) also go there, followed by the
+// system-scope store h_flag <- seq
+void spa_launch_step_scalars(const SpaDev & alt, const double * cand, double * partial, bool sharded, double * scal, void * stream,
+                             double * h_out = nullptr, int32_t * h_flag = nullptr, const int32_t * fail_flag = nullptr, int32_t seq = 0);
 // debugging aid (KH_SPA_CHECK): out[0] = |(Hs + D / radius) step + gs|^2, out[1] = |gs|^2 from the BSR matrix
 void spa_launch_lin_check(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, const double * step, double * out2,
                           void * stream);

@@ -214,24 +214,22 @@ void spa_launch_jacobi_scale(const SpaDev & d, double * scale_out, void * stream
   hipLaunchKernelGGL(k_jacobi_scale, dim3((d.n_free * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, scale_out);
 }
 
-__global__ void k_diag(SpaDev d, const double * scale, double * diag, double lo, double hi)
+// The head of a factorisation in ONE launch (round 6; three launches before): the scaled + damped H into the fronts, the LM
+// diagonal itself where a new one is due (compute_diag: clamp(diag(S H S)) to [lo, hi], levenberg_marquardt_strategy.cc -- the entry
+// that needs it is the entry that computes it, and it is kept in `diagonal` for the iterations that reuse it), and behind the blocks
+// of the matrix the right-hand side rhs (elimination order) <- scale * g and the fail word <- 0.
+__global__ __launch_bounds__(256) void k_assemble(SpaDev d, const int32_t * slot_row, const double * scale, double * diagonal, double inv_radius,
+                                                  int compute_diag, double lo, double hi, double * rhs, int32_t * fail_flag, int nb_matrix)
 {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= d.n_free * 3) {return;}
-  const int i = t / 3, c = t - i * 3;
-  double v = scale[t] * d.H[(size_t)d.bsr_diag_slot[i] * 9 + c * 3 + c] * scale[t];
-  v = v < lo ? lo : v;          // levenberg_marquardt_strategy.cc: clamp to [min_diagonal, max_diagonal]
-  v = v > hi ? hi : v;
-  diag[t] = v;
-}
-void spa_launch_diag(const SpaDev & d, const double * scale, double * diag_out, double min_diag, double max_diag, void * stream)
-{
-  hipLaunchKernelGGL(k_diag, dim3((d.n_free * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, scale, diag_out, min_diag, max_diag);
-}
-
-__global__ void k_assemble(SpaDev d, const int32_t * slot_row, const double * scale, const double * diagonal, double inv_radius)
-{
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)blockIdx.x >= nb_matrix) {
+    const int t = ((int)blockIdx.x - nb_matrix) * 256 + (int)threadIdx.x;
+    if (t == 0 && fail_flag) {*fail_flag = 0;}
+    if (t >= d.n_free * 3) {return;}
+    const int i = t / 3, c = t - i * 3;
+    rhs[3 * d.elim_of_free[i] + c] = scale[t] * d.g[t];
+    return;
+  }
+  const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= d.n_slots * 9) {return;}
   const int slot = t / 9, el = t - slot * 9;
   const int64_t dest = d.slot_dest[slot];
@@ -242,29 +240,29 @@ __global__ void k_assemble(SpaDev d, const int32_t * slot_row, const double * sc
   // block above the diagonal would outlive a change of the fronts' layout
   if (d.scatter && i == j && r < c) {return;}
   double v = scale[3 * i + r] * d.H[t] * scale[3 * j + c];
-  if (i == j && r == c) {v += diagonal[3 * i + r] * inv_radius;}
+  if (i == j && r == c) {
+    double dg;
+    if (compute_diag) {
+      dg = v < lo ? lo : v;
+      dg = dg > hi ? hi : dg;
+      diagonal[3 * i + r] = dg;
+    } else {
+      dg = diagonal[3 * i + r];
+    }
+    v += dg * inv_radius;
+  }
   d.fronts[dest + r + (int64_t)c * d.slot_ld[slot]] = v;
 }
 
 // slot_row is stored right behind bsr_col by the host (bsr_col + n_slots)
-void spa_launch_assemble(const SpaDev & d, const double * scale, const double * diagonal, double inv_radius, void * stream)
+void spa_launch_assemble(const SpaDev & d, const double * scale, double * diagonal, double inv_radius, bool compute_diag, double min_diag, double max_diag,
+                         double * rhs, int32_t * fail_flag, void * stream)
 {
   hipStream_t s = (hipStream_t)stream;
-  // (the fronts have been zeroed by the caller)
-  hipLaunchKernelGGL(k_assemble, dim3((d.n_slots * 9 + 255) / 256), dim3(256), 0, s, d, d.bsr_col + d.n_slots, scale, diagonal, inv_radius);
-}
-
-__global__ void k_make_rhs(SpaDev d, const double * scale, double * rhs, int32_t * fail_flag)
-{
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0 && fail_flag) {*fail_flag = 0;}        // (a memset node of its own cost 4 us and a gap on the critical stream)
-  if (t >= d.n_free * 3) {return;}
-  const int i = t / 3, c = t - i * 3;
-  rhs[3 * d.elim_of_free[i] + c] = scale[t] * d.g[t];
-}
-void spa_launch_make_rhs(const SpaDev & d, const double * scale, double * rhs, int32_t * fail_flag, void * stream)
-{
-  hipLaunchKernelGGL(k_make_rhs, dim3((d.n_free * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, scale, rhs, fail_flag);
+  // (the fronts have been zeroed by the caller, or clean themselves)
+  const int nbm = (d.n_slots * 9 + 255) / 256, nbr = (d.n_free * 3 + 255) / 256;
+  hipLaunchKernelGGL(k_assemble, dim3(nbm + nbr), dim3(256), 0, s, d, d.bsr_col + d.n_slots, scale, diagonal, inv_radius, compute_diag ? 1 : 0, min_diag,
+                     max_diag, rhs, fail_flag, nbm);
 }
 
 __global__ void k_finish_step(SpaDev d, const double * scale, const double * rhs, double * step, double * delta)
@@ -491,8 +489,12 @@ __global__ __launch_bounds__(256) void k_gather_Hg_norms(SpaDev d, const double 
   block_reduce_store<2>(p, 1, partial + 2 * blockIdx.x);
 }
 
-// out[3..7] <- step partials, out[8] <- 0.5 * cost partials, out[9], out[10] <- gradient norm partials
-__global__ __launch_bounds__(256) void k_reduce_partials(const double * ps, int ns, const double * pe, int ne, const double * pg, int ng, double * out)
+// out[3..7] <- step partials, out[8] <- 0.5 * cost partials, out[9], out[10] <- gradient norm partials.  With h_out (host-coherent
+// memory): the same eight numbers and the factorisation's fail word (h_out[11]) go straight to the host, then the flag h_flag <- seq
+// (system-scope release): the LM loop reads its iteration's scalars without two copy nodes and a stream drain (30 us of every
+// iteration).
+__global__ __launch_bounds__(256) void k_reduce_partials(const double * ps, int ns, const double * pe, int ne, const double * pg, int ng, double * out,
+                                                         double * h_out, int32_t * h_flag, const int32_t * fail_flag, int32_t seq)
 {
   double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int b = threadIdx.x; b < ns; b += 256) {
@@ -508,6 +510,15 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double * ps, int 
   if (threadIdx.x == 5) {out[8] = 0.5 * res[5];}
   if (threadIdx.x == 6) {out[9] = res[6];}
   if (threadIdx.x == 7) {out[10] = res[7];}
+  if (h_out && threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {h_out[3 + q] = res[q];}
+    h_out[8] = 0.5 * res[5]; h_out[9] = res[6]; h_out[10] = res[7];
+    h_out[11] = (double)*fail_flag;
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 int64_t spa_step_partials_size(const SpaDev & d)
@@ -561,13 +572,14 @@ void spa_launch_step_and_linearize(const SpaDev & cur, const SpaDev & alt, const
 }
 
 // second half: scal[3..10] from the partial sums (sharded: the gradient norms from the summed g first)
-void spa_launch_step_scalars(const SpaDev & alt, const double * cand, double * partial, bool sharded, double * scal, void * stream)
+void spa_launch_step_scalars(const SpaDev & alt, const double * cand, double * partial, bool sharded, double * scal, void * stream, double * h_out,
+                             int32_t * h_flag, const int32_t * fail_flag, int32_t seq)
 {
   hipStream_t s = (hipStream_t)stream;
   const int nbs = (kStepLanes * alt.n_free + 255) / 256, nbe = (alt.n_edges + 255) / 256, nbg = (3 * alt.n_free + 255) / 256;
   double * ps = partial, * pe = ps + 5 * (size_t)nbs, * pg = pe + nbe;
   if (sharded) {hipLaunchKernelGGL(k_grad_norm_partials, dim3(nbg), dim3(256), 0, s, alt, cand, pg);}
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, ps, nbs, pe, alt.n_edges > 0 ? nbe : 0, pg, nbg, scal);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, ps, nbs, pe, alt.n_edges > 0 ? nbe : 0, pg, nbg, scal, h_out, h_flag, fail_flag, seq);
 }
 
 // ---------------------------------------------------------------------------------------------
