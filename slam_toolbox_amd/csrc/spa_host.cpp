@@ -151,6 +151,9 @@ struct kh_spa
   std::vector<std::array<double, 8>> iter_log;
   int32_t n_slots = 0;
   std::vector<int32_t> level_offsets, level_max_m, level_max_ns;
+  // per level: the fronts behind the first level_split[l] of it go through k_front_update (they fit one workgroup's LDS), with
+  // level_fused_lds[l] bytes of it; level_split[l] = the level's size: none
+  std::vector<int32_t> level_split; std::vector<size_t> level_fused_lds;
   DevBuf<double> d_upd, d_fsb, d_partial;
   DevBuf<double> d_Hg_alt, d_best;          // normal equations at the candidate point (speculative); minimum-cost iterate
   // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
@@ -502,13 +505,23 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     // level lists, concatenated
     std::vector<int32_t> level_fronts;
     s->level_offsets.assign(1, 0);
-    s->level_max_m.clear(); s->level_max_ns.clear();
+    s->level_max_m.clear(); s->level_max_ns.clear(); s->level_split.clear(); s->level_fused_lds.clear();
     for (auto & lv : sym.levels) {
       level_fronts.insert(level_fronts.end(), lv.begin(), lv.end());
       s->level_offsets.push_back(static_cast<int32_t>(level_fronts.size()));
       int32_t mm = 0, mns = 0;
       for (int32_t k : lv) {mm = std::max(mm, sym.front_m[k]); mns = std::max(mns, sym.front_ns[k]);}
       s->level_max_m.push_back(mm); s->level_max_ns.push_back(mns);
+      // the fronts of a level are numbered largest first: the ones that do not fit k_front_update are (nearly) a prefix
+      static const int fuse_min = std::getenv("KH_SPA_FUSE_MIN") ? std::atoi(std::getenv("KH_SPA_FUSE_MIN")) : 256;
+      int32_t split = 0;
+      size_t lds = 0;
+      for (size_t q = 0; q < lv.size(); ++q) {
+        const size_t b = spa_front_update_lds(sym.front_m[lv[q]], sym.front_ns[lv[q]]);
+        if (b == 0 && sym.front_m[lv[q]] > sym.front_ns[lv[q]]) {split = static_cast<int32_t>(q) + 1; lds = 0;} else {lds = std::max(lds, b);}
+      }
+      if (static_cast<int32_t>(lv.size()) - split < fuse_min) {split = static_cast<int32_t>(lv.size());}
+      s->level_split.push_back(split); s->level_fused_lds.push_back(lds);
     }
     // uploads
     hipStream_t st = s->stream;
@@ -1366,7 +1379,11 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
         }
         spa_launch_potrf_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_fail.p, s->d_rhs.p, s->d_upd.p, st);
         if (split_ea) {KS_HIP(hipStreamWaitEvent(st, s->ev_level[1], 0));}
-        spa_launch_update_level(dev, s->level_offsets[l], n_level, s->level_max_m[l], s->level_max_ns[l], s->d_rhs.p, s->d_upd.p, st);
+        // the update of the level: the fronts that fit one workgroup's LDS whole in k_front_update (when there are enough of them), the
+        // larger ones -- the head of the level -- in k_trsm / k_syrk
+        const int32_t split = dev.gather ? n_level : s->level_split[l];
+        spa_launch_update_level(dev, s->level_offsets[l], split, s->level_max_m[l], s->level_max_ns[l], s->d_rhs.p, s->d_upd.p, st);
+        spa_launch_front_update(dev, s->level_offsets[l] + split, n_level - split, s->level_fused_lds[l], s->d_rhs.p, s->d_upd.p, st);
         continue;
       }
       // narrow levels: the extend-add runs chip-wide in its own launch instead of on each front's single CU

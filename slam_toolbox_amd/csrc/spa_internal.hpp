@@ -120,6 +120,11 @@ void spa_launch_backward_level(const SpaDev & d, const int32_t * level_fronts, i
 void spa_launch_potrf_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, int32_t * fail_flag,
                             double * rhs, double * upd, void * stream);
 void spa_launch_update_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, double * upd, void * stream);
+// round 6: trsm + syrk of one front per workgroup with L21 resident in LDS (k_front_update), for the fronts first_front .. + n - 1,
+// all of which must fit: spa_front_update_lds(m, ns) = the LDS such a front takes, 0 when it does not fit or has nothing to update;
+// lds_bytes = the largest of the range
+size_t spa_front_update_lds(int32_t m, int32_t ns);
+void spa_launch_front_update(const SpaDev & d, int32_t first_front, int32_t n, size_t lds_bytes, const double * rhs, double * upd, void * stream);
 void spa_launch_backward3_level(const SpaDev & d, int32_t first_front, int32_t n, int32_t max_m, int32_t max_ns, double * rhs, void * stream);
 // self-cleaning fronts (scatter mode): zero the update matrices of the fronts in `list` (children read in place by their parents)
 void spa_launch_zero_update_blocks(const SpaDev & d, const int32_t * list, int32_t n, int32_t max_m, void * stream);

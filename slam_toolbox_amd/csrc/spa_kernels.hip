@@ -2082,6 +2082,255 @@ __global__ __launch_bounds__(TS * 8) void k_syrk(SpaDev d, int first_front, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_front_update (round 6): k_trsm AND k_syrk of one front in ONE workgroup, L21 resident in LDS.
+//
+// On the wide levels of the tree (hundreds of fronts of 200-300 rows with 60-80 pivots) the split kernels are bound by what
+// they re-read: every 64 x 64 tile of k_syrk stages its two 64-row slabs of L21 from the L2 again (level 0 of the 10k-node
+// graph: 282 MB of slabs + 135 MB of update blocks + 67 MB of scatter in 61 us = the L2's rate, for 0.5 GFLOP), after k_trsm
+// has written L21 and before that staged F21 once per slab.  A front of such a level fits one compute unit's LDS whole:
+//   stage   F21 (both buffers, and the children read in place) -> S [nup][LD], W -> Wl [nsp][LDW], y1, the rows' places in the
+//           parent
+//   trsm    a wave per 16-row tile: L21 = F21 W with one accumulator per column block (independent MFMAs back to back),
+//           written over the tile's own rows of S, to the front (the backward sweep reads it) and into upd -= L21 y1
+//   syrk    16 x 16 sub-tiles of F22 -= L21 L21^T, two at a time per wave (they share the row operand), operands straight from
+//           S; initial values from the front (both buffers), results added into the parent (or stored, Symbolic::scatter_mode)
+// so F21, W and F22 are read once and L21 is written once.  The host sends the fronts of a level that fit (front_update_fits)
+// here when there are enough of them to fill the chip; the larger ones (the head of the level: fronts are sorted by size) keep
+// k_trsm / k_syrk.
+// stage_rows with the number of rows known at run time (the whole F21 of a front at once, column by column)
+__device__ __forceinline__ void stage_rows_rt(double * S, int LD, int R, const SpaDev & d, const FrontDesc & fd, int prow0, int nr, int ns, int nsp, int nkids,
+                                              const double * Bfront, int tid, int nthreads)
+{
+  constexpr int LU = 8;
+  const int m = fd.m, mp = m / 3;
+  const double * Fcol0 = d.fronts + fd.off + prow0;
+  const double * Bcol0 = Bfront ? Bfront + prow0 : nullptr;
+  for (int base = 0; base < R * nsp; base += LU * nthreads) {
+    double v[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int idx = base + u * nthreads + tid;
+      const int c = idx / R, i = idx - c * R;
+      const bool want = idx < R * nsp && i < nr && c < ns;
+      v[u] = *(want ? Fcol0 + i + (int64_t)c * m : Fcol0);
+    }
+    if (Bcol0) {
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int idx = base + u * nthreads + tid;
+        const int c = idx / R, i = idx - c * R;
+        const bool want = idx < R * nsp && i < nr && c < ns;
+        const double * bp = want ? Bcol0 + i + (int64_t)c * m : Bcol0;
+        v[u] += *bp;
+        if (want) {*const_cast<double *>(bp) = 0.0;}          // self-cleaning (buffer A's entries become L21)
+      }
+    }
+    for (int s = 0; s < nkids; ++s) {
+      const ChildInfo ci = child_info(d, fd, s);
+      const int32_t * inv = d.cinv + fd.cinv_ptr + s * mp;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int idx = base + u * nthreads + tid;
+        const int c = idx / R, i = idx - c * R;
+        const bool want = idx < R * nsp && i < nr && c < ns;
+        const double g = gather_entry(d.fronts, ci, inv, want ? prow0 + i : 0, want ? c : 0);
+        v[u] += want ? g : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int idx = base + u * nthreads + tid;
+      const int c = idx / R, i = idx - c * R;
+      if (idx < R * nsp) {S[(size_t)i * LD + c] = (i < nr && c < ns) ? v[u] : 0.0;}
+    }
+  }
+}
+
+constexpr int kFuThreads = 1024, kFuWaves = kFuThreads / 64;
+constexpr int kFuMaxNt = 5;          // pivot blocks of up to 80 columns (the leaves of the dissection: 24 nodes = 72): one accumulator per column
+                                     // block in the trsm phase, and 1024 threads leave a lane 128 registers
+
+static size_t front_update_lds_bytes(int m, int ns)
+{
+  const int nu = m - ns, nup = (nu + NB - 1) & ~(NB - 1), nsp = (ns + NB - 1) & ~(NB - 1);
+  return sizeof(double) * ((size_t)nup * (nsp + 2) + (size_t)nsp * (nsp + 4) + nsp + 8) + sizeof(int32_t) * (size_t)(nup / 3 + 8);
+}
+// LDS a front takes in k_front_update, 0 when it does not fit (or has no rows below the pivot block: nothing to do)
+size_t spa_front_update_lds(int32_t m, int32_t ns)
+{
+  if (ns > NB * kFuMaxNt || m <= ns) {return 0;}
+  const size_t b = front_update_lds_bytes(m, ns);
+  return b <= 160 * 1024 - 512 ? b : 0;
+}
+
+__global__ __launch_bounds__(kFuThreads) void k_front_update(SpaDev d, int first_front, const double * __restrict__ rhs, double * upd)
+{
+  const FrontDesc fd = d.desc[first_front + blockIdx.x];
+  const int m = fd.m, ns = fd.ns, nu = m - ns;
+  if (nu <= 0) {return;}
+  const int nsp = (ns + NB - 1) & ~(NB - 1), nt = nsp >> 4, LD = nsp + 2, LDW = nsp + 4;
+  const int nup = (nu + NB - 1) & ~(NB - 1), nrt = nup >> 4;
+  double * F = d.fronts + fd.off;
+  const double * Bf = front_b(d, fd);
+  const double * W = d.winv + fd.woff;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  extern __shared__ double smem[];
+  double * S = smem;                                   // [nup][LD]   F21, then L21
+  double * Wl = S + (size_t)nup * LD;                  // [nsp][LDW]  Wl[k][j] = (L^-T)[k][j]
+  double * yv = Wl + (size_t)nsp * LDW;                // [nsp]       y1
+  int32_t * rpp = reinterpret_cast<int32_t *>(yv + nsp + 8);       // [nup / 3 + 1]  the struct rows' places in the parent (node units)
+  const int first = 3 * fd.first;
+  const int nkids = front_nkids(d, fd), mp = m / 3;
+  const int mode = d.scatter ? (fd.flags & 3) : 0;
+  // ---- stage ----
+  for (int j = tid; j < nsp; j += nthreads) {yv[j] = j < ns ? rhs[first + j] : 0.0;}
+  if (mode != 0) {
+    const int32_t * rp = d.relpos + fd.relpos_ptr;
+    for (int j = tid; j < nup / 3 + 1; j += nthreads) {rpp[j] = rp[min(j, nu / 3 - 1)];}
+  }
+  for (int idx = tid; idx < nsp * nsp; idx += nthreads) {
+    const int k = idx / nsp, j = idx - k * nsp;
+    Wl[k * LDW + j] = j >= (k & ~(NB - 1)) ? W[j + (int64_t)k * nsp] : 0.0;      // (left of the diagonal block W holds nothing)
+  }
+  stage_rows_rt(S, LD, nup, d, fd, ns, nu, ns, nsp, nkids, Bf, tid, nthreads);
+  __syncthreads();
+  // ---- trsm ----
+  double * uk = upd + 3 * (int64_t)fd.rows_ptr;
+  for (int it = wave; it < nrt; it += kFuWaves) {
+    v4d acc[kFuMaxNt];
+#pragma unroll
+    for (int J = 0; J < kFuMaxNt; ++J) {acc[J] = v4d{0.0, 0.0, 0.0, 0.0};}
+    const double * srow = S + (size_t)(NB * it + lr) * LD + 4 * lk;
+#pragma unroll
+    for (int K = 0; K < kFuMaxNt; ++K) {
+      if (K < nt) {
+        double b[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {b[kk] = srow[NB * K + kk];}
+        const double * wk = Wl + (size_t)(NB * K + 4 * lk) * LDW + lr;
+#pragma unroll
+        for (int J = K; J < kFuMaxNt; ++J) {
+          if (J < nt) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(wk[kk * LDW + NB * J], b[kk], acc[J], 0, 0, 0);}
+          }
+        }
+      }
+    }
+    // lane (lr, lk) holds L21[16 it + lr][16 J + lk + 4 r]: over the tile's own rows of S (nobody else reads them before the
+    // barrier), to the front, and into the forward solve
+    const int row = NB * it + lr;
+    double part = 0.0;
+#pragma unroll
+    for (int J = 0; J < kFuMaxNt; ++J) {
+      if (J < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = NB * J + lk + 4 * r;
+          S[(size_t)row * LD + col] = acc[J][r];
+          if (row < nu && col < ns) {F[(ns + row) + (int64_t)col * m] = acc[J][r];}
+          part += acc[J][r] * yv[col];                             // yv is zero on the padding columns
+        }
+      }
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (lk == 0 && row < nu) {uk[row] -= part;}
+  }
+  __syncthreads();
+  // ---- syrk ----
+  const FrontDesc * pd = mode != 0 ? d.desc + fd.parent : nullptr;
+  const int64_t pm = pd ? pd->m : 0;
+  double * P = pd ? (mode == 1 ? d.fronts : d.fronts_b) + pd->off : nullptr;
+  // units: (si, pair of sub-tile columns 2 u, 2 u + 1), si = 0 .. nrt - 1, u = 0 .. si / 2, numbered row by row
+  int unit = wave;
+  int si = 0, ubase = 0;                               // ubase = units before tile row si
+  const int nunits = [&]() {int n = 0; for (int q = 0; q < nrt; ++q) {n += q / 2 + 1;} return n;}();
+  for (; unit < nunits; unit += kFuWaves) {
+    while (unit >= ubase + si / 2 + 1) {ubase += si / 2 + 1; ++si;}
+    const int sj0 = 2 * (unit - ubase);
+    const bool two = sj0 + 1 <= si;
+    const int row = NB * si + lr;
+    v4d acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = NB * (sj0 + u) + lk + 4 * r;
+        const bool ok = (u == 0 || two) && row < nu && col <= row;
+        const int64_t at = ok ? (ns + row) + (int64_t)(ns + col) * m : 0;
+        double v = F[at];
+        if (Bf) {v += Bf[at];}
+        acc[u][r] = ok ? v : 0.0;
+        if (d.scatter && ok) {
+          F[at] = 0.0;
+          if (Bf) {const_cast<double *>(Bf)[at] = 0.0;}
+        }
+      }
+    }
+    for (int s = 0; s < nkids; ++s) {
+      const ChildInfo ci = child_info(d, fd, s);
+      const int32_t * inv = d.cinv + fd.cinv_ptr + s * mp;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = NB * (sj0 + u) + lk + 4 * r;
+          const bool ok = (u == 0 || two) && row < nu && col <= row;
+          const double g = gather_entry(d.fronts, ci, inv, ok ? ns + row : 0, ok ? ns + col : 0);
+          acc[u][r] += ok ? g : 0.0;
+        }
+      }
+    }
+    const double * xb = S + (size_t)(NB * si + lr) * LD + 4 * lk;
+    const double * xa0 = S + (size_t)(NB * sj0 + lr) * LD + 4 * lk;
+    const double * xa1 = xa0 + (two ? NB * LD : 0);
+    if (two) {
+      for (int K = 0; K < nsp; K += NB) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double b = xb[K + kk];
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa0[K + kk], b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa1[K + kk], b, acc[1], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int K = 0; K < nsp; K += NB) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa0[K + kk], xb[K + kk], acc[0], 0, 0, 0);}
+      }
+    }
+    const int rowc = min(row, nu - 1);
+    const int64_t prow = mode != 0 ? 3 * (int64_t)rpp[rowc / 3] + rowc % 3 : 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = NB * (sj0 + u) + lk + 4 * r;
+        if ((u == 0 || two) && row < nu && col <= row) {
+          if (mode != 0) {
+            const int64_t pcol = 3 * (int64_t)rpp[col / 3] + col % 3;
+            unsafeAtomicAdd(P + prow + pcol * pm, acc[u][r]);
+          } else {
+            F[(ns + row) + (int64_t)(ns + col) * m] = acc[u][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+void spa_launch_front_update(const SpaDev & d, int32_t first_front, int32_t n, size_t lds_bytes, const double * rhs, double * upd, void * stream)
+{
+  if (n <= 0) {return;}
+  static std::atomic<unsigned long long> done{0};
+  allow_dynamic_lds(reinterpret_cast<const void *>(k_front_update), 160 * 1024 - 256, done);
+  hipLaunchKernelGGL(k_front_update, dim3(n), dim3(kFuThreads), lds_bytes, (hipStream_t)stream, d, first_front, rhs, upd);
+}
+
 // Backward solve of a level with W = L11^-T:  x1 = W (y1 - L21^T x2), two sets of independent dot products, one wave per
 // pair of columns.  (A variant that requested every entry of L21 and W a wave needs right after the descriptor -- 80 loads
 // per lane, fully unrolled -- was SLOWER, 306 us per sweep against 177: these kernels run once per level, and a long
