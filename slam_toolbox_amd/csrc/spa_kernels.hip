@@ -2335,6 +2335,7 @@ void spa_launch_front_update(const SpaDev & d, int32_t first_front, int32_t n, s
 // pair of columns.  (A variant that requested every entry of L21 and W a wave needs right after the descriptor -- 80 loads
 // per lane, fully unrolled -- was SLOWER, 306 us per sweep against 177: these kernels run once per level, and a long
 // straight-line body is paid for in instruction fetch.)
+template <bool kNarrow>
 __global__ __launch_bounds__(1024) void k_backward3(SpaDev d, int first_front, double * rhs)
 {
   const FrontDesc fd = d.desc[first_front + blockIdx.x];
@@ -2350,38 +2351,68 @@ __global__ __launch_bounds__(1024) void k_backward3(SpaDev d, int first_front, d
   for (int t = tid; t < ns; t += nthreads) {sb[t] = rhs[first + t];}
   for (int q = tid; q < nu; q += nthreads) {sb[ns + q] = rhs[3 * rows[q / 3] + q % 3];}
   __syncthreads();
-  // w[c] = y1[c] - L21[:, c] . x2
-  for (int c = 2 * wave; c < ns; c += 2 * nwaves) {
-    const double * col0 = F + ns + (int64_t)c * m;
-    const double * col1 = col0 + (c + 1 < ns ? m : 0);
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = lane; i < nu; i += 64) {
-      const double x = sb[ns + i];
-      a0 += col0[i] * x;
-      a1 += col1[i] * x;
-      if (d.scatter) {                        // self-cleaning fronts: this was the last reader of L21
-        const_cast<double *>(col0)[i] = 0.0;
-        if (c + 1 < ns) {const_cast<double *>(col1)[i] = 0.0;}
+  if (kNarrow) {
+    // NARROW levels (a handful of fronts: latency is everything).  Eight lanes per column, 128 columns at a time: every column
+    // of the pivot block is in flight at once (with a wave per pair of columns a 126-pivot front took its 63 pairs in four
+    // rounds of sixteen, each round a memory latency of its own).  On the wide levels the 64-byte pieces of this form cost more
+    // than the rounds (measured: 17.6 -> 21.0 us on the 69-front level), so they keep the wave per pair.
+    const int grp = tid >> 3, sub = tid & 7, ngrp = nthreads >> 3;
+    // w[c] = y1[c] - L21[:, c] . x2
+    for (int c = grp; c < ns; c += ngrp) {
+      const double * col = F + ns + (int64_t)c * m;
+      double a0 = 0.0;
+#pragma unroll 4
+      for (int i = sub; i < nu; i += 8) {
+        a0 += col[i] * sb[ns + i];
+        if (d.scatter) {const_cast<double *>(col)[i] = 0.0;}        // self-cleaning fronts: this was the last reader of L21
       }
+      a0 += __shfl_xor(a0, 1); a0 += __shfl_xor(a0, 2); a0 += __shfl_xor(a0, 4);
+      if (sub == 0) {sb[c] -= a0;}
     }
+    __syncthreads();
+    // x1[c] = sum_{j >= c} (L^-T)[c][j] w[j],  (L^-T)[c][j] = W[j + c * nsp]  (zeros left of the diagonal)
+    for (int c = grp; c < ns; c += ngrp) {
+      const double * w0 = W + (int64_t)c * nsp;
+      double a0 = 0.0;
+#pragma unroll 4
+      for (int j = c + sub; j < ns; j += 8) {a0 += w0[j] * sb[j];}
+      a0 += __shfl_xor(a0, 1); a0 += __shfl_xor(a0, 2); a0 += __shfl_xor(a0, 4);
+      if (sub == 0) {xo[c] = a0;}
+    }
+  } else {
+    // w[c] = y1[c] - L21[:, c] . x2
+    for (int c = 2 * wave; c < ns; c += 2 * nwaves) {
+      const double * col0 = F + ns + (int64_t)c * m;
+      const double * col1 = col0 + (c + 1 < ns ? m : 0);
+      double a0 = 0.0, a1 = 0.0;
+      for (int i = lane; i < nu; i += 64) {
+        const double x = sb[ns + i];
+        a0 += col0[i] * x;
+        a1 += col1[i] * x;
+        if (d.scatter) {                        // self-cleaning fronts: this was the last reader of L21
+          const_cast<double *>(col0)[i] = 0.0;
+          if (c + 1 < ns) {const_cast<double *>(col1)[i] = 0.0;}
+        }
+      }
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
-    if (lane == 0) {sb[c] -= a0; if (c + 1 < ns) {sb[c + 1] -= a1;}}
-  }
-  __syncthreads();
-  // x1[c] = sum_{j >= c} (L^-T)[c][j] w[j],  (L^-T)[c][j] = W[j + c * nsp]  (zeros left of the diagonal)
-  for (int c = 2 * wave; c < ns; c += 2 * nwaves) {
-    const double * w0 = W + (int64_t)c * nsp;
-    const double * w1 = w0 + (c + 1 < ns ? nsp : 0);
-    double a0 = 0.0, a1 = 0.0;
-    for (int j = c + lane; j < ns; j += 64) {
-      const double wj = sb[j];
-      a0 += w0[j] * wj;
-      a1 += j > c ? w1[j] * wj : 0.0;       // row c + 1 starts at column c + 1: left of it W holds nothing (not even zeros when
-    }                                        // c + 1 opens a new block of 16)
+      for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
+      if (lane == 0) {sb[c] -= a0; if (c + 1 < ns) {sb[c + 1] -= a1;}}
+    }
+    __syncthreads();
+    // x1[c] = sum_{j >= c} (L^-T)[c][j] w[j],  (L^-T)[c][j] = W[j + c * nsp]  (zeros left of the diagonal)
+    for (int c = 2 * wave; c < ns; c += 2 * nwaves) {
+      const double * w0 = W + (int64_t)c * nsp;
+      const double * w1 = w0 + (c + 1 < ns ? nsp : 0);
+      double a0 = 0.0, a1 = 0.0;
+      for (int j = c + lane; j < ns; j += 64) {
+        const double wj = sb[j];
+        a0 += w0[j] * wj;
+        a1 += j > c ? w1[j] * wj : 0.0;       // row c + 1 starts at column c + 1: left of it W holds nothing (not even zeros when
+      }                                        // c + 1 opens a new block of 16)
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
-    if (lane == 0) {xo[c] = a0; if (c + 1 < ns) {xo[c + 1] = a1;}}
+      for (int s = 32; s > 0; s >>= 1) {a0 += __shfl_xor(a0, s); a1 += __shfl_xor(a1, s);}
+      if (lane == 0) {xo[c] = a0; if (c + 1 < ns) {xo[c + 1] = a1;}}
+    }
   }
   __syncthreads();
   for (int t = tid; t < ns; t += nthreads) {rhs[first + t] = xo[t];}
@@ -2494,7 +2525,11 @@ void spa_launch_backward3_level(const SpaDev & d, int32_t first_front, int32_t n
 {
   if (n <= 0) {return;}
   const int nsp = (max_ns + NB - 1) & ~(NB - 1);
-  hipLaunchKernelGGL(k_backward3, dim3(n), dim3(max_ns <= 48 ? 256 : 1024), sizeof(double) * ((size_t)max_m + nsp + 8), (hipStream_t)stream, d, first_front, rhs);
+  if (n <= 12) {
+    hipLaunchKernelGGL(k_backward3<true>, dim3(n), dim3(1024), sizeof(double) * ((size_t)max_m + nsp + 8), (hipStream_t)stream, d, first_front, rhs);
+  } else {
+    hipLaunchKernelGGL(k_backward3<false>, dim3(n), dim3(max_ns <= 48 ? 256 : 1024), sizeof(double) * ((size_t)max_m + nsp + 8), (hipStream_t)stream, d, first_front, rhs);
+  }
 }
 
 }  // namespace kh
