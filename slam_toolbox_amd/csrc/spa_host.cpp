@@ -154,6 +154,8 @@ struct kh_spa
   // per level: the fronts behind the first level_split[l] of it go through k_front_update (they fit one workgroup's LDS), with
   // level_fused_lds[l] bytes of it; level_split[l] = the level's size: none
   std::vector<int32_t> level_split; std::vector<size_t> level_fused_lds;
+  // per level: the most rows any of its fronts has below the pivot block (0: the root -- no update launches)
+  std::vector<int32_t> level_max_nu;
   DevBuf<double> d_upd, d_fsb, d_partial;
   DevBuf<double> d_Hg_alt, d_best;          // normal equations at the candidate point (speculative); minimum-cost iterate
   // multi-GPU: edge-block sharded linearisation, H and g summed by the caller's collective
@@ -505,7 +507,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     // level lists, concatenated
     std::vector<int32_t> level_fronts;
     s->level_offsets.assign(1, 0);
-    s->level_max_m.clear(); s->level_max_ns.clear(); s->level_split.clear(); s->level_fused_lds.clear();
+    s->level_max_m.clear(); s->level_max_ns.clear(); s->level_split.clear(); s->level_fused_lds.clear(); s->level_max_nu.clear();
     for (auto & lv : sym.levels) {
       level_fronts.insert(level_fronts.end(), lv.begin(), lv.end());
       s->level_offsets.push_back(static_cast<int32_t>(level_fronts.size()));
@@ -522,6 +524,9 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       }
       if (static_cast<int32_t>(lv.size()) - split < fuse_min) {split = static_cast<int32_t>(lv.size());}
       s->level_split.push_back(split); s->level_fused_lds.push_back(lds);
+      int32_t mnu = 0;
+      for (int32_t k : lv) {mnu = std::max(mnu, sym.front_m[k] - sym.front_ns[k]);}
+      s->level_max_nu.push_back(mnu);
     }
     // uploads
     hipStream_t st = s->stream;
@@ -1381,6 +1386,7 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
         if (split_ea) {KS_HIP(hipStreamWaitEvent(st, s->ev_level[1], 0));}
         // the update of the level: the fronts that fit one workgroup's LDS whole in k_front_update (when there are enough of them), the
         // larger ones -- the head of the level -- in k_trsm / k_syrk
+        if (s->level_max_nu[l] == 0) {continue;}                   // (the root: nothing below the pivot block)
         const int32_t split = dev.gather ? n_level : s->level_split[l];
         spa_launch_update_level(dev, s->level_offsets[l], split, s->level_max_m[l], s->level_max_ns[l], s->d_rhs.p, s->d_upd.p, st);
         spa_launch_front_update(dev, s->level_offsets[l] + split, n_level - split, s->level_fused_lds[l], s->d_rhs.p, s->d_upd.p, st);

@@ -1593,14 +1593,13 @@ __device__ __forceinline__ void ll_accumulate(v4d & acc, const double * X, int L
 // times the pivot chain they were meant to hide behind (the kernel ran as long WITHOUT the chain).  The barriers of a step
 // order LDS traffic only (lds_barrier): the next step's tile requests and the stores of W stay in flight across them.
 constexpr int kPotrfThreads = 512, kPotrfHelpers = kPotrfThreads / 64 - 1;
-__global__ __launch_bounds__(kPotrfThreads) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
-                                                         long long * tbuf, int stamp_off)
+__device__ __forceinline__ void potrf_body(const SpaDev & d, const FrontDesc & fd, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
+                                           long long * tbuf, int stamp_off)
 {
   int tcount = 0;
   extern __shared__ double smem[];
   long long * stamps = reinterpret_cast<long long *>(smem) + stamp_off;
   PSTAMP();
-  const FrontDesc fd = d.desc[first_front + blockIdx.x];
   const int m = fd.m, ns = fd.ns;
   const int nsp = (ns + NB - 1) & ~(NB - 1), nt = nsp >> 4, LD = nsp + 2;
   const double * F = d.fronts + fd.off;
@@ -1816,6 +1815,13 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf(SpaDev d, int first_fro
     for (int i = 0; i < tcount; ++i) {tbuf[1 + i] = stamps[i];}
   }
   if (tid == 0 && s_fail) {atomicExch(fail_flag, 1);}
+}
+
+__global__ __launch_bounds__(kPotrfThreads) void k_potrf(SpaDev d, int first_front, int32_t * fail_flag, double * rhs, double * upd, int lds_nsp,
+                                                         long long * tbuf, int stamp_off)
+{
+  const FrontDesc fd = d.desc[first_front + blockIdx.x];
+  potrf_body(d, fd, fail_flag, rhs, upd, lds_nsp, tbuf, stamp_off);
 }
 
 // rows [prow0, prow0 + R) x columns [0, nsp) of the panel columns of a front -> LDS rows of stride LD (zeros outside
@@ -2164,9 +2170,9 @@ size_t spa_front_update_lds(int32_t m, int32_t ns)
   return b <= 160 * 1024 - 512 ? b : 0;
 }
 
-__global__ __launch_bounds__(kFuThreads) void k_front_update(SpaDev d, int first_front, const double * __restrict__ rhs, double * upd)
+template <int kWaves, int kMaxNt>
+__device__ __forceinline__ void front_update_body(const SpaDev & d, const FrontDesc & fd, const double * rhs, double * upd)
 {
-  const FrontDesc fd = d.desc[first_front + blockIdx.x];
   const int m = fd.m, ns = fd.ns, nu = m - ns;
   if (nu <= 0) {return;}
   const int nsp = (ns + NB - 1) & ~(NB - 1), nt = nsp >> 4, LD = nsp + 2, LDW = nsp + 4;
@@ -2199,20 +2205,20 @@ __global__ __launch_bounds__(kFuThreads) void k_front_update(SpaDev d, int first
   __syncthreads();
   // ---- trsm ----
   double * uk = upd + 3 * (int64_t)fd.rows_ptr;
-  for (int it = wave; it < nrt; it += kFuWaves) {
-    v4d acc[kFuMaxNt];
+  for (int it = wave; it < nrt; it += kWaves) {
+    v4d acc[kMaxNt];
 #pragma unroll
-    for (int J = 0; J < kFuMaxNt; ++J) {acc[J] = v4d{0.0, 0.0, 0.0, 0.0};}
+    for (int J = 0; J < kMaxNt; ++J) {acc[J] = v4d{0.0, 0.0, 0.0, 0.0};}
     const double * srow = S + (size_t)(NB * it + lr) * LD + 4 * lk;
 #pragma unroll
-    for (int K = 0; K < kFuMaxNt; ++K) {
+    for (int K = 0; K < kMaxNt; ++K) {
       if (K < nt) {
         double b[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {b[kk] = srow[NB * K + kk];}
         const double * wk = Wl + (size_t)(NB * K + 4 * lk) * LDW + lr;
 #pragma unroll
-        for (int J = K; J < kFuMaxNt; ++J) {
+        for (int J = K; J < kMaxNt; ++J) {
           if (J < nt) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(wk[kk * LDW + NB * J], b[kk], acc[J], 0, 0, 0);}
@@ -2225,7 +2231,7 @@ __global__ __launch_bounds__(kFuThreads) void k_front_update(SpaDev d, int first
     const int row = NB * it + lr;
     double part = 0.0;
 #pragma unroll
-    for (int J = 0; J < kFuMaxNt; ++J) {
+    for (int J = 0; J < kMaxNt; ++J) {
       if (J < nt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2249,7 +2255,7 @@ __global__ __launch_bounds__(kFuThreads) void k_front_update(SpaDev d, int first
   int unit = wave;
   int si = 0, ubase = 0;                               // ubase = units before tile row si
   const int nunits = [&]() {int n = 0; for (int q = 0; q < nrt; ++q) {n += q / 2 + 1;} return n;}();
-  for (; unit < nunits; unit += kFuWaves) {
+  for (; unit < nunits; unit += kWaves) {
     while (unit >= ubase + si / 2 + 1) {ubase += si / 2 + 1; ++si;}
     const int sj0 = 2 * (unit - ubase);
     const bool two = sj0 + 1 <= si;
@@ -2321,6 +2327,12 @@ __global__ __launch_bounds__(kFuThreads) void k_front_update(SpaDev d, int first
       }
     }
   }
+}
+
+__global__ __launch_bounds__(kFuThreads) void k_front_update(SpaDev d, int first_front, const double * __restrict__ rhs, double * upd)
+{
+  const FrontDesc fd = d.desc[first_front + blockIdx.x];
+  front_update_body<kFuWaves, kFuMaxNt>(d, fd, rhs, upd);
 }
 
 void spa_launch_front_update(const SpaDev & d, int32_t first_front, int32_t n, size_t lds_bytes, const double * rhs, double * upd, void * stream)

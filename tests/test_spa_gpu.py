@@ -253,11 +253,11 @@ def test_linear_solves_of_pose_graphs(kartohip_lib, n, e, seed):
     # the level pipeline with the children's update matrices read in place (no extend-add launches)
     sg, xg = _solve(g, check_linear_solves=True, factor_kernels=3, gather_children=True)
     assert sg["iterations"] == s3["iterations"] and 0.0 < sg["worst_linear_residual"] < 1e-9, sg
-    assert _diff(xg, x3) < 1e-9
+    assert _diff(xg, x3) < 1e-8
     # ... and with an extend-add launch per level (rounds 3-5); the default adds a front's update matrix into its parent in k_syrk
     se, xe = _solve(g, check_linear_solves=True, factor_kernels=3, extend_add_pass=True)
     assert se["iterations"] == s3["iterations"] and 0.0 < se["worst_linear_residual"] < 1e-9, se
-    assert _diff(xe, x3) < 1e-9
+    assert _diff(xe, x3) < 1e-8
     # the default path is bit-reproducible from run to run (two children of one level add into DIFFERENT buffers of the parent)
     s3b, x3b = _solve(g, check_linear_solves=True, factor_kernels=3)
     assert np.array_equal(x3, x3b) and s3b["final_cost"] == s3["final_cost"]
