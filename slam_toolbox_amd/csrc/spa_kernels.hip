@@ -1572,10 +1572,22 @@ __device__ __forceinline__ void ll_accumulate(v4d & acc, const double * X, int L
   const int lr = lane & 15, lk = lane >> 4;
   const double * xa = X + (arow0 + lr) * LD + 4 * lk;
   const double * xb = X + (brow0 + lr) * LD + 4 * lk;
-  for (int p = p_lo; p < p_hi; ++p) {
+  // two column blocks at a time into two accumulators: a product is a chain of four DEPENDENT matrix-core operations (81 clocks
+  // each, 64 of pipe), and a helper wave of k_potrf has up to six of them in a row per tile
+  v4d other = v4d{0.0, 0.0, 0.0, 0.0};
+  int p = p_lo;
+  for (; p + 1 < p_hi; p += 2) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[NB * p + kk], xb[NB * p + kk], acc, 0, 0, 0);
+      other = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[NB * (p + 1) + kk], xb[NB * (p + 1) + kk], other, 0, 0, 0);
+    }
+  }
+  if (p < p_hi) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[NB * p + kk], xb[NB * p + kk], acc, 0, 0, 0);}
   }
+  acc += other;
 }
 
 // Pivot block of every front of a level, LEFT-LOOKING, 512 threads (= 8 waves) per front.  Step jb (16 columns):
@@ -1880,7 +1892,7 @@ __device__ __forceinline__ void stage_rows(double * S, int LD, const SpaDev & d,
 // of 16: the W entries of a block -- up to 128 k x 16 columns, 32 loads per lane -- are all requested before the first
 // MFMA (a loop over k blocks with its loads inside is a chain of L2 latencies), and serve the R / 16 row tiles of the slab.
 template <int R>
-__global__ __launch_bounds__(256) void k_trsm(SpaDev d, int first_front, const double * __restrict__ rhs, double * upd, int lds_nsp)
+__global__ __launch_bounds__(512) void k_trsm(SpaDev d, int first_front, const double * __restrict__ rhs, double * upd, int lds_nsp)
 {
   const FrontDesc fd = d.desc[first_front + blockIdx.x];
   const int m = fd.m, ns = fd.ns, nu = m - ns;
@@ -1896,14 +1908,14 @@ __global__ __launch_bounds__(256) void k_trsm(SpaDev d, int first_front, const d
   extern __shared__ double smem[];
   double * S = smem;                                         // [R][LD] the slab of F21
   double * yv = smem + (size_t)R * (lds_nsp + 2);            // [lds_nsp] y1
-  double * red = yv + lds_nsp;                               // [4][R] per-wave partial sums of L21 y1
+  double * red = yv + lds_nsp;                               // [8][R] per-wave partial sums of L21 y1 (four or eight waves)
   const int first = 3 * fd.first;
   constexpr int RT = R / NB;
   constexpr int NTMAX = kPotrfMaxNs / NB;
   double * uk = upd + 3 * (int64_t)fd.rows_ptr;
   const double uold = tid < nr ? uk[r0 + tid] : 0.0;
   for (int j = tid; j < nsp; j += nthreads) {yv[j] = j < ns ? rhs[first + j] : 0.0;}
-  for (int j = tid; j < 4 * R; j += nthreads) {red[j] = 0.0;}
+  for (int j = tid; j < 8 * R; j += nthreads) {red[j] = 0.0;}
   stage_rows<R>(S, LD, d, fd, ns + r0, nr, ns, nsp, front_nkids(d, fd), front_b(d, fd), tid, nthreads);
   __syncthreads();
   double part[RT];
@@ -1955,7 +1967,10 @@ __global__ __launch_bounds__(256) void k_trsm(SpaDev d, int first_front, const d
     if (lk == 0) {red[wave * R + NB * it + lr] = p;}
   }
   __syncthreads();
-  if (tid < nr) {uk[r0 + tid] = uold - ((red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid]));}
+  if (tid < nr) {
+    uk[r0 + tid] = uold - (((red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid])) +
+                           ((red[4 * R + tid] + red[5 * R + tid]) + (red[6 * R + tid] + red[7 * R + tid])));
+  }
 }
 
 // F22 -= L21 L21^T, one TS x TS tile of the lower triangle per workgroup (grid: front x tile).  TS = 64: eight waves,
@@ -2520,9 +2535,11 @@ void spa_launch_update_level(const SpaDev & d, int32_t first_front, int32_t n, i
   const int slabs32 = (max_nu + 31) / 32;
   const bool r64 = force_r ? force_r == 64 : (int64_t)n * slabs32 >= 1024;
   if (r64) {
-    hipLaunchKernelGGL(k_trsm<64>, dim3(n, (max_nu + 63) / 64), dim3(256), sizeof(double) * ((size_t)64 * (nsp + 2) + nsp + 4 * 64 + 8), s, d, first_front, rhs, upd, nsp);
+    hipLaunchKernelGGL(k_trsm<64>, dim3(n, (max_nu + 63) / 64), dim3(256), sizeof(double) * ((size_t)64 * (nsp + 2) + nsp + 8 * 64 + 8), s, d, first_front, rhs, upd, nsp);
   } else {
-    hipLaunchKernelGGL(k_trsm<32>, dim3(n, slabs32), dim3(256), sizeof(double) * ((size_t)32 * (nsp + 2) + nsp + 4 * 32 + 8), s, d, first_front, rhs, upd, nsp);
+    // a narrow level: eight waves, so that every column block of the pivots has a wave of its own (one round of W loads, not two)
+    const int threads = (int64_t)n * slabs32 <= 256 ? 512 : 256;
+    hipLaunchKernelGGL(k_trsm<32>, dim3(n, slabs32), dim3(threads), sizeof(double) * ((size_t)32 * (nsp + 2) + nsp + 8 * 32 + 8), s, d, first_front, rhs, upd, nsp);
   }
   const int nt32 = (max_nu + 31) / 32, nt64 = (max_nu + 63) / 64;
   const bool t64 = force_ts ? force_ts == 64 : (int64_t)n * (nt32 * (nt32 + 1) / 2) >= 2048;
