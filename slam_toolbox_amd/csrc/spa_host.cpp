@@ -1298,8 +1298,9 @@ int kh_spa_compute(kh_spa * s, kh_spa_summary * summary)
   auto zero_fronts = [&]() -> int {
     if (dev.scatter && s->clean_a == dev.fronts && s->clean_b == dev.fronts_b) {s->clean_a = nullptr; return KH_OK;}
     s->clean_a = nullptr;
-    KS_HIP(hipMemsetAsync(dev.fronts, 0, sizeof(double) * dev.fronts_size, st));
-    if (dev.scatter) {KS_HIP(hipMemsetAsync(dev.fronts_b, 0, sizeof(double) * dev.fronts_size, st));}
+    // (the WHOLE allocation: a later analysis may lay larger fronts over the same buffers, and "clean" has to mean all of them)
+    KS_HIP(hipMemsetAsync(dev.fronts, 0, sizeof(double) * (dev.scatter ? s->d_fronts.cap : static_cast<size_t>(dev.fronts_size)), st));
+    if (dev.scatter) {KS_HIP(hipMemsetAsync(dev.fronts_b, 0, sizeof(double) * s->d_fronts_b.cap, st));}
     return KH_OK;
   };
   rc = linearize(dev, x, scal + 0); if (rc) {return finish(rc);}

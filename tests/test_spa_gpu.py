@@ -329,3 +329,30 @@ def test_iteration_log_describes_the_compute(kartohip_lib):
     acc = log[log[:, 7] == 1.0]
     assert (acc[:, 3] > 0).all() and (log[:, 4] > 0).all()                       # model decrease and radius positive
     assert abs(log[0, 1] - summ["initial_cost"]) <= 1e-12 * summ["initial_cost"]
+
+
+def test_a_larger_graph_over_the_same_buffers_reads_nothing_stale(kartohip_lib):
+    """The self-cleaning fronts are zeroed once per ALLOCATION: a graph whose fronts are larger than the last one's but still fit the
+    buffers (they grow by half when they grow) must find zeros behind the old extent too.  Run with poisoned allocations
+    (KH_SPA_POISON: new device buffers start as NaN), a solve of the larger graph after a smaller one must equal a fresh solver's
+    bit for bit -- round 6's first form zeroed the old extent only, and a mapper's 7th Compute came out 2e-3 off."""
+    import subprocess, sys, os
+    code = """
+import numpy as np
+from slam_toolbox_amd import synth
+from slam_toolbox_amd.scan_solver import HipSpaSolver
+def solve(sol, g):
+    sol.load(g["init"], g["edges"], g["z"], g["cov"]); s = sol.Compute(); return s, sol.poses()
+graphs = [synth.make_pose_graph(n, e, seed=21) for n, e in ((400, 900), (440, 1000), (470, 1080), (520, 1200))]
+a = HipSpaSolver(); a.set_debug(check_linear_solves=True)
+for g in graphs:
+    sa, xa = solve(a, g)
+    b = HipSpaSolver(); sb, xb = solve(b, g); b.close()
+    assert sa["usable"] == 1 and sa["iterations"] == sb["iterations"], (sa, sb)
+    assert np.array_equal(xa.view(np.uint64), xb.view(np.uint64)), np.abs(xa - xb).max()
+print("ok")
+"""
+    env = dict(os.environ, KH_SPA_POISON="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
