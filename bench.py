@@ -334,18 +334,19 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
         lin_gbs = lin_bytes / (summ["linearize_gpu_ms"] * 1e-3) / 1e9 if summ["linearize_gpu_ms"] > 0 else 0.0
         spa_name = newest_profile("spa_pmc.json")
         spa_doc = recorded_kernels(spa_name)
-        k6_traffic = recorded_traffic(spa_doc, ("k_potrf", "k_trsm", "k_syrk", "k_extend_add"), spa_doc.get("factorizations"))
-        k5_traffic = recorded_traffic(spa_doc, ("k_edge_lin", "k_gather_H", "k_gather_g"),
-                                      spa_doc.get("kernels", {}).get("k_gather_H", {}).get("calls"))
+        k6_traffic = recorded_traffic(spa_doc, ("k_potrf", "k_trsm", "k_syrk", "k_front_update", "k_extend_add"), spa_doc.get("factorizations"))
+        n_lin_rec = sum(spa_doc.get("kernels", {}).get(k, {}).get("calls", 0) for k in ("k_gather_H", "k_gather_Hg_norms"))
+        k5_traffic = recorded_traffic(spa_doc, ("k_edge_lin", "k_gather_H", "k_gather_g"), n_lin_rec)
         out["solve_rooflines"] = [
-            {"kernel": "K6 level pipeline: k_potrf + k_trsm + k_syrk + k_extend_add (+ assemble), multifrontal Cholesky with the forward solve fused",
+            {"kernel": "K6 level pipeline: k_potrf + k_trsm + k_syrk + k_front_update (+ assemble), multifrontal Cholesky with the forward solve fused",
              "bound": "latency (dependent levels: the pivot chains of k_potrf); ceiling quoted = mfma f64",
              "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
              "flops_per_factorization": 2.0 * float(summ["factor_flops"]), "multiply_adds_per_factorization": float(summ["factor_flops"]),
              "factorizations": int(summ["factorizations"]),
              "gpu_ms": float(summ["factor_gpu_ms"]), "levels": int(summ["levels"]), "nnz_factor": int(summ["nnz_factor"]),
              "traffic": k6_traffic, "traffic_source": "recorded: profiles/" + spa_name + " (rocprofv3 PMC passes of tools/quick_spa.py, the same "
-                                                      "graph): HBM bytes of k_potrf + k_trsm + k_syrk + k_extend_add per numeric factorisation"},
+                                                      "graph): HBM bytes of k_potrf + k_trsm + k_syrk + k_front_update per numeric factorisation",
+             "timing": "HIP events around the phases in one extra solve (kh_spa_set_debug bit 1); the timed solves run without them"},
             {"kernel": "K5 k_edge_lin + k_gather_H / _g (normal equations)", "bound": "hbm", "achieved": lin_gbs, "peak": HBM_PEAK_GBS,
              "unit": "GB/s", "frac": lin_gbs / HBM_PEAK_GBS, "algorithmic_bytes": lin_bytes, "linearizations": int(n_lin),
              "gpu_ms": float(summ["linearize_gpu_ms"]), "traffic": k5_traffic,
@@ -359,7 +360,7 @@ def solver_leg(device=0, rank=0, world=1, cpu=True):
             from oracle import spa
             t = time.time()
             _, info = spa.solve(g["init"], g["edges"], g["z"], g["cov"])
-            out["solve_cpu_baseline"] = {"value": (time.time() - t) * 1e3, "unit": "ms", "cores": 1, "kind": "port",
+            out["solve_cpu_baseline"] = {"value": (time.time() - t) * 1e3, "unit": "ms", "cores": 1, "cpu_quota": cpu_quota(), "kind": "port",
                                          "sample": f"oracle/spa.py (numpy + scipy SuperLU restatement of the Ceres LM, not Ceres itself), "
                                                    f"one solve of the same graph, {info['iterations']} iterations"}
         except Exception as exc:
@@ -523,7 +524,7 @@ def loop_cpu_baseline(lb, n_sample=32):
         for t in th:
             t.join()
         dt = time.time() - t0
-    return {"value": len(work) / dt, "unit": "pairs/s", "cores": cores, "kind": "reference",
+    return {"value": len(work) / dt, "unit": "pairs/s", "cores": cores, "cpu_quota": cpu_quota(), "kind": "reference",
             "sample": f"{len(work)} of the batch's pairs, {T} concurrent (L, S) matcher pairs x {max(1, cores // T)} threads, {dt:.1f} s"}
 
 
@@ -753,7 +754,7 @@ def replay_cpu_baseline(n_scans=1500):
         iou_truth = None
     truth = q.truth[np.asarray(ids)]
     d = poses - truth
-    return {"replay_cpu_baseline": {"value": n_scans / t_ref, "unit": "scans/s", "cores": threads, "kind": "reference",
+    return {"replay_cpu_baseline": {"value": n_scans / t_ref, "unit": "scans/s", "cores": threads, "cpu_quota": cpu_quota(), "kind": "reference",
                                     "sample": f"first {n_scans} scans of the replay queue, non-lifelong, reference karto::Mapper::Process with its "
                                               f"CPU scan matcher ({t_ref:.1f} s); the library's mapper on the same scans: {t_hip:.2f} s"},
             "replay_poses_identical_to_reference": same, "replay_map_iou_vs_reference": iou,
@@ -960,7 +961,7 @@ def spawn_ranks(args):
 # long texts (workload descriptions, notes, per-form arrays) go to the details file, not into the line
 LINE_ORDER = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "solve_ms", "solve_ms_cached_analysis", "solve_ms_edge_sharded", "loop_batch_ms", "loop_pairs_per_s", "replay_scans_per_s",
-              "match_scan_ms", "value_windows", "value_no_skipping", "value_dense_world", "roofline", "cpu_baseline"]
+              "match_scan_ms", "value_windows", "value_no_skipping", "value_dense_world", "roofline", "cpu_baseline", "solve_rooflines"]
 LINE_BUDGET = 6000
 
 

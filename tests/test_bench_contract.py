@@ -116,9 +116,30 @@ def test_loop_and_solver_rooflines_carry_the_recorded_traffic():
     assert got is not None and abs(got - want) / want < 0.03
     assert 0.0 < d["loop_rooflines"][0]["frac"] <= 1.0
     spa = _recorded(f"{ROUND}_spa_pmc.json")
-    want = _traffic(spa, ("k_potrf", "k_trsm", "k_syrk", "k_extend_add"), spa["factorizations"])
+    want = _traffic(spa, ("k_potrf", "k_trsm", "k_syrk", "k_front_update", "k_extend_add"), spa["factorizations"])
     k6 = d["solve_rooflines"][0]
     assert k6["traffic"] is not None and abs(k6["traffic"] - want) / want < 0.05
     assert 0.0 < k6["frac"] <= 1.0 and k6["unit"] == "TFLOP/s"
     # flops = 2 x multiply-adds of the symbolic analysis, per factorisation
     assert abs(k6["flops_per_factorization"] - 2.0 * k6["multiply_adds_per_factorization"]) < 1.0
+
+
+def test_the_printed_line_carries_the_solver_roofline():
+    """Round 5's driver line lost `solve_rooflines` to the line budget: from round 6 on it is one of the ordered
+    keys, and the compact line the bench prints (profiles/rN_bench_line_compact.json) must hold it, with the same numbers as the
+    full record, next to every *_cpu_baseline's cores AND cpu_quota."""
+    if _round_number(ROUND) < 6:
+        return
+    with open(os.path.join(PROF, f"{ROUND}_bench_line_compact.json")) as f:
+        c = json.loads(f.read().strip().splitlines()[-1])
+    d = _line()
+    assert "solve_rooflines" in c and len(c["solve_rooflines"]) == 2
+    for a, b in zip(c["solve_rooflines"], d["solve_rooflines"]):
+        for k in ("achieved", "peak", "frac", "unit", "traffic"):
+            assert k in a
+            assert a[k] == b[k] or abs(a[k] - b[k]) <= 1e-5 * abs(b[k]), (k, a[k], b[k])
+    for k in ("cpu_baseline", "loop_cpu_baseline", "replay_cpu_baseline"):
+        if k in d:
+            assert "cores" in d[k] and "cpu_quota" in d[k], k
+    # the profiles the solver's figures come from are this round's
+    assert os.path.exists(os.path.join(PROF, f"{ROUND}_spa_pmc.json")) and os.path.exists(os.path.join(PROF, f"{ROUND}_spa_levels_timeline.txt"))
