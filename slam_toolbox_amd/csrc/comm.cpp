@@ -93,6 +93,12 @@ struct kh_comm
   int32_t device = 0, rank = 0, world = 1;
 };
 
+namespace kh
+{
+// (library-internal: the mapper's host code is free of HIP) waits for everything queued on the stream
+void stream_synchronize(void * hip_stream) {(void)hipStreamSynchronize(static_cast<hipStream_t>(hip_stream));}
+}  // namespace kh
+
 extern "C" {
 
 int kh_comm_unique_id(uint8_t id[KH_COMM_ID_BYTES])

@@ -43,7 +43,7 @@ public:
     if (n == 0) {return;}
     // a region entered from inside a region (fn calling run() again, on the caller thread or on a worker) runs in line: the
     // flag, not a try_lock on a mutex this thread may already own (undefined behaviour)
-    if (n == 1 || workers_.empty() || inside_region()) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
+    if (n == 1 || workers_.empty() || (inside_region() & bit_) != 0) {for (size_t i = 0; i < n; ++i) {fn(i);} return;}
     // one parallel region at a time; a second handle arriving from another thread while the workers are taken does its
     // loop itself instead of queueing behind the first (the regions are short: waiting would idle the caller's GPU stream)
     std::unique_lock<std::mutex> serial(run_mu_, std::try_to_lock);
@@ -97,17 +97,21 @@ private:
   {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAKE_PRIVATE, INT32_MAX, nullptr, nullptr, 0);
   }
-  explicit HostPool(int wide_pool)
+  explicit HostPool(int wide_pool) : bit_(wide_pool ? 2u : 1u)
   {
     static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the futex word is the atomic itself");
     unsigned want = std::min(wide_pool ? 64u : 32u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char * e = std::getenv(wide_pool ? "KH_MAPPER_UPDATE_THREADS" : "KH_HOST_THREADS")) {want = static_cast<unsigned>(std::max(1, std::atoi(e)));}
     for (unsigned t = 1; t < want; ++t) {workers_.emplace_back([this] {loop();});}
   }
-  static bool & inside_region() {static thread_local bool inside = false; return inside;}
+  // the pools whose regions this thread is running an item of, one bit per pool (per pool: a region of one pool may hand a loop to
+  // the other; a region re-entered at any depth runs in line)
+  static uint32_t & inside_region() {static thread_local uint32_t inside = 0; return inside;}
+  const uint32_t bit_;
   void work()
   {
-    inside_region() = true;
+    const uint32_t outer = inside_region();
+    inside_region() = outer | bit_;
     for (;;) {
       const size_t i = next_.fetch_add(1);
       if (i >= n_) {break;}
@@ -119,7 +123,7 @@ private:
         next_.store(n_, std::memory_order_relaxed);
       }
     }
-    inside_region() = false;
+    inside_region() = outer;
   }
   void loop()
   {

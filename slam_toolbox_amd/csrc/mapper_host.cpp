@@ -35,6 +35,8 @@
 
 namespace kh
 {
+void stream_synchronize(void * hip_stream);      // comm.cpp
+
 void set_error(const std::string & s);
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
 void host_parallel_for_wide(size_t n, const std::function<void(size_t)> & fn);
@@ -824,7 +826,12 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     const int rc = kh_matcher_match(m->seq, &q, base.data(), static_cast<int32_t>(base.size()), 1, 1, mean, cov, &response);
     m->stats.match_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     m->stats.matches += 1;
-    if (rc) {return rc;}
+    if (rc) {
+      // an early return of the match (invalid argument, empty query, a HIP error) may leave the uploads queued above in flight:
+      // wait for them, so that no other stream reads a copy marked fresh while it is still arriving
+      kh::stream_synchronize(seq_stream);
+      return rc;
+    }
     // KH_MAPPER_DUMP_MATCH=<scan id>:<path> (debugging aid): the inputs and the result of this sequential match as raw doubles
     // (n_base, n_beams, query pose, query ranges, per base scan: pose, ranges; mean, covariance, response)
     static const char * dump_spec = std::getenv("KH_MAPPER_DUMP_MATCH");

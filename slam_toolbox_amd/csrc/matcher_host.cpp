@@ -55,6 +55,7 @@ void fill_raster_job(const kh_matcher * m, const Slot & s, const double * pose, 
   }
 }
 
+constexpr int kNoFirstPointTable = -1000;      // internal: ensure_seq_tables could not allocate a slot's first-point table
 int ensure_seq_tables(kh_matcher * m, Slot & s, int32_t n_points, RasterJob & j)
 {
   hipStream_t st = m->stream;
@@ -73,7 +74,14 @@ int ensure_seq_tables(kh_matcher * m, Slot & s, int32_t n_points, RasterJob & j)
   const size_t roi_cells = static_cast<size_t>(m->roi_w) * m->roi_h;
   if (roi_cells > s.cap_first) {
     if (s.d_first) {KH_HIP(hipStreamSynchronize(st)); KH_HIP(hipFree(s.d_first)); s.d_first = nullptr;}
-    KH_HIP(hipMalloc(reinterpret_cast<void **>(&s.d_first), roi_cells * sizeof(int32_t)));
+    // (the tables were budgeted at create, 4 B x cells of the region of interest per slot, but are allocated here: when the device
+    // cannot give one -- other handles, other tenants -- this handle goes back to the hash-table rasteriser for good)
+    if (hipMalloc(reinterpret_cast<void **>(&s.d_first), roi_cells * sizeof(int32_t)) != hipSuccess) {
+      (void)hipGetLastError();
+      s.d_first = nullptr; s.cap_first = 0;
+      m->table_raster = false;
+      return kNoFirstPointTable;
+    }
     s.cap_first = roi_cells; s.first_clean = false;
   }
   if (!s.first_clean) {
@@ -155,6 +163,7 @@ int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
   ValidItem * items = reinterpret_cast<ValidItem *>(m->h_meta + items_at);
   size_t item = 0;
   for (size_t r = 0; r < n_jobs; ++r) {
+    if (r == 0) {max_points = 0; max_cap = 0; max_scan_n = 1; any_copies = false; item = 0;}      // (also on the restart below)
     Slot & s = m->slots[reqs[r].slot];
     const double * pose = reqs[r].query->sensor_pose;
     // MatchScan steps 1-4, Mapper.cpp:543-569
@@ -188,7 +197,9 @@ int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs)
     any_copies = any_copies || s.d_grid2 != nullptr;
     j.n_foot = n_foot;
     if (use_table) {
-      rc = ensure_seq_tables(m, s, points_of[r], j); if (rc) {return rc;}
+      rc = ensure_seq_tables(m, s, points_of[r], j);
+      if (rc == kNoFirstPointTable) {use_table = false; r = static_cast<size_t>(-1); continue;}      // the jobs again, with the hash tables
+      if (rc) {return rc;}
       s.first_clean = false;                      // until this batch's stamping launch has handed the table back
     } else if (n_foot > 0) {
       // AddScan's "cell already occupied -> skip" (Mapper.cpp:1093-1096) is order dependent as soon as the smear kernel

@@ -22,6 +22,8 @@ struct SeqState
   SeqFineOut * h_fine = nullptr;
   int32_t * h_flag = nullptr;
   int32_t seq = 0;
+  bool ready = false;                     // the one-time blocks below (job, mid, fine sums, host-coherent result and flag) all exist
+  bool unavailable = false;               // sticky: this platform hands out no host-coherent memory (kh_matcher_set_debug does not clear it)
   long long * d_dbg = nullptr;            // KH_SEQ_TIMING=1: phase stamps of kseq_bin [0..7], kseq_prep [8..15], the final kernels [16..31]
   double dbg_acc[32] = {0}; long dbg_calls = 0;
   std::vector<uint8_t> fine_scratch;
@@ -59,9 +61,9 @@ const int64_t * seq_stats(const kh_matcher * m)
 template <class T>
 static int ensure_coherent(T *& p, size_t & cap, size_t need)
 {
-  if (need <= cap) {return KH_OK;}
-  if (p) {KS_HIP(hipHostFree(p)); p = nullptr;}
+  if (need <= cap && p) {return KH_OK;}
   const size_t n = std::max(need, cap + cap / 2);
+  if (p) {cap = 0; KS_HIP(hipHostFree(p)); p = nullptr;}
   KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), n * sizeof(T), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
   cap = n;
   return KH_OK;
@@ -90,10 +92,15 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   static const bool env_off = std::getenv("KH_SEQ_FUSED") != nullptr && std::atoi(std::getenv("KH_SEQ_FUSED")) == 0;
   if (env_off || m->no_seq) {return KH_OK;}
   if (!m->seq) {m->seq = new SeqState();}
+  if (m->seq->unavailable) {return KH_OK;}
   // a call the kernels' fixed-size tables cannot take goes the general way; stats [6] counts them, [7] keeps the last reason
   auto ineligible = [&](int64_t reason) {m->seq->stats[6] += 1; m->seq->stats[7] = reason; return KH_OK;};
   // a platform that does not hand out host-coherent mapped memory keeps the general path for this handle (reason 7)
-  auto no_coherent_memory = [&]() {m->no_seq = true; (void)hipStreamSynchronize(m->stream); m->slots[0].first_clean = false; return ineligible(7);};
+  // (its own flag: kh_matcher_set_debug rewrites m->no_seq from its bit 7 on every call)
+  auto no_coherent_memory = [&]() {
+    (void)hipGetLastError();
+    m->seq->unavailable = true; (void)hipStreamSynchronize(m->stream); m->slots[0].first_clean = false; return ineligible(7);
+  };
   if (m->profiling || m->keep_responses) {return ineligible(1);}
   if (query->n <= 0 || query->n > kSeqMaxReadings) {return ineligible(2);}
   // ---- eligibility: what the kernels' fixed-size tables can take
@@ -125,19 +132,22 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   const size_t npad = (static_cast<size_t>(np) + 3) & ~static_cast<size_t>(3);
   rc = ensure_device(s.d_ractive, s.cap_ractive, static_cast<size_t>(np), st); if (rc) {return rc;}
   rc = ensure_device(s.d_rlists, s.cap_rlists, npad * 10, st); if (rc) {return rc;}
-  if (!Q.d_job) {
-    KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_job), sizeof(RasterJob)));
-    KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_mid), sizeof(SeqMid)));
-    KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_fsum), sizeof(int32_t) * kSeqMaxFine));
-    size_t one = 0;
+  if (!Q.ready) {
+    // keyed on `ready`, not on the first pointer: a failure half way (the next call would have skipped the block and dereferenced the
+    // missing pieces) leaves what it allocated for the retry
+    if (!Q.d_job) {KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_job), sizeof(RasterJob)));}
+    if (!Q.d_mid) {KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_mid), sizeof(SeqMid)));}
+    if (!Q.d_fsum) {KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_fsum), sizeof(int32_t) * kSeqMaxFine));}
+    size_t one = Q.h_fine ? 1 : 0;
     rc = ensure_coherent(Q.h_fine, one, 1); if (rc) {return no_coherent_memory();}
-    one = 0;
+    one = Q.h_flag ? 16 : 0;
     rc = ensure_coherent(Q.h_flag, one, 16); if (rc) {return no_coherent_memory();}
     Q.h_flag[0] = 0;
-    if (std::getenv("KH_SEQ_TIMING")) {
+    if (std::getenv("KH_SEQ_TIMING") && !Q.d_dbg) {
       KS_HIP(hipMalloc(reinterpret_cast<void **>(&Q.d_dbg), sizeof(long long) * 32));
       KS_HIP(hipMemset(Q.d_dbg, 0, sizeof(long long) * 32));
     }
+    Q.ready = true;
   }
   const bool fused_tiles = m->kernel_size >= 8;
   // scans the caller does not keep on the device: one upload of their points (the matcher's arena, as in the batch path)

@@ -64,6 +64,7 @@ class LocalizedRangeScan:
 
     _resident = None
     _c_points = None
+    _c_ranges = None
     _c = None          # the kh_scan view of this scan, rebuilt after Update() / MakeResident (building one costs more than a match's launch)
 
     def SetSensorPose(self, pose):
@@ -92,7 +93,10 @@ class LocalizedRangeScan:
         return self.ranges.shape[0]
 
     def c(self) -> capi.KhScan:
-        if self._c is not None and self._c_points is self.points:
+        # (the struct holds raw pointers into ranges / points and the pose by value: it is rebuilt when any of them was replaced
+        # or the pose edited in place)
+        if (self._c is not None and self._c_points is self.points and self._c_ranges is self.ranges
+                and all(self._c.sensor_pose[i] == self.sensor_pose[i] for i in range(3))):
             return self._c
         s = capi.KhScan()
         s.n = self.ranges.shape[0]
@@ -101,7 +105,7 @@ class LocalizedRangeScan:
         for i in range(3):
             s.sensor_pose[i] = self.sensor_pose[i]
         s.device_points_xy = self._resident.ptr if self._resident is not None else None
-        self._c, self._c_points = s, self.points
+        self._c, self._c_points, self._c_ranges = s, self.points, self.ranges
         return s
 
 
