@@ -614,6 +614,25 @@ def latency_leg(device=0):
                 hm.CorrelateScan(q, sc.query_pose, *args, True)
             row["single_correlate_scan_ms"] = (time.perf_counter() - t) / n * 1e3
             row["single_correlate_scan_per_s"] = 1e3 / row["single_correlate_scan_ms"]
+        # algorithmic bytes of ONE MatchScan = B_rast + sum of B_corr over its CorrelateScan calls (coarse, then fine), with
+        # B_corr = nPoses * P * 5 + nPoses * 32 + A * P * 4 and B_rast = grid bytes (Grid::Clear) + 16 B per point -- the stamps'
+        # read-modify-write term (<= cells * k^2 * 2) is left out, so the figure is a lower bound of the reference's access stream
+        from common import PRESETS as _PRESETS
+        size, res = _PRESETS[preset]["create"][0], _PRESETS[preset]["create"][1]
+        prm = _PRESETS[preset]["params"]
+        P = 1081
+        nxy = int(round(size / (2.0 * res))) + 1
+        na = int(round(2.0 * prm["coarse_search_angle_offset"] / prm["coarse_angle_resolution"])) + 1
+        naf = int(round(prm["coarse_angle_resolution"] / prm["fine_search_angle_offset"])) + 1
+        b_corr = lambda n_poses, n_ang: n_poses * P * 5 + n_poses * 32 + n_ang * P * 4
+        gi = hm.grid_info()
+        b_rast = int(gi["data_size"]) + sum(int(scan.points.size // 2) for scan in b) * 16
+        total = b_rast + b_corr(nxy * nxy * na, na) + b_corr(9 * naf, naf)
+        wall = row["base_scans_resident_ms"] * 1e-3
+        row["roofline"] = {"bound": "hbm", "achieved": total / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": total / wall / 1e9 / HBM_PEAK_GBS,
+                           "algorithmic_bytes": total, "b_rast": b_rast, "b_corr_coarse": b_corr(nxy * nxy * na, na), "b_corr_fine": b_corr(9 * naf, naf),
+                           "coarse_poses": nxy * nxy * na, "fine_poses": 9 * naf, "wall_ms": wall * 1e3, "traffic": None,
+                           "note": "wall time of one call (base scans resident), nine dependent launches; kernel-time sums: profiles/rN_seq_*_kernel_stats.csv"}
         hm.close()
         out[preset] = row
     # config[1]'s geometry as FULL MatchScans in one batch (rasterise + coarse 31 x 31 x 81 + fine per pair): 64 pairs per call
@@ -638,6 +657,8 @@ def latency_leg(device=0):
     return {"single_call_latency": out,
             # the same, short enough to sit in front of the line: ONE MatchScan (penalise + refine) per call, ms
             "match_scan_ms": {p: out[p]["base_scans_resident_ms"] for p in out} | {p + "_uploaded": out[p]["base_scans_uploaded_per_call_ms"] for p in out},
+            "match_scan_roofline": {p: {k: out[p]["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes", "wall_ms", "traffic")} | {"bound": "hbm"}
+                                    for p in out},
             "config2_match_scan_batch_ms": batch_ms, "config2_match_scans_per_s": 64.0 / (batch_ms * 1e-3),
             "config2_match_scan_workload": "64 (query, 10 base scans) pairs per kh_matcher_match_batch at config[1]'s geometry: AddScans + coarse "
                                            "CorrelateScan 31 x 31 x 81 poses + fine pass (SURVEY 8d), base scans resident",
@@ -763,7 +784,7 @@ def replay_cpu_baseline(n_scans=1500):
             "replay_reference_pose_error_xy_rms_m": float(np.sqrt((d[:, :2] ** 2).sum(1).mean()))}
 
 
-def replay_leg(device=0, n_scans=3000, cpu=True):
+def replay_leg(device=0, n_scans=3000, cpu=True, full_length=True):
     """BASELINE config[4]: lifelong-mode replay, end to end on one GPU -- scan queue -> mapper front end of the library
     (sequential match, links, speculative loop closure, SPA solves, node decay) -> occupancy grid (extra keys).  The
     default run replays a bounded prefix, once with every scan processed (sync) and once behind the asynchronous node's
@@ -777,7 +798,7 @@ def replay_leg(device=0, n_scans=3000, cpu=True):
            f"{st['matches']} matches", "replay_wall_s": out["wall_s"], "replay_closures": int(st["loop_closures"]),
            "replay_matches": int(st["matches"]), "replay_fused_matches": int(st.get("fused_matches", 0)),
            "replay_fused_fine_passes": int(st.get("fused_fine_passes", 0)),
-           "replay_ms_split": {"match": st["match_ms"], "solver": st["solver_ms"], "pose_updates": st["update_ms"], "node_decay": st["lifelong_ms"]},
+           "replay_ms_split": out["ms_split"],
            "replay_map_build_ms": out["map_build_ms"], "replay_map_iou_vs_truth_poses": out["map_iou_vs_truth_poses"],
            "replay_map_occupied_within_one_cell_of_truth_map": out["map_occupied_within_one_cell_of_truth_map"],
            "replay_pose_error_xy_rms_m": out["pose_error_xy_rms_m"], "replay_pose_error_xy_max_m": out["pose_error_xy_max_m"],
@@ -786,6 +807,21 @@ def replay_leg(device=0, n_scans=3000, cpu=True):
                                    "removes vertices together with their edges and keeps nothing connected: on a circuit driven lap after lap the pose "
                                    "graph falls apart into replay_graph_components pieces and the map drifts with it; the same queue WITHOUT node decay "
                                    "(replay_nonlifelong_*, poses identical to the reference mapper's) is the accuracy reference"}
+    # the SAME queue without node decay: the run whose poses are pinned to the reference mapper's bit for bit (replay_cpu_baseline,
+    # tools/replay_vs_reference.py) and whose map is usable -- the honest end-to-end figure next to the lifelong one
+    nl = replay.run(n_scans, lifelong=False, mode="sync", device=device)
+    res["replay_nonlifelong_scans_per_s"] = nl["scans_per_s"]
+    res["replay_nonlifelong"] = {"scans_per_s": nl["scans_per_s"], "wall_s": nl["wall_s"], "accepted": nl["accepted"], "closures": int(nl["stats"]["loop_closures"]),
+                                 "map_iou_vs_truth_poses": nl["map_iou_vs_truth_poses"], "pose_error_xy_rms_m": nl["pose_error_xy_rms_m"],
+                                 "graph_components": nl["graph_components"], "ms_split": nl["ms_split"]}
+    if full_length:
+        # config[4] at its stated size: 50 000 scans, lifelong, sync queue (13 s of replay + the queue's range noise)
+        big = replay.run(50000, lifelong=True, mode="sync", device=device)
+        res["replay_50k_scans_per_s"] = big["scans_per_s"]
+        res["replay_50k"] = {"scans_per_s": big["scans_per_s"], "wall_s": big["wall_s"], "accepted": big["accepted"], "alive": big["alive"],
+                             "closures": int(big["stats"]["loop_closures"]), "matches": int(big["stats"]["matches"]),
+                             "map_iou_vs_truth_poses": big["map_iou_vs_truth_poses"], "pose_error_xy_rms_m": big["pose_error_xy_rms_m"],
+                             "graph_components": big["graph_components"], "ms_split": big["ms_split"]}
     period, n_async = 0.025, 800                      # 40 Hz (UTM-30LX): 20 s of wall time when nothing is dropped
     a = replay.run(n_async, lifelong=True, mode="async", period_s=period, device=device)
     res["replay_async"] = {"period_s": period, "scans": n_async, "processed": a["processed"], "dropped": a["dropped"], "wall_s": a["wall_s"],
@@ -961,7 +997,8 @@ def spawn_ranks(args):
 # long texts (workload descriptions, notes, per-form arrays) go to the details file, not into the line
 LINE_ORDER = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "solve_ms", "solve_ms_cached_analysis", "solve_ms_edge_sharded", "loop_batch_ms", "loop_pairs_per_s", "replay_scans_per_s",
-              "match_scan_ms", "value_windows", "value_no_skipping", "value_dense_world", "roofline", "cpu_baseline", "solve_rooflines"]
+              "replay_nonlifelong_scans_per_s", "replay_50k_scans_per_s",
+              "match_scan_ms", "value_windows", "value_no_skipping", "value_dense_world", "roofline", "cpu_baseline", "solve_rooflines", "match_scan_roofline"]
 LINE_BUDGET = 6000
 
 
@@ -1020,6 +1057,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solver", action="store_true")
     ap.add_argument("--no-loop", action="store_true")
+    ap.add_argument("--no-replay-50k", action="store_true", help="skip config[4] at its stated size (50 000 scans: ~25 s with the queue's making)")
     ap.add_argument("--no-variants", action="store_true", help="skip the no-skipping / dense-world variants of the headline")
     ap.add_argument("--details", default=os.path.join(ROOT, "profiles", "bench_details_latest.json"),
                     help="where the full record (every key, notes, workload texts) is written; '' = nowhere")
@@ -1310,7 +1348,7 @@ def main():
             full.update(enumeration_leg(local_rank))
             full.update(occupancy_leg(local_rank))
             try:
-                full.update(replay_leg(local_rank, cpu=not args.no_cpu_baseline))
+                full.update(replay_leg(local_rank, cpu=not args.no_cpu_baseline, full_length=not args.no_replay_50k))
                 full.update(latency_leg(local_rank))
             except Exception as exc:
                 full["replay_leg_error"] = repr(exc)[:200]

@@ -168,6 +168,12 @@ def run(n_scans: int, lifelong: bool = True, mode: str = "sync", period_s: float
                        "pose_error_xy_rms_m": float(np.sqrt((da[:, :2] ** 2).sum(1).mean())),
                        "pose_error_heading_max_rad": float(np.abs(da[:, 2]).max())},
            "stats": st}
+    # where the wall time of the replay loop went: inside kh_mapper_process (the mapper's own split; `other_in_process` = scan update,
+    # graph store sync, candidate enumeration, links) and outside it (this loop, ctypes marshalling of 1081 ranges per scan)
+    known = st["match_ms"] + st["solver_ms"] + st["update_ms"] + st["lifelong_ms"]
+    out["ms_split"] = {"match": st["match_ms"], "solver": st["solver_ms"], "pose_updates": st["update_ms"], "node_decay": st["lifelong_ms"],
+                       "other_in_process": st["process_ms"] - known, "process_total": st["process_ms"],
+                       "outside_process_python_ctypes": (wall - waited_s) * 1e3 - st["process_ms"], "wall": (wall - waited_s) * 1e3}
     out["poses"] = poses
     out["alive_queue_index"] = [queue_index[k] for k in alive]
     ref_grid.close()
