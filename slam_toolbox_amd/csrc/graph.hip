@@ -219,6 +219,23 @@ int kh_graph_set(kh_graph * g, int32_t n_scans, const double * ref_xy, const int
   return KH_OK;
 }
 
+}  // extern "C"
+namespace kh
+{
+// (library-internal, the mapper's sync_graph) kh_graph_set without the copies: the store takes the caller's arrays and hands its old
+// ones back (same capacity next time); the caller built adj_idx from its own tables, so the range check is skipped.  A lifelong mapper
+// rebuilds the store after every node removal -- once per accepted scan, 18 000 scans alive in the 50 000-scan replay.
+int graph_swap(kh_graph * g, int32_t n_scans, std::vector<double> & ref_xy, std::vector<int32_t> & adj_ptr, std::vector<int32_t> & adj_idx)
+{
+  if (!g || n_scans < 0 || ref_xy.size() != 2 * static_cast<size_t>(n_scans) || adj_ptr.size() != static_cast<size_t>(n_scans) + 1) {return KH_ERR_INVALID_ARG;}
+  g->device_stale = true;
+  g->n = n_scans; g->n_visit = n_scans;
+  g->h_xy.swap(ref_xy); g->h_adj_ptr.swap(adj_ptr); g->h_adj_idx.swap(adj_idx);
+  return KH_OK;
+}
+}  // namespace kh
+extern "C" {
+
 int kh_graph_append_scan(kh_graph * g, const double ref_xy[2])
 {
   if (!g || !ref_xy) {return KH_ERR_INVALID_ARG;}

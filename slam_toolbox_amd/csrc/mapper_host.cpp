@@ -36,6 +36,10 @@
 namespace kh
 {
 void stream_synchronize(void * hip_stream);      // comm.cpp
+int decay_scores(int32_t device, const kh_scan_box * reference, int32_t n, const kh_scan_box * candidates, const double * const * resident,
+  const uint64_t * const * masks, int32_t n_scan, const kh_decay_params * params, int32_t * kept, double * iou, double * area_overlap,
+  double * reading_overlap, double * scores);                                                                       // lifelong.hip
+int graph_swap(kh_graph * g, int32_t n_scans, std::vector<double> & ref_xy, std::vector<int32_t> & adj_ptr, std::vector<int32_t> & adj_idx);   // graph.hip
 
 void set_error(const std::string & s);
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
@@ -132,6 +136,7 @@ struct MScan
   std::vector<double> ranges;
   std::vector<double> points;        // unfiltered point readings, x0 y0 x1 y1 ...
   std::vector<double> filtered;      // point readings with the range inside [minimum range, range threshold]
+  std::vector<uint64_t> filter_mask; // bit i: reading i is one of `filtered` (the node-decay kernel reads `points` in HBM through it)
   double score = 1.0;                // Vertex::GetScore (Mapper.h: vertices start at 1.0)
   double barycenter[2] = {0.0, 0.0};
   double bbox[4] = {0.0, 0.0, 0.0, 0.0};   // min x, min y, max x, max y of the sensor position and the filtered readings
@@ -183,6 +188,7 @@ void update_scan(MScan & s, const Laser & L)
   s.points.resize(2 * static_cast<size_t>(L.n));
   s.d_fresh = 0;
   s.filtered.clear();
+  s.filter_mask.assign((static_cast<size_t>(L.n) + 63) / 64, 0);
   double sum_x = 0.0, sum_y = 0.0;
   int32_t n_filtered = 0;
   double bb[4] = {sp.x, sp.y, sp.x, sp.y};
@@ -197,6 +203,7 @@ void update_scan(MScan & s, const Laser & L)
     if (r >= L.min_range && r <= L.range_threshold) {          // math::InRange
       sum_x += px; sum_y += py; ++n_filtered;
       s.filtered.push_back(px); s.filtered.push_back(py);
+      s.filter_mask[static_cast<size_t>(i) >> 6] |= 1ull << (i & 63);
       bb[0] = std::min(bb[0], px); bb[1] = std::min(bb[1], py); bb[2] = std::max(bb[2], px); bb[3] = std::max(bb[3], py);
     }
   }
@@ -234,6 +241,9 @@ struct kh_mapper
   std::vector<std::unique_ptr<MScan>> scans;             // processed scans, index = state id = unique id; null once removed
   std::vector<int32_t> alive;                            // ids still in the scan map, ascending: the graph store's scan list
   std::vector<int32_t> compact_of;                       // id -> position in `alive`, -1 when removed
+  std::vector<double> sync_xy; std::vector<int32_t> sync_ptr, sync_idx;      // sync_graph's scratch (swapped with the store's arrays)
+  // KH_MAPPER_TIMING=1 (measurement aid): wall time per piece of the host code, printed by kh_mapper_destroy
+  double prof_ms[12] = {0}; long prof_n[12] = {0};
   bool lifelong = false;
   kh_decay_params decay;
   std::vector<int32_t> running;
@@ -315,16 +325,29 @@ void reference_xy(const kh_mapper * m, const MScan & s, double xy[2])     // Get
 
 // the graph store the enumeration kernels and the near-chain walks read: reference positions + adjacency of the scans
 // still in the map, in id order (a removed scan is a NULL entry the reference's walks skip)
+struct ProfScope
+{
+  kh_mapper * m; int k; std::chrono::steady_clock::time_point t0;
+  ProfScope(kh_mapper * m_, int k_) : m(m_), k(k_), t0(std::chrono::steady_clock::now()) {}
+  ~ProfScope() {m->prof_ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); m->prof_n[k] += 1;}
+};
+static const char * const kProfNames[12] = {"sync_graph", "near_linked", "decay_boxes", "decay_scores", "remove_node", "update_scan(new)", "add_to_graph",
+                                           "loop_enumeration", "link_near_chains", "", "", ""};
+
 int sync_graph(kh_mapper * m)
 {
+  ProfScope prof(m, 0);
   m->alive.clear();
   m->compact_of.assign(m->scans.size(), -1);
   for (size_t i = 0; i < m->scans.size(); ++i) {
     if (m->scans[i]) {m->compact_of[i] = static_cast<int32_t>(m->alive.size()); m->alive.push_back(static_cast<int32_t>(i));}
   }
   const size_t n = m->alive.size();
-  std::vector<double> xy(2 * n);
-  std::vector<int32_t> ptr(n + 1, 0), idx;
+  // (scratch kept by the mapper and swapped with the store's arrays: no allocation, no copy -- see kh::graph_swap)
+  std::vector<double> & xy = m->sync_xy;
+  std::vector<int32_t> & ptr = m->sync_ptr, & idx = m->sync_idx;
+  xy.resize(2 * n); ptr.resize(n + 1); idx.clear();
+  ptr[0] = 0;
   for (size_t c = 0; c < n; ++c) {
     reference_xy(m, *m->scans[m->alive[c]], &xy[2 * c]);
     ptr[c + 1] = ptr[c] + static_cast<int32_t>(m->adj[m->alive[c]].size());
@@ -333,7 +356,7 @@ int sync_graph(kh_mapper * m)
   for (size_t c = 0; c < n; ++c) {
     for (int32_t w : m->adj[m->alive[c]]) {idx.push_back(m->compact_of[w]);}
   }
-  int rc = kh_graph_set(m->graph, static_cast<int32_t>(n), xy.data(), ptr.data(), idx.data());
+  int rc = kh::graph_swap(m->graph, static_cast<int32_t>(n), xy, ptr, idx);
   if (rc) {return rc;}
   // the reference bounds its candidate walks by the scan map's SIZE, in id space (Mapper.cpp:1974-1976, 1751-1756)
   const int32_t n_visit = static_cast<int32_t>(std::lower_bound(m->alive.begin(), m->alive.end(), static_cast<int32_t>(n)) - m->alive.begin());
@@ -525,8 +548,11 @@ int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
     // every chain successive FindPossibleLoopClosure calls would return from `start` on, for the CURRENT poses
     std::vector<int32_t> chain_begin(2, 0), flat(2 * static_cast<size_t>(m->max_candidates));
     int32_t n_chains = 0;
-    int rc = kh_graph_find_loop_candidates_from(m->graph, 1, &query, &start, m->p.loop_search_maximum_distance,
+    int rc;
+    {ProfScope prof(m, 7);
+    rc = kh_graph_find_loop_candidates_from(m->graph, 1, &query, &start, m->p.loop_search_maximum_distance,
         m->p.loop_match_minimum_chain_size, chain_begin.data(), flat.data(), m->max_candidates, &n_chains);
+    }
     if (rc) {return rc;}
     if (n_chains > m->max_candidates) {
       flat.resize(2 * static_cast<size_t>(n_chains));
@@ -591,6 +617,7 @@ int try_close_loop(kh_mapper * m, int32_t scan_id, bool & closed)
 // Mapper::RemoveNodeFromGraph (Mapper.cpp:2964-3021) + MapperSensorManager::RemoveScan (:208-218)
 int remove_node(kh_mapper * m, int32_t id)
 {
+  ProfScope prof(m, 4);
   if (id < 0 || id >= static_cast<int32_t>(m->scans.size()) || !m->scans[id]) {
     set_error("RemoveNode: Failed to find node matching id");
     return KH_ERR_NOT_FOUND;
@@ -644,7 +671,11 @@ int lifelong_step(kh_mapper * m, int32_t id)
   if (m->graph_dirty) {const int rc = sync_graph(m); if (rc) {return rc;}}
   std::vector<int32_t> near(64);
   int32_t n = 0;
-  int rc = kh_graph_find_near_linked(m->graph, m->compact_of[id], radius, near.data(), static_cast<int32_t>(near.size()), &n);
+  int rc;
+  {
+  ProfScope prof(m, 1);
+  rc = kh_graph_find_near_linked(m->graph, m->compact_of[id], radius, near.data(), static_cast<int32_t>(near.size()), &n);
+  }
   if (rc) {return rc;}
   if (n > static_cast<int32_t>(near.size())) {
     near.resize(static_cast<size_t>(n));
@@ -655,10 +686,29 @@ int lifelong_step(kh_mapper * m, int32_t id)
   for (int32_t & c : near) {c = m->alive[c];}                     // graph store positions -> scan ids
   const kh_scan_box ref = box_of(m, s);
   std::vector<kh_scan_box> cands;
-  for (int32_t c : near) {cands.push_back(box_of(m, *m->scans[c]));}
+  // the candidates' readings where the matcher left them in HBM (a copy a pose update made stale is refreshed first); a scan
+  // without a device copy (slot allocation failed) sends the whole call down the packed form
+  std::vector<const double *> resident;
+  std::vector<const uint64_t *> masks;
+  bool all_resident = m->laser.n <= 4096;
+  {ProfScope prof(m, 2);
+  for (int32_t c : near) {
+    MScan & cs = *m->scans[c];
+    cands.push_back(box_of(m, cs));
+    // (a candidate inside the scan buffer, and vertices 0 and 1, keep their score whatever their readings say, :204-207: the mapper
+    // does not read the overlap metrics, so their readings are not fetched -- the new scan itself, always a candidate, has no copy yet)
+    const bool score_kept = s.id - cs.id < m->decay.scan_buffer_size || cs.id == 0 || cs.id == 1;
+    const double * d = (all_resident && !score_kept) ? resident_points(m, cs, 0) : nullptr;
+    if (!d && !score_kept) {all_resident = false;}
+    resident.push_back(d); masks.push_back(cs.filter_mask.data());
+  }
+  }
   std::vector<int32_t> kept(near.size(), 0);
   std::vector<double> scores(near.size(), 0.0);
-  rc = kh_lifelong_scores(m->device, &ref, n, cands.data(), &m->decay, kept.data(), nullptr, nullptr, nullptr, scores.data());
+  {ProfScope prof(m, 3);
+  rc = kh::decay_scores(m->device, &ref, n, cands.data(), all_resident ? resident.data() : nullptr, all_resident ? masks.data() : nullptr,
+      all_resident ? m->laser.n : 0, &m->decay, kept.data(), nullptr, nullptr, nullptr, scores.data());
+  }
   if (rc) {return rc;}
   for (size_t k = 0; k < near.size(); ++k) {
     if (!kept[k]) {continue;}
@@ -754,6 +804,11 @@ int kh_mapper_create(const kh_mapper_params * params, const kh_laser * laser, in
 void kh_mapper_destroy(kh_mapper * m)
 {
   if (!m) {return;}
+  if (std::getenv("KH_MAPPER_TIMING")) {
+    std::fprintf(stderr, "[kh_mapper] host pieces (ms, calls):");
+    for (int k = 0; k < 12; ++k) {if (m->prof_n[k]) {std::fprintf(stderr, "  %s %.1f (%ld)", kh::kProfNames[k], m->prof_ms[k], m->prof_n[k]);}}
+    std::fprintf(stderr, "\n");
+  }
   if (m->log) {std::fclose(m->log);}
   kh_matcher_group_destroy(m->seq_group); kh_matcher_group_destroy(m->loop_group);
   kh_spa_destroy(m->solver); kh_graph_destroy(m->graph);
@@ -811,7 +866,7 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     }
     if (!moved) {return KH_OK;}
   }
-  update_scan(*scan, m->laser);
+  {ProfScope prof(m, 5); update_scan(*scan, m->laser);}
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   // correct the scan against the running scans (:2713-2724)
   if (m->p.use_scan_matching && last) {
@@ -870,7 +925,8 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     // AddVertex (:1418-1432): the solver node carries the corrected pose
     const double node[3] = {s.corrected.x, s.corrected.y, s.corrected.h};
     if (m->log) {std::fprintf(m->log, "N %d %.17g %.17g %.17g\n", id, node[0], node[1], node[2]);}
-    int rc = kh_spa_add_node(m->solver, id, node);
+    int rc;
+    {ProfScope prof(m, 6); rc = kh_spa_add_node(m->solver, id, node);}
     if (rc) {return rc;}
     // AddEdges (:1434-1498)
     std::vector<double> means, covs;
@@ -889,7 +945,9 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
       std::vector<int32_t> flat(2 * static_cast<size_t>(m->max_candidates));
       int32_t n_chains = 0;
       const int32_t query = m->compact_of[id];
+      {ProfScope prof(m, 8);
       rc = kh_graph_find_near_chains(m->graph, query, m->p.link_scan_maximum_distance, flat.data(), m->max_candidates, &n_chains);
+      }
       if (rc) {return rc;}
       if (n_chains > m->max_candidates) {
         flat.resize(2 * static_cast<size_t>(n_chains));
