@@ -399,6 +399,9 @@ KH_API int kh_device_upload(void * device_dst, const void * host_src, int64_t by
 /* the upload queued on a HIP stream (hipStream_t as void *, e.g. kh_matcher_stream): ordered in front of whatever is launched there next */
 KH_API int kh_device_upload_on(void * device_dst, const void * host_src, int64_t bytes, void * hip_stream);
 KH_API int kh_device_download(void * host_dst, const void * device_src, int64_t bytes);
+/* self-test of the once-per-device bookkeeping behind the kernels' dynamic-LDS attribute (csrc/lds_attr.hpp), run on made-up
+ * device ids; 0 = every check holds.  Needs no device: the CPU test suite calls it. */
+KH_API int kh_selftest_lds_attr(void);
 
 /* ---------------------------------------------------------------- loop-candidate enumeration (next row f-1) */
 /* GPU-resident copy of what karto::MapperGraph's candidate search reads: the reference position

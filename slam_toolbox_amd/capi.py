@@ -84,7 +84,7 @@ SYMBOLS = [
     "kh_decay_params_default", "kh_lifelong_scores",
     "kh_spa_set_comm", "kh_comm_unique_id", "kh_comm_create", "kh_comm_destroy", "kh_comm_rank", "kh_comm_world", "kh_comm_device",
     "kh_comm_allreduce_sum_f64", "kh_comm_allgather_f64",
-    "kh_device_malloc", "kh_device_free", "kh_device_upload", "kh_device_upload_on", "kh_device_download",
+    "kh_device_malloc", "kh_device_free", "kh_device_upload", "kh_device_upload_on", "kh_device_download", "kh_selftest_lds_attr",
     "kh_graph_find_loop_candidates_from",
     "kh_mapper_params_default", "kh_mapper_create", "kh_mapper_create_on_devices", "kh_mapper_destroy", "kh_mapper_process", "kh_mapper_num_scans",
     "kh_mapper_num_edges", "kh_mapper_get_poses", "kh_mapper_get_scan", "kh_mapper_get_stats", "kh_mapper_solver",
@@ -242,6 +242,8 @@ def lib():
         L.kh_device_upload.argtypes = [vp, vp, C.c_int64]
         L.kh_device_upload_on.argtypes = [vp, vp, C.c_int64, vp]
         L.kh_device_download.argtypes = [vp, vp, C.c_int64]
+        L.kh_selftest_lds_attr.argtypes = []
+        L.kh_selftest_lds_attr.restype = C.c_int
     if hasattr(L, "kh_graph_create"):
         L.kh_graph_create.argtypes = [i32, C.POINTER(vp)]
         L.kh_graph_destroy.argtypes = [vp]

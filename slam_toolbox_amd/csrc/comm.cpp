@@ -12,6 +12,8 @@
 // translated here, there is none.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include "lds_attr.hpp"
 #include <rccl/rccl.h>
 
 #include <cstdint>
@@ -205,6 +207,26 @@ int kh_device_upload_on(void * device_dst, const void * host_src, int64_t bytes,
     kh::set_error("hipMemcpyAsync H2D failed"); return KH_ERR_HIP;
   }
   return KH_OK;
+}
+
+/* the per-device bookkeeping of allow_dynamic_lds (lds_attr.hpp) driven with made-up device ids: 0 when every check holds,
+ * otherwise the number of the first check that failed.  Needs no device. */
+int kh_selftest_lds_attr(void)
+{
+  std::atomic<unsigned long long> done{0};
+  for (int dev = -1; dev < 70; ++dev) {if (!kh::lds_attr_pending(done, dev)) {return 1;}}           // nothing is set at the start
+  kh::lds_attr_mark(done, 3);
+  if (kh::lds_attr_pending(done, 3)) {return 2;}                                                    // a marked device is done ...
+  for (int dev = 0; dev < 70; ++dev) {if (dev != 3 && !kh::lds_attr_pending(done, dev)) {return 3;}} // ... and no other one with it (3 + 64 included)
+  kh::lds_attr_mark(done, 0); kh::lds_attr_mark(done, 63);
+  if (kh::lds_attr_pending(done, 0) || kh::lds_attr_pending(done, 63) || kh::lds_attr_pending(done, 3)) {return 4;}
+  if (!kh::lds_attr_pending(done, 1) || !kh::lds_attr_pending(done, 62)) {return 5;}
+  kh::lds_attr_mark(done, 64); kh::lds_attr_mark(done, 67); kh::lds_attr_mark(done, -1);            // devices without a bit: never "done",
+  if (!kh::lds_attr_pending(done, 64) || !kh::lds_attr_pending(done, 67) || !kh::lds_attr_pending(done, -1)) {return 6;}
+  if (done.load() != ((1ull << 3) | 1ull | (1ull << 63))) {return 7;}                               // and they do not touch the others' bits
+  kh::lds_attr_mark(done, 3);
+  if (done.load() != ((1ull << 3) | 1ull | (1ull << 63))) {return 8;}                               // marking twice changes nothing
+  return 0;
 }
 
 int kh_device_download(void * host_dst, const void * device_src, int64_t bytes)

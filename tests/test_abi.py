@@ -31,6 +31,13 @@ def test_no_cpu_fallback(kartohip_lib):
     assert kartohip_lib.kh_spa_create(0, C.byref(s)) == capi.KH_ERR_NO_DEVICE
 
 
+def test_dynamic_lds_attribute_is_tracked_per_device(kartohip_lib):
+    """csrc/lds_attr.hpp: the kernels' dynamic-LDS attribute is set once per DEVICE (a launch on a device that never set it fails
+    beyond 64 KB).  No box of the pool has a second GPU, so the bookkeeping -- one bit per device, devices beyond 63 always pending,
+    marking idempotent and local to the device -- is driven with made-up device ids by the library's self-test."""
+    assert kartohip_lib.kh_selftest_lds_attr() == 0
+
+
 def test_invalid_create_arguments(kartohip_lib):
     h = C.c_void_p()
     assert kartohip_lib.kh_matcher_create(0.3, 0.0, 0.03, 12.0, 0, 1, C.byref(h)) == capi.KH_ERR_INVALID_ARG
