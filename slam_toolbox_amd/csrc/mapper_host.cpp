@@ -39,6 +39,8 @@ void stream_synchronize(void * hip_stream);      // comm.cpp
 int decay_scores(int32_t device, const kh_scan_box * reference, int32_t n, const kh_scan_box * candidates, const double * const * resident,
   const uint64_t * const * masks, int32_t n_scan, const kh_decay_params * params, int32_t * kept, double * iou, double * area_overlap,
   double * reading_overlap, double * scores);                                                                       // lifelong.hip
+void set_pending_query_hook(std::function<void()> fn);       // matcher_seq.cpp (QueryHook, matcher_private.hpp)
+void run_pending_query_hook();
 int graph_swap(kh_graph * g, int32_t n_scans, std::vector<double> & ref_xy, std::vector<int32_t> & adj_ptr, std::vector<int32_t> & adj_idx);   // graph.hip
 
 void set_error(const std::string & s);
@@ -866,11 +868,18 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     }
     if (!moved) {return KH_OK;}
   }
-  {ProfScope prof(m, 5); update_scan(*scan, m->laser);}
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (!(m->p.use_scan_matching && last)) {ProfScope prof(m, 5); update_scan(*scan, m->laser);}
   // correct the scan against the running scans (:2713-2724)
   if (m->p.use_scan_matching && last) {
-    const kh_scan q = as_kh_scan(*scan);
+    // LocalizedRangeScan::Update of the new scan (1081 sincos) is handed to the matcher as a QueryHook: the match's rasteriser needs
+    // the query's sensor pose and nothing else of it, so the readings are computed behind its launches, while the GPU works; the
+    // matcher runs the hook before anything reads the readings, whatever path the call takes, and before it returns
+    MScan * const sp = scan.get();
+    sp->sensor = sensor_at(m->laser, sp->corrected);
+    sp->points.assign(2 * static_cast<size_t>(m->laser.n), 0.0);
+    const kh_scan q = as_kh_scan(*sp);
+    kh::set_pending_query_hook([m, sp]() {ProfScope prof(m, 5); update_scan(*sp, m->laser);});
     std::vector<kh_scan> base;
     // (uploads of scans not yet resident go in front of the match on the matcher's own stream; the match returns after its
     // last kernel, so every other reader finds them in place)
@@ -879,6 +888,7 @@ int kh_mapper_process(kh_mapper * m, const double * ranges, const double odometr
     double mean[3], response = 0.0;
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = kh_matcher_match(m->seq, &q, base.data(), static_cast<int32_t>(base.size()), 1, 1, mean, cov, &response);
+    kh::run_pending_query_hook();             // (an argument check that refused the call before the hook was taken)
     m->stats.match_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     m->stats.matches += 1;
     if (rc) {

@@ -1436,6 +1436,9 @@ int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, c
     }
   } report{batch_timing, t_batch, n};
   const kh_match_params & mp = m->params;
+  // (a query whose readings the caller finishes later -- QueryHook, matcher_private.hpp: whatever way this call takes, they are
+  // complete before it reads them, and when it returns)
+  struct HookGuard {~HookGuard() {pending_query_hook().run();}} hook_guard;
   std::vector<int> st(n, KH_OK);
   std::vector<int32_t> active;
   std::vector<RasterReq> rreqs;
@@ -1467,9 +1470,11 @@ int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, c
     int seq_status = KH_OK;
     rc = seq_match(m, &queries[0], base ? base + base_begin[0] : nullptr, base_begin[1] - base_begin[0], do_penalize != 0, do_refine != 0,
       means, covs, responses, &seq_status, &coarse_done, &fine_done);
+    pending_query_hook().run();              // (a call the fused path declined before its launches)
     if (rc) {return rc;}
     if (coarse_done) {st[0] = seq_status;}
   }
+  pending_query_hook().run();
   if (!coarse_done) {
     rc = raster_batch(m, rreqs);
     if (rc) {return rc;}

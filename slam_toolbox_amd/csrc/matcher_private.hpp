@@ -289,6 +289,16 @@ int finalize_job(kh_matcher * m, CorrReq & q, CorrHost & c, const ResultView & v
 int raster_batch(kh_matcher * m, const std::vector<RasterReq> & reqs);
 int correlate_batch(kh_matcher * m, std::vector<CorrReq> & reqs);
 // matcher_seq.cpp: ONE MatchScan through the fused kernels.  *coarse_done / *fine_done say which passes it finished
+// A caller inside the library (the mapper's Process) may leave the QUERY scan's readings unfinished when it calls kh_matcher_match
+// and hand over the function that finishes them: the fused path runs it behind the rasteriser's launches -- which need the query's
+// sensor pose and nothing else of it -- so that LocalizedRangeScan::Update of the new scan (1081 sincos: 15 us) runs while the GPU
+// works; every other path runs it before it reads the query.  Per thread; consumed by the next kh_matcher_match_batch on the thread.
+struct QueryHook
+{
+  std::function<void()> fn;
+  void run() {if (fn) {std::function<void()> f; f.swap(fn); f();}}
+};
+QueryHook & pending_query_hook();
 int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32_t n_base, bool penalize, bool refine,
   double mean[3], double cov[9], double * response, int * status, bool * coarse_done, bool * fine_done);
 void seq_destroy(kh_matcher * m);

@@ -85,6 +85,15 @@ static SeqLayout seq_layout(size_t base, int32_t nx, int32_t ny, int32_t na, int
   return L;
 }
 
+QueryHook & pending_query_hook()
+{
+  static thread_local QueryHook hook;
+  return hook;
+}
+
+void set_pending_query_hook(std::function<void()> fn) {pending_query_hook().fn = std::move(fn);}     // (the mapper: it does not see matcher_private.hpp)
+void run_pending_query_hook() {pending_query_hook().run();}
+
 int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32_t n_base, bool penalize, bool refine,
   double mean[3], double cov[9], double * response, int * status, bool * coarse_done, bool * fine_done)
 {
@@ -226,6 +235,8 @@ int seq_match(kh_matcher * m, const kh_scan * query, const kh_scan * base, int32
   launch_seq_links(Q.d_job, 1, np, st);
   launch_seq_bin(Q.d_job, 1, bin_lds, bm_global ? 1 : 0, Q.d_dbg, st);
   KS_HIP(hipGetLastError());
+  // the query's readings, if the caller left them for now (QueryHook): nothing above read them, everything below does
+  pending_query_hook().run();
 
   // ---- 2. the coarse search's host half (tables with libm), while the kernels above run
   const int32_t naf = device_fine ? cf.na : 1;
