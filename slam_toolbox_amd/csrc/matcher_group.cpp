@@ -24,6 +24,8 @@
 
 namespace kh
 {
+void set_pending_query_hook(std::function<void()> fn);       // matcher_seq.cpp (QueryHook, matcher_private.hpp)
+void run_pending_query_hook();
 void set_error(const std::string & s);
 void host_parallel_for(size_t n, const std::function<void(size_t)> & fn);
 int32_t matcher_max_batch(const kh_matcher * m);
@@ -240,65 +242,87 @@ int kh_loop_closure_batch(kh_matcher * coarse, kh_matcher * fine, int32_t n, con
   }
   std::vector<int32_t> bound(pieces + 1);
   for (int32_t k = 0; k <= pieces; ++k) {bound[k] = static_cast<int32_t>(static_cast<int64_t>(n) * k / pieces);}
+  int fine_rc = KH_OK;
+  std::string fine_error;
+  // the gate and the fine matches of piece k (its coarse results are in)
+  auto fine_piece = [&](int32_t k) {
+    std::vector<int32_t> ids;
+    for (int32_t i = bound[k]; i < bound[k + 1]; ++i) {
+      // Mapper.cpp:1519-1521
+      passed[i] = (coarse_responses[i] > minimum_response_coarse && coarse_covs[9 * i] < maximum_variance_coarse &&
+        coarse_covs[9 * i + 4] < maximum_variance_coarse) ? 1 : 0;
+      if (passed[i]) {ids.push_back(i);}
+    }
+    if (ids.empty()) {return;}
+    const size_t m = ids.size();
+    std::vector<std::vector<double>> points(m);
+    std::vector<kh_scan> q(m), b;
+    std::vector<int32_t> begin(m + 1, 0);
+    for (size_t j = 0; j < m; ++j) {
+      const int32_t i = ids[j];
+      q[j] = queries[i];
+      std::copy(coarse_means + 3 * i, coarse_means + 3 * i + 3, q[j].sensor_pose);
+      points[j].resize(2 * static_cast<size_t>(q[j].n));
+      q[j].points_xy = points[j].data(); q[j].device_points_xy = nullptr;
+      for (int32_t t = base_begin[i]; t < base_begin[i + 1]; ++t) {b.push_back(base[t]);}
+      begin[j + 1] = static_cast<int32_t>(b.size());
+    }
+    // LocalizedRangeScan::Update of the temporary scans (one libm sincos per reading: 15 us a scan, on the worker pool) as the
+    // match's QueryHook: the fine matcher's rasteriser reads the temporary scans' POSES only, so their readings are made behind
+    // its launches, while the GPU stamps the chains
+    kh::set_pending_query_hook([&]() {
+      kh::host_parallel_for(m, [&](size_t j) {
+        kh_scan_points(q[j].ranges, q[j].n, q[j].sensor_pose, min_angle, angular_resolution, points[j].data());
+      });
+    });
+    std::vector<double> mean(3 * m), cov(9 * m), resp(m);
+    std::vector<int32_t> st(m, KH_OK);
+    int rc = kh_matcher_match_batch(fine, static_cast<int32_t>(m), q.data(), b.empty() ? nullptr : b.data(), begin.data(), 0, 1,
+        mean.data(), cov.data(), resp.data(), st.data());
+    kh::run_pending_query_hook();          // (an argument check that refused the call before the hook was taken)
+    for (size_t j = 0; j < m && rc == KH_OK; ++j) {rc = st[j];}
+    if (rc) {fine_rc = rc; fine_error = kh_last_error(); return;}
+    for (size_t j = 0; j < m; ++j) {
+      const int32_t i = ids[j];
+      std::copy(mean.begin() + 3 * j, mean.begin() + 3 * j + 3, fine_means + 3 * static_cast<size_t>(i));
+      std::copy(cov.begin() + 9 * j, cov.begin() + 9 * j + 9, fine_covs + 9 * static_cast<size_t>(i));
+      fine_responses[i] = resp[j];
+    }
+  };
+  auto coarse_piece = [&](int32_t k) -> int {
+    const int32_t i0 = bound[k], nk = bound[k + 1] - bound[k];
+    std::vector<int32_t> st(nk, KH_OK);
+    int rc = kh_matcher_match_batch(coarse, nk, queries + i0, base, base_begin + i0, 0, 0, coarse_means + 3 * static_cast<size_t>(i0),
+        coarse_covs + 9 * static_cast<size_t>(i0), coarse_responses + i0, st.data());
+    for (int32_t j = 0; j < nk && rc == KH_OK; ++j) {rc = st[j];}
+    return rc;
+  };
+  if (pieces == 1) {
+    // one piece: nothing to overlap -- both stages on the calling thread (round 6: a thread was created, woken through a condition
+    // variable and joined per call, ~0.15 ms of the batch)
+    const int rc = coarse_piece(0);
+    if (rc) {return rc;}
+    fine_piece(0);
+    if (fine_rc) {kh::set_error(fine_error); return fine_rc;}
+    return KH_OK;
+  }
   std::mutex mu;
   std::condition_variable cv;
   int32_t ready = 0;                 // pieces whose coarse results are in
   bool abort = false;
-  int fine_rc = KH_OK;
-  std::string fine_error;
   std::thread consumer([&] {
-    for (int32_t k = 0; k < pieces; ++k) {
+    for (int32_t k = 0; k < pieces && fine_rc == KH_OK; ++k) {
       {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] {return ready > k || abort;});
         if (abort) {return;}
       }
-      std::vector<int32_t> ids;
-      for (int32_t i = bound[k]; i < bound[k + 1]; ++i) {
-        // Mapper.cpp:1519-1521
-        passed[i] = (coarse_responses[i] > minimum_response_coarse && coarse_covs[9 * i] < maximum_variance_coarse &&
-          coarse_covs[9 * i + 4] < maximum_variance_coarse) ? 1 : 0;
-        if (passed[i]) {ids.push_back(i);}
-      }
-      if (ids.empty()) {continue;}
-      const size_t m = ids.size();
-      std::vector<std::vector<double>> points(m);
-      std::vector<kh_scan> q(m), b;
-      std::vector<int32_t> begin(m + 1, 0);
-      for (size_t j = 0; j < m; ++j) {
-        const int32_t i = ids[j];
-        q[j] = queries[i];
-        std::copy(coarse_means + 3 * i, coarse_means + 3 * i + 3, q[j].sensor_pose);
-        points[j].resize(2 * static_cast<size_t>(q[j].n));
-        q[j].points_xy = points[j].data(); q[j].device_points_xy = nullptr;
-        for (int32_t t = base_begin[i]; t < base_begin[i + 1]; ++t) {b.push_back(base[t]);}
-        begin[j + 1] = static_cast<int32_t>(b.size());
-      }
-      // LocalizedRangeScan::Update of the temporary scans (one libm sincos per reading): on the worker pool
-      kh::host_parallel_for(m, [&](size_t j) {
-        kh_scan_points(q[j].ranges, q[j].n, q[j].sensor_pose, min_angle, angular_resolution, points[j].data());
-      });
-      std::vector<double> mean(3 * m), cov(9 * m), resp(m);
-      std::vector<int32_t> st(m, KH_OK);
-      int rc = kh_matcher_match_batch(fine, static_cast<int32_t>(m), q.data(), b.empty() ? nullptr : b.data(), begin.data(), 0, 1,
-          mean.data(), cov.data(), resp.data(), st.data());
-      for (size_t j = 0; j < m && rc == KH_OK; ++j) {rc = st[j];}
-      if (rc) {fine_rc = rc; fine_error = kh_last_error(); return;}
-      for (size_t j = 0; j < m; ++j) {
-        const int32_t i = ids[j];
-        std::copy(mean.begin() + 3 * j, mean.begin() + 3 * j + 3, fine_means + 3 * static_cast<size_t>(i));
-        std::copy(cov.begin() + 9 * j, cov.begin() + 9 * j + 9, fine_covs + 9 * static_cast<size_t>(i));
-        fine_responses[i] = resp[j];
-      }
+      fine_piece(k);
     }
   });
   int rc = KH_OK;
   for (int32_t k = 0; k < pieces && rc == KH_OK; ++k) {
-    const int32_t i0 = bound[k], nk = bound[k + 1] - bound[k];
-    std::vector<int32_t> st(nk, KH_OK);
-    rc = kh_matcher_match_batch(coarse, nk, queries + i0, base, base_begin + i0, 0, 0, coarse_means + 3 * static_cast<size_t>(i0),
-        coarse_covs + 9 * static_cast<size_t>(i0), coarse_responses + i0, st.data());
-    for (int32_t j = 0; j < nk && rc == KH_OK; ++j) {rc = st[j];}
+    rc = coarse_piece(k);
     {
       std::lock_guard<std::mutex> lk(mu);
       if (rc) {abort = true;} else {ready = k + 1;}

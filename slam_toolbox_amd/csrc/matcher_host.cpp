@@ -1470,13 +1470,13 @@ int kh_matcher_match_batch(kh_matcher * m, int32_t n, const kh_scan * queries, c
     int seq_status = KH_OK;
     rc = seq_match(m, &queries[0], base ? base + base_begin[0] : nullptr, base_begin[1] - base_begin[0], do_penalize != 0, do_refine != 0,
       means, covs, responses, &seq_status, &coarse_done, &fine_done);
-    pending_query_hook().run();              // (a call the fused path declined before its launches)
     if (rc) {return rc;}
     if (coarse_done) {st[0] = seq_status;}
   }
-  pending_query_hook().run();
   if (!coarse_done) {
     rc = raster_batch(m, rreqs);
+    // (the rasteriser reads the queries' sensor poses only: readings a caller left to a QueryHook are made now, behind its launches)
+    pending_query_hook().run();
     if (rc) {return rc;}
   }
 
