@@ -129,7 +129,7 @@ struct kh_spa
   std::vector<int32_t> cached_ea, cached_eb; int32_t cached_n = -1, cached_fixed = -2;
   // supernodes of the last nested dissection by NODE ID (incremental re-analysis), the factorisation cost and size it had
   std::vector<std::vector<int32_t>> cached_sn_ids;
-  int64_t cached_full_flops = 0; int32_t cached_full_nf = 0; int32_t reuse_count = 0;
+  int64_t cached_full_flops = 0; int32_t cached_full_nf = 0; int32_t reuse_count = 0; int32_t cached_full_levels = 0;
   int32_t last_analysis_incremental = 0;
   // device buffers
   DevBuf<int32_t> d_edge_a, d_edge_b, d_free_of_node, d_node_of_free, d_slot_contrib_ptr, d_slot_contrib,
@@ -403,7 +403,19 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
           // closure's few dozen new nodes add little fill, but a bound of 1.5 sent most closures of the 50 000-scan replay back
           // to a full dissection (5 ms each: the replay's solver time went from 4.1 to 7.5 s)
           const double allowed = 3.0 * static_cast<double>(s->cached_full_flops) * static_cast<double>(nf) / static_cast<double>(std::max(1, s->cached_full_nf));
-          if (sym_rc == KH_OK && static_cast<double>(s->sym.factor_flops) <= allowed) {
+          // level guard (round 6): the leading leaf's update matrix reaches into every supernode its nodes touch and strings those up
+          // as ancestors of one another -- on a connected graph (the non-lifelong replay) every re-analysis added one to three levels of
+          // ONE front each to the top of the tree (8 levels after a full dissection, 26 sixteen closures later), and a level is three
+          // launches of 10-27 us per factorisation whatever it holds.  Back to a full dissection once the tree is extra_levels taller
+          // than the last one left it.  Measured (solver ms of the 3000-scan non-lifelong / the 20 000-scan lifelong replay): no guard
+          // 499 / 810, 5 levels 418 / 647, 3: 384 / 642, 2: 364-377 / 508, 1: 366 / 518, 0: 370 / 602, never incremental 358 / 621.
+          // On the 50 000-scan lifelong replay (12 000 free nodes in thousands of components: a dissection costs 5-7 ms, the tree
+          // grows slowly) 2 / 6 / no guard gave 2772 / 2576 / 2606 ms (medians of three alternating runs): 6 from 6000 free nodes on.
+          // (KH_SPA_EXTRA_LEVELS is read at every analysis: tests/test_spa_gpu.py switches the guard off around one Compute().)
+          const char * guard_env = std::getenv("KH_SPA_EXTRA_LEVELS");
+          const int extra_levels = guard_env ? std::atoi(guard_env) : (nf <= 6000 ? 2 : 6);
+          const bool levels_ok = static_cast<int>(s->sym.levels.size()) <= s->cached_full_levels + extra_levels;
+          if (sym_rc == KH_OK && static_cast<double>(s->sym.factor_flops) <= allowed && levels_ok) {
             sym_incremental = true;
             return;
           }
@@ -418,6 +430,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
         }
         sym_rc = build_structure(s->sym, nf, adj_ptr, adj_idx, sopt, dissected);
         s->cached_full_flops = s->sym.factor_flops; s->cached_full_nf = nf; s->reuse_count = 0;
+        s->cached_full_levels = static_cast<int32_t>(s->sym.levels.size());
       }
       if (sym_rc != KH_OK) {sym_error = kh_last_error();}
     });

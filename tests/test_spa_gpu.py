@@ -263,10 +263,13 @@ def test_linear_solves_of_pose_graphs(kartohip_lib, n, e, seed):
     assert np.array_equal(x3, x3b) and s3b["final_cost"] == s3["final_cost"]
 
 
-def test_incremental_reanalysis_after_a_loop_closure(kartohip_lib):
+def test_incremental_reanalysis_after_a_loop_closure(kartohip_lib, monkeypatch):
     """A solved graph grows by a stretch of new scans and a few loop-closure links, and loses a node: the next Compute()
     reuses the supernodes of the last nested dissection (new nodes as leading leaves, summary.analysis == 2) and must return
-    what a solver that sees the final graph for the first time returns -- same iterations, same poses to rounding."""
+    what a solver that sees the final graph for the first time returns -- same iterations, same poses to rounding.
+    (The level guard of round 6 -- a re-analysis whose tree is more than two levels taller than the last dissection's goes back
+    to a full dissection -- would send this one back: it is switched off here, and has its own test below.)"""
+    monkeypatch.setenv("KH_SPA_EXTRA_LEVELS", "100")
     from oracle import spa
     from slam_toolbox_amd.scan_solver import HipSpaSolver
     g = synth.make_pose_graph(1500, 4000, seed=21)
@@ -310,6 +313,36 @@ def test_incremental_reanalysis_after_a_loop_closure(kartohip_lib):
     s4 = a.Compute()
     assert s4["analysis"] == 0
     a.close(); b.close()
+
+
+def test_level_guard_sends_a_tall_reanalysis_back_to_a_full_dissection(kartohip_lib, monkeypatch):
+    """The same growth with the guard at its tightest (no extra level allowed): the re-analysis is discarded, the solver dissects
+    from scratch (summary.analysis == 1) and returns the same poses as with the incremental tree -- the guard only picks between two
+    valid elimination orders."""
+    from slam_toolbox_amd.scan_solver import HipSpaSolver
+    g = synth.make_pose_graph(1500, 4000, seed=21)
+    n0, extra = 1470, 30
+    e = g["edges"]
+    first = (e[:, 0] < n0) & (e[:, 1] < n0)
+    poses = {}
+    for guard in ("100", "0"):
+        monkeypatch.setenv("KH_SPA_EXTRA_LEVELS", guard)
+        a = HipSpaSolver()
+        for i in range(n0):
+            a.AddNode(i, g["init"][i])
+        for k in np.flatnonzero(first):
+            a.AddConstraint(int(e[k, 0]), int(e[k, 1]), g["z"][k], g["cov"][k].reshape(3, 3))
+        assert a.Compute()["analysis"] == 1
+        for i in range(n0, n0 + extra):
+            a.AddNode(i, g["init"][i])
+        for k in np.flatnonzero(~first):
+            a.AddConstraint(int(e[k, 0]), int(e[k, 1]), g["z"][k], g["cov"][k].reshape(3, 3))
+        s2 = a.Compute()
+        assert s2["analysis"] == (2 if guard == "100" else 1), s2
+        assert s2["usable"] == 1
+        poses[guard] = np.array([p for _, p in a.GetCorrections()])
+        a.close()
+    assert _diff(poses["100"], poses["0"]) < 1e-8
 
 
 @pytest.mark.gpu
