@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <type_traits>
 #include <limits>
 #include <map>
 #include <string>
@@ -60,9 +61,18 @@ struct Constraint {int32_t a, b; double z[3]; double u[9]; double omega[6]; uint
 template <class T>
 struct DevBuf
 {
+  typedef T value_type;
   T * p = nullptr; size_t cap = 0;
+  bool owned = true;                 // false: p is a slice of another allocation (alias)
+  // the buffer becomes n elements of somebody else's allocation (the analysis' arrays: slices of ONE block, one copy)
+  void alias(T * slice, size_t n)
+  {
+    if (owned && p) {(void)hipFree(p);}
+    p = slice; cap = n; owned = false;
+  }
   int ensure(size_t n)
   {
+    if (!owned) {p = nullptr; cap = 0; owned = true;}
     if (n <= cap) {return KH_OK;}
     if (p) {KS_HIP(hipFree(p)); p = nullptr;}
     cap = std::max(n, cap + cap / 2);
@@ -80,7 +90,7 @@ struct DevBuf
     if (!v.empty()) {KS_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));}
     return KH_OK;
   }
-  void release() {if (p) {(void)hipFree(p); p = nullptr; cap = 0;}}
+  void release() {if (p && owned) {(void)hipFree(p);} p = nullptr; cap = 0; owned = true;}
 };
 
 }  // namespace kh
@@ -141,6 +151,7 @@ struct kh_spa
   DevBuf<FrontDesc> d_desc;
   uint8_t * h_upload = nullptr; size_t h_upload_cap = 0;     // pinned staging of an analysis' uploads (one block, ~30 copies out of it)
   DevBuf<int32_t> d_cinv;
+  DevBuf<char> d_pack;                         // the analysis' arrays (the DevBufs the upload block of prepare_problem lists are its slices)
   DevBuf<double> d_fronts_b;                   // buffer B of the fronts (Symbolic::scatter_mode)
   DevBuf<double> d_edge_z, d_edge_u, d_edge_lin, d_edge_cost, d_Hg, d_fronts, d_x, d_cand, d_scale,
     d_diag, d_rhs, d_step, d_delta, d_scal;
@@ -375,21 +386,37 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     int sym_rc = KH_OK;
     bool sym_incremental = false;
     std::string sym_error;
-    std::thread sym_thread([&]() {
+    auto analyse = [&]() {
       constexpr int kMaxReuse = 24;
       std::vector<std::vector<int32_t>> sn;
       if (incremental_on && !s->cached_sn_ids.empty() && s->reuse_count < kMaxReuse) {
-        // node id -> free index of this problem
+        // node id -> free index of this problem: a table when the ids are dense (a mapper's scan ids are), a hash map otherwise
+        int32_t id_lo = INT32_MAX, id_hi = INT32_MIN;
+        for (int32_t f = 0; f < nf; ++f) {const int32_t id = s->nodes[s->node_of_free[f]].id; id_lo = std::min(id_lo, id); id_hi = std::max(id_hi, id);}
+        const bool dense_ids = nf > 0 && static_cast<int64_t>(id_hi) - id_lo < 8 * static_cast<int64_t>(nf) + 1024;
+        std::vector<int32_t> free_of_dense;
         std::unordered_map<int32_t, int32_t> free_of_id;
-        free_of_id.reserve(static_cast<size_t>(nf) * 2);
-        for (int32_t f = 0; f < nf; ++f) {free_of_id[s->nodes[s->node_of_free[f]].id] = f;}
+        if (dense_ids) {
+          free_of_dense.assign(static_cast<size_t>(id_hi - id_lo) + 1, -1);
+          for (int32_t f = 0; f < nf; ++f) {free_of_dense[static_cast<size_t>(s->nodes[s->node_of_free[f]].id - id_lo)] = f;}
+        } else {
+          free_of_id.reserve(static_cast<size_t>(nf) * 2);
+          for (int32_t f = 0; f < nf; ++f) {free_of_id[s->nodes[s->node_of_free[f]].id] = f;}
+        }
+        auto free_index = [&](int32_t id) -> int32_t {
+          if (dense_ids) {return (id >= id_lo && id <= id_hi) ? free_of_dense[static_cast<size_t>(id - id_lo)] : -1;}
+          const auto it = free_of_id.find(id);
+          return it != free_of_id.end() ? it->second : -1;
+        };
         std::vector<uint8_t> placed(nf, 0);
         int32_t kept = 0;
+        sn.reserve(s->cached_sn_ids.size() + 1);
         for (const auto & ids : s->cached_sn_ids) {
           std::vector<int32_t> g;
+          g.reserve(ids.size());
           for (int32_t id : ids) {
-            auto it = free_of_id.find(id);
-            if (it != free_of_id.end()) {g.push_back(it->second); placed[it->second] = 1; ++kept;}
+            const int32_t f = free_index(id);
+            if (f >= 0) {g.push_back(f); placed[f] = 1; ++kept;}
           }
           if (!g.empty()) {std::sort(g.begin(), g.end()); sn.push_back(std::move(g));}
         }
@@ -433,7 +460,12 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
         s->cached_full_levels = static_cast<int32_t>(s->sym.levels.size());
       }
       if (sym_rc != KH_OK) {sym_error = kh_last_error();}
-    });
+    };
+    // (a thread of its own only where there is something to win: the lists below take 0.6 ms on the 10 000-node graph and 0.08 ms on
+    // a mapper's 2000 nodes, creating and joining a thread 0.1 ms)
+    const bool analysis_beside = nf >= 4000;
+    std::thread sym_thread;
+    if (analysis_beside) {sym_thread = std::thread(analyse);}
     struct Joiner {std::thread & t; ~Joiner() {if (t.joinable()) {t.join();}}} sym_joiner{sym_thread};
     auto slot_of = [&](int32_t i, int32_t j) {
       const auto b = col.begin() + row_ptr[i], e2 = col.begin() + row_ptr[i + 1];
@@ -465,7 +497,7 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
       if (fb >= 0) {ncl[nfill[fb]++] = e * 2 + 1;}
     }
     const auto t_lists = std::chrono::steady_clock::now();
-    sym_thread.join();
+    if (analysis_beside) {sym_thread.join();} else {analyse();}
     if (sym_rc) {set_error(sym_error); return sym_rc;}
     if (sym_incremental) {++s->reuse_count;}
     s->last_analysis_incremental = sym_incremental ? 1 : 0;
@@ -546,13 +578,18 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     std::vector<int32_t> col_and_row = col;
     col_and_row.insert(col_and_row.end(), slot_row.begin(), slot_row.end());
     int r2 = 0;
-    // Every array is copied into ONE pinned block first and goes to its device buffer from there: ~30 asynchronous copies the
-    // stream can queue, instead of ~30 copies out of pageable vectors, each of which the runtime stages (and waits for) on its own.
-    struct Pending {void * dst; const void * src; size_t bytes;};
+    // Every array is copied into ONE pinned block and travels to ONE device block in ONE copy; the device buffers of the arrays are
+    // slices of that block (round 5: one pinned block, ~35 asynchronous copies -- 3-4 us of the caller's time each, on every
+    // closure of a mapper; before that ~35 copies out of pageable vectors, each staged and waited for on its own).
+    struct Pending {std::function<void(char *)> bind; const void * src; size_t bytes; size_t off;};
     std::vector<Pending> pending;
+    size_t pack_bytes = 0;
     auto up = [&](auto & buf, const auto & vec) {
-      r2 |= buf.ensure(std::max<size_t>(vec.size(), 1));
-      if (!vec.empty()) {pending.push_back({buf.p, vec.data(), vec.size() * sizeof(vec[0])});}
+      typedef typename std::remove_reference<decltype(buf)>::type::value_type T;
+      const size_t n = std::max<size_t>(vec.size(), 1);
+      auto * bp = &buf;
+      pending.push_back({[bp, n](char * base) {bp->alias(reinterpret_cast<T *>(base), n);}, vec.empty() ? nullptr : vec.data(), vec.size() * sizeof(T), pack_bytes});
+      pack_bytes += (n * sizeof(T) + 63) & ~static_cast<size_t>(63);
     };
     up(s->d_edge_a, ea); up(s->d_edge_b, eb);
     up(s->d_free_of_node, s->free_of_node); up(s->d_node_of_free, s->node_of_free);
@@ -593,25 +630,26 @@ static int prepare_problem(kh_spa * s, SpaDev & dev, bool & has_work)
     }
     up(s->d_cinv, sym.cinv);
     up(s->d_desc, desc);
-    if (r2) {return KH_ERR_HIP;}
     {
-      size_t total = 0;
-      for (const Pending & q : pending) {total += (q.bytes + 63) & ~static_cast<size_t>(63);}
+      const size_t total = std::max<size_t>(pack_bytes, 64);
       if (total > s->h_upload_cap) {
+        KS_HIP(hipStreamSynchronize(st));          // (an earlier copy may still read the old block)
         if (s->h_upload) {KS_HIP(hipHostFree(s->h_upload)); s->h_upload = nullptr; s->h_upload_cap = 0;}
         const size_t cap = total + total / 2;
         KS_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_upload), cap, hipHostMallocDefault));
         s->h_upload_cap = cap;
       }
-      size_t at = 0;
+      if (total > s->d_pack.cap) {KS_HIP(hipStreamSynchronize(st));}       // (kernels of the last solve read slices of the old block)
+      r2 |= s->d_pack.ensure(total);
+      if (r2) {return KH_ERR_HIP;}
       for (const Pending & q : pending) {
-        std::memcpy(s->h_upload + at, q.src, q.bytes);
-        if (hipMemcpyAsync(q.dst, s->h_upload + at, q.bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
-          (void)hipStreamSynchronize(st);        // the copies already queued read the staging block: nobody may reuse it under them
-          set_error("hipMemcpyAsync: upload of the analysis");
-          return KH_ERR_HIP;
-        }
-        at += (q.bytes + 63) & ~static_cast<size_t>(63);
+        if (q.bytes) {std::memcpy(s->h_upload + q.off, q.src, q.bytes);}
+        q.bind(s->d_pack.p + q.off);
+      }
+      if (hipMemcpyAsync(s->d_pack.p, s->h_upload, total, hipMemcpyHostToDevice, st) != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        set_error("hipMemcpyAsync: upload of the analysis");
+        return KH_ERR_HIP;
       }
     }
     r2 |= s->d_winv.ensure(static_cast<size_t>(sym.winv_size) + 16);
@@ -739,7 +777,7 @@ void kh_spa_destroy(kh_spa * s)
   s->d_child_ptr.release(); s->d_child_list.release(); s->d_relpos_ptr.release(); s->d_relpos.release();
   s->d_slot_ld.release(); s->d_elim_of_free.release(); s->d_free_of_elim.release(); s->d_level_fronts.release();
   s->d_fail.release(); s->d_sync.release(); s->d_front_off.release(); s->d_slot_dest.release(); s->d_winv_off.release(); s->d_winv.release(); s->d_desc.release(); s->d_cinv.release(); s->d_edge_z.release(); s->d_edge_u.release();
-  s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release(); s->d_fronts_b.release(); s->d_deferred.release();
+  s->d_edge_lin.release(); s->d_edge_cost.release(); s->d_Hg.release(); s->d_fronts.release(); s->d_fronts_b.release(); s->d_deferred.release(); s->d_pack.release();
   s->d_x.release(); s->d_cand.release(); s->d_scale.release(); s->d_diag.release(); s->d_rhs.release();
   s->d_step.release(); s->d_delta.release(); s->d_scal.release(); s->d_upd.release(); s->d_fsb.release(); s->d_partial.release(); s->d_Hg_alt.release(); s->d_best.release();
   for (auto & row : s->ev_phase) {for (auto & e : row) {if (e) {(void)hipEventDestroy(e);}}}
