@@ -20,14 +20,29 @@ constexpr int32_t kBlockShift = 5;             // occupancy block map: one bit p
 constexpr int32_t kCountsPerAngle = 8;        // counts[a][0..3] = beams per class, [4] = slow beams
 // LDS-staged scoring (k_score_lds): a workgroup scores kGroupAngles adjacent angles; the beams are cut into chunks of
 // consecutive beams whose windows' union fits one LDS region (built by kLdsRanges waves, a quarter of the beams each)
-constexpr int32_t kGroupAngles = 2;
+// (geometry as macros: a measurement build can change it -- four angles on 2 x 74 KB regions of 320 B x 236 rows, one workgroup of
+// sixteen waves per compute unit, scored 0.50 ms per launch against 0.44: chunks end at the builder's runs of 64 beams, not at the region)
+#ifndef KH_GROUP_ANGLES
+#define KH_GROUP_ANGLES 2
+#endif
+#ifndef KH_LDS_PITCH
+#define KH_LDS_PITCH 192
+#endif
+#ifndef KH_LDS_ROWS
+#define KH_LDS_ROWS 196
+#endif
+#ifndef KH_LDS_REGION_KB
+#define KH_LDS_REGION_KB 37
+#endif
+constexpr int32_t kGroupAngles = KH_GROUP_ANGLES;
 constexpr int32_t kLdsRanges = 4;             // builder waves of K2' (each writes its own descriptor list)
 // descriptors one builder wave can write: it sees ceil(P / 256) runs of 64 beams, every beam of a run may end up a chunk of its own
 inline __host__ __device__ int32_t lds_desc_capacity(int32_t n_points) {return 64 * ((n_points + 255) / 256);}
-constexpr int32_t kChunkWords = 8;            // int32 words per chunk descriptor
-constexpr int32_t kLdsPitch = 192;            // bytes per staged grid row (64 mod 128: conflict-free ds_read_b32 of two rows)
-constexpr int32_t kLdsRows = 196;             // rows of one staged region
-constexpr int32_t kLdsRegionBytes = 37 * 1024;   // >= kLdsRows * kLdsPitch, a multiple of the 1 KB an LDS-DMA instruction fills; double buffered
+constexpr int32_t kChunkWords = 8;            // int32 words per chunk descriptor: first beam, grid offset, rows, windows, per angle the class counts
+static_assert(4 + kGroupAngles <= kChunkWords, "descriptor words");
+constexpr int32_t kLdsPitch = KH_LDS_PITCH;   // bytes per staged grid row (64 mod 128: conflict-free ds_read_b32 of two rows)
+constexpr int32_t kLdsRows = KH_LDS_ROWS;     // rows of one staged region
+constexpr int32_t kLdsRegionBytes = KH_LDS_REGION_KB * 1024;   // >= kLdsRows * kLdsPitch, a multiple of the 1 KB an LDS-DMA instruction fills; double buffered
 
 // One rasterisation job (ScanMatcher::AddScans, Mapper.cpp:1032-1105) -- device visible.
 // The base scans' UNFILTERED point readings live once per distinct scan in the batch's arena; a job names its scans

@@ -623,7 +623,7 @@ void prepare_job(kh_matcher * m, const CorrReq & q, CorrHost & c, const StageLay
   // ... and a launch of at least two workgroups (angle pairs) per compute unit: one config-2 search alone is 41 workgroups that
   // walk their 25 chunks one after the other -- 0.26 ms against the windowed kernel's 0.14
   const bool lds_wanted = lds_always || (!lds_never && static_cast<double>(c.nx) * c.ny * c.na * c.P >= 1e8 &&
-    static_cast<double>(n_launch) * ((c.na + kGroupAngles - 1) / kGroupAngles) >= 512.0);
+    static_cast<double>(n_launch) * c.na >= 1024.0);      // (workgroup = kGroupAngles angles)
   const bool lds_ok = lds_wanted && linear && (c.nx - 1) * sx + 1 <= kTileSpan && c.ny <= 64 && c.P <= 2048 &&
     sy_ws % m->ws == 0 && sy_ws / m->ws == sx && (m->ws % 4) == 0 && 63 * sx + 1 <= kLdsRows;
   shape.lds = lds_ok ? 1 : 0;
@@ -964,9 +964,9 @@ static int correlate_stage(kh_matcher * m, CorrReq * reqs, size_t n, CorrBatch &
     for (size_t g = 0; g < groups * kLdsRanges; ++g) {
       for (int32_t k = 0; k < cc[g]; ++k) {
         const int32_t * d = dd.data() + (g * range_len + k) * kChunkWords;
-        ++total; bytes += static_cast<long>(d[3]) * kLdsPitch; windows += d[6];
-        maxb = std::max<long>(maxb, static_cast<long>(d[3]) * kLdsPitch);
-        if (d[6] < 16) {++small;}
+        ++total; bytes += static_cast<long>(d[2]) * kLdsPitch; windows += d[3];
+        maxb = std::max<long>(maxb, static_cast<long>(d[2]) * kLdsPitch);
+        if (d[3] < 16) {++small;}
       }
     }
     std::fprintf(stderr, "[kh lds] job 0: %zu angle pairs, %ld chunks (%.1f per pair, %ld with < 16 windows), mean region %.1f KB, max %.1f KB, "

@@ -1503,9 +1503,9 @@ void launch_ties(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int32_t 
 namespace kh
 {
 
-struct ChunkDesc {int32_t beam_begin, beam_end, g0, rows, cnt[kGroupAngles], windows, pad1;};
+struct ChunkDesc {int32_t beam_begin, g0, rows, windows, cnt[kChunkWords - 4];};      // cnt[q]: angle q's windows per alignment class, 4 x 8 bits
 static_assert(sizeof(ChunkDesc) == kChunkWords * 4, "descriptor size");
-static_assert(kGroupAngles == 2, "the wave roles below assume two angles per workgroup");
+static_assert(kGroupAngles >= 2 && kGroupAngles <= 4, "K3' runs kGroupAngles x 4 waves: at most 1024 threads");
 static_assert(kLdsPitch % 16 == 0 && kLdsPitch % 128 == 64, "rows of a 32-lane half must fall into disjoint banks");
 static_assert(kLdsRegionBytes % 1024 == 0 && kLdsRegionBytes >= kLdsRows * kLdsPitch, "one LDS-DMA instruction fills 1 KB");
 
@@ -1693,20 +1693,29 @@ __global__ __launch_bounds__(256) void k_offsets_lds(const uint8_t * jobs, size_
           any_chunk = __shfl((int)any, first_bad - 1) != 0;
           break;
         }
-        // the two windows of beam `begin` are too far apart for one region: the second angle's goes the exact per-pose way
-        // (a window alone always fits; the first angle's follows only if it ever did not)
+        // the windows of beam `begin` at the group's angles are too far apart for one region: the last angle that still has one
+        // goes the exact per-pose way (a window alone always fits; the first angle's follows only if it ever did not)
         if (lane == begin) {
-          const int qd = gy[1] != kNotFast ? 1 : 0;
-          (slow + (size_t)(a0 + qd) * P)[atomicAdd(&s_slow[qd], 1)] = gx[qd] + gy[qd] * ws;
-          gy[qd] = kNotFast;
+          int qd = 0;
+#pragma unroll
+          for (int q = 1; q < kGroupAngles; ++q) {qd = gy[q] != kNotFast ? q : qd;}
+#pragma unroll
+          for (int q = 0; q < kGroupAngles; ++q) {
+            if (q == qd) {
+              (slow + (size_t)(a0 + q) * P)[atomicAdd(&s_slow[q], 1)] = gx[q] + gy[q] * ws;
+              gy[q] = kNotFast;
+            }
+          }
         }
       }
       n = min(n, n_run - begin);
       if (any_chunk) {
         const bool in = lane >= begin && lane < begin + n;
         ChunkDesc d;
-        d.beam_begin = run_lo + begin; d.beam_end = run_lo + begin + n;
-        d.g0 = y0 * ws + x0; d.rows = rows; d.pad1 = 0;
+        d.beam_begin = run_lo + begin;
+        d.g0 = y0 * ws + x0; d.rows = rows;
+#pragma unroll
+        for (int q = kGroupAngles; q < kChunkWords - 4; ++q) {d.cnt[q] = 0;}
         int windows = 0;
 #pragma unroll
         for (int q = 0; q < kGroupAngles; ++q) {
@@ -1764,8 +1773,13 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(1))) const void gvoid;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+#ifndef KH_PRIO
+#define KH_PRIO 1
+#endif
+constexpr int kScoreLdsBlocksPerCu = (160 * 1024 - 4096) / (2 * kLdsRegionBytes);      // two regions per workgroup
+static_assert(kScoreLdsBlocksPerCu >= 1 && kScoreLdsBlocksPerCu * kGroupAngles * 4 <= 16, "four waves per SIMD");
 template <int S, int NW, bool kFull>
-__global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
+__global__ __launch_bounds__(64 * kGroupAngles * NW, kScoreLdsBlocksPerCu) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
 {
   // kFull: every job of the launch has a lattice of more than 32 rows -- each of an angle's NW waves has its own rows and takes every
   // step (the bookkeeping of who takes which step leaves the chunk loop)
@@ -1833,7 +1847,8 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   // of LDS starting at a wave-uniform address.  (job.ws is read once, in front of the loop: a load of it inside would put an
   // s_waitcnt vmcnt(0) -- i.e. a wait for the PREVIOUS DMA -- in front of every DMA instruction.)
   constexpr int kUnitsPerRow = kLdsPitch / 16;
-  constexpr int kDmaPerWave = (kLdsRegionBytes / 1024 + 2 * NW - 1) / (2 * NW);
+  constexpr int kWaves = kGroupAngles * NW;
+  constexpr int kDmaPerWave = (kLdsRegionBytes / 1024 + kWaves - 1) / kWaves;
   const int ws = job.ws;
   // the grid offset (relative to the region's first byte) of the unit this lane moves in the wave's t-th DMA instruction is the same
   // for every chunk: computed once (a division per instruction and chunk otherwise); past the region's last unit it is clamped to
@@ -1841,20 +1856,21 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   uint32_t dma_off[kDmaPerWave];
 #pragma unroll
   for (int t = 0; t < kDmaPerWave; ++t) {
-    const int u = 64 * (wave + 2 * NW * t) + lane;
+    const int u = 64 * (wave + kWaves * t) + lane;
     const int row = u / kUnitsPerRow, col = u - row * kUnitsPerRow;
     dma_off[t] = (uint32_t)(row * ws + 16 * col);
   }
-  auto issue_dma = [&](const Chunk & d, int buf) {
+  auto issue_dma = [&](const Chunk & d, int buf, int t_lo, int t_hi) {
     const gbyte * src = gwin + d.g0;
     const int nblk = (d.rows * kUnitsPerRow + 63) >> 6;
     const uint32_t o_last = (uint32_t)((d.rows - 1) * ws + 16 * (kUnitsPerRow - 1));
     lds_u32 * dst = (lds_u32 *)s_region + buf * (kLdsRegionBytes / 4) + wave * 256;
 #pragma unroll
     for (int t = 0; t < kDmaPerWave; ++t) {
-      if (wave + 2 * NW * t >= nblk) {break;}
+      if (t < t_lo || t >= t_hi) {continue;}
+      if (wave + kWaves * t >= nblk) {break;}
       const uint32_t o = dma_off[t] < o_last ? dma_off[t] : o_last;
-      __builtin_amdgcn_global_load_lds((gvoid *)(src + o), (__attribute__((address_space(3))) void *)(dst + 2 * NW * t * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid *)(src + o), (__attribute__((address_space(3))) void *)(dst + kWaves * t * 256), 16, 0, 0);
     }
   };
   // this wave's offsets of a chunk: angle q's class-sorted run, lane k = k-th window
@@ -1888,13 +1904,22 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     } \
   } while (0)
   int step_base = 0;
-  auto score = [&](const Chunk & d, int buf, int32_t rels) {
+  auto score = [&](const Chunk & d, int buf, int32_t rels, const Chunk & dn, bool dma_next) {
+#ifdef KH_DMA_SPREAD
+    if (!live) {if (dma_next) {issue_dma(dn, buf ^ 1, 1, kDmaPerWave);} return;}
+#else
     if (!live) {return;}
+#endif
     const uint32_t base = lds_lane + (uint32_t)(buf * kLdsRegionBytes);
     int off = 0;
 #pragma unroll
     for (int c = 0; c < kClasses; ++c) {
       const int cnt = (d.packed >> (8 * c)) & 0xff;
+#ifdef KH_DMA_SPREAD
+      // the next region's DMA, one piece in front of every class: sixteen waves' pieces at once queue up in front of the texture
+      // addresser and every wave waits its turn
+      if (dma_next) {issue_dma(dn, buf ^ 1, c + 1, c == kClasses - 1 ? kDmaPerWave : c + 2);}
+#endif
       // this wave's steps of the class: those whose running number (over the classes and chunks of the angle) is `part`
       // modulo `parts`
       const int first = kFull ? 0 : (part - step_base) & (parts - 1);
@@ -1934,7 +1959,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     const int range = (fetched >= end0 ? 1 : 0) + (fetched >= end1 ? 1 : 0) + (fetched >= end2 ? 1 : 0);
     const int start = fetched >= end2 ? end2 : fetched >= end1 ? end1 : fetched >= end0 ? end0 : 0;
     cint * w = cdescs + ((size_t)range * range_len + (fetched - start)) * kChunkWords;
-    d.beam_begin = w[0]; d.g0 = w[2]; d.rows = w[3]; d.packed = w[4 + q];
+    d.beam_begin = w[0]; d.g0 = w[1]; d.rows = w[2]; d.packed = w[4 + q];
     ++fetched;
     return true;
   };
@@ -1943,12 +1968,20 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
   bool more = have && next_chunk(nxt);
   int buf = 0;
   int32_t rel_cur = 0, rel_nxt = 0;
-  if (have) {issue_dma(cur, 0); rel_cur = load_rel(cur);}
+  if (have) {issue_dma(cur, 0, 0, kDmaPerWave); rel_cur = load_rel(cur);}
   while (have) {
     __syncthreads();                                 // this region landed (the barrier drains the DMA); the other one is free
-    if (more) {issue_dma(nxt, buf ^ 1); rel_nxt = load_rel(nxt);}
+#ifdef KH_DMA_SPREAD
+    if (more) {issue_dma(nxt, buf ^ 1, 0, 1); rel_nxt = load_rel(nxt);}
+#else
+    if (more) {issue_dma(nxt, buf ^ 1, 0, kDmaPerWave); rel_nxt = load_rel(nxt);}
+#endif
     const bool after = more && next_chunk(aft);
-    score(cur, buf, rel_cur);
+    // the scoring steps above the waves of K2' / K4 that share the compute unit (the other staging set's launches): their issue slots
+    // are the scoring kernel's own time, the side kernels have a whole scoring launch to finish in (0.441 -> 0.427 ms per launch, same box)
+    __builtin_amdgcn_s_setprio(KH_PRIO);
+    score(cur, buf, rel_cur, nxt, more);
+    __builtin_amdgcn_s_setprio(0);
     cur = nxt; nxt = aft; rel_cur = rel_nxt; buf ^= 1; have = more; more = after;
   }
   __syncthreads();
@@ -2054,7 +2087,7 @@ __global__ __launch_bounds__(128 * NW, NW) void k_score_lds(const uint8_t * jobs
     best = o > best ? o : best;
   }
   // angle maximum -> K4 skips the angles without ties (one scoring tile per angle on this path); one atomic per angle
-  __shared__ double s_best[2 * NW];
+  __shared__ double s_best[kGroupAngles * NW];
   if (lane == 0) {s_best[wave] = best;}
   __syncthreads();
   if (live && ta == 0) {
@@ -2083,7 +2116,7 @@ void launch_score_lds(const uint8_t * d_jobs, size_t stride, int32_t n_jobs, int
   allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<1, 4, false>), kDyn, attr_done[2]);
   allow_dynamic_lds(reinterpret_cast<const void *>(k_score_lds<2, 4, false>), kDyn, attr_done[3]);
   hipStream_t s = (hipStream_t)stream;
-#define KH_SCORE_LDS(SV, FV) hipLaunchKernelGGL((k_score_lds<SV, 4, FV>), dim3((unsigned int)blocks), dim3(512), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map)
+#define KH_SCORE_LDS(SV, FV) hipLaunchKernelGGL((k_score_lds<SV, 4, FV>), dim3((unsigned int)blocks), dim3(64 * kGroupAngles * 4), kDyn, s, d_jobs, stride, (int)n_jobs, groups, xcd_map)
   if (sx_variant == 2) {
     if (full_rows) {KH_SCORE_LDS(2, true);} else {KH_SCORE_LDS(2, false);}
   } else {

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include "kh_internal.hpp"
 #include "matcher_device.hpp"
@@ -509,12 +510,20 @@ __global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobs, const u
   uint8_t * const grid = job.grid;
   const int32_t * const list = job.list;
   const int tid = threadIdx.x;
+  // a workgroup's tiles one after the other: the record of the tile after the next and the next tile's first 512 list entries are on
+  // their way while this one is stamped (a batch gives a workgroup several tiles; as load -> load -> stamp per tile the chain of two
+  // dependent round trips was what a tile cost)
+  const int4 none = make_int4(0, 0, 0, 0);
+  int4 wk = work2[blockIdx.x];
+  int4 wk1 = (int)blockIdx.x + tile_blocks < n_work ? work2[blockIdx.x + tile_blocks] : none;
+  int pk0 = tid < min(512, wk.z) ? list[wk.y + tid] : 0;
   for (int i = tid; i < kTabRows * kTabPitch / 16; i += 512) {reinterpret_cast<uint4 *>(s_tab)[i] = tab[i];}
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int band = 8 * wave;                   // first tile row of this wave
   for (int w = blockIdx.x; w < n_work; w += tile_blocks) {
-    const int4 wk = work2[w];
     const int t = wk.x, begin = wk.y, count = wk.z;
+    const int4 wk2 = w + 2 * tile_blocks < n_work ? work2[w + 2 * tile_blocks] : none;
+    const int pk1 = tid < min(512, wk1.z) ? list[wk1.y + tid] : 0;
     const int ty = t / tiles_w, tx = t - ty * tiles_w;
     const int ox = tx * kRasterTile, oy = ty * kRasterTile;       // grid cell of the tile's corner
     uint32_t acc[8];
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobs, const u
     for (int chunk = 0; chunk < count; chunk += 512) {
       const int here = min(512, count - chunk);
       __syncthreads();                                            // table complete / previous chunk consumed
-      if (tid < here) {s_pxy[tid] = list[begin + chunk + tid];}
+      if (tid < here) {s_pxy[tid] = chunk == 0 ? pk0 : list[begin + chunk + tid];}
       __syncthreads();
       for (int q0 = 0; q0 < here; q0 += 64) {
         const int cnt = min(64, here - q0);
@@ -542,6 +551,7 @@ __global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobs, const u
         }
       }
     }
+    wk = wk1; wk1 = wk2; pk0 = pk1;
     // write the band: 8 rows x 64 bytes, lane = column (clipped to the grid)
     const int x = ox + lane;
     if (x < ws) {
@@ -588,7 +598,12 @@ void launch_seq_tile(const RasterJob * d_jobs, int32_t n_jobs, const uint8_t * d
 {
   if (n_jobs <= 0) {return;}
   const SeqStage g = make_stage(a);
-  const int tile_blocks = std::max(1, std::min(std::min(max_tiles, 4 * max_points), n_jobs > 1 ? 2048 : 1024));
+  // one job: a workgroup per tile (latency).  A batch: 64 workgroups per job, each walking its share of the job's tiles with the next
+  // tile's record and list on their way -- one copy of the kernel image into LDS per ~6 tiles instead of one per tile, and no
+  // workgroups that find nothing to do (2048 per job, ~370 of them with a tile: 1070 us per 224 jobs; 64: 822; 16 or 256: 880)
+  static const int env_blocks = std::getenv("KH_TILE_BLOCKS") ? std::atoi(std::getenv("KH_TILE_BLOCKS")) : 0;
+  const int batch_blocks = env_blocks > 0 ? env_blocks : 64;
+  const int tile_blocks = std::max(1, std::min(std::min(max_tiles, 4 * max_points), n_jobs > 1 ? batch_blocks : 1024));
   hipLaunchKernelGGL(kseq_tile, dim3(tile_blocks + (a ? kTileStageBlocks : 4), n_jobs), dim3(512), 0, (hipStream_t)stream, d_jobs,
     reinterpret_cast<const uint4 *>(d_tab), tile_blocks, g);
 }
