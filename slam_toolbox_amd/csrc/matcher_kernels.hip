@@ -1778,8 +1778,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kScoreLdsBlocksPerCu = (160 * 1024 - 4096) / (2 * kLdsRegionBytes);      // two regions per workgroup
 static_assert(kScoreLdsBlocksPerCu >= 1 && kScoreLdsBlocksPerCu * kGroupAngles * 4 <= 16, "four waves per SIMD");
+// (__launch_bounds__' second argument: the waves per SIMD the kernel must fit -- four: two workgroups of eight waves per compute unit)
 template <int S, int NW, bool kFull>
-__global__ __launch_bounds__(64 * kGroupAngles * NW, kScoreLdsBlocksPerCu) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
+__global__ __launch_bounds__(64 * kGroupAngles * NW, 4) void k_score_lds(const uint8_t * jobs, size_t stride, int n_jobs, int groups_max, int xcd_map)
 {
   // kFull: every job of the launch has a lattice of more than 32 rows -- each of an angle's NW waves has its own rows and takes every
   // step (the bookkeeping of who takes which step leaves the chunk loop)
@@ -1860,14 +1861,13 @@ __global__ __launch_bounds__(64 * kGroupAngles * NW, kScoreLdsBlocksPerCu) void 
     const int row = u / kUnitsPerRow, col = u - row * kUnitsPerRow;
     dma_off[t] = (uint32_t)(row * ws + 16 * col);
   }
-  auto issue_dma = [&](const Chunk & d, int buf, int t_lo, int t_hi) {
+  auto issue_dma = [&](const Chunk & d, int buf) {
     const gbyte * src = gwin + d.g0;
     const int nblk = (d.rows * kUnitsPerRow + 63) >> 6;
     const uint32_t o_last = (uint32_t)((d.rows - 1) * ws + 16 * (kUnitsPerRow - 1));
     lds_u32 * dst = (lds_u32 *)s_region + buf * (kLdsRegionBytes / 4) + wave * 256;
 #pragma unroll
     for (int t = 0; t < kDmaPerWave; ++t) {
-      if (t < t_lo || t >= t_hi) {continue;}
       if (wave + kWaves * t >= nblk) {break;}
       const uint32_t o = dma_off[t] < o_last ? dma_off[t] : o_last;
       __builtin_amdgcn_global_load_lds((gvoid *)(src + o), (__attribute__((address_space(3))) void *)(dst + kWaves * t * 256), 16, 0, 0);
@@ -1904,22 +1904,13 @@ __global__ __launch_bounds__(64 * kGroupAngles * NW, kScoreLdsBlocksPerCu) void 
     } \
   } while (0)
   int step_base = 0;
-  auto score = [&](const Chunk & d, int buf, int32_t rels, const Chunk & dn, bool dma_next) {
-#ifdef KH_DMA_SPREAD
-    if (!live) {if (dma_next) {issue_dma(dn, buf ^ 1, 1, kDmaPerWave);} return;}
-#else
+  auto score = [&](const Chunk & d, int buf, int32_t rels) {
     if (!live) {return;}
-#endif
     const uint32_t base = lds_lane + (uint32_t)(buf * kLdsRegionBytes);
     int off = 0;
 #pragma unroll
     for (int c = 0; c < kClasses; ++c) {
       const int cnt = (d.packed >> (8 * c)) & 0xff;
-#ifdef KH_DMA_SPREAD
-      // the next region's DMA, one piece in front of every class: sixteen waves' pieces at once queue up in front of the texture
-      // addresser and every wave waits its turn
-      if (dma_next) {issue_dma(dn, buf ^ 1, c + 1, c == kClasses - 1 ? kDmaPerWave : c + 2);}
-#endif
       // this wave's steps of the class: those whose running number (over the classes and chunks of the angle) is `part`
       // modulo `parts`
       const int first = kFull ? 0 : (part - step_base) & (parts - 1);
@@ -1968,19 +1959,16 @@ __global__ __launch_bounds__(64 * kGroupAngles * NW, kScoreLdsBlocksPerCu) void 
   bool more = have && next_chunk(nxt);
   int buf = 0;
   int32_t rel_cur = 0, rel_nxt = 0;
-  if (have) {issue_dma(cur, 0, 0, kDmaPerWave); rel_cur = load_rel(cur);}
+  if (have) {issue_dma(cur, 0); rel_cur = load_rel(cur);}
   while (have) {
     __syncthreads();                                 // this region landed (the barrier drains the DMA); the other one is free
-#ifdef KH_DMA_SPREAD
-    if (more) {issue_dma(nxt, buf ^ 1, 0, 1); rel_nxt = load_rel(nxt);}
-#else
-    if (more) {issue_dma(nxt, buf ^ 1, 0, kDmaPerWave); rel_nxt = load_rel(nxt);}
-#endif
+    // (the region's DMA pieces issued one in front of every alignment class instead of together here: 0.455 against 0.444 ms)
+    if (more) {issue_dma(nxt, buf ^ 1); rel_nxt = load_rel(nxt);}
     const bool after = more && next_chunk(aft);
     // the scoring steps above the waves of K2' / K4 that share the compute unit (the other staging set's launches): their issue slots
     // are the scoring kernel's own time, the side kernels have a whole scoring launch to finish in (0.441 -> 0.427 ms per launch, same box)
     __builtin_amdgcn_s_setprio(KH_PRIO);
-    score(cur, buf, rel_cur, nxt, more);
+    score(cur, buf, rel_cur);
     __builtin_amdgcn_s_setprio(0);
     cur = nxt; nxt = aft; rel_cur = rel_nxt; buf ^= 1; have = more; more = after;
   }
