@@ -537,12 +537,17 @@ __global__ __launch_bounds__(512) void kseq_tile(const RasterJob * jobs, const u
       __syncthreads();
       for (int q0 = 0; q0 < here; q0 += 64) {
         const int cnt = min(64, here - q0);
-        const int pk = s_pxy[q0 + lane];                          // (entries beyond `here` are stale: not read out below)
-        for (int q = 0; q < cnt; ++q) {
+        const int pk = s_pxy[q0 + lane];                          // (entries beyond `here` are stale: masked out below)
+        // which of the 64 points reach this wave's eight rows: every lane tests its own, the wave visits the hits only (a footprint
+        // of 19 rows meets a band of 8 in two cases of five; tested one point after the other the misses cost as much as the hits)
+        const int dl = (pk >> 16) - hk - oy - band;
+        unsigned long long hits = __ballot(lane < cnt && !(dl > 7 || dl + k <= 0));
+        while (hits) {
+          const int q = __builtin_ctzll(hits);
+          hits &= hits - 1ull;
           const int v = __builtin_amdgcn_readlane(pk, q);
           const int fx = (v & 0xffff) - hk - ox, fy = (v >> 16) - hk - oy;      // footprint corner relative to the tile
           const int d = fy - band;                                // footprint row of tile row band + j: j - d
-          if (d > 7 || d + k <= 0) {continue;}                    // the footprint misses this wave's eight rows
           const uint8_t * row0 = s_tab + (kTabGuard - d) * kTabPitch + 64 - fx + lane;
           uint32_t r[8];
 #pragma unroll
