@@ -1172,6 +1172,16 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
       yi = yi < job.ny ? yi : job.ny - 1;
       voff[r] = (uint32_t)(4 * lx) + (uint32_t)yi * row_bytes;
     }
+    // a tile narrower than 61 poses (the second tile column of an 81-pose search holds 20): the lanes whose dword lies behind the
+    // tile's last pose do not load -- their registers stay zero, their sums are never read
+    const int np_tile = min(PX, job.nx - x0);
+    const bool lane_on = 4 * lx <= s + (np_tile - 1) * SX;
+    uint32_t w[UB][RY];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {w[u][r] = 0u;}
+    }
     for (int jc = 0; jc < n_list; jc += 64) {
       const int cnt = min(64, n_list - jc);
       const int32_t mine = (lane < cnt) ? glist[jc + lane] : 0;
@@ -1179,12 +1189,13 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
       // latency bound: ~1500 cycles per beam when every beam waits for its own loads)
       int k = 0;
       for (; k + UB <= cnt; k += UB) {
-        uint32_t w[UB][RY];
+        if (lane_on) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const gbyte * wb = gbase + __builtin_amdgcn_readlane(mine, k + u);
+          for (int u = 0; u < UB; ++u) {
+            const gbyte * wb = gbase + __builtin_amdgcn_readlane(mine, k + u);
 #pragma unroll
-          for (int r = 0; r < RY; ++r) {w[u][r] = *reinterpret_cast<const gu32 *>(wb + voff[r]);}
+            for (int r = 0; r < RY; ++r) {w[u][r] = *reinterpret_cast<const gu32 *>(wb + voff[r]);}
+          }
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -1203,12 +1214,12 @@ __global__ __launch_bounds__(256 * AW) void k_score(const uint8_t * jobs, size_t
         const gbyte * wbase = gbase + __builtin_amdgcn_readlane(mine, k);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-          const uint32_t w = *reinterpret_cast<const gu32 *>(wbase + voff[r]);
+          const uint32_t w1 = lane_on ? *reinterpret_cast<const gu32 *>(wbase + voff[r]) : 0u;
           if (SX == 1) {
-            lo[r] += w & 0x00ff00ffu;
-            hi[r] += __builtin_amdgcn_perm(0u, w, 0x0c030c01u);
+            lo[r] += w1 & 0x00ff00ffu;
+            hi[r] += __builtin_amdgcn_perm(0u, w1, 0x0c030c01u);
           } else {
-            lo[r] += __builtin_amdgcn_perm(0u, w, sel);
+            lo[r] += __builtin_amdgcn_perm(0u, w1, sel);
           }
         }
       }
