@@ -357,14 +357,20 @@ __global__ __launch_bounds__(1024) void kseq_bin(const RasterJob * jobs, int bm_
     if (job.n_foot > 0 && state[p] != 1) {return false;}
     const int fx0 = (cx - hk) >> job.bshift, fx1 = (cx + hk) >> job.bshift;
     const int fy0 = (cy - hk) >> job.bshift, fy1 = (cy + hk) >> job.bshift;
+    // the footprint's blocks of a block row are neighbouring bits: one mask per row and word (two words where the run of bits
+    // crosses a word end) instead of a probe per block -- a 19-cell footprint on 8 x 8 blocks is 3-4 blocks a side
+    const int w0 = fx0 >> 5, w1 = fx1 >> 5;
+    const uint32_t m0 = w0 == w1 ? (uint32_t)(((1ull << (fx1 - fx0 + 1)) - 1ull) << (fx0 & 31)) : ~0u << (fx0 & 31);
+    const uint32_t m1 = w0 == w1 ? 0u : (uint32_t)((1ull << ((fx1 & 31) + 1)) - 1ull);
     for (int by = fy0; by <= fy1; ++by) {
-      for (int bx = fx0; bx <= fx1; ++bx) {
-        uint32_t * word = &s_bm[by * job.bm_w + (bx >> 5)];
-        const uint32_t bit = 1u << (bx & 31);
-        // in LDS: test first (the bit is set already for all but the first stamps of a block); in global memory the test would be
-        // a memory round trip per block -- the atomics leave the wave without waiting for anything
-        if (bm_global) {atomicOr(word, bit);}
-        else if ((*reinterpret_cast<volatile uint32_t *>(word) & bit) == 0u) {atomicOr(word, bit);}
+      uint32_t * word = &s_bm[by * job.bm_w + w0];
+      // in LDS: test first (the bits are set already for all but the first stamps of a block); in global memory the test would be
+      // a memory round trip per row -- the atomics leave the wave without waiting for anything
+      if (bm_global) {atomicOr(word, m0);}
+      else if ((*reinterpret_cast<volatile uint32_t *>(word) & m0) != m0) {atomicOr(word, m0);}
+      if (m1) {
+        if (bm_global) {atomicOr(word + 1, m1);}
+        else if ((*reinterpret_cast<volatile uint32_t *>(word + 1) & m1) != m1) {atomicOr(word + 1, m1);}
       }
     }
 #pragma unroll
