@@ -1174,6 +1174,14 @@ def main():
                 assert os.environ.get("KH_BENCH_NO_CHECK") or ((status == 0).all() and (resp > 0.1).all()), "matches failed"
         return (shard.max_over_ranks(dt, device="cuda") if world > 1 else dt), per_step
 
+    # (untimed setup in front of the W warm-up steps: half a second of steps, so that the device's clocks and the host pool's threads
+    # are where a running service has them -- on some boxes of the pool the first 50 steps behind a 5-step warm-up ran at 88 k
+    # matches/s and every window behind them at 103 k; KH_BENCH_PREROLL_S=0 switches it off)
+    preroll_s = float(os.environ.get("KH_BENCH_PREROLL_S", "0.5"))
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < preroll_s:
+        for h in handles:
+            step(h)
     for _ in range(args.warmup):
         for h in handles:
             step(h)
@@ -1306,7 +1314,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 gather / i32 sum / f64 penalty",
             "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: CorrelateScan 1081 beams 61x61x81 poses", "matches_per_step_per_gpu": B,
-                       "parallelism": f"{world} x independent match shards (no collective)", "streams_per_gpu": S},
+                       "parallelism": f"{world} x independent match shards (no collective)", "streams_per_gpu": S,
+                       "untimed_preroll_s": preroll_s},
             "config_workload": "BASELINE config[1]: single-scan CorrelateScan, 1081 beams, 0.3m x 0.3m x +-20deg @ 5mm/0.5deg "
                                "(61x61x81 poses), 8087^2 grid",
             # per-step wall times of the timed region, dealt into five interleaved windows: spread of the headline
